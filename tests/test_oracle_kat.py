@@ -1,0 +1,259 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference ships no tests or golden vectors for this path and cannot be executed here, so the
+oracle is pinned against closed forms derived from the mathematics of each reference function.
+"""
+import math
+
+import numpy as np
+import pytest
+import scipy.linalg
+import torch
+
+from oracle import nerfds_oracle as O
+
+T = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64))
+
+
+# 1. posenc (model_utils.py:398-436) ------------------------------------------------------------
+def test_posenc_layout_and_values():
+  x = T([[0.3, -1.1, 2.0]])
+  out = O.posenc(x, 0, 3).numpy()[0]
+  assert out.shape == (18,)
+  for f in range(3):
+    for c in range(3):
+      assert out[f * 6 + c] == pytest.approx(math.sin(x[0, c].item() * 2 ** f), abs=1e-14)       # sin block
+      assert out[f * 6 + 3 + c] == pytest.approx(math.cos(x[0, c].item() * 2 ** f), abs=1e-14)   # sin(x+pi/2)
+
+
+def test_posenc_closed_forms_identity_and_min_deg():
+  assert np.allclose(O.posenc(T([[0.0]]), 0, 2).numpy(), [[0, 1, 0, 1]], atol=1e-15)
+  assert np.allclose(O.posenc(T([[math.pi / 2]]), 0, 2).numpy(), [[1, 0, 0, -1]], atol=1e-15)
+  out = O.posenc(T([[1.0, 2.0]]), 1, 2, use_identity=True).numpy()[0]
+  assert np.allclose(out, [1.0, 2.0, math.sin(2), math.sin(4), math.cos(2), math.cos(4)], atol=1e-15)
+
+
+def test_posenc_window():
+  w = O.posenc_window(0, 4, 0.0, torch.float64).numpy()
+  assert np.allclose(w, 0)
+  w = O.posenc_window(0, 4, 4.0, torch.float64).numpy()
+  assert np.allclose(w, 1)
+  w = O.posenc_window(0, 4, 1.5, torch.float64).numpy()
+  assert np.allclose(w, [1.0, 0.5 * (1 + math.cos(math.pi * 0.5 + math.pi)), 0.0, 0.0])
+  # windowed posenc scales whole bands
+  x = T([[0.7, 0.2, -0.4]])
+  a = O.posenc(x, 0, 4, alpha=1.5).numpy()[0].reshape(4, 6)
+  b = O.posenc(x, 0, 4).numpy()[0].reshape(4, 6)
+  assert np.allclose(a, b * w[:, None])
+  # mask net at render time: 6 bands windowed by warp_alpha=4 -> top two bands exactly zero
+  assert np.allclose(O.posenc_window(0, 6, 4.0, torch.float64).numpy(), [1, 1, 1, 1, 0, 0])
+
+
+# 2. exp_se3 (rigid_body.py:59-101) -------------------------------------------------------------
+@pytest.mark.parametrize('theta', [1e-4, 0.1, 1.3, math.pi - 1e-3])
+def test_exp_se3_matches_expm(theta):
+  rng = np.random.default_rng(0)
+  w = rng.normal(size=3)
+  w /= np.linalg.norm(w)
+  v = rng.normal(size=3)
+  S = T(np.concatenate([w, v]))
+  R, p = O.exp_se3(S, T(theta))
+  twist = np.zeros((4, 4))
+  twist[:3, :3] = O.skew(T(w)).numpy()
+  twist[:3, 3] = v
+  ref = scipy.linalg.expm(twist * theta)
+  assert np.allclose(R.numpy(), ref[:3, :3], atol=1e-12)
+  assert np.allclose(p.numpy(), ref[:3, 3], atol=1e-12)
+  Ri, pi = O.exp_se3(S, T(theta), inverse=True)
+  assert np.allclose(Ri.numpy() @ R.numpy(), np.eye(3), atol=1e-12)
+  assert np.allclose(Ri.numpy() @ p.numpy() + pi.numpy(), 0, atol=1e-12)
+  Rr, pr = O.exp_se3(S, T(theta), rotation_only=True)
+  assert np.all(pr.numpy() == 0) and np.allclose(Rr.numpy(), R.numpy())
+
+
+def test_skew_is_cross_product():
+  a, b = np.array([0.3, -2.0, 1.1]), np.array([1.5, 0.2, -0.7])
+  assert np.allclose(O.skew(T(a)).numpy() @ b, np.cross(a, b))
+
+
+# 3. volumetric_rendering (model_utils.py:95-159) -----------------------------------------------
+def test_volumetric_rendering_constant_density():
+  S, sig, near, far = 16, 2.0, 1.0, 3.0
+  z = np.linspace(near, far, S)[None]
+  delta = (far - near) / (S - 1)
+  d = np.array([[0.0, 0.0, 2.0]])            # |d| = 2 scales the interval lengths
+  rgb = np.tile(np.array([0.2, 0.5, 0.9]), (1, S, 1))
+  out = O.volumetric_rendering(T(rgb), T(np.full((1, S), sig)), T(z), T(d), False)
+  a = 1 - math.exp(-sig * delta * 2)
+  w_expected = np.array([(1 - a + 1e-10) ** i * a for i in range(S - 1)] + [(1 - a + 1e-10) ** (S - 1) * 1.0])
+  assert np.allclose(out['weights'].numpy()[0], w_expected, rtol=1e-12)
+  assert out['weights'].sum().item() == pytest.approx(1.0, abs=1e-8)        # 1e10 tail closes the ray
+  assert out['acc'].item() == pytest.approx(w_expected[:-1].sum(), rel=1e-12)  # acc excludes the tail
+  assert np.allclose(out['rgb'].numpy()[0], [0.2, 0.5, 0.9], atol=1e-8)
+  assert out['depth'].item() == pytest.approx((w_expected * z[0]).sum(), rel=1e-12)
+  k = int(np.argmax(np.cumsum(w_expected) >= 0.5))
+  assert out['med_depth'].item() == pytest.approx(z[0, k])
+  assert O.compute_depth_index(out['weights']).item() == k
+  assert np.allclose(out['accum_prod'].numpy()[0, 0], 1.0)
+
+
+def test_volumetric_rendering_empty_ray_and_no_infinity():
+  S = 8
+  z = np.linspace(1, 2, S)[None]
+  out = O.volumetric_rendering(T(np.ones((1, S, 3))), T(np.zeros((1, S))), T(z), T([[0, 0, 1.0]]), False)
+  assert np.all(out['rgb'].numpy() == 0) and out['med_depth'].item() == 0 and out['acc'].item() == 0
+  assert O.compute_depth_index(out['weights']).item() == 0
+  out = O.volumetric_rendering(T(np.ones((1, S, 3))), T(np.full((1, S), 50.0)), T(z), T([[0, 0, 1.0]]), True,
+                               sample_at_infinity=False)
+  assert out['weights'].numpy()[0, -1] == pytest.approx(0.0, abs=1e-15)    # last interval is 1e-19 long
+  assert np.allclose(out['rgb'].numpy(), 1.0, atol=1e-6)                    # white bg adds (1 - acc)
+
+
+def test_cal_weights_equals_rendering_weights_and_scale():
+  rng = np.random.default_rng(3)
+  sig, z = rng.random((4, 9)) * 3, np.sort(rng.random((4, 9)), -1) + 1
+  d = rng.normal(size=(4, 3))
+  w0 = O.volumetric_rendering(T(np.zeros((4, 9, 3))), T(sig), T(z), T(d), False)['weights']
+  assert np.allclose(O.cal_weights(T(sig), T(z), T(d)).numpy(), w0.numpy(), rtol=1e-14)
+  assert np.allclose(O.cal_weights(T(sig), T(z), T(d), scale=5).numpy(),
+                     O.cal_weights(T(5 * sig), T(z), T(d)).numpy(), rtol=1e-14)
+
+
+def test_sharpen_weights_row_gather_quirk():
+  """model_utils.py:181-182: ray i is sharpened around the z ROW of ray argmax_i, not its own peak."""
+  w = np.array([[0.1, 0.7, 0.2], [0.6, 0.3, 0.1], [0.2, 0.2, 0.6]])
+  z = np.array([[1.0, 2.0, 3.0], [1.5, 2.5, 3.5], [1.2, 2.2, 3.2]])
+  out = O.sharpen_weights(T(w), T(z), std=0.5).numpy()
+  idx = w.argmax(1)                       # [1, 0, 2] -> rows of z
+  g = np.exp(-0.5 * ((z - z[idx]) / 0.5) ** 2) / (0.5 * math.sqrt(2 * math.pi))
+  exp = w * g
+  exp /= exp.sum(1, keepdims=True)
+  assert np.allclose(out, exp, rtol=1e-13)
+  assert np.allclose(out[1], w[1] / w[1].sum())      # ray 1 gathers row 0 -> offset is constant 0.5 -> plain renorm
+
+
+# 4. piecewise_constant_pdf / sample_pdf (model_utils.py:193-269) --------------------------------
+def test_pdf_uniform_weights_is_linear_map():
+  bins = np.linspace(2.0, 6.0, 9)[None]               # 8 bins
+  w = np.ones((1, 8))
+  u = np.linspace(0, 1, 33)[None, :-1]
+  z = O.piecewise_constant_pdf(T(u), T(bins), T(w), 32, True).numpy()
+  assert np.allclose(z, 2.0 + 4.0 * u, atol=1e-12)
+  z2 = O.piecewise_constant_pdf(None, T(bins), T(w), 5, False).numpy()
+  assert np.allclose(z2[0, :-1], np.linspace(2.0, 6.0, 5)[:-1], atol=1e-12)
+  assert bins[0, 0] <= z2.min() and z2.max() <= bins[0, -1] + 1e-12
+
+
+def test_pdf_spike_monotone_and_bounded():
+  rng = np.random.default_rng(0)
+  bins = np.sort(rng.random((3, 12)), -1)
+  w = np.zeros((3, 11))
+  w[:, 4] = 1.0
+  u = np.sort(rng.random((3, 64)), -1)
+  z = O.piecewise_constant_pdf(T(u), T(bins), T(w), 64, True).numpy()
+  assert np.all(np.diff(z, axis=-1) >= -1e-12)
+  assert np.all(z >= bins[:, :1] - 1e-12) and np.all(z <= bins[:, -1:] + 1e-12)
+  inside = (z >= bins[:, 4:5]) & (z <= bins[:, 5:6])
+  assert inside.mean() > 0.99                                              # eps=1e-5 leaks ~1e-4 of the mass
+
+
+def test_sample_pdf_sorted_union():
+  rng = np.random.default_rng(1)
+  zc = np.sort(rng.random((2, 8)), -1) + 1
+  mids = 0.5 * (zc[:, 1:] + zc[:, :-1])
+  w = rng.random((2, 6))
+  o, d = rng.normal(size=(2, 3)), rng.normal(size=(2, 3))
+  z, pts = O.sample_pdf(T(rng.random((2, 8))), T(mids), T(w), T(o), T(d), T(zc), 8, True)
+  z = z.numpy()
+  assert z.shape == (2, 16) and np.all(np.diff(z, axis=-1) >= 0)
+  for r in range(2):
+    assert set(np.round(zc[r], 12)).issubset(set(np.round(z[r], 12)))
+  assert np.allclose(pts.numpy(), o[:, None] + z[..., None] * d[:, None])
+
+
+# 5. sample_along_rays (model_utils.py:55-92) ----------------------------------------------------
+def test_sample_along_rays():
+  o, d = T(np.zeros((2, 3))), T([[0, 0, 1.0], [1.0, 0, 0]])
+  z, pts = O.sample_along_rays(None, o, d, 5, 2.0, 6.0, False)
+  assert np.allclose(z.numpy(), np.tile(np.linspace(2, 6, 5), (2, 1)))
+  assert np.allclose(pts.numpy()[1, :, 0], np.linspace(2, 6, 5))
+  z, _ = O.sample_along_rays(T(np.full((2, 5), 0.5)), o, d, 5, 2.0, 6.0, True)
+  zz = np.linspace(2, 6, 5)
+  mids = 0.5 * (zz[1:] + zz[:-1])
+  lower, upper = np.r_[zz[0], mids], np.r_[mids, zz[-1]]
+  assert np.allclose(z.numpy()[0], 0.5 * (lower + upper))
+  z0, _ = O.sample_along_rays(T(np.zeros((2, 5))), o, d, 5, 2.0, 6.0, True)
+  assert np.allclose(z0.numpy()[0], lower)
+
+
+# 6. MLP skip semantics (modules.py:57-83) against an independent torch.nn stack -------------------
+def test_mlp_skip_semantics_vs_nn_linear():
+  torch.manual_seed(0)
+  in_dim, width, depth, skips, out_dim = 5, 7, 6, (4,), 3
+  lin = []
+  for i in range(depth):
+    k = (width if i else in_dim) + (in_dim if i in skips else 0)
+    lin.append(torch.nn.Linear(k, width).double())
+  head = torch.nn.Linear(width, out_dim).double()
+  p = {f'hidden_{i}': {'kernel': l.weight.detach().T.clone(), 'bias': l.bias.detach().clone()} for i, l in enumerate(lin)}
+  p['logit'] = {'kernel': head.weight.detach().T.clone(), 'bias': head.bias.detach().clone()}
+  x = torch.randn(11, in_dim, dtype=torch.float64)
+  h = x
+  for i, l in enumerate(lin):
+    if i in skips:
+      h = torch.cat([h, x], -1)            # activations FIRST, raw inputs appended (modules.py:67)
+    h = torch.relu(l(h))
+  ref = head(h)
+  out = O.mlp(p, x, depth, skips, output_channels=out_dim)
+  assert torch.allclose(out, ref.detach(), atol=1e-13)
+
+
+def test_normalize_vector_eps():
+  v = T([[3.0, 0, 4.0], [0, 0, 0], [1e-5, 0, 0]])
+  n = O.normalize_vector(v).numpy()
+  assert np.allclose(n[0], [0.6, 0, 0.8]) and np.all(n[1] == 0)
+  assert n[2, 0] == pytest.approx(1e-5 / math.sqrt(np.finfo(np.float32).eps))   # below eps: divided by sqrt(eps)
+
+
+# 7. full-ray cross-check: fp64 vs fp32 restatement ------------------------------------------------
+def _tiny_case(cfg_fn, **kw):
+  from nerfds_amd import init_params
+  cfg = cfg_fn(**kw)
+  p = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  rng = np.random.default_rng(7)
+  R = 5
+  o = rng.normal(size=(R, 3)) * 0.1
+  d = rng.normal(size=(R, 3))
+  d /= np.linalg.norm(d, axis=-1, keepdims=True)
+  rays = dict(origins=o, directions=d, viewdirs=d,
+              metadata={'warp': rng.integers(0, cfg.num_warp_embeds, (R, 1))},
+              mask=(rng.random((R, 1)) < 0.3).astype(np.float64))
+  extra = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
+  t = rng.random((R, cfg.num_coarse_samples))
+  u = rng.random((R, max(cfg.num_fine_samples, 1)))
+  return cfg, p, rays, extra, t, u
+
+
+def test_full_graph_fp64_vs_fp32():
+  from nerfds_amd import nerf_ds_config
+  cfg, p, rays, extra, t, u = _tiny_case(nerf_ds_config, num_warp_embeds=4, num_coarse_samples=8, num_fine_samples=8)
+  kw = dict(t_rand=t, u_rand=u, use_predicted_norm=True, sharp_weights_std=0.1)
+  a = O.NerfModel(cfg, p, torch.float64).apply(rays, extra, **kw)
+  b = O.NerfModel(cfg, p, torch.float32).apply(rays, extra, **kw)
+  for level in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'acc', 'ray_norm', 'ray_delta_x', 'ray_predicted_mask', 'ray_hyper_points'):
+      x, y = a[level][k].numpy(), b[level][k].numpy()
+      assert np.abs(x - y).max() <= 2e-5 * max(np.abs(x).max(), 1e-3), (level, k)
+  assert 'weights' not in a['fine'] and 'points' not in a['fine']            # models.py:1555-1563
+  assert a['fine']['med_points'].shape == (5, 1, 5) and a['fine']['ray_hyper_c'].abs().max() == 0
+
+
+def test_static_graph_runs_and_is_identity_warp():
+  from nerfds_amd import static_config
+  cfg, p, rays, extra, t, u = _tiny_case(static_config, num_coarse_samples=8)
+  out = O.NerfModel(cfg, p).apply(rays, extra, t_rand=t, return_points=True, return_weights=True)
+  assert set(out) == {'coarse'}
+  c = out['coarse']
+  assert np.allclose(c['warped_points'].numpy(), c['points'].numpy())
+  assert 'ray_rotation_field' not in c and c['ray_hyper_points'].shape == (5, 0)
+  assert np.all((c['rgb'].numpy() >= 0) & (c['rgb'].numpy() <= 1))
