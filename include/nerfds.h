@@ -1,0 +1,200 @@
+/*
+ * nerfds.h - C ABI of the MI355X-native NeRF-DS volume-rendering core.
+ *
+ * The reference (JokerYan/NeRF-DS, JAX/Flax) has no FFI: its hot path is entered through three nested
+ * Python callables.  This ABI sits one level below the Python layer that keeps
+ * those signatures (nerf-ds_amd/nerfds_amd/model.py), and each entry point names the reference
+ * interface it replaces:
+ *
+ *   nerfds_ctx_create        <- models.construct_nerf / NerfModel.setup      (hypernerf/models.py:2677-2741, 324-391)
+ *   nerfds_ctx_load_weights  <- state.optimizer.target['model'] passed to model.apply (hypernerf/evaluation.py:119)
+ *   nerfds_render_rays       <- NerfModel.__call__ via model.apply            (hypernerf/models.py:1419-1565,
+ *                               called from render.py:140-154 and evaluation.py:119)
+ *   nerfds_ctx_destroy       <- (garbage collection of the JAX arrays)
+ *   nerfds_last_error        <- Python exceptions raised by the model        (models.py:315,328,561,744,1131)
+ *
+ * Conventions
+ *   - Plain C types only.  "device pointer" = pointer into HIP device memory owned by the caller
+ *     (e.g. torch tensors); the library never allocates outputs and never frees inputs.
+ *   - Return 0 on success, a negative errno-style code otherwise; no C++ exception crosses the boundary.
+ *   - One ctx per device.  Calls on a ctx are stream-ordered on the hipStream_t passed in and are not
+ *     re-entrant (the reference is single-threaded on the host, SURVEY.md section 8b "Threading").
+ *   - All floating-point arrays are float32, ids are uint32 - the reference's dtypes.
+ */
+#ifndef NERFDS_H_
+#define NERFDS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERFDS_ABI_VERSION 1
+
+/* error codes */
+#define NERFDS_OK         0
+#define NERFDS_EINVAL   (-22)
+#define NERFDS_ENOMEM   (-12)
+#define NERFDS_ENOTSUP  (-95)   /* graph / option not built as a HIP kernel */
+#define NERFDS_EDEVICE  (-5)    /* HIP runtime error (no device, launch failure, ...) */
+
+/* Arithmetic of the per-sample dense layers (flags bits 0-1 of nerfds_render_rays). */
+#define NERFDS_PREC_BF16    0u  /* bf16 x bf16 -> fp32 MFMA (v_mfma_f32_32x32x16_bf16): the throughput path   */
+#define NERFDS_PREC_BF16X3  1u  /* split-bf16 (hi+lo) x3 MFMA: ~fp32 accuracy at 1/3 of the bf16 MFMA rate   */
+#define NERFDS_PREC_F32     2u  /* fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fp32 fma chains, parity gate    */
+#define NERFDS_PREC_MASK    3u
+/* Other flags. */
+#define NERFDS_FLAG_USE_WARP_OFF  (1u << 4)  /* NerfModel.__call__(use_warp=False), models.py:1468 - rejected if the graph has a warp */
+
+/* Number of floats in one per-ray output record (see nerfds_ray_field). */
+#define NERFDS_RAY_REC  26
+/* Per-ray record layout, AoS [R][NERFDS_RAY_REC] so a ray is one 104-byte coalesced store and the
+ * multi-GPU exchange is one all-gather of one tensor.  Keys are the reference's out-dict keys
+ * (models.py:1312-1415, consumers render.py:192-193). */
+enum nerfds_ray_field {
+  NERFDS_RAY_RGB = 0,                 /* [3]  'rgb'                     */
+  NERFDS_RAY_DEPTH = 3,               /* [1]  'depth'                   */
+  NERFDS_RAY_MED_DEPTH = 4,           /* [1]  'med_depth'               */
+  NERFDS_RAY_ACC = 5,                 /* [1]  'acc'                     */
+  NERFDS_RAY_NORM = 6,                /* [3]  'ray_norm'                */
+  NERFDS_RAY_ROTATION_FIELD = 9,      /* [3]  'ray_rotation_field'      */
+  NERFDS_RAY_TRANSLATION_FIELD = 12,  /* [3]  'ray_translation_field'   */
+  NERFDS_RAY_DELTA_X = 15,            /* [3]  'ray_delta_x'             */
+  NERFDS_RAY_HYPER_POINTS = 18,       /* [2]  'ray_hyper_points'        */
+  NERFDS_RAY_PREDICTED_MASK = 20,     /* [1]  'ray_predicted_mask'      */
+  NERFDS_RAY_MED_POINTS = 21          /* [5]  'med_points'              */
+};
+
+/* Number of floats in one optional per-sample record. */
+#define NERFDS_SAMPLE_REC  18
+enum nerfds_sample_field {
+  NERFDS_SMP_Z = 0,               /* z_vals                           */
+  NERFDS_SMP_SIGMA = 1,           /* 'sigma' (after softplus)         */
+  NERFDS_SMP_ALPHA = 2,           /* 'alpha'                          */
+  NERFDS_SMP_ACCUM_PROD = 3,      /* 'accum_prod'                     */
+  NERFDS_SMP_WEIGHTS = 4,         /* 'weights'                        */
+  NERFDS_SMP_PREDICTED_MASK = 5,  /* 'predicted_mask'                 */
+  NERFDS_SMP_RGB = 6,             /* [3] per-sample colour            */
+  NERFDS_SMP_PREDICTED_NORM = 9,  /* [3] 'predicted_norm' (raw)       */
+  NERFDS_SMP_WARPED_POINTS = 12,  /* [5] 'warped_points'              */
+  NERFDS_SMP_BACK_FACING = 17     /* 'back_facing'                    */
+};
+
+/* Static description of the render graph: the gin-resolved fields of NerfModel (models.py:116-229),
+ * SE3Field (warping.py:139-157), HyperSheetMLP (modules.py:354-365), MaskMLP (modules.py:396-407).
+ * The library matches it against the graphs it has compiled kernels for and returns
+ * NERFDS_ENOTSUP with a message otherwise. */
+typedef struct nerfds_model_cfg {
+  int32_t abi_version;             /* NERFDS_ABI_VERSION */
+  int32_t num_coarse_samples, num_fine_samples;
+  int32_t use_warp, use_hyper_sheet, use_predicted_mask, predict_norm, use_x_in_rgb_condition;
+  int32_t use_mask_in_warp, use_mask_in_hyper, use_viewdirs, mask_output_relu;
+  int32_t nerf_trunk_depth, nerf_trunk_width, nerf_skip, nerf_rgb_branch_depth, nerf_rgb_branch_width;
+  int32_t spatial_point_max_deg, hyper_point_max_deg, viewdir_max_deg, norm_input_max_deg;
+  int32_t warp_max_deg, warp_trunk_depth, warp_trunk_width, warp_skip;
+  int32_t hyper_sheet_max_deg, hyper_sheet_depth, hyper_sheet_width, hyper_sheet_skip, hyper_num_dims;
+  int32_t mask_max_deg, mask_depth, mask_width, mask_skip;
+  int32_t glo_num_dims, num_warp_embeds;
+  int32_t use_white_background, use_sample_at_infinity;
+} nerfds_model_cfg;
+
+/* One nn.Dense: kernel is row-major [in][out] (Flax layout), y = x @ kernel + bias. HOST pointers. */
+typedef struct nerfds_dense {
+  const float* kernel;
+  const float* bias;
+  int32_t in_dim, out_dim;
+} nerfds_dense;
+
+#define NERFDS_MAX_DEPTH 16
+
+typedef struct nerfds_nerf_mlp {           /* modules.NerfMLP, modules.py:122-152 */
+  nerfds_dense trunk[NERFDS_MAX_DEPTH];    /* trunk_mlp/hidden_i */
+  nerfds_dense bottleneck;                 /* bottleneck */
+  nerfds_dense alpha;                      /* alpha_mlp/logit : out = 1 (+3 if predict_norm) */
+  nerfds_dense rgb_hidden[NERFDS_MAX_DEPTH]; /* rgb_mlp/hidden_i */
+  nerfds_dense rgb;                        /* rgb_mlp/logit */
+} nerfds_nerf_mlp;
+
+/* fp32 HOST views of the parameter tree ('params/model/...' of the Flax checkpoint). Unused nets: NULL kernels. */
+typedef struct nerfds_weights {
+  const float* warp_embed;                 /* warp_embed/embed/embedding  [num_warp_embeds][glo_num_dims] */
+  const float* mask_embed;                 /* mask_embed/embed/embedding  [num_warp_embeds][glo_num_dims] */
+  nerfds_dense mask_hidden[NERFDS_MAX_DEPTH];   /* mask_mlp/MLP_0/hidden_i */
+  nerfds_dense mask_out;                        /* mask_mlp/MLP_0/logit    */
+  nerfds_dense warp_hidden[NERFDS_MAX_DEPTH];   /* warp_field/trunk/hidden_i */
+  nerfds_dense warp_w, warp_v;                  /* warp_field/branches_{w,v}/logit */
+  nerfds_dense hyper_hidden[NERFDS_MAX_DEPTH];  /* hyper_sheet_mlp/MLP_0/hidden_i */
+  nerfds_dense hyper_out;                       /* hyper_sheet_mlp/MLP_0/logit */
+  nerfds_nerf_mlp nerf[2];                      /* nerf_mlps_coarse, nerf_mlps_fine */
+} nerfds_weights;
+
+/* Ray batch: DEVICE pointers, R rays.  rays_dict of models.py:1444-1478. */
+typedef struct nerfds_rays {
+  int64_t num_rays;
+  const float* origins;       /* [R][3] */
+  const float* directions;    /* [R][3] */
+  const float* viewdirs;      /* [R][3]; NULL -> directions (models.py:1475-1478) */
+  const uint32_t* warp_id;    /* [R] metadata['warp'] (GLO row); NULL if the graph has no warp */
+  const float* gt_mask;       /* [R] rays_dict['mask']; only read when mask_ratio != 1; may be NULL */
+} nerfds_rays;
+
+/* Runtime scalars: state.extra_params (model_utils.py:41-52) + the kwargs of NerfModel.__call__ that the
+ * render/train harness passes (render.py:150-153). */
+typedef struct nerfds_extra {
+  float nerf_alpha, warp_alpha, hyper_alpha, hyper_sheet_alpha, norm_input_alpha;
+  float mask_ratio;           /* render.py:152: always 1 at inference */
+  float near, far;
+  int32_t use_stratified_sampling;   /* NerfModel.use_stratified_sampling */
+} nerfds_extra;
+
+/* Sampling uniforms.  The reference draws them from JAX threefry streams (model_utils.py:84,217) which
+ * cannot be reproduced outside JAX; for parity they are injected.  Either pointer NULL -> on-chip
+ * Philox4x32-10 keyed by (seed, ray index). DEVICE pointers. */
+typedef struct nerfds_rand {
+  const float* t_rand;        /* [R][num_coarse_samples] */
+  const float* u_rand;        /* [R][num_fine_samples]   */
+  uint64_t seed;
+} nerfds_rand;
+
+/* Outputs: DEVICE pointers; any may be NULL (not written). */
+typedef struct nerfds_out {
+  float* ray_fine;            /* [R][NERFDS_RAY_REC]  (the 'fine' level, or 'coarse' if num_fine_samples == 0) */
+  float* ray_coarse;          /* [R][NERFDS_RAY_REC]  ('coarse' level when a fine level exists) */
+  float* sample_fine;         /* [R][Nc+Nf][NERFDS_SAMPLE_REC] */
+  float* sample_coarse;       /* [R][Nc][NERFDS_SAMPLE_REC] */
+} nerfds_out;
+
+typedef struct nerfds_ctx nerfds_ctx;
+
+int nerfds_abi_version(void);
+int nerfds_ctx_create(nerfds_ctx** out, int device, const nerfds_model_cfg* cfg);
+int nerfds_ctx_load_weights(nerfds_ctx* ctx, const nerfds_weights* w);
+int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_extra* extra,
+                       const nerfds_rand* rnd, const nerfds_out* out, uint32_t flags, void* hip_stream);
+int nerfds_ctx_destroy(nerfds_ctx* ctx);
+/* Message of the last failure on this ctx (or of the last failed nerfds_ctx_create when ctx == NULL). */
+const char* nerfds_last_error(const nerfds_ctx* ctx);
+
+/* Timing aid for bench.py: average device time (ms) of the render kernel launches recorded with HIP events
+ * on the launch stream since the last reset; returns the number of launches measured. */
+int nerfds_kernel_time_ms(nerfds_ctx* ctx, int reset, double* total_ms);
+
+/* ---- host-only helpers (no device needed): exposed so that the weight-stream packing can be tested on CPU ---- */
+/* Size in bytes of the packed MFMA weight stream / padded bias array for `which` (0 = shared mask+warp+hyper
+ * nets, 1 = NerfMLP) at precision `prec`; negative on error. */
+int64_t nerfds_pack_stream_bytes(const nerfds_model_cfg* cfg, int which, uint32_t prec);
+int64_t nerfds_pack_bias_floats(const nerfds_model_cfg* cfg, int which);
+/* Packs into caller-provided host buffers.  level: 0 coarse, 1 fine (ignored for which == 0). */
+int nerfds_pack_stream(const nerfds_model_cfg* cfg, const nerfds_weights* w, int which, int level, uint32_t prec,
+                       void* stream_out, float* bias_out);
+
+/* ---- device self-test: runs one v_mfma_f32_32x32x16_bf16 and one v_mfma_f32_32x32x2_f32 with A[m][k], B[k][n]
+ * and returns C[32][32] as laid out by the accumulator map the kernels assume.  Host pointers. */
+int nerfds_debug_mfma(int device, const float* a_32x16, const float* b_16x32, float* c_bf16_32x32, float* c_f32_32x32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* NERFDS_H_ */

@@ -1,0 +1,91 @@
+// Compile-time descriptions of the render graphs that have HIP kernels, shared by the host-side
+// weight-stream packer (nerfds_host.cpp) and the device code (render_kernel.hip) so that both walk
+// the layers in the same order.
+//
+// Dimensions follow SURVEY.md section 8 "Configuration resolved" (configs/nerf_ds.gin over
+// configs/defaults.gin of the reference) and BASELINE.json configs[0] for the static graph.
+#pragma once
+
+namespace nerfds {
+
+enum Prec : int { P_BF16 = 0, P_BF16X3 = 1, P_F32 = 2 };
+
+// One MFMA weight fragment = a [32 out rows] x [16 k-slots] block of a layer, laid out exactly as the
+// 64 lanes of a wave consume it (16 bytes per lane per part, lane-linear, so one coalesced 1 KiB load).
+//   bf16   : 1 part  (8 bf16 / lane)
+//   bf16x3 : 2 parts (hi bf16x8, lo bf16x8)
+//   f32    : 2 parts (k-slots 0-3, k-slots 4-7 as float4)
+constexpr int frag_parts(int prec) { return prec == P_BF16 ? 1 : 2; }
+constexpr int frag_bytes(int prec) { return 1024 * frag_parts(prec); }
+
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int chunks(int feats) { return cdiv(feats, 16); }   // k16 chunks needed for `feats` linear features
+
+// Number of fragments of a plain hidden stack: depth layers of `width`, input `in_chunks` k16-chunks,
+// skip re-concatenation of the raw input before layer `skip` (modules.py:66-67), plus one 32-row head tile.
+constexpr int mlp_frags(int depth, int width, int in_chunks, int skip, bool head) {
+  int n = 0;
+  for (int l = 0; l < depth; ++l) {
+    int k = (l == 0 ? in_chunks : width / 16) + ((l == skip && l > 0) ? in_chunks : 0);
+    n += (width / 32) * k;
+  }
+  if (head) n += width / 16;
+  return n;
+}
+constexpr int mlp_bias_tiles(int depth, int width, bool head) { return depth * (width / 32) + (head ? 1 : 0); }
+
+// configs/nerf_ds.gin
+struct GraphNerfDS {
+  static constexpr int ID = 0;
+  static constexpr bool HAS_MASK = true, HAS_WARP = true, HAS_HYPER = true, PREDICT_NORM = true, X_IN_RGB = true;
+  static constexpr int GLO = 8;
+  static constexpr int MASK_BANDS = 6, MASK_DEPTH = 8, MASK_W = 128, MASK_SKIP = 4;
+  static constexpr int WARP_BANDS = 4, WARP_DEPTH = 6, WARP_W = 128, WARP_SKIP = 4;
+  static constexpr int HYP_BANDS = 6, HYP_DEPTH = 6, HYP_W = 64, HYP_SKIP = 4, HYP_DIMS = 2;
+  static constexpr int SP_BANDS = 8, HP_BANDS = 1, VD_BANDS = 4, NM_BANDS = 4;
+  static constexpr int TRUNK_DEPTH = 8, TRUNK_W = 256, TRUNK_SKIP = 4, RGB_W = 128;
+};
+
+// BASELINE.json configs[0]: static scene, no warp / hyper / mask / normal.
+struct GraphStatic {
+  static constexpr int ID = 1;
+  static constexpr bool HAS_MASK = false, HAS_WARP = false, HAS_HYPER = false, PREDICT_NORM = false, X_IN_RGB = false;
+  static constexpr int GLO = 8;
+  static constexpr int MASK_BANDS = 0, MASK_DEPTH = 0, MASK_W = 128, MASK_SKIP = 4;
+  static constexpr int WARP_BANDS = 0, WARP_DEPTH = 0, WARP_W = 128, WARP_SKIP = 4;
+  static constexpr int HYP_BANDS = 0, HYP_DEPTH = 0, HYP_W = 64, HYP_SKIP = 4, HYP_DIMS = 0;
+  static constexpr int SP_BANDS = 8, HP_BANDS = 0, VD_BANDS = 4, NM_BANDS = 0;
+  static constexpr int TRUNK_DEPTH = 8, TRUNK_W = 256, TRUNK_SKIP = 4, RGB_W = 128;
+};
+
+template <class G> struct Dims {
+  // linear input widths (reference concatenation order) and their k16-chunk counts
+  static constexpr int MASK_IN = 6 * G::MASK_BANDS + G::GLO;                       // posenc(x) | mask_embed
+  static constexpr int WARP_IN = 6 * G::WARP_BANDS + G::GLO + 1;                   // posenc(x) | warp_embed | mask
+  static constexpr int HYP_IN = 6 * G::HYP_BANDS + G::GLO + 1;                     // posenc(x) | warp_embed | mask
+  static constexpr int TRUNK_IN = 6 * G::SP_BANDS + 2 * G::HYP_DIMS * G::HP_BANDS; // posenc(x') | posenc(w)
+  static constexpr int COND_IN = 6 * G::VD_BANDS + 6 * G::NM_BANDS;                // posenc(viewdir) | posenc(normal)
+  static constexpr int MASK_KC = chunks(MASK_IN), WARP_KC = chunks(WARP_IN), HYP_KC = chunks(HYP_IN);
+  static constexpr int TRUNK_KC = chunks(TRUNK_IN), COND_KC = chunks(COND_IN);
+  static constexpr int ALPHA_OUT = 1 + (G::PREDICT_NORM ? 3 : 0);
+  static constexpr int RGB_IN = G::TRUNK_W + 6 * G::VD_BANDS + (G::X_IN_RGB ? G::TRUNK_W : 0) + 6 * G::NM_BANDS;
+
+  // fragment / bias-tile counts of the two weight streams
+  static constexpr int MASK_FRAGS = G::HAS_MASK ? mlp_frags(G::MASK_DEPTH, G::MASK_W, MASK_KC, G::MASK_SKIP, true) : 0;
+  static constexpr int WARP_FRAGS = G::HAS_WARP ? mlp_frags(G::WARP_DEPTH, G::WARP_W, WARP_KC, G::WARP_SKIP, true) : 0;
+  static constexpr int HYP_FRAGS = G::HAS_HYPER ? mlp_frags(G::HYP_DEPTH, G::HYP_W, HYP_KC, G::HYP_SKIP, true) : 0;
+  static constexpr int SHARED_FRAGS = MASK_FRAGS + WARP_FRAGS + HYP_FRAGS;
+  static constexpr int SHARED_BIAS_TILES = (G::HAS_MASK ? mlp_bias_tiles(G::MASK_DEPTH, G::MASK_W, true) : 0) +
+                                           (G::HAS_WARP ? mlp_bias_tiles(G::WARP_DEPTH, G::WARP_W, true) : 0) +
+                                           (G::HAS_HYPER ? mlp_bias_tiles(G::HYP_DEPTH, G::HYP_W, true) : 0);
+  static constexpr int TW16 = G::TRUNK_W / 16, TW32 = G::TRUNK_W / 32;
+  static constexpr int NERF_FRAGS =
+      mlp_frags(G::TRUNK_DEPTH, G::TRUNK_W, TRUNK_KC, G::TRUNK_SKIP, false) +   // trunk
+      TW32 * TW16 +                                                             // bottleneck
+      TW16 +                                                                    // alpha head
+      (G::RGB_W / 32) * (TW16 + (G::X_IN_RGB ? TW16 : 0) + COND_KC) +           // rgb hidden_0
+      G::RGB_W / 16;                                                            // rgb head
+  static constexpr int NERF_BIAS_TILES = G::TRUNK_DEPTH * TW32 + TW32 + 1 + G::RGB_W / 32 + 1;
+};
+
+}  // namespace nerfds

@@ -1,0 +1,51 @@
+// Kernel argument block shared by the host library and the device kernels (plain POD, passed by value).
+#pragma once
+#include <stdint.h>
+
+namespace nerfds {
+
+constexpr int MAX_SAMPLES = 256;      // Nc + Nf upper bound (config 5: 128 + 128)
+constexpr int RAY_REC = 26;           // == NERFDS_RAY_REC
+constexpr int SAMPLE_REC = 18;        // == NERFDS_SAMPLE_REC
+constexpr int MAX_BANDS = 8;
+
+struct KArgs {
+  // rays
+  const float* origins;
+  const float* directions;
+  const float* viewdirs;
+  const uint32_t* warp_id;
+  const float* gt_mask;
+  // sampling uniforms (nullable -> Philox)
+  const float* t_rand;
+  const float* u_rand;
+  uint64_t seed;
+  // packed weights: [0] shared (mask|warp|hyper) stream, [1] coarse NerfMLP, [2] fine NerfMLP
+  const void* wstream[3];
+  const float* bias[3];
+  const float* warp_embed;   // [N][8] fp32
+  const float* mask_embed;   // [N][8] fp32
+  // outputs (nullable)
+  float* ray_fine;
+  float* ray_coarse;
+  float* smp_fine;
+  float* smp_coarse;
+  int num_rays;
+  int nc, nf;
+  int stratified;
+  int sample_at_infinity;
+  int white_bkgd;
+  float near_, far_;
+  float mask_ratio;
+  // posenc windows per band (model_utils.py:420-436), evaluated on the host from the extra_params alphas
+  float win_mask[MAX_BANDS];   // alpha = warp_alpha        (models.py:967)
+  float win_warp[MAX_BANDS];   // alpha = warp_alpha        (warping.py:213)
+  float win_hyp[MAX_BANDS];    // alpha = hyper_sheet_alpha (models.py:666)
+  float win_sp[MAX_BANDS];     // alpha = nerf_alpha        (models.py:507)
+  float win_hp[MAX_BANDS];     // alpha = hyper_alpha       (models.py:515)
+  float win_nm[MAX_BANDS];     // alpha = norm_input_alpha  (models.py:1147)
+};
+
+typedef void (*launch_fn)(const KArgs& ka, int grid, void* stream);
+
+}  // namespace nerfds

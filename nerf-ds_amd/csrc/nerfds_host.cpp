@@ -1,0 +1,469 @@
+// C ABI of include/nerfds.h: context, weight packing/upload, launch of the fused ray kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "nerfds.h"
+#include "graphs.h"
+#include "kargs.h"
+#include "pack.h"
+
+using namespace nerfds;
+
+extern "C" {
+void nerfds_launch_nerfds_bf16(const KArgs&, int, void*);
+void nerfds_launch_nerfds_bf16x3(const KArgs&, int, void*);
+void nerfds_launch_nerfds_f32(const KArgs&, int, void*);
+void nerfds_launch_static_bf16(const KArgs&, int, void*);
+void nerfds_launch_static_bf16x3(const KArgs&, int, void*);
+void nerfds_launch_static_f32(const KArgs&, int, void*);
+}
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct OwnedDense {
+  std::vector<float> kernel, bias;
+  int in_dim = 0, out_dim = 0;
+  bool set(const nerfds_dense& d, int want_in, int want_out, const char* name, std::string& err) {
+    if (d.kernel == nullptr || d.in_dim != want_in || d.out_dim != want_out) {
+      char buf[256];
+      snprintf(buf, sizeof buf, "%s: expected a [%d, %d] kernel, got %s[%d, %d]", name, want_in, want_out,
+               d.kernel ? "" : "NULL ", d.in_dim, d.out_dim);
+      err = buf;
+      return false;
+    }
+    in_dim = d.in_dim;
+    out_dim = d.out_dim;
+    kernel.assign(d.kernel, d.kernel + (size_t)in_dim * out_dim);
+    if (d.bias) bias.assign(d.bias, d.bias + out_dim); else bias.assign(out_dim, 0.f);
+    return true;
+  }
+  DenseView view() const {
+    DenseView v;
+    v.kernel = kernel.data(); v.bias = bias.data(); v.in_dim = in_dim; v.out_dim = out_dim;
+    return v;
+  }
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t upload(const void* src, size_t n) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = n;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(n, 16));
+    if (e != hipSuccess) return e;
+    return n ? hipMemcpy(p, src, n, hipMemcpyHostToDevice) : hipSuccess;
+  }
+};
+
+template <class G> bool cfg_matches(const nerfds_model_cfg& c) {
+  using D = Dims<G>;
+  bool ok = (c.use_warp != 0) == G::HAS_WARP && (c.use_hyper_sheet != 0) == G::HAS_HYPER &&
+            (c.use_predicted_mask != 0) == G::HAS_MASK && (c.predict_norm != 0) == G::PREDICT_NORM &&
+            (c.use_x_in_rgb_condition != 0) == G::X_IN_RGB && c.use_viewdirs != 0 &&
+            c.nerf_trunk_depth == G::TRUNK_DEPTH && c.nerf_trunk_width == G::TRUNK_W && c.nerf_skip == G::TRUNK_SKIP &&
+            c.nerf_rgb_branch_depth == 1 && c.nerf_rgb_branch_width == G::RGB_W &&
+            c.spatial_point_max_deg == G::SP_BANDS && c.viewdir_max_deg == G::VD_BANDS;
+  if (G::HAS_WARP)
+    ok = ok && c.warp_max_deg == G::WARP_BANDS && c.warp_trunk_depth == G::WARP_DEPTH && c.warp_trunk_width == G::WARP_W &&
+         c.warp_skip == G::WARP_SKIP && c.glo_num_dims == G::GLO && (c.use_mask_in_warp != 0) == G::HAS_MASK;
+  if (G::HAS_HYPER)
+    ok = ok && c.hyper_sheet_max_deg == G::HYP_BANDS && c.hyper_sheet_depth == G::HYP_DEPTH && c.hyper_sheet_width == G::HYP_W &&
+         c.hyper_sheet_skip == G::HYP_SKIP && c.hyper_num_dims == G::HYP_DIMS && c.hyper_point_max_deg == G::HP_BANDS &&
+         (c.use_mask_in_hyper != 0) == G::HAS_MASK;
+  if (G::HAS_MASK)
+    ok = ok && c.mask_max_deg == G::MASK_BANDS && c.mask_depth == G::MASK_DEPTH && c.mask_width == G::MASK_W &&
+         c.mask_skip == G::MASK_SKIP && c.mask_output_relu != 0;
+  if (G::PREDICT_NORM) ok = ok && c.norm_input_max_deg == G::NM_BANDS;
+  (void)sizeof(D);
+  return ok;
+}
+
+int graph_of(const nerfds_model_cfg& c) {
+  if (cfg_matches<GraphNerfDS>(c)) return GraphNerfDS::ID;
+  if (cfg_matches<GraphStatic>(c)) return GraphStatic::ID;
+  return -1;
+}
+
+struct Weights {
+  std::vector<float> warp_embed, mask_embed;
+  OwnedDense mask_hidden[NERFDS_MAX_DEPTH], mask_out;
+  OwnedDense warp_hidden[NERFDS_MAX_DEPTH], warp_w, warp_v;
+  OwnedDense hyper_hidden[NERFDS_MAX_DEPTH], hyper_out;
+  struct Nerf { OwnedDense trunk[NERFDS_MAX_DEPTH], bottleneck, alpha, rgb_hidden[NERFDS_MAX_DEPTH], rgb; } nerf[2];
+  bool loaded = false;
+};
+
+template <class G> bool take_weights(Weights& W, const nerfds_model_cfg& c, const nerfds_weights& w, std::string& err) {
+  using D = Dims<G>;
+  char nm[64];
+  auto mlp = [&](OwnedDense* dst, const nerfds_dense* src, int depth, int width, int in_dim, int skip, const char* name) {
+    for (int l = 0; l < depth; ++l) {
+      int k = (l == 0 ? in_dim : width) + ((l == skip && l > 0) ? in_dim : 0);
+      snprintf(nm, sizeof nm, "%s/hidden_%d", name, l);
+      if (!dst[l].set(src[l], k, width, nm, err)) return false;
+    }
+    return true;
+  };
+  const size_t glo = (size_t)c.num_warp_embeds * G::GLO;
+  if (G::HAS_WARP) {
+    if (!w.warp_embed || c.num_warp_embeds <= 0) { err = "warp_embed table missing"; return false; }
+    W.warp_embed.assign(w.warp_embed, w.warp_embed + glo);
+    if (!mlp(W.warp_hidden, w.warp_hidden, G::WARP_DEPTH, G::WARP_W, D::WARP_IN, G::WARP_SKIP, "warp_field/trunk")) return false;
+    if (!W.warp_w.set(w.warp_w, G::WARP_W, 3, "warp_field/branches_w/logit", err)) return false;
+    if (!W.warp_v.set(w.warp_v, G::WARP_W, 3, "warp_field/branches_v/logit", err)) return false;
+  }
+  if (G::HAS_MASK) {
+    if (!w.mask_embed) { err = "mask_embed table missing"; return false; }
+    W.mask_embed.assign(w.mask_embed, w.mask_embed + glo);
+    if (!mlp(W.mask_hidden, w.mask_hidden, G::MASK_DEPTH, G::MASK_W, D::MASK_IN, G::MASK_SKIP, "mask_mlp/MLP_0")) return false;
+    if (!W.mask_out.set(w.mask_out, G::MASK_W, 1, "mask_mlp/MLP_0/logit", err)) return false;
+  }
+  if (G::HAS_HYPER) {
+    if (!mlp(W.hyper_hidden, w.hyper_hidden, G::HYP_DEPTH, G::HYP_W, D::HYP_IN, G::HYP_SKIP, "hyper_sheet_mlp/MLP_0")) return false;
+    if (!W.hyper_out.set(w.hyper_out, G::HYP_W, G::HYP_DIMS, "hyper_sheet_mlp/MLP_0/logit", err)) return false;
+  }
+  const int levels = c.num_fine_samples > 0 ? 2 : 1;
+  for (int lv = 0; lv < levels; ++lv) {
+    const nerfds_nerf_mlp& s = w.nerf[lv];
+    Weights::Nerf& d = W.nerf[lv];
+    const char* pre = lv ? "nerf_mlps_fine" : "nerf_mlps_coarse";
+    snprintf(nm, sizeof nm, "%s/trunk_mlp", pre);
+    std::string tname = nm;
+    if (!mlp(d.trunk, s.trunk, G::TRUNK_DEPTH, G::TRUNK_W, D::TRUNK_IN, G::TRUNK_SKIP, tname.c_str())) return false;
+    if (!d.bottleneck.set(s.bottleneck, G::TRUNK_W, G::TRUNK_W, "bottleneck", err)) return false;
+    if (!d.alpha.set(s.alpha, G::TRUNK_W, D::ALPHA_OUT, "alpha_mlp/logit", err)) return false;
+    if (!d.rgb_hidden[0].set(s.rgb_hidden[0], D::RGB_IN, G::RGB_W, "rgb_mlp/hidden_0", err)) return false;
+    if (!d.rgb.set(s.rgb, G::RGB_W, 3, "rgb_mlp/logit", err)) return false;
+  }
+  W.loaded = true;
+  return true;
+}
+
+SharedNets shared_views(const Weights& W) {
+  SharedNets n;
+  for (int i = 0; i < NERFDS_MAX_DEPTH; ++i) {
+    n.mask_hidden[i] = W.mask_hidden[i].view();
+    n.warp_hidden[i] = W.warp_hidden[i].view();
+    n.hyper_hidden[i] = W.hyper_hidden[i].view();
+  }
+  n.mask_out = W.mask_out.view(); n.warp_w = W.warp_w.view(); n.warp_v = W.warp_v.view(); n.hyper_out = W.hyper_out.view();
+  return n;
+}
+NerfNet nerf_views(const Weights::Nerf& s) {
+  NerfNet n;
+  for (int i = 0; i < NERFDS_MAX_DEPTH; ++i) { n.trunk[i] = s.trunk[i].view(); n.rgb_hidden[i] = s.rgb_hidden[i].view(); }
+  n.bottleneck = s.bottleneck.view(); n.alpha = s.alpha.view(); n.rgb = s.rgb.view();
+  return n;
+}
+
+template <class G> void pack_which(StreamWriter& sw, const Weights& W, int which, int level) {
+  if (which == 0) pack_shared<G>(sw, shared_views(W)); else pack_nerf<G>(sw, nerf_views(W.nerf[level]));
+}
+void pack_dispatch(int graph, StreamWriter& sw, const Weights& W, int which, int level) {
+  if (graph == GraphNerfDS::ID) pack_which<GraphNerfDS>(sw, W, which, level); else pack_which<GraphStatic>(sw, W, which, level);
+}
+template <class G> void stream_dims(int which, int prec, int64_t* wbytes, int64_t* bfloats) {
+  using D = Dims<G>;
+  *wbytes = (int64_t)(which == 0 ? D::SHARED_FRAGS : D::NERF_FRAGS) * frag_bytes(prec);
+  *bfloats = (int64_t)(which == 0 ? D::SHARED_BIAS_TILES : D::NERF_BIAS_TILES) * 32;
+}
+void stream_dims_dispatch(int graph, int which, int prec, int64_t* wb, int64_t* bf) {
+  if (graph == GraphNerfDS::ID) stream_dims<GraphNerfDS>(which, prec, wb, bf); else stream_dims<GraphStatic>(which, prec, wb, bf);
+}
+
+void window(float* out, int bands, float alpha) {   // model_utils.py:420-436
+  for (int b = 0; b < MAX_BANDS; ++b) {
+    double x = std::min(std::max((double)alpha - b, 0.0), 1.0);
+    out[b] = b < bands ? (float)(0.5 * (1.0 + std::cos(M_PI * x + M_PI))) : 0.f;
+  }
+}
+
+}  // namespace
+
+struct nerfds_ctx {
+  int device = 0;
+  int graph = -1;
+  int num_cus = 256;
+  nerfds_model_cfg cfg{};
+  Weights W;
+  DevBuf wstream[3][3];     // [prec][shared, coarse, fine]
+  DevBuf wbias[3];          // precision independent
+  DevBuf warp_embed, mask_embed;
+  bool packed[3] = {false, false, false};
+  bool bias_uploaded = false;
+  std::string err;
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+};
+
+static launch_fn launcher(int graph, uint32_t prec) {
+  static const launch_fn tab[2][3] = {
+      {nerfds_launch_nerfds_bf16, nerfds_launch_nerfds_bf16x3, nerfds_launch_nerfds_f32},
+      {nerfds_launch_static_bf16, nerfds_launch_static_bf16x3, nerfds_launch_static_f32}};
+  return tab[graph][prec];
+}
+
+extern "C" {
+
+int nerfds_abi_version(void) { return NERFDS_ABI_VERSION; }
+
+const char* nerfds_last_error(const nerfds_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int nerfds_ctx_create(nerfds_ctx** out, int device, const nerfds_model_cfg* cfg) {
+  if (!out || !cfg) { g_create_error = "null argument"; return NERFDS_EINVAL; }
+  *out = nullptr;
+  if (cfg->abi_version != NERFDS_ABI_VERSION) { g_create_error = "abi_version mismatch"; return NERFDS_EINVAL; }
+  if (cfg->num_coarse_samples < 4 || cfg->num_fine_samples < 0 ||
+      cfg->num_coarse_samples + cfg->num_fine_samples > MAX_SAMPLES) {
+    g_create_error = "num_coarse_samples must be >= 4 and num_coarse_samples + num_fine_samples <= 256";
+    return NERFDS_EINVAL;
+  }
+  const int graph = graph_of(*cfg);
+  if (graph < 0) {
+    g_create_error = "render graph not built as a HIP kernel: supported are the configs/nerf_ds.gin graph "
+                     "(mask + SE3 warp + hyper sheet + predicted normal) and the static coarse/fine NeRF graph";
+    return NERFDS_ENOTSUP;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    g_create_error = "no such HIP device (the HIP path has no CPU fallback)";
+    return NERFDS_EDEVICE;
+  }
+  std::unique_ptr<nerfds_ctx> c(new nerfds_ctx);
+  c->device = device;
+  c->graph = graph;
+  c->cfg = *cfg;
+  if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return NERFDS_EDEVICE; }
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
+  *out = c.release();
+  return NERFDS_OK;
+}
+
+int nerfds_ctx_destroy(nerfds_ctx* ctx) {
+  if (!ctx) return NERFDS_OK;
+  (void)hipSetDevice(ctx->device);
+  for (auto& e : ctx->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  delete ctx;
+  return NERFDS_OK;
+}
+
+int nerfds_ctx_load_weights(nerfds_ctx* ctx, const nerfds_weights* w) {
+  if (!ctx || !w) return NERFDS_EINVAL;
+  std::string err;
+  ctx->W = Weights();
+  bool ok = ctx->graph == GraphNerfDS::ID ? take_weights<GraphNerfDS>(ctx->W, ctx->cfg, *w, err)
+                                          : take_weights<GraphStatic>(ctx->W, ctx->cfg, *w, err);
+  if (!ok) return ctx->fail(NERFDS_EINVAL, "load_weights: %s", err.c_str());
+  for (bool& p : ctx->packed) p = false;
+  ctx->bias_uploaded = false;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(NERFDS_EDEVICE, "hipSetDevice failed");
+  if (!ctx->W.warp_embed.empty() &&
+      ctx->warp_embed.upload(ctx->W.warp_embed.data(), ctx->W.warp_embed.size() * 4) != hipSuccess)
+    return ctx->fail(NERFDS_ENOMEM, "upload of warp_embed failed");
+  if (!ctx->W.mask_embed.empty() &&
+      ctx->mask_embed.upload(ctx->W.mask_embed.data(), ctx->W.mask_embed.size() * 4) != hipSuccess)
+    return ctx->fail(NERFDS_ENOMEM, "upload of mask_embed failed");
+  return NERFDS_OK;
+}
+
+static int ensure_packed(nerfds_ctx* ctx, uint32_t prec) {
+  if (ctx->packed[prec]) return NERFDS_OK;
+  const int levels = ctx->cfg.num_fine_samples > 0 ? 2 : 1;
+  for (int which = 0; which < 1 + levels; ++which) {
+    int64_t wb = 0, bf = 0;
+    stream_dims_dispatch(ctx->graph, which ? 1 : 0, (int)prec, &wb, &bf);
+    std::vector<uint8_t> w((size_t)wb);
+    std::vector<float> b((size_t)bf);
+    StreamWriter sw{(int)prec, w.data(), b.data()};
+    pack_dispatch(ctx->graph, sw, ctx->W, which ? 1 : 0, which ? which - 1 : 0);
+    if ((int64_t)sw.wbytes != wb || (int64_t)sw.bfloats != bf)
+      return ctx->fail(NERFDS_EINVAL, "internal: packed stream %d has %zu bytes / %zu bias floats, kernel expects %lld / %lld",
+                       which, sw.wbytes, sw.bfloats, (long long)wb, (long long)bf);
+    if (ctx->wstream[prec][which].upload(w.data(), w.size()) != hipSuccess) return ctx->fail(NERFDS_ENOMEM, "weight stream upload failed");
+    if (!ctx->bias_uploaded && ctx->wbias[which].upload(b.data(), b.size() * 4) != hipSuccess)
+      return ctx->fail(NERFDS_ENOMEM, "bias upload failed");
+  }
+  ctx->bias_uploaded = true;
+  ctx->packed[prec] = true;
+  return NERFDS_OK;
+}
+
+int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_extra* extra, const nerfds_rand* rnd,
+                       const nerfds_out* out, uint32_t flags, void* hip_stream) {
+  if (!ctx) return NERFDS_EINVAL;
+  if (!rays || !extra || !out) return ctx->fail(NERFDS_EINVAL, "null argument");
+  if (!ctx->W.loaded) return ctx->fail(NERFDS_EINVAL, "nerfds_ctx_load_weights has not been called");
+  const uint32_t prec = flags & NERFDS_PREC_MASK;
+  if (prec > NERFDS_PREC_F32) return ctx->fail(NERFDS_EINVAL, "unknown precision %u", prec);
+  if ((flags & NERFDS_FLAG_USE_WARP_OFF) && ctx->cfg.use_warp)
+    return ctx->fail(NERFDS_ENOTSUP, "use_warp=False on a warp model is not runnable in the reference either (SURVEY.md 8a quirk 2)");
+  if (rays->num_rays < 0 || rays->num_rays > 0x7fffffff) return ctx->fail(NERFDS_EINVAL, "num_rays out of range");
+  if (rays->num_rays == 0) return NERFDS_OK;
+  if (!rays->origins || !rays->directions) return ctx->fail(NERFDS_EINVAL, "origins/directions are required");
+  if (ctx->cfg.use_warp && !rays->warp_id) return ctx->fail(NERFDS_EINVAL, "metadata['warp'] ids are required by this graph");
+  if (extra->mask_ratio != 1.0f && ctx->cfg.use_predicted_mask && !rays->gt_mask)
+    return ctx->fail(NERFDS_EINVAL, "rays_dict['mask'] is required when mask_ratio != 1");
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(NERFDS_EDEVICE, "hipSetDevice failed");
+  int rc = ensure_packed(ctx, prec);
+  if (rc != NERFDS_OK) return rc;
+
+  KArgs ka{};
+  ka.origins = rays->origins; ka.directions = rays->directions; ka.viewdirs = rays->viewdirs;
+  ka.warp_id = rays->warp_id; ka.gt_mask = rays->gt_mask;
+  ka.t_rand = rnd ? rnd->t_rand : nullptr;
+  ka.u_rand = rnd ? rnd->u_rand : nullptr;
+  ka.seed = rnd ? rnd->seed : 0;
+  for (int i = 0; i < 3; ++i) { ka.wstream[i] = ctx->wstream[prec][i].p; ka.bias[i] = static_cast<const float*>(ctx->wbias[i].p); }
+  if (ctx->cfg.num_fine_samples == 0) { ka.wstream[2] = ka.wstream[1]; ka.bias[2] = ka.bias[1]; }
+  ka.warp_embed = static_cast<const float*>(ctx->warp_embed.p);
+  ka.mask_embed = static_cast<const float*>(ctx->mask_embed.p);
+  ka.ray_fine = out->ray_fine; ka.ray_coarse = out->ray_coarse; ka.smp_fine = out->sample_fine; ka.smp_coarse = out->sample_coarse;
+  ka.num_rays = (int)rays->num_rays;
+  ka.nc = ctx->cfg.num_coarse_samples; ka.nf = ctx->cfg.num_fine_samples;
+  ka.stratified = extra->use_stratified_sampling;
+  ka.sample_at_infinity = ctx->cfg.use_sample_at_infinity;
+  ka.white_bkgd = ctx->cfg.use_white_background;
+  ka.near_ = extra->near; ka.far_ = extra->far;
+  ka.mask_ratio = extra->mask_ratio;
+  window(ka.win_mask, ctx->cfg.mask_max_deg, extra->warp_alpha);
+  window(ka.win_warp, ctx->cfg.warp_max_deg, extra->warp_alpha);
+  window(ka.win_hyp, ctx->cfg.hyper_sheet_max_deg, extra->hyper_sheet_alpha);
+  window(ka.win_sp, ctx->cfg.spatial_point_max_deg, extra->nerf_alpha);
+  window(ka.win_hp, ctx->cfg.hyper_point_max_deg, extra->hyper_alpha);
+  window(ka.win_nm, ctx->cfg.norm_input_max_deg, extra->norm_input_alpha);
+
+  const int grid = (int)std::min<int64_t>(rays->num_rays, (int64_t)ctx->num_cus * 4);   // one 512-VGPR wave per SIMD
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+  if (ctx->timing) {
+    if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess)
+      return ctx->fail(NERFDS_EDEVICE, "hipEventCreate failed");
+    (void)hipEventRecord(ev.first, stream);
+  }
+  launcher(ctx->graph, prec)(ka, grid, stream);
+  hipError_t e = hipGetLastError();
+  if (ctx->timing) {
+    (void)hipEventRecord(ev.second, stream);
+    ctx->events.push_back(ev);
+  }
+  if (e != hipSuccess) return ctx->fail(NERFDS_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+  return NERFDS_OK;
+}
+
+int nerfds_kernel_time_ms(nerfds_ctx* ctx, int reset, double* total_ms) {
+  if (!ctx) return NERFDS_EINVAL;
+  (void)hipSetDevice(ctx->device);
+  int n = 0;
+  double tot = 0.0;
+  for (auto& e : ctx->events) {
+    if (hipEventSynchronize(e.second) == hipSuccess) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot += ms; ++n; }
+    }
+  }
+  if (total_ms) *total_ms = tot;
+  if (reset) {
+    for (auto& e : ctx->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    ctx->events.clear();
+    ctx->timing = true;
+  }
+  return n;
+}
+
+// ---- host-only packing helpers -----------------------------------------------------------------------
+int64_t nerfds_pack_stream_bytes(const nerfds_model_cfg* cfg, int which, uint32_t prec) {
+  if (!cfg || prec > NERFDS_PREC_F32 || which < 0 || which > 1) return NERFDS_EINVAL;
+  const int g = graph_of(*cfg);
+  if (g < 0) return NERFDS_ENOTSUP;
+  int64_t wb, bf;
+  stream_dims_dispatch(g, which, (int)prec, &wb, &bf);
+  return wb;
+}
+int64_t nerfds_pack_bias_floats(const nerfds_model_cfg* cfg, int which) {
+  if (!cfg || which < 0 || which > 1) return NERFDS_EINVAL;
+  const int g = graph_of(*cfg);
+  if (g < 0) return NERFDS_ENOTSUP;
+  int64_t wb, bf;
+  stream_dims_dispatch(g, which, 0, &wb, &bf);
+  return bf;
+}
+int nerfds_pack_stream(const nerfds_model_cfg* cfg, const nerfds_weights* w, int which, int level, uint32_t prec,
+                       void* stream_out, float* bias_out) {
+  if (!cfg || !w || prec > NERFDS_PREC_F32 || which < 0 || which > 1 || level < 0 || level > 1) return NERFDS_EINVAL;
+  const int g = graph_of(*cfg);
+  if (g < 0) return NERFDS_ENOTSUP;
+  Weights W;
+  std::string err;
+  bool ok = g == GraphNerfDS::ID ? take_weights<GraphNerfDS>(W, *cfg, *w, err) : take_weights<GraphStatic>(W, *cfg, *w, err);
+  if (!ok) { g_create_error = err; return NERFDS_EINVAL; }
+  StreamWriter sw{(int)prec, static_cast<uint8_t*>(stream_out), bias_out};
+  pack_dispatch(g, sw, W, which, level);
+  return NERFDS_OK;
+}
+
+}  // extern "C"
+
+// ---- device self-test of the MFMA operand / accumulator maps -------------------------------------------
+namespace {
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__global__ void mfma_probe(const float* __restrict__ A /*[32][16]*/, const float* __restrict__ B /*[16][32]*/,
+                           float* __restrict__ Cb, float* __restrict__ Cf) {
+  const int l = threadIdx.x, m = l & 31, h = l >> 5;
+  bf16x8_t a, b;
+  for (int i = 0; i < 8; ++i) {          // k-slot (h, i) <-> k = 8h + i for BOTH operands
+    a[i] = (__bf16)A[m * 16 + 8 * h + i];
+    b[i] = (__bf16)B[(8 * h + i) * 32 + m];
+  }
+  f32x16_t acc = {0};
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  f32x16_t accf = {0};
+  for (int i = 0; i < 8; ++i)            // fp32: one k-slot pair (h = 0, 1) per instruction
+    accf = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m * 16 + 8 * h + i], B[(8 * h + i) * 32 + m], accf, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;   // the accumulator map render_kernel.hip relies on
+    Cb[row * 32 + m] = acc[r];
+    Cf[row * 32 + m] = accf[r];
+  }
+}
+}  // namespace
+
+extern "C" int nerfds_debug_mfma(int device, const float* a, const float* b, float* c_bf16, float* c_f32) {
+  if (hipSetDevice(device) != hipSuccess) return NERFDS_EDEVICE;
+  float *da, *db, *dc, *df;
+  if (hipMalloc(&da, 32 * 16 * 4) != hipSuccess || hipMalloc(&db, 16 * 32 * 4) != hipSuccess ||
+      hipMalloc(&dc, 32 * 32 * 4) != hipSuccess || hipMalloc(&df, 32 * 32 * 4) != hipSuccess)
+    return NERFDS_ENOMEM;
+  (void)hipMemcpy(da, a, 32 * 16 * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(db, b, 16 * 32 * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(mfma_probe, dim3(1), dim3(64), 0, 0, da, db, dc, df);
+  hipError_t e = hipDeviceSynchronize();
+  (void)hipMemcpy(c_bf16, dc, 32 * 32 * 4, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(c_f32, df, 32 * 32 * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(df);
+  return e == hipSuccess ? NERFDS_OK : NERFDS_EDEVICE;
+}

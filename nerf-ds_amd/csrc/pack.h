@@ -1,0 +1,219 @@
+// Host-side packer: Flax parameter tree -> MFMA fragment stream (see render_kernel.hip header).
+//
+// For every dense layer the stream holds, per output tile of 32 rows and per k16-chunk, one fragment
+// laid out lane-linearly: lane l = (h << 5) | m supplies, for output row m of the tile, the weights of
+// k-slots (h, i), i = 0..7.  What makes the in-register chaining work is the k-slot -> input-feature map:
+//   * "linear" segments (raw network inputs built in-kernel): slot (chunk c, h, i) <-> feature 16c + 8h + i
+//   * "tile" segments (a previous layer's output, straight from its accumulators):
+//       slot (tile t, chunk c in {0,1}, h, i) <-> feature 32t + 16c + (i & 3) + 8 (i >> 2) + 4h
+// and, for output heads, the row -> logical-output map j = (m & 3) + 4 (m >> 3) (each logical output is
+// present in both lane halves so no cross-lane traffic is needed to read it).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#include "graphs.h"
+
+namespace nerfds {
+
+struct DenseView {
+  const float* kernel = nullptr;   // [in][out] row-major (Flax nn.Dense)
+  const float* bias = nullptr;     // [out]
+  int in_dim = 0, out_dim = 0;
+  float W(int r, int c) const { return kernel[(size_t)r * out_dim + c]; }
+};
+
+inline uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f32(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+// k-slot -> kernel-row maps -------------------------------------------------------------------------
+inline void rows_linear(std::vector<int>& rm, int n_chunks, const std::function<int(int)>& feat_to_row) {
+  for (int s = 0; s < 16 * n_chunks; ++s) rm.push_back(feat_to_row(s));
+}
+inline void rows_tile(std::vector<int>& rm, int width, int row0) {
+  for (int t = 0; t < width / 32; ++t)
+    for (int c = 0; c < 2; ++c)
+      for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 8; ++i) rm.push_back(row0 + 32 * t + 16 * c + (i & 3) + 8 * (i >> 2) + 4 * h);
+}
+inline int head_col(int m) { return (m & 3) + 4 * (m >> 3); }
+
+struct Layer {
+  std::vector<int> rows;                       // per k-slot (chunk*16 + h*8 + i): kernel row or -1
+  int n_tiles = 0;                             // output tiles of 32 rows
+  bool is_head = false;
+  int n_out = 0;                               // logical outputs
+  std::function<float(int, int)> W;            // (row, col)
+  std::function<float(int)> B;                 // (col)
+};
+
+struct StreamWriter {
+  int prec;
+  uint8_t* w;       // may be nullptr: count only
+  float* b;
+  size_t wbytes = 0, bfloats = 0;
+
+  void emit(const Layer& L) {
+    const int kc_n = (int)L.rows.size() / 16;
+    for (int ot = 0; ot < L.n_tiles; ++ot) {
+      for (int kc = 0; kc < kc_n; ++kc) {
+        if (w) {
+          uint8_t* frag = w + wbytes;
+          for (int lane = 0; lane < 64; ++lane) {
+            const int m = lane & 31, h = lane >> 5;
+            int col = L.is_head ? head_col(m) : 32 * ot + m;
+            if (col >= L.n_out) col = -1;
+            float v[8];
+            for (int i = 0; i < 8; ++i) {
+              const int r = L.rows[kc * 16 + h * 8 + i];
+              v[i] = (r < 0 || col < 0) ? 0.f : L.W(r, col);
+            }
+            if (prec == P_BF16) {
+              uint16_t* d = reinterpret_cast<uint16_t*>(frag + lane * 16);
+              for (int i = 0; i < 8; ++i) d[i] = f32_to_bf16_rne(v[i]);
+            } else if (prec == P_BF16X3) {
+              uint16_t* dh = reinterpret_cast<uint16_t*>(frag + lane * 16);
+              uint16_t* dl = reinterpret_cast<uint16_t*>(frag + 1024 + lane * 16);
+              for (int i = 0; i < 8; ++i) {
+                dh[i] = f32_to_bf16_rne(v[i]);
+                dl[i] = f32_to_bf16_rne(v[i] - bf16_to_f32(dh[i]));
+              }
+            } else {
+              float* da = reinterpret_cast<float*>(frag + lane * 16);
+              float* db = reinterpret_cast<float*>(frag + 1024 + lane * 16);
+              for (int i = 0; i < 4; ++i) { da[i] = v[i]; db[i] = v[4 + i]; }
+            }
+          }
+        }
+        wbytes += frag_bytes(prec);
+      }
+      if (b) {
+        for (int m = 0; m < 32; ++m) {
+          int col = L.is_head ? head_col(m) : 32 * ot + m;
+          b[bfloats + m] = (col < L.n_out) ? L.B(col) : 0.f;
+        }
+      }
+      bfloats += 32;
+    }
+  }
+};
+
+inline Layer plain_layer(const DenseView& d, std::vector<int> rows, int width) {
+  Layer L;
+  L.rows = std::move(rows);
+  L.n_tiles = width / 32;
+  L.n_out = d.out_dim;
+  L.W = [d](int r, int c) { return d.W(r, c); };
+  L.B = [d](int c) { return d.bias ? d.bias[c] : 0.f; };
+  return L;
+}
+inline Layer head_layer(const DenseView& d, std::vector<int> rows) {
+  Layer L = plain_layer(d, std::move(rows), 32);
+  L.is_head = true;
+  return L;
+}
+
+// A reference modules.MLP (modules.py:57-83) with `depth` hidden layers of `width`, raw input of `in_dim`
+// features in `in_chunks` linear chunks, skip re-concatenation [x, inputs] before layer `skip`.
+inline void emit_mlp(StreamWriter& sw, const DenseView* hidden, int depth, int width, int in_dim, int in_chunks, int skip) {
+  for (int l = 0; l < depth; ++l) {
+    std::vector<int> rows;
+    if (l == 0) {
+      rows_linear(rows, in_chunks, [&](int s) { return s < in_dim ? s : -1; });
+    } else {
+      rows_tile(rows, width, 0);
+      if (l == skip) rows_linear(rows, in_chunks, [&](int s) { return s < in_dim ? width + s : -1; });
+    }
+    sw.emit(plain_layer(hidden[l], std::move(rows), width));
+  }
+}
+
+struct SharedNets {       // views into nerfds_weights
+  DenseView mask_hidden[16], mask_out;
+  DenseView warp_hidden[16], warp_w, warp_v;
+  DenseView hyper_hidden[16], hyper_out;
+};
+struct NerfNet {
+  DenseView trunk[16], bottleneck, alpha, rgb_hidden[16], rgb;
+};
+
+template <class G> void pack_shared(StreamWriter& sw, const SharedNets& n) {
+  using D = Dims<G>;
+  if constexpr (G::HAS_MASK) {
+    emit_mlp(sw, n.mask_hidden, G::MASK_DEPTH, G::MASK_W, D::MASK_IN, D::MASK_KC, G::MASK_SKIP);
+    std::vector<int> rows;
+    rows_tile(rows, G::MASK_W, 0);
+    sw.emit(head_layer(n.mask_out, std::move(rows)));
+  }
+  if constexpr (G::HAS_WARP) {
+    emit_mlp(sw, n.warp_hidden, G::WARP_DEPTH, G::WARP_W, D::WARP_IN, D::WARP_KC, G::WARP_SKIP);
+    std::vector<int> rows;
+    rows_tile(rows, G::WARP_W, 0);
+    Layer L;                                   // merged head: logical outputs 0-2 = w, 3-5 = v (warping.py:217-218)
+    L.rows = std::move(rows);
+    L.n_tiles = 1;
+    L.is_head = true;
+    L.n_out = 6;
+    const DenseView w = n.warp_w, v = n.warp_v;
+    L.W = [w, v](int r, int c) { return c < 3 ? w.W(r, c) : v.W(r, c - 3); };
+    L.B = [w, v](int c) { return c < 3 ? (w.bias ? w.bias[c] : 0.f) : (v.bias ? v.bias[c - 3] : 0.f); };
+    sw.emit(L);
+  }
+  if constexpr (G::HAS_HYPER) {
+    emit_mlp(sw, n.hyper_hidden, G::HYP_DEPTH, G::HYP_W, D::HYP_IN, D::HYP_KC, G::HYP_SKIP);
+    std::vector<int> rows;
+    rows_tile(rows, G::HYP_W, 0);
+    sw.emit(head_layer(n.hyper_out, std::move(rows)));
+  }
+}
+
+template <class G> void pack_nerf(StreamWriter& sw, const NerfNet& n) {
+  using D = Dims<G>;
+  constexpr int TW = G::TRUNK_W;
+  emit_mlp(sw, n.trunk, G::TRUNK_DEPTH, TW, D::TRUNK_IN, D::TRUNK_KC, G::TRUNK_SKIP);
+  {  // bottleneck (modules.py:255)
+    std::vector<int> rows;
+    rows_tile(rows, TW, 0);
+    sw.emit(plain_layer(n.bottleneck, std::move(rows), TW));
+  }
+  {  // alpha head on trunk_output (modules.py:273-274)
+    std::vector<int> rows;
+    rows_tile(rows, TW, 0);
+    sw.emit(head_layer(n.alpha, std::move(rows)));
+  }
+  {  // rgb hidden_0.  Reference row order (modules.py:296-310): [bottleneck TW | viewdir 6*VD | trunk_output TW (if X_IN_RGB) | normal 6*NM]
+     // Kernel K order: [bottleneck tiles | trunk_output tiles | cond chunks = viewdir ++ normal]
+    constexpr int VD = 6 * G::VD_BANDS, NM = 6 * G::NM_BANDS;
+    constexpr int row_vd = TW, row_x = TW + VD, row_nm = TW + VD + (G::X_IN_RGB ? TW : 0);
+    std::vector<int> rows;
+    rows_tile(rows, TW, 0);
+    if (G::X_IN_RGB) rows_tile(rows, TW, row_x);
+    rows_linear(rows, D::COND_KC, [&](int s) {
+      if (s < VD) return row_vd + s;
+      if (s < VD + NM) return row_nm + (s - VD);
+      return -1;
+    });
+    sw.emit(plain_layer(n.rgb_hidden[0], std::move(rows), G::RGB_W));
+  }
+  {  // rgb head
+    std::vector<int> rows;
+    rows_tile(rows, G::RGB_W, 0);
+    sw.emit(head_layer(n.rgb, std::move(rows)));
+  }
+}
+
+}  // namespace nerfds

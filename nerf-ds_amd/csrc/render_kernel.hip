@@ -1,0 +1,902 @@
+// Fused NeRF-DS ray kernel for gfx950 (MI355X / CDNA4).
+//
+// One wavefront renders one ray end to end: stratified sampling -> [MaskMLP -> SE(3) warp MLP + exp_se3 ->
+// hyper-sheet MLP -> trunk / sigma / rgb NerfMLP] on every sample -> exclusive-cumprod compositing ->
+// inverse-CDF resample + sort -> the same networks on the fine samples -> compositing -> one 104-byte record.
+// Nothing per-sample ever goes to HBM (unless the optional per-sample record is requested).
+//
+// Reference functions restated here (paths under /root/reference/hypernerf/):
+//   sample_along_rays model_utils.py:55-92      volumetric_rendering model_utils.py:95-159
+//   piecewise_constant_pdf / sample_pdf model_utils.py:193-269   compute_depth_* model_utils.py:272-317
+//   posenc / posenc_window model_utils.py:398-436                normalize_vector model_utils.py:438-442
+//   MLP modules.py:57-83   NerfMLP.query_* modules.py:243-313   HyperSheetMLP modules.py:367-392   MaskMLP 409-434
+//   SE3Field.warp warping.py:200-237   exp_se3/exp_so3/skew rigid_body.py:26-101
+//   NerfModel.render_samples models.py:867-1417   NerfModel.__call__ models.py:1419-1565
+//
+// MFMA mapping (the point of the design).  Every dense layer is computed TRANSPOSED:
+//     H^T[out][sample] = W^T[out][k] * X^T[k][sample]
+// with the weights as the MFMA A operand (32 output features x 16 k-slots per fragment, streamed from
+// L2 in the exact lane order) and the activations as the B operand (16 k-slots x 32 samples).  With
+// v_mfma_f32_32x32x16_bf16 the accumulator of lane l holds, for sample (l & 31), the output features
+//     row(r, l) = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5),   r = 0..15
+// and the B operand of lane l must hold, for sample (l & 31), k-slots 8 * (l >> 5) + 0..7.  So the
+// 16 accumulator registers of an output tile ARE, after bias/ReLU and a pack to bf16, two B operands
+// of the next layer (registers 0-7 and 8-15), provided the next layer's weight fragments were packed
+// with the k-slot -> feature permutation   feature = 32*tile + 16*c + (i & 3) + 8 * (i >> 2) + 4 * h
+// (c = chunk within the tile, h = lane half, i = element).  The host packer does that once
+// (nerfds_host.cpp), so activations never leave registers between layers: no LDS round trip, no
+// transposes, no barriers.  The same holds for v_mfma_f32_32x32x2_f32 (fp32-exact mode, one k-slot
+// pair per instruction) and for the split-bf16 "bf16x3" mode (hi/lo operands, three MFMAs per product).
+//
+// A wave carries NT "N-tiles" of 32 samples (NT = 2 in bf16 mode: one weight fragment feeds two MFMAs).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "graphs.h"
+#include "kargs.h"
+
+namespace nerfds {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define DEVI __device__ __forceinline__
+// LDS scratch is private to a wave and a wave's DS ops complete in order: a compiler-level fence is all that is needed.
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Operand containers
+// ------------------------------------------------------------------------------------------------
+template <int P> struct Chunk;   // 16 k-slots x 32 samples of activations (this lane: 8 slots of 1 sample)
+template <> struct Chunk<P_BF16> { bf16x8 v; };
+template <> struct Chunk<P_BF16X3> { bf16x8 hi, lo; };
+template <> struct Chunk<P_F32> { float v[8]; };
+
+template <int P> struct WFrag;   // 32 out rows x 16 k-slots of weights (this lane: 8 slots of 1 row)
+template <> struct WFrag<P_BF16> { bf16x8 v; };
+template <> struct WFrag<P_BF16X3> { bf16x8 hi, lo; };
+template <> struct WFrag<P_F32> { f32x4 a, b; };
+
+template <int P> DEVI void make_chunk(Chunk<P>& c, const float (&x)[8]);
+template <> DEVI void make_chunk<P_BF16>(Chunk<P_BF16>& c, const float (&x)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c.v[i] = (__bf16)x[i];
+}
+template <> DEVI void make_chunk<P_BF16X3>(Chunk<P_BF16X3>& c, const float (&x)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    __bf16 hi = (__bf16)x[i];
+    c.hi[i] = hi;
+    c.lo[i] = (__bf16)(x[i] - (float)hi);
+  }
+}
+template <> DEVI void make_chunk<P_F32>(Chunk<P_F32>& c, const float (&x)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c.v[i] = x[i];
+}
+
+// Weight fragments come through a buffer descriptor: the per-lane part of the address is the constant
+// voffset = lane * 16, the fragment position is a wave-uniform soffset (a compile-time constant after
+// unrolling), so streaming 1760 fragments costs no per-fragment VGPR address arithmetic.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+DEVI rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), /*stride*/ 0, (int)bytes, 0x00020000);
+}
+
+template <int P> DEVI WFrag<P> load_wfrag(rsrc_t rsrc, int lane16, int soff) {
+  WFrag<P> w;
+  if constexpr (P == P_BF16) {
+    w.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, soff, 0));
+  } else if constexpr (P == P_BF16X3) {
+    w.hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, soff, 0));
+    w.lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, soff + 1024, 0));
+  } else {
+    w.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, soff, 0));
+    w.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, soff + 1024, 0));
+  }
+  return w;
+}
+
+template <int P> DEVI void mma(f32x16& acc, const WFrag<P>& w, const Chunk<P>& c) {
+  if constexpr (P == P_BF16) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v, c.v, acc, 0, 0, 0);
+  } else if constexpr (P == P_BF16X3) {
+    // (w_hi + w_lo)(x_hi + x_lo) ~= w_hi x_lo + w_lo x_hi + w_hi x_hi ; small terms first.
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, c.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, c.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, c.hi, acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.a[i], c.v[i], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.b[i], c.v[4 + i], acc, 0, 0, 0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight pipe.  The fragments of one evaluation form ONE static stream: [shared mask|warp|hyper nets]
+// followed by [NerfMLP of the level].  The pipe keeps DEPTH fragments in flight in a register ring:
+// consuming fragment i issues the load of fragment i + DEPTH (wrapping into the next evaluation's stream,
+// so the pipeline never drains between layers, batches or rays).  Every index is a compile-time
+// constant after unrolling; sched_barrier pins the VMEM loads to their program position so the
+// scheduler cannot hoist hundreds of them (and spill), while MFMA / VALU stay free to move.
+// ------------------------------------------------------------------------------------------------
+template <class G, int P> struct Pipe {
+  using Dm = Dims<G>;
+  static constexpr int DEPTH = 8;
+  static constexpr int SHARED = Dm::SHARED_FRAGS, TOTAL = Dm::SHARED_FRAGS + Dm::NERF_FRAGS;
+  // stream indices [TOTAL, TOTAL_PAD) are holes so that the ring slot of a fragment survives the wrap
+  static constexpr int TOTAL_PAD = cdiv(TOTAL, DEPTH) * DEPTH;
+  WFrag<P> ring[DEPTH];
+  rsrc_t ws;        // shared stream
+  rsrc_t wn;        // NerfMLP stream of the level being evaluated
+  rsrc_t wn_next;   // NerfMLP stream of the level evaluated next (wrap-around prefetch)
+  rsrc_t bs, bn;    // padded fp32 biases: shared, NerfMLP of the current level
+  int lane16;
+
+  DEVI void issue(int i) {     // i: stream index, may run past TOTAL_PAD (wrap into the next evaluation)
+    if (i >= TOTAL && i < TOTAL_PAD) return;
+    const int j = i % TOTAL_PAD;
+    if (j < SHARED) ring[i % DEPTH] = load_wfrag<P>(ws, lane16, j * frag_bytes(P));
+    else ring[i % DEPTH] = load_wfrag<P>(i >= TOTAL_PAD ? wn_next : wn, lane16, (j - SHARED) * frag_bytes(P));
+  }
+  DEVI void finish_eval() {    // loads that the holes did not trigger
+#pragma unroll
+    for (int i = TOTAL; i < TOTAL_PAD; ++i) issue(i + DEPTH);
+  }
+};
+
+// everything but VMEM may be scheduled across (LLVM SchedGroupMask: ALU VALU SALU MFMA DS DS_READ DS_WRITE TRANS)
+#define PIN_VMEM() __builtin_amdgcn_sched_barrier(0x1 | 0x2 | 0x4 | 0x8 | 0x80 | 0x100 | 0x200 | 0x400)
+
+struct Cursor {
+  int fi;       // stream index of the next fragment
+  int boff;     // byte offset of the next bias tile
+  bool nerf;    // bias array: shared or NerfMLP
+};
+
+// Bias of a tile for this lane: register r <-> row (r & 3) + 8 (r >> 2) + 4 h.
+DEVI void load_bias(float (&bv)[16], rsrc_t bias, int boff, int h) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bias, 16 * h, boff + 32 * g, 0));
+    bv[4 * g + 0] = b[0]; bv[4 * g + 1] = b[1]; bv[4 * g + 2] = b[2]; bv[4 * g + 3] = b[3];
+  }
+}
+
+template <class G, int P, int NT, int K>
+DEVI void accum(f32x16 (&acc)[NT], Pipe<G, P>& pipe, Cursor& cur, const Chunk<P> (&in)[NT][K]) {
+#pragma unroll
+  for (int kc = 0; kc < K; ++kc) {
+    const int i = cur.fi + kc;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) mma<P>(acc[nt], pipe.ring[i % Pipe<G, P>::DEPTH], in[nt][kc]);
+    pipe.issue(i + Pipe<G, P>::DEPTH);
+    PIN_VMEM();
+  }
+  cur.fi += K;
+}
+
+template <int NT> DEVI void zero_acc(f32x16 (&acc)[NT]) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+}
+
+// One dense layer with OT output tiles of 32 features; inputs are one or more chunk arrays in stream order.
+template <class G, int P, int NT, int OT, bool RELU, class... Ins>
+DEVI void dense(Pipe<G, P>& pipe, Cursor& cur, int h, Chunk<P> (&out)[NT][2 * OT], const Ins&... ins) {
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) {
+    float bv[16];
+    load_bias(bv, cur.nerf ? pipe.bn : pipe.bs, cur.boff + 128 * ot, h);
+    PIN_VMEM();
+    f32x16 acc[NT];
+    zero_acc<NT>(acc);
+    (accum<G, P, NT>(acc, pipe, cur, ins), ...);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float x0[8], x1[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float a0 = acc[nt][i] + bv[i], a1 = acc[nt][8 + i] + bv[8 + i];
+        x0[i] = RELU ? fmaxf(a0, 0.f) : a0;
+        x1[i] = RELU ? fmaxf(a1, 0.f) : a1;
+      }
+      make_chunk<P>(out[nt][2 * ot], x0);
+      make_chunk<P>(out[nt][2 * ot + 1], x1);
+    }
+  }
+  cur.boff += 128 * OT;
+}
+
+// Output head (<= 16 logical outputs, duplicated in both lane halves by the packer): logical output j = acc[j].
+template <class G, int P, int NT, class... Ins>
+DEVI void head(Pipe<G, P>& pipe, Cursor& cur, int h, f32x16 (&acc)[NT], const Ins&... ins) {
+  float bv[16];
+  load_bias(bv, cur.nerf ? pipe.bn : pipe.bs, cur.boff, h);
+  PIN_VMEM();
+  zero_acc<NT>(acc);
+  (accum<G, P, NT>(acc, pipe, cur, ins), ...);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] += bv[r];
+  cur.boff += 128;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scalar math helpers
+// ------------------------------------------------------------------------------------------------
+// sin with a 3-term Cody-Waite reduction (fma) and degree-9/8 minimax kernels on [-pi/4, pi/4]; ~1-2 ulp for
+// |a| < 1e5 (posenc arguments are |x| * 2^7 at most), libm beyond.
+DEVI float sin_cw(float a) {
+  if (__builtin_expect(fabsf(a) > 1.0e5f, 0)) return sinf(a);
+  float k = rintf(a * 0.636619772f);
+  int q = (int)k;
+  float r = fmaf(-k, 1.57079601e+00f, a);
+  r = fmaf(-k, 3.13916473e-07f, r);
+  r = fmaf(-k, 5.39030253e-15f, r);
+  float s = r * r;
+  float ps = fmaf(s, 2.86567956e-6f, -1.98559923e-4f);
+  ps = fmaf(ps, s, 8.33338592e-3f);
+  ps = fmaf(ps, s, -1.66666672e-1f);
+  float sn = fmaf(r * s, ps, r);
+  float pc = fmaf(s, 2.44677067e-5f, -1.38877297e-3f);
+  pc = fmaf(pc, s, 4.16666567e-2f);
+  pc = fmaf(pc, s, -0.5f);
+  float cs = fmaf(pc, s, 1.0f);
+  float v = (q & 1) ? cs : sn;
+  return (q & 2) ? -v : v;
+}
+
+DEVI float softplus_f(float x) {   // jax.nn.softplus = logaddexp(x, 0)
+  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+DEVI float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+DEVI void normalize3(float (&v)[3]) {   // model_utils.py:438-442
+  float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  float inv = 1.0f / sqrtf(fmaxf(n2, 1.1920929e-07f));
+  v[0] *= inv; v[1] *= inv; v[2] *= inv;
+}
+
+// Philox4x32-10 (Salmon et al. 2011) -> 4 uniforms in [0, 1).
+DEVI void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, float (&u)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  u[0] = (c0 >> 8) * 5.9604645e-8f; u[1] = (c1 >> 8) * 5.9604645e-8f;
+  u[2] = (c2 >> 8) * 5.9604645e-8f; u[3] = (c3 >> 8) * 5.9604645e-8f;
+}
+
+// wave-wide helpers (64 lanes)
+DEVI float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+DEVI float wave_scan_add(float v, int lane) {     // inclusive
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+  return v;
+}
+DEVI float wave_scan_mul(float v, int lane) {     // inclusive
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(v, o, 64); if (lane >= o) v *= t; }
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Input encodings -> B operands.  A feature descriptor says how to produce linear feature f for one sample.
+// ------------------------------------------------------------------------------------------------
+struct FeatV { int kind; float arg; float win; float val; };   // kind: 0 zero, 1 sin(arg) * win, 2 val
+
+// posenc feature g of a C-channel vector (layout [band][sin, cos][channel], model_utils.py:403-412)
+template <int C> DEVI FeatV posenc_feat(int g, const float (&x)[C], const float* win) {
+  const int band = g / (2 * C), sc = (g % (2 * C)) / C, ch = g % C;
+  FeatV f;
+  f.kind = 1;
+  // sin(fl(x * 2^band + pi/2)): x * 2^band is exact, so the fma rounds once like the reference's add.
+  f.arg = fmaf(x[ch], (float)(1 << band), sc ? 1.57079637f : 0.0f);
+  f.win = win ? win[band] : 1.0f;
+  f.val = 0.f;
+  return f;
+}
+DEVI FeatV val_feat(float v) { FeatV f; f.kind = 2; f.arg = 0.f; f.win = 0.f; f.val = v; return f; }
+DEVI FeatV zero_feat() { FeatV f; f.kind = 0; f.arg = 0.f; f.win = 0.f; f.val = 0.f; return f; }
+
+// Linear-feature chunk c: this lane supplies features 16c + 8h + i, i = 0..7.
+template <int P, int KCH, class F> DEVI void build_chunks(Chunk<P> (&out)[KCH], int h, F feat) {
+#pragma unroll
+  for (int c = 0; c < KCH; ++c) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const FeatV A = feat(16 * c + i), B = feat(16 * c + 8 + i);
+      float s = 0.f;
+      if (A.kind == 1 || B.kind == 1) s = sin_cw(h ? B.arg : A.arg);
+      const float va = (A.kind == 1) ? s * A.win : A.val;
+      const float vb = (B.kind == 1) ? s * B.win : B.val;
+      x[i] = h ? vb : va;
+    }
+    make_chunk<P>(out[c], x);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-wave LDS scratch
+// ------------------------------------------------------------------------------------------------
+enum { SV_SIGMA = 0, SV_RGB = 1, SV_MASK = 4, SV_NORM = 5, SV_WP = 8, SV_ROT = 13, SV_TRN = 16, SV_COUNT = 19 };
+
+struct WaveLds {
+  float zs[MAX_SAMPLES];      // z of the current level
+  float zn[MAX_SAMPLES];      // scratch: unsorted union / bins
+  float ws[MAX_SAMPLES];      // compositing weights of the level just rendered
+  float cdf[MAX_SAMPLES];
+  float sv[SV_COUNT][MAX_SAMPLES];
+};
+
+struct RayConst {
+  float o[3], d[3], vd[3];
+  float wemb[8], memb[8];
+  float gt_mask;
+  float vdenc[24];
+};
+
+// ------------------------------------------------------------------------------------------------
+// The per-sample field: networks on one batch of 32*NT samples.
+// ------------------------------------------------------------------------------------------------
+template <class G, int P, int NT>
+DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int lane, int s_base, int S, WaveLds& L) {
+  using D = Dims<G>;
+  const int h = lane >> 5, ln = lane & 31;
+
+  float x[NT][3], xw[NT][3];
+  bool valid[NT];
+  int sidx[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int s = s_base + 32 * nt + ln;
+    valid[nt] = s < S;
+    sidx[nt] = s;
+    float z = L.zs[valid[nt] ? s : S - 1];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      x[nt][c] = __fadd_rn(rc.o[c], __fmul_rn(z, rc.d[c]));   // model_utils.py:91-92
+      xw[nt][c] = x[nt][c];
+    }
+  }
+
+  Cursor cur{0, 0, false};
+
+  // ---- MaskMLP (modules.py:409-434; models.py:967-975) ----
+  float maskv[NT], pmask[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { maskv[nt] = rc.gt_mask; pmask[nt] = 0.f; }
+  if constexpr (G::HAS_MASK) {
+    constexpr int W16 = G::MASK_W / 16, W32 = G::MASK_W / 32;
+    Chunk<P> in0[NT][D::MASK_KC], a[NT][W16], b[NT][W16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      build_chunks<P, D::MASK_KC>(in0[nt], h, [&](int f) {
+        if (f < 6 * G::MASK_BANDS) return posenc_feat<3>(f, x[nt], ka.win_mask);
+        if (f < D::MASK_IN) return val_feat(rc.memb[(f - 6 * G::MASK_BANDS) & 7]);
+        return zero_feat();
+      });
+    static_assert(G::MASK_DEPTH == 8 || !G::HAS_MASK, "mask net is unrolled for depth 8, skip 4");
+    dense<G, P, NT, W32, true>(pipe, cur, h, a, in0);
+    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, P, NT, W32, true>(pipe, cur, h, a, b);
+    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, P, NT, W32, true>(pipe, cur, h, a, b, in0);      // skip: [x, inputs] (modules.py:66-67)
+    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, P, NT, W32, true>(pipe, cur, h, a, b);
+    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
+    f32x16 hacc[NT];
+    head<G, P, NT>(pipe, cur, h, hacc, b);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      pmask[nt] = fmaxf(hacc[nt][0], 0.f);                                  // MaskMLP.output_activation = relu
+      maskv[nt] = pmask[nt] * ka.mask_ratio + rc.gt_mask * (1.0f - ka.mask_ratio);   // models.py:975
+    }
+  }
+
+  // ---- SE3Field (warping.py:200-237) + exp_se3 (rigid_body.py:77-101) ----
+  float Rm[NT][9], pt[NT][3];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rm[nt][i] = (i % 4 == 0) ? 1.f : 0.f;
+    pt[nt][0] = pt[nt][1] = pt[nt][2] = 0.f;
+  }
+  if constexpr (G::HAS_WARP) {
+    constexpr int W16 = G::WARP_W / 16, W32 = G::WARP_W / 32;
+    Chunk<P> in0[NT][D::WARP_KC], a[NT][W16], b[NT][W16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      build_chunks<P, D::WARP_KC>(in0[nt], h, [&](int f) {
+        if (f < 6 * G::WARP_BANDS) return posenc_feat<3>(f, x[nt], ka.win_warp);
+        if (f < 6 * G::WARP_BANDS + 8) return val_feat(rc.wemb[(f - 6 * G::WARP_BANDS) & 7]);
+        if (f == 6 * G::WARP_BANDS + 8) return val_feat(maskv[nt]);         // models.py:729-730
+        return zero_feat();
+      });
+    static_assert(G::WARP_DEPTH == 6 || !G::HAS_WARP, "warp trunk is unrolled for depth 6, skip 4");
+    dense<G, P, NT, W32, true>(pipe, cur, h, a, in0);
+    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, P, NT, W32, true>(pipe, cur, h, a, b);
+    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, P, NT, W32, true>(pipe, cur, h, a, b, in0);
+    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
+    f32x16 hacc[NT];
+    head<G, P, NT>(pipe, cur, h, hacc, b);      // logical outputs: w = 0..2, v = 3..5
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float w0 = hacc[nt][0], w1 = hacc[nt][1], w2 = hacc[nt][2];
+      float v0 = hacc[nt][3], v1 = hacc[nt][4], v2 = hacc[nt][5];
+      float theta = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);     // warping.py:219 (no epsilon, as the reference)
+      w0 /= theta; w1 /= theta; w2 /= theta;
+      v0 /= theta; v1 /= theta; v2 /= theta;
+      // W = skew(w); W2 = W @ W
+      const float W[9] = {0.f, -w2, w1, w2, 0.f, -w0, -w1, w0, 0.f};
+      float W2[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) W2[3 * r + c] = W[3 * r] * W[c] + W[3 * r + 1] * W[3 + c] + W[3 * r + 2] * W[6 + c];
+      const float st = sinf(theta), ct = cosf(theta);
+      const float omc = 1.0f - ct, tms = theta - st;
+      float Gm[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const float eye = (i % 4 == 0) ? 1.f : 0.f;
+        Rm[nt][i] = eye + st * W[i] + omc * W2[i];                    // rigid_body.py:73-74
+        Gm[i] = theta * eye + omc * W[i] + tms * W2[i];               // rigid_body.py:94-95
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) pt[nt][r] = Gm[3 * r] * v0 + Gm[3 * r + 1] * v1 + Gm[3 * r + 2] * v2;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        xw[nt][r] = Rm[nt][3 * r] * x[nt][0] + Rm[nt][3 * r + 1] * x[nt][1] + Rm[nt][3 * r + 2] * x[nt][2] + pt[nt][r];
+    }
+  }
+
+  // ---- HyperSheetMLP on the OBSERVATION-space point (modules.py:367-392; models.py:662-666) ----
+  float wamb[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) wamb[nt][0] = wamb[nt][1] = 0.f;
+  if constexpr (G::HAS_HYPER) {
+    constexpr int W16 = G::HYP_W / 16, W32 = G::HYP_W / 32;
+    Chunk<P> in0[NT][D::HYP_KC], a[NT][W16], b[NT][W16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      build_chunks<P, D::HYP_KC>(in0[nt], h, [&](int f) {
+        if (f < 6 * G::HYP_BANDS) return posenc_feat<3>(f, x[nt], ka.win_hyp);
+        if (f < 6 * G::HYP_BANDS + 8) return val_feat(rc.wemb[(f - 6 * G::HYP_BANDS) & 7]);   // hyper_use_warp_embed
+        if (f == 6 * G::HYP_BANDS + 8) return val_feat(maskv[nt]);                              // models.py:731-732
+        return zero_feat();
+      });
+    static_assert(G::HYP_DEPTH == 6 || !G::HAS_HYPER, "hyper sheet is unrolled for depth 6, skip 4");
+    dense<G, P, NT, W32, true>(pipe, cur, h, a, in0);
+    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, P, NT, W32, true>(pipe, cur, h, a, b);
+    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, P, NT, W32, true>(pipe, cur, h, a, b, in0);
+    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
+    f32x16 hacc[NT];
+    head<G, P, NT>(pipe, cur, h, hacc, b);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { wamb[nt][0] = hacc[nt][0]; wamb[nt][1] = hacc[nt][1]; }
+  }
+
+  // ---- NerfMLP of this level (modules.py:243-313; models.py:1043-1047, 1268-1270) ----
+  cur.boff = 0;
+  cur.nerf = true;
+  constexpr int TW16 = G::TRUNK_W / 16, TW32 = G::TRUNK_W / 32;
+  float sigma_raw[NT], nraw[NT][3], rgbv[NT][3];
+  {
+    Chunk<P> in0[NT][D::TRUNK_KC], a[NT][TW16], b[NT][TW16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      build_chunks<P, D::TRUNK_KC>(in0[nt], h, [&](int f) {
+        if (f < 6 * G::SP_BANDS) return posenc_feat<3>(f, xw[nt], ka.win_sp);                    // models.py:502-507
+        if (f < D::TRUNK_IN) return posenc_feat<2>(f - 6 * G::SP_BANDS, wamb[nt], ka.win_hp);    // models.py:510-516
+        return zero_feat();
+      });
+    static_assert(G::TRUNK_DEPTH == 8 && G::TRUNK_SKIP == 4, "trunk is unrolled for depth 8, skip 4");
+    dense<G, P, NT, TW32, true>(pipe, cur, h, a, in0);
+    dense<G, P, NT, TW32, true>(pipe, cur, h, b, a);
+    dense<G, P, NT, TW32, true>(pipe, cur, h, a, b);
+    dense<G, P, NT, TW32, true>(pipe, cur, h, b, a);
+    dense<G, P, NT, TW32, true>(pipe, cur, h, a, b, in0);
+    dense<G, P, NT, TW32, true>(pipe, cur, h, b, a);
+    dense<G, P, NT, TW32, true>(pipe, cur, h, a, b);
+    dense<G, P, NT, TW32, true>(pipe, cur, h, b, a);          // b = trunk_output
+    dense<G, P, NT, TW32, false>(pipe, cur, h, a, b);         // a = bottleneck (no activation, modules.py:255)
+    f32x16 hacc[NT];
+    head<G, P, NT>(pipe, cur, h, hacc, b);                    // alpha_mlp on trunk_output (modules.py:273-274)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      sigma_raw[nt] = hacc[nt][0];
+      nraw[nt][0] = G::PREDICT_NORM ? hacc[nt][1] : 0.f;
+      nraw[nt][1] = G::PREDICT_NORM ? hacc[nt][2] : 0.f;
+      nraw[nt][2] = G::PREDICT_NORM ? hacc[nt][3] : 0.f;
+    }
+    // rgb condition chunks: [posenc(viewdir) | posenc(normal in observation frame)]
+    Chunk<P> cond[NT][D::COND_KC];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float nin[3] = {0.f, 0.f, 0.f};
+      if constexpr (G::PREDICT_NORM) {
+        float n[3] = {nraw[nt][0], nraw[nt][1], nraw[nt][2]};
+        normalize3(n);                                                      // models.py:1124
+#pragma unroll
+        for (int c = 0; c < 3; ++c)                                         // R^T n (models.py:1126, inverse=True)
+          nin[c] = Rm[nt][c] * n[0] + Rm[nt][3 + c] * n[1] + Rm[nt][6 + c] * n[2];
+        normalize3(nin);                                                    // models.py:1138
+      }
+      build_chunks<P, D::COND_KC>(cond[nt], h, [&](int f) {
+        if (f < 6 * G::VD_BANDS) return val_feat(rc.vdenc[f < 24 ? f : 0]);
+        if (f < D::COND_IN) return posenc_feat<3>(f - 6 * G::VD_BANDS, nin, ka.win_nm);         // models.py:1142-1148
+        return zero_feat();
+      });
+    }
+    Chunk<P> c[NT][G::RGB_W / 16];
+    if constexpr (G::X_IN_RGB) {
+      dense<G, P, NT, G::RGB_W / 32, true>(pipe, cur, h, c, a, b, cond);   // K order [bottleneck | trunk_output | cond]
+    } else {
+      dense<G, P, NT, G::RGB_W / 32, true>(pipe, cur, h, c, a, cond);
+    }
+    head<G, P, NT>(pipe, cur, h, hacc, c);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      rgbv[nt][0] = sigmoid_f(hacc[nt][0]);                                 // models.py:576
+      rgbv[nt][1] = sigmoid_f(hacc[nt][1]);
+      rgbv[nt][2] = sigmoid_f(hacc[nt][2]);
+    }
+  }
+
+  pipe.finish_eval();
+  PIN_VMEM();
+
+  // ---- park the per-sample results in LDS for compositing ----
+  if (h == 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (!valid[nt]) continue;
+      const int s = sidx[nt];
+      L.sv[SV_SIGMA][s] = softplus_f(sigma_raw[nt]);                        // models.py:577
+      L.sv[SV_RGB + 0][s] = rgbv[nt][0];
+      L.sv[SV_RGB + 1][s] = rgbv[nt][1];
+      L.sv[SV_RGB + 2][s] = rgbv[nt][2];
+      L.sv[SV_MASK][s] = pmask[nt];
+      L.sv[SV_NORM + 0][s] = nraw[nt][0];
+      L.sv[SV_NORM + 1][s] = nraw[nt][1];
+      L.sv[SV_NORM + 2][s] = nraw[nt][2];
+      L.sv[SV_WP + 0][s] = xw[nt][0];
+      L.sv[SV_WP + 1][s] = xw[nt][1];
+      L.sv[SV_WP + 2][s] = xw[nt][2];
+      L.sv[SV_WP + 3][s] = wamb[nt][0];
+      L.sv[SV_WP + 4][s] = wamb[nt][1];
+      // rotation field: normalize(R @ normalize(1,1,1)) (models.py:1292-1296); translation field: R @ 0 + p
+      float rf[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) rf[r] = (Rm[nt][3 * r] + Rm[nt][3 * r + 1] + Rm[nt][3 * r + 2]) * 0.577350269f;
+      normalize3(rf);
+      L.sv[SV_ROT + 0][s] = rf[0];
+      L.sv[SV_ROT + 1][s] = rf[1];
+      L.sv[SV_ROT + 2][s] = rf[2];
+      L.sv[SV_TRN + 0][s] = pt[nt][0];
+      L.sv[SV_TRN + 1][s] = pt[nt][1];
+      L.sv[SV_TRN + 2][s] = pt[nt][2];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Compositing of one level (model_utils.py:95-159, 272-317; models.py:1346-1415) -> ray record.
+// ------------------------------------------------------------------------------------------------
+template <class G>
+DEVI void composite(const KArgs& ka, const RayConst& rc, int lane, int S, bool at_infinity, WaveLds& L,
+                    float* __restrict__ rec_out, float* __restrict__ smp_out) {
+  const float dnorm = sqrtf(rc.d[0] * rc.d[0] + rc.d[1] * rc.d[1] + rc.d[2] * rc.d[2]);
+  const float last = at_infinity ? 1e10f : 1e-19f;
+  float carryT = 1.0f, carryC = 0.0f;
+  int med_idx = -1;
+  float acc_v[21];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) acc_v[i] = 0.f;
+  // acc_v: 0-2 rgb, 3 depth, 4 acc, 5-7 norm, 8-10 rot, 11-13 trn, 14-16 delta_x, 17-18 hyper, 19 mask, 20 sum of all w
+  for (int j = 0; j * 64 < S; ++j) {
+    const int s = lane + 64 * j;
+    const bool valid = s < S;
+    const int sc = valid ? s : S - 1;
+    const float z = L.zs[sc];
+    const float zn = L.zs[(sc + 1 < S) ? sc + 1 : sc];
+    float dist = (sc == S - 1) ? last : (zn - z);
+    dist *= dnorm;                                                         // model_utils.py:124-128
+    const float sigma = L.sv[SV_SIGMA][sc];
+    float alpha = valid ? (1.0f - expf(-sigma * dist)) : 0.0f;             // model_utils.py:129
+    float om = valid ? ((1.0f - alpha) + 1e-10f) : 1.0f;                   // model_utils.py:133
+    float incl = wave_scan_mul(om, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.0f;
+    const float T = carryT * excl;                                         // exclusive cumprod
+    carryT *= __shfl(incl, 63, 64);
+    const float w = alpha * T;                                             // model_utils.py:135
+    if (valid) L.ws[s] = w;
+    float cum = wave_scan_add(w, lane) + carryC;
+    carryC = __shfl(cum, 63, 64);
+    unsigned long long hit = __ballot(valid && cum >= 0.5f);               // model_utils.py:285-291
+    if (med_idx < 0 && hit) med_idx = 64 * j + __builtin_ctzll(hit);
+    float xo[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xo[c] = __fadd_rn(rc.o[c], __fmul_rn(z, rc.d[c]));
+    acc_v[0] += w * L.sv[SV_RGB + 0][sc];
+    acc_v[1] += w * L.sv[SV_RGB + 1][sc];
+    acc_v[2] += w * L.sv[SV_RGB + 2][sc];
+    acc_v[3] += w * z;
+    acc_v[4] += (at_infinity && sc == S - 1) ? 0.f : w;                    // model_utils.py:147-148
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      acc_v[5 + c] += w * L.sv[SV_NORM + c][sc];
+      acc_v[8 + c] += w * L.sv[SV_ROT + c][sc];
+      acc_v[11 + c] += w * L.sv[SV_TRN + c][sc];
+      acc_v[14 + c] += w * (L.sv[SV_WP + c][sc] - xo[c]);                  // models.py:1363-1364
+    }
+    acc_v[17] += w * L.sv[SV_WP + 3][sc];
+    acc_v[18] += w * L.sv[SV_WP + 4][sc];
+    acc_v[19] += w * L.sv[SV_MASK][sc];
+    acc_v[20] += w;
+    if (smp_out != nullptr && valid) {
+      float* r = smp_out + (size_t)s * SAMPLE_REC;
+      r[0] = z; r[1] = sigma; r[2] = alpha; r[3] = T; r[4] = w; r[5] = L.sv[SV_MASK][s];
+      r[6] = L.sv[SV_RGB][s]; r[7] = L.sv[SV_RGB + 1][s]; r[8] = L.sv[SV_RGB + 2][s];
+      r[9] = L.sv[SV_NORM][s]; r[10] = L.sv[SV_NORM + 1][s]; r[11] = L.sv[SV_NORM + 2][s];
+#pragma unroll
+      for (int c = 0; c < 5; ++c) r[12 + c] = L.sv[SV_WP + c][s];
+      float bf = L.sv[SV_NORM][s] * rc.vd[0] + L.sv[SV_NORM + 1][s] * rc.vd[1] + L.sv[SV_NORM + 2][s] * rc.vd[2];
+      bf = fmaxf(bf, 0.f);
+      r[17] = bf * bf;                                                     // models.py:1341-1343
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 21; ++i) acc_v[i] = wave_sum(acc_v[i]);
+  if (rec_out == nullptr) return;
+  const int mi = med_idx < 0 ? 0 : med_idx;                                // argmax of an all-zero mask is 0
+  if (ka.white_bkgd) {                                                     // model_utils.py:144-145 (acc before :-1)
+    acc_v[0] += 1.0f - acc_v[20];
+    acc_v[1] += 1.0f - acc_v[20];
+    acc_v[2] += 1.0f - acc_v[20];
+  }
+  // Select the record element for this lane (26 lanes active).
+  float outv = 0.f;
+  if (lane < 4) outv = lane == 0 ? acc_v[0] : lane == 1 ? acc_v[1] : lane == 2 ? acc_v[2] : acc_v[3];
+  else if (lane == 4) outv = med_idx < 0 ? 0.f : L.zs[mi];                 // model_utils.py:316-317
+  else if (lane <= 20) {
+#pragma unroll
+    for (int i = 4; i < 20; ++i) if (lane == i + 1) outv = acc_v[i];
+  } else if (lane < RAY_REC) outv = L.sv[SV_WP + (lane - 21)][mi];        // models.py:1411-1415
+  if (lane < RAY_REC) rec_out[lane] = outv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Coarse -> fine: inverse-CDF resample + sorted union (model_utils.py:193-269; models.py:1522-1526).
+// On entry zs[0..nc) = coarse z, ws[0..nc) = coarse weights.  On exit zs[0..nc+nf) = sorted union.
+// ------------------------------------------------------------------------------------------------
+DEVI void resample(const KArgs& ka, int ray, int lane, int nc, int nf, WaveLds& L) {
+  const int nb = nc - 1;          // bins = mid points (nc-1 of them); cdf has nb entries, cdf[0] = 0
+  const int nw = nc - 2;          // weights[..., 1:-1]
+  // pdf / cdf
+  float tot = 0.f;
+  for (int j = 0; j * 64 < nw; ++j) {
+    int i = lane + 64 * j;
+    tot += (i < nw) ? (L.ws[i + 1] + 1e-5f) : 0.f;
+  }
+  tot = wave_sum(tot);
+  float carry = 0.f;
+  if (lane == 0) L.cdf[0] = 0.f;
+  for (int j = 0; j * 64 < nw; ++j) {
+    int i = lane + 64 * j;
+    float pdf = (i < nw) ? (L.ws[i + 1] + 1e-5f) / tot : 0.f;
+    float c = wave_scan_add(pdf, lane) + carry;
+    carry = __shfl(c, 63, 64);
+    if (i < nw) L.cdf[i + 1] = c;
+  }
+  for (int j = 0; j * 64 < nb; ++j) {
+    int i = lane + 64 * j;
+    if (i < nb) L.zn[i] = 0.5f * (L.zs[i + 1] + L.zs[i]);      // bins (models.py:1522)
+  }
+  WAVE_SYNC();
+  // inverse CDF for my fine samples
+  float zf[MAX_SAMPLES / 64];
+#pragma unroll
+  for (int j = 0; j < MAX_SAMPLES / 64; ++j) {
+    zf[j] = 0.f;
+    int k = lane + 64 * j;
+    if (k >= nf) continue;
+    float u;
+    if (ka.stratified) {
+      if (ka.u_rand != nullptr) {
+        u = ka.u_rand[(size_t)ray * nf + k];
+      } else {
+        float r4[4];
+        philox4((uint32_t)ray, 1u, (uint32_t)(k >> 2), 0u, (uint32_t)ka.seed, (uint32_t)(ka.seed >> 32), r4);
+        u = r4[k & 3];
+      }
+    } else {
+      u = (nf > 1) ? (float)k / (float)(nf - 1) : 0.f;                       // linspace(0, 1, nf)
+    }
+    // count = #(cdf[i] <= u): mask = u >= cdf (model_utils.py:223)
+    int lo = 0, hi = nb;                 // upper bound
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (L.cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    int k0 = lo - 1;
+    if (k0 < 0) k0 = 0;
+    const int k1 = (k0 + 1 < nb) ? k0 + 1 : nb - 1;
+    // minmax clamps (model_utils.py:228-229)
+    const float b0 = fminf(L.zn[k0], L.zn[nb - 2]), b1 = fmaxf(L.zn[k1], L.zn[1]);
+    const float c0 = fminf(L.cdf[k0], L.cdf[nb - 2]), c1 = fmaxf(L.cdf[k1], L.cdf[1]);
+    float denom = c1 - c0;
+    if (denom < 1e-5f) denom = 1.0f;
+    const float t = (u - c0) / denom;
+    zf[j] = b0 + t * (b1 - b0);
+  }
+  WAVE_SYNC();
+  // union into zn (unsorted), then rank-sort into zs
+  const int n = nc + nf;
+#pragma unroll
+  for (int j = 0; j < MAX_SAMPLES / 64; ++j) {
+    int k = lane + 64 * j;
+    if (k < nc) L.zn[k] = L.zs[k];
+    if (k < nf) L.zn[nc + k] = zf[j];
+  }
+  WAVE_SYNC();
+  for (int j = 0; j * 64 < n; ++j) {
+    int i = lane + 64 * j;
+    if (i < n) {
+      const float v = L.zn[i];
+      int rank = 0;
+      for (int q = 0; q < n; ++q) {
+        const float o = L.zn[q];
+        rank += (o < v || (o == v && q < i)) ? 1 : 0;
+      }
+      L.zs[rank] = v;
+    }
+  }
+  WAVE_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel: persistent waves, one ray per wave per iteration.
+// ------------------------------------------------------------------------------------------------
+template <class G, int P>
+__global__ __launch_bounds__(64, 1) void render_rays_kernel(const KArgs ka) {
+  constexpr int NT = (P == P_BF16) ? 2 : 1;
+  using Dm = Dims<G>;
+  __shared__ WaveLds L;
+  const int lane = threadIdx.x & 63;
+
+  Pipe<G, P> pipe;
+  const rsrc_t rs_nerf[2] = {make_rsrc(ka.wstream[1], Dm::NERF_FRAGS * frag_bytes(P)),
+                             make_rsrc(ka.wstream[2], Dm::NERF_FRAGS * frag_bytes(P))};
+  const rsrc_t rb_nerf[2] = {make_rsrc(ka.bias[1], Dm::NERF_BIAS_TILES * 128), make_rsrc(ka.bias[2], Dm::NERF_BIAS_TILES * 128)};
+  pipe.ws = make_rsrc(ka.wstream[0], Dm::SHARED_FRAGS * frag_bytes(P));
+  pipe.bs = make_rsrc(ka.bias[0], Dm::SHARED_BIAS_TILES * 128);
+  pipe.wn = pipe.wn_next = rs_nerf[0];
+  pipe.bn = rb_nerf[0];
+  pipe.lane16 = lane * 16;
+  // pipeline prologue: the first DEPTH fragments of the first (coarse) evaluation
+#pragma unroll
+  for (int i = 0; i < Pipe<G, P>::DEPTH; ++i) pipe.issue(i);
+  PIN_VMEM();
+  auto set_level = [&](int level, int next_level) {
+    pipe.wn = level ? rs_nerf[1] : rs_nerf[0];
+    pipe.bn = level ? rb_nerf[1] : rb_nerf[0];
+    pipe.wn_next = next_level ? rs_nerf[1] : rs_nerf[0];
+  };
+
+  for (int ray = blockIdx.x; ray < ka.num_rays; ray += gridDim.x) {
+    RayConst rc;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      rc.o[c] = ka.origins[3 * (size_t)ray + c];
+      rc.d[c] = ka.directions[3 * (size_t)ray + c];
+      rc.vd[c] = (ka.viewdirs ? ka.viewdirs : ka.directions)[3 * (size_t)ray + c];
+    }
+    rc.gt_mask = (ka.gt_mask != nullptr) ? ka.gt_mask[ray] : 0.f;
+    const uint32_t wid = (G::HAS_WARP && ka.warp_id != nullptr) ? ka.warp_id[ray] : 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      rc.wemb[i] = G::HAS_WARP ? ka.warp_embed[(size_t)wid * 8 + i] : 0.f;   // GLOEmbed (modules.py:336-348)
+      rc.memb[i] = G::HAS_MASK ? ka.mask_embed[(size_t)wid * 8 + i] : 0.f;
+    }
+#pragma unroll
+    for (int f = 0; f < 24; ++f) {                                            // posenc(viewdirs), no window
+      const int band = f / 6, sc = (f % 6) / 3, ch = f % 3;
+      rc.vdenc[f] = sin_cw(fmaf(rc.vd[ch], (float)(1 << band), sc ? 1.57079637f : 0.0f));
+    }
+
+    // ---- coarse z (model_utils.py:75-89) ----
+    const int nc = ka.nc, nf = ka.nf;
+    for (int j = 0; j * 64 < nc; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nc) {
+        auto zlin = [&](int q) {
+          const float t = (nc > 1) ? (float)q / (float)(nc - 1) : 0.f;
+          return ka.near_ * (1.0f - t) + ka.far_ * t;
+        };
+        float z = zlin(i);
+        if (ka.stratified) {
+          const float zlo = (i > 0) ? 0.5f * (z + zlin(i - 1)) : z;
+          const float zhi = (i + 1 < nc) ? 0.5f * (zlin(i + 1) + z) : z;
+          float t;
+          if (ka.t_rand != nullptr) {
+            t = ka.t_rand[(size_t)ray * nc + i];
+          } else {
+            float r4[4];
+            philox4((uint32_t)ray, 0u, (uint32_t)(i >> 2), 0u, (uint32_t)ka.seed, (uint32_t)(ka.seed >> 32), r4);
+            t = r4[i & 3];
+          }
+          z = zlo + (zhi - zlo) * t;
+        }
+        L.zs[i] = z;
+      }
+    }
+    WAVE_SYNC();
+
+    // ---- coarse level ----
+    for (int sb = 0; sb < nc; sb += 32 * NT) {
+      set_level(0, (sb + 32 * NT < nc) ? 0 : (nf > 0 ? 1 : 0));
+      eval_batch<G, P, NT>(ka, rc, pipe, lane, sb, nc, L);
+    }
+    WAVE_SYNC();
+    {
+      float* rec = (nf > 0) ? ka.ray_coarse : ka.ray_fine;
+      float* smp = (nf > 0) ? ka.smp_coarse : ka.smp_fine;
+      composite<G>(ka, rc, lane, nc, ka.sample_at_infinity != 0, L,
+                   rec ? rec + (size_t)ray * RAY_REC : nullptr,
+                   smp ? smp + (size_t)ray * nc * SAMPLE_REC : nullptr);
+    }
+    WAVE_SYNC();
+
+    // ---- fine level ----
+    if (nf > 0) {
+      resample(ka, ray, lane, nc, nf, L);
+      const int n = nc + nf;
+      for (int sb = 0; sb < n; sb += 32 * NT) {
+        set_level(1, (sb + 32 * NT < n) ? 1 : 0);
+        eval_batch<G, P, NT>(ka, rc, pipe, lane, sb, n, L);
+      }
+      WAVE_SYNC();
+      composite<G>(ka, rc, lane, n, ka.sample_at_infinity != 0, L,
+                   ka.ray_fine ? ka.ray_fine + (size_t)ray * RAY_REC : nullptr,
+                   ka.smp_fine ? ka.smp_fine + (size_t)ray * n * SAMPLE_REC : nullptr);
+      WAVE_SYNC();
+    }
+  }
+}
+
+}  // namespace nerfds
+
+// One translation unit per (graph, precision): -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_PREC=P_BF16 -DNERFDS_NAME=nerfds_bf16
+#ifndef NERFDS_GRAPH
+#error "compile with -DNERFDS_GRAPH=<GraphNerfDS|GraphStatic> -DNERFDS_PREC=<P_BF16|P_BF16X3|P_F32> -DNERFDS_NAME=<suffix>"
+#endif
+#define NERFDS_CAT2(a, b) a##b
+#define NERFDS_CAT(a, b) NERFDS_CAT2(a, b)
+
+extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::KArgs& ka, int grid, void* stream) {
+  hipLaunchKernelGGL((nerfds::render_rays_kernel<nerfds::NERFDS_GRAPH, nerfds::NERFDS_PREC>), dim3(grid), dim3(64), 0,
+                     static_cast<hipStream_t>(stream), ka);
+}

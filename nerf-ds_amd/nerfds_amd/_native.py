@@ -1,0 +1,123 @@
+"""ctypes binding of include/nerfds.h (libnerfds_hip.so, built in-tree by csrc/Makefile).
+
+There is no fallback: if the shared library is missing or fails to load, importing the product path
+raises.  (The CPU oracle under /oracle is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, '_lib', 'libnerfds_hip.so')
+
+ABI_VERSION = 1
+MAX_DEPTH = 16
+RAY_REC = 26
+SAMPLE_REC = 18
+PREC = {'bf16': 0, 'bf16x3': 1, 'f32': 2}
+
+# per-ray record slices (enum nerfds_ray_field)
+RAY_FIELDS = {
+    'rgb': (0, 3), 'depth': (3, 1), 'med_depth': (4, 1), 'acc': (5, 1), 'ray_norm': (6, 3),
+    'ray_rotation_field': (9, 3), 'ray_translation_field': (12, 3), 'ray_delta_x': (15, 3),
+    'ray_hyper_points': (18, 2), 'ray_predicted_mask': (20, 1), 'med_points': (21, 5),
+}
+SAMPLE_FIELDS = {
+    'z_vals': (0, 1), 'sigma': (1, 1), 'alpha': (2, 1), 'accum_prod': (3, 1), 'weights': (4, 1),
+    'predicted_mask': (5, 1), 'sample_rgb': (6, 3), 'predicted_norm': (9, 3), 'warped_points': (12, 5),
+    'back_facing': (17, 1),
+}
+
+
+class ModelCfg(C.Structure):
+  _fields_ = [(n, C.c_int32) for n in (
+      'abi_version', 'num_coarse_samples', 'num_fine_samples',
+      'use_warp', 'use_hyper_sheet', 'use_predicted_mask', 'predict_norm', 'use_x_in_rgb_condition',
+      'use_mask_in_warp', 'use_mask_in_hyper', 'use_viewdirs', 'mask_output_relu',
+      'nerf_trunk_depth', 'nerf_trunk_width', 'nerf_skip', 'nerf_rgb_branch_depth', 'nerf_rgb_branch_width',
+      'spatial_point_max_deg', 'hyper_point_max_deg', 'viewdir_max_deg', 'norm_input_max_deg',
+      'warp_max_deg', 'warp_trunk_depth', 'warp_trunk_width', 'warp_skip',
+      'hyper_sheet_max_deg', 'hyper_sheet_depth', 'hyper_sheet_width', 'hyper_sheet_skip', 'hyper_num_dims',
+      'mask_max_deg', 'mask_depth', 'mask_width', 'mask_skip',
+      'glo_num_dims', 'num_warp_embeds', 'use_white_background', 'use_sample_at_infinity')]
+
+
+class Dense(C.Structure):
+  _fields_ = [('kernel', C.c_void_p), ('bias', C.c_void_p), ('in_dim', C.c_int32), ('out_dim', C.c_int32)]
+
+
+class NerfMlp(C.Structure):
+  _fields_ = [('trunk', Dense * MAX_DEPTH), ('bottleneck', Dense), ('alpha', Dense),
+              ('rgb_hidden', Dense * MAX_DEPTH), ('rgb', Dense)]
+
+
+class Weights(C.Structure):
+  _fields_ = [('warp_embed', C.c_void_p), ('mask_embed', C.c_void_p),
+              ('mask_hidden', Dense * MAX_DEPTH), ('mask_out', Dense),
+              ('warp_hidden', Dense * MAX_DEPTH), ('warp_w', Dense), ('warp_v', Dense),
+              ('hyper_hidden', Dense * MAX_DEPTH), ('hyper_out', Dense),
+              ('nerf', NerfMlp * 2)]
+
+
+class Rays(C.Structure):
+  _fields_ = [('num_rays', C.c_int64), ('origins', C.c_void_p), ('directions', C.c_void_p),
+              ('viewdirs', C.c_void_p), ('warp_id', C.c_void_p), ('gt_mask', C.c_void_p)]
+
+
+class Extra(C.Structure):
+  _fields_ = [('nerf_alpha', C.c_float), ('warp_alpha', C.c_float), ('hyper_alpha', C.c_float),
+              ('hyper_sheet_alpha', C.c_float), ('norm_input_alpha', C.c_float), ('mask_ratio', C.c_float),
+              ('near', C.c_float), ('far', C.c_float), ('use_stratified_sampling', C.c_int32)]
+
+
+class Rand(C.Structure):
+  _fields_ = [('t_rand', C.c_void_p), ('u_rand', C.c_void_p), ('seed', C.c_uint64)]
+
+
+class Out(C.Structure):
+  _fields_ = [('ray_fine', C.c_void_p), ('ray_coarse', C.c_void_p),
+              ('sample_fine', C.c_void_p), ('sample_coarse', C.c_void_p)]
+
+
+# every symbol include/nerfds.h declares
+SYMBOLS = ('nerfds_abi_version', 'nerfds_ctx_create', 'nerfds_ctx_load_weights', 'nerfds_render_rays',
+           'nerfds_ctx_destroy', 'nerfds_last_error', 'nerfds_kernel_time_ms', 'nerfds_pack_stream_bytes',
+           'nerfds_pack_bias_floats', 'nerfds_pack_stream', 'nerfds_debug_mfma')
+
+_lib = None
+
+
+def load():
+  """Loads the HIP library; raises if it is not built (python __graft_entry__.py / make -C nerf-ds_amd/csrc)."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise RuntimeError(f'{LIB_PATH} is not built: run `make -C nerf-ds_amd/csrc -j8` (there is no CPU fallback)')
+  lib = C.CDLL(LIB_PATH)
+  lib.nerfds_abi_version.restype = C.c_int
+  lib.nerfds_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(ModelCfg)]
+  lib.nerfds_ctx_load_weights.argtypes = [C.c_void_p, C.POINTER(Weights)]
+  lib.nerfds_render_rays.argtypes = [C.c_void_p, C.POINTER(Rays), C.POINTER(Extra), C.POINTER(Rand), C.POINTER(Out),
+                                     C.c_uint32, C.c_void_p]
+  lib.nerfds_ctx_destroy.argtypes = [C.c_void_p]
+  lib.nerfds_last_error.argtypes = [C.c_void_p]
+  lib.nerfds_last_error.restype = C.c_char_p
+  lib.nerfds_kernel_time_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+  lib.nerfds_pack_stream_bytes.argtypes = [C.POINTER(ModelCfg), C.c_int, C.c_uint32]
+  lib.nerfds_pack_stream_bytes.restype = C.c_int64
+  lib.nerfds_pack_bias_floats.argtypes = [C.POINTER(ModelCfg), C.c_int]
+  lib.nerfds_pack_bias_floats.restype = C.c_int64
+  lib.nerfds_pack_stream.argtypes = [C.POINTER(ModelCfg), C.POINTER(Weights), C.c_int, C.c_int, C.c_uint32,
+                                     C.c_void_p, C.c_void_p]
+  lib.nerfds_debug_mfma.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+  if lib.nerfds_abi_version() != ABI_VERSION:
+    raise RuntimeError('libnerfds_hip.so ABI version mismatch: rebuild')
+  _lib = lib
+  return lib
+
+
+def last_error(ctx=None) -> str:
+  msg = load().nerfds_last_error(ctx)
+  return msg.decode() if msg else ''

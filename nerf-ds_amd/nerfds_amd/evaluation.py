@@ -1,0 +1,174 @@
+"""Chunked, ray-sharded frame rendering: the drop-in for hypernerf/evaluation.py:53-149 (``render_image``)
+and for the pmapped ``_model_fn`` of render.py:139-163.
+
+Reference scheme: one host process, ``jax.pmap`` over D local devices, rays of a chunk reshaped to
+``[D, R_c / D, ...]`` (utils.shard, utils.py:295-299), an in-pmap ``all_gather`` of the WHOLE two-level output
+dict (render.py:155), device->host copy of the fine level, ``unshard`` + drop padding (utils.py:307-312).
+
+Here: one process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI), each rank renders its
+contiguous block of the chunk with the fused HIP kernel, and the only exchange is ONE all-gather of the
+``[R_c / D, 26]`` per-ray record tensor (104 B/ray) of the returned level - the path has no other collective.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+from typing import Any, Callable, Dict, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _native as N
+
+
+@dataclass
+class TrainState:
+  """model_utils.TrainState (model_utils.py:28-52) reduced to what the render path reads."""
+  optimizer: Any = None
+  nerf_alpha: Optional[float] = None
+  warp_alpha: Optional[float] = None
+  hyper_alpha: Optional[float] = None
+  hyper_sheet_alpha: Optional[float] = None
+  norm_loss_weight: Optional[float] = None
+  norm_input_alpha: Optional[float] = None
+
+  @property
+  def extra_params(self):
+    return {'nerf_alpha': self.nerf_alpha, 'warp_alpha': self.warp_alpha, 'hyper_alpha': self.hyper_alpha,
+            'hyper_sheet_alpha': self.hyper_sheet_alpha, 'norm_loss_weight': self.norm_loss_weight,
+            'norm_input_alpha': self.norm_input_alpha}
+
+  @classmethod
+  def create(cls, params, **alphas):
+    return cls(optimizer=SimpleNamespace(target={'model': params}), **alphas)
+
+
+def _world():
+  if dist.is_available() and dist.is_initialized():
+    return dist.get_rank(), dist.get_world_size()
+  return 0, 1
+
+
+def shard_bounds(num_chunk_rays: int, device_count: int, proc_id: int):
+  """Padding (edge replication, evaluation.py:99-107) and this rank's [lo, hi) block of the padded chunk."""
+  remainder = num_chunk_rays % device_count
+  padding = (device_count - remainder) if remainder else 0
+  per = (num_chunk_rays + padding) // device_count
+  return padding, proc_id * per, (proc_id + 1) * per
+
+
+def pad_edge(x: torch.Tensor, padding: int) -> torch.Tensor:
+  """jnp.pad(x, ((0, padding), (0, 0)), mode='edge') (evaluation.py:103-105)."""
+  if padding == 0:
+    return x
+  return torch.cat([x, x[-1:].expand(padding, *x.shape[1:])], dim=0)
+
+
+def tree_map(fn, tree):
+  if isinstance(tree, dict):
+    return {k: tree_map(fn, v) for k, v in tree.items()}
+  return fn(tree)
+
+
+def all_gather_records(rec: torch.Tensor) -> torch.Tensor:
+  """[R_local, 26] on every rank -> [D * R_local, 26] on every rank (render.py:155 ``all_gather``), one collective."""
+  rank, world = _world()
+  if world == 1:
+    return rec
+  out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+  dist.all_gather_into_tensor(out, rec.contiguous())
+  return out
+
+
+def records_to_dict(rec: torch.Tensor, cfg) -> Dict[str, torch.Tensor]:
+  """Splits a [R, 26] record tensor into the reference's per-ray keys (models.py:1312-1415)."""
+  o = {}
+  for k, (a, n) in N.RAY_FIELDS.items():
+    v = rec[:, a:a + n]
+    o[k] = v[:, 0] if k in ('depth', 'med_depth', 'acc') else v
+  o['med_points'] = o['med_points'][:, None, :3 + cfg.num_hyper_dims]
+  o['ray_hyper_points'] = o['ray_hyper_points'][:, :cfg.num_hyper_dims]
+  o['ray_hyper_c'] = torch.zeros_like(o['ray_hyper_points'])
+  if not cfg.use_warp:
+    del o['ray_rotation_field'], o['ray_translation_field']
+  if not cfg.use_predicted_mask:
+    del o['ray_predicted_mask']
+  if not cfg.predict_norm:
+    del o['ray_norm']
+  return o
+
+
+def make_model_fn(model, use_predicted_norm: Optional[bool] = None, sharp_weights_std: float = 0.1,
+                  precision: Optional[str] = None, render_fn: Optional[Callable] = None) -> Callable:
+  """The ``_model_fn`` of render.py:139-155: render the local shard, all-gather the per-ray records.
+
+  ``render_fn(params, rays, extra_params, key) -> (rec_fine [R,26], rec_coarse or None)`` may be injected
+  (the gloo CPU tests use a deterministic stand-in so the sharding/gather logic runs without a GPU).
+  """
+  cfg = model.cfg if model is not None else None
+  upn = (cfg.predict_norm if use_predicted_norm is None else use_predicted_norm) if cfg is not None else False
+
+  def _default_render(params, rays_dict, extra_params, keys):
+    model.apply({'params': params}, rays_dict, extra_params, rngs={'coarse': keys[0], 'fine': keys[1]},
+                use_predicted_norm=upn, return_points=False, return_nv_details=False, mask_ratio=1,
+                sharp_weights_std=sharp_weights_std, precision=precision)
+    return model.last_records['fine'], model.last_records['coarse']
+
+  render = render_fn or _default_render
+
+  def model_fn(key_0, key_1, key_2, params, rays_dict, extra_params):
+    rec_fine, rec_coarse = render(params, rays_dict, extra_params, (key_0, key_1, key_2))
+    out = {}
+    if rec_coarse is not None:
+      out['coarse'] = rec_coarse     # kept local: the reference gathers it too but evaluation.py:121-126 drops it
+      out['fine'] = all_gather_records(rec_fine)
+    else:
+      out['coarse'] = all_gather_records(rec_fine)
+    return out
+
+  return model_fn
+
+
+def render_image(state, rays_dict, model_fn, device_count, rng, chunk=8192, default_ret_key=None, cfg=None,
+                 to_host: bool = True):
+  """evaluation.render_image (evaluation.py:53-149).
+
+  ``rays_dict`` leaves have leading shape [H, W]; returns a dict of [H, W, ...] maps of the fine level
+  (coarse when there is no fine level).  ``device_count`` is the number of ranks the chunk is sharded over
+  and must equal the torch.distributed world size (1 without a process group).
+  """
+  rank, world = _world()
+  if device_count != world:
+    raise ValueError(f'device_count={device_count} but the process group has {world} ranks')
+  as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))
+  rays_dict = tree_map(as_t, rays_dict)
+  batch_shape = tuple(rays_dict['origins'].shape[:-1])
+  num_rays = int(np.prod(batch_shape))
+  rays_dict = tree_map(lambda x: x.reshape(num_rays, -1), rays_dict)
+  seed = int(np.asarray(rng).ravel()[-1]) if rng is not None else 0
+  key_0, key_1, key_2 = (seed * 4 + 1) * world + rank, (seed * 4 + 2) * world + rank, (seed * 4 + 3) * world + rank
+  params = state.optimizer.target['model']
+  ret_chunks = []
+  num_batches = int(math.ceil(num_rays / chunk))
+  for batch_idx in range(num_batches):
+    ray_idx = batch_idx * chunk
+    chunk_rays = tree_map(lambda x: x[ray_idx:ray_idx + chunk], rays_dict)
+    num_chunk_rays = chunk_rays['origins'].shape[0]
+    padding, lo, hi = shard_bounds(num_chunk_rays, device_count, rank)
+    chunk_rays = tree_map(lambda x: pad_edge(x, padding)[lo:hi], chunk_rays)         # evaluation.py:99-118
+    model_out = model_fn(key_0, key_1, key_2, params, chunk_rays, state.extra_params)   # evaluation.py:119
+    ret_key = default_ret_key or ('fine' if 'fine' in model_out else 'coarse')          # evaluation.py:121-124
+    rec = model_out[ret_key]
+    if padding:
+      rec = rec[:-padding]                                                               # utils.unshard (utils.py:307-312)
+    ret_chunks.append(rec.cpu() if to_host else rec)                                     # evaluation.py:126
+  rec = torch.cat(ret_chunks, dim=0)
+  if cfg is None:
+    return {'records': rec.reshape(*batch_shape, rec.shape[-1])}
+  out = records_to_dict(rec, cfg)
+  return {k: v.reshape(*batch_shape, *v.shape[1:]) for k, v in out.items()}             # evaluation.py:143-147
+
+
+render_image_on_rays = render_image   # the name BASELINE.json's north_star uses for the same surface

@@ -1,0 +1,319 @@
+"""Host-side mirror of the reference's model surface, backed by the fused HIP ray kernel.
+
+``NerfModel.apply`` keeps the call shape of ``model.apply({'params': params}, rays_dict, extra_params=...,
+rngs=..., use_predicted_norm=..., return_points=..., mask_ratio=..., sharp_weights_std=...)`` as used by the
+reference's render.py:140-154 / training.py:441-455 on ``NerfModel.__call__`` (hypernerf/models.py:1419-1565),
+and returns the same ``{'coarse': {...}, 'fine': {...}}`` dictionary of per-ray maps.  ``construct_nerf``
+mirrors hypernerf/models.py:2677-2741.
+
+Deviations, all deliberate (DESIGN.md "Out of scope"):
+  * per-sample tensors (sigma, alpha, weights, ...) are produced only when asked for
+    (``return_weights`` / ``return_points`` / ``return_samples``): the reference always returns ~15
+    per-sample arrays that render.py then throws away (render.py:192-193);
+  * ``target_norm`` (needs d sigma / d x, models.py:1065-1077) is not produced by the HIP path yet;
+  * sampling randomness: JAX threefry streams cannot be reproduced, so either inject ``t_rand`` / ``u_rand``
+    or an on-chip Philox4x32 stream keyed by the integer seed derived from ``rngs`` is used.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .config import NerfModelConfig
+from .params import init_params, levels, mlp_layer_dims
+
+
+def _cfg_struct(cfg: NerfModelConfig) -> N.ModelCfg:
+  def skip(s):
+    return int(s[0]) if len(s) == 1 else -1
+  c = N.ModelCfg()
+  c.abi_version = N.ABI_VERSION
+  c.num_coarse_samples, c.num_fine_samples = cfg.num_coarse_samples, cfg.num_fine_samples
+  c.use_warp = int(cfg.use_warp)
+  c.use_hyper_sheet = int(cfg.has_hyper and cfg.use_hyper)
+  c.use_predicted_mask = int(cfg.use_predicted_mask)
+  c.predict_norm = int(cfg.predict_norm)
+  c.use_x_in_rgb_condition = int(cfg.use_x_in_rgb_condition)
+  c.use_mask_in_warp, c.use_mask_in_hyper = int(cfg.use_mask_in_warp), int(cfg.use_mask_in_hyper)
+  c.use_viewdirs, c.mask_output_relu = int(cfg.use_viewdirs), int(cfg.mask_output_relu)
+  c.nerf_trunk_depth, c.nerf_trunk_width, c.nerf_skip = cfg.nerf_trunk_depth, cfg.nerf_trunk_width, skip(cfg.nerf_skips)
+  c.nerf_rgb_branch_depth, c.nerf_rgb_branch_width = cfg.nerf_rgb_branch_depth, cfg.nerf_rgb_branch_width
+  c.spatial_point_max_deg, c.hyper_point_max_deg = cfg.spatial_point_max_deg, cfg.hyper_point_max_deg
+  c.viewdir_max_deg, c.norm_input_max_deg = cfg.viewdir_max_deg, cfg.norm_input_max_deg
+  c.warp_max_deg, c.warp_trunk_depth = cfg.warp_max_deg, cfg.warp_trunk.depth
+  c.warp_trunk_width, c.warp_skip = cfg.warp_trunk.width, skip(cfg.warp_trunk.skips)
+  c.hyper_sheet_max_deg, c.hyper_sheet_depth = cfg.hyper_sheet_max_deg, cfg.hyper_sheet_mlp.depth
+  c.hyper_sheet_width, c.hyper_sheet_skip = cfg.hyper_sheet_mlp.width, skip(cfg.hyper_sheet_mlp.skips)
+  c.hyper_num_dims = cfg.hyper_sheet_output_channels
+  c.mask_max_deg, c.mask_depth = cfg.mask_max_deg, cfg.mask_mlp.depth
+  c.mask_width, c.mask_skip = cfg.mask_mlp.width, skip(cfg.mask_mlp.skips)
+  c.glo_num_dims, c.num_warp_embeds = cfg.glo_num_dims, cfg.num_warp_embeds
+  c.use_white_background, c.use_sample_at_infinity = int(cfg.use_white_background), int(cfg.use_sample_at_infinity)
+  for name in ('spatial_point_min_deg', 'hyper_point_min_deg', 'viewdir_min_deg', 'norm_input_min_deg',
+               'warp_min_deg', 'hyper_sheet_min_deg', 'mask_min_deg'):
+    if getattr(cfg, name) != 0:
+      raise NotImplementedError(f'{name} != 0 is not configured by any shipped gin file')
+  if cfg.use_posenc_identity or cfg.warp_use_posenc_identity:
+    raise NotImplementedError('use_posenc_identity=True (configs/base.gin graph) has no HIP kernel yet')
+  return c
+
+
+class _WeightsHolder:
+  """Builds the nerfds_weights view over a Flax-style numpy tree and keeps the arrays alive."""
+
+  def __init__(self, cfg: NerfModelConfig, params: Dict[str, Any]):
+    self.keep = []
+    self.struct = N.Weights()
+    w = self.struct
+
+    def arr(a):
+      a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+      self.keep.append(a)
+      return a
+
+    def dense(dst, p):
+      k, b = arr(p['kernel']), arr(p['bias'])
+      dst.kernel, dst.bias = k.ctypes.data, b.ctypes.data
+      dst.in_dim, dst.out_dim = k.shape
+
+    def mlp(dst_hidden, tree, depth):
+      for i in range(depth):
+        dense(dst_hidden[i], tree[f'hidden_{i}'])
+
+    if cfg.use_warp:
+      w.warp_embed = arr(params['warp_embed']['embed']['embedding']).ctypes.data
+      mlp(w.warp_hidden, params['warp_field']['trunk'], cfg.warp_trunk.depth)
+      dense(w.warp_w, params['warp_field']['branches_w']['logit'])
+      dense(w.warp_v, params['warp_field']['branches_v']['logit'])
+    if cfg.use_predicted_mask:
+      w.mask_embed = arr(params['mask_embed']['embed']['embedding']).ctypes.data
+      mlp(w.mask_hidden, params['mask_mlp']['MLP_0'], cfg.mask_mlp.depth)
+      dense(w.mask_out, params['mask_mlp']['MLP_0']['logit'])
+    if cfg.has_hyper:
+      mlp(w.hyper_hidden, params['hyper_sheet_mlp']['MLP_0'], cfg.hyper_sheet_mlp.depth)
+      dense(w.hyper_out, params['hyper_sheet_mlp']['MLP_0']['logit'])
+    for li, level in enumerate(levels(cfg)):
+      t = params[f'nerf_mlps_{level}']
+      mlp(w.nerf[li].trunk, t['trunk_mlp'], cfg.nerf_trunk_depth)
+      dense(w.nerf[li].bottleneck, t['bottleneck'])
+      dense(w.nerf[li].alpha, t['alpha_mlp']['logit'])
+      mlp(w.nerf[li].rgb_hidden, t['rgb_mlp'], cfg.nerf_rgb_branch_depth)
+      dense(w.nerf[li].rgb, t['rgb_mlp']['logit'])
+
+
+def _seed_from_rngs(rngs) -> int:
+  if rngs is None:
+    return 0
+  if isinstance(rngs, dict):
+    vals = [rngs.get(k) for k in ('coarse', 'fine')]
+  else:
+    vals = [rngs]
+  seed = 0
+  for v in vals:
+    if v is None:
+      continue
+    a = np.asarray(v.cpu() if isinstance(v, torch.Tensor) else v).astype(np.uint64).ravel()
+    for x in a:
+      seed = (seed * 0x9E3779B97F4A7C15 + int(x) + 1) & 0xFFFFFFFFFFFFFFFF
+  return seed
+
+
+class NerfModel:
+  """Drop-in for the reference's ``NerfModel`` on one MI355X: functional ``apply``, parameters passed in."""
+
+  def __init__(self, cfg: NerfModelConfig, device: Optional[torch.device] = None, precision: str = 'bf16'):
+    cfg.validate()
+    self.cfg = cfg
+    self.precision = precision
+    self._lib = N.load()                      # raises if the HIP library is not built: no fallback
+    if not torch.cuda.is_available():
+      raise RuntimeError('NerfModel needs an MI355X (torch.cuda is not available); there is no CPU path')
+    self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    self._cstruct = _cfg_struct(cfg)
+    ctx = C.c_void_p()
+    rc = self._lib.nerfds_ctx_create(C.byref(ctx), self.device.index or 0, C.byref(self._cstruct))
+    if rc != 0:
+      msg = N.last_error(None)
+      if rc == -95:
+        raise NotImplementedError(msg)
+      raise RuntimeError(f'nerfds_ctx_create failed ({rc}): {msg}')
+    self._ctx = ctx
+    self._params_id = None
+    self._holder = None
+
+  def __del__(self):
+    ctx = getattr(self, '_ctx', None)
+    if ctx:
+      self._lib.nerfds_ctx_destroy(ctx)
+      self._ctx = None
+
+  # -- parameters ---------------------------------------------------------------------------------------
+  def init(self, seed: int = 0, **kw) -> Dict[str, Any]:
+    """``model.init`` of construct_nerf (models.py:2707-2739): a fresh Flax-named parameter tree."""
+    return init_params(self.cfg, seed, **kw)
+
+  def load_params(self, params: Dict[str, Any]) -> None:
+    """Packs ``params`` (the 'model' sub-tree of the checkpoint) into the MFMA weight streams."""
+    holder = _WeightsHolder(self.cfg, params)
+    rc = self._lib.nerfds_ctx_load_weights(self._ctx, C.byref(holder.struct))
+    if rc != 0:
+      raise ValueError(f'nerfds_ctx_load_weights failed ({rc}): {N.last_error(self._ctx)}')
+    self._holder = holder
+    self._params_id = id(params)
+
+  # -- NerfModel.__call__ -------------------------------------------------------------------------------
+  def apply(self, variables: Dict[str, Any], rays_dict: Dict[str, Any], extra_params: Dict[str, Any], *,
+            rngs=None, mutable=False, metadata_encoded=False, use_warp=True, return_points=False,
+            return_weights=False, return_samples=False, return_nv_details=True, near=None, far=None,
+            use_sample_at_infinity=None, render_opts=None, use_sigma_gradient=False, use_predicted_norm=False,
+            mask_ratio=1, sharp_weights_std=1.0, t_rand=None, u_rand=None, precision: Optional[str] = None,
+            stream: Optional[torch.cuda.Stream] = None):
+    cfg = self.cfg
+    params = variables['params'] if 'params' in variables else variables
+    if id(params) != self._params_id:
+      self.load_params(params)
+    if metadata_encoded:
+      raise NotImplementedError('metadata_encoded=True (pre-encoded GLO vectors) is not built')
+    if render_opts is not None:
+      raise NotImplementedError('render_opts (dust_threshold / bounding_box, models.py:38-66) is not built')
+    if use_sigma_gradient:
+      raise NotImplementedError('use_sigma_gradient=True needs d sigma/dx, which the HIP path does not compute yet')
+    if bool(use_predicted_norm) != bool(cfg.predict_norm):
+      raise ValueError('use_predicted_norm must equal NerfModel.predict_norm: the rgb branch width depends on it '
+                       '(models.py:2707-2739 initialises the parameters with the same flag)')
+    if use_sample_at_infinity is not None and bool(use_sample_at_infinity) != bool(cfg.use_sample_at_infinity):
+      raise NotImplementedError('per-call use_sample_at_infinity override')
+    if not use_warp and cfg.use_warp:
+      raise NotImplementedError('use_warp=False on a warp model raises in the reference too (SURVEY.md 8a quirk 2)')
+
+    dev = self.device
+    f32 = lambda a: torch.as_tensor(np.asarray(a) if not isinstance(a, torch.Tensor) else a).to(dev, torch.float32).contiguous()
+    origins, directions = f32(rays_dict['origins']), f32(rays_dict['directions'])
+    batch_shape = origins.shape[:-1]
+    origins, directions = origins.reshape(-1, 3), directions.reshape(-1, 3)
+    R = origins.shape[0]
+    viewdirs = f32(rays_dict['viewdirs']).reshape(-1, 3) if 'viewdirs' in rays_dict else None
+    warp_id = None
+    if cfg.use_warp:
+      ids = rays_dict['metadata']['warp']
+      ids = ids if isinstance(ids, torch.Tensor) else torch.as_tensor(np.asarray(ids).astype(np.int64))
+      if ids.numel() and (int(ids.max()) >= cfg.num_warp_embeds or int(ids.min()) < 0):
+        raise IndexError('metadata["warp"] id out of range of the GLO table')
+      warp_id = ids.to(dev).reshape(-1).to(torch.int32).contiguous()   # uint32 bit pattern for ids < 2^31
+    gt_mask = None
+    if rays_dict.get('mask') is not None:
+      gt_mask = f32(rays_dict['mask']).reshape(-1)
+    want_samples = bool(return_samples or return_weights or return_points)
+    nc, nf = cfg.num_coarse_samples, cfg.num_fine_samples
+    two = nf > 0
+    rec_fine = torch.empty((R, N.RAY_REC), device=dev, dtype=torch.float32)
+    rec_coarse = torch.empty((R, N.RAY_REC), device=dev, dtype=torch.float32) if two else None
+    smp_fine = torch.empty((R, nc + nf, N.SAMPLE_REC), device=dev, dtype=torch.float32) if want_samples else None
+    smp_coarse = torch.empty((R, nc, N.SAMPLE_REC), device=dev, dtype=torch.float32) if (want_samples and two) else None
+    if t_rand is not None:
+      t_rand = f32(t_rand).reshape(R, nc)
+    if u_rand is not None:
+      u_rand = f32(u_rand).reshape(R, max(nf, 1))
+
+    ptr = lambda t: (t.data_ptr() if t is not None else None)
+    rays = N.Rays(R, ptr(origins), ptr(directions), ptr(viewdirs), ptr(warp_id), ptr(gt_mask))
+    g = lambda k, d=0.0: float(extra_params[k]) if extra_params.get(k) is not None else d
+    extra = N.Extra(g('nerf_alpha'), g('warp_alpha'), g('hyper_alpha'), g('hyper_sheet_alpha'), g('norm_input_alpha'),
+                    float(mask_ratio), float(cfg.near if near is None else near), float(cfg.far if far is None else far),
+                    int(cfg.use_stratified_sampling))
+    rnd = N.Rand(ptr(t_rand), ptr(u_rand), _seed_from_rngs(rngs))
+    out = N.Out(ptr(rec_fine), ptr(rec_coarse), ptr(smp_fine), ptr(smp_coarse))
+    flags = N.PREC[precision or self.precision]
+    s = stream if stream is not None else torch.cuda.current_stream(dev)
+    rc = self._lib.nerfds_render_rays(self._ctx, C.byref(rays), C.byref(extra), C.byref(rnd), C.byref(out), flags,
+                                      C.c_void_p(s.cuda_stream))
+    if rc != 0:
+      raise RuntimeError(f'nerfds_render_rays failed ({rc}): {N.last_error(self._ctx)}')
+
+    ret = {}
+    level_recs = [('coarse', rec_coarse, smp_coarse, nc), ('fine', rec_fine, smp_fine, nc + nf)] if two else \
+                 [('coarse', rec_fine, smp_fine, nc)]
+    for level, rec, smp, S in level_recs:
+      ret[level] = self._unpack(rec, smp, S, batch_shape, origins, directions, return_points, return_weights,
+                                sharp_weights_std)
+    self.last_records = {'fine': rec_fine, 'coarse': rec_coarse}
+    return ret
+
+  __call__ = apply
+
+  def _unpack(self, rec, smp, S, batch_shape, origins, directions, return_points, return_weights, sharp_std):
+    cfg = self.cfg
+    o = {}
+    for k, (a, n) in N.RAY_FIELDS.items():
+      v = rec[:, a:a + n]
+      o[k] = v[:, 0] if k in ('depth', 'med_depth', 'acc') else v
+    o['med_points'] = o['med_points'][:, None, :3 + cfg.num_hyper_dims]
+    o['ray_hyper_points'] = o['ray_hyper_points'][:, :cfg.num_hyper_dims]
+    o['ray_hyper_c'] = torch.zeros_like(o['ray_hyper_points'])          # models.py:1384
+    if not cfg.use_warp:                                                # models.py:1303-1305
+      del o['ray_rotation_field'], o['ray_translation_field']
+    if not cfg.use_predicted_mask:
+      del o['ray_predicted_mask']
+    if not cfg.predict_norm:
+      del o['ray_norm']           # reference: sum w * normalize(-d sigma/dx) (models.py:1353); needs the sigma gradient
+    if smp is not None:
+      for k, (a, n) in N.SAMPLE_FIELDS.items():
+        v = smp[:, :, a:a + n]
+        o[k] = v if k in ('predicted_mask', 'sample_rgb', 'predicted_norm', 'warped_points') else v[:, :, 0]
+      o['warped_points'] = o['warped_points'][..., :3 + cfg.num_hyper_dims]
+      o['points'] = origins[:, None, :] + o['z_vals'][..., None] * directions[:, None, :]
+      o['delta_x'] = o['warped_points'][..., :3] - o['points']          # models.py:1363
+      if cfg.use_mask_sharp_weights:
+        o['sharp_weights'] = sharpen_weights(o['weights'], o['z_vals'], sharp_std)
+      if not cfg.use_predicted_mask:
+        del o['predicted_mask']
+      if not cfg.predict_norm:
+        del o['predicted_norm'], o['back_facing']
+      if not return_weights:
+        pass                      # kept: the caller asked for per-sample data explicitly
+      if not return_points:
+        pass
+    return {k: v.reshape(*batch_shape, *v.shape[1:]) for k, v in o.items()}
+
+  # timing hooks for bench.py -------------------------------------------------------------------------
+  def kernel_time_ms(self, reset: bool = False):
+    tot = C.c_double(0.0)
+    n = self._lib.nerfds_kernel_time_ms(self._ctx, int(reset), C.byref(tot))
+    return n, tot.value
+
+
+def sharpen_weights(weights: torch.Tensor, z_vals: torch.Tensor, std: float) -> torch.Tensor:
+  """model_utils.py:180-190 on device, including the row-gather quirk of line 182."""
+  idx = torch.argmax(weights, dim=1).clamp(max=z_vals.shape[0] - 1)
+  mu = z_vals[idx]
+  g = torch.exp(-0.5 * ((z_vals - mu) / std) ** 2) / (std * 2.5066282746310002)
+  sw = weights * g
+  return sw / sw.sum(dim=1, keepdim=True)
+
+
+def construct_nerf(key, batch_size: int = 0, embeddings_dict=None, near: float = 0.0, far: float = 1.0,
+                   cfg: Optional[NerfModelConfig] = None, use_predicted_norm: Optional[bool] = None,
+                   use_sigma_gradient: bool = False, device=None, precision: str = 'bf16', **init_kw):
+  """models.construct_nerf (models.py:2677-2741): returns ``(model, params)``.
+
+  ``key`` is an integer seed (JAX PRNG keys have no meaning here); ``embeddings_dict`` as in the reference
+  ({'warp': [ids], ...}) sizes the GLO tables (models.py:235-237).
+  """
+  from .config import nerf_ds_config
+  if cfg is None:
+    cfg = nerf_ds_config(near=near, far=far)
+  else:
+    cfg = cfg.replace(near=near, far=far) if (near, far) != (0.0, 1.0) else cfg
+  if embeddings_dict is not None and cfg.use_warp:
+    cfg = cfg.replace(num_warp_embeds=int(max(embeddings_dict['warp'])) + 1)
+  if use_predicted_norm is not None and bool(use_predicted_norm) != cfg.predict_norm:
+    raise ValueError('use_predicted_norm must equal NerfModel.predict_norm')
+  if use_sigma_gradient:
+    raise NotImplementedError('use_sigma_gradient=True is not built')
+  model = NerfModel(cfg, device=device, precision=precision)
+  params = model.init(int(key) if not hasattr(key, '__len__') else int(np.asarray(key).ravel()[-1]), **init_kw)
+  return model, params

@@ -1,0 +1,227 @@
+"""GPU parity tests: the fused HIP ray kernel, called through the C ABI (libnerfds_hip.so), against the CPU oracle
+on identical rays, weights and injected sampling uniforms.
+
+Tolerance (BASELINE.json north_star): composited RGB within 1e-4 relative of the reference semantics.  The
+fp32-MFMA kernel (exact fp32 fma chains) and the split-bf16 kernel are held to that bar; the plain-bf16 MFMA
+kernel's measured error is reported and bounded loosely (it cannot meet 1e-4 - see DESIGN.md "Precision").
+"""
+import ctypes as C
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from nerfds_amd import nerf_ds_config, static_config, init_params
+from oracle import nerfds_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+EXTRA = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
+RTOL = {'f32': 1e-4, 'bf16x3': 1e-4, 'bf16': 6e-2}
+
+
+def _rays(R, n_ids, seed, spread=0.1):
+  rng = np.random.default_rng(seed)
+  d = rng.normal(size=(R, 3))
+  d /= np.linalg.norm(d, axis=-1, keepdims=True)
+  return dict(origins=rng.normal(size=(R, 3)) * spread, directions=d, viewdirs=d,
+              metadata={'warp': rng.integers(0, n_ids, (R, 1))},
+              mask=(rng.random((R, 1)) < 0.3).astype(np.float32)), rng
+
+
+def _relerr(a, b):
+  return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-6))
+
+
+def _model(cfg):
+  from nerfds_amd.model import NerfModel
+  return NerfModel(cfg, device=torch.device('cuda', 0))
+
+
+def test_extension_is_loaded_and_mfma_layout():
+  """The accumulator / operand maps the kernel relies on, checked with an asymmetric product."""
+  from nerfds_amd import _native as N
+  lib = N.load()
+  rng = np.random.default_rng(0)
+  a = rng.integers(-4, 5, (32, 16)).astype(np.float32)      # exactly representable in bf16
+  b = rng.integers(-4, 5, (16, 32)).astype(np.float32)
+  cb, cf = np.zeros((32, 32), np.float32), np.zeros((32, 32), np.float32)
+  rc = lib.nerfds_debug_mfma(0, a.ctypes.data, b.ctypes.data, cb.ctypes.data, cf.ctypes.data)
+  assert rc == 0
+  assert np.array_equal(cb, a @ b) and np.array_equal(cf, a @ b)
+  assert any('libnerfds_hip' in l for l in open('/proc/self/maps'))
+
+
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16'])
+def test_nerf_ds_graph_tiny(prec):
+  cfg = nerf_ds_config(num_warp_embeds=4, num_coarse_samples=8, num_fine_samples=8)
+  params = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  R = 12
+  rays, rng = _rays(R, 4, 1)
+  t, u = rng.random((R, 8)), rng.random((R, 8))
+  ref = O.NerfModel(cfg, params).apply(rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, sharp_weights_std=0.1,
+                                       return_weights=True, return_points=True, compute_sigma_gradient=False)
+  out = _model(cfg).apply({'params': params}, rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True,
+                          sharp_weights_std=0.1, return_samples=True, precision=prec)
+  tol = RTOL[prec]
+  for level in ('coarse', 'fine'):
+    r, g = ref[level], {k: v.cpu().numpy() for k, v in out[level].items()}
+    assert np.allclose(g['z_vals'], r['z_vals'].numpy(), rtol=2e-6, atol=1e-6), level
+    for k in ('sigma', 'predicted_mask', 'warped_points', 'predicted_norm', 'sample_rgb', 'weights', 'alpha',
+              'accum_prod', 'back_facing', 'delta_x', 'sharp_weights'):
+      e = _relerr(g[k], r[k].numpy())
+      print(f'{prec} {level} per-sample {k}: {e:.2e}', file=sys.stderr)
+      assert e < 20 * tol, (level, k, e)
+    for k in ('rgb', 'depth', 'med_depth', 'acc', 'ray_norm', 'ray_rotation_field', 'ray_translation_field',
+              'ray_delta_x', 'ray_hyper_points', 'ray_predicted_mask', 'med_points', 'ray_hyper_c'):
+      e = _relerr(g[k], r[k].numpy())
+      print(f'{prec} {level} {k}: {e:.2e}', file=sys.stderr)
+      lim = tol if k == 'rgb' else 10 * tol
+      if k in ('med_depth', 'med_points') and prec == 'bf16':
+        continue          # index of the median sample may flip under bf16 noise
+      assert e <= lim, (level, k, e)
+
+
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16'])
+def test_nerf_ds_graph_full_samples_init_regime(prec):
+  """64 + 64 samples (nerf_ds.gin), freshly initialised weights: theta ~ 1e-4 stresses exp_se3 (quirk 5)."""
+  cfg = nerf_ds_config(num_warp_embeds=8)
+  params = init_params(cfg, 1)
+  R = 70                         # not a multiple of anything
+  rays, rng = _rays(R, 8, 2, spread=0.3)
+  t, u = rng.random((R, 64)), rng.random((R, 64))
+  ref = O.NerfModel(cfg, params).apply(rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, compute_sigma_gradient=False)
+  out = _model(cfg).apply({'params': params}, rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, precision=prec)
+  for level in ('coarse', 'fine'):
+    e = _relerr(out[level]['rgb'].cpu().numpy(), ref[level]['rgb'].numpy())
+    print(f'{prec} {level} rgb: {e:.2e}', file=sys.stderr)
+    assert e <= RTOL[prec], (level, e)
+    assert torch.isfinite(out[level]['ray_delta_x']).all()
+
+
+def test_nerf_ds_trained_regime_and_deterministic_sampling():
+  cfg = nerf_ds_config(num_warp_embeds=3, use_stratified_sampling=False)
+  params = init_params(cfg, 2, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.2)
+  R = 33
+  rays, _ = _rays(R, 3, 3)
+  ref = O.NerfModel(cfg, params).apply(rays, EXTRA, use_predicted_norm=True, compute_sigma_gradient=False)
+  m = _model(cfg)
+  for prec in ('f32', 'bf16x3'):
+    out = m.apply({'params': params}, rays, EXTRA, use_predicted_norm=True, precision=prec)
+    for level in ('coarse', 'fine'):
+      for k in ('rgb', 'depth', 'acc', 'ray_predicted_mask', 'ray_delta_x'):
+        e = _relerr(out[level][k].cpu().numpy(), ref[level][k].numpy())
+        assert e <= (1e-4 if k == 'rgb' else 1e-3), (prec, level, k, e)
+
+
+def test_windows_partially_open():
+  """warp_alpha / nerf_alpha mid-schedule: fractional Hann windows on the top bands (model_utils.py:420-436)."""
+  cfg = nerf_ds_config(num_warp_embeds=2, num_coarse_samples=16, num_fine_samples=16)
+  params = init_params(cfg, 4, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  extra = dict(nerf_alpha=5.3, warp_alpha=2.6, hyper_alpha=0.4, hyper_sheet_alpha=3.7, norm_input_alpha=1.5)
+  R = 9
+  rays, rng = _rays(R, 2, 5)
+  t, u = rng.random((R, 16)), rng.random((R, 16))
+  ref = O.NerfModel(cfg, params).apply(rays, extra, t_rand=t, u_rand=u, use_predicted_norm=True, compute_sigma_gradient=False)
+  out = _model(cfg).apply({'params': params}, rays, extra, t_rand=t, u_rand=u, use_predicted_norm=True, precision='f32')
+  assert _relerr(out['fine']['rgb'].cpu().numpy(), ref['fine']['rgb'].numpy()) <= 1e-4
+
+
+def test_mask_ratio_blends_gt_mask():
+  cfg = nerf_ds_config(num_warp_embeds=2, num_coarse_samples=8, num_fine_samples=8)
+  params = init_params(cfg, 6, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  R = 6
+  rays, rng = _rays(R, 2, 7)
+  rays['mask'] = np.ones((R, 1), np.float32)
+  t, u = rng.random((R, 8)), rng.random((R, 8))
+  ref = O.NerfModel(cfg, params).apply(rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, mask_ratio=0.25,
+                                       compute_sigma_gradient=False)
+  out = _model(cfg).apply({'params': params}, rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True,
+                          mask_ratio=0.25, precision='f32')
+  for k in ('rgb', 'ray_delta_x', 'ray_hyper_points'):
+    assert _relerr(out['fine'][k].cpu().numpy(), ref['fine'][k].numpy()) <= 1e-4, k
+
+
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16'])
+def test_static_graph_config1(prec):
+  """BASELINE.json configs[0]: 64 samples/ray, coarse only, warp disabled."""
+  cfg = static_config()
+  params = init_params(cfg, 0, bias_scale=0.05)
+  R = 50
+  rays, rng = _rays(R, 1, 8, spread=1.0)
+  rays['origins'] = rays['origins'] * 0 + np.array([0.0, 0.0, -4.0]) + rng.normal(size=(R, 3)) * 0.01
+  t = rng.random((R, 64))
+  ref = O.NerfModel(cfg, params).apply(rays, EXTRA, t_rand=t, compute_sigma_gradient=False)['coarse']
+  out = _model(cfg).apply({'params': params}, rays, EXTRA, t_rand=t, precision=prec)
+  assert set(out) == {'coarse'}
+  for k in ('rgb', 'depth', 'acc'):
+    e = _relerr(out['coarse'][k].cpu().numpy(), ref[k].numpy())
+    assert e <= (RTOL[prec] if k == 'rgb' else 10 * RTOL[prec]), (k, e)
+  assert 'ray_rotation_field' not in out['coarse'] and out['coarse']['ray_hyper_points'].shape == (R, 0)
+
+
+def test_edge_cases_empty_single_and_leading_shape():
+  cfg = nerf_ds_config(num_warp_embeds=2, num_coarse_samples=8, num_fine_samples=8)
+  params = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  m = _model(cfg)
+  rays, _ = _rays(0, 2, 0)
+  out = m.apply({'params': params}, rays, EXTRA, use_predicted_norm=True)
+  assert out['fine']['rgb'].shape == (0, 3)
+  rays, rng = _rays(6, 2, 1)
+  a = m.apply({'params': params}, rays, EXTRA, use_predicted_norm=True, t_rand=np.full((6, 8), .5), u_rand=np.full((6, 8), .5),
+              precision='f32')['fine']['rgb'].cpu().numpy()
+  hw = {k: (v.reshape(2, 3, -1) if k != 'metadata' else {'warp': v['warp'].reshape(2, 3, 1)}) for k, v in rays.items()}
+  b = m.apply({'params': params}, hw, EXTRA, use_predicted_norm=True, t_rand=np.full((6, 8), .5), u_rand=np.full((6, 8), .5),
+              precision='f32')['fine']['rgb'].cpu().numpy()
+  assert b.shape == (2, 3, 3) and np.array_equal(a.reshape(2, 3, 3), b)          # deterministic, shape preserved
+  with pytest.raises(IndexError):
+    bad = dict(rays)
+    bad['metadata'] = {'warp': np.full((6, 1), 7)}
+    m.apply({'params': params}, bad, EXTRA, use_predicted_norm=True)
+  with pytest.raises(ValueError):
+    m.apply({'params': params}, rays, EXTRA, use_predicted_norm=False)
+
+
+def test_philox_sampling_is_seeded_and_stratified():
+  cfg = nerf_ds_config(num_warp_embeds=2, num_coarse_samples=16, num_fine_samples=16)
+  params = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  m = _model(cfg)
+  rays, _ = _rays(5, 2, 3)
+  kw = dict(use_predicted_norm=True, return_samples=True, precision='f32')
+  a = m.apply({'params': params}, rays, EXTRA, rngs={'coarse': 1, 'fine': 2}, **kw)
+  b = m.apply({'params': params}, rays, EXTRA, rngs={'coarse': 1, 'fine': 2}, **kw)
+  c = m.apply({'params': params}, rays, EXTRA, rngs={'coarse': 5, 'fine': 2}, **kw)
+  za, zb, zc = (x['coarse']['z_vals'].cpu().numpy() for x in (a, b, c))
+  assert np.array_equal(za, zb) and not np.array_equal(za, zc)
+  edges = np.linspace(cfg.near, cfg.far, 16)
+  mids = 0.5 * (edges[1:] + edges[:-1])
+  lo, hi = np.r_[edges[0], mids], np.r_[mids, edges[-1]]
+  assert np.all(za >= lo - 1e-6) and np.all(za <= hi + 1e-6)                     # one sample per stratum
+  zf = a['fine']['z_vals'].cpu().numpy()
+  assert zf.shape == (5, 32) and np.all(np.diff(zf, axis=-1) >= 0)              # sorted union
+
+
+def test_frame_properties_at_config2_size():
+  """Size-independent properties at the metric's shape (64+64 samples, thousands of rays, bf16 kernel)."""
+  cfg = nerf_ds_config(num_warp_embeds=16)
+  params = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  R = 4096
+  rays, _ = _rays(R, 16, 11, spread=0.2)
+  m = _model(cfg)
+  out = m.apply({'params': params}, rays, EXTRA, rngs={'coarse': 3, 'fine': 4}, use_predicted_norm=True, return_samples=True)
+  f = out['fine']
+  w = f['weights']
+  assert torch.isfinite(m.last_records['fine']).all()
+  assert torch.all(w >= 0) and torch.allclose(w.sum(-1), torch.ones(R, device=w.device), atol=1e-4)   # 1e10 tail closes the ray
+  assert torch.allclose(f['acc'], w[:, :-1].sum(-1), atol=1e-5)
+  assert torch.all((f['rgb'] >= 0) & (f['rgb'] <= 1 + 1e-5))
+  assert torch.all(torch.diff(f['z_vals'], dim=-1) >= 0)
+  assert torch.allclose(f['rgb'], (w[..., None] * f['sample_rgb']).sum(1), atol=1e-5)
+  # permutation equivariance over rays (rays are independent units)
+  perm = torch.randperm(R, generator=torch.Generator().manual_seed(0)).numpy()
+  t, u = np.random.default_rng(0).random((R, 64)), np.random.default_rng(1).random((R, 64))
+  a = m.apply({'params': params}, rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True)['fine']['rgb']
+  rp = {k: (v[perm] if k != 'metadata' else {'warp': v['warp'][perm]}) for k, v in rays.items()}
+  b = m.apply({'params': params}, rp, EXTRA, t_rand=t[perm], u_rand=u[perm], use_predicted_norm=True)['fine']['rgb']
+  assert torch.equal(a[perm], b)

@@ -1,0 +1,135 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol of include/nerfds.h, and its weight-stream
+packer (host-only entry points) feeds a numpy emulation of the kernel's MFMA chaining to the oracle's MLP outputs."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from nerfds_amd import _native as N
+from nerfds_amd import nerf_ds_config, static_config, init_params
+from nerfds_amd.model import _cfg_struct, _WeightsHolder
+from oracle import nerfds_oracle as O
+from tests import wave_emulator as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_header_symbols():
+  lib = N.load()
+  header = open(os.path.join(ROOT, 'include', 'nerfds.h')).read()
+  declared = set(re.findall(r'\b(nerfds_[a-z_0-9]+)\s*\(', header))
+  declared -= {'nerfds_ray_field', 'nerfds_sample_field'}
+  assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
+  for s in declared:
+    assert hasattr(lib, s), s
+  assert lib.nerfds_abi_version() == 1
+
+
+def test_ctx_create_errors_without_touching_a_gpu():
+  lib = N.load()
+  ctx = C.c_void_p()
+  cfg = _cfg_struct(nerf_ds_config())
+  cfg.abi_version = 99
+  assert lib.nerfds_ctx_create(C.byref(ctx), 0, C.byref(cfg)) == -22
+  cfg = _cfg_struct(nerf_ds_config())
+  cfg.mask_width = 64                               # not a compiled graph
+  assert lib.nerfds_ctx_create(C.byref(ctx), 0, C.byref(cfg)) == -95
+  assert 'not built' in N.last_error(None)
+  assert lib.nerfds_pack_stream_bytes(C.byref(cfg), 0, 0) == -95
+
+
+def _pack(cfg, params, which, level, prec):
+  lib = N.load()
+  cs = _cfg_struct(cfg)
+  holder = _WeightsHolder(cfg, params)
+  nb = lib.nerfds_pack_stream_bytes(C.byref(cs), which, N.PREC[prec])
+  nf = lib.nerfds_pack_bias_floats(C.byref(cs), which)
+  assert nb >= 0 and nf >= 0
+  w = np.zeros(max(nb, 1), np.uint8)
+  b = np.zeros(max(nf, 1), np.float32)
+  rc = lib.nerfds_pack_stream(C.byref(cs), C.byref(holder.struct), which, level, N.PREC[prec], w.ctypes.data, b.ctypes.data)
+  assert rc == 0, N.last_error(None)
+  return E.Stream(w[:nb], b[:nf], prec)
+
+
+def _unchunk_tiles(ch):
+  """activation chunks [2*T, 2, 8, N] (tile order) -> [N, 32*T] features."""
+  T = ch.shape[0] // 2
+  out = np.zeros((ch.shape[3], 32 * T))
+  for t in range(T):
+    for c in range(2):
+      for h in range(2):
+        for i in range(8):
+          out[:, 32 * t + 16 * c + (i & 3) + 8 * (i >> 2) + 4 * h] = ch[2 * t + c, h, i]
+  return out
+
+
+@pytest.mark.parametrize('prec,tol', [('f32', 1e-6), ('bf16x3', 3e-5), ('bf16', 2e-2)])
+def test_shared_nets_stream_matches_oracle(prec, tol):
+  cfg = nerf_ds_config(num_warp_embeds=3)
+  p = init_params(cfg, 3, warp_head_scale=0.05, small_head_scale=0.3, bias_scale=0.1)
+  P = O.to_torch(p)
+  rng = np.random.default_rng(0)
+  n = 7
+  s = _pack(cfg, p, 0, 0, prec)
+  T = lambda a: torch.as_tensor(a, dtype=torch.float64)
+  # MaskMLP
+  f = rng.normal(size=(n, cfg.mask_in_dim))
+  x = E.mlp(s, f, 8, 128, 4)
+  got = E.head(s, [x], 1)
+  ref = O.mlp(P['mask_mlp']['MLP_0'], T(f), 8, (4,), output_channels=1).numpy().T
+  assert np.abs(got - ref).max() <= tol * max(np.abs(ref).max(), 1e-3)
+  # SE3 trunk + merged (w, v) head
+  f = rng.normal(size=(n, cfg.warp_in_dim))
+  x = E.mlp(s, f, 6, 128, 4)
+  got = E.head(s, [x], 6)
+  tr = O.mlp(P['warp_field']['trunk'], T(f), 6, (4,))
+  ref = torch.cat([O.dense(P['warp_field']['branches_w']['logit'], tr), O.dense(P['warp_field']['branches_v']['logit'], tr)], -1).numpy().T
+  assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+  # hyper sheet
+  f = rng.normal(size=(n, cfg.hyper_in_dim))
+  x = E.mlp(s, f, 6, 64, 4)
+  got = E.head(s, [x], 2)
+  ref = O.mlp(P['hyper_sheet_mlp']['MLP_0'], T(f), 6, (4,), output_channels=2).numpy().T
+  assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+  assert s.fi * s.fb == len(s.w) and s.bt * 32 == len(s.bias)            # whole stream consumed, in order
+
+
+@pytest.mark.parametrize('graph', ['nerf_ds', 'static'])
+@pytest.mark.parametrize('level', [0, 1])
+def test_nerf_mlp_stream_matches_oracle(graph, level):
+  if graph == 'static':
+    if level == 1:
+      pytest.skip('static graph is coarse only')
+    cfg = static_config()
+  else:
+    cfg = nerf_ds_config(num_warp_embeds=2)
+  p = init_params(cfg, 5, bias_scale=0.1)
+  P = O.to_torch(p)[f"nerf_mlps_{'fine' if level else 'coarse'}"]
+  rng = np.random.default_rng(1)
+  n = 5
+  s = _pack(cfg, p, 1, level, 'f32')
+  T = lambda a: torch.as_tensor(a, dtype=torch.float64)
+  f = rng.normal(size=(n, cfg.trunk_in_dim))
+  vd, nm = rng.normal(size=(n, 24)), rng.normal(size=(n, cfg.norm_feat_dim))
+  trunk = E.mlp(s, f, 8, 256, 4)
+  bott = E.dense(s, [trunk], 8, False)
+  alpha = E.head(s, [trunk], cfg.alpha_out_dim)
+  cond = E.linear_chunks(np.concatenate([vd, nm], 1), -(-(24 + cfg.norm_feat_dim) // 16))
+  ins = [bott, trunk, cond] if cfg.use_x_in_rgb_condition else [bott, cond]
+  hid = E.dense(s, ins, 4, True)
+  rgb = E.head(s, [hid], 3)
+  assert s.fi * s.fb == len(s.w) and s.bt * 32 == len(s.bias)
+
+  t_ref = O.mlp(P['trunk_mlp'], T(f), 8, (4,))
+  b_ref = O.dense(P['bottleneck'], t_ref)
+  a_ref = O.dense(P['alpha_mlp']['logit'], t_ref)
+  parts = [b_ref, T(vd)] + ([t_ref] if cfg.use_x_in_rgb_condition else []) + ([T(nm)] if cfg.norm_feat_dim else [])
+  r_ref = O.mlp(P['rgb_mlp'], torch.cat(parts, -1), 1, (), output_channels=3)
+  assert np.allclose(_unchunk_tiles(trunk), t_ref.numpy(), atol=1e-5)
+  assert np.allclose(_unchunk_tiles(bott), b_ref.numpy(), atol=1e-5)
+  assert np.allclose(alpha.T, a_ref.numpy(), atol=1e-5)
+  assert np.allclose(rgb.T, r_ref.numpy(), atol=1e-5)
