@@ -19,6 +19,11 @@ constexpr int frag_parts(int prec) { return prec == P_BF16 ? 1 : 2; }
 constexpr int frag_bytes(int prec) { return 1024 * frag_parts(prec); }
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+// The kernel stages the stream through LDS in 16 KiB stages; each of the two streams is zero-padded to a
+// whole number of stages so that a stage never straddles the shared -> NerfMLP seam.
+constexpr int STAGE_BYTES = 16384;
+constexpr int stage_frags(int prec) { return STAGE_BYTES / frag_bytes(prec); }
+constexpr int pad_frags(int n, int prec) { return cdiv(n, stage_frags(prec)) * stage_frags(prec); }
 constexpr int chunks(int feats) { return cdiv(feats, 16); }   // k16 chunks needed for `feats` linear features
 
 // Number of fragments of a plain hidden stack: depth layers of `width`, input `in_chunks` k16-chunks,

@@ -4,7 +4,7 @@
 
 namespace nerfds {
 
-constexpr int MAX_SAMPLES = 256;      // Nc + Nf upper bound (config 5: 128 + 128)
+constexpr int MAX_SAMPLES = 128;      // Nc + Nf upper bound (nerf_ds.gin: 64 + 64); 160 KiB LDS holds ring + biases + 4 waves of this
 constexpr int RAY_REC = 26;           // == NERFDS_RAY_REC
 constexpr int SAMPLE_REC = 18;        // == NERFDS_SAMPLE_REC
 constexpr int MAX_BANDS = 8;

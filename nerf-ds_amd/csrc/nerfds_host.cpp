@@ -176,7 +176,7 @@ void pack_dispatch(int graph, StreamWriter& sw, const Weights& W, int which, int
 }
 template <class G> void stream_dims(int which, int prec, int64_t* wbytes, int64_t* bfloats) {
   using D = Dims<G>;
-  *wbytes = (int64_t)(which == 0 ? D::SHARED_FRAGS : D::NERF_FRAGS) * frag_bytes(prec);
+  *wbytes = (int64_t)pad_frags(which == 0 ? D::SHARED_FRAGS : D::NERF_FRAGS, prec) * frag_bytes(prec);   // zero padded to whole stages
   *bfloats = (int64_t)(which == 0 ? D::SHARED_BIAS_TILES : D::NERF_BIAS_TILES) * 32;
 }
 void stream_dims_dispatch(int graph, int which, int prec, int64_t* wb, int64_t* bf) {
@@ -237,7 +237,7 @@ int nerfds_ctx_create(nerfds_ctx** out, int device, const nerfds_model_cfg* cfg)
   if (cfg->abi_version != NERFDS_ABI_VERSION) { g_create_error = "abi_version mismatch"; return NERFDS_EINVAL; }
   if (cfg->num_coarse_samples < 4 || cfg->num_fine_samples < 0 ||
       cfg->num_coarse_samples + cfg->num_fine_samples > MAX_SAMPLES) {
-    g_create_error = "num_coarse_samples must be >= 4 and num_coarse_samples + num_fine_samples <= 256";
+    g_create_error = "num_coarse_samples must be >= 4 and num_coarse_samples + num_fine_samples <= 128";
     return NERFDS_EINVAL;
   }
   const int graph = graph_of(*cfg);
@@ -299,7 +299,7 @@ static int ensure_packed(nerfds_ctx* ctx, uint32_t prec) {
     std::vector<float> b((size_t)bf);
     StreamWriter sw{(int)prec, w.data(), b.data()};
     pack_dispatch(ctx->graph, sw, ctx->W, which ? 1 : 0, which ? which - 1 : 0);
-    if ((int64_t)sw.wbytes != wb || (int64_t)sw.bfloats != bf)
+    if ((int64_t)sw.wbytes > wb || wb - (int64_t)sw.wbytes >= STAGE_BYTES || (int64_t)sw.bfloats != bf)
       return ctx->fail(NERFDS_EINVAL, "internal: packed stream %d has %zu bytes / %zu bias floats, kernel expects %lld / %lld",
                        which, sw.wbytes, sw.bfloats, (long long)wb, (long long)bf);
     if (ctx->wstream[prec][which].upload(w.data(), w.size()) != hipSuccess) return ctx->fail(NERFDS_ENOMEM, "weight stream upload failed");
@@ -355,7 +355,8 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   window(ka.win_hp, ctx->cfg.hyper_point_max_deg, extra->hyper_alpha);
   window(ka.win_nm, ctx->cfg.norm_input_max_deg, extra->norm_input_alpha);
 
-  const int grid = (int)std::min<int64_t>(rays->num_rays, (int64_t)ctx->num_cus * 4);   // one 512-VGPR wave per SIMD
+  // one workgroup of four 512-VGPR waves (one per SIMD) per CU, four rays per workgroup iteration
+  const int grid = (int)std::min<int64_t>((rays->num_rays + 3) / 4, (int64_t)ctx->num_cus);
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
   if (ctx->timing) {

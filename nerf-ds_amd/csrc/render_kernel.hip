@@ -46,6 +46,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // LDS scratch is private to a wave and a wave's DS ops complete in order: a compiler-level fence is all that is needed.
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
+// All LDS of the kernel is ONE array (a second __shared__ object de-pipelines LDS-DMA code, cdna guide section 5):
+// [0, RING_BYTES) weight ring, then one WaveLds scratch block per wave.
+extern __shared__ __attribute__((aligned(16))) char g_smem[];
+
 // ------------------------------------------------------------------------------------------------
 // Operand containers
 // ------------------------------------------------------------------------------------------------
@@ -123,47 +127,91 @@ template <int P> DEVI void mma(f32x16& acc, const WFrag<P>& w, const Chunk<P>& c
 // constant after unrolling; sched_barrier pins the VMEM loads to their program position so the
 // scheduler cannot hoist hundreds of them (and spill), while MFMA / VALU stay free to move.
 // ------------------------------------------------------------------------------------------------
+// STAGE_BYTES (graphs.h): one ring stage = 16 bf16 fragments (8 in the 2-part precisions)
+constexpr int NUM_STAGES = 4;          // ring depth
+constexpr int RING_BYTES = NUM_STAGES * STAGE_BYTES;
+constexpr int WG_WAVES = 4;            // one 512-VGPR wave per SIMD
+// LDS map: [0, RING_BYTES) weight ring | padded fp32 biases (shared, coarse NerfMLP, fine NerfMLP) | WG_WAVES x WaveLds
+constexpr int BIAS_OFF = RING_BYTES;
+template <class G> constexpr int bias_bytes() { return (Dims<G>::SHARED_BIAS_TILES + 2 * Dims<G>::NERF_BIAS_TILES) * 128; }
+
 template <class G, int P> struct Pipe {
   using Dm = Dims<G>;
-  static constexpr int DEPTH = 8;
-  static constexpr int SHARED = Dm::SHARED_FRAGS, TOTAL = Dm::SHARED_FRAGS + Dm::NERF_FRAGS;
-  // stream indices [TOTAL, TOTAL_PAD) are holes so that the ring slot of a fragment survives the wrap
-  static constexpr int TOTAL_PAD = cdiv(TOTAL, DEPTH) * DEPTH;
-  WFrag<P> ring[DEPTH];
+  static constexpr int FB = frag_bytes(P);
+  static constexpr int GF = STAGE_BYTES / FB;                     // fragments per stage
+  static constexpr int NS = NUM_STAGES;
+  // stream positions count the zero padding at the end of each stream (graphs.h pad_frags)
+  static constexpr int SHARED_PAD = pad_frags(Dm::SHARED_FRAGS, P), NERF_PAD = pad_frags(Dm::NERF_FRAGS, P);
+  static constexpr int SHARED_STAGES = SHARED_PAD / GF, USED_STAGES = (SHARED_PAD + NERF_PAD) / GF;
+  static constexpr int STAGES = cdiv(USED_STAGES, NS) * NS;       // per evaluation, padded so ring slots survive the wrap
+  static constexpr int PIECES = STAGE_BYTES / 1024 / WG_WAVES;    // 1 KiB LDS-DMA pieces per wave per stage
   rsrc_t ws;        // shared stream
   rsrc_t wn;        // NerfMLP stream of the level being evaluated
   rsrc_t wn_next;   // NerfMLP stream of the level evaluated next (wrap-around prefetch)
-  rsrc_t bs, bn;    // padded fp32 biases: shared, NerfMLP of the current level
   int lane16;
+  int wave1k;       // wave index in the workgroup * 1024 (SGPR)
 
-  DEVI void issue(int i) {     // i: stream index, may run past TOTAL_PAD (wrap into the next evaluation)
-    if (i >= TOTAL && i < TOTAL_PAD) return;
-    const int j = i % TOTAL_PAD;
-    if (j < SHARED) ring[i % DEPTH] = load_wfrag<P>(ws, lane16, j * frag_bytes(P));
-    else ring[i % DEPTH] = load_wfrag<P>(i >= TOTAL_PAD ? wn_next : wn, lane16, (j - SHARED) * frag_bytes(P));
-  }
-  DEVI void finish_eval() {    // loads that the holes did not trigger
+  // This wave's share of stage t: LDS-DMA (buffer_load ... lds), 1 KiB per instruction, no VGPRs.  Which
+  // stream a stage comes from is a compile-time fact; only "+ wave * 1024" is run-time (one s_add).
+  DEVI void issue_stage(int t) {
+    const bool wrap = t >= STAGES;
+    const int tt = t % STAGES, slot = t % NS;
+    if (tt >= USED_STAGES) return;                                 // hole stage
+    const bool shared = tt < SHARED_STAGES;
+    const int base = (shared ? tt : tt - SHARED_STAGES) * STAGE_BYTES;
 #pragma unroll
-    for (int i = TOTAL; i < TOTAL_PAD; ++i) issue(i + DEPTH);
+    for (int k = 0; k < PIECES; ++k) {
+      const int off = WG_WAVES * k * 1024 + wave1k;
+      auto dst = (__attribute__((address_space(3))) void*)(g_smem + slot * STAGE_BYTES + off);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(shared ? ws : (wrap ? wn_next : wn), dst, 16, lane16, base + off, 0, 0);
+    }
+  }
+  // Start of stage s: everything issued so far has landed (it was issued >= one stage ago), every wave is
+  // done with stage s - 1, whose slot is refilled with stage s + NS - 1.
+  DEVI void boundary(int s) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    issue_stage(s + NS - 1);
+  }
+  DEVI void prologue() {
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) issue_stage(t);
+  }
+  DEVI WFrag<P> frag(int i) const {
+    const int off = ((i / GF) % NS) * STAGE_BYTES + (i % GF) * FB;
+    WFrag<P> w;
+    const u32x4* p = reinterpret_cast<const u32x4*>(g_smem + off + lane16);
+    if constexpr (P == P_BF16) {
+      w.v = __builtin_bit_cast(bf16x8, p[0]);
+    } else if constexpr (P == P_BF16X3) {
+      w.hi = __builtin_bit_cast(bf16x8, p[0]);
+      w.lo = __builtin_bit_cast(bf16x8, p[64]);
+    } else {
+      w.a = __builtin_bit_cast(f32x4, p[0]);
+      w.b = __builtin_bit_cast(f32x4, p[64]);
+    }
+    return w;
+  }
+  DEVI void finish_eval() {    // boundaries of the hole stages keep the barrier count and the ring in step
+#pragma unroll
+    for (int s = USED_STAGES; s < STAGES; ++s) boundary(s);
   }
 };
-
-// everything but VMEM may be scheduled across (LLVM SchedGroupMask: ALU VALU SALU MFMA DS DS_READ DS_WRITE TRANS)
-#define PIN_VMEM() __builtin_amdgcn_sched_barrier(0x1 | 0x2 | 0x4 | 0x8 | 0x80 | 0x100 | 0x200 | 0x400)
 
 struct Cursor {
   int fi;       // stream index of the next fragment
-  int boff;     // byte offset of the next bias tile
-  bool nerf;    // bias array: shared or NerfMLP
+  int boff;     // LDS byte offset of the next bias tile
 };
 
-// Bias of a tile for this lane: register r <-> row (r & 3) + 8 (r >> 2) + 4 h.
-DEVI void load_bias(float (&bv)[16], rsrc_t bias, int boff, int h) {
+// Bias of a tile for this lane, as an MFMA C operand: register r <-> row (r & 3) + 8 (r >> 2) + 4 h.
+DEVI f32x16 load_bias(int boff, int h) {
+  f32x16 bv;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bias, 16 * h, boff + 32 * g, 0));
+    const f32x4 b = *reinterpret_cast<const f32x4*>(g_smem + boff + 32 * g + 16 * h);
     bv[4 * g + 0] = b[0]; bv[4 * g + 1] = b[1]; bv[4 * g + 2] = b[2]; bv[4 * g + 3] = b[3];
   }
+  return bv;
 }
 
 template <class G, int P, int NT, int K>
@@ -171,40 +219,33 @@ DEVI void accum(f32x16 (&acc)[NT], Pipe<G, P>& pipe, Cursor& cur, const Chunk<P>
 #pragma unroll
   for (int kc = 0; kc < K; ++kc) {
     const int i = cur.fi + kc;
+    if (i % Pipe<G, P>::GF == 0) pipe.boundary(i / Pipe<G, P>::GF);
+    const WFrag<P> w = pipe.frag(i);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) mma<P>(acc[nt], pipe.ring[i % Pipe<G, P>::DEPTH], in[nt][kc]);
-    pipe.issue(i + Pipe<G, P>::DEPTH);
-    PIN_VMEM();
+    for (int nt = 0; nt < NT; ++nt) mma<P>(acc[nt], w, in[nt][kc]);
   }
   cur.fi += K;
 }
 
-template <int NT> DEVI void zero_acc(f32x16 (&acc)[NT]) {
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-}
-
 // One dense layer with OT output tiles of 32 features; inputs are one or more chunk arrays in stream order.
+// The accumulators start from the bias (the first MFMA of a tile reads the bias registers as its C operand).
 template <class G, int P, int NT, int OT, bool RELU, class... Ins>
 DEVI void dense(Pipe<G, P>& pipe, Cursor& cur, int h, Chunk<P> (&out)[NT][2 * OT], const Ins&... ins) {
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot) {
-    float bv[16];
-    load_bias(bv, cur.nerf ? pipe.bn : pipe.bs, cur.boff + 128 * ot, h);
-    PIN_VMEM();
+    const f32x16 bv = load_bias(cur.boff + 128 * ot, h);
     f32x16 acc[NT];
-    zero_acc<NT>(acc);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = bv;
     (accum<G, P, NT>(acc, pipe, cur, ins), ...);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float x0[8], x1[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float a0 = acc[nt][i] + bv[i], a1 = acc[nt][8 + i] + bv[8 + i];
-        x0[i] = RELU ? fmaxf(a0, 0.f) : a0;
-        x1[i] = RELU ? fmaxf(a1, 0.f) : a1;
+        // relu as one v_med3_f32 (fmaxf would add a canonicalising v_max per element in IEEE mode)
+        x0[i] = RELU ? __builtin_amdgcn_fmed3f(acc[nt][i], 0.f, __builtin_inff()) : acc[nt][i];
+        x1[i] = RELU ? __builtin_amdgcn_fmed3f(acc[nt][8 + i], 0.f, __builtin_inff()) : acc[nt][8 + i];
       }
       make_chunk<P>(out[nt][2 * ot], x0);
       make_chunk<P>(out[nt][2 * ot + 1], x1);
@@ -216,15 +257,10 @@ DEVI void dense(Pipe<G, P>& pipe, Cursor& cur, int h, Chunk<P> (&out)[NT][2 * OT
 // Output head (<= 16 logical outputs, duplicated in both lane halves by the packer): logical output j = acc[j].
 template <class G, int P, int NT, class... Ins>
 DEVI void head(Pipe<G, P>& pipe, Cursor& cur, int h, f32x16 (&acc)[NT], const Ins&... ins) {
-  float bv[16];
-  load_bias(bv, cur.nerf ? pipe.bn : pipe.bs, cur.boff, h);
-  PIN_VMEM();
-  zero_acc<NT>(acc);
+  const f32x16 bv = load_bias(cur.boff, h);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = bv;
   (accum<G, P, NT>(acc, pipe, cur, ins), ...);
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nt][r] += bv[r];
   cur.boff += 128;
 }
 
@@ -335,40 +371,53 @@ template <int P, int KCH, class F> DEVI void build_chunks(Chunk<P> (&out)[KCH], 
 // ------------------------------------------------------------------------------------------------
 // Per-wave LDS scratch
 // ------------------------------------------------------------------------------------------------
-enum { SV_SIGMA = 0, SV_RGB = 1, SV_MASK = 4, SV_NORM = 5, SV_WP = 8, SV_ROT = 13, SV_TRN = 16, SV_COUNT = 19 };
+enum { SV_SIGMA = 0, SV_RGB = 1, SV_MASK = 4, SV_NORM = 5, SV_WP = 8, SV_ROT = 13, SV_TRN = 16,
+       SV_AX = 19, SV_SN = 22, SV_OMC = 23, SV_COUNT = 24 };
+enum { RC_WEMB = 0, RC_MEMB = 8, RC_VDENC = 16, RC_COUNT = 64 };
 
 struct WaveLds {
   float zs[MAX_SAMPLES];      // z of the current level
   float zn[MAX_SAMPLES];      // scratch: unsorted union / bins
   float ws[MAX_SAMPLES];      // compositing weights of the level just rendered
   float cdf[MAX_SAMPLES];
-  float sv[SV_COUNT][MAX_SAMPLES];
+  float sv[SV_COUNT][MAX_SAMPLES];   // per-sample results / parked state (SoA: conflict-free by sample)
+  float rayc[RC_COUNT];       // per-ray constants: warp GLO row, mask GLO row, posenc(viewdir)
 };
 
 struct RayConst {
-  float o[3], d[3], vd[3];
-  float wemb[8], memb[8];
+  float o[3], d[3];
   float gt_mask;
-  float vdenc[24];
 };
 
+// Rodrigues from the parked (unit axis, sin, 1 - cos): R = I + sin * W + (1 - cos) * W @ W (rigid_body.py:59-74).
+DEVI void rodrigues(float (&R)[9], const float (&w)[3], float st, float omc) {
+  const float W[9] = {0.f, -w[2], w[1], w[2], 0.f, -w[0], -w[1], w[0], 0.f};
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float w2 = W[3 * r] * W[c] + W[3 * r + 1] * W[3 + c] + W[3 * r + 2] * W[6 + c];
+      R[3 * r + c] = ((r == c) ? 1.f : 0.f) + st * W[3 * r + c] + omc * w2;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
-// The per-sample field: networks on one batch of 32*NT samples.
+// The per-sample field: networks on one batch of 32*NT samples.  Per-sample state that is not needed by
+// the next network is parked in the wave's LDS block at once (it is going there for compositing anyway),
+// so the 8x256 trunk runs with (almost) only MFMA operands in registers.
 // ------------------------------------------------------------------------------------------------
 template <class G, int P, int NT>
-DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int lane, int s_base, int S, WaveLds& L) {
+DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int level, int lane, int s_base, int S, WaveLds& L) {
   using D = Dims<G>;
   const int h = lane >> 5, ln = lane & 31;
+  auto sample_of = [&](int nt) { return s_base + 32 * nt + ln; };
+  auto slot_of = [&](int nt) { const int s = sample_of(nt); return s < S ? s : S - 1; };   // clamp: tail lanes redo the last sample
+  auto writer = [&](int nt) { return h == 0 && sample_of(nt) < S; };
 
   float x[NT][3], xw[NT][3];
-  bool valid[NT];
-  int sidx[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    int s = s_base + 32 * nt + ln;
-    valid[nt] = s < S;
-    sidx[nt] = s;
-    float z = L.zs[valid[nt] ? s : S - 1];
+    const float z = L.zs[slot_of(nt)];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       x[nt][c] = __fadd_rn(rc.o[c], __fmul_rn(z, rc.d[c]));   // model_utils.py:91-92
@@ -376,12 +425,12 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
     }
   }
 
-  Cursor cur{0, 0, false};
+  Cursor cur{0, BIAS_OFF};
 
   // ---- MaskMLP (modules.py:409-434; models.py:967-975) ----
-  float maskv[NT], pmask[NT];
+  float maskv[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) { maskv[nt] = rc.gt_mask; pmask[nt] = 0.f; }
+  for (int nt = 0; nt < NT; ++nt) maskv[nt] = rc.gt_mask;
   if constexpr (G::HAS_MASK) {
     constexpr int W16 = G::MASK_W / 16, W32 = G::MASK_W / 32;
     Chunk<P> in0[NT][D::MASK_KC], a[NT][W16], b[NT][W16];
@@ -389,7 +438,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
     for (int nt = 0; nt < NT; ++nt)
       build_chunks<P, D::MASK_KC>(in0[nt], h, [&](int f) {
         if (f < 6 * G::MASK_BANDS) return posenc_feat<3>(f, x[nt], ka.win_mask);
-        if (f < D::MASK_IN) return val_feat(rc.memb[(f - 6 * G::MASK_BANDS) & 7]);
+        if (f < D::MASK_IN) return val_feat(L.rayc[RC_MEMB + ((f - 6 * G::MASK_BANDS) & 7)]);
         return zero_feat();
       });
     static_assert(G::MASK_DEPTH == 8 || !G::HAS_MASK, "mask net is unrolled for depth 8, skip 4");
@@ -405,19 +454,16 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
     head<G, P, NT>(pipe, cur, h, hacc, b);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      pmask[nt] = fmaxf(hacc[nt][0], 0.f);                                  // MaskMLP.output_activation = relu
-      maskv[nt] = pmask[nt] * ka.mask_ratio + rc.gt_mask * (1.0f - ka.mask_ratio);   // models.py:975
+      const float pm = fmaxf(hacc[nt][0], 0.f);                              // MaskMLP.output_activation = relu
+      maskv[nt] = pm * ka.mask_ratio + rc.gt_mask * (1.0f - ka.mask_ratio);  // models.py:975
+      if (writer(nt)) L.sv[SV_MASK][sample_of(nt)] = pm;
     }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) if (writer(nt)) L.sv[SV_MASK][sample_of(nt)] = 0.f;
   }
 
   // ---- SE3Field (warping.py:200-237) + exp_se3 (rigid_body.py:77-101) ----
-  float Rm[NT][9], pt[NT][3];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Rm[nt][i] = (i % 4 == 0) ? 1.f : 0.f;
-    pt[nt][0] = pt[nt][1] = pt[nt][2] = 0.f;
-  }
   if constexpr (G::HAS_WARP) {
     constexpr int W16 = G::WARP_W / 16, W32 = G::WARP_W / 32;
     Chunk<P> in0[NT][D::WARP_KC], a[NT][W16], b[NT][W16];
@@ -425,7 +471,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
     for (int nt = 0; nt < NT; ++nt)
       build_chunks<P, D::WARP_KC>(in0[nt], h, [&](int f) {
         if (f < 6 * G::WARP_BANDS) return posenc_feat<3>(f, x[nt], ka.win_warp);
-        if (f < 6 * G::WARP_BANDS + 8) return val_feat(rc.wemb[(f - 6 * G::WARP_BANDS) & 7]);
+        if (f < 6 * G::WARP_BANDS + 8) return val_feat(L.rayc[RC_WEMB + ((f - 6 * G::WARP_BANDS) & 7)]);
         if (f == 6 * G::WARP_BANDS + 8) return val_feat(maskv[nt]);         // models.py:729-730
         return zero_feat();
       });
@@ -440,33 +486,61 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
     head<G, P, NT>(pipe, cur, h, hacc, b);      // logical outputs: w = 0..2, v = 3..5
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      float w0 = hacc[nt][0], w1 = hacc[nt][1], w2 = hacc[nt][2];
+      float w[3] = {hacc[nt][0], hacc[nt][1], hacc[nt][2]};
       float v0 = hacc[nt][3], v1 = hacc[nt][4], v2 = hacc[nt][5];
-      float theta = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);     // warping.py:219 (no epsilon, as the reference)
-      w0 /= theta; w1 /= theta; w2 /= theta;
+      const float theta = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);     // warping.py:219 (no epsilon, as the reference)
+      w[0] /= theta; w[1] /= theta; w[2] /= theta;
       v0 /= theta; v1 /= theta; v2 /= theta;
-      // W = skew(w); W2 = W @ W
-      const float W[9] = {0.f, -w2, w1, w2, 0.f, -w0, -w1, w0, 0.f};
-      float W2[9];
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) W2[3 * r + c] = W[3 * r] * W[c] + W[3 * r + 1] * W[3 + c] + W[3 * r + 2] * W[6 + c];
       const float st = sinf(theta), ct = cosf(theta);
       const float omc = 1.0f - ct, tms = theta - st;
-      float Gm[9];
+      float Rm[9];
+      rodrigues(Rm, w, st, omc);
+      // p = (theta I + (1 - cos) W + (theta - sin) W @ W) v   (rigid_body.py:94-95)
+      const float W[9] = {0.f, -w[2], w[1], w[2], 0.f, -w[0], -w[1], w[0], 0.f};
+      float pt[3];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        const float eye = (i % 4 == 0) ? 1.f : 0.f;
-        Rm[nt][i] = eye + st * W[i] + omc * W2[i];                    // rigid_body.py:73-74
-        Gm[i] = theta * eye + omc * W[i] + tms * W2[i];               // rigid_body.py:94-95
+      for (int r = 0; r < 3; ++r) {
+        float g[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float w2 = W[3 * r] * W[c] + W[3 * r + 1] * W[3 + c] + W[3 * r + 2] * W[6 + c];
+          g[c] = ((r == c) ? theta : 0.f) + omc * W[3 * r + c] + tms * w2;
+        }
+        pt[r] = g[0] * v0 + g[1] * v1 + g[2] * v2;
       }
 #pragma unroll
-      for (int r = 0; r < 3; ++r) pt[nt][r] = Gm[3 * r] * v0 + Gm[3 * r + 1] * v1 + Gm[3 * r + 2] * v2;
-#pragma unroll
       for (int r = 0; r < 3; ++r)
-        xw[nt][r] = Rm[nt][3 * r] * x[nt][0] + Rm[nt][3 * r + 1] * x[nt][1] + Rm[nt][3 * r + 2] * x[nt][2] + pt[nt][r];
+        xw[nt][r] = Rm[3 * r] * x[nt][0] + Rm[3 * r + 1] * x[nt][1] + Rm[3 * r + 2] * x[nt][2] + pt[r];
+      if (writer(nt)) {
+        const int s = sample_of(nt);
+        // rotation field: normalize(R @ normalize(1,1,1)) (models.py:1292-1296); translation field: R @ 0 + p
+        float rf[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) rf[r] = (Rm[3 * r] + Rm[3 * r + 1] + Rm[3 * r + 2]) * 0.577350269f;
+        normalize3(rf);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          L.sv[SV_WP + c][s] = xw[nt][c];
+          L.sv[SV_ROT + c][s] = rf[c];
+          L.sv[SV_TRN + c][s] = pt[c];
+          L.sv[SV_AX + c][s] = w[c];
+        }
+        L.sv[SV_SN][s] = st;
+        L.sv[SV_OMC][s] = omc;
+      }
     }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      if (writer(nt)) {
+        const int s = sample_of(nt);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          L.sv[SV_WP + c][s] = x[nt][c];
+          L.sv[SV_ROT + c][s] = 0.577350269f;
+          L.sv[SV_TRN + c][s] = 0.f;
+        }
+      }
   }
 
   // ---- HyperSheetMLP on the OBSERVATION-space point (modules.py:367-392; models.py:662-666) ----
@@ -480,8 +554,8 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
     for (int nt = 0; nt < NT; ++nt)
       build_chunks<P, D::HYP_KC>(in0[nt], h, [&](int f) {
         if (f < 6 * G::HYP_BANDS) return posenc_feat<3>(f, x[nt], ka.win_hyp);
-        if (f < 6 * G::HYP_BANDS + 8) return val_feat(rc.wemb[(f - 6 * G::HYP_BANDS) & 7]);   // hyper_use_warp_embed
-        if (f == 6 * G::HYP_BANDS + 8) return val_feat(maskv[nt]);                              // models.py:731-732
+        if (f < 6 * G::HYP_BANDS + 8) return val_feat(L.rayc[RC_WEMB + ((f - 6 * G::HYP_BANDS) & 7)]);   // hyper_use_warp_embed
+        if (f == 6 * G::HYP_BANDS + 8) return val_feat(maskv[nt]);                                        // models.py:731-732
         return zero_feat();
       });
     static_assert(G::HYP_DEPTH == 6 || !G::HAS_HYPER, "hyper sheet is unrolled for depth 6, skip 4");
@@ -496,12 +570,17 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { wamb[nt][0] = hacc[nt][0]; wamb[nt][1] = hacc[nt][1]; }
   }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    if (writer(nt)) {
+      L.sv[SV_WP + 3][sample_of(nt)] = wamb[nt][0];
+      L.sv[SV_WP + 4][sample_of(nt)] = wamb[nt][1];
+    }
 
   // ---- NerfMLP of this level (modules.py:243-313; models.py:1043-1047, 1268-1270) ----
-  cur.boff = 0;
-  cur.nerf = true;
+  cur.fi = Pipe<G, P>::SHARED_PAD;      // skip the zero padding of the shared stream
+  cur.boff = BIAS_OFF + (D::SHARED_BIAS_TILES + level * D::NERF_BIAS_TILES) * 128;
   constexpr int TW16 = G::TRUNK_W / 16, TW32 = G::TRUNK_W / 32;
-  float sigma_raw[NT], nraw[NT][3], rgbv[NT][3];
   {
     Chunk<P> in0[NT][D::TRUNK_KC], a[NT][TW16], b[NT][TW16];
 #pragma unroll
@@ -523,28 +602,39 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
     dense<G, P, NT, TW32, false>(pipe, cur, h, a, b);         // a = bottleneck (no activation, modules.py:255)
     f32x16 hacc[NT];
     head<G, P, NT>(pipe, cur, h, hacc, b);                    // alpha_mlp on trunk_output (modules.py:273-274)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      sigma_raw[nt] = hacc[nt][0];
-      nraw[nt][0] = G::PREDICT_NORM ? hacc[nt][1] : 0.f;
-      nraw[nt][1] = G::PREDICT_NORM ? hacc[nt][2] : 0.f;
-      nraw[nt][2] = G::PREDICT_NORM ? hacc[nt][3] : 0.f;
-    }
     // rgb condition chunks: [posenc(viewdir) | posenc(normal in observation frame)]
     Chunk<P> cond[NT][D::COND_KC];
+    WAVE_SYNC();                                              // parked SE3 state was written by the h == 0 lanes
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float nin[3] = {0.f, 0.f, 0.f};
+      if (writer(nt)) L.sv[SV_SIGMA][sample_of(nt)] = softplus_f(hacc[nt][0]);                    // models.py:577
       if constexpr (G::PREDICT_NORM) {
-        float n[3] = {nraw[nt][0], nraw[nt][1], nraw[nt][2]};
-        normalize3(n);                                                      // models.py:1124
+        float n[3] = {hacc[nt][1], hacc[nt][2], hacc[nt][3]};
+        if (writer(nt)) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c)                                         // R^T n (models.py:1126, inverse=True)
-          nin[c] = Rm[nt][c] * n[0] + Rm[nt][3 + c] * n[1] + Rm[nt][6 + c] * n[2];
+          for (int c = 0; c < 3; ++c) L.sv[SV_NORM + c][sample_of(nt)] = n[c];
+        }
+        normalize3(n);                                                      // models.py:1124
+        if constexpr (G::HAS_WARP) {
+          const int sl = slot_of(nt);
+          const float ax[3] = {L.sv[SV_AX][sl], L.sv[SV_AX + 1][sl], L.sv[SV_AX + 2][sl]};
+          float Rm[9];
+          rodrigues(Rm, ax, L.sv[SV_SN][sl], L.sv[SV_OMC][sl]);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) nin[c] = Rm[c] * n[0] + Rm[3 + c] * n[1] + Rm[6 + c] * n[2];   // R^T n (models.py:1126)
+        } else {
+          nin[0] = n[0]; nin[1] = n[1]; nin[2] = n[2];
+        }
         normalize3(nin);                                                    // models.py:1138
+      } else {
+        if (writer(nt)) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) L.sv[SV_NORM + c][sample_of(nt)] = 0.f;
+        }
       }
       build_chunks<P, D::COND_KC>(cond[nt], h, [&](int f) {
-        if (f < 6 * G::VD_BANDS) return val_feat(rc.vdenc[f < 24 ? f : 0]);
+        if (f < 6 * G::VD_BANDS) return val_feat(L.rayc[RC_VDENC + (f < 24 ? f : 0)]);
         if (f < D::COND_IN) return posenc_feat<3>(f - 6 * G::VD_BANDS, nin, ka.win_nm);         // models.py:1142-1148
         return zero_feat();
       });
@@ -557,55 +647,22 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
     }
     head<G, P, NT>(pipe, cur, h, hacc, c);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      rgbv[nt][0] = sigmoid_f(hacc[nt][0]);                                 // models.py:576
-      rgbv[nt][1] = sigmoid_f(hacc[nt][1]);
-      rgbv[nt][2] = sigmoid_f(hacc[nt][2]);
-    }
+    for (int nt = 0; nt < NT; ++nt)
+      if (writer(nt)) {
+        const int s = sample_of(nt);
+        L.sv[SV_RGB + 0][s] = sigmoid_f(hacc[nt][0]);                       // models.py:576
+        L.sv[SV_RGB + 1][s] = sigmoid_f(hacc[nt][1]);
+        L.sv[SV_RGB + 2][s] = sigmoid_f(hacc[nt][2]);
+      }
   }
-
   pipe.finish_eval();
-  PIN_VMEM();
-
-  // ---- park the per-sample results in LDS for compositing ----
-  if (h == 0) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      if (!valid[nt]) continue;
-      const int s = sidx[nt];
-      L.sv[SV_SIGMA][s] = softplus_f(sigma_raw[nt]);                        // models.py:577
-      L.sv[SV_RGB + 0][s] = rgbv[nt][0];
-      L.sv[SV_RGB + 1][s] = rgbv[nt][1];
-      L.sv[SV_RGB + 2][s] = rgbv[nt][2];
-      L.sv[SV_MASK][s] = pmask[nt];
-      L.sv[SV_NORM + 0][s] = nraw[nt][0];
-      L.sv[SV_NORM + 1][s] = nraw[nt][1];
-      L.sv[SV_NORM + 2][s] = nraw[nt][2];
-      L.sv[SV_WP + 0][s] = xw[nt][0];
-      L.sv[SV_WP + 1][s] = xw[nt][1];
-      L.sv[SV_WP + 2][s] = xw[nt][2];
-      L.sv[SV_WP + 3][s] = wamb[nt][0];
-      L.sv[SV_WP + 4][s] = wamb[nt][1];
-      // rotation field: normalize(R @ normalize(1,1,1)) (models.py:1292-1296); translation field: R @ 0 + p
-      float rf[3];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) rf[r] = (Rm[nt][3 * r] + Rm[nt][3 * r + 1] + Rm[nt][3 * r + 2]) * 0.577350269f;
-      normalize3(rf);
-      L.sv[SV_ROT + 0][s] = rf[0];
-      L.sv[SV_ROT + 1][s] = rf[1];
-      L.sv[SV_ROT + 2][s] = rf[2];
-      L.sv[SV_TRN + 0][s] = pt[nt][0];
-      L.sv[SV_TRN + 1][s] = pt[nt][1];
-      L.sv[SV_TRN + 2][s] = pt[nt][2];
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Compositing of one level (model_utils.py:95-159, 272-317; models.py:1346-1415) -> ray record.
 // ------------------------------------------------------------------------------------------------
 template <class G>
-DEVI void composite(const KArgs& ka, const RayConst& rc, int lane, int S, bool at_infinity, WaveLds& L,
+DEVI void composite(const KArgs& ka, const RayConst& rc, int ray, int lane, int S, bool at_infinity, WaveLds& L,
                     float* __restrict__ rec_out, float* __restrict__ smp_out) {
   const float dnorm = sqrtf(rc.d[0] * rc.d[0] + rc.d[1] * rc.d[1] + rc.d[2] * rc.d[2]);
   const float last = at_infinity ? 1e10f : 1e-19f;
@@ -663,7 +720,8 @@ DEVI void composite(const KArgs& ka, const RayConst& rc, int lane, int S, bool a
       r[9] = L.sv[SV_NORM][s]; r[10] = L.sv[SV_NORM + 1][s]; r[11] = L.sv[SV_NORM + 2][s];
 #pragma unroll
       for (int c = 0; c < 5; ++c) r[12 + c] = L.sv[SV_WP + c][s];
-      float bf = L.sv[SV_NORM][s] * rc.vd[0] + L.sv[SV_NORM + 1][s] * rc.vd[1] + L.sv[SV_NORM + 2][s] * rc.vd[2];
+      const float* vd = (ka.viewdirs ? ka.viewdirs : ka.directions) + 3 * (size_t)ray;
+      float bf = L.sv[SV_NORM][s] * vd[0] + L.sv[SV_NORM + 1][s] * vd[1] + L.sv[SV_NORM + 2][s] * vd[2];
       bf = fmaxf(bf, 0.f);
       r[17] = bf * bf;                                                     // models.py:1341-1343
     }
@@ -781,50 +839,59 @@ DEVI void resample(const KArgs& ka, int ray, int lane, int nc, int nf, WaveLds& 
 // Kernel: persistent waves, one ray per wave per iteration.
 // ------------------------------------------------------------------------------------------------
 template <class G, int P>
-__global__ __launch_bounds__(64, 1) void render_rays_kernel(const KArgs ka) {
+__global__ __launch_bounds__(64 * WG_WAVES, 1) void render_rays_kernel(const KArgs ka) {
   constexpr int NT = (P == P_BF16) ? 2 : 1;
   using Dm = Dims<G>;
-  __shared__ WaveLds L;
   const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  WaveLds& L = *reinterpret_cast<WaveLds*>(g_smem + BIAS_OFF + bias_bytes<G>() + wave * (int)sizeof(WaveLds));
 
   Pipe<G, P> pipe;
-  const rsrc_t rs_nerf[2] = {make_rsrc(ka.wstream[1], Dm::NERF_FRAGS * frag_bytes(P)),
-                             make_rsrc(ka.wstream[2], Dm::NERF_FRAGS * frag_bytes(P))};
-  const rsrc_t rb_nerf[2] = {make_rsrc(ka.bias[1], Dm::NERF_BIAS_TILES * 128), make_rsrc(ka.bias[2], Dm::NERF_BIAS_TILES * 128)};
-  pipe.ws = make_rsrc(ka.wstream[0], Dm::SHARED_FRAGS * frag_bytes(P));
-  pipe.bs = make_rsrc(ka.bias[0], Dm::SHARED_BIAS_TILES * 128);
+  const rsrc_t rs_nerf[2] = {make_rsrc(ka.wstream[1], Pipe<G, P>::NERF_PAD * frag_bytes(P)),
+                             make_rsrc(ka.wstream[2], Pipe<G, P>::NERF_PAD * frag_bytes(P))};
+  pipe.ws = make_rsrc(ka.wstream[0], Pipe<G, P>::SHARED_PAD * frag_bytes(P));
   pipe.wn = pipe.wn_next = rs_nerf[0];
-  pipe.bn = rb_nerf[0];
   pipe.lane16 = lane * 16;
-  // pipeline prologue: the first DEPTH fragments of the first (coarse) evaluation
-#pragma unroll
-  for (int i = 0; i < Pipe<G, P>::DEPTH; ++i) pipe.issue(i);
-  PIN_VMEM();
+  pipe.wave1k = wave * 1024;
+  pipe.prologue();     // the first NS - 1 stages of the first (coarse) evaluation
   auto set_level = [&](int level, int next_level) {
     pipe.wn = level ? rs_nerf[1] : rs_nerf[0];
-    pipe.bn = level ? rb_nerf[1] : rb_nerf[0];
     pipe.wn_next = next_level ? rs_nerf[1] : rs_nerf[0];
   };
+  {  // padded biases -> LDS, once per workgroup
+    f32x4* dst = reinterpret_cast<f32x4*>(g_smem + BIAS_OFF);
+    constexpr int n0 = Dm::SHARED_BIAS_TILES * 8, n1 = Dm::NERF_BIAS_TILES * 8;     // float4 counts
+    for (int i = threadIdx.x; i < n0; i += 64 * WG_WAVES) dst[i] = reinterpret_cast<const f32x4*>(ka.bias[0])[i];
+    for (int i = threadIdx.x; i < n1; i += 64 * WG_WAVES) dst[n0 + i] = reinterpret_cast<const f32x4*>(ka.bias[1])[i];
+    for (int i = threadIdx.x; i < n1; i += 64 * WG_WAVES) dst[n0 + n1 + i] = reinterpret_cast<const f32x4*>(ka.bias[2])[i];
+    __syncthreads();
+  }
 
-  for (int ray = blockIdx.x; ray < ka.num_rays; ray += gridDim.x) {
+  // The four waves of a workgroup walk the SAME weight stream in lockstep (one barrier per 16 KiB stage),
+  // each on its own ray: ray = 4 * group + wave.  Tail waves re-render the last ray and drop the result.
+  const int groups = (ka.num_rays + WG_WAVES - 1) / WG_WAVES;
+  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const int ray_raw = grp * WG_WAVES + wave;
+    const bool live = ray_raw < ka.num_rays;
+    const int ray = live ? ray_raw : ka.num_rays - 1;
     RayConst rc;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       rc.o[c] = ka.origins[3 * (size_t)ray + c];
       rc.d[c] = ka.directions[3 * (size_t)ray + c];
-      rc.vd[c] = (ka.viewdirs ? ka.viewdirs : ka.directions)[3 * (size_t)ray + c];
     }
     rc.gt_mask = (ka.gt_mask != nullptr) ? ka.gt_mask[ray] : 0.f;
-    const uint32_t wid = (G::HAS_WARP && ka.warp_id != nullptr) ? ka.warp_id[ray] : 0u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      rc.wemb[i] = G::HAS_WARP ? ka.warp_embed[(size_t)wid * 8 + i] : 0.f;   // GLOEmbed (modules.py:336-348)
-      rc.memb[i] = G::HAS_MASK ? ka.mask_embed[(size_t)wid * 8 + i] : 0.f;
-    }
-#pragma unroll
-    for (int f = 0; f < 24; ++f) {                                            // posenc(viewdirs), no window
-      const int band = f / 6, sc = (f % 6) / 3, ch = f % 3;
-      rc.vdenc[f] = sin_cw(fmaf(rc.vd[ch], (float)(1 << band), sc ? 1.57079637f : 0.0f));
+    {  // per-ray constants -> LDS: GLO rows (modules.py:336-348) and posenc(viewdirs) (models.py:401-405, no window)
+      const uint32_t wid = (G::HAS_WARP && ka.warp_id != nullptr) ? ka.warp_id[ray] : 0u;
+      if (lane < 8) {
+        L.rayc[RC_WEMB + lane] = G::HAS_WARP ? ka.warp_embed[(size_t)wid * 8 + lane] : 0.f;
+        L.rayc[RC_MEMB + lane] = G::HAS_MASK ? ka.mask_embed[(size_t)wid * 8 + lane] : 0.f;
+      }
+      if (lane < 24) {
+        const int band = lane / 6, sc = (lane % 6) / 3, ch = lane % 3;
+        const float vdc = (ka.viewdirs ? ka.viewdirs : ka.directions)[3 * (size_t)ray + ch];
+        L.rayc[RC_VDENC + lane] = sin_cw(fmaf(vdc, (float)(1 << band), sc ? 1.57079637f : 0.0f));
+      }
     }
 
     // ---- coarse z (model_utils.py:75-89) ----
@@ -858,13 +925,13 @@ __global__ __launch_bounds__(64, 1) void render_rays_kernel(const KArgs ka) {
     // ---- coarse level ----
     for (int sb = 0; sb < nc; sb += 32 * NT) {
       set_level(0, (sb + 32 * NT < nc) ? 0 : (nf > 0 ? 1 : 0));
-      eval_batch<G, P, NT>(ka, rc, pipe, lane, sb, nc, L);
+      eval_batch<G, P, NT>(ka, rc, pipe, 0, lane, sb, nc, L);
     }
     WAVE_SYNC();
     {
-      float* rec = (nf > 0) ? ka.ray_coarse : ka.ray_fine;
-      float* smp = (nf > 0) ? ka.smp_coarse : ka.smp_fine;
-      composite<G>(ka, rc, lane, nc, ka.sample_at_infinity != 0, L,
+      float* rec = live ? ((nf > 0) ? ka.ray_coarse : ka.ray_fine) : nullptr;
+      float* smp = live ? ((nf > 0) ? ka.smp_coarse : ka.smp_fine) : nullptr;
+      composite<G>(ka, rc, ray, lane, nc, ka.sample_at_infinity != 0, L,
                    rec ? rec + (size_t)ray * RAY_REC : nullptr,
                    smp ? smp + (size_t)ray * nc * SAMPLE_REC : nullptr);
     }
@@ -876,12 +943,12 @@ __global__ __launch_bounds__(64, 1) void render_rays_kernel(const KArgs ka) {
       const int n = nc + nf;
       for (int sb = 0; sb < n; sb += 32 * NT) {
         set_level(1, (sb + 32 * NT < n) ? 1 : 0);
-        eval_batch<G, P, NT>(ka, rc, pipe, lane, sb, n, L);
+        eval_batch<G, P, NT>(ka, rc, pipe, 1, lane, sb, n, L);
       }
       WAVE_SYNC();
-      composite<G>(ka, rc, lane, n, ka.sample_at_infinity != 0, L,
-                   ka.ray_fine ? ka.ray_fine + (size_t)ray * RAY_REC : nullptr,
-                   ka.smp_fine ? ka.smp_fine + (size_t)ray * n * SAMPLE_REC : nullptr);
+      composite<G>(ka, rc, ray, lane, n, ka.sample_at_infinity != 0, L,
+                   (live && ka.ray_fine) ? ka.ray_fine + (size_t)ray * RAY_REC : nullptr,
+                   (live && ka.smp_fine) ? ka.smp_fine + (size_t)ray * n * SAMPLE_REC : nullptr);
       WAVE_SYNC();
     }
   }
@@ -897,6 +964,13 @@ __global__ __launch_bounds__(64, 1) void render_rays_kernel(const KArgs ka) {
 #define NERFDS_CAT(a, b) NERFDS_CAT2(a, b)
 
 extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::KArgs& ka, int grid, void* stream) {
-  hipLaunchKernelGGL((nerfds::render_rays_kernel<nerfds::NERFDS_GRAPH, nerfds::NERFDS_PREC>), dim3(grid), dim3(64), 0,
-                     static_cast<hipStream_t>(stream), ka);
+  constexpr int lds = nerfds::BIAS_OFF + nerfds::bias_bytes<nerfds::NERFDS_GRAPH>() + nerfds::WG_WAVES * (int)sizeof(nerfds::WaveLds);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  auto kern = nerfds::render_rays_kernel<nerfds::NERFDS_GRAPH, nerfds::NERFDS_PREC>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nerfds::WG_WAVES), lds, static_cast<hipStream_t>(stream), ka);
 }

@@ -55,6 +55,12 @@ def _pack(cfg, params, which, level, prec):
   return E.Stream(w[:nb], b[:nf], prec)
 
 
+def _assert_consumed(s):
+  """Whole stream consumed in order; what remains is the zero padding to a whole 16 KiB LDS stage."""
+  rest = s.w[s.fi * s.fb:]
+  assert len(s.w) % 16384 == 0 and len(rest) < 16384 and not rest.any() and s.bt * 32 == len(s.bias)
+
+
 def _unchunk_tiles(ch):
   """activation chunks [2*T, 2, 8, N] (tile order) -> [N, 32*T] features."""
   T = ch.shape[0] // 2
@@ -95,7 +101,7 @@ def test_shared_nets_stream_matches_oracle(prec, tol):
   got = E.head(s, [x], 2)
   ref = O.mlp(P['hyper_sheet_mlp']['MLP_0'], T(f), 6, (4,), output_channels=2).numpy().T
   assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
-  assert s.fi * s.fb == len(s.w) and s.bt * 32 == len(s.bias)            # whole stream consumed, in order
+  _assert_consumed(s)
 
 
 @pytest.mark.parametrize('graph', ['nerf_ds', 'static'])
@@ -122,7 +128,7 @@ def test_nerf_mlp_stream_matches_oracle(graph, level):
   ins = [bott, trunk, cond] if cfg.use_x_in_rgb_condition else [bott, cond]
   hid = E.dense(s, ins, 4, True)
   rgb = E.head(s, [hid], 3)
-  assert s.fi * s.fb == len(s.w) and s.bt * 32 == len(s.bias)
+  _assert_consumed(s)
 
   t_ref = O.mlp(P['trunk_mlp'], T(f), 8, (4,))
   b_ref = O.dense(P['bottleneck'], t_ref)
