@@ -63,7 +63,20 @@ template <> struct WFrag<P_BF16> { bf16x8 v; };
 template <> struct WFrag<P_BF16X3> { bf16x8 hi, lo; };
 template <> struct WFrag<P_F32> { f32x4 a, b; };
 
+// relu on raw float bits: signed-integer max with 0 (one v_max_i32; fmaxf costs a canonicalising v_max on top).
+DEVI float relu_f(float x) {
+  const int i = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
 template <int P> DEVI void make_chunk(Chunk<P>& c, const float (&x)[8]);
+// Accumulator registers -> next layer's B operand, with optional ReLU.
+template <int P, bool RELU> DEVI void make_act_chunk(Chunk<P>& c, const float (&x)[8]) {
+  // (a packed v_pk_max_i16 on the converted pairs would be cheaper still, but hipcc then un-pairs the v_cvt_pk_bf16_f32)
+  float y[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = RELU ? relu_f(x[i]) : x[i];
+  make_chunk<P>(c, y);
+}
 template <> DEVI void make_chunk<P_BF16>(Chunk<P_BF16>& c, const float (&x)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) c.v[i] = (__bf16)x[i];
@@ -130,8 +143,21 @@ template <int P> DEVI void mma(f32x16& acc, const WFrag<P>& w, const Chunk<P>& c
 // STAGE_BYTES (graphs.h): one ring stage = 16 bf16 fragments (8 in the 2-part precisions)
 constexpr int NUM_STAGES = 4;          // ring depth
 constexpr int RING_BYTES = NUM_STAGES * STAGE_BYTES;
-constexpr int WG_WAVES = 4;            // one 512-VGPR wave per SIMD
-// LDS map: [0, RING_BYTES) weight ring | padded fp32 biases (shared, coarse NerfMLP, fine NerfMLP) | WG_WAVES x WaveLds
+constexpr int RAYS_PER_WG = 4;         // rays in flight per workgroup (each with its own RayLds block)
+// Work shape per precision.  NT = N-tiles (32 samples) per wave and evaluation; SPLIT = waves that share one ray's
+// batch of 32 * NT * SPLIT samples.  bf16: SPLIT 2 -> 8 waves, two per SIMD at 256 registers each, so one wave's
+// LDS/epilogue latency is covered by the other wave's MFMAs; the 2-part precisions need >256 registers of
+// operands and run one 512-register wave per SIMD.
+#ifndef NERFDS_BF16_NT
+#define NERFDS_BF16_NT 1
+#endif
+#ifndef NERFDS_BF16_SPLIT
+#define NERFDS_BF16_SPLIT 2
+#endif
+template <int P> struct Tune { static constexpr int NT = 1, SPLIT = 1; };
+template <> struct Tune<P_BF16> { static constexpr int NT = NERFDS_BF16_NT, SPLIT = NERFDS_BF16_SPLIT; };
+template <int P> constexpr int wg_waves() { return RAYS_PER_WG * Tune<P>::SPLIT; }
+// LDS map: [0, RING_BYTES) weight ring | padded fp32 biases (shared, coarse NerfMLP, fine NerfMLP) | RAYS_PER_WG x WaveLds
 constexpr int BIAS_OFF = RING_BYTES;
 template <class G> constexpr int bias_bytes() { return (Dims<G>::SHARED_BIAS_TILES + 2 * Dims<G>::NERF_BIAS_TILES) * 128; }
 
@@ -144,7 +170,13 @@ template <class G, int P> struct Pipe {
   static constexpr int SHARED_PAD = pad_frags(Dm::SHARED_FRAGS, P), NERF_PAD = pad_frags(Dm::NERF_FRAGS, P);
   static constexpr int SHARED_STAGES = SHARED_PAD / GF, USED_STAGES = (SHARED_PAD + NERF_PAD) / GF;
   static constexpr int STAGES = cdiv(USED_STAGES, NS) * NS;       // per evaluation, padded so ring slots survive the wrap
-  static constexpr int PIECES = STAGE_BYTES / 1024 / WG_WAVES;    // 1 KiB LDS-DMA pieces per wave per stage
+  static constexpr int WAVES = wg_waves<P>();
+  static constexpr int PIECES = STAGE_BYTES / 1024 / WAVES;       // 1 KiB LDS-DMA pieces per wave per stage
+  // LDS -> register prefetch distance in fragments: a ds_read_b128 takes ~100+ cycles to return, a bf16 fragment
+  // is consumed in 64 MFMA cycles, so the reads must run several fragments ahead of the MFMAs.
+  static constexpr int DEPTH = (P == P_BF16) ? 4 : 2;
+  static_assert(GF % DEPTH == 0, "ring slot = fragment index mod DEPTH");
+  WFrag<P> ring[DEPTH];
   rsrc_t ws;        // shared stream
   rsrc_t wn;        // NerfMLP stream of the level being evaluated
   rsrc_t wn_next;   // NerfMLP stream of the level evaluated next (wrap-around prefetch)
@@ -161,16 +193,30 @@ template <class G, int P> struct Pipe {
     const int base = (shared ? tt : tt - SHARED_STAGES) * STAGE_BYTES;
 #pragma unroll
     for (int k = 0; k < PIECES; ++k) {
-      const int off = WG_WAVES * k * 1024 + wave1k;
+      // readfirstlane makes the uniformity of the scalar operands provable: without it hipcc may keep them in
+      // VGPRs under SGPR pressure and wrap every LDS-DMA in a waterfall loop (cdna guide T20).
+      const int off = __builtin_amdgcn_readfirstlane(WAVES * k * 1024 + wave1k);
       auto dst = (__attribute__((address_space(3))) void*)(g_smem + slot * STAGE_BYTES + off);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(shared ? ws : (wrap ? wn_next : wn), dst, 16, lane16, base + off, 0, 0);
     }
   }
   // Start of stage s: everything issued so far has landed (it was issued >= one stage ago), every wave is
   // done with stage s - 1, whose slot is refilled with stage s + NS - 1.
+  static constexpr int loads_of(int t) { return (t % STAGES) < USED_STAGES ? PIECES : 0; }
   DEVI void boundary(int s) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
+    // Stage s must have landed; the LDS-DMA of stages s+1 .. s+NS-2 (issued at the last NS-2 boundaries) stays in
+    // flight.  vmcnt counts in order, so other VMEM traffic issued since can only make this wait longer, never shorter.
+    int inflight = 0;
+#pragma unroll
+    for (int t = s + 1; t <= s + NS - 2; ++t) inflight += loads_of(t);
+    // s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt[6:4] = 7 (don't wait) | lgkmcnt[11:8] = 0
+#ifdef NERFDS_DRAIN_ALL
+    inflight = 0;
+#endif
+    if (inflight == 2 * PIECES) asm volatile("s_waitcnt %0" ::"n"(0x70 | (2 * PIECES)) : "memory");
+    else if (inflight == PIECES) asm volatile("s_waitcnt %0" ::"n"(0x70 | PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // raw barrier: __syncthreads() would drain vmcnt to 0 while LDS-DMA is in flight
     issue_stage(s + NS - 1);
   }
   DEVI void prologue() {
@@ -192,6 +238,11 @@ template <class G, int P> struct Pipe {
     }
     return w;
   }
+  DEVI void begin_stage(int i0) {   // i0: first fragment of the stage
+    boundary(i0 / GF);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) ring[d] = frag(i0 + d);
+  }
   DEVI void finish_eval() {    // boundaries of the hole stages keep the barrier count and the ring in step
 #pragma unroll
     for (int s = USED_STAGES; s < STAGES; ++s) boundary(s);
@@ -206,9 +257,11 @@ struct Cursor {
 // Bias of a tile for this lane, as an MFMA C operand: register r <-> row (r & 3) + 8 (r >> 2) + 4 h.
 DEVI f32x16 load_bias(int boff, int h) {
   f32x16 bv;
+  int hoff = 16 * h;
+  asm volatile("" : "+v"(hoff));      // each accumulator gets its own ds_read_b128 x4 (no CSE -> no register copies)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(g_smem + boff + 32 * g + 16 * h);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(g_smem + boff + 32 * g + hoff);
     bv[4 * g + 0] = b[0]; bv[4 * g + 1] = b[1]; bv[4 * g + 2] = b[2]; bv[4 * g + 3] = b[3];
   }
   return bv;
@@ -219,10 +272,11 @@ DEVI void accum(f32x16 (&acc)[NT], Pipe<G, P>& pipe, Cursor& cur, const Chunk<P>
 #pragma unroll
   for (int kc = 0; kc < K; ++kc) {
     const int i = cur.fi + kc;
-    if (i % Pipe<G, P>::GF == 0) pipe.boundary(i / Pipe<G, P>::GF);
-    const WFrag<P> w = pipe.frag(i);
+    using PP = Pipe<G, P>;
+    if (i % PP::GF == 0) pipe.begin_stage(i);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) mma<P>(acc[nt], w, in[nt][kc]);
+    for (int nt = 0; nt < NT; ++nt) mma<P>(acc[nt], pipe.ring[i % PP::DEPTH], in[nt][kc]);
+    if (i % PP::GF + PP::DEPTH < PP::GF) pipe.ring[i % PP::DEPTH] = pipe.frag(i + PP::DEPTH);
   }
   cur.fi += K;
 }
@@ -233,22 +287,17 @@ template <class G, int P, int NT, int OT, bool RELU, class... Ins>
 DEVI void dense(Pipe<G, P>& pipe, Cursor& cur, int h, Chunk<P> (&out)[NT][2 * OT], const Ins&... ins) {
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot) {
-    const f32x16 bv = load_bias(cur.boff + 128 * ot, h);
     f32x16 acc[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = bv;
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = load_bias(cur.boff + 128 * ot, h);
     (accum<G, P, NT>(acc, pipe, cur, ins), ...);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float x0[8], x1[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        // relu as one v_med3_f32 (fmaxf would add a canonicalising v_max per element in IEEE mode)
-        x0[i] = RELU ? __builtin_amdgcn_fmed3f(acc[nt][i], 0.f, __builtin_inff()) : acc[nt][i];
-        x1[i] = RELU ? __builtin_amdgcn_fmed3f(acc[nt][8 + i], 0.f, __builtin_inff()) : acc[nt][8 + i];
-      }
-      make_chunk<P>(out[nt][2 * ot], x0);
-      make_chunk<P>(out[nt][2 * ot + 1], x1);
+      for (int i = 0; i < 8; ++i) { x0[i] = acc[nt][i]; x1[i] = acc[nt][8 + i]; }
+      make_act_chunk<P, RELU>(out[nt][2 * ot], x0);
+      make_act_chunk<P, RELU>(out[nt][2 * ot + 1], x1);
     }
   }
   cur.boff += 128 * OT;
@@ -257,9 +306,8 @@ DEVI void dense(Pipe<G, P>& pipe, Cursor& cur, int h, Chunk<P> (&out)[NT][2 * OT
 // Output head (<= 16 logical outputs, duplicated in both lane halves by the packer): logical output j = acc[j].
 template <class G, int P, int NT, class... Ins>
 DEVI void head(Pipe<G, P>& pipe, Cursor& cur, int h, f32x16 (&acc)[NT], const Ins&... ins) {
-  const f32x16 bv = load_bias(cur.boff, h);
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) acc[nt] = bv;
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = load_bias(cur.boff, h);
   (accum<G, P, NT>(acc, pipe, cur, ins), ...);
   cur.boff += 128;
 }
@@ -408,6 +456,7 @@ DEVI void rodrigues(float (&R)[9], const float (&w)[3], float st, float omc) {
 // ------------------------------------------------------------------------------------------------
 template <class G, int P, int NT>
 DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int level, int lane, int s_base, int S, WaveLds& L) {
+  // s_base already includes this wave's share of a split batch (32 * NT * q)
   using D = Dims<G>;
   const int h = lane >> 5, ln = lane & 31;
   auto sample_of = [&](int nt) { return s_base + 32 * nt + ln; };
@@ -839,12 +888,16 @@ DEVI void resample(const KArgs& ka, int ray, int lane, int nc, int nf, WaveLds& 
 // Kernel: persistent waves, one ray per wave per iteration.
 // ------------------------------------------------------------------------------------------------
 template <class G, int P>
-__global__ __launch_bounds__(64 * WG_WAVES, 1) void render_rays_kernel(const KArgs ka) {
-  constexpr int NT = (P == P_BF16) ? 2 : 1;
+__global__ __launch_bounds__(64 * wg_waves<P>(), Tune<P>::SPLIT) void render_rays_kernel(const KArgs ka) {
+  constexpr int NT = Tune<P>::NT, SPLIT = Tune<P>::SPLIT, WAVES = wg_waves<P>(), BATCH = 32 * NT * SPLIT;
   using Dm = Dims<G>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  WaveLds& L = *reinterpret_cast<WaveLds*>(g_smem + BIAS_OFF + bias_bytes<G>() + wave * (int)sizeof(WaveLds));
+  const int slot = wave / SPLIT, q = wave % SPLIT;        // ray slot in the workgroup, share of the ray's batch
+  WaveLds& L = *reinterpret_cast<WaveLds*>(g_smem + BIAS_OFF + bias_bytes<G>() + slot * (int)sizeof(WaveLds));
+  // Waves that share a ray meet at workgroup barriers around the per-ray phases (every wave executes the same
+  // barrier sequence, so these interleave consistently with the per-stage barriers of the weight pipe).
+  auto ray_sync = [&]() { if constexpr (SPLIT > 1) __syncthreads(); else WAVE_SYNC(); };
 
   Pipe<G, P> pipe;
   const rsrc_t rs_nerf[2] = {make_rsrc(ka.wstream[1], Pipe<G, P>::NERF_PAD * frag_bytes(P)),
@@ -861,19 +914,19 @@ __global__ __launch_bounds__(64 * WG_WAVES, 1) void render_rays_kernel(const KAr
   {  // padded biases -> LDS, once per workgroup
     f32x4* dst = reinterpret_cast<f32x4*>(g_smem + BIAS_OFF);
     constexpr int n0 = Dm::SHARED_BIAS_TILES * 8, n1 = Dm::NERF_BIAS_TILES * 8;     // float4 counts
-    for (int i = threadIdx.x; i < n0; i += 64 * WG_WAVES) dst[i] = reinterpret_cast<const f32x4*>(ka.bias[0])[i];
-    for (int i = threadIdx.x; i < n1; i += 64 * WG_WAVES) dst[n0 + i] = reinterpret_cast<const f32x4*>(ka.bias[1])[i];
-    for (int i = threadIdx.x; i < n1; i += 64 * WG_WAVES) dst[n0 + n1 + i] = reinterpret_cast<const f32x4*>(ka.bias[2])[i];
+    for (int i = threadIdx.x; i < n0; i += 64 * WAVES) dst[i] = reinterpret_cast<const f32x4*>(ka.bias[0])[i];
+    for (int i = threadIdx.x; i < n1; i += 64 * WAVES) dst[n0 + i] = reinterpret_cast<const f32x4*>(ka.bias[1])[i];
+    for (int i = threadIdx.x; i < n1; i += 64 * WAVES) dst[n0 + n1 + i] = reinterpret_cast<const f32x4*>(ka.bias[2])[i];
     __syncthreads();
   }
 
-  // The four waves of a workgroup walk the SAME weight stream in lockstep (one barrier per 16 KiB stage),
-  // each on its own ray: ray = 4 * group + wave.  Tail waves re-render the last ray and drop the result.
-  const int groups = (ka.num_rays + WG_WAVES - 1) / WG_WAVES;
+  // All waves of a workgroup walk the SAME weight stream in lockstep (one barrier per 16 KiB stage); ray slot s
+  // renders ray 4 * group + s.  Tail slots re-render the last ray and drop the result.
+  const int groups = (ka.num_rays + RAYS_PER_WG - 1) / RAYS_PER_WG;
   for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-    const int ray_raw = grp * WG_WAVES + wave;
-    const bool live = ray_raw < ka.num_rays;
-    const int ray = live ? ray_raw : ka.num_rays - 1;
+    const int ray_raw = grp * RAYS_PER_WG + slot;
+    const bool live = (ray_raw < ka.num_rays) && (q == 0);     // the q == 0 wave of a ray owns its outputs
+    const int ray = (ray_raw < ka.num_rays) ? ray_raw : ka.num_rays - 1;
     RayConst rc;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -881,7 +934,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 1) void render_rays_kernel(const KAr
       rc.d[c] = ka.directions[3 * (size_t)ray + c];
     }
     rc.gt_mask = (ka.gt_mask != nullptr) ? ka.gt_mask[ray] : 0.f;
-    {  // per-ray constants -> LDS: GLO rows (modules.py:336-348) and posenc(viewdirs) (models.py:401-405, no window)
+    if (q == 0) {  // per-ray constants -> LDS: GLO rows (modules.py:336-348) and posenc(viewdirs) (models.py:401-405, no window)
       const uint32_t wid = (G::HAS_WARP && ka.warp_id != nullptr) ? ka.warp_id[ray] : 0u;
       if (lane < 8) {
         L.rayc[RC_WEMB + lane] = G::HAS_WARP ? ka.warp_embed[(size_t)wid * 8 + lane] : 0.f;
@@ -898,7 +951,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 1) void render_rays_kernel(const KAr
     const int nc = ka.nc, nf = ka.nf;
     for (int j = 0; j * 64 < nc; ++j) {
       const int i = lane + 64 * j;
-      if (i < nc) {
+      if (i < nc && q == 0) {
         auto zlin = [&](int q) {
           const float t = (nc > 1) ? (float)q / (float)(nc - 1) : 0.f;
           return ka.near_ * (1.0f - t) + ka.far_ * t;
@@ -920,36 +973,38 @@ __global__ __launch_bounds__(64 * WG_WAVES, 1) void render_rays_kernel(const KAr
         L.zs[i] = z;
       }
     }
-    WAVE_SYNC();
+    ray_sync();
 
     // ---- coarse level ----
-    for (int sb = 0; sb < nc; sb += 32 * NT) {
-      set_level(0, (sb + 32 * NT < nc) ? 0 : (nf > 0 ? 1 : 0));
-      eval_batch<G, P, NT>(ka, rc, pipe, 0, lane, sb, nc, L);
+    for (int sb = 0; sb < nc; sb += BATCH) {
+      set_level(0, (sb + BATCH < nc) ? 0 : (nf > 0 ? 1 : 0));
+      eval_batch<G, P, NT>(ka, rc, pipe, 0, lane, sb + 32 * NT * q, nc, L);
     }
-    WAVE_SYNC();
-    {
+    ray_sync();
+    if (q == 0) {
       float* rec = live ? ((nf > 0) ? ka.ray_coarse : ka.ray_fine) : nullptr;
       float* smp = live ? ((nf > 0) ? ka.smp_coarse : ka.smp_fine) : nullptr;
       composite<G>(ka, rc, ray, lane, nc, ka.sample_at_infinity != 0, L,
                    rec ? rec + (size_t)ray * RAY_REC : nullptr,
                    smp ? smp + (size_t)ray * nc * SAMPLE_REC : nullptr);
+      WAVE_SYNC();
+      if (nf > 0) resample(ka, ray, lane, nc, nf, L);
     }
-    WAVE_SYNC();
+    ray_sync();
 
     // ---- fine level ----
     if (nf > 0) {
-      resample(ka, ray, lane, nc, nf, L);
       const int n = nc + nf;
-      for (int sb = 0; sb < n; sb += 32 * NT) {
-        set_level(1, (sb + 32 * NT < n) ? 1 : 0);
-        eval_batch<G, P, NT>(ka, rc, pipe, 1, lane, sb, n, L);
+      for (int sb = 0; sb < n; sb += BATCH) {
+        set_level(1, (sb + BATCH < n) ? 1 : 0);
+        eval_batch<G, P, NT>(ka, rc, pipe, 1, lane, sb + 32 * NT * q, n, L);
       }
-      WAVE_SYNC();
-      composite<G>(ka, rc, ray, lane, n, ka.sample_at_infinity != 0, L,
-                   (live && ka.ray_fine) ? ka.ray_fine + (size_t)ray * RAY_REC : nullptr,
-                   (live && ka.smp_fine) ? ka.smp_fine + (size_t)ray * n * SAMPLE_REC : nullptr);
-      WAVE_SYNC();
+      ray_sync();
+      if (q == 0)
+        composite<G>(ka, rc, ray, lane, n, ka.sample_at_infinity != 0, L,
+                     (live && ka.ray_fine) ? ka.ray_fine + (size_t)ray * RAY_REC : nullptr,
+                     (live && ka.smp_fine) ? ka.smp_fine + (size_t)ray * n * SAMPLE_REC : nullptr);
+      ray_sync();
     }
   }
 }
@@ -964,13 +1019,14 @@ __global__ __launch_bounds__(64 * WG_WAVES, 1) void render_rays_kernel(const KAr
 #define NERFDS_CAT(a, b) NERFDS_CAT2(a, b)
 
 extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::KArgs& ka, int grid, void* stream) {
-  constexpr int lds = nerfds::BIAS_OFF + nerfds::bias_bytes<nerfds::NERFDS_GRAPH>() + nerfds::WG_WAVES * (int)sizeof(nerfds::WaveLds);
+  constexpr int lds = nerfds::BIAS_OFF + nerfds::bias_bytes<nerfds::NERFDS_GRAPH>() + nerfds::RAYS_PER_WG * (int)sizeof(nerfds::WaveLds);
   static_assert(lds <= 160 * 1024, "LDS budget");
+  static_assert(nerfds::NUM_STAGES == 4 && 2 * nerfds::Pipe<nerfds::NERFDS_GRAPH, nerfds::NERFDS_PREC>::PIECES < 16, "vmcnt arithmetic in Pipe::boundary");
   static bool attr_set = false;
   auto kern = nerfds::render_rays_kernel<nerfds::NERFDS_GRAPH, nerfds::NERFDS_PREC>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nerfds::WG_WAVES), lds, static_cast<hipStream_t>(stream), ka);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nerfds::wg_waves<nerfds::NERFDS_PREC>()), lds, static_cast<hipStream_t>(stream), ka);
 }
