@@ -31,6 +31,7 @@ struct KArgs {
   float* smp_fine;
   float* smp_coarse;
   int num_rays;
+  int num_embeds;            // rows of the GLO tables (ids are clamped like a jnp gather)
   int nc, nf;
   int stratified;
   int sample_at_infinity;

@@ -342,6 +342,7 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   ka.mask_embed = static_cast<const float*>(ctx->mask_embed.p);
   ka.ray_fine = out->ray_fine; ka.ray_coarse = out->ray_coarse; ka.smp_fine = out->sample_fine; ka.smp_coarse = out->sample_coarse;
   ka.num_rays = (int)rays->num_rays;
+  ka.num_embeds = ctx->cfg.num_warp_embeds > 0 ? ctx->cfg.num_warp_embeds : 1;
   ka.nc = ctx->cfg.num_coarse_samples; ka.nf = ctx->cfg.num_fine_samples;
   ka.stratified = extra->use_stratified_sampling;
   ka.sample_at_infinity = ctx->cfg.use_sample_at_infinity;

@@ -201,8 +201,7 @@ class NerfModel:
     if cfg.use_warp:
       ids = rays_dict['metadata']['warp']
       ids = ids if isinstance(ids, torch.Tensor) else torch.as_tensor(np.asarray(ids).astype(np.int64))
-      if ids.numel() and (int(ids.max()) >= cfg.num_warp_embeds or int(ids.min()) < 0):
-        raise IndexError('metadata["warp"] id out of range of the GLO table')
+      # out-of-range ids are clamped in the kernel, as a jnp gather does (nn.Embed, modules.py:331-348)
       warp_id = ids.to(dev).reshape(-1).to(torch.int32).contiguous()   # uint32 bit pattern for ids < 2^31
     gt_mask = None
     if rays_dict.get('mask') is not None:

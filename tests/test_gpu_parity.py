@@ -179,10 +179,11 @@ def test_edge_cases_empty_single_and_leading_shape():
   b = m.apply({'params': params}, hw, EXTRA, use_predicted_norm=True, t_rand=np.full((6, 8), .5), u_rand=np.full((6, 8), .5),
               precision='f32')['fine']['rgb'].cpu().numpy()
   assert b.shape == (2, 3, 3) and np.array_equal(a.reshape(2, 3, 3), b)          # deterministic, shape preserved
-  with pytest.raises(IndexError):
-    bad = dict(rays)
-    bad['metadata'] = {'warp': np.full((6, 1), 7)}
-    m.apply({'params': params}, bad, EXTRA, use_predicted_norm=True)
+  big, last = dict(rays), dict(rays)                 # out-of-range GLO ids clamp to the last row, like a jnp gather
+  big['metadata'], last['metadata'] = {'warp': np.full((6, 1), 7)}, {'warp': np.full((6, 1), 1)}
+  kw = dict(use_predicted_norm=True, t_rand=np.full((6, 8), .5), u_rand=np.full((6, 8), .5), precision='f32')
+  assert torch.equal(m.apply({'params': params}, big, EXTRA, **kw)['fine']['rgb'],
+                     m.apply({'params': params}, last, EXTRA, **kw)['fine']['rgb'])
   with pytest.raises(ValueError):
     m.apply({'params': params}, rays, EXTRA, use_predicted_norm=False)
 
