@@ -84,13 +84,15 @@ template <class G> struct Dims {
                                            (G::HAS_WARP ? mlp_bias_tiles(G::WARP_DEPTH, G::WARP_W, true) : 0) +
                                            (G::HAS_HYPER ? mlp_bias_tiles(G::HYP_DEPTH, G::HYP_W, true) : 0);
   static constexpr int TW16 = G::TRUNK_W / 16, TW32 = G::TRUNK_W / 32;
+  // The bottleneck Dense has no activation (modules.py:255), so it is folded into rgb hidden_0 by the packer:
+  //   rgb_pre = trunk_out @ (W_bn @ W_rgb[bottleneck rows] + W_rgb[trunk_out rows]) + cond @ W_rgb[cond rows] + b'
+  // i.e. no bottleneck layer in the stream and one 256-wide segment (instead of two) in rgb hidden_0.
   static constexpr int NERF_FRAGS =
       mlp_frags(G::TRUNK_DEPTH, G::TRUNK_W, TRUNK_KC, G::TRUNK_SKIP, false) +   // trunk
-      TW32 * TW16 +                                                             // bottleneck
       TW16 +                                                                    // alpha head
-      (G::RGB_W / 32) * (TW16 + (G::X_IN_RGB ? TW16 : 0) + COND_KC) +           // rgb hidden_0
+      (G::RGB_W / 32) * (TW16 + COND_KC) +                                      // rgb hidden_0 (bottleneck folded in)
       G::RGB_W / 16;                                                            // rgb head
-  static constexpr int NERF_BIAS_TILES = G::TRUNK_DEPTH * TW32 + TW32 + 1 + G::RGB_W / 32 + 1;
+  static constexpr int NERF_BIAS_TILES = G::TRUNK_DEPTH * TW32 + 1 + G::RGB_W / 32 + 1;
 };
 
 }  // namespace nerfds

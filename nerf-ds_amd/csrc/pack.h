@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <vector>
 
 #include "graphs.h"
@@ -185,29 +186,44 @@ template <class G> void pack_nerf(StreamWriter& sw, const NerfNet& n) {
   using D = Dims<G>;
   constexpr int TW = G::TRUNK_W;
   emit_mlp(sw, n.trunk, G::TRUNK_DEPTH, TW, D::TRUNK_IN, D::TRUNK_KC, G::TRUNK_SKIP);
-  {  // bottleneck (modules.py:255)
-    std::vector<int> rows;
-    rows_tile(rows, TW, 0);
-    sw.emit(plain_layer(n.bottleneck, std::move(rows), TW));
-  }
   {  // alpha head on trunk_output (modules.py:273-274)
     std::vector<int> rows;
     rows_tile(rows, TW, 0);
     sw.emit(head_layer(n.alpha, std::move(rows)));
   }
-  {  // rgb hidden_0.  Reference row order (modules.py:296-310): [bottleneck TW | viewdir 6*VD | trunk_output TW (if X_IN_RGB) | normal 6*NM]
-     // Kernel K order: [bottleneck tiles | trunk_output tiles | cond chunks = viewdir ++ normal]
+  {  // rgb hidden_0 with the (activation-free, modules.py:255) bottleneck Dense folded in.
+     // Reference (modules.py:296-310): rgb_pre = [bottleneck TW | viewdir 6*VD | trunk_output TW (if X_IN_RGB) | normal 6*NM] @ K + b
+     //   with bottleneck = trunk_output @ Wb + bb.  Hence, with F = Wb @ K[bottleneck rows] (+ K[trunk_output rows]):
+     //   rgb_pre = trunk_output @ F + [viewdir | normal] @ K[cond rows] + (b + bb @ K[bottleneck rows]).
+     // Kernel K order: [trunk_output tiles | cond chunks = viewdir ++ normal]; virtual rows 0..TW-1 = F, TW.. = cond.
     constexpr int VD = 6 * G::VD_BANDS, NM = 6 * G::NM_BANDS;
     constexpr int row_vd = TW, row_x = TW + VD, row_nm = TW + VD + (G::X_IN_RGB ? TW : 0);
+    const DenseView K = n.rgb_hidden[0], B = n.bottleneck;
+    const int W = G::RGB_W;
+    auto fused = std::make_shared<std::vector<float>>((size_t)(TW + VD + NM) * W);
+    auto fbias = std::make_shared<std::vector<float>>(W);
+    for (int c = 0; c < W; ++c) {
+      for (int r = 0; r < TW; ++r) {
+        double acc = G::X_IN_RGB ? (double)K.W(row_x + r, c) : 0.0;
+        for (int k = 0; k < TW; ++k) acc += (double)B.W(r, k) * (double)K.W(k, c);
+        (*fused)[(size_t)r * W + c] = (float)acc;
+      }
+      for (int q = 0; q < VD; ++q) (*fused)[(size_t)(TW + q) * W + c] = K.W(row_vd + q, c);
+      for (int q = 0; q < NM; ++q) (*fused)[(size_t)(TW + VD + q) * W + c] = K.W(row_nm + q, c);
+      double bacc = K.bias ? (double)K.bias[c] : 0.0;
+      for (int k = 0; k < TW; ++k) bacc += (double)(B.bias ? B.bias[k] : 0.f) * (double)K.W(k, c);
+      (*fbias)[c] = (float)bacc;
+    }
     std::vector<int> rows;
     rows_tile(rows, TW, 0);
-    if (G::X_IN_RGB) rows_tile(rows, TW, row_x);
-    rows_linear(rows, D::COND_KC, [&](int s) {
-      if (s < VD) return row_vd + s;
-      if (s < VD + NM) return row_nm + (s - VD);
-      return -1;
-    });
-    sw.emit(plain_layer(n.rgb_hidden[0], std::move(rows), G::RGB_W));
+    rows_linear(rows, D::COND_KC, [&](int s) { return s < VD + NM ? TW + s : -1; });
+    Layer L;
+    L.rows = std::move(rows);
+    L.n_tiles = W / 32;
+    L.n_out = W;
+    L.W = [fused, W](int r, int c) { return (*fused)[(size_t)r * W + c]; };
+    L.B = [fbias](int c) { return (*fbias)[c]; };
+    sw.emit(L);
   }
   {  // rgb head
     std::vector<int> rows;

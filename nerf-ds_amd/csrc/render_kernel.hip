@@ -175,7 +175,7 @@ template <class G, int P> struct Pipe {
   // LDS -> register prefetch distance in fragments: a ds_read_b128 takes ~100+ cycles to return, a bf16 fragment
   // is consumed in 64 MFMA cycles, so the reads must run several fragments ahead of the MFMAs.
   static constexpr int DEPTH = (P == P_BF16) ? 4 : 2;
-  static_assert(GF % DEPTH == 0, "ring slot = fragment index mod DEPTH");
+  static_assert(GF % DEPTH == 0 && DEPTH <= GF, "ring slot = fragment index mod DEPTH; prefetch reaches at most one stage ahead");
   WFrag<P> ring[DEPTH];
   rsrc_t ws;        // shared stream
   rsrc_t wn;        // NerfMLP stream of the level being evaluated
@@ -200,21 +200,17 @@ template <class G, int P> struct Pipe {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(shared ? ws : (wrap ? wn_next : wn), dst, 16, lane16, base + off, 0, 0);
     }
   }
-  // Start of stage s: everything issued so far has landed (it was issued >= one stage ago), every wave is
-  // done with stage s - 1, whose slot is refilled with stage s + NS - 1.
+  // Entering stage s: stages s and s + 1 are complete in LDS (so the LDS->register prefetch can run ahead across the
+  // next boundary without a cold start), stage s + 2 may still be in flight, every wave is done with stage s - 1,
+  // whose slot is refilled with stage s + NS - 1.
   static constexpr int loads_of(int t) { return (t % STAGES) < USED_STAGES ? PIECES : 0; }
   DEVI void boundary(int s) {
-    // Stage s must have landed; the LDS-DMA of stages s+1 .. s+NS-2 (issued at the last NS-2 boundaries) stays in
-    // flight.  vmcnt counts in order, so other VMEM traffic issued since can only make this wait longer, never shorter.
-    int inflight = 0;
-#pragma unroll
-    for (int t = s + 1; t <= s + NS - 2; ++t) inflight += loads_of(t);
+    // vmcnt counts in order, so other VMEM traffic issued since can only make this wait longer, never shorter.
+    // lgkmcnt(0): this wave's reads of stage s - 1 have returned before its slot can be overwritten.
     // s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt[6:4] = 7 (don't wait) | lgkmcnt[11:8] = 0
-#ifdef NERFDS_DRAIN_ALL
-    inflight = 0;
-#endif
-    if (inflight == 2 * PIECES) asm volatile("s_waitcnt %0" ::"n"(0x70 | (2 * PIECES)) : "memory");
-    else if (inflight == PIECES) asm volatile("s_waitcnt %0" ::"n"(0x70 | PIECES) : "memory");
+    static_assert(NS == 4, "protocol below is written for a 4-stage ring");
+    const int inflight = loads_of(s + 2);
+    if (inflight == PIECES) asm volatile("s_waitcnt %0" ::"n"(0x70 | PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // raw barrier: __syncthreads() would drain vmcnt to 0 while LDS-DMA is in flight
     issue_stage(s + NS - 1);
@@ -240,8 +236,10 @@ template <class G, int P> struct Pipe {
   }
   DEVI void begin_stage(int i0) {   // i0: first fragment of the stage
     boundary(i0 / GF);
+    if (i0 == 0 || i0 == SHARED_PAD) {        // cold start of a stream segment: fill the register ring
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) ring[d] = frag(i0 + d);
+      for (int d = 0; d < DEPTH; ++d) ring[(i0 + d) % DEPTH] = frag(i0 + d);
+    }
   }
   DEVI void finish_eval() {    // boundaries of the hole stages keep the barrier count and the ring in step
 #pragma unroll
@@ -276,7 +274,7 @@ DEVI void accum(f32x16 (&acc)[NT], Pipe<G, P>& pipe, Cursor& cur, const Chunk<P>
     if (i % PP::GF == 0) pipe.begin_stage(i);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) mma<P>(acc[nt], pipe.ring[i % PP::DEPTH], in[nt][kc]);
-    if (i % PP::GF + PP::DEPTH < PP::GF) pipe.ring[i % PP::DEPTH] = pipe.frag(i + PP::DEPTH);
+    if ((i + PP::DEPTH) / PP::GF < PP::USED_STAGES) pipe.ring[i % PP::DEPTH] = pipe.frag(i + PP::DEPTH);   // stage (i / GF) + 1 is resident
   }
   cur.fi += K;
 }
@@ -398,6 +396,16 @@ template <int C> DEVI FeatV posenc_feat(int g, const float (&x)[C], const float*
 DEVI FeatV val_feat(float v) { FeatV f; f.kind = 2; f.arg = 0.f; f.win = 0.f; f.val = v; return f; }
 DEVI FeatV zero_feat() { FeatV f; f.kind = 0; f.arg = 0.f; f.win = 0.f; f.val = 0.f; return f; }
 
+// sin for the network-input encodings.  The bf16 kernel rounds every feature to 8 mantissa bits anyway, so it uses
+// the hardware v_sin_f32 (argument in revolutions, abs error ~1e-6); the parity-grade kernels use sin_cw.
+template <int P> DEVI float sin_enc(float a) {
+  if constexpr (P == P_BF16) {
+    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(a * 0.159154943f));
+  } else {
+    return sin_cw(a);
+  }
+}
+
 // Linear-feature chunk c: this lane supplies features 16c + 8h + i, i = 0..7.
 template <int P, int KCH, class F> DEVI void build_chunks(Chunk<P> (&out)[KCH], int h, F feat) {
 #pragma unroll
@@ -407,7 +415,7 @@ template <int P, int KCH, class F> DEVI void build_chunks(Chunk<P> (&out)[KCH], 
     for (int i = 0; i < 8; ++i) {
       const FeatV A = feat(16 * c + i), B = feat(16 * c + 8 + i);
       float s = 0.f;
-      if (A.kind == 1 || B.kind == 1) s = sin_cw(h ? B.arg : A.arg);
+      if (A.kind == 1 || B.kind == 1) s = sin_enc<P>(h ? B.arg : A.arg);
       const float va = (A.kind == 1) ? s * A.win : A.val;
       const float vb = (B.kind == 1) ? s * B.win : B.val;
       x[i] = h ? vb : va;
@@ -648,7 +656,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
     dense<G, P, NT, TW32, true>(pipe, cur, h, b, a);
     dense<G, P, NT, TW32, true>(pipe, cur, h, a, b);
     dense<G, P, NT, TW32, true>(pipe, cur, h, b, a);          // b = trunk_output
-    dense<G, P, NT, TW32, false>(pipe, cur, h, a, b);         // a = bottleneck (no activation, modules.py:255)
+    // (the activation-free bottleneck Dense, modules.py:255, is folded into rgb hidden_0 by the packer)
     f32x16 hacc[NT];
     head<G, P, NT>(pipe, cur, h, hacc, b);                    // alpha_mlp on trunk_output (modules.py:273-274)
     // rgb condition chunks: [posenc(viewdir) | posenc(normal in observation frame)]
@@ -689,11 +697,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
       });
     }
     Chunk<P> c[NT][G::RGB_W / 16];
-    if constexpr (G::X_IN_RGB) {
-      dense<G, P, NT, G::RGB_W / 32, true>(pipe, cur, h, c, a, b, cond);   // K order [bottleneck | trunk_output | cond]
-    } else {
-      dense<G, P, NT, G::RGB_W / 32, true>(pipe, cur, h, c, a, cond);
-    }
+    dense<G, P, NT, G::RGB_W / 32, true>(pipe, cur, h, c, b, cond);        // K order [trunk_output | cond]
     head<G, P, NT>(pipe, cur, h, hacc, c);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -1022,7 +1026,6 @@ __global__ __launch_bounds__(64 * wg_waves<P>(), Tune<P>::SPLIT) void render_ray
 extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::KArgs& ka, int grid, void* stream) {
   constexpr int lds = nerfds::BIAS_OFF + nerfds::bias_bytes<nerfds::NERFDS_GRAPH>() + nerfds::RAYS_PER_WG * (int)sizeof(nerfds::WaveLds);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static_assert(nerfds::NUM_STAGES == 4 && 2 * nerfds::Pipe<nerfds::NERFDS_GRAPH, nerfds::NERFDS_PREC>::PIECES < 16, "vmcnt arithmetic in Pipe::boundary");
   static bool attr_set = false;
   auto kern = nerfds::render_rays_kernel<nerfds::NERFDS_GRAPH, nerfds::NERFDS_PREC>;
   if (!attr_set) {

@@ -122,11 +122,9 @@ def test_nerf_mlp_stream_matches_oracle(graph, level):
   f = rng.normal(size=(n, cfg.trunk_in_dim))
   vd, nm = rng.normal(size=(n, 24)), rng.normal(size=(n, cfg.norm_feat_dim))
   trunk = E.mlp(s, f, 8, 256, 4)
-  bott = E.dense(s, [trunk], 8, False)
   alpha = E.head(s, [trunk], cfg.alpha_out_dim)
   cond = E.linear_chunks(np.concatenate([vd, nm], 1), -(-(24 + cfg.norm_feat_dim) // 16))
-  ins = [bott, trunk, cond] if cfg.use_x_in_rgb_condition else [bott, cond]
-  hid = E.dense(s, ins, 4, True)
+  hid = E.dense(s, [trunk, cond], 4, True)          # the activation-free bottleneck Dense is folded into rgb hidden_0
   rgb = E.head(s, [hid], 3)
   _assert_consumed(s)
 
@@ -136,6 +134,5 @@ def test_nerf_mlp_stream_matches_oracle(graph, level):
   parts = [b_ref, T(vd)] + ([t_ref] if cfg.use_x_in_rgb_condition else []) + ([T(nm)] if cfg.norm_feat_dim else [])
   r_ref = O.mlp(P['rgb_mlp'], torch.cat(parts, -1), 1, (), output_channels=3)
   assert np.allclose(_unchunk_tiles(trunk), t_ref.numpy(), atol=1e-5)
-  assert np.allclose(_unchunk_tiles(bott), b_ref.numpy(), atol=1e-5)
   assert np.allclose(alpha.T, a_ref.numpy(), atol=1e-5)
   assert np.allclose(rgb.T, r_ref.numpy(), atol=1e-5)
