@@ -1,0 +1,52 @@
+"""The gin-subset reader resolves the render graph from gin text (own minimal files here; the reference's real
+configs/*.gin are additionally checked when /root/reference is present, i.e. only in the authoring container)."""
+import os
+import textwrap
+
+import pytest
+
+from nerfds_amd import nerf_ds_config
+from nerfds_amd.gin_subset import config_from_gin, extra_params_from_gin, resolve
+
+
+def _write(tmp_path, name, text):
+  p = tmp_path / name
+  p.write_text(textwrap.dedent(text))
+  return str(p)
+
+
+def test_macros_are_lazy_includes_scopes_and_refs(tmp_path):
+  _write(tmp_path, 'base.gin', """
+      # defaults
+      warp_max_deg = 8
+      SE3Field.max_deg = %warp_max_deg
+      NerfModel.warp_field_cls = @SE3Field
+      warp/GLOEmbed.num_dims = 8
+      SCHED = {
+        'type': 'linear', 'initial_value': 0,
+        'final_value': %warp_max_deg, 'num_steps': 10,
+      }
+      TrainConfig.warp_alpha_schedule = %SCHED
+      NerfiesDataSource.data_dir = %data_dir
+  """)
+  top = _write(tmp_path, 'top.gin', """
+      include 'base.gin'
+      warp_max_deg = 4          # overrides the macro for EVERY use, also the earlier ones (lazy resolution)
+      NerfModel.use_warp = True
+      NerfModel.nerf_skips = (4,)
+      MaskMLP.output_activation = @jax.nn.relu
+      TrainConfig.nerf_alpha_schedule = ('constant', 8)
+  """)
+  b = resolve(top)
+  assert b['SE3Field.max_deg'] == 4 and b['warp/GLOEmbed.num_dims'] == 8
+  assert b['NerfModel.warp_field_cls'] == '@SE3Field' and b['MaskMLP.output_activation'] == '@jax.nn.relu'
+  assert 'NerfiesDataSource.data_dir' not in b                      # undefined macro -> binding skipped, not fatal
+  assert extra_params_from_gin(top) == {'warp_alpha': 4.0, 'nerf_alpha': 8.0}
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/configs/nerf_ds.gin'), reason='reference configs not present')
+def test_reference_nerf_ds_gin_resolves_to_the_compiled_graph():
+  cfg = config_from_gin('/root/reference/configs/nerf_ds.gin', near=0.3, far=1.7, num_warp_embeds=256)
+  assert cfg == nerf_ds_config(near=0.3, far=1.7, num_warp_embeds=256)
+  assert extra_params_from_gin('/root/reference/configs/nerf_ds.gin') == {
+      'nerf_alpha': 8.0, 'warp_alpha': 4.0, 'hyper_alpha': 1.0, 'hyper_sheet_alpha': 6.0, 'norm_input_alpha': 4.0}
