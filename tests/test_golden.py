@@ -48,5 +48,8 @@ def test_hip_matches_golden(name, prec, tol):
       if f'{level}/{k}' not in z.files or k not in o:
         continue
       ref, got = z[f'{level}/{k}'], o[k].cpu().numpy()
+      assert ref.shape == got.shape, (level, k)
+      if ref.size == 0:          # e.g. ray_hyper_points of the static graph is [R, 0]
+        continue
       err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6)
       assert err <= (tol if k == 'rgb' else 10 * tol), (level, k, err)        # 1e-4 rel on composited RGB (north_star)
