@@ -173,6 +173,12 @@ def main():
     avg_launch_s = (kernel_ms / max(n_launch, 1)) * 1e-3
     achieved = rays_per_launch * FLOP_PER_RAY / avg_launch_s / 1e12 if n_launch else None
     peak = PEAK_TFLOPS[args.precision]
+    # HBM bytes per launch cannot be read live (PMC passes are separate rocprofv3 runs of this same command):
+    # the committed measurement of the current kernel is used when present (profiles/, see tools/prof_bench.sh).
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', f'r1_{args.precision}_hbm_traffic.json')
+    if os.path.exists(tpath) and args.rays == 480000 and args.chunk == 65536:
+      traffic = json.load(open(tpath))['hbm_bytes_per_launch']
     result = {
         'metric': 'rendered rays/sec (128 samples/ray, full warp+NerfMLP)',
         'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -184,7 +190,7 @@ def main():
                    'rays_per_gpu_per_step': args.rays, 'chunk': args.chunk, 'parallelism': f'ray-shard x{world}',
                    'exchange': 'all-gather of [chunk, 26] fp32 ray records' if world > 1 else 'none (1 GPU)'},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                     'frac': (achieved / peak) if achieved else None, 'traffic': None,
+                     'frac': (achieved / peak) if achieved else None, 'traffic': traffic,
                      'kernel': 'nerfds::render_rays_kernel<GraphNerfDS, %s>' % args.precision,
                      'avg_launch_ms': avg_launch_s * 1e3, 'launches': n_launch,
                      'algorithmic_flop_per_launch': rays_per_launch * FLOP_PER_RAY},

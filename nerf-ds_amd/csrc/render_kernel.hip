@@ -43,6 +43,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define DEVI __device__ __forceinline__
+// Development only: timing ablations (results are WRONG when any bit is set).  1: no LDS-DMA, 2: no stage barrier,
+// 4: no tile epilogue, 8: no sin in the encodings, 16: no compositing / resampling, 32: no LDS->register weight reads
+#ifndef NERFDS_ABLATE
+#define NERFDS_ABLATE 0
+#endif
 // LDS scratch is private to a wave and a wave's DS ops complete in order: a compiler-level fence is all that is needed.
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
@@ -174,7 +179,10 @@ template <class G, int P> struct Pipe {
   static constexpr int PIECES = STAGE_BYTES / 1024 / WAVES;       // 1 KiB LDS-DMA pieces per wave per stage
   // LDS -> register prefetch distance in fragments: a ds_read_b128 takes ~100+ cycles to return, a bf16 fragment
   // is consumed in 64 MFMA cycles, so the reads must run several fragments ahead of the MFMAs.
-  static constexpr int DEPTH = (P == P_BF16) ? 4 : 2;
+#ifndef NERFDS_BF16_DEPTH
+#define NERFDS_BF16_DEPTH 4
+#endif
+  static constexpr int DEPTH = (P == P_BF16) ? NERFDS_BF16_DEPTH : 2;
   static_assert(GF % DEPTH == 0 && DEPTH <= GF, "ring slot = fragment index mod DEPTH; prefetch reaches at most one stage ahead");
   WFrag<P> ring[DEPTH];
   rsrc_t ws;        // shared stream
@@ -186,6 +194,7 @@ template <class G, int P> struct Pipe {
   // This wave's share of stage t: LDS-DMA (buffer_load ... lds), 1 KiB per instruction, no VGPRs.  Which
   // stream a stage comes from is a compile-time fact; only "+ wave * 1024" is run-time (one s_add).
   DEVI void issue_stage(int t) {
+    if (NERFDS_ABLATE & 1) return;
     const bool wrap = t >= STAGES;
     const int tt = t % STAGES, slot = t % NS;
     if (tt >= USED_STAGES) return;                                 // hole stage
@@ -212,7 +221,7 @@ template <class G, int P> struct Pipe {
     const int inflight = loads_of(s + 2);
     if (inflight == PIECES) asm volatile("s_waitcnt %0" ::"n"(0x70 | PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();      // raw barrier: __syncthreads() would drain vmcnt to 0 while LDS-DMA is in flight
+    if (!(NERFDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();      // raw barrier: __syncthreads() would drain vmcnt to 0 while LDS-DMA is in flight
     issue_stage(s + NS - 1);
   }
   DEVI void prologue() {
@@ -220,6 +229,9 @@ template <class G, int P> struct Pipe {
     for (int t = 0; t < NS - 1; ++t) issue_stage(t);
   }
   DEVI WFrag<P> frag(int i) const {
+#if (NERFDS_ABLATE & 32) && defined(__HIP_DEVICE_COMPILE__)
+    { WFrag<P> z{}; u32x4 t = {0u, 0u, 0u, (unsigned)i}; asm volatile("" : "+v"(t)); if constexpr (P == P_BF16) z.v = __builtin_bit_cast(bf16x8, t); return z; }
+#endif
     const int off = ((i / GF) % NS) * STAGE_BYTES + (i % GF) * FB;
     WFrag<P> w;
     const u32x4* p = reinterpret_cast<const u32x4*>(g_smem + off + lane16);
@@ -265,8 +277,10 @@ DEVI f32x16 load_bias(int boff, int h) {
   return bv;
 }
 
-template <class G, int P, int NT, int K>
-DEVI void accum(f32x16 (&acc)[NT], Pipe<G, P>& pipe, Cursor& cur, const Chunk<P> (&in)[NT][K]) {
+// `hook` (the deferred epilogue of the previous output tile) is dropped into the MFMA stream right after the
+// second fragment of the segment when `hook_here`: its VALU work then overlaps this tile's MFMA chain.
+template <class G, int P, int NT, int K, class H>
+DEVI void accum(f32x16 (&acc)[NT], Pipe<G, P>& pipe, Cursor& cur, const Chunk<P> (&in)[NT][K], bool hook_here, H&& hook) {
 #pragma unroll
   for (int kc = 0; kc < K; ++kc) {
     const int i = cur.fi + kc;
@@ -275,29 +289,56 @@ DEVI void accum(f32x16 (&acc)[NT], Pipe<G, P>& pipe, Cursor& cur, const Chunk<P>
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) mma<P>(acc[nt], pipe.ring[i % PP::DEPTH], in[nt][kc]);
     if ((i + PP::DEPTH) / PP::GF < PP::USED_STAGES) pipe.ring[i % PP::DEPTH] = pipe.frag(i + PP::DEPTH);   // stage (i / GF) + 1 is resident
+    if (hook_here && kc == (K > 1 ? 1 : 0)) hook();
   }
   cur.fi += K;
 }
 
+template <int P, int NT, bool RELU, int W>
+DEVI void tile_epilogue(Chunk<P> (&out)[NT][W], int ot, const f32x16 (&acc)[NT]) {
+#if (NERFDS_ABLATE & 4) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { f32x16 t = acc[nt]; asm volatile("" ::"v"(t)); }
+  return;
+#endif
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float x0[8], x1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x0[i] = acc[nt][i]; x1[i] = acc[nt][8 + i]; }
+    make_act_chunk<P, RELU>(out[nt][2 * ot], x0);
+    make_act_chunk<P, RELU>(out[nt][2 * ot + 1], x1);
+  }
+}
+
 // One dense layer with OT output tiles of 32 features; inputs are one or more chunk arrays in stream order.
 // The accumulators start from the bias (the first MFMA of a tile reads the bias registers as its C operand).
+// Software pipeline over the tiles of the layer: the bias of tile t + 1 is fetched from LDS before the MFMA chain
+// of tile t, and the epilogue (ReLU + pack to the next layer's B operand) of tile t runs inside the chain of tile
+// t + 1, so a wave keeps issuing MFMAs back to back instead of draining the matrix pipe at every tile.
 template <class G, int P, int NT, int OT, bool RELU, class... Ins>
 DEVI void dense(Pipe<G, P>& pipe, Cursor& cur, int h, Chunk<P> (&out)[NT][2 * OT], const Ins&... ins) {
+  f32x16 acc[OT][NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[0][nt] = load_bias(cur.boff, h);
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot) {
-    f32x16 acc[NT];
+    if (ot + 1 < OT) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = load_bias(cur.boff + 128 * ot, h);
-    (accum<G, P, NT>(acc, pipe, cur, ins), ...);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      float x0[8], x1[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { x0[i] = acc[nt][i]; x1[i] = acc[nt][8 + i]; }
-      make_act_chunk<P, RELU>(out[nt][2 * ot], x0);
-      make_act_chunk<P, RELU>(out[nt][2 * ot + 1], x1);
+      for (int nt = 0; nt < NT; ++nt) acc[ot + 1][nt] = load_bias(cur.boff + 128 * (ot + 1), h);
     }
+    int seg = 0;
+#ifndef NERFDS_EPILOGUE_PIPELINE      // measured: with two waves per SIMD the second wave already covers the epilogue (-1.5 % when pipelined)
+    (accum<G, P, NT>(acc[ot], pipe, cur, ins, false, [] {}), ...);
+    tile_epilogue<P, NT, RELU>(out, ot, acc[ot]);
+    (void)seg;
   }
+#else
+    auto hook = [&]() { if (ot > 0) tile_epilogue<P, NT, RELU>(out, ot - 1, acc[ot > 0 ? ot - 1 : 0]); };
+    (accum<G, P, NT>(acc[ot], pipe, cur, ins, seg++ == 0, hook), ...);
+  }
+  tile_epilogue<P, NT, RELU>(out, OT - 1, acc[OT - 1]);
+#endif
   cur.boff += 128 * OT;
 }
 
@@ -306,7 +347,7 @@ template <class G, int P, int NT, class... Ins>
 DEVI void head(Pipe<G, P>& pipe, Cursor& cur, int h, f32x16 (&acc)[NT], const Ins&... ins) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = load_bias(cur.boff, h);
-  (accum<G, P, NT>(acc, pipe, cur, ins), ...);
+  (accum<G, P, NT>(acc, pipe, cur, ins, false, [] {}), ...);
   cur.boff += 128;
 }
 
@@ -399,6 +440,7 @@ DEVI FeatV zero_feat() { FeatV f; f.kind = 0; f.arg = 0.f; f.win = 0.f; f.val = 
 // sin for the network-input encodings.  The bf16 kernel rounds every feature to 8 mantissa bits anyway, so it uses
 // the hardware v_sin_f32 (argument in revolutions, abs error ~1e-6); the parity-grade kernels use sin_cw.
 template <int P> DEVI float sin_enc(float a) {
+  if (NERFDS_ABLATE & 8) return a;
   if constexpr (P == P_BF16) {
     return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(a * 0.159154943f));
   } else {
@@ -903,6 +945,9 @@ __global__ __launch_bounds__(64 * wg_waves<P>(), Tune<P>::SPLIT) void render_ray
   // barrier sequence, so these interleave consistently with the per-stage barriers of the weight pipe).
   auto ray_sync = [&]() { if constexpr (SPLIT > 1) __syncthreads(); else WAVE_SYNC(); };
 
+#ifdef NERFDS_SETPRIO
+  if (q == NERFDS_SETPRIO - 1) __builtin_amdgcn_s_setprio(1);
+#endif
   Pipe<G, P> pipe;
   const rsrc_t rs_nerf[2] = {make_rsrc(ka.wstream[1], Pipe<G, P>::NERF_PAD * frag_bytes(P)),
                              make_rsrc(ka.wstream[2], Pipe<G, P>::NERF_PAD * frag_bytes(P))};
@@ -986,7 +1031,7 @@ __global__ __launch_bounds__(64 * wg_waves<P>(), Tune<P>::SPLIT) void render_ray
       eval_batch<G, P, NT>(ka, rc, pipe, 0, lane, sb + 32 * NT * q, nc, L);
     }
     ray_sync();
-    if (q == 0) {
+    if (q == 0 && !(NERFDS_ABLATE & 16)) {
       float* rec = live ? ((nf > 0) ? ka.ray_coarse : ka.ray_fine) : nullptr;
       float* smp = live ? ((nf > 0) ? ka.smp_coarse : ka.smp_fine) : nullptr;
       composite<G>(ka, rc, ray, lane, nc, ka.sample_at_infinity != 0, L,
@@ -1005,7 +1050,7 @@ __global__ __launch_bounds__(64 * wg_waves<P>(), Tune<P>::SPLIT) void render_ray
         eval_batch<G, P, NT>(ka, rc, pipe, 1, lane, sb + 32 * NT * q, n, L);
       }
       ray_sync();
-      if (q == 0)
+      if (q == 0 && !(NERFDS_ABLATE & 16))
         composite<G>(ka, rc, ray, lane, n, ka.sample_at_infinity != 0, L,
                      (live && ka.ray_fine) ? ka.ray_fine + (size_t)ray * RAY_REC : nullptr,
                      (live && ka.smp_fine) ? ka.smp_fine + (size_t)ray * n * SAMPLE_REC : nullptr);

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, '_lib', 'libnerfds_hip.so')
+LIB_PATH = os.environ.get('NERFDS_LIB', os.path.join(_HERE, '_lib', 'libnerfds_hip.so'))   # NERFDS_LIB: development builds
 
 ABI_VERSION = 1
 MAX_DEPTH = 16
