@@ -130,6 +130,20 @@ typedef struct nerfds_weights {
   nerfds_nerf_mlp nerf[2];                      /* nerf_mlps_coarse, nerf_mlps_fine */
 } nerfds_weights;
 
+/* Pinhole camera with radial / tangential distortion: the JSON fields of hypernerf/camera.py:140-161 (Camera.from_json;
+ * the legacy key "tangential" == tangential_distortion).  orientation is the world->camera rotation, row major. */
+typedef struct nerfds_camera {
+  float orientation[9];
+  float position[3];
+  float focal_length;
+  float principal_point[2];
+  float skew;
+  float pixel_aspect_ratio;
+  float radial_distortion[3];
+  float tangential_distortion[2];
+  int32_t image_width, image_height;
+} nerfds_camera;
+
 /* Ray batch: DEVICE pointers, R rays.  rays_dict of models.py:1444-1478. */
 typedef struct nerfds_rays {
   int64_t num_rays;
@@ -138,6 +152,12 @@ typedef struct nerfds_rays {
   const float* viewdirs;      /* [R][3]; NULL -> directions (models.py:1475-1478) */
   const uint32_t* warp_id;    /* [R] metadata['warp'] (GLO row); NULL if the graph has no warp */
   const float* gt_mask;       /* [R] rays_dict['mask']; only read when mask_ratio != 1; may be NULL */
+  /* Fused camera -> rays (render.py:201 camera_to_rays + evaluation.py:78-98 flatten/chunk): when camera != NULL
+   * (HOST pointer), origins/directions/viewdirs are ignored and ray r is generated on the GPU (a camera kernel on the
+   * same stream, into library-owned device scratch) for the row-major pixel centre first_pixel + r
+   * (origin = camera position, viewdir = direction). */
+  const nerfds_camera* camera;
+  int64_t first_pixel;
 } nerfds_rays;
 
 /* Runtime scalars: state.extra_params (model_utils.py:41-52) + the kwargs of NerfModel.__call__ that the
@@ -176,6 +196,14 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
 int nerfds_ctx_destroy(nerfds_ctx* ctx);
 /* Message of the last failure on this ctx (or of the last failed nerfds_ctx_create when ctx == NULL). */
 const char* nerfds_last_error(const nerfds_ctx* ctx);
+
+/* Camera -> rays on the GPU: datasets.camera_to_rays (hypernerf/datasets/core.py:51-76) = Camera.pixels_to_rays
+ * (hypernerf/camera.py:245-270, Newton undistortion camera.py:75-106) on Camera.get_pixel_centers (camera.py:364-368).
+ * Pixels are either given ([n][2] DEVICE floats) or, when pixels == NULL, the row-major pixel centres
+ * first_pixel .. first_pixel + n - 1 of the image.  Outputs are DEVICE pointers, any may be NULL:
+ * origins [n][3] (the camera position), directions [n][3] (unit, world frame), pixels_out [n][2]. */
+int nerfds_camera_to_rays(int device, const nerfds_camera* cam, int64_t first_pixel, int64_t n, const float* pixels,
+                          float* origins, float* directions, float* pixels_out, void* hip_stream);
 
 /* Timing aid for bench.py: average device time (ms) of the render kernel launches recorded with HIP events
  * on the launch stream since the last reset; returns the number of launches measured. */

@@ -14,6 +14,7 @@
 #include "graphs.h"
 #include "kargs.h"
 #include "pack.h"
+#include "camera_dev.h"
 
 using namespace nerfds;
 
@@ -24,7 +25,9 @@ void nerfds_launch_nerfds_f32(const KArgs&, int, void*);
 void nerfds_launch_static_bf16(const KArgs&, int, void*);
 void nerfds_launch_static_bf16x3(const KArgs&, int, void*);
 void nerfds_launch_static_f32(const KArgs&, int, void*);
+void nerfds_launch_camera_rays(const nerfds::CameraParams&, long long, long long, const float*, float*, float*, float*, void*);
 }
+static_assert(sizeof(nerfds_camera) == sizeof(nerfds::CameraParams), "nerfds_camera and CameraParams must have the same layout");
 
 namespace {
 
@@ -201,6 +204,7 @@ struct nerfds_ctx {
   DevBuf wstream[3][3];     // [prec][shared, coarse, fine]
   DevBuf wbias[3];          // precision independent
   DevBuf warp_embed, mask_embed;
+  DevBuf ray_scratch;       // origins | directions generated from a camera
   bool packed[3] = {false, false, false};
   bool bias_uploaded = false;
   std::string err;
@@ -322,7 +326,10 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
     return ctx->fail(NERFDS_ENOTSUP, "use_warp=False on a warp model is not runnable in the reference either (SURVEY.md 8a quirk 2)");
   if (rays->num_rays < 0 || rays->num_rays > 0x7fffffff) return ctx->fail(NERFDS_EINVAL, "num_rays out of range");
   if (rays->num_rays == 0) return NERFDS_OK;
-  if (!rays->origins || !rays->directions) return ctx->fail(NERFDS_EINVAL, "origins/directions are required");
+  if (!rays->camera && (!rays->origins || !rays->directions)) return ctx->fail(NERFDS_EINVAL, "origins/directions (or a camera) are required");
+  if (rays->camera && (rays->first_pixel < 0 || rays->camera->image_width <= 0 ||
+                       rays->first_pixel + rays->num_rays > (int64_t)rays->camera->image_width * rays->camera->image_height))
+    return ctx->fail(NERFDS_EINVAL, "camera pixel range [first_pixel, first_pixel + num_rays) is outside the image");
   if (ctx->cfg.use_warp && !rays->warp_id) return ctx->fail(NERFDS_EINVAL, "metadata['warp'] ids are required by this graph");
   if (extra->mask_ratio != 1.0f && ctx->cfg.use_predicted_mask && !rays->gt_mask)
     return ctx->fail(NERFDS_EINVAL, "rays_dict['mask'] is required when mask_ratio != 1");
@@ -342,6 +349,24 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   ka.mask_embed = static_cast<const float*>(ctx->mask_embed.p);
   ka.ray_fine = out->ray_fine; ka.ray_coarse = out->ray_coarse; ka.smp_fine = out->sample_fine; ka.smp_coarse = out->sample_coarse;
   ka.num_rays = (int)rays->num_rays;
+  if (rays->camera) {
+    // camera_to_rays ahead of sampling, on the same stream, into a library-owned device scratch (48 B/ray) - the rays
+    // never cross PCIe.  (It is a separate tiny HBM-bound launch rather than a branch inside the 1000-MFMA ray kernel:
+    // hipcc miscompiled the fine-level evaluation of the split-bf16 kernel when the Newton loop lived in there.)
+    const size_t need = (size_t)rays->num_rays * 6 * sizeof(float);
+    if (ctx->ray_scratch.bytes < need) {          // grow-only; the old block may still be in use by earlier launches
+      (void)hipStreamSynchronize(static_cast<hipStream_t>(hip_stream));
+      if (ctx->ray_scratch.p) { (void)hipFree(ctx->ray_scratch.p); ctx->ray_scratch.p = nullptr; ctx->ray_scratch.bytes = 0; }
+      if (hipMalloc(&ctx->ray_scratch.p, need) != hipSuccess) return ctx->fail(NERFDS_ENOMEM, "hipMalloc of %zu bytes of ray scratch failed", need);
+      ctx->ray_scratch.bytes = need;
+    }
+    float* o = static_cast<float*>(ctx->ray_scratch.p);
+    float* d = o + (size_t)rays->num_rays * 3;
+    nerfds::CameraParams cp;
+    std::memcpy(&cp, rays->camera, sizeof cp);
+    nerfds_launch_camera_rays(cp, rays->first_pixel, rays->num_rays, nullptr, o, d, nullptr, hip_stream);
+    ka.origins = o; ka.directions = d; ka.viewdirs = d;
+  }
   ka.num_embeds = ctx->cfg.num_warp_embeds > 0 ? ctx->cfg.num_warp_embeds : 1;
   ka.nc = ctx->cfg.num_coarse_samples; ka.nf = ctx->cfg.num_fine_samples;
   ka.stratified = extra->use_stratified_sampling;
@@ -372,6 +397,21 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
     ctx->events.push_back(ev);
   }
   if (e != hipSuccess) return ctx->fail(NERFDS_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+  return NERFDS_OK;
+}
+
+int nerfds_camera_to_rays(int device, const nerfds_camera* cam, int64_t first_pixel, int64_t n, const float* pixels,
+                          float* origins, float* directions, float* pixels_out, void* hip_stream) {
+  if (!cam || n < 0 || first_pixel < 0 || cam->image_width <= 0 || cam->image_height <= 0 || cam->focal_length == 0.f) {
+    g_create_error = "nerfds_camera_to_rays: invalid argument";
+    return NERFDS_EINVAL;
+  }
+  if (hipSetDevice(device) != hipSuccess) { g_create_error = "no such HIP device"; return NERFDS_EDEVICE; }
+  nerfds::CameraParams cp;
+  std::memcpy(&cp, cam, sizeof cp);
+  nerfds_launch_camera_rays(cp, first_pixel, n, pixels, origins, directions, pixels_out, hip_stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return NERFDS_EDEVICE; }
   return NERFDS_OK;
 }
 

@@ -212,16 +212,15 @@ template <class G, int P> struct Pipe {
   // Entering stage s: stages s and s + 1 are complete in LDS (so the LDS->register prefetch can run ahead across the
   // next boundary without a cold start), stage s + 2 may still be in flight, every wave is done with stage s - 1,
   // whose slot is refilled with stage s + NS - 1.
-  static constexpr int loads_of(int t) { return (t % STAGES) < USED_STAGES ? PIECES : 0; }
   DEVI void boundary(int s) {
-    // vmcnt counts in order, so other VMEM traffic issued since can only make this wait longer, never shorter.
-    // lgkmcnt(0): this wave's reads of stage s - 1 have returned before its slot can be overwritten.
-    // s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt[6:4] = 7 (don't wait) | lgkmcnt[11:8] = 0
-    static_assert(NS == 4, "protocol below is written for a 4-stage ring");
-    const int inflight = loads_of(s + 2);
-    if (inflight == PIECES) asm volatile("s_waitcnt %0" ::"n"(0x70 | PIECES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (!(NERFDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();      // raw barrier: __syncthreads() would drain vmcnt to 0 while LDS-DMA is in flight
+    // vmcnt(0): every LDS-DMA this wave has issued (stages <= s + 2, the youngest a full stage ago) has landed.
+    // A COUNTED vmcnt(N) is NOT safe here: on gfx9-family VM_CNT, loads and stores complete out of order with respect
+    // to each other, so a younger store (ray-record store, register spill) retiring early lets the count drop below N
+    // while an older LDS-DMA is still in flight -> stale weights (seen as 2e-2 errors on the fine level).
+    // lgkmcnt(0): this wave's reads of stage s - 1 have returned before its slot is overwritten.
+    static_assert(NS == 4, "protocol is written for a 4-stage ring");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (!(NERFDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();      // raw barrier (no compiler-added fences)
     issue_stage(s + NS - 1);
   }
   DEVI void prologue() {
@@ -977,10 +976,12 @@ __global__ __launch_bounds__(64 * wg_waves<P>(), Tune<P>::SPLIT) void render_ray
     const bool live = (ray_raw < ka.num_rays) && (q == 0);     // the q == 0 wave of a ray owns its outputs
     const int ray = (ray_raw < ka.num_rays) ? ray_raw : ka.num_rays - 1;
     RayConst rc;
+    float vdir[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       rc.o[c] = ka.origins[3 * (size_t)ray + c];
       rc.d[c] = ka.directions[3 * (size_t)ray + c];
+      vdir[c] = (ka.viewdirs ? ka.viewdirs : ka.directions)[3 * (size_t)ray + c];
     }
     rc.gt_mask = (ka.gt_mask != nullptr) ? ka.gt_mask[ray] : 0.f;
     if (q == 0) {  // per-ray constants -> LDS: GLO rows (modules.py:336-348) and posenc(viewdirs) (models.py:401-405, no window)
@@ -992,7 +993,7 @@ __global__ __launch_bounds__(64 * wg_waves<P>(), Tune<P>::SPLIT) void render_ray
       }
       if (lane < 24) {
         const int band = lane / 6, sc = (lane % 6) / 3, ch = lane % 3;
-        const float vdc = (ka.viewdirs ? ka.viewdirs : ka.directions)[3 * (size_t)ray + ch];
+        const float vdc = ch == 0 ? vdir[0] : (ch == 1 ? vdir[1] : vdir[2]);
         L.rayc[RC_VDENC + lane] = sin_cw(fmaf(vdc, (float)(1 << band), sc ? 1.57079637f : 0.0f));
       }
     }

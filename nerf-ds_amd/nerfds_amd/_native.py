@@ -60,9 +60,17 @@ class Weights(C.Structure):
               ('nerf', NerfMlp * 2)]
 
 
+class CameraStruct(C.Structure):
+  _fields_ = [('orientation', C.c_float * 9), ('position', C.c_float * 3), ('focal_length', C.c_float),
+              ('principal_point', C.c_float * 2), ('skew', C.c_float), ('pixel_aspect_ratio', C.c_float),
+              ('radial_distortion', C.c_float * 3), ('tangential_distortion', C.c_float * 2),
+              ('image_width', C.c_int32), ('image_height', C.c_int32)]
+
+
 class Rays(C.Structure):
   _fields_ = [('num_rays', C.c_int64), ('origins', C.c_void_p), ('directions', C.c_void_p),
-              ('viewdirs', C.c_void_p), ('warp_id', C.c_void_p), ('gt_mask', C.c_void_p)]
+              ('viewdirs', C.c_void_p), ('warp_id', C.c_void_p), ('gt_mask', C.c_void_p),
+              ('camera', C.POINTER(CameraStruct)), ('first_pixel', C.c_int64)]
 
 
 class Extra(C.Structure):
@@ -83,7 +91,7 @@ class Out(C.Structure):
 # every symbol include/nerfds.h declares
 SYMBOLS = ('nerfds_abi_version', 'nerfds_ctx_create', 'nerfds_ctx_load_weights', 'nerfds_render_rays',
            'nerfds_ctx_destroy', 'nerfds_last_error', 'nerfds_kernel_time_ms', 'nerfds_pack_stream_bytes',
-           'nerfds_pack_bias_floats', 'nerfds_pack_stream', 'nerfds_debug_mfma')
+           'nerfds_pack_bias_floats', 'nerfds_pack_stream', 'nerfds_debug_mfma', 'nerfds_camera_to_rays')
 
 _lib = None
 
@@ -112,6 +120,8 @@ def load():
   lib.nerfds_pack_stream.argtypes = [C.POINTER(ModelCfg), C.POINTER(Weights), C.c_int, C.c_int, C.c_uint32,
                                      C.c_void_p, C.c_void_p]
   lib.nerfds_debug_mfma.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+  lib.nerfds_camera_to_rays.argtypes = [C.c_int, C.POINTER(CameraStruct), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
   if lib.nerfds_abi_version() != ABI_VERSION:
     raise RuntimeError('libnerfds_hip.so ABI version mismatch: rebuild')
   _lib = lib

@@ -192,11 +192,21 @@ class NerfModel:
 
     dev = self.device
     f32 = lambda a: torch.as_tensor(np.asarray(a) if not isinstance(a, torch.Tensor) else a).to(dev, torch.float32).contiguous()
-    origins, directions = f32(rays_dict['origins']), f32(rays_dict['directions'])
-    batch_shape = origins.shape[:-1]
-    origins, directions = origins.reshape(-1, 3), directions.reshape(-1, 3)
-    R = origins.shape[0]
-    viewdirs = f32(rays_dict['viewdirs']).reshape(-1, 3) if 'viewdirs' in rays_dict else None
+    camera, cam_struct, first_pixel = rays_dict.get('camera'), None, 0
+    if camera is not None:
+      # Fused camera -> rays: rays_dict = {'camera': Camera, 'pixel_range': (first, count), 'metadata', 'mask'};
+      # origins / directions / viewdirs are generated on chip for the row-major pixel centres of the range.
+      H, W = camera.image_shape
+      first_pixel, R = rays_dict.get('pixel_range', (0, H * W))
+      batch_shape = (H, W) if (first_pixel, R) == (0, H * W) else (R,)
+      origins = directions = viewdirs = None
+      cam_struct = camera._struct()
+    else:
+      origins, directions = f32(rays_dict['origins']), f32(rays_dict['directions'])
+      batch_shape = origins.shape[:-1]
+      origins, directions = origins.reshape(-1, 3), directions.reshape(-1, 3)
+      R = origins.shape[0]
+      viewdirs = f32(rays_dict['viewdirs']).reshape(-1, 3) if 'viewdirs' in rays_dict else None
     warp_id = None
     if cfg.use_warp:
       ids = rays_dict['metadata']['warp']
@@ -219,7 +229,8 @@ class NerfModel:
       u_rand = f32(u_rand).reshape(R, max(nf, 1))
 
     ptr = lambda t: (t.data_ptr() if t is not None else None)
-    rays = N.Rays(R, ptr(origins), ptr(directions), ptr(viewdirs), ptr(warp_id), ptr(gt_mask))
+    rays = N.Rays(R, ptr(origins), ptr(directions), ptr(viewdirs), ptr(warp_id), ptr(gt_mask),
+                  C.pointer(cam_struct) if cam_struct is not None else None, int(first_pixel))
     g = lambda k, d=0.0: float(extra_params[k]) if extra_params.get(k) is not None else d
     extra = N.Extra(g('nerf_alpha'), g('warp_alpha'), g('hyper_alpha'), g('hyper_sheet_alpha'), g('norm_input_alpha'),
                     float(mask_ratio), float(cfg.near if near is None else near), float(cfg.far if far is None else far),
@@ -237,6 +248,11 @@ class NerfModel:
     level_recs = [('coarse', rec_coarse, smp_coarse, nc), ('fine', rec_fine, smp_fine, nc + nf)] if two else \
                  [('coarse', rec_fine, smp_fine, nc)]
     for level, rec, smp, S in level_recs:
+      if smp is not None and camera is not None:
+        from .camera import camera_to_rays
+        cr = camera_to_rays(camera, dev)
+        origins = cr['origins'].reshape(-1, 3)[first_pixel:first_pixel + R]
+        directions = cr['directions'].reshape(-1, 3)[first_pixel:first_pixel + R]
       ret[level] = self._unpack(rec, smp, S, batch_shape, origins, directions, return_points, return_weights,
                                 sharp_weights_std)
     self.last_records = {'fine': rec_fine, 'coarse': rec_coarse}
