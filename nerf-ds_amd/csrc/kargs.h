@@ -4,7 +4,7 @@
 
 namespace nerfds {
 
-constexpr int MAX_SAMPLES = 128;      // Nc + Nf upper bound (nerf_ds.gin: 64 + 64); 160 KiB LDS holds ring + biases + 4 waves of this
+constexpr int MAX_SAMPLES = 256;      // Nc + Nf upper bound: 128 with 4 rays per workgroup (nerf_ds.gin 64 + 64), 256 with 2 rays (128 + 128)
 constexpr int RAY_REC = 26;           // == NERFDS_RAY_REC
 constexpr int SAMPLE_REC = 18;        // == NERFDS_SAMPLE_REC
 constexpr int MAX_BANDS = 8;
@@ -47,6 +47,6 @@ struct KArgs {
   float win_nm[MAX_BANDS];     // alpha = norm_input_alpha  (models.py:1147)
 };
 
-typedef void (*launch_fn)(const KArgs& ka, int grid, void* stream);
+typedef void (*launch_fn)(const KArgs& ka, int num_cus, void* stream);
 
 }  // namespace nerfds

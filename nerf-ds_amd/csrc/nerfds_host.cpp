@@ -241,7 +241,7 @@ int nerfds_ctx_create(nerfds_ctx** out, int device, const nerfds_model_cfg* cfg)
   if (cfg->abi_version != NERFDS_ABI_VERSION) { g_create_error = "abi_version mismatch"; return NERFDS_EINVAL; }
   if (cfg->num_coarse_samples < 4 || cfg->num_fine_samples < 0 ||
       cfg->num_coarse_samples + cfg->num_fine_samples > MAX_SAMPLES) {
-    g_create_error = "num_coarse_samples must be >= 4 and num_coarse_samples + num_fine_samples <= 128";
+    g_create_error = "num_coarse_samples must be >= 4 and num_coarse_samples + num_fine_samples <= 256";
     return NERFDS_EINVAL;
   }
   const int graph = graph_of(*cfg);
@@ -381,8 +381,6 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   window(ka.win_hp, ctx->cfg.hyper_point_max_deg, extra->hyper_alpha);
   window(ka.win_nm, ctx->cfg.norm_input_max_deg, extra->norm_input_alpha);
 
-  // one workgroup of four 512-VGPR waves (one per SIMD) per CU, four rays per workgroup iteration
-  const int grid = (int)std::min<int64_t>((rays->num_rays + 3) / 4, (int64_t)ctx->num_cus);
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
   if (ctx->timing) {
@@ -390,7 +388,7 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
       return ctx->fail(NERFDS_EDEVICE, "hipEventCreate failed");
     (void)hipEventRecord(ev.first, stream);
   }
-  launcher(ctx->graph, prec)(ka, grid, stream);
+  launcher(ctx->graph, prec)(ka, ctx->num_cus, stream);   // grid = min(ray groups, CUs) persistent workgroups
   hipError_t e = hipGetLastError();
   if (ctx->timing) {
     (void)hipEventRecord(ev.second, stream);

@@ -49,7 +49,14 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define NERFDS_ABLATE 0
 #endif
 // LDS scratch is private to a wave and a wave's DS ops complete in order: a compiler-level fence is all that is needed.
+#ifndef NERFDS_DBG
+#define NERFDS_DBG 0
+#endif
+#if NERFDS_DBG & 4
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 
 // All LDS of the kernel is ONE array (a second __shared__ object de-pipelines LDS-DMA code, cdna guide section 5):
 // [0, RING_BYTES) weight ring, then one WaveLds scratch block per wave.
@@ -148,21 +155,28 @@ template <int P> DEVI void mma(f32x16& acc, const WFrag<P>& w, const Chunk<P>& c
 // STAGE_BYTES (graphs.h): one ring stage = 16 bf16 fragments (8 in the 2-part precisions)
 constexpr int NUM_STAGES = 4;          // ring depth
 constexpr int RING_BYTES = NUM_STAGES * STAGE_BYTES;
-constexpr int RAYS_PER_WG = 4;         // rays in flight per workgroup (each with its own RayLds block)
 // Work shape per precision.  NT = N-tiles (32 samples) per wave and evaluation; SPLIT = waves that share one ray's
-// batch of 32 * NT * SPLIT samples.  bf16: SPLIT 2 -> 8 waves, two per SIMD at 256 registers each, so one wave's
-// LDS/epilogue latency is covered by the other wave's MFMAs; the 2-part precisions need >256 registers of
-// operands and run one 512-register wave per SIMD.
+// batch of 32 * NT * SPLIT samples; RAYS = rays in flight per workgroup (each with its own RayLds block).
+//   bf16: 8 waves, two per SIMD at 256 registers each, so one wave's LDS/epilogue latency is covered by the other
+//         wave's MFMAs; the 2-part precisions need > 256 registers of operands: one 512-register wave per SIMD.
+//   WIDE (Nc + Nf > 128, e.g. 128 + 128): half as many rays per workgroup, twice the waves per ray and a 256-sample
+//         LDS block per ray, so the LDS footprint is unchanged.
 #ifndef NERFDS_BF16_NT
 #define NERFDS_BF16_NT 1
 #endif
 #ifndef NERFDS_BF16_SPLIT
 #define NERFDS_BF16_SPLIT 2
 #endif
-template <int P> struct Tune { static constexpr int NT = 1, SPLIT = 1; };
-template <> struct Tune<P_BF16> { static constexpr int NT = NERFDS_BF16_NT, SPLIT = NERFDS_BF16_SPLIT; };
-template <int P> constexpr int wg_waves() { return RAYS_PER_WG * Tune<P>::SPLIT; }
-// LDS map: [0, RING_BYTES) weight ring | padded fp32 biases (shared, coarse NerfMLP, fine NerfMLP) | RAYS_PER_WG x WaveLds
+template <int P, bool WIDE> struct Shape {
+  static constexpr int NT = 1, SPLIT = WIDE ? 2 : 1, RAYS = WIDE ? 2 : 4, MAXS = WIDE ? 256 : 128;
+};
+template <bool WIDE> struct Shape<P_BF16, WIDE> {
+  static constexpr int NT = NERFDS_BF16_NT, SPLIT = NERFDS_BF16_SPLIT * (WIDE ? 2 : 1), RAYS = WIDE ? 2 : 4, MAXS = WIDE ? 256 : 128;
+};
+template <int P> constexpr int wg_waves() { return Shape<P, false>::RAYS * Shape<P, false>::SPLIT; }
+static_assert(Shape<P_BF16, true>::RAYS * Shape<P_BF16, true>::SPLIT == wg_waves<P_BF16>() &&
+              Shape<P_F32, true>::RAYS * Shape<P_F32, true>::SPLIT == wg_waves<P_F32>(), "both shapes use the same workgroup size");
+// LDS map: [0, RING_BYTES) weight ring | padded fp32 biases (shared, coarse NerfMLP, fine NerfMLP) | RAYS x WaveLds
 constexpr int BIAS_OFF = RING_BYTES;
 template <class G> constexpr int bias_bytes() { return (Dims<G>::SHARED_BIAS_TILES + 2 * Dims<G>::NERF_BIAS_TILES) * 128; }
 
@@ -221,6 +235,7 @@ template <class G, int P> struct Pipe {
     static_assert(NS == 4, "protocol is written for a 4-stage ring");
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (!(NERFDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();      // raw barrier (no compiler-added fences)
+    if (NERFDS_DBG & 2) __builtin_amdgcn_s_sleep(4);
     issue_stage(s + NS - 1);
   }
   DEVI void prologue() {
@@ -353,10 +368,10 @@ DEVI void head(Pipe<G, P>& pipe, Cursor& cur, int h, f32x16 (&acc)[NT], const In
 // ------------------------------------------------------------------------------------------------
 // Scalar math helpers
 // ------------------------------------------------------------------------------------------------
-// sin with a 3-term Cody-Waite reduction (fma) and degree-9/8 minimax kernels on [-pi/4, pi/4]; ~1-2 ulp for
-// |a| < 1e5 (posenc arguments are |x| * 2^7 at most), libm beyond.
-DEVI float sin_cw(float a) {
-  if (__builtin_expect(fabsf(a) > 1.0e5f, 0)) return sinf(a);
+// sin / cos with a 3-term Cody-Waite reduction (fma) and degree-9/8 minimax kernels on [-pi/4, pi/4]: ~1-2 ulp while
+// the quadrant count stays exact in fp32 (|a| < ~1e7; posenc arguments are |x| * 2^7 at most).  Branch-free on purpose:
+// eval_batch must not contain divergent regions (see the note at eval_batch), which rules out libm's sinf/cosf.
+DEVI void sincos_cw(float a, float& sn_out, float& cs_out) {
   float k = rintf(a * 0.636619772f);
   int q = (int)k;
   float r = fmaf(-k, 1.57079601e+00f, a);
@@ -371,8 +386,14 @@ DEVI float sin_cw(float a) {
   pc = fmaf(pc, s, 4.16666567e-2f);
   pc = fmaf(pc, s, -0.5f);
   float cs = fmaf(pc, s, 1.0f);
-  float v = (q & 1) ? cs : sn;
-  return (q & 2) ? -v : v;
+  const float vs = (q & 1) ? cs : sn, vc = (q & 1) ? sn : cs;
+  sn_out = (q & 2) ? -vs : vs;
+  cs_out = ((q + 1) & 2) ? -vc : vc;
+}
+DEVI float sin_cw(float a) {
+  float sn, cs;
+  sincos_cw(a, sn, cs);
+  return sn;
 }
 
 DEVI float softplus_f(float x) {   // jax.nn.softplus = logaddexp(x, 0)
@@ -472,12 +493,13 @@ enum { SV_SIGMA = 0, SV_RGB = 1, SV_MASK = 4, SV_NORM = 5, SV_WP = 8, SV_ROT = 1
        SV_AX = 19, SV_SN = 22, SV_OMC = 23, SV_COUNT = 24 };
 enum { RC_WEMB = 0, RC_MEMB = 8, RC_VDENC = 16, RC_COUNT = 64 };
 
-struct WaveLds {
-  float zs[MAX_SAMPLES];      // z of the current level
-  float zn[MAX_SAMPLES];      // scratch: unsorted union / bins
-  float ws[MAX_SAMPLES];      // compositing weights of the level just rendered
-  float cdf[MAX_SAMPLES];
-  float sv[SV_COUNT][MAX_SAMPLES];   // per-sample results / parked state (SoA: conflict-free by sample)
+template <int MAXS> struct WaveLdsT {
+  static constexpr int MAX_S = MAXS;
+  float zs[MAXS];      // z of the current level
+  float zn[MAXS];      // scratch: unsorted union / bins
+  float ws[MAXS];      // compositing weights of the level just rendered
+  float cdf[MAXS];
+  float sv[SV_COUNT][MAXS];   // per-sample results / parked state (SoA: conflict-free by sample)
   float rayc[RC_COUNT];       // per-ray constants: warp GLO row, mask GLO row, posenc(viewdir)
 };
 
@@ -503,14 +525,19 @@ DEVI void rodrigues(float (&R)[9], const float (&w)[3], float st, float omc) {
 // the next network is parked in the wave's LDS block at once (it is going there for compositing anyway),
 // so the 8x256 trunk runs with (almost) only MFMA operands in registers.
 // ------------------------------------------------------------------------------------------------
-template <class G, int P, int NT>
-DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int level, int lane, int s_base, int S, WaveLds& L) {
+template <class G, int P, int NT, class LT>
+DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int level, int lane, int s_base, int S, LT& L) {
   // s_base already includes this wave's share of a split batch (32 * NT * q)
   using D = Dims<G>;
   const int h = lane >> 5, ln = lane & 31;
   auto sample_of = [&](int nt) { return s_base + 32 * nt + ln; };
   auto slot_of = [&](int nt) { const int s = sample_of(nt); return s < S ? s : S - 1; };   // clamp: tail lanes redo the last sample
-  auto writer = [&](int nt) { return h == 0 && sample_of(nt) < S; };
+  // Per-sample results are stored by EVERY lane, unconditionally, to slot_of(nt): the two lane halves of a sample
+  // (and the clamped tail lanes, which recompute sample S - 1) hold bit-identical values, so the duplicate stores are
+  // harmless.  They must not be predicated: eval_batch has to stay free of divergent (partial-EXEC) regions, because
+  // this hipcc places VGPR->AGPR live-range-split copies at the top of the join block, BEFORE exec is restored; the
+  // copy then saves only the active lanes and the later full-EXEC reload returns garbage in the others (seen as
+  // run-to-run varying rgb in the split-bf16 kernel).  Same reason for the branch-free sincos_cw above.
 
   float x[NT][3], xw[NT][3];
 #pragma unroll
@@ -554,11 +581,11 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
     for (int nt = 0; nt < NT; ++nt) {
       const float pm = fmaxf(hacc[nt][0], 0.f);                              // MaskMLP.output_activation = relu
       maskv[nt] = pm * ka.mask_ratio + rc.gt_mask * (1.0f - ka.mask_ratio);  // models.py:975
-      if (writer(nt)) L.sv[SV_MASK][sample_of(nt)] = pm;
+      L.sv[SV_MASK][slot_of(nt)] = pm;
     }
   } else {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) if (writer(nt)) L.sv[SV_MASK][sample_of(nt)] = 0.f;
+    for (int nt = 0; nt < NT; ++nt) L.sv[SV_MASK][slot_of(nt)] = 0.f;
   }
 
   // ---- SE3Field (warping.py:200-237) + exp_se3 (rigid_body.py:77-101) ----
@@ -589,7 +616,8 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
       const float theta = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);     // warping.py:219 (no epsilon, as the reference)
       w[0] /= theta; w[1] /= theta; w[2] /= theta;
       v0 /= theta; v1 /= theta; v2 /= theta;
-      const float st = sinf(theta), ct = cosf(theta);
+      float st, ct;
+      sincos_cw(theta, st, ct);
       const float omc = 1.0f - ct, tms = theta - st;
       float Rm[9];
       rodrigues(Rm, w, st, omc);
@@ -609,8 +637,8 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
 #pragma unroll
       for (int r = 0; r < 3; ++r)
         xw[nt][r] = Rm[3 * r] * x[nt][0] + Rm[3 * r + 1] * x[nt][1] + Rm[3 * r + 2] * x[nt][2] + pt[r];
-      if (writer(nt)) {
-        const int s = sample_of(nt);
+      {
+        const int s = slot_of(nt);
         // rotation field: normalize(R @ normalize(1,1,1)) (models.py:1292-1296); translation field: R @ 0 + p
         float rf[3];
 #pragma unroll
@@ -630,8 +658,8 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
   } else {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      if (writer(nt)) {
-        const int s = sample_of(nt);
+      {
+        const int s = slot_of(nt);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           L.sv[SV_WP + c][s] = x[nt][c];
@@ -670,9 +698,9 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
-    if (writer(nt)) {
-      L.sv[SV_WP + 3][sample_of(nt)] = wamb[nt][0];
-      L.sv[SV_WP + 4][sample_of(nt)] = wamb[nt][1];
+    {
+      L.sv[SV_WP + 3][slot_of(nt)] = wamb[nt][0];
+      L.sv[SV_WP + 4][slot_of(nt)] = wamb[nt][1];
     }
 
   // ---- NerfMLP of this level (modules.py:243-313; models.py:1043-1047, 1268-1270) ----
@@ -706,12 +734,12 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float nin[3] = {0.f, 0.f, 0.f};
-      if (writer(nt)) L.sv[SV_SIGMA][sample_of(nt)] = softplus_f(hacc[nt][0]);                    // models.py:577
+      L.sv[SV_SIGMA][slot_of(nt)] = softplus_f(hacc[nt][0]);                    // models.py:577
       if constexpr (G::PREDICT_NORM) {
         float n[3] = {hacc[nt][1], hacc[nt][2], hacc[nt][3]};
-        if (writer(nt)) {
+        {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) L.sv[SV_NORM + c][sample_of(nt)] = n[c];
+          for (int c = 0; c < 3; ++c) L.sv[SV_NORM + c][slot_of(nt)] = n[c];
         }
         normalize3(n);                                                      // models.py:1124
         if constexpr (G::HAS_WARP) {
@@ -726,9 +754,9 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
         }
         normalize3(nin);                                                    // models.py:1138
       } else {
-        if (writer(nt)) {
+        {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) L.sv[SV_NORM + c][sample_of(nt)] = 0.f;
+          for (int c = 0; c < 3; ++c) L.sv[SV_NORM + c][slot_of(nt)] = 0.f;
         }
       }
       build_chunks<P, D::COND_KC>(cond[nt], h, [&](int f) {
@@ -742,8 +770,8 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
     head<G, P, NT>(pipe, cur, h, hacc, c);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      if (writer(nt)) {
-        const int s = sample_of(nt);
+      {
+        const int s = slot_of(nt);
         L.sv[SV_RGB + 0][s] = sigmoid_f(hacc[nt][0]);                       // models.py:576
         L.sv[SV_RGB + 1][s] = sigmoid_f(hacc[nt][1]);
         L.sv[SV_RGB + 2][s] = sigmoid_f(hacc[nt][2]);
@@ -755,8 +783,8 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
 // ------------------------------------------------------------------------------------------------
 // Compositing of one level (model_utils.py:95-159, 272-317; models.py:1346-1415) -> ray record.
 // ------------------------------------------------------------------------------------------------
-template <class G>
-DEVI void composite(const KArgs& ka, const RayConst& rc, int ray, int lane, int S, bool at_infinity, WaveLds& L,
+template <class G, class LT>
+DEVI void composite(const KArgs& ka, const RayConst& rc, int ray, int lane, int S, bool at_infinity, LT& L,
                     float* __restrict__ rec_out, float* __restrict__ smp_out) {
   const float dnorm = sqrtf(rc.d[0] * rc.d[0] + rc.d[1] * rc.d[1] + rc.d[2] * rc.d[2]);
   const float last = at_infinity ? 1e10f : 1e-19f;
@@ -844,7 +872,8 @@ DEVI void composite(const KArgs& ka, const RayConst& rc, int ray, int lane, int 
 // Coarse -> fine: inverse-CDF resample + sorted union (model_utils.py:193-269; models.py:1522-1526).
 // On entry zs[0..nc) = coarse z, ws[0..nc) = coarse weights.  On exit zs[0..nc+nf) = sorted union.
 // ------------------------------------------------------------------------------------------------
-DEVI void resample(const KArgs& ka, int ray, int lane, int nc, int nf, WaveLds& L) {
+template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int nc, int nf, LT& L) {
+  constexpr int MAX_SAMPLES = LT::MAX_S;
   const int nb = nc - 1;          // bins = mid points (nc-1 of them); cdf has nb entries, cdf[0] = 0
   const int nw = nc - 2;          // weights[..., 1:-1]
   // pdf / cdf
@@ -932,9 +961,11 @@ DEVI void resample(const KArgs& ka, int ray, int lane, int nc, int nf, WaveLds& 
 // ------------------------------------------------------------------------------------------------
 // Kernel: persistent waves, one ray per wave per iteration.
 // ------------------------------------------------------------------------------------------------
-template <class G, int P>
-__global__ __launch_bounds__(64 * wg_waves<P>(), Tune<P>::SPLIT) void render_rays_kernel(const KArgs ka) {
-  constexpr int NT = Tune<P>::NT, SPLIT = Tune<P>::SPLIT, WAVES = wg_waves<P>(), BATCH = 32 * NT * SPLIT;
+template <class G, int P, bool WIDE>
+__global__ __launch_bounds__(64 * wg_waves<P>(), wg_waves<P>() / 4) void render_rays_kernel(const KArgs ka) {
+  using SH = Shape<P, WIDE>;
+  using WaveLds = WaveLdsT<SH::MAXS>;
+  constexpr int NT = SH::NT, SPLIT = SH::SPLIT, RAYS_PER_WG = SH::RAYS, WAVES = wg_waves<P>(), BATCH = 32 * NT * SPLIT;
   using Dm = Dims<G>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -947,6 +978,11 @@ __global__ __launch_bounds__(64 * wg_waves<P>(), Tune<P>::SPLIT) void render_ray
 #ifdef NERFDS_SETPRIO
   if (q == NERFDS_SETPRIO - 1) __builtin_amdgcn_s_setprio(1);
 #endif
+  if (NERFDS_DBG & 1) {
+    constexpr int total = BIAS_OFF + bias_bytes<G>() + RAYS_PER_WG * (int)sizeof(WaveLds);
+    for (int i = threadIdx.x; i < total / 4; i += 64 * WAVES) reinterpret_cast<float*>(g_smem)[i] = 0.f;
+    __syncthreads();
+  }
   Pipe<G, P> pipe;
   const rsrc_t rs_nerf[2] = {make_rsrc(ka.wstream[1], Pipe<G, P>::NERF_PAD * frag_bytes(P)),
                              make_rsrc(ka.wstream[2], Pipe<G, P>::NERF_PAD * frag_bytes(P))};
@@ -1069,14 +1105,24 @@ __global__ __launch_bounds__(64 * wg_waves<P>(), Tune<P>::SPLIT) void render_ray
 #define NERFDS_CAT2(a, b) a##b
 #define NERFDS_CAT(a, b) NERFDS_CAT2(a, b)
 
-extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::KArgs& ka, int grid, void* stream) {
-  constexpr int lds = nerfds::BIAS_OFF + nerfds::bias_bytes<nerfds::NERFDS_GRAPH>() + nerfds::RAYS_PER_WG * (int)sizeof(nerfds::WaveLds);
+template <bool WIDE> static void launch_shape(const nerfds::KArgs& ka, int num_cus, void* stream) {
+  using namespace nerfds;
+  using SH = Shape<NERFDS_PREC, WIDE>;
+  constexpr int lds = BIAS_OFF + bias_bytes<NERFDS_GRAPH>() + SH::RAYS * (int)sizeof(WaveLdsT<SH::MAXS>);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = nerfds::render_rays_kernel<nerfds::NERFDS_GRAPH, nerfds::NERFDS_PREC>;
+  auto kern = render_rays_kernel<NERFDS_GRAPH, NERFDS_PREC, WIDE>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nerfds::wg_waves<nerfds::NERFDS_PREC>()), lds, static_cast<hipStream_t>(stream), ka);
+  // one persistent workgroup per CU (LDS-bound), SH::RAYS rays per workgroup iteration
+  const long long groups = ((long long)ka.num_rays + SH::RAYS - 1) / SH::RAYS;
+  const int grid = (int)(groups < num_cus ? groups : num_cus);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wg_waves<NERFDS_PREC>()), lds, static_cast<hipStream_t>(stream), ka);
+}
+
+extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::KArgs& ka, int num_cus, void* stream) {
+  if (ka.nc + ka.nf > nerfds::Shape<nerfds::NERFDS_PREC, false>::MAXS) launch_shape<true>(ka, num_cus, stream);
+  else launch_shape<false>(ka, num_cus, stream);
 }

@@ -104,6 +104,26 @@ def test_nerf_ds_graph_full_samples_init_regime(prec):
     assert torch.isfinite(out[level]['ray_delta_x']).all()
 
 
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16'])
+def test_nerf_ds_graph_256_samples_per_ray(prec):
+  """BASELINE.json configs[4] shape: 128 coarse + 128 fine (256 on the fine pass) - the WIDE kernel shape
+  (2 rays per workgroup, twice the waves per ray)."""
+  cfg = nerf_ds_config(num_warp_embeds=4, num_coarse_samples=128, num_fine_samples=128)
+  params = init_params(cfg, 3, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  R = 7
+  rays, rng = _rays(R, 4, 12, spread=0.2)
+  t, u = rng.random((R, 128)), rng.random((R, 128))
+  ref = O.NerfModel(cfg, params).apply(rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, compute_sigma_gradient=False)
+  out = _model(cfg).apply({'params': params}, rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, return_samples=True,
+                          precision=prec)
+  assert out['fine']['z_vals'].shape == (R, 256) and torch.all(torch.diff(out['fine']['z_vals'], dim=-1) >= 0)
+  for level in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'acc', 'ray_delta_x'):
+      e = _relerr(out[level][k].cpu().numpy(), ref[level][k].numpy())
+      print(f'{prec} {level} {k}: {e:.2e}', file=sys.stderr)
+      assert e <= (RTOL[prec] if k == 'rgb' else 10 * RTOL[prec]), (level, k, e)
+
+
 def test_nerf_ds_trained_regime_and_deterministic_sampling():
   cfg = nerf_ds_config(num_warp_embeds=3, use_stratified_sampling=False)
   params = init_params(cfg, 2, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.2)

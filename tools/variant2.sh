@@ -1,0 +1,14 @@
+#!/bin/bash
+# Development: variants of one nerf_ds kernel.  usage: tools/variant2.sh name:prec:"-DFLAG" ...   (prec = bf16|bf16x3|f32)
+cd "$(dirname "$0")/../nerf-ds_amd/csrc" || exit 1
+mkdir -p build/abl ../nerfds_amd/_lib/abl
+for v in "$@"; do
+  n=${v%%:*}; r=${v#*:}; p=${r%%:*}; f=${r#*:}
+  case $p in bf16) P=P_BF16;; bf16x3) P=P_BF16X3;; f32) P=P_F32;; esac
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-value -c render_kernel.hip $f \
+      -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_PREC=$P -DNERFDS_NAME=nerfds_$p -Rpass-analysis=kernel-resource-usage -o build/abl/kv_$n.o 2>&1 | grep -E "error|VGPRs Spill" | sed "s/^/$n: /"
+    others=$(for q in bf16 bf16x3 f32; do [ $q != $p ] && echo build/k_nerfds_$q.o; done)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../nerfds_amd/_lib/abl/libnerfds_hip_$n.so build/abl/kv_$n.o $others \
+      build/k_static_bf16.o build/k_static_bf16x3.o build/k_static_f32.o build/host.o build/camera.o ) &
+done
+wait
