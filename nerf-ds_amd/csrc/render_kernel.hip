@@ -281,8 +281,13 @@ struct Cursor {
 // Bias of a tile for this lane, as an MFMA C operand: register r <-> row (r & 3) + 8 (r >> 2) + 4 h.
 DEVI f32x16 load_bias(int boff, int h) {
   f32x16 bv;
+  // 16 * h, recomputed from the lane id at every use (4 VALU): as a loop-invariant value it is the first thing the
+  // register allocator spills, and its reload (scratch_load + vmcnt(0)) then also waits for the LDS-DMA in flight.
+  // Being opaque, it also gives each accumulator its own ds_read_b128 x4 (no CSE -> no register copies).
   int hoff = 16 * h;
-  asm volatile("" : "+v"(hoff));      // each accumulator gets its own ds_read_b128 x4 (no CSE -> no register copies)
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_and_b32 %0, 32, %0\n\tv_lshrrev_b32 %0, 1, %0" : "=v"(hoff));
+#endif
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const f32x4 b = *reinterpret_cast<const f32x4*>(g_smem + boff + 32 * g + hoff);
@@ -483,6 +488,9 @@ template <int P, int KCH, class F> DEVI void build_chunks(Chunk<P> (&out)[KCH], 
       x[i] = h ? vb : va;
     }
     make_chunk<P>(out[c], x);
+    // Straight-line code (no branches since sin_cw lost its libm fallback): without a fence the scheduler interleaves
+    // the sin evaluations of every chunk and spills thousands of registers.
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
