@@ -205,6 +205,15 @@ const char* nerfds_last_error(const nerfds_ctx* ctx);
 int nerfds_camera_to_rays(int device, const nerfds_camera* cam, int64_t first_pixel, int64_t n, const float* pixels,
                           float* origins, float* directions, float* pixels_out, void* hip_stream);
 
+/* Frame output path that follows the gather (render.py:231-268): one frame of ray records ([height * width][NERFDS_RAY_REC]
+ * DEVICE floats, row major) -> rgb_u8 [height][width][3] (image_utils.image_to_uint8 of 'rgb', render.py:269) and
+ * debug_u8 [2 * height][3 * width][3], the mosaic  rgb | colorize(med_depth, near, far, invert) | normal  over
+ * predicted mask | |delta_x| * 10 | (med_points + 1.5) / 3  (render.py:263-268, visualization.py:199-235).
+ * colormap: [256][3] DEVICE doubles (matplotlib colormaps are float64; the reference uses 'magma').  Either output may be
+ * NULL.  Byte-exact with the numpy arithmetic of those lines. */
+int nerfds_frame_images(int device, const float* ray_records, int32_t height, int32_t width, double near_, double far_,
+                        const double* colormap, uint8_t* rgb_u8, uint8_t* debug_u8, void* hip_stream);
+
 /* Timing aid for bench.py: average device time (ms) of the render kernel launches recorded with HIP events
  * on the launch stream since the last reset; returns the number of launches measured. */
 int nerfds_kernel_time_ms(nerfds_ctx* ctx, int reset, double* total_ms);

@@ -26,6 +26,7 @@ void nerfds_launch_static_bf16(const KArgs&, int, void*);
 void nerfds_launch_static_bf16x3(const KArgs&, int, void*);
 void nerfds_launch_static_f32(const KArgs&, int, void*);
 void nerfds_launch_camera_rays(const nerfds::CameraParams&, long long, long long, const float*, float*, float*, float*, void*);
+void nerfds_launch_frame_images(const float*, int, int, float, float, const double*, uint8_t*, uint8_t*, void*);
 }
 static_assert(sizeof(nerfds_camera) == sizeof(nerfds::CameraParams), "nerfds_camera and CameraParams must have the same layout");
 
@@ -408,6 +409,22 @@ int nerfds_camera_to_rays(int device, const nerfds_camera* cam, int64_t first_pi
   nerfds::CameraParams cp;
   std::memcpy(&cp, cam, sizeof cp);
   nerfds_launch_camera_rays(cp, first_pixel, n, pixels, origins, directions, pixels_out, hip_stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return NERFDS_EDEVICE; }
+  return NERFDS_OK;
+}
+
+int nerfds_frame_images(int device, const float* ray_records, int32_t height, int32_t width, double near_, double far_,
+                        const double* colormap, uint8_t* rgb_u8, uint8_t* debug_u8, void* hip_stream) {
+  if (height < 0 || width < 0 || (!ray_records && (int64_t)height * width > 0) || (debug_u8 && !colormap)) {
+    g_create_error = "nerfds_frame_images: invalid argument";
+    return NERFDS_EINVAL;
+  }
+  if ((int64_t)height * width == 0 || (!rgb_u8 && !debug_u8)) return NERFDS_OK;
+  if (hipSetDevice(device) != hipSuccess) { g_create_error = "no such HIP device"; return NERFDS_EDEVICE; }
+  // scale_values (visualization.py:195-196): the range is formed in double (python floats), then applied in float32
+  const double range = std::max(far_ - near_, 1e-6);
+  nerfds_launch_frame_images(ray_records, height, width, (float)near_, (float)range, colormap, rgb_u8, debug_u8, hip_stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return NERFDS_EDEVICE; }
   return NERFDS_OK;

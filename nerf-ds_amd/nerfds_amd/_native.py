@@ -91,7 +91,8 @@ class Out(C.Structure):
 # every symbol include/nerfds.h declares
 SYMBOLS = ('nerfds_abi_version', 'nerfds_ctx_create', 'nerfds_ctx_load_weights', 'nerfds_render_rays',
            'nerfds_ctx_destroy', 'nerfds_last_error', 'nerfds_kernel_time_ms', 'nerfds_pack_stream_bytes',
-           'nerfds_pack_bias_floats', 'nerfds_pack_stream', 'nerfds_debug_mfma', 'nerfds_camera_to_rays')
+           'nerfds_pack_bias_floats', 'nerfds_pack_stream', 'nerfds_debug_mfma', 'nerfds_camera_to_rays',
+           'nerfds_frame_images')
 
 _lib = None
 
@@ -122,6 +123,8 @@ def load():
   lib.nerfds_debug_mfma.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
   lib.nerfds_camera_to_rays.argtypes = [C.c_int, C.POINTER(CameraStruct), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
+  lib.nerfds_frame_images.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
   if lib.nerfds_abi_version() != ABI_VERSION:
     raise RuntimeError('libnerfds_hip.so ABI version mismatch: rebuild')
   _lib = lib

@@ -1,0 +1,94 @@
+"""Frame output path: oracle known answers on CPU, byte-exact HIP-vs-oracle on the GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.join(os.path.dirname(__file__), '..')
+sys.path.insert(0, os.path.join(ROOT, 'nerf-ds_amd'))
+sys.path.insert(0, ROOT)
+from oracle import frame_oracle as FO      # noqa: E402
+
+
+def _records(H, W, seed, near, far):
+  rng = np.random.default_rng(seed)
+  r = rng.normal(size=(H * W, FO.RAY_REC)).astype(np.float32)
+  r[:, 0:3] = rng.random((H * W, 3)) * 1.2 - 0.1                      # rgb slightly out of [0, 1]: exercises the clip
+  r[:, FO.F_MED_DEPTH] = rng.random(H * W) * (far - near) * 1.3 + near - 0.15 * (far - near)      # some depths outside [near, far]
+  r[:7, FO.F_MED_DEPTH] = [near, far, 0.0, near - 1, far + 1, (near + far) / 2, near + (far - near) / 255]
+  r[7, FO.F_NORM:FO.F_NORM + 3] = 0.0                                 # zero normal: eps clamp
+  r[:, FO.F_MASK] = rng.random(H * W)
+  r[:, FO.F_MED_POINTS:FO.F_MED_POINTS + 5] = rng.random((H * W, 5)) * 3.4 - 1.7
+  return r
+
+
+def test_oracle_known_answers():
+  gray = FO.get_colormap('gray')
+  # gray map, no inversion: colorize(x) = x inside [cmin, cmax], white above, black below (visualization.py:229-233)
+  d = np.array([2.0, 6.0, 4.0, 1.0, 7.0], np.float32)
+  c = FO.colorize(d, 2.0, 6.0, gray)
+  np.testing.assert_allclose(c[:, 0], [0.0, 1.0, 0.5, 0.0, 1.0], atol=1e-6)
+  ci = FO.colorize(d, 2.0, 6.0, gray, invert=True)
+  np.testing.assert_allclose(ci[:, 0], [1.0, 0.0, 0.5, 1.0, 0.0], atol=1e-6)
+  assert ci.dtype == np.float64
+  np.testing.assert_array_equal(FO.image_to_uint8(np.array([-0.5, 0.0, 0.999, 1.0, 2.0, 0.5], np.float32)), [0, 0, 254, 255, 255, 127])
+  with pytest.raises(ValueError):
+    FO.image_to_uint8(np.zeros(3, np.int32))
+  sb = FO.get_colormap('sinebow')
+  np.testing.assert_allclose(sb[0], [1.0, 0.25, 0.25], atol=1e-12)     # sin^2(pi/2), sin^2(5 pi/6), sin^2(7 pi/6)
+  n = FO.normalize_vector(np.array([[3.0, 0.0, 4.0], [0.0, 0.0, 0.0]], np.float32))
+  np.testing.assert_allclose(n, [[0.6, 0.0, 0.8], [0.0, 0.0, 0.0]], atol=1e-7)
+
+
+def test_oracle_mosaic_layout():
+  H, W = 3, 4
+  r = np.zeros((H * W, FO.RAY_REC), np.float32)
+  r[:, 0:3] = [1.0, 0.0, 0.0]
+  r[:, FO.F_MED_DEPTH] = 2.0                       # == near -> inverted gray map -> white
+  r[:, FO.F_NORM:FO.F_NORM + 3] = [0.0, 0.0, 1.0]  # -> (0.5, 0.5, 1.0)
+  r[:, FO.F_MASK] = 0.5
+  r[:, FO.F_DELTA_X:FO.F_DELTA_X + 3] = [-0.05, 0.0, 0.2]
+  r[:, FO.F_MED_POINTS:FO.F_MED_POINTS + 3] = [1.5, -1.5, 0.0]
+  rgb, dbg = FO.frame_images(r, H, W, 2.0, 6.0, FO.get_colormap('gray'))
+  assert rgb.shape == (H, W, 3) and dbg.shape == (2 * H, 3 * W, 3) and dbg.dtype == np.uint8
+  np.testing.assert_array_equal(rgb[0, 0], [255, 0, 0])
+  np.testing.assert_array_equal(dbg[0, 0], [255, 0, 0])               # rgb tile
+  np.testing.assert_array_equal(dbg[0, W], [255, 255, 255])           # depth tile
+  np.testing.assert_array_equal(dbg[0, 2 * W], [127, 127, 255])       # normal tile
+  np.testing.assert_array_equal(dbg[H, 0], [127, 127, 127])           # mask tile
+  np.testing.assert_array_equal(dbg[H, W], [127, 0, 255])             # |delta_x| * 10, clipped
+  np.testing.assert_array_equal(dbg[H, 2 * W], [255, 0, 127])         # (p + 1.5) / 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,cmap', [(5, 7, 'sinebow'), (64, 48, 'gray'), (600, 800, 'random')])
+def test_hip_frame_images_are_byte_exact(H, W, cmap):
+  import torch
+  from nerfds_amd.frames import frame_images
+  near, far = 0.3, 1.7
+  r = _records(H, W, 3, near, far)
+  table = np.random.default_rng(9).random((256, 3)) if cmap == 'random' else FO.get_colormap(cmap)
+  want_rgb, want_dbg = FO.frame_images(r, H, W, near, far, table)
+  rgb, dbg = frame_images(torch.from_numpy(r).cuda(), H, W, near, far, colormap=table)
+  assert int((rgb.cpu().numpy() != want_rgb).sum()) == 0
+  diff = dbg.cpu().numpy() != want_dbg
+  assert int(diff.sum()) == 0, f'{int(diff.sum())} differing bytes, first at {np.argwhere(diff)[0]}'
+  only_rgb, none = frame_images(torch.from_numpy(r).cuda(), H, W, near, far, want_debug=False)
+  assert none is None and int((only_rgb.cpu().numpy() != want_rgb).sum()) == 0
+
+
+@pytest.mark.gpu
+def test_frame_images_from_a_render_dict():
+  import torch
+  from nerfds_amd import _native as N
+  from nerfds_amd.frames import frame_images, raw_result
+  H, W = 6, 5
+  r = _records(H, W, 4, 0.3, 1.7)
+  rec = torch.from_numpy(r).cuda()
+  render = {k: rec[:, o:o + n].reshape(H, W, n) for k, (o, n) in N.RAY_FIELDS.items()}
+  a = frame_images(rec, H, W, 0.3, 1.7, colormap='sinebow')
+  b = frame_images(render, H, W, 0.3, 1.7, colormap='sinebow')
+  assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+  raw = raw_result(render)
+  assert set(raw) == {'rgb', 'med_depth', 'ray_norm', 'ray_delta_x', 'med_points', 'ray_predicted_mask', 'ray_rotation_field'}
