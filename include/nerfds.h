@@ -214,6 +214,33 @@ int nerfds_camera_to_rays(int device, const nerfds_camera* cam, int64_t first_pi
 int nerfds_frame_images(int device, const float* ray_records, int32_t height, int32_t width, double near_, double far_,
                         const double* colormap, uint8_t* rgb_u8, uint8_t* debug_u8, void* hip_stream);
 
+/* ---- Training step (BASELINE config 4; replaces training.train_step, hypernerf/training.py:198-511, for the first-order
+ * objective  loss = mean((rgb_fine - gt)^2) + mean((rgb_coarse - gt)^2)  (training.py:265-274, 459-466, 481) --------------
+ * A trainer owns the parameters as ONE flat fp32 device vector (leaves in a fixed order, named by their Flax paths: see
+ * nerfds_trainer_leaf), their gradient, the Adam moments (flax.optim.Adam: b1 0.9, b2 0.999, eps 1e-8) and an HBM workspace
+ * sized for max_rays.  nerfds_trainer_step: forward + backward of both levels into the gradient vector, then (unless
+ * NERFDS_TRAIN_GRADS_ONLY) one Adam update with `learning_rate`.  rays / target_rgb ([R][3]) / rnd->t_rand,u_rand are DEVICE
+ * pointers; rnd == NULL or NULL uniforms = non-stratified sampling.  loss_host (optional, HOST float[2]) receives
+ * {loss of the fine level (coarse if there is none), loss of the coarse level} and synchronises the stream.
+ * Only the configs/nerf_ds.gin graph is built (NERFDS_ENOTSUP otherwise).  The norm / mask / regulariser losses of the full
+ * objective (training.py:276-438) are not part of config 4 and not built. */
+typedef struct nerfds_trainer nerfds_trainer;
+#define NERFDS_TRAIN_GRADS_ONLY 1u
+int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_cfg* cfg, int64_t max_rays);
+int nerfds_trainer_destroy(nerfds_trainer* t);
+int64_t nerfds_trainer_param_count(const nerfds_trainer* t);
+int nerfds_trainer_num_leaves(const nerfds_trainer* t);
+int nerfds_trainer_leaf(const nerfds_trainer* t, int index, char* name, int name_cap, int64_t* offset, int32_t* rows, int32_t* cols);
+float* nerfds_trainer_params(nerfds_trainer* t);   /* DEVICE [param_count], read/write between steps */
+float* nerfds_trainer_grads(nerfds_trainer* t);    /* DEVICE [param_count], valid after a step */
+/* HOST <-> DEVICE copies of a whole vector; which: 0 parameters, 1 gradients, 2 / 3 Adam first / second moments */
+int nerfds_trainer_download(nerfds_trainer* t, int which, float* host);
+int nerfds_trainer_upload(nerfds_trainer* t, int which, const float* host);
+int nerfds_trainer_reset_optimizer(nerfds_trainer* t);   /* zero the Adam moments and the step count */
+int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* extra,
+                        const nerfds_rand* rnd, float learning_rate, uint32_t flags, float* loss_host, void* hip_stream);
+const char* nerfds_trainer_last_error(const nerfds_trainer* t);
+
 /* Timing aid for bench.py: average device time (ms) of the render kernel launches recorded with HIP events
  * on the launch stream since the last reset; returns the number of launches measured. */
 int nerfds_kernel_time_ms(nerfds_ctx* ctx, int reset, double* total_ms);

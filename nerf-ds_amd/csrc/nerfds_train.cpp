@@ -1,0 +1,409 @@
+// Training step of BASELINE config 4: loss = MSE(rgb_fine, gt) + MSE(rgb_coarse, gt)
+// (training.py:265-274, 459-466, 481), gradients w.r.t. every parameter of the nerf_ds graph (training.py:494) and the
+// Adam update (training.py:508).  First correct version: fp32 throughout, activations of every layer resident in HBM
+// (needed for dW), dense layers as plain row-major GEMMs through rocBLAS (forward X W, backward dX = dZ W^T and
+// dW = X^T dZ), everything else in the hand-written kernels of train_kernels.hip.  The two levels are processed one
+// after the other through the same workspace: their losses are independent sums and the fine z samples carry a
+// stop_gradient (model_utils.py:241), so no gradient crosses from the fine level into the coarse one.
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "nerfds.h"
+#include "train_kernels.h"
+
+using namespace nerfds_train;
+
+namespace {
+
+thread_local std::string g_train_error;
+
+struct Leaf { std::string name; int64_t off; int rows, cols; };
+struct LayerP { int64_t w, b; int K, N; };
+struct MlpP { std::vector<LayerP> hidden; int in_dim = 0, width = 0, depth = 0, skip = -1; };
+struct Seg { const float* x; int ld; int K; float* dx; int dld; bool acc; };
+
+void window(float* out, int bands, float alpha) {   // model_utils.py:420-436
+  for (int b = 0; b < 8; ++b) {
+    const double x = std::min(std::max((double)alpha - b, 0.0), 1.0);
+    out[b] = b < bands ? (float)(0.5 * (1.0 + std::cos(M_PI * x + M_PI))) : 0.f;
+  }
+}
+
+}  // namespace
+
+struct nerfds_trainer {
+  int device = 0;
+  nerfds_model_cfg cfg{};
+  Dims D{};
+  int64_t max_rays = 0;
+  std::vector<Leaf> leaves;
+  int64_t P = 0;
+  MlpP mask, warp, hyper, trunk[2];
+  LayerP mask_out, warp_w, warp_v, hyper_out, bott[2], alpha[2], rgb_h[2], rgb_out[2];
+  int64_t warp_tbl = -1, mask_tbl = -1;
+  float *theta = nullptr, *grad = nullptr, *m1 = nullptr, *m2 = nullptr;
+  int64_t adam_t = 0;
+  rocblas_handle blas = nullptr;
+  float* ws = nullptr;      // one workspace allocation
+  size_t ws_floats = 0;
+  float* loss_dev = nullptr;
+  std::string err;
+  // workspace views (set by carve())
+  float *zc, *zf, *wc, *rs_scratch, *x, *mask_in, *mask_logit, *warp_in, *wv, *xw, *hyper_in, *wamb, *trunk_in, *bottv, *alphav, *sigma,
+      *cond, *rgb_hv, *rgb_logit, *weights, *rgb_ray, *g0, *g1, *g2, *d_trunk_in, *d_rgb_logit, *d_alpha, *dxw, *dwamb, *dwv, *d_warp_in,
+      *d_hyper_in, *d_mask_in, *d_mask_logit;
+  std::vector<float*> mask_h, warp_h, hyper_h, trunk_h;
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+  ~nerfds_trainer() {
+    for (float* p : {theta, grad, m1, m2, ws, loss_dev}) if (p) (void)hipFree(p);
+    if (blas) (void)rocblas_destroy_handle(blas);
+  }
+};
+
+namespace {
+
+int64_t add_leaf(nerfds_trainer& t, const std::string& name, int rows, int cols) {
+  const int64_t off = t.P;
+  t.leaves.push_back({name, off, rows, cols});
+  t.P += (int64_t)rows * cols;
+  return off;
+}
+LayerP add_dense(nerfds_trainer& t, const std::string& name, int K, int N) {
+  LayerP l;
+  l.K = K; l.N = N;
+  l.w = add_leaf(t, name + "/kernel", K, N);
+  l.b = add_leaf(t, name + "/bias", 1, N);
+  return l;
+}
+MlpP add_mlp(nerfds_trainer& t, const std::string& name, int in_dim, int width, int depth, int skip) {
+  MlpP m;
+  m.in_dim = in_dim; m.width = width; m.depth = depth; m.skip = skip;
+  for (int l = 0; l < depth; ++l) {
+    const int K = (l == 0 ? in_dim : width) + ((l == skip && l > 0) ? in_dim : 0);     // modules.py:66-67
+    m.hidden.push_back(add_dense(t, name + "/hidden_" + std::to_string(l), K, width));
+  }
+  return m;
+}
+
+// ---- row-major GEMM helpers over column-major rocBLAS -------------------------------------------------------------
+// C[M x N] (ldc) = A[M x K] (lda) * B[K x N] (ldb) + beta * C
+rocblas_status gemm_nn(rocblas_handle h, int64_t M, int N, int K, const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc) {
+  const float one = 1.f;
+  return rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, N, (rocblas_int)M, K, &one, B, ldb, A, lda, &beta, C, ldc);
+}
+// C[K x N] (ldc) = A[M x K]^T (lda) * B[M x N] (ldb) + beta * C        (contraction over the M rows)
+rocblas_status gemm_tn(rocblas_handle h, int64_t M, int N, int K, const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc) {
+  const float one = 1.f;
+  return rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, N, K, (rocblas_int)M, &one, B, ldb, A, lda, &beta, C, ldc);
+}
+// C[M x K] (ldc) = A[M x N] (lda) * B[K x N]^T (ldb) + beta * C
+rocblas_status gemm_nt(rocblas_handle h, int64_t M, int N, int K, const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc) {
+  const float one = 1.f;
+  return rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, K, (rocblas_int)M, N, &one, B, ldb, A, lda, &beta, C, ldc);
+}
+
+struct Run {
+  nerfds_trainer& t;
+  hipStream_t st;
+  int64_t M;
+  bool ok = true;
+  void chk(rocblas_status s) { if (s != rocblas_status_success) ok = false; }
+
+  // y[M x N] (ldy) = act(sum_s x_s W[rows of s] + b)
+  void dense_fwd(const LayerP& L, const std::vector<Seg>& segs, float* y, int ldy, bool relu) {
+    int k0 = 0;
+    for (size_t i = 0; i < segs.size(); ++i) {
+      chk(gemm_nn(t.blas, M, L.N, segs[i].K, segs[i].x, segs[i].ld, t.theta + L.w + (int64_t)k0 * L.N, L.N, i ? 1.f : 0.f, y, ldy));
+      k0 += segs[i].K;
+    }
+    bias_act(st, y, t.theta + L.b, M, L.N, ldy, relu ? 1 : 0);
+  }
+  // dy[M x N] (ldy) is d loss / d (post-activation output y); relu_y != nullptr -> mask with y > 0 first (needs ldy == N)
+  void dense_bwd(const LayerP& L, const std::vector<Seg>& segs, float* dy, int ldy, const float* relu_y) {
+    if (relu_y) relu_bwd(st, dy, relu_y, M * L.N);
+    colsum_add(st, dy, M, L.N, ldy, t.grad + L.b);
+    int k0 = 0;
+    for (const Seg& s : segs) {
+      chk(gemm_tn(t.blas, M, L.N, s.K, s.x, s.ld, dy, ldy, 1.f, t.grad + L.w + (int64_t)k0 * L.N, L.N));
+      if (s.dx) chk(gemm_nt(t.blas, M, L.N, s.K, dy, ldy, t.theta + L.w + (int64_t)k0 * L.N, L.N, s.acc ? 1.f : 0.f, s.dx, s.dld));
+      k0 += s.K;
+    }
+  }
+  void mlp_fwd(const MlpP& m, const float* in0, const std::vector<float*>& h) {
+    for (int l = 0; l < m.depth; ++l) {
+      std::vector<Seg> segs;
+      if (l > 0) segs.push_back({h[l - 1], m.width, m.width, nullptr, 0, false});
+      if (l == 0 || l == m.skip) segs.push_back({in0, m.in_dim, m.in_dim, nullptr, 0, false});
+      dense_fwd(m.hidden[l], segs, h[l], m.width, true);
+    }
+  }
+  // cur holds d loss / d h[depth-1] on entry; other is a second [M x width] buffer; d_in0 receives d loss / d in0
+  void mlp_bwd(const MlpP& m, const float* in0, const std::vector<float*>& h, float* cur, float* other, float* d_in0) {
+    bool in0_written = false;
+    for (int l = m.depth - 1; l >= 0; --l) {
+      std::vector<Seg> segs;
+      if (l > 0) segs.push_back({h[l - 1], m.width, m.width, other, m.width, false});
+      if (l == 0 || l == m.skip) { segs.push_back({in0, m.in_dim, m.in_dim, d_in0, m.in_dim, in0_written}); in0_written = true; }
+      dense_bwd(m.hidden[l], segs, cur, m.width, h[l]);
+      std::swap(cur, other);
+    }
+  }
+};
+
+void carve(nerfds_trainer& t) {
+  const int64_t R = t.max_rays, Nc = t.cfg.num_coarse_samples, Nf = t.cfg.num_fine_samples, S = Nc + Nf, M = R * S;
+  size_t need = 0;
+  std::vector<std::pair<float**, size_t>> views;
+  auto take = [&](float** p, size_t n) { views.push_back({p, n}); need += (n + 63) & ~(size_t)63; };
+  const Dims& D = t.D;
+  take(&t.zc, R * Nc); take(&t.zf, R * S); take(&t.wc, R * Nc); take(&t.rs_scratch, R * (2 * Nc + Nf));
+  take(&t.x, M * 3); take(&t.mask_in, M * D.mask_in); take(&t.mask_logit, M);
+  t.mask_h.assign(t.mask.depth, nullptr); for (auto& p : t.mask_h) take(&p, M * t.mask.width);
+  take(&t.warp_in, M * D.warp_in); t.warp_h.assign(t.warp.depth, nullptr); for (auto& p : t.warp_h) take(&p, M * t.warp.width);
+  take(&t.wv, M * 6); take(&t.xw, M * 3);
+  take(&t.hyper_in, M * D.hyper_in); t.hyper_h.assign(t.hyper.depth, nullptr); for (auto& p : t.hyper_h) take(&p, M * t.hyper.width);
+  take(&t.wamb, M * 2); take(&t.trunk_in, M * D.trunk_in);
+  t.trunk_h.assign(t.trunk[0].depth, nullptr); for (auto& p : t.trunk_h) take(&p, M * t.trunk[0].width);
+  take(&t.bottv, M * t.trunk[0].width); take(&t.alphav, M * 4); take(&t.sigma, M); take(&t.cond, M * (6 * D.vd_bands + 6 * D.nm_bands));
+  take(&t.rgb_hv, M * t.rgb_h[0].N); take(&t.rgb_logit, M * 3); take(&t.weights, M); take(&t.rgb_ray, R * 3);
+  take(&t.g0, M * t.trunk[0].width); take(&t.g1, M * t.trunk[0].width); take(&t.g2, M * t.trunk[0].width);
+  take(&t.d_trunk_in, M * D.trunk_in); take(&t.d_rgb_logit, M * 3); take(&t.d_alpha, M * 4); take(&t.dxw, M * 3); take(&t.dwamb, M * 2);
+  take(&t.dwv, M * 6); take(&t.d_warp_in, M * D.warp_in); take(&t.d_hyper_in, M * D.hyper_in); take(&t.d_mask_in, M * D.mask_in);
+  take(&t.d_mask_logit, M);
+  t.ws_floats = need;
+  // (pointers into vectors: the vectors are not resized after this point)
+  float* base = t.ws;
+  if (!base) return;
+  for (auto& v : views) { *v.first = base; base += (v.second + 63) & ~(size_t)63; }
+}
+
+int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const float* z, const nerfds_rays* rays, const float* target,
+              const nerfds_extra* ex, const Windows& W, float* weights_out) {
+  const Dims& D = t.D;
+  Run r{t, st, (int64_t)R * S};
+  const int64_t M = r.M;
+  const float* viewdirs = rays->viewdirs ? rays->viewdirs : rays->directions;
+  // ---------------- forward ----------------
+  encode_inputs(st, D, R, S, rays->origins, rays->directions, z, rays->warp_id, t.cfg.num_warp_embeds, t.theta + t.warp_tbl, t.theta + t.mask_tbl,
+                W, t.x, t.mask_in, t.warp_in, t.hyper_in);
+  r.mlp_fwd(t.mask, t.mask_in, t.mask_h);
+  r.dense_fwd(t.mask_out, {{t.mask_h.back(), t.mask.width, t.mask.width, nullptr, 0, false}}, t.mask_logit, 1, false);
+  mask_post(st, D, R, S, t.mask_logit, rays->gt_mask, ex->mask_ratio, t.warp_in, t.hyper_in);
+  r.mlp_fwd(t.warp, t.warp_in, t.warp_h);
+  r.dense_fwd(t.warp_w, {{t.warp_h.back(), t.warp.width, t.warp.width, nullptr, 0, false}}, t.wv, 6, false);
+  r.dense_fwd(t.warp_v, {{t.warp_h.back(), t.warp.width, t.warp.width, nullptr, 0, false}}, t.wv + 3, 6, false);
+  se3_fwd(st, M, t.wv, t.x, t.xw);
+  r.mlp_fwd(t.hyper, t.hyper_in, t.hyper_h);
+  r.dense_fwd(t.hyper_out, {{t.hyper_h.back(), t.hyper.width, t.hyper.width, nullptr, 0, false}}, t.wamb, 2, false);
+  trunk_in(st, D, M, t.xw, t.wamb, W, t.trunk_in);
+  const MlpP& trunk = t.trunk[level];
+  const int TW = trunk.width, VD = 6 * D.vd_bands, NM = 6 * D.nm_bands, CW = VD + NM;
+  r.mlp_fwd(trunk, t.trunk_in, t.trunk_h);
+  float* tout = t.trunk_h.back();
+  r.dense_fwd(t.bott[level], {{tout, TW, TW, nullptr, 0, false}}, t.bottv, TW, false);          // modules.py:255 (no activation)
+  r.dense_fwd(t.alpha[level], {{tout, TW, TW, nullptr, 0, false}}, t.alphav, 4, false);          // modules.py:273-274
+  alpha_post(st, D, R, S, t.alphav, t.wv, viewdirs, W, t.sigma, t.cond);
+  // query_rgb input order [bottleneck | viewdir enc | trunk_output | normal enc] (modules.py:300-310)
+  r.dense_fwd(t.rgb_h[level], {{t.bottv, TW, TW, nullptr, 0, false}, {t.cond, CW, VD, nullptr, 0, false}, {tout, TW, TW, nullptr, 0, false},
+                               {t.cond + VD, CW, NM, nullptr, 0, false}}, t.rgb_hv, t.rgb_h[level].N, true);
+  r.dense_fwd(t.rgb_out[level], {{t.rgb_hv, t.rgb_h[level].N, t.rgb_h[level].N, nullptr, 0, false}}, t.rgb_logit, 3, false);
+  composite_loss(st, R, S, z, rays->directions, t.sigma, t.rgb_logit, target, t.cfg.use_sample_at_infinity, t.cfg.use_white_background, t.rgb_ray,
+                 weights_out, t.loss_dev + level, t.d_rgb_logit, t.d_alpha);
+  // ---------------- backward ----------------
+  const int RW = t.rgb_h[level].N;
+  r.dense_bwd(t.rgb_out[level], {{t.rgb_hv, RW, RW, t.g0, RW, false}}, t.d_rgb_logit, 3, nullptr);
+  r.dense_bwd(t.rgb_h[level], {{t.bottv, TW, TW, t.g1, TW, false}, {t.cond, CW, VD, nullptr, 0, false}, {tout, TW, TW, t.g2, TW, false},
+                               {t.cond + VD, CW, NM, nullptr, 0, false}}, t.g0, RW, t.rgb_hv);
+  r.dense_bwd(t.bott[level], {{tout, TW, TW, t.g2, TW, true}}, t.g1, TW, nullptr);
+  r.dense_bwd(t.alpha[level], {{tout, TW, TW, t.g2, TW, true}}, t.d_alpha, 4, nullptr);
+  r.mlp_bwd(trunk, t.trunk_in, t.trunk_h, t.g2, t.g0, t.d_trunk_in);
+  trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, t.dxw, t.dwamb);
+  r.dense_bwd(t.hyper_out, {{t.hyper_h.back(), t.hyper.width, t.hyper.width, t.g0, t.hyper.width, false}}, t.dwamb, 2, nullptr);
+  r.mlp_bwd(t.hyper, t.hyper_in, t.hyper_h, t.g0, t.g1, t.d_hyper_in);
+  se3_bwd(st, M, t.wv, t.x, t.dxw, t.dwv);
+  r.dense_bwd(t.warp_w, {{t.warp_h.back(), t.warp.width, t.warp.width, t.g0, t.warp.width, false}}, t.dwv, 6, nullptr);
+  r.dense_bwd(t.warp_v, {{t.warp_h.back(), t.warp.width, t.warp.width, t.g0, t.warp.width, true}}, t.dwv + 3, 6, nullptr);
+  r.mlp_bwd(t.warp, t.warp_in, t.warp_h, t.g0, t.g1, t.d_warp_in);
+  shared_in_bwd(st, D, R, S, t.d_warp_in, t.d_hyper_in, t.mask_logit, ex->mask_ratio, rays->warp_id, t.cfg.num_warp_embeds,
+                t.grad + t.warp_tbl, t.d_mask_logit);
+  r.dense_bwd(t.mask_out, {{t.mask_h.back(), t.mask.width, t.mask.width, t.g0, t.mask.width, false}}, t.d_mask_logit, 1, nullptr);
+  r.mlp_bwd(t.mask, t.mask_in, t.mask_h, t.g0, t.g1, t.d_mask_in);
+  mask_in_bwd(st, D, R, S, t.d_mask_in, rays->warp_id, t.cfg.num_warp_embeds, t.grad + t.mask_tbl);
+  if (!r.ok) return t.fail(NERFDS_EDEVICE, "rocBLAS sgemm failed");
+  return NERFDS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nerfds_trainer_last_error(const nerfds_trainer* t) { return t ? t->err.c_str() : g_train_error.c_str(); }
+
+int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_cfg* c, int64_t max_rays) {
+  if (!out || !c || max_rays <= 0) { g_train_error = "null / invalid argument"; return NERFDS_EINVAL; }
+  *out = nullptr;
+  if (c->abi_version != NERFDS_ABI_VERSION) { g_train_error = "abi_version mismatch"; return NERFDS_EINVAL; }
+  // the graph of configs/nerf_ds.gin (the one BASELINE config 4 names); anything else has no training path yet
+  if (!(c->use_warp && c->use_hyper_sheet && c->use_predicted_mask && c->predict_norm && c->use_x_in_rgb_condition && c->use_mask_in_warp &&
+        c->use_mask_in_hyper && c->use_viewdirs && c->mask_output_relu && c->nerf_rgb_branch_depth == 1 && c->glo_num_dims == 8 &&
+        c->hyper_num_dims == 2 && c->num_warp_embeds > 0 && c->num_coarse_samples >= 4 && c->num_fine_samples >= 0)) {
+    g_train_error = "training step is built for the configs/nerf_ds.gin graph only";
+    return NERFDS_ENOTSUP;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_train_error = "no such HIP device (no CPU fallback)"; return NERFDS_EDEVICE; }
+  if (hipSetDevice(device) != hipSuccess) { g_train_error = "hipSetDevice failed"; return NERFDS_EDEVICE; }
+  std::unique_ptr<nerfds_trainer> t(new nerfds_trainer);
+  t->device = device; t->cfg = *c; t->max_rays = max_rays;
+  Dims& D = t->D;
+  D.mask_bands = c->mask_max_deg; D.warp_bands = c->warp_max_deg; D.hyp_bands = c->hyper_sheet_max_deg; D.sp_bands = c->spatial_point_max_deg;
+  D.hp_bands = c->hyper_point_max_deg; D.vd_bands = c->viewdir_max_deg; D.nm_bands = c->norm_input_max_deg;
+  if (std::max({D.mask_bands, D.warp_bands, D.hyp_bands, D.sp_bands, D.hp_bands, D.vd_bands, D.nm_bands}) > 8) { g_train_error = "more than 8 posenc bands"; return NERFDS_ENOTSUP; }
+  D.mask_in = 6 * D.mask_bands + 8; D.warp_in = 6 * D.warp_bands + 8 + 1; D.hyper_in = 6 * D.hyp_bands + 8 + 1; D.trunk_in = 6 * D.sp_bands + 4 * D.hp_bands;
+  // flat parameter vector: leaves in this order, names = the Flax paths (params.py)
+  t->warp_tbl = add_leaf(*t, "warp_embed/embed/embedding", c->num_warp_embeds, 8);
+  t->warp = add_mlp(*t, "warp_field/trunk", D.warp_in, c->warp_trunk_width, c->warp_trunk_depth, c->warp_skip);
+  t->warp_w = add_dense(*t, "warp_field/branches_w/logit", c->warp_trunk_width, 3);
+  t->warp_v = add_dense(*t, "warp_field/branches_v/logit", c->warp_trunk_width, 3);
+  t->mask_tbl = add_leaf(*t, "mask_embed/embed/embedding", c->num_warp_embeds, 8);
+  t->mask = add_mlp(*t, "mask_mlp/MLP_0", D.mask_in, c->mask_width, c->mask_depth, c->mask_skip);
+  t->mask_out = add_dense(*t, "mask_mlp/MLP_0/logit", c->mask_width, 1);
+  t->hyper = add_mlp(*t, "hyper_sheet_mlp/MLP_0", D.hyper_in, c->hyper_sheet_width, c->hyper_sheet_depth, c->hyper_sheet_skip);
+  t->hyper_out = add_dense(*t, "hyper_sheet_mlp/MLP_0/logit", c->hyper_sheet_width, 2);
+  const int levels = c->num_fine_samples > 0 ? 2 : 1;
+  const int TW = c->nerf_trunk_width, cond = 6 * D.vd_bands + 6 * D.nm_bands;
+  for (int lv = 0; lv < levels; ++lv) {
+    const std::string pre = lv ? "nerf_mlps_fine" : "nerf_mlps_coarse";
+    t->trunk[lv] = add_mlp(*t, pre + "/trunk_mlp", D.trunk_in, TW, c->nerf_trunk_depth, c->nerf_skip);
+    t->bott[lv] = add_dense(*t, pre + "/bottleneck", TW, TW);
+    t->alpha[lv] = add_dense(*t, pre + "/alpha_mlp/logit", TW, 4);
+    t->rgb_h[lv] = add_dense(*t, pre + "/rgb_mlp/hidden_0", 2 * TW + cond, c->nerf_rgb_branch_width);
+    t->rgb_out[lv] = add_dense(*t, pre + "/rgb_mlp/logit", c->nerf_rgb_branch_width, 3);
+  }
+  carve(*t);      // sizes only
+  const size_t pbytes = (size_t)t->P * sizeof(float);
+  if (hipMalloc(&t->theta, pbytes) != hipSuccess || hipMalloc(&t->grad, pbytes) != hipSuccess || hipMalloc(&t->m1, pbytes) != hipSuccess ||
+      hipMalloc(&t->m2, pbytes) != hipSuccess || hipMalloc(&t->loss_dev, 2 * sizeof(float)) != hipSuccess ||
+      hipMalloc(&t->ws, t->ws_floats * sizeof(float)) != hipSuccess) {
+    g_train_error = "hipMalloc failed (workspace of " + std::to_string(t->ws_floats * 4 >> 20) + " MiB)";
+    return NERFDS_ENOMEM;
+  }
+  (void)hipMemset(t->theta, 0, pbytes); (void)hipMemset(t->m1, 0, pbytes); (void)hipMemset(t->m2, 0, pbytes); (void)hipMemset(t->grad, 0, pbytes);
+  carve(*t);
+  if (rocblas_create_handle(&t->blas) != rocblas_status_success) { g_train_error = "rocblas_create_handle failed"; return NERFDS_EDEVICE; }
+  *out = t.release();
+  return NERFDS_OK;
+}
+
+int nerfds_trainer_destroy(nerfds_trainer* t) {
+  if (!t) return NERFDS_OK;
+  (void)hipSetDevice(t->device);
+  delete t;
+  return NERFDS_OK;
+}
+
+int64_t nerfds_trainer_param_count(const nerfds_trainer* t) { return t ? t->P : -1; }
+int nerfds_trainer_num_leaves(const nerfds_trainer* t) { return t ? (int)t->leaves.size() : -1; }
+int nerfds_trainer_leaf(const nerfds_trainer* t, int index, char* name, int name_cap, int64_t* offset, int32_t* rows, int32_t* cols) {
+  if (!t || index < 0 || index >= (int)t->leaves.size()) return NERFDS_EINVAL;
+  const Leaf& l = t->leaves[index];
+  if (name && name_cap > 0) { std::strncpy(name, l.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (offset) *offset = l.off;
+  if (rows) *rows = l.rows;
+  if (cols) *cols = l.cols;
+  return NERFDS_OK;
+}
+float* nerfds_trainer_params(nerfds_trainer* t) { return t ? t->theta : nullptr; }
+float* nerfds_trainer_grads(nerfds_trainer* t) { return t ? t->grad : nullptr; }
+
+// which: 0 parameters, 1 gradients, 2 / 3 Adam first / second moment
+static float* vec_of(nerfds_trainer* t, int which) { return which == 0 ? t->theta : which == 1 ? t->grad : which == 2 ? t->m1 : which == 3 ? t->m2 : nullptr; }
+int nerfds_trainer_download(nerfds_trainer* t, int which, float* host) {
+  if (!t || !host || !vec_of(t, which)) return NERFDS_EINVAL;
+  (void)hipSetDevice(t->device);
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, vec_of(t, which), (size_t)t->P * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return t->fail(NERFDS_EDEVICE, "download failed");
+  return NERFDS_OK;
+}
+int nerfds_trainer_upload(nerfds_trainer* t, int which, const float* host) {
+  if (!t || !host || !vec_of(t, which)) return NERFDS_EINVAL;
+  (void)hipSetDevice(t->device);
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(vec_of(t, which), host, (size_t)t->P * 4, hipMemcpyHostToDevice) != hipSuccess)
+    return t->fail(NERFDS_EDEVICE, "upload failed");
+  return NERFDS_OK;
+}
+
+int nerfds_trainer_reset_optimizer(nerfds_trainer* t) {
+  if (!t) return NERFDS_EINVAL;
+  (void)hipSetDevice(t->device);
+  (void)hipMemset(t->m1, 0, (size_t)t->P * 4); (void)hipMemset(t->m2, 0, (size_t)t->P * 4);
+  t->adam_t = 0;
+  return NERFDS_OK;
+}
+
+int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* ex, const nerfds_rand* rnd,
+                        float learning_rate, uint32_t flags, float* loss_host, void* hip_stream) {
+  if (!t) return NERFDS_EINVAL;
+  if (!rays || !target_rgb || !ex || !rays->origins || !rays->directions || !rays->warp_id) return t->fail(NERFDS_EINVAL, "null argument");
+  if (rays->num_rays <= 0 || rays->num_rays > t->max_rays) return t->fail(NERFDS_EINVAL, "num_rays must be in [1, max_rays = %lld]", (long long)t->max_rays);
+  if (ex->mask_ratio != 1.0f && !rays->gt_mask) return t->fail(NERFDS_EINVAL, "rays_dict['mask'] is required when mask_ratio != 1");
+  if (hipSetDevice(t->device) != hipSuccess) return t->fail(NERFDS_EDEVICE, "hipSetDevice failed");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (rocblas_set_stream(t->blas, st) != rocblas_status_success) return t->fail(NERFDS_EDEVICE, "rocblas_set_stream failed");
+  const int R = (int)rays->num_rays, Nc = t->cfg.num_coarse_samples, Nf = t->cfg.num_fine_samples;
+  Windows W;
+  window(W.mask, t->D.mask_bands, ex->warp_alpha);          // models.py:967
+  window(W.warp, t->D.warp_bands, ex->warp_alpha);
+  window(W.hyp, t->D.hyp_bands, ex->hyper_sheet_alpha);
+  window(W.sp, t->D.sp_bands, ex->nerf_alpha);
+  window(W.hp, t->D.hp_bands, ex->hyper_alpha);
+  window(W.nm, t->D.nm_bands, ex->norm_input_alpha);
+  (void)hipMemsetAsync(t->grad, 0, (size_t)t->P * 4, st);
+  (void)hipMemsetAsync(t->loss_dev, 0, 2 * sizeof(float), st);
+  const int strat = ex->use_stratified_sampling;
+  coarse_z(st, R, Nc, ex->near, ex->far, strat, rnd ? rnd->t_rand : nullptr, t->zc);
+  int rc = run_level(*t, st, 0, R, Nc, t->zc, rays, target_rgb, ex, W, t->wc);
+  if (rc != NERFDS_OK) return rc;
+  if (Nf > 0) {
+    resample(st, R, Nc, Nf, t->zc, t->wc, strat, rnd ? rnd->u_rand : nullptr, t->zf, t->rs_scratch);
+    rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights);
+    if (rc != NERFDS_OK) return rc;
+  }
+  if (!(flags & NERFDS_TRAIN_GRADS_ONLY)) {
+    const double b1 = 0.9, b2 = 0.999;
+    const double tt = (double)(t->adam_t + 1);
+    adam(st, t->theta, t->grad, t->m1, t->m2, t->P, learning_rate, (float)b1, (float)b2, 1e-8f, (float)(1.0 - std::pow(b1, tt)),
+         (float)(1.0 - std::pow(b2, tt)));
+    t->adam_t += 1;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return t->fail(NERFDS_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+  if (loss_host) {
+    float l[2];
+    if (hipMemcpyAsync(l, t->loss_dev, sizeof l, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return t->fail(NERFDS_EDEVICE, "loss read-back failed");
+    loss_host[0] = Nf > 0 ? l[1] : l[0];     // fine (the level render_image returns), coarse
+    loss_host[1] = l[0];
+  }
+  return NERFDS_OK;
+}
+
+}  // extern "C"

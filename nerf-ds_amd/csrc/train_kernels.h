@@ -1,0 +1,36 @@
+// Declarations shared by train_kernels.hip (element-wise / per-ray kernels) and nerfds_train.cpp (orchestration).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nerfds_train {
+
+struct Dims {      // the nerf_ds graph's widths (from nerfds_model_cfg)
+  int mask_bands, warp_bands, hyp_bands, sp_bands, hp_bands, vd_bands, nm_bands;
+  int mask_in, warp_in, hyper_in, trunk_in;     // 44, 33, 45, 52
+};
+struct Windows {   // posenc windows (model_utils.py:420-436), one weight per band
+  float mask[8], warp[8], hyp[8], sp[8], hp[8], nm[8];
+};
+
+void coarse_z(hipStream_t, int R, int Nc, float near_, float far_, int stratified, const float* t_rand, float* z);
+void resample(hipStream_t, int R, int Nc, int Nf, const float* zc, const float* wc, int stratified, const float* u_rand, float* zf, float* scratch);
+void encode_inputs(hipStream_t, const Dims&, int R, int S, const float* o, const float* d, const float* z, const uint32_t* warp_id, int n_embeds,
+                   const float* warp_tbl, const float* mask_tbl, const Windows&, float* x, float* mask_in, float* warp_in, float* hyper_in);
+void bias_act(hipStream_t, float* y, const float* b, long long M, int N, int ld, int relu);
+void mask_post(hipStream_t, const Dims&, int R, int S, const float* logit, const float* gt, float ratio, float* warp_in, float* hyper_in);
+void se3_fwd(hipStream_t, long long M, const float* wv, const float* x, float* xw);
+void se3_bwd(hipStream_t, long long M, const float* wv, const float* x, const float* dxw, float* dwv);
+void trunk_in(hipStream_t, const Dims&, long long M, const float* xw, const float* wamb, const Windows&, float* tin);
+void trunk_in_bwd(hipStream_t, const Dims&, long long M, const float* dtin, const float* xw, const float* wamb, const Windows&, float* dxw, float* dwamb);
+void alpha_post(hipStream_t, const Dims&, int R, int S, const float* alpha, const float* wv, const float* viewdirs, const Windows&, float* sigma, float* cond);
+void composite_loss(hipStream_t, int R, int S, const float* z, const float* dirs, const float* sigma, const float* rgb_logit, const float* target,
+                    int at_infinity, int white, float* rgb_ray, float* weights, float* loss, float* d_rgb_logit, float* d_alpha);
+void relu_bwd(hipStream_t, float* dy, const float* y, long long n);
+void colsum_add(hipStream_t, const float* dz, long long M, int N, int ld, float* db);
+void shared_in_bwd(hipStream_t, const Dims&, int R, int S, const float* d_warp_in, const float* d_hyper_in, const float* mask_logit, float ratio,
+                   const uint32_t* warp_id, int n_embeds, float* d_warp_tbl, float* d_mask_logit);
+void mask_in_bwd(hipStream_t, const Dims&, int R, int S, const float* d_mask_in, const uint32_t* warp_id, int n_embeds, float* d_mask_tbl);
+void adam(hipStream_t, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2);
+
+}  // namespace nerfds_train

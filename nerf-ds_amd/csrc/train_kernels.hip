@@ -1,0 +1,429 @@
+// Element-wise / per-ray kernels of the training step (BASELINE config 4): everything of the
+// nerf_ds graph that is not a dense layer, forward AND backward, in fp32.  The dense layers themselves are plain
+// [samples x width] GEMMs over HBM-resident activations (rocBLAS, see nerfds_train.cpp): a training step has to keep
+// every layer's activations for dW anyway, so this path is HBM-resident by design, unlike the fused render kernel.
+// One thread per sample unless stated; sample m = ray * S + s.  Reference lines are cited per kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "train_kernels.h"
+
+namespace nerfds_train {
+
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+// posenc feature g of a C-vector, layout [band][sin, cos][channel] (model_utils.py:398-417), windowed (420-436)
+template <int C> __device__ __forceinline__ float posenc_val(int g, const float* x, const float* win) {
+  const int band = g / (2 * C), sc = (g % (2 * C)) / C, ch = g % C;
+  return win[band] * sinf(x[ch] * (float)(1 << band) + (sc ? 1.57079637f : 0.0f));
+}
+// d feature / d x[ch]
+template <int C> __device__ __forceinline__ float posenc_dval(int g, const float* x, const float* win) {
+  const int band = g / (2 * C), sc = (g % (2 * C)) / C, ch = g % C;
+  return win[band] * (float)(1 << band) * cosf(x[ch] * (float)(1 << band) + (sc ? 1.57079637f : 0.0f));
+}
+
+// ---- sampling (model_utils.py:55-92) ---------------------------------------------------------------------------
+__global__ void k_coarse_z(int R, int Nc, float near_, float far_, int stratified, const float* __restrict__ t_rand, float* __restrict__ z) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)R * Nc) return;
+  const int s = (int)(i % Nc);
+  auto zlin = [&](int q) {
+    const float t = (Nc > 1) ? (float)q / (float)(Nc - 1) : 0.f;
+    return near_ * (1.0f - t) + far_ * t;
+  };
+  float v = zlin(s);
+  if (stratified && t_rand) {
+    const float lo = s > 0 ? 0.5f * (v + zlin(s - 1)) : v, hi = s + 1 < Nc ? 0.5f * (zlin(s + 1) + v) : v;
+    v = lo + (hi - lo) * t_rand[i];
+  }
+  z[i] = v;
+}
+
+// ---- inverse-CDF resample + sorted union (model_utils.py:193-269), one thread per ray; no gradient (line 241) -----
+__global__ void k_resample(int R, int Nc, int Nf, const float* __restrict__ zc, const float* __restrict__ wc, int stratified,
+                           const float* __restrict__ u_rand, float* __restrict__ zf, float* __restrict__ scratch) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* z = zc + (size_t)r * Nc;
+  const float* w = wc + (size_t)r * Nc;
+  const int nb = Nc - 1, nw = Nc - 2;
+  float* cdf = scratch + (size_t)r * (2 * Nc + Nf);       // [nb]
+  float* bins = cdf + Nc;                                  // [nb]
+  float* zs = bins + Nc;                                   // [Nf]
+  float tot = 0.f;
+  for (int i = 0; i < nw; ++i) tot += w[i + 1] + 1e-5f;
+  cdf[0] = 0.f;
+  float c = 0.f;
+  for (int i = 0; i < nw; ++i) { c += (w[i + 1] + 1e-5f) / tot; cdf[i + 1] = c; }
+  for (int i = 0; i < nb; ++i) bins[i] = 0.5f * (z[i + 1] + z[i]);
+  for (int k = 0; k < Nf; ++k) {
+    const float u = (stratified && u_rand) ? u_rand[(size_t)r * Nf + k] : (Nf > 1 ? (float)k / (float)(Nf - 1) : 0.f);
+    int lo = 0, hi = nb;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+    int k0 = lo - 1; if (k0 < 0) k0 = 0;
+    const int k1 = (k0 + 1 < nb) ? k0 + 1 : nb - 1;
+    const float b0 = fminf(bins[k0], bins[nb - 2]), b1 = fmaxf(bins[k1], bins[1]);
+    const float c0 = fminf(cdf[k0], cdf[nb - 2]), c1 = fmaxf(cdf[k1], cdf[1]);
+    float denom = c1 - c0; if (denom < 1e-5f) denom = 1.0f;
+    zs[k] = b0 + (u - c0) / denom * (b1 - b0);
+  }
+  // sort(concat(z_coarse, z_fine)): rank sort (stable)
+  float* out = zf + (size_t)r * (Nc + Nf);
+  const int n = Nc + Nf;
+  for (int i = 0; i < n; ++i) {
+    const float v = i < Nc ? z[i] : zs[i - Nc];
+    int rank = 0;
+    for (int q = 0; q < n; ++q) { const float o = q < Nc ? z[q] : zs[q - Nc]; rank += (o < v || (o == v && q < i)) ? 1 : 0; }
+    out[rank] = v;
+  }
+}
+
+// ---- inputs of the three shared nets (models.py:931-975, 729-732; modules.py:367-434; warping.py:200-237) --------
+__global__ void k_encode_inputs(Dims D, int R, int S, const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z,
+                                const uint32_t* __restrict__ warp_id, int n_embeds, const float* __restrict__ warp_tbl,
+                                const float* __restrict__ mask_tbl, Windows W, float* __restrict__ x, float* __restrict__ mask_in,
+                                float* __restrict__ warp_in, float* __restrict__ hyper_in) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= (long long)R * S) return;
+  const int r = (int)(m / S);
+  float p[3];
+  for (int c = 0; c < 3; ++c) { p[c] = o[3 * r + c] + z[m] * d[3 * r + c]; x[3 * m + c] = p[c]; }
+  uint32_t id = warp_id ? warp_id[r] : 0u;
+  if (id >= (uint32_t)n_embeds) id = n_embeds - 1;      // jnp gathers clamp
+  float* mi = mask_in + m * D.mask_in;
+  for (int g = 0; g < 6 * D.mask_bands; ++g) mi[g] = posenc_val<3>(g, p, W.mask);
+  for (int g = 0; g < 8; ++g) mi[6 * D.mask_bands + g] = mask_tbl[id * 8 + g];
+  float* wi = warp_in + m * D.warp_in;
+  for (int g = 0; g < 6 * D.warp_bands; ++g) wi[g] = posenc_val<3>(g, p, W.warp);
+  for (int g = 0; g < 8; ++g) wi[6 * D.warp_bands + g] = warp_tbl[id * 8 + g];
+  float* hi = hyper_in + m * D.hyper_in;
+  for (int g = 0; g < 6 * D.hyp_bands; ++g) hi[g] = posenc_val<3>(g, p, W.hyp);
+  for (int g = 0; g < 8; ++g) hi[6 * D.hyp_bands + g] = warp_tbl[id * 8 + g];
+}
+
+__global__ void k_bias_act(float* __restrict__ y, const float* __restrict__ b, long long M, int N, int ld, int relu) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const long long row = i / N;
+  const int col = (int)(i % N);
+  float v = y[row * ld + col] + b[col];
+  y[row * ld + col] = relu ? fmaxf(v, 0.f) : v;
+}
+
+// mask = relu(logit) * ratio + gt * (1 - ratio) (models.py:975) appended to the warp / hyper inputs (models.py:729-732)
+__global__ void k_mask_post(Dims D, int R, int S, const float* __restrict__ logit, const float* __restrict__ gt, float ratio,
+                            float* __restrict__ warp_in, float* __restrict__ hyper_in) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= (long long)R * S) return;
+  const float pm = fmaxf(logit[m], 0.f);
+  const float g = gt ? gt[m / S] : 0.f;
+  const float v = pm * ratio + g * (1.0f - ratio);
+  warp_in[m * D.warp_in + D.warp_in - 1] = v;
+  hyper_in[m * D.hyper_in + D.hyper_in - 1] = v;
+}
+
+// ---- SE(3): x' = exp_se3(w / |w|, v / |w|, |w|) x (warping.py:219-237, rigid_body.py:59-101), generic in the scalar -----
+struct Dual {      // value + gradient w.r.t. (w0 w1 w2 v0 v1 v2)
+  float v, g[6];
+};
+__device__ __forceinline__ Dual dconst(float c) { Dual r; r.v = c; for (int i = 0; i < 6; ++i) r.g[i] = 0.f; return r; }
+__device__ __forceinline__ Dual operator+(const Dual& a, const Dual& b) { Dual r; r.v = a.v + b.v; for (int i = 0; i < 6; ++i) r.g[i] = a.g[i] + b.g[i]; return r; }
+__device__ __forceinline__ Dual operator-(const Dual& a, const Dual& b) { Dual r; r.v = a.v - b.v; for (int i = 0; i < 6; ++i) r.g[i] = a.g[i] - b.g[i]; return r; }
+__device__ __forceinline__ Dual operator-(const Dual& a) { Dual r; r.v = -a.v; for (int i = 0; i < 6; ++i) r.g[i] = -a.g[i]; return r; }
+__device__ __forceinline__ Dual operator*(const Dual& a, const Dual& b) { Dual r; r.v = a.v * b.v; for (int i = 0; i < 6; ++i) r.g[i] = a.g[i] * b.v + a.v * b.g[i]; return r; }
+__device__ __forceinline__ Dual operator/(const Dual& a, const Dual& b) {
+  Dual r; const float inv = 1.0f / b.v; r.v = a.v * inv;
+  for (int i = 0; i < 6; ++i) r.g[i] = (a.g[i] - r.v * b.g[i]) * inv;
+  return r;
+}
+__device__ __forceinline__ Dual operator*(const Dual& a, float b) { Dual r; r.v = a.v * b; for (int i = 0; i < 6; ++i) r.g[i] = a.g[i] * b; return r; }
+__device__ __forceinline__ Dual dsqrt(const Dual& a) { Dual r; r.v = sqrtf(a.v); const float k = 0.5f / r.v; for (int i = 0; i < 6; ++i) r.g[i] = a.g[i] * k; return r; }
+__device__ __forceinline__ Dual dsin(const Dual& a) { Dual r; r.v = sinf(a.v); const float k = cosf(a.v); for (int i = 0; i < 6; ++i) r.g[i] = a.g[i] * k; return r; }
+__device__ __forceinline__ Dual dcos(const Dual& a) { Dual r; r.v = cosf(a.v); const float k = -sinf(a.v); for (int i = 0; i < 6; ++i) r.g[i] = a.g[i] * k; return r; }
+__device__ __forceinline__ float dsqrt(float a) { return sqrtf(a); }
+__device__ __forceinline__ float dsin(float a) { return sinf(a); }
+__device__ __forceinline__ float dcos(float a) { return cosf(a); }
+__device__ __forceinline__ float tconst(float c, const float*) { return c; }
+__device__ __forceinline__ Dual tconst(float c, const Dual*) { return dconst(c); }
+
+// R (row major) and p of exp_se3 for raw head outputs (w, v)
+template <class T> __device__ void se3_Rp(const T (&w_raw)[3], const T (&v_raw)[3], T (&Rm)[9], T (&p)[3]) {
+  const T* tag = nullptr;
+  const T theta = dsqrt(w_raw[0] * w_raw[0] + w_raw[1] * w_raw[1] + w_raw[2] * w_raw[2]);      // no epsilon, as the reference
+  T w[3], v[3];
+  for (int i = 0; i < 3; ++i) { w[i] = w_raw[i] / theta; v[i] = v_raw[i] / theta; }
+  const T st = dsin(theta), ct = dcos(theta);
+  const T one = tconst(1.0f, tag), zero = tconst(0.0f, tag);
+  const T omc = one - ct, tms = theta - st;
+  const T W[9] = {zero, -w[2], w[1], w[2], zero, -w[0], -w[1], w[0], zero};
+  for (int r = 0; r < 3; ++r) {
+    T g[3];
+    for (int c = 0; c < 3; ++c) {
+      const T w2 = W[3 * r] * W[c] + W[3 * r + 1] * W[3 + c] + W[3 * r + 2] * W[6 + c];
+      const T id = (r == c) ? one : zero;
+      Rm[3 * r + c] = id + st * W[3 * r + c] + omc * w2;                                     // rigid_body.py:59-74
+      g[c] = ((r == c) ? theta : zero) + omc * W[3 * r + c] + tms * w2;                       // rigid_body.py:94-95
+    }
+    p[r] = g[0] * v[0] + g[1] * v[1] + g[2] * v[2];
+  }
+}
+
+__global__ void k_se3_fwd(long long M, const float* __restrict__ wv, const float* __restrict__ x, float* __restrict__ xw) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float w[3] = {wv[6 * m], wv[6 * m + 1], wv[6 * m + 2]}, v[3] = {wv[6 * m + 3], wv[6 * m + 4], wv[6 * m + 5]};
+  float Rm[9], p[3];
+  se3_Rp<float>(w, v, Rm, p);
+  for (int r = 0; r < 3; ++r) xw[3 * m + r] = Rm[3 * r] * x[3 * m] + Rm[3 * r + 1] * x[3 * m + 1] + Rm[3 * r + 2] * x[3 * m + 2] + p[r];
+}
+
+// d loss / d (w, v) from d loss / d x'   (x is a constant: the observation-space sample point)
+__global__ void k_se3_bwd(long long M, const float* __restrict__ wv, const float* __restrict__ x, const float* __restrict__ dxw,
+                          float* __restrict__ dwv) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  Dual w[3], v[3];
+  for (int i = 0; i < 3; ++i) { w[i] = dconst(wv[6 * m + i]); w[i].g[i] = 1.f; v[i] = dconst(wv[6 * m + 3 + i]); v[i].g[3 + i] = 1.f; }
+  Dual Rm[9], p[3];
+  se3_Rp<Dual>(w, v, Rm, p);
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < 3; ++r) {
+    const Dual xr = Rm[3 * r] * x[3 * m] + Rm[3 * r + 1] * x[3 * m + 1] + Rm[3 * r + 2] * x[3 * m + 2] + p[r];
+    for (int i = 0; i < 6; ++i) acc[i] += dxw[3 * m + r] * xr.g[i];
+  }
+  for (int i = 0; i < 6; ++i) dwv[6 * m + i] = acc[i];
+}
+
+// ---- NerfMLP trunk input: posenc(x') | posenc(ambient coords) (models.py:493-523) and its backward -------------------
+__global__ void k_trunk_in(Dims D, long long M, const float* __restrict__ xw, const float* __restrict__ wamb, Windows W, float* __restrict__ tin) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float p[3] = {xw[3 * m], xw[3 * m + 1], xw[3 * m + 2]}, a[2] = {wamb[2 * m], wamb[2 * m + 1]};
+  float* t = tin + m * D.trunk_in;
+  for (int g = 0; g < 6 * D.sp_bands; ++g) t[g] = posenc_val<3>(g, p, W.sp);
+  for (int g = 0; g < 4 * D.hp_bands; ++g) t[6 * D.sp_bands + g] = posenc_val<2>(g, a, W.hp);
+}
+__global__ void k_trunk_in_bwd(Dims D, long long M, const float* __restrict__ dtin, const float* __restrict__ xw, const float* __restrict__ wamb,
+                               Windows W, float* __restrict__ dxw, float* __restrict__ dwamb) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float p[3] = {xw[3 * m], xw[3 * m + 1], xw[3 * m + 2]}, a[2] = {wamb[2 * m], wamb[2 * m + 1]};
+  const float* t = dtin + m * D.trunk_in;
+  for (int c = 0; c < 3; ++c) {
+    float acc = 0.f;
+    for (int bs = 0; bs < 2 * D.sp_bands; ++bs) acc += t[3 * bs + c] * posenc_dval<3>(3 * bs + c, p, W.sp);
+    dxw[3 * m + c] = acc;
+  }
+  for (int c = 0; c < 2; ++c) {
+    float acc = 0.f;
+    for (int bs = 0; bs < 2 * D.hp_bands; ++bs) acc += t[6 * D.sp_bands + 2 * bs + c] * posenc_dval<2>(2 * bs + c, a, W.hp);
+    dwamb[2 * m + c] = acc;
+  }
+}
+
+// ---- after the alpha head: sigma (models.py:577) and the rgb condition [posenc(viewdir) | posenc(R^T n)] ---------------
+// (models.py:401-405, 1124-1150; the normal branch carries a stop_gradient, models.py:1132-1133 -> no backward)
+__global__ void k_alpha_post(Dims D, int R, int S, const float* __restrict__ alpha, const float* __restrict__ wv, const float* __restrict__ viewdirs,
+                             Windows W, float* __restrict__ sigma, float* __restrict__ cond) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= (long long)R * S) return;
+  const int r = (int)(m / S);
+  sigma[m] = softplus_f(alpha[4 * m]);
+  float n[3] = {alpha[4 * m + 1], alpha[4 * m + 2], alpha[4 * m + 3]};
+  auto normalize = [](float (&v)[3]) {
+    const float inv = 1.0f / sqrtf(fmaxf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2], 1.1920929e-07f));
+    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+  };
+  normalize(n);
+  const float w[3] = {wv[6 * m], wv[6 * m + 1], wv[6 * m + 2]}, v[3] = {wv[6 * m + 3], wv[6 * m + 4], wv[6 * m + 5]};
+  float Rm[9], p[3];
+  se3_Rp<float>(w, v, Rm, p);
+  float nin[3];
+  for (int c = 0; c < 3; ++c) nin[c] = Rm[c] * n[0] + Rm[3 + c] * n[1] + Rm[6 + c] * n[2];       // R^T n (inverse warp of a vector)
+  normalize(nin);
+  const float vd[3] = {viewdirs[3 * r], viewdirs[3 * r + 1], viewdirs[3 * r + 2]};
+  float* c = cond + m * (6 * D.vd_bands + 6 * D.nm_bands);
+  const float ones[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  for (int g = 0; g < 6 * D.vd_bands; ++g) c[g] = posenc_val<3>(g, vd, ones);
+  for (int g = 0; g < 6 * D.nm_bands; ++g) c[6 * D.vd_bands + g] = posenc_val<3>(g, nin, W.nm);
+}
+
+// ---- compositing (model_utils.py:95-159), MSE loss (training.py:265-274) and the backward of both; one thread per ray ----
+__global__ void k_composite_loss(int R, int S, const float* __restrict__ z, const float* __restrict__ dirs, const float* __restrict__ sigma,
+                                 const float* __restrict__ rgb_logit, const float* __restrict__ target, int at_infinity, int white,
+                                 float* __restrict__ rgb_ray, float* __restrict__ weights, float* __restrict__ loss,
+                                 float* __restrict__ d_rgb_logit, float* __restrict__ d_alpha) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* zr = z + (size_t)r * S;
+  const float dn = sqrtf(dirs[3 * r] * dirs[3 * r] + dirs[3 * r + 1] * dirs[3 * r + 1] + dirs[3 * r + 2] * dirs[3 * r + 2]);
+  const float last = at_infinity ? 1e10f : 1e-19f;
+  float T = 1.0f, acc[3] = {0.f, 0.f, 0.f}, wsum = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const size_t m = (size_t)r * S + s;
+    const float dist = ((s == S - 1) ? last : (zr[s + 1] - zr[s])) * dn;
+    const float a = 1.0f - expf(-sigma[m] * dist);
+    const float w = a * T;
+    weights[m] = w;
+    wsum += w;
+    for (int c = 0; c < 3; ++c) acc[c] += w / (1.0f + expf(-rgb_logit[3 * m + c]));
+    T *= (1.0f - a) + 1e-10f;
+  }
+  float g[3], gsum = 0.f, l = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    if (white) acc[c] += 1.0f - wsum;
+    rgb_ray[3 * r + c] = acc[c];
+    const float e = acc[c] - target[3 * r + c];
+    l += e * e;
+    g[c] = 2.0f * e / (3.0f * (float)R);
+    gsum += g[c];
+  }
+  atomicAdd(loss, l / (3.0f * (float)R));
+  // backward: w_i = a_i T_i, T_i = prod_{j<i} (1 - a_j + eps);  dL/da_i = G_i T_i - (sum_{k>i} G_k w_k) / (1 - a_i + eps)
+  float suffix = 0.f;
+  for (int s = S - 1; s >= 0; --s) {
+    const size_t m = (size_t)r * S + s;
+    const float dist = ((s == S - 1) ? last : (zr[s + 1] - zr[s])) * dn;
+    const float sg = sigma[m];
+    const float ex = expf(-sg * dist);
+    const float a = 1.0f - ex;
+    const float w = weights[m];
+    const float om = (1.0f - a) + 1e-10f;
+    const float Ti = (a > 0.f) ? w / a : 0.f;     // T_i (only its product with d a / d sigma matters; a == 0 only if sigma == 0)
+    float G = white ? -gsum : 0.f;
+    for (int c = 0; c < 3; ++c) {
+      const float col = 1.0f / (1.0f + expf(-rgb_logit[3 * m + c]));
+      G += g[c] * col;
+      d_rgb_logit[3 * m + c] = g[c] * w * col * (1.0f - col);
+    }
+    const float dLda = G * Ti - suffix / om;
+    const float dads = dist * ex;                                   // d a / d sigma
+    d_alpha[4 * m] = dLda * dads * (1.0f - expf(-sg));              // d sigma / d sigma_raw = sigmoid(sigma_raw) = 1 - exp(-sigma)
+    d_alpha[4 * m + 1] = 0.f; d_alpha[4 * m + 2] = 0.f; d_alpha[4 * m + 3] = 0.f;      // normal channels: stop_gradient
+    suffix += G * w;
+  }
+}
+
+__global__ void k_relu_bwd(float* __restrict__ dy, const float* __restrict__ y, long long n) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n && !(y[i] > 0.f)) dy[i] = 0.f;
+}
+
+// db[n] += sum_m dz[m][n]
+__global__ void k_colsum_add(const float* __restrict__ dz, long long M, int N, int ld, float* __restrict__ db) {
+  __shared__ float red[256];
+  const int rows_per_pass = 256 / N > 0 ? 256 / N : 1;
+  const int tid = threadIdx.x;
+  const long long chunk = 4096;
+  const long long r0 = blockIdx.x * chunk, r1 = (r0 + chunk < M) ? r0 + chunk : M;
+  for (int c0 = 0; c0 < N; c0 += 256) {
+    const int col = c0 + tid % (N < 256 ? N : 256), sub = tid / (N < 256 ? N : 256);
+    float s = 0.f;
+    if (col < N && sub < rows_per_pass)
+      for (long long r = r0 + sub; r < r1; r += rows_per_pass) s += dz[r * ld + col];
+    red[tid] = s;
+    __syncthreads();
+    if (N < 256) {
+      if (tid < N) { float t = 0.f; for (int k = 0; k < rows_per_pass; ++k) t += red[tid + k * N]; atomicAdd(db + tid, t); }
+    } else if (col < N) {
+      atomicAdd(db + col, s);
+    }
+    __syncthreads();
+  }
+}
+
+// gradient of the shared-net inputs: the mask column (models.py:729-732) -> mask head, the GLO columns -> embedding rows
+__global__ void k_shared_in_bwd(Dims D, int R, int S, const float* __restrict__ d_warp_in, const float* __restrict__ d_hyper_in,
+                                const float* __restrict__ mask_logit, float ratio, const uint32_t* __restrict__ warp_id, int n_embeds,
+                                float* __restrict__ d_warp_tbl, float* __restrict__ d_mask_logit) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  uint32_t id = warp_id ? warp_id[r] : 0u;
+  if (id >= (uint32_t)n_embeds) id = n_embeds - 1;
+  float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) {
+    const size_t m = (size_t)r * S + s;
+    const float* dw = d_warp_in + m * D.warp_in;
+    const float* dh = d_hyper_in + m * D.hyper_in;
+    for (int g = 0; g < 8; ++g) e[g] += dw[6 * D.warp_bands + g] + dh[6 * D.hyp_bands + g];
+    const float dmask = dw[D.warp_in - 1] + dh[D.hyper_in - 1];
+    d_mask_logit[m] = (mask_logit[m] > 0.f) ? dmask * ratio : 0.f;
+  }
+  for (int g = 0; g < 8; ++g) atomicAdd(d_warp_tbl + id * 8 + g, e[g]);
+}
+__global__ void k_mask_in_bwd(Dims D, int R, int S, const float* __restrict__ d_mask_in, const uint32_t* __restrict__ warp_id, int n_embeds,
+                              float* __restrict__ d_mask_tbl) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  uint32_t id = warp_id ? warp_id[r] : 0u;
+  if (id >= (uint32_t)n_embeds) id = n_embeds - 1;
+  float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) {
+    const float* dm = d_mask_in + ((size_t)r * S + s) * D.mask_in;
+    for (int g = 0; g < 8; ++g) e[g] += dm[6 * D.mask_bands + g];
+  }
+  for (int g = 0; g < 8; ++g) atomicAdd(d_mask_tbl + id * 8 + g, e[g]);
+}
+
+// flax.optim.Adam (flax 0.3.4): bias-corrected, no weight decay (training.py:508, train.py:297-301)
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, long long n,
+                       float lr, float b1, float b2, float eps, float c1, float c2) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float a = (1.0f - b1) * gi + b1 * m1[i];
+  const float b = (1.0f - b2) * gi * gi + b2 * m2[i];
+  m1[i] = a; m2[i] = b;
+  p[i] -= lr * (a / c1) / (sqrtf(b / c2) + eps);
+}
+
+static inline dim3 grid1(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+#define LAUNCH(kern, n, stream, ...) hipLaunchKernelGGL(kern, grid1(n), dim3(256), 0, stream, __VA_ARGS__)
+
+void coarse_z(hipStream_t st, int R, int Nc, float near_, float far_, int stratified, const float* t_rand, float* z) {
+  LAUNCH(k_coarse_z, (long long)R * Nc, st, R, Nc, near_, far_, stratified, t_rand, z);
+}
+void resample(hipStream_t st, int R, int Nc, int Nf, const float* zc, const float* wc, int stratified, const float* u_rand, float* zf, float* scratch) {
+  hipLaunchKernelGGL(k_resample, grid1(R, 64), dim3(64), 0, st, R, Nc, Nf, zc, wc, stratified, u_rand, zf, scratch);
+}
+void encode_inputs(hipStream_t st, const Dims& D, int R, int S, const float* o, const float* d, const float* z, const uint32_t* warp_id, int n_embeds,
+                   const float* warp_tbl, const float* mask_tbl, const Windows& W, float* x, float* mask_in, float* warp_in, float* hyper_in) {
+  LAUNCH(k_encode_inputs, (long long)R * S, st, D, R, S, o, d, z, warp_id, n_embeds, warp_tbl, mask_tbl, W, x, mask_in, warp_in, hyper_in);
+}
+void bias_act(hipStream_t st, float* y, const float* b, long long M, int N, int ld, int relu) { LAUNCH(k_bias_act, M * N, st, y, b, M, N, ld, relu); }
+void mask_post(hipStream_t st, const Dims& D, int R, int S, const float* logit, const float* gt, float ratio, float* warp_in, float* hyper_in) {
+  LAUNCH(k_mask_post, (long long)R * S, st, D, R, S, logit, gt, ratio, warp_in, hyper_in);
+}
+void se3_fwd(hipStream_t st, long long M, const float* wv, const float* x, float* xw) { LAUNCH(k_se3_fwd, M, st, M, wv, x, xw); }
+void se3_bwd(hipStream_t st, long long M, const float* wv, const float* x, const float* dxw, float* dwv) { LAUNCH(k_se3_bwd, M, st, M, wv, x, dxw, dwv); }
+void trunk_in(hipStream_t st, const Dims& D, long long M, const float* xw, const float* wamb, const Windows& W, float* tin) {
+  LAUNCH(k_trunk_in, M, st, D, M, xw, wamb, W, tin);
+}
+void trunk_in_bwd(hipStream_t st, const Dims& D, long long M, const float* dtin, const float* xw, const float* wamb, const Windows& W, float* dxw, float* dwamb) {
+  LAUNCH(k_trunk_in_bwd, M, st, D, M, dtin, xw, wamb, W, dxw, dwamb);
+}
+void alpha_post(hipStream_t st, const Dims& D, int R, int S, const float* alpha, const float* wv, const float* viewdirs, const Windows& W, float* sigma, float* cond) {
+  LAUNCH(k_alpha_post, (long long)R * S, st, D, R, S, alpha, wv, viewdirs, W, sigma, cond);
+}
+void composite_loss(hipStream_t st, int R, int S, const float* z, const float* dirs, const float* sigma, const float* rgb_logit, const float* target,
+                    int at_infinity, int white, float* rgb_ray, float* weights, float* loss, float* d_rgb_logit, float* d_alpha) {
+  hipLaunchKernelGGL(k_composite_loss, grid1(R, 64), dim3(64), 0, st, R, S, z, dirs, sigma, rgb_logit, target, at_infinity, white, rgb_ray, weights,
+                     loss, d_rgb_logit, d_alpha);
+}
+void relu_bwd(hipStream_t st, float* dy, const float* y, long long n) { LAUNCH(k_relu_bwd, n, st, dy, y, n); }
+void colsum_add(hipStream_t st, const float* dz, long long M, int N, int ld, float* db) {
+  hipLaunchKernelGGL(k_colsum_add, dim3((unsigned)((M + 4095) / 4096)), dim3(256), 0, st, dz, M, N, ld, db);
+}
+void shared_in_bwd(hipStream_t st, const Dims& D, int R, int S, const float* d_warp_in, const float* d_hyper_in, const float* mask_logit, float ratio,
+                   const uint32_t* warp_id, int n_embeds, float* d_warp_tbl, float* d_mask_logit) {
+  hipLaunchKernelGGL(k_shared_in_bwd, grid1(R, 64), dim3(64), 0, st, D, R, S, d_warp_in, d_hyper_in, mask_logit, ratio, warp_id, n_embeds, d_warp_tbl, d_mask_logit);
+}
+void mask_in_bwd(hipStream_t st, const Dims& D, int R, int S, const float* d_mask_in, const uint32_t* warp_id, int n_embeds, float* d_mask_tbl) {
+  hipLaunchKernelGGL(k_mask_in_bwd, grid1(R, 64), dim3(64), 0, st, D, R, S, d_mask_in, warp_id, n_embeds, d_mask_tbl);
+}
+void adam(hipStream_t st, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2) {
+  LAUNCH(k_adam, n, st, p, g, m1, m2, n, lr, b1, b2, eps, c1, c2);
+}
+
+}  // namespace nerfds_train

@@ -1,0 +1,162 @@
+"""Host-side mirror of the reference's training step for BASELINE config 4 (hypernerf/training.py:198-511 reduced to the
+first-order MSE objective): ``Trainer`` wraps the C-ABI ``nerfds_trainer_*`` (csrc/nerfds_train.cpp),
+``train_step`` keeps the call shape ``train_step(model, rng_key, state, batch, scalar_params)``.  No CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .config import NerfModelConfig
+from .model import _cfg_struct
+
+GRADS_ONLY = 1
+
+
+def _bind(lib):
+  if getattr(lib, '_trainer_bound', False):
+    return lib
+  lib.nerfds_trainer_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(N.ModelCfg), C.c_int64]
+  lib.nerfds_trainer_destroy.argtypes = [C.c_void_p]
+  lib.nerfds_trainer_param_count.argtypes = [C.c_void_p]
+  lib.nerfds_trainer_param_count.restype = C.c_int64
+  lib.nerfds_trainer_num_leaves.argtypes = [C.c_void_p]
+  lib.nerfds_trainer_leaf.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+  lib.nerfds_trainer_params.argtypes = [C.c_void_p]
+  lib.nerfds_trainer_params.restype = C.c_void_p
+  lib.nerfds_trainer_grads.argtypes = [C.c_void_p]
+  lib.nerfds_trainer_grads.restype = C.c_void_p
+  lib.nerfds_trainer_reset_optimizer.argtypes = [C.c_void_p]
+  lib.nerfds_trainer_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+  lib.nerfds_trainer_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+  lib.nerfds_trainer_step.argtypes = [C.c_void_p, C.POINTER(N.Rays), C.c_void_p, C.POINTER(N.Extra), C.POINTER(N.Rand), C.c_float, C.c_uint32,
+                                      C.POINTER(C.c_float), C.c_void_p]
+  lib.nerfds_trainer_last_error.argtypes = [C.c_void_p]
+  lib.nerfds_trainer_last_error.restype = C.c_char_p
+  lib._trainer_bound = True
+  return lib
+
+
+class Trainer:
+  """Owns the flat fp32 parameter / gradient / Adam vectors on one MI355X."""
+
+  def __init__(self, cfg: NerfModelConfig, params: Optional[Dict[str, Any]] = None, max_rays: int = 4096,
+               device: Optional[torch.device] = None):
+    cfg.validate()
+    self.cfg = cfg
+    self._lib = _bind(N.load())
+    if not torch.cuda.is_available():
+      raise RuntimeError('Trainer needs an MI355X (torch.cuda is not available); there is no CPU path')
+    self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    self._cstruct = _cfg_struct(cfg)
+    h = C.c_void_p()
+    rc = self._lib.nerfds_trainer_create(C.byref(h), self.device.index or 0, C.byref(self._cstruct), max_rays)
+    if rc != 0:
+      msg = (self._lib.nerfds_trainer_last_error(None) or b'').decode()
+      raise (NotImplementedError if rc == -95 else RuntimeError)(f'nerfds_trainer_create failed ({rc}): {msg}')
+    self._h = h
+    self.max_rays = max_rays
+    self.num_params = int(self._lib.nerfds_trainer_param_count(h))
+    self.leaves = []
+    name = C.create_string_buffer(256)
+    off, rows, cols = C.c_int64(), C.c_int32(), C.c_int32()
+    for i in range(self._lib.nerfds_trainer_num_leaves(h)):
+      self._lib.nerfds_trainer_leaf(h, i, name, 256, C.byref(off), C.byref(rows), C.byref(cols))
+      self.leaves.append((name.value.decode(), off.value, rows.value, cols.value))
+    if params is not None:
+      self.set_params(params)
+
+  def __del__(self):
+    h = getattr(self, '_h', None)
+    if h:
+      self._lib.nerfds_trainer_destroy(h)
+      self._h = None
+
+  # -- flat vector <-> Flax-named tree -----------------------------------------------------------------------
+  def _download(self, which: int) -> np.ndarray:
+    out = np.empty(self.num_params, np.float32)
+    rc = self._lib.nerfds_trainer_download(self._h, which, out.ctypes.data)
+    if rc != 0:
+      raise RuntimeError(f'nerfds_trainer_download failed ({rc})')
+    return out
+
+  def _tree(self, flat: np.ndarray) -> Dict[str, Any]:
+    tree: Dict[str, Any] = {}
+    for name, off, rows, cols in self.leaves:
+      parts = name.split('/')
+      node = tree
+      for p in parts[:-1]:
+        node = node.setdefault(p, {})
+      a = flat[off:off + rows * cols]
+      node[parts[-1]] = a.reshape(cols).copy() if parts[-1] == 'bias' else a.reshape(rows, cols).copy()
+    return tree
+
+  def set_params(self, params: Dict[str, Any]) -> None:
+    flat = np.zeros(self.num_params, np.float32)
+    for name, off, rows, cols in self.leaves:
+      node = params
+      for p in name.split('/'):
+        node = node[p]
+      a = np.asarray(node, np.float32)
+      if a.size != rows * cols:
+        raise ValueError(f'{name}: expected {rows * cols} values, got shape {a.shape}')
+      flat[off:off + rows * cols] = a.ravel()
+    rc = self._lib.nerfds_trainer_upload(self._h, 0, flat.ctypes.data)
+    if rc != 0:
+      raise RuntimeError(f'nerfds_trainer_upload failed ({rc})')
+    self._lib.nerfds_trainer_reset_optimizer(self._h)
+
+  def get_params(self) -> Dict[str, Any]:
+    return self._tree(self._download(0))
+
+  def get_grads(self) -> Dict[str, Any]:
+    return self._tree(self._download(1))
+
+  # -- one step ------------------------------------------------------------------------------------------
+  def step(self, batch: Dict[str, Any], extra_params: Dict[str, Any], learning_rate: float = 0.0, *, t_rand=None, u_rand=None,
+           mask_ratio: float = 1.0, near: Optional[float] = None, far: Optional[float] = None, grads_only: bool = False,
+           stream: Optional[torch.cuda.Stream] = None) -> Dict[str, float]:
+    dev = self.device
+    f32 = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).to(dev, torch.float32).contiguous()
+    origins = f32(batch['origins']).reshape(-1, 3)
+    R = origins.shape[0]
+    directions = f32(batch['directions']).reshape(-1, 3)
+    viewdirs = f32(batch['viewdirs']).reshape(-1, 3) if batch.get('viewdirs') is not None else directions
+    target = f32(batch['rgb']).reshape(-1, 3)[:, :3].contiguous()
+    wid = batch['metadata']['warp']
+    wid = (wid if isinstance(wid, torch.Tensor) else torch.as_tensor(np.asarray(wid).astype(np.int64))).to(dev).reshape(-1).to(torch.int32).contiguous()
+    gt_mask = f32(batch['mask']).reshape(-1) if batch.get('mask') is not None else None
+    keep = [origins, directions, viewdirs, target, wid, gt_mask]
+    rays = N.Rays(num_rays=R, origins=origins.data_ptr(), directions=directions.data_ptr(), viewdirs=viewdirs.data_ptr(),
+                  warp_id=wid.data_ptr(), gt_mask=gt_mask.data_ptr() if gt_mask is not None else None, camera=None, first_pixel=0)
+    g = lambda k, d=0.0: float(extra_params[k]) if extra_params.get(k) is not None else d
+    ex = N.Extra(nerf_alpha=g('nerf_alpha'), warp_alpha=g('warp_alpha'), hyper_alpha=g('hyper_alpha'), hyper_sheet_alpha=g('hyper_sheet_alpha'),
+                 norm_input_alpha=g('norm_input_alpha'), mask_ratio=float(mask_ratio), near=float(self.cfg.near if near is None else near),
+                 far=float(self.cfg.far if far is None else far), use_stratified_sampling=int(self.cfg.use_stratified_sampling))
+    rnd = N.Rand(t_rand=None, u_rand=None, seed=0)
+    if t_rand is not None:
+      t = f32(t_rand).reshape(R, self.cfg.num_coarse_samples); keep.append(t); rnd.t_rand = t.data_ptr()
+    if u_rand is not None and self.cfg.num_fine_samples > 0:
+      u = f32(u_rand).reshape(R, self.cfg.num_fine_samples); keep.append(u); rnd.u_rand = u.data_ptr()
+    loss = (C.c_float * 2)()
+    s = stream if stream is not None else torch.cuda.current_stream(dev)
+    rc = self._lib.nerfds_trainer_step(self._h, C.byref(rays), target.data_ptr(), C.byref(ex), C.byref(rnd), float(learning_rate),
+                                       GRADS_ONLY if grads_only else 0, loss, C.c_void_p(s.cuda_stream))
+    if rc != 0:
+      raise RuntimeError(f'nerfds_trainer_step failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
+    del keep
+    fine, coarse = float(loss[0]), float(loss[1])
+    total = fine + coarse if self.cfg.num_fine_samples > 0 else coarse
+    return {'loss/fine': fine, 'loss/coarse': coarse, 'loss/total': total}
+
+
+def train_step(trainer: Trainer, rng_key, state, batch, scalar_params, **static_flags):
+  """``training.train_step`` look-alike (training.py:198-216, 511): returns (state, stats, rng_key, None).  ``state`` carries
+  ``extra_params`` (evaluation.TrainState); ``scalar_params`` needs ``learning_rate`` and optionally ``mask_ratio``."""
+  lr = float(getattr(scalar_params, 'learning_rate', scalar_params['learning_rate'] if isinstance(scalar_params, dict) else 0.0))
+  mr = getattr(scalar_params, 'mask_ratio', scalar_params.get('mask_ratio', 1.0) if isinstance(scalar_params, dict) else 1.0)
+  stats = trainer.step(batch, state.extra_params, lr, mask_ratio=float(mr), t_rand=static_flags.get('t_rand'), u_rand=static_flags.get('u_rand'))
+  return state, stats, rng_key, None

@@ -450,6 +450,7 @@ class NerfModel:
     if use_predicted_norm and cfg.predict_norm:                      # models.py:1113-1133
       normalized_norm = normalize_vector(norm)
       norm_input = self.map_vectors(points, normalized_norm, warp_embed, extra_params, mask, inverse=True)
+      norm_input = norm_input.detach()                               # stop_norm_gradient=True (models.py:179, 1132-1133)
     norm_input_feat = None
     if norm_input is not None:                                       # models.py:1137-1150
       norm_input = normalize_vector(norm_input)
