@@ -56,6 +56,8 @@ struct nerfds_trainer {
   float* ws = nullptr;      // one workspace allocation
   size_t ws_floats = 0;
   float* loss_dev = nullptr;
+  float* part = nullptr;    // split-K partials of the weight-gradient GEMMs
+  size_t part_floats = 0;
   std::string err;
   // workspace views (set by carve())
   float *zc, *zf, *wc, *rs_scratch, *x, *mask_in, *mask_logit, *warp_in, *wv, *xw, *hyper_in, *wamb, *trunk_in, *bottv, *alphav, *sigma,
@@ -73,7 +75,7 @@ struct nerfds_trainer {
     return code;
   }
   ~nerfds_trainer() {
-    for (float* p : {theta, grad, m1, m2, ws, loss_dev}) if (p) (void)hipFree(p);
+    for (float* p : {theta, grad, m1, m2, ws, loss_dev, part}) if (p) (void)hipFree(p);
     if (blas) (void)rocblas_destroy_handle(blas);
   }
 };
@@ -120,6 +122,8 @@ rocblas_status gemm_nt(rocblas_handle h, int64_t M, int N, int K, const float* A
   return rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, K, (rocblas_int)M, N, &one, B, ldb, A, lda, &beta, C, ldc);
 }
 
+constexpr int64_t SLAB = 4096;     // rows per split-K slab of the weight-gradient GEMMs
+
 struct Run {
   nerfds_trainer& t;
   hipStream_t st;
@@ -137,12 +141,32 @@ struct Run {
     bias_act(st, y, t.theta + L.b, M, L.N, ldy, relu ? 1 : 0);
   }
   // dy[M x N] (ldy) is d loss / d (post-activation output y); relu_y != nullptr -> mask with y > 0 first (needs ldy == N)
+  // dW[K x N] += X[M x K]^T dY[M x N].  The output is tiny and the contraction is the sample axis (up to 524 288): a
+  // single GEMM runs on a handful of workgroups (measured 3 ms per layer), so the sample axis is cut into slabs of
+  // SLAB rows, each slab is one problem of a strided-batched GEMM into a partial, and a small kernel adds the partials.
+  void weight_grad(const float* X, int ldx, int K, const float* dy, int ldy, int N, float* dW) {
+    const int64_t slabs = M / SLAB;
+    const float one = 1.f, zero = 0.f;
+    if (slabs >= 2 && (size_t)slabs * K * N <= t.part_floats) {
+      chk(rocblas_sgemm_strided_batched(t.blas, rocblas_operation_none, rocblas_operation_transpose, N, K, SLAB, &one, dy, ldy,
+                                        (rocblas_stride)SLAB * ldy, X, ldx, (rocblas_stride)SLAB * ldx, &zero, t.part, N,
+                                        (rocblas_stride)K * N, (rocblas_int)slabs));
+      sum_partials(st, t.part, (int)slabs, (long long)K * N, dW);
+      const int64_t done = slabs * SLAB;
+      if (done < M) chk(gemm_tn(t.blas, M - done, N, K, X + done * ldx, ldx, dy + done * ldy, ldy, 1.f, dW, N));
+    } else {
+      chk(gemm_tn(t.blas, M, N, K, X, ldx, dy, ldy, 1.f, dW, N));
+    }
+  }
   void dense_bwd(const LayerP& L, const std::vector<Seg>& segs, float* dy, int ldy, const float* relu_y) {
-    if (relu_y) relu_bwd(st, dy, relu_y, M * L.N);
-    colsum_add(st, dy, M, L.N, ldy, t.grad + L.b);
+    if (relu_y && L.N <= 256) relu_bwd_colsum(st, dy, relu_y, M, L.N, t.grad + L.b);      // mask with y > 0, db[N] += dY^T 1
+    else {
+      if (relu_y) relu_bwd(st, dy, relu_y, M * L.N);
+      colsum_add(st, dy, M, L.N, ldy, t.grad + L.b);
+    }
     int k0 = 0;
     for (const Seg& s : segs) {
-      chk(gemm_tn(t.blas, M, L.N, s.K, s.x, s.ld, dy, ldy, 1.f, t.grad + L.w + (int64_t)k0 * L.N, L.N));
+      weight_grad(s.x, s.ld, s.K, dy, ldy, L.N, t.grad + L.w + (int64_t)k0 * L.N);
       if (s.dx) chk(gemm_nt(t.blas, M, L.N, s.K, dy, ldy, t.theta + L.w + (int64_t)k0 * L.N, L.N, s.acc ? 1.f : 0.f, s.dx, s.dld));
       k0 += s.K;
     }
@@ -305,6 +329,15 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
       hipMalloc(&t->ws, t->ws_floats * sizeof(float)) != hipSuccess) {
     g_train_error = "hipMalloc failed (workspace of " + std::to_string(t->ws_floats * 4 >> 20) + " MiB)";
     return NERFDS_ENOMEM;
+  }
+  {
+    const int64_t Mmax = max_rays * (c->num_coarse_samples + c->num_fine_samples);
+    const int maxK = std::max({2 * TW + cond, TW + D.trunk_in, c->mask_width + D.mask_in}), maxN = std::max(TW, c->mask_width);
+    t->part_floats = (size_t)std::max<int64_t>(Mmax / SLAB, 1) * maxK * maxN;
+    if (hipMalloc(&t->part, t->part_floats * sizeof(float)) != hipSuccess) {
+      g_train_error = "hipMalloc failed (split-K partials)";
+      return NERFDS_ENOMEM;
+    }
   }
   (void)hipMemset(t->theta, 0, pbytes); (void)hipMemset(t->m1, 0, pbytes); (void)hipMemset(t->m2, 0, pbytes); (void)hipMemset(t->grad, 0, pbytes);
   carve(*t);

@@ -27,10 +27,13 @@ void alpha_post(hipStream_t, const Dims&, int R, int S, const float* alpha, cons
 void composite_loss(hipStream_t, int R, int S, const float* z, const float* dirs, const float* sigma, const float* rgb_logit, const float* target,
                     int at_infinity, int white, float* rgb_ray, float* weights, float* loss, float* d_rgb_logit, float* d_alpha);
 void relu_bwd(hipStream_t, float* dy, const float* y, long long n);
+void relu_bwd_colsum(hipStream_t, float* dy, const float* y, long long M, int N, float* db);
 void colsum_add(hipStream_t, const float* dz, long long M, int N, int ld, float* db);
 void shared_in_bwd(hipStream_t, const Dims&, int R, int S, const float* d_warp_in, const float* d_hyper_in, const float* mask_logit, float ratio,
                    const uint32_t* warp_id, int n_embeds, float* d_warp_tbl, float* d_mask_logit);
 void mask_in_bwd(hipStream_t, const Dims&, int R, int S, const float* d_mask_in, const uint32_t* warp_id, int n_embeds, float* d_mask_tbl);
+void sum_partials(hipStream_t, const float* part, int slabs, long long n, float* out);
+void fill(hipStream_t, float* p, long long n, float v);
 void adam(hipStream_t, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2);
 
 }  // namespace nerfds_train

@@ -310,26 +310,46 @@ __global__ void k_relu_bwd(float* __restrict__ dy, const float* __restrict__ y, 
   if (i < n && !(y[i] > 0.f)) dy[i] = 0.f;
 }
 
-// db[n] += sum_m dz[m][n]
+// db[n] += sum_m dz[m][n] (bias gradients): one block per 256 rows, one atomicAdd per column and block
 __global__ void k_colsum_add(const float* __restrict__ dz, long long M, int N, int ld, float* __restrict__ db) {
   __shared__ float red[256];
-  const int rows_per_pass = 256 / N > 0 ? 256 / N : 1;
   const int tid = threadIdx.x;
-  const long long chunk = 4096;
-  const long long r0 = blockIdx.x * chunk, r1 = (r0 + chunk < M) ? r0 + chunk : M;
-  for (int c0 = 0; c0 < N; c0 += 256) {
-    const int col = c0 + tid % (N < 256 ? N : 256), sub = tid / (N < 256 ? N : 256);
-    float s = 0.f;
-    if (col < N && sub < rows_per_pass)
-      for (long long r = r0 + sub; r < r1; r += rows_per_pass) s += dz[r * ld + col];
-    red[tid] = s;
-    __syncthreads();
-    if (N < 256) {
-      if (tid < N) { float t = 0.f; for (int k = 0; k < rows_per_pass; ++k) t += red[tid + k * N]; atomicAdd(db + tid, t); }
-    } else if (col < N) {
-      atomicAdd(db + col, s);
+  const int per = N < 256 ? N : 256, rows_per_pass = 256 / per;
+  const long long r0 = blockIdx.x * 256LL, r1 = (r0 + 256 < M) ? r0 + 256 : M;
+  const int col = tid % per, sub = tid / per;
+  float s = 0.f;
+  if (sub < rows_per_pass)
+    for (long long r = r0 + sub; r < r1; r += rows_per_pass) s += dz[r * ld + col];
+  red[tid] = s;
+  __syncthreads();
+  if (tid < per) {
+    float t = 0.f;
+    for (int k = 0; k < rows_per_pass; ++k) t += red[tid + k * per];
+    atomicAdd(db + tid, t);
+  }
+}
+
+// ReLU backward fused with the bias gradient: dy = (y > 0) ? dy : 0 in place, db += column sums (one pass over dy, y)
+__global__ void k_relu_bwd_colsum(float* __restrict__ dy, const float* __restrict__ y, long long M, int N, float* __restrict__ db) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  const int per = N < 256 ? N : 256, rows_per_pass = 256 / per;
+  const long long r0 = blockIdx.x * 128LL, r1 = (r0 + 128 < M) ? r0 + 128 : M;
+  const int col = tid % per, sub = tid / per;
+  float s = 0.f;
+  if (sub < rows_per_pass)
+    for (long long r = r0 + sub; r < r1; r += rows_per_pass) {
+      const long long i = r * N + col;
+      const float v = (y[i] > 0.f) ? dy[i] : 0.f;
+      dy[i] = v;
+      s += v;
     }
-    __syncthreads();
+  red[tid] = s;
+  __syncthreads();
+  if (tid < per) {
+    float t = 0.f;
+    for (int k = 0; k < rows_per_pass; ++k) t += red[tid + k * per];
+    atomicAdd(db + tid, t);
   }
 }
 
@@ -378,6 +398,18 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
   p[i] -= lr * (a / c1) / (sqrtf(b / c2) + eps);
 }
 
+__global__ void k_sum_partials(const float* __restrict__ part, int slabs, long long n, float* __restrict__ out) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < slabs; ++k) s += part[(long long)k * n + i];
+  out[i] += s;
+}
+__global__ void k_fill(float* __restrict__ p, long long n, float v) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 static inline dim3 grid1(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 #define LAUNCH(kern, n, stream, ...) hipLaunchKernelGGL(kern, grid1(n), dim3(256), 0, stream, __VA_ARGS__)
 
@@ -412,8 +444,11 @@ void composite_loss(hipStream_t st, int R, int S, const float* z, const float* d
                      loss, d_rgb_logit, d_alpha);
 }
 void relu_bwd(hipStream_t st, float* dy, const float* y, long long n) { LAUNCH(k_relu_bwd, n, st, dy, y, n); }
-void colsum_add(hipStream_t st, const float* dz, long long M, int N, int ld, float* db) {
-  hipLaunchKernelGGL(k_colsum_add, dim3((unsigned)((M + 4095) / 4096)), dim3(256), 0, st, dz, M, N, ld, db);
+void colsum_add(hipStream_t st, const float* dz, long long M, int N, int ld, float* db) {      // N <= 256
+  hipLaunchKernelGGL(k_colsum_add, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, dz, M, N, ld, db);
+}
+void relu_bwd_colsum(hipStream_t st, float* dy, const float* y, long long M, int N, float* db) {      // N <= 256, contiguous rows
+  hipLaunchKernelGGL(k_relu_bwd_colsum, dim3((unsigned)((M + 127) / 128)), dim3(256), 0, st, dy, y, M, N, db);
 }
 void shared_in_bwd(hipStream_t st, const Dims& D, int R, int S, const float* d_warp_in, const float* d_hyper_in, const float* mask_logit, float ratio,
                    const uint32_t* warp_id, int n_embeds, float* d_warp_tbl, float* d_mask_logit) {
@@ -422,6 +457,8 @@ void shared_in_bwd(hipStream_t st, const Dims& D, int R, int S, const float* d_w
 void mask_in_bwd(hipStream_t st, const Dims& D, int R, int S, const float* d_mask_in, const uint32_t* warp_id, int n_embeds, float* d_mask_tbl) {
   hipLaunchKernelGGL(k_mask_in_bwd, grid1(R, 64), dim3(64), 0, st, D, R, S, d_mask_in, warp_id, n_embeds, d_mask_tbl);
 }
+void sum_partials(hipStream_t st, const float* part, int slabs, long long n, float* out) { LAUNCH(k_sum_partials, n, st, part, slabs, n, out); }
+void fill(hipStream_t st, float* p, long long n, float v) { LAUNCH(k_fill, n, st, p, n, v); }
 void adam(hipStream_t st, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2) {
   LAUNCH(k_adam, n, st, p, g, m1, m2, n, lr, b1, b2, eps, c1, c2);
 }

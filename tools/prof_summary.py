@@ -8,7 +8,7 @@ def main(root):
     print(f'== {os.path.relpath(db, root)}')
     try:
       for name, calls, tot, avg, pct in cur.execute('select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 4'):
-        print(f'  kernel {name[:90]:90s} calls={calls} total_ms={tot/1e6:.3f} avg_ms={avg/1e6:.4f} pct={pct:.1f}')   # durations are ns in the db
+        print(f'  kernel {name[:90]:90s} calls={calls} total_ms={tot/1e3:.3f} avg_ms={avg/1e3:.4f} pct={pct:.1f}')   # top_kernels durations are microseconds
     except Exception as e:
       print('  (no top_kernels)', e)
     try:

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Kernel trace of the training step (GPU box). Usage: tools/prof_train.sh <tag>
+TAG=${1:-train}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $GRAFT_REPO_ROOT/tools/bench_train.py 4096 3 > $OUT/trace.log 2>&1
+python - <<PY
+import glob, sqlite3
+for db in glob.glob('$OUT/trace/**/*_results.db', recursive=True):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute('select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 25').fetchall()
+    tot = sum(r[2] for r in cur.execute('select name,total_calls,total_duration from top_kernels').fetchall())
+    print('total kernel time ms', tot / 1e3, '(6 steps: 3 warm-up + 3 timed)')   # top_kernels durations are microseconds
+    for name, calls, t, avg, pct in rows:
+        print(f'{name[:100]:100s} calls={calls:5d} total_ms={t/1e3:9.3f} avg_ms={avg/1e3:8.4f} pct={pct:5.1f}')
+PY
