@@ -239,6 +239,9 @@ int nerfds_trainer_upload(nerfds_trainer* t, int which, const float* host);
 int nerfds_trainer_reset_optimizer(nerfds_trainer* t);   /* zero the Adam moments and the step count */
 int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* extra,
                         const nerfds_rand* rnd, float learning_rate, uint32_t flags, float* loss_host, void* hip_stream);
+/* One Adam update with the gradient vector as it stands (after a NERFDS_TRAIN_GRADS_ONLY step and, on N GPUs, after the
+ * all-reduce of nerfds_trainer_grads that replaces jax.lax.pmean(grad), training.py:502). */
+int nerfds_trainer_apply(nerfds_trainer* t, float learning_rate, void* hip_stream);
 const char* nerfds_trainer_last_error(const nerfds_trainer* t);
 
 /* Timing aid for bench.py: average device time (ms) of the render kernel launches recorded with HIP events

@@ -392,6 +392,23 @@ int nerfds_trainer_reset_optimizer(nerfds_trainer* t) {
   return NERFDS_OK;
 }
 
+static void adam_update(nerfds_trainer* t, float learning_rate, hipStream_t st) {
+  const double b1 = 0.9, b2 = 0.999;
+  const double tt = (double)(t->adam_t + 1);
+  adam(st, t->theta, t->grad, t->m1, t->m2, t->P, learning_rate, (float)b1, (float)b2, 1e-8f, (float)(1.0 - std::pow(b1, tt)),
+       (float)(1.0 - std::pow(b2, tt)));
+  t->adam_t += 1;
+}
+
+int nerfds_trainer_apply(nerfds_trainer* t, float learning_rate, void* hip_stream) {
+  if (!t) return NERFDS_EINVAL;
+  if (hipSetDevice(t->device) != hipSuccess) return t->fail(NERFDS_EDEVICE, "hipSetDevice failed");
+  adam_update(t, learning_rate, static_cast<hipStream_t>(hip_stream));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return t->fail(NERFDS_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+  return NERFDS_OK;
+}
+
 int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* ex, const nerfds_rand* rnd,
                         float learning_rate, uint32_t flags, float* loss_host, void* hip_stream) {
   if (!t) return NERFDS_EINVAL;
@@ -420,13 +437,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights);
     if (rc != NERFDS_OK) return rc;
   }
-  if (!(flags & NERFDS_TRAIN_GRADS_ONLY)) {
-    const double b1 = 0.9, b2 = 0.999;
-    const double tt = (double)(t->adam_t + 1);
-    adam(st, t->theta, t->grad, t->m1, t->m2, t->P, learning_rate, (float)b1, (float)b2, 1e-8f, (float)(1.0 - std::pow(b1, tt)),
-         (float)(1.0 - std::pow(b2, tt)));
-    t->adam_t += 1;
-  }
+  if (!(flags & NERFDS_TRAIN_GRADS_ONLY)) adam_update(t, learning_rate, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return t->fail(NERFDS_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));
   if (loss_host) {

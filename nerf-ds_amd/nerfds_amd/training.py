@@ -16,6 +16,22 @@ from .model import _cfg_struct
 GRADS_ONLY = 1
 
 
+class _DevVec:
+  """Zero-copy torch view of a library-owned fp32 device vector (through __cuda_array_interface__)."""
+
+  def __init__(self, ptr: int, n: int):
+    self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
+
+
+def allreduce_mean_(t: torch.Tensor) -> torch.Tensor:
+  """jax.lax.pmean(grad, 'batch') (training.py:502): in-place mean over the ranks of the default process group."""
+  import torch.distributed as dist
+  if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t /= dist.get_world_size()
+  return t
+
+
 def _bind(lib):
   if getattr(lib, '_trainer_bound', False):
     return lib
@@ -34,6 +50,7 @@ def _bind(lib):
   lib.nerfds_trainer_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
   lib.nerfds_trainer_step.argtypes = [C.c_void_p, C.POINTER(N.Rays), C.c_void_p, C.POINTER(N.Extra), C.POINTER(N.Rand), C.c_float, C.c_uint32,
                                       C.POINTER(C.c_float), C.c_void_p]
+  lib.nerfds_trainer_apply.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
   lib.nerfds_trainer_last_error.argtypes = [C.c_void_p]
   lib.nerfds_trainer_last_error.restype = C.c_char_p
   lib._trainer_bound = True
@@ -109,6 +126,20 @@ class Trainer:
       raise RuntimeError(f'nerfds_trainer_upload failed ({rc})')
     self._lib.nerfds_trainer_reset_optimizer(self._h)
 
+  def grads_tensor(self) -> torch.Tensor:
+    """The flat gradient vector as a torch CUDA tensor aliasing the library's memory (for the RCCL all-reduce)."""
+    return torch.as_tensor(_DevVec(self._lib.nerfds_trainer_grads(self._h), self.num_params), device=self.device)
+
+  def params_tensor(self) -> torch.Tensor:
+    return torch.as_tensor(_DevVec(self._lib.nerfds_trainer_params(self._h), self.num_params), device=self.device)
+
+  def apply_gradients(self, learning_rate: float, stream: Optional[torch.cuda.Stream] = None) -> None:
+    """optimizer.apply_gradient (training.py:508) on the gradient vector as it stands."""
+    s = stream if stream is not None else torch.cuda.current_stream(self.device)
+    rc = self._lib.nerfds_trainer_apply(self._h, float(learning_rate), C.c_void_p(s.cuda_stream))
+    if rc != 0:
+      raise RuntimeError(f'nerfds_trainer_apply failed ({rc})')
+
   def get_params(self) -> Dict[str, Any]:
     return self._tree(self._download(0))
 
@@ -143,10 +174,17 @@ class Trainer:
       u = f32(u_rand).reshape(R, self.cfg.num_fine_samples); keep.append(u); rnd.u_rand = u.data_ptr()
     loss = (C.c_float * 2)()
     s = stream if stream is not None else torch.cuda.current_stream(dev)
+    import torch.distributed as dist
+    data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rc = self._lib.nerfds_trainer_step(self._h, C.byref(rays), target.data_ptr(), C.byref(ex), C.byref(rnd), float(learning_rate),
-                                       GRADS_ONLY if grads_only else 0, loss, C.c_void_p(s.cuda_stream))
+                                       GRADS_ONLY if (grads_only or data_parallel) else 0, loss, C.c_void_p(s.cuda_stream))
     if rc != 0:
       raise RuntimeError(f'nerfds_trainer_step failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
+    if data_parallel:       # one rank per GPU, each with its own rays: ONE all-reduce of the 6 MB gradient vector (training.py:502)
+      with torch.cuda.stream(s):
+        allreduce_mean_(self.grads_tensor())
+      if not grads_only:
+        self.apply_gradients(learning_rate, s)
     del keep
     fine, coarse = float(loss[0]), float(loss[1])
     total = fine + coarse if self.cfg.num_fine_samples > 0 else coarse

@@ -97,3 +97,35 @@ def test_single_process_render_image_and_helpers():
   x = torch.arange(6.).reshape(3, 2)
   assert torch.equal(pad_edge(x, 2), torch.cat([x, x[-1:], x[-1:]]))            # mode='edge'
   assert state.extra_params['nerf_alpha'] is None and 'norm_input_alpha' in state.extra_params
+
+
+def _grad_worker(rank, world, port, q):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from nerfds_amd.training import allreduce_mean_
+    g = torch.arange(10, dtype=torch.float32) * (rank + 1)          # this rank's "gradient vector"
+    allreduce_mean_(g)
+    q.put((rank, g.numpy()))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_gradient_mean_over_two_ranks():
+  """training.py:502 jax.lax.pmean(grad): the data-parallel training step all-reduces the flat gradient vector."""
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  got = dict(q.get(timeout=120) for _ in range(2))
+  for p in procs:
+    p.join(timeout=60)
+  want = np.arange(10, dtype=np.float32) * 1.5
+  np.testing.assert_allclose(got[0], want)
+  np.testing.assert_allclose(got[1], want)
+  from nerfds_amd.training import allreduce_mean_
+  t = torch.ones(3)
+  assert allreduce_mean_(t) is t and float(t.sum()) == 3.0           # no process group: identity

@@ -129,3 +129,21 @@ def test_trainer_rejects_what_it_cannot_do():
   tr = Trainer(cfg, params, max_rays=8)
   with pytest.raises(RuntimeError):
     tr.step(batch, EX, 0.0, t_rand=t, u_rand=u)       # 9 rays > max_rays
+
+
+@pytest.mark.gpu
+def test_grads_only_then_apply_equals_one_step_and_views_alias():
+  import torch
+  from nerfds_amd.training import Trainer
+  cfg, params, batch, t, u = _problem(32, 8, 8)
+  a = Trainer(cfg, params, max_rays=32)
+  b = Trainer(cfg, params, max_rays=32)
+  a.step(batch, EX, 1e-3, t_rand=t, u_rand=u)
+  b.step(batch, EX, 1e-3, t_rand=t, u_rand=u, grads_only=True)
+  g = b.grads_tensor()
+  assert g.is_cuda and g.numel() == b.num_params
+  np.testing.assert_array_equal(g.cpu().numpy(), b._download(1))           # the view aliases the library's vector
+  b.apply_gradients(1e-3)
+  torch.cuda.synchronize()
+  # (bias / embedding gradients are accumulated with float atomics: two runs may differ in the last bit)
+  np.testing.assert_allclose(a._download(0), b._download(0), rtol=0, atol=1e-7)
