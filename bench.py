@@ -95,7 +95,7 @@ def cpu_baseline(cfg, params, budget_s=15.0):
     R *= 4
     dt = run(R)
   return {'value': R / dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
-          'sample': f'{R} rays x (64 coarse + 128 fine) samples of the same nerf_ds graph, torch-CPU fp32 oracle, '
+          'sample': f'{R} rays x ({cfg.num_coarse_samples} coarse + {cfg.num_coarse_samples + cfg.num_fine_samples} fine) samples of the same nerf_ds graph, torch-CPU fp32 oracle, '
                     f'{dt:.1f} s on {cores} threads, sigma-gradient off as on the GPU'}
 
 
@@ -108,6 +108,7 @@ def main():
   ap.add_argument('--chunk', type=int, default=65536)
   ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'f32'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--samples', type=int, default=64, help='coarse = fine sample count (64 = the headline config; 128 = BASELINE config 5)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -127,7 +128,8 @@ def main():
   from nerfds_amd.model import NerfModel
   from nerfds_amd.evaluation import all_gather_records
 
-  cfg = nerf_ds_config(near=0.3, far=1.7, num_warp_embeds=256)
+  cfg = nerf_ds_config(near=0.3, far=1.7, num_warp_embeds=256, num_coarse_samples=args.samples, num_fine_samples=args.samples)
+  flop_per_ray = FLOP_PER_RAY * args.samples / 64        # 3 N field evaluations per ray
   params = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)   # random-init weights
   model = NerfModel(cfg, device=device, precision=args.precision)
   model.load_params(params)
@@ -171,29 +173,29 @@ def main():
     value = args.rays * world / (elapsed / args.steps)
     rays_per_launch = args.rays / len(chunks)
     avg_launch_s = (kernel_ms / max(n_launch, 1)) * 1e-3
-    achieved = rays_per_launch * FLOP_PER_RAY / avg_launch_s / 1e12 if n_launch else None
+    achieved = rays_per_launch * flop_per_ray / avg_launch_s / 1e12 if n_launch else None
     peak = PEAK_TFLOPS[args.precision]
     # HBM bytes per launch cannot be read live (PMC passes are separate rocprofv3 runs of this same command):
     # the committed measurement of the current kernel is used when present (profiles/, see tools/prof_bench.sh).
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', f'r1_{args.precision}_hbm_traffic.json')
-    if os.path.exists(tpath) and args.rays == 480000 and args.chunk == 65536:
+    if os.path.exists(tpath) and args.rays == 480000 and args.chunk == 65536 and args.samples == 64:
       traffic = json.load(open(tpath))['hbm_bytes_per_launch']
     result = {
-        'metric': 'rendered rays/sec (128 samples/ray, full warp+NerfMLP)',
+        'metric': 'rendered rays/sec (%d samples/ray, full warp+NerfMLP)' % (2 * args.samples),
         'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
-        'config': {'workload': "NeRF-DS 'bell'-shaped synthetic scene, 800x600 frame per GPU (480000 rays), 64 coarse + "
-                               '64 fine samples (128 on the fine pass, 192 field evaluations/ray), SE(3) warp + hyper-slice + '
-                               'mask + predicted-normal NerfMLP (configs/nerf_ds.gin graph), random-init weights',
+        'config': {'workload': "NeRF-DS 'bell'-shaped synthetic scene, 800x600 frame per GPU (480000 rays), %d coarse + "
+                               '%d fine samples (%d on the fine pass, %d field evaluations/ray), SE(3) warp + hyper-slice + '
+                               'mask + predicted-normal NerfMLP (configs/nerf_ds.gin graph), random-init weights' % (args.samples, args.samples, 2 * args.samples, 3 * args.samples),
                    'rays_per_gpu_per_step': args.rays, 'chunk': args.chunk, 'parallelism': f'ray-shard x{world}',
                    'exchange': 'all-gather of [chunk, 26] fp32 ray records' if world > 1 else 'none (1 GPU)'},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                      'frac': (achieved / peak) if achieved else None, 'traffic': traffic,
                      'kernel': 'nerfds::render_rays_kernel<GraphNerfDS, %s>' % args.precision,
                      'avg_launch_ms': avg_launch_s * 1e3, 'launches': n_launch,
-                     'algorithmic_flop_per_launch': rays_per_launch * FLOP_PER_RAY},
+                     'algorithmic_flop_per_launch': rays_per_launch * flop_per_ray},
     }
     if world == 1 and not args.no_cpu_baseline:
       result['cpu_baseline'] = cpu_baseline(cfg, params)
