@@ -85,7 +85,7 @@ def cpu_baseline(cfg, params, budget_s=15.0):
     rng = np.random.default_rng(0)
     t, u = rng.random((R, cfg.num_coarse_samples)), rng.random((R, cfg.num_fine_samples))
     t0 = time.perf_counter()
-    model.apply(rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, compute_sigma_gradient=False)
+    model.apply(rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=cfg.predict_norm, compute_sigma_gradient=False)
     return time.perf_counter() - t0
 
   t_all = time.perf_counter()
@@ -108,6 +108,7 @@ def main():
   ap.add_argument('--chunk', type=int, default=65536)
   ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'f32'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--graph', default='nerf_ds', choices=['nerf_ds', 'hypernerf'], help="'hypernerf' = configs/base.gin graph (BASELINE config 5 per SURVEY 8d; use with --samples 128)")
   ap.add_argument('--samples', type=int, default=64, help='coarse = fine sample count (64 = the headline config; 128 = BASELINE config 5)')
   args = ap.parse_args()
 
@@ -124,12 +125,14 @@ def main():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     dist.init_process_group('nccl', device_id=device)      # "nccl" is RCCL on ROCm
 
-  from nerfds_amd import nerf_ds_config, init_params
+  from nerfds_amd import nerf_ds_config, hypernerf_config, init_params
   from nerfds_amd.model import NerfModel
   from nerfds_amd.evaluation import all_gather_records
 
-  cfg = nerf_ds_config(near=0.3, far=1.7, num_warp_embeds=256, num_coarse_samples=args.samples, num_fine_samples=args.samples)
-  flop_per_ray = FLOP_PER_RAY * args.samples / 64        # 3 N field evaluations per ray
+  make_cfg = nerf_ds_config if args.graph == 'nerf_ds' else hypernerf_config
+  cfg = make_cfg(near=0.3, far=1.7, num_warp_embeds=256, num_coarse_samples=args.samples, num_fine_samples=args.samples)
+  # 3 N field evaluations per ray x FLOP per sample (nerf_ds 1 735 168, base.gin graph 1 420 544)
+  flop_per_ray = 3 * args.samples * (1735168.0 if args.graph == 'nerf_ds' else 1420544.0)
   params = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)   # random-init weights
   model = NerfModel(cfg, device=device, precision=args.precision)
   model.load_params(params)
@@ -144,7 +147,7 @@ def main():
     out = None
     for ci, cr in enumerate(chunk_rays):
       model.apply(variables, cr, EXTRA, rngs={'coarse': seed * 1000 + ci, 'fine': seed * 1000 + ci + 500},
-                  use_predicted_norm=True, return_points=False, mask_ratio=1, sharp_weights_std=0.1)
+                  use_predicted_norm=cfg.predict_norm, return_points=False, mask_ratio=1, sharp_weights_std=0.1)
       out = all_gather_records(model.last_records['fine'])      # the path's only exchange (one collective per chunk)
     return out
 
@@ -179,21 +182,24 @@ def main():
     # the committed measurement of the current kernel is used when present (profiles/, see tools/prof_bench.sh).
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', f'r1_{args.precision}_hbm_traffic.json')
-    if os.path.exists(tpath) and args.rays == 480000 and args.chunk == 65536 and args.samples == 64:
+    if os.path.exists(tpath) and args.rays == 480000 and args.chunk == 65536 and args.samples == 64 and args.graph == 'nerf_ds':
       traffic = json.load(open(tpath))['hbm_bytes_per_launch']
+    nets = ('mask + predicted-normal NerfMLP (configs/nerf_ds.gin graph)' if args.graph == 'nerf_ds'
+            else 'NerfMLP with posenc identity (configs/base.gin HyperNeRF graph)')
+    workload = (f"NeRF-DS 'bell'-shaped synthetic scene, 800x600 frame per GPU (480000 rays), {args.samples} coarse + {args.samples} fine "
+                f'samples ({2 * args.samples} on the fine pass, {3 * args.samples} field evaluations/ray), SE(3) warp + hyper-slice + '
+                f'{nets}, random-init weights')
     result = {
         'metric': 'rendered rays/sec (%d samples/ray, full warp+NerfMLP)' % (2 * args.samples),
         'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
-        'config': {'workload': "NeRF-DS 'bell'-shaped synthetic scene, 800x600 frame per GPU (480000 rays), %d coarse + "
-                               '%d fine samples (%d on the fine pass, %d field evaluations/ray), SE(3) warp + hyper-slice + '
-                               'mask + predicted-normal NerfMLP (configs/nerf_ds.gin graph), random-init weights' % (args.samples, args.samples, 2 * args.samples, 3 * args.samples),
+        'config': {'workload': workload,
                    'rays_per_gpu_per_step': args.rays, 'chunk': args.chunk, 'parallelism': f'ray-shard x{world}',
                    'exchange': 'all-gather of [chunk, 26] fp32 ray records' if world > 1 else 'none (1 GPU)'},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                      'frac': (achieved / peak) if achieved else None, 'traffic': traffic,
-                     'kernel': 'nerfds::render_rays_kernel<GraphNerfDS, %s>' % args.precision,
+                     'kernel': 'nerfds::render_rays_kernel<%s, %s>' % ('GraphNerfDS' if args.graph == 'nerf_ds' else 'GraphHyperNeRF', args.precision),
                      'avg_launch_ms': avg_launch_s * 1e3, 'launches': n_launch,
                      'algorithmic_flop_per_launch': rays_per_launch * flop_per_ray},
     }

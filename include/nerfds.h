@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NERFDS_ABI_VERSION 1
+#define NERFDS_ABI_VERSION 2
 
 /* error codes */
 #define NERFDS_OK         0
@@ -98,6 +98,7 @@ typedef struct nerfds_model_cfg {
   int32_t mask_max_deg, mask_depth, mask_width, mask_skip;
   int32_t glo_num_dims, num_warp_embeds;
   int32_t use_white_background, use_sample_at_infinity;
+  int32_t use_posenc_identity, warp_use_posenc_identity;   /* NerfModel / SE3Field.use_posenc_identity (models.py:143, warping.py:141) */
 } nerfds_model_cfg;
 
 /* One nn.Dense: kernel is row-major [in][out] (Flax layout), y = x @ kernel + bias. HOST pointers. */

@@ -43,6 +43,7 @@ constexpr int mlp_bias_tiles(int depth, int width, bool head) { return depth * (
 struct GraphNerfDS {
   static constexpr int ID = 0;
   static constexpr bool HAS_MASK = true, HAS_WARP = true, HAS_HYPER = true, PREDICT_NORM = true, X_IN_RGB = true;
+  static constexpr bool IDENT = false, WARP_IDENT = false;      // use_posenc_identity (defaults.gin:111,138)
   static constexpr int GLO = 8;
   static constexpr int MASK_BANDS = 6, MASK_DEPTH = 8, MASK_W = 128, MASK_SKIP = 4;
   static constexpr int WARP_BANDS = 4, WARP_DEPTH = 6, WARP_W = 128, WARP_SKIP = 4;
@@ -55,6 +56,7 @@ struct GraphNerfDS {
 struct GraphStatic {
   static constexpr int ID = 1;
   static constexpr bool HAS_MASK = false, HAS_WARP = false, HAS_HYPER = false, PREDICT_NORM = false, X_IN_RGB = false;
+  static constexpr bool IDENT = false, WARP_IDENT = false;
   static constexpr int GLO = 8;
   static constexpr int MASK_BANDS = 0, MASK_DEPTH = 0, MASK_W = 128, MASK_SKIP = 4;
   static constexpr int WARP_BANDS = 0, WARP_DEPTH = 0, WARP_W = 128, WARP_SKIP = 4;
@@ -63,17 +65,34 @@ struct GraphStatic {
   static constexpr int TRUNK_DEPTH = 8, TRUNK_W = 256, TRUNK_SKIP = 4, RGB_W = 128;
 };
 
+// configs/base.gin (the HyperNeRF graph the reference inherits; BASELINE config 5 per SURVEY 8d): SE(3) warp with 6 bands
+// + identity, bendy-sheet hyper slicing, posenc identity on x' and viewdirs, no mask net, no predicted normal.
+struct GraphHyperNeRF {
+  static constexpr int ID = 2;
+  static constexpr bool HAS_MASK = false, HAS_WARP = true, HAS_HYPER = true, PREDICT_NORM = false, X_IN_RGB = false;
+  static constexpr bool IDENT = true, WARP_IDENT = true;        // base.gin:21-22
+  static constexpr int GLO = 8;
+  static constexpr int MASK_BANDS = 0, MASK_DEPTH = 0, MASK_W = 128, MASK_SKIP = 4;
+  static constexpr int WARP_BANDS = 6, WARP_DEPTH = 6, WARP_W = 128, WARP_SKIP = 4;
+  static constexpr int HYP_BANDS = 6, HYP_DEPTH = 6, HYP_W = 64, HYP_SKIP = 4, HYP_DIMS = 2;
+  static constexpr int SP_BANDS = 8, HP_BANDS = 1, VD_BANDS = 4, NM_BANDS = 0;
+  static constexpr int TRUNK_DEPTH = 8, TRUNK_W = 256, TRUNK_SKIP = 4, RGB_W = 128;
+};
+
 template <class G> struct Dims {
   // linear input widths (reference concatenation order) and their k16-chunk counts
+  static constexpr int ID3 = G::IDENT ? 3 : 0, WARP_ID3 = G::WARP_IDENT ? 3 : 0;   // identity prefix of posenc (model_utils.py:414-417)
   static constexpr int MASK_IN = 6 * G::MASK_BANDS + G::GLO;                       // posenc(x) | mask_embed
-  static constexpr int WARP_IN = 6 * G::WARP_BANDS + G::GLO + 1;                   // posenc(x) | warp_embed | mask
-  static constexpr int HYP_IN = 6 * G::HYP_BANDS + G::GLO + 1;                     // posenc(x) | warp_embed | mask
-  static constexpr int TRUNK_IN = 6 * G::SP_BANDS + 2 * G::HYP_DIMS * G::HP_BANDS; // posenc(x') | posenc(w)
-  static constexpr int COND_IN = 6 * G::VD_BANDS + 6 * G::NM_BANDS;                // posenc(viewdir) | posenc(normal)
+  static constexpr int WARP_IN = WARP_ID3 + 6 * G::WARP_BANDS + G::GLO + (G::HAS_MASK ? 1 : 0);   // [x] posenc(x) | warp_embed | [mask]
+  static constexpr int HYP_IN = 6 * G::HYP_BANDS + G::GLO + (G::HAS_MASK ? 1 : 0);  // posenc(x) | warp_embed | [mask]
+  static constexpr int TRUNK_IN = ID3 + 6 * G::SP_BANDS + 2 * G::HYP_DIMS * G::HP_BANDS;   // [x'] posenc(x') | posenc(w)
+  static constexpr int VD_FEATS = ID3 + 6 * G::VD_BANDS;                           // [viewdir] posenc(viewdir)
+  static constexpr int NM_FEATS = G::PREDICT_NORM ? ID3 + 6 * G::NM_BANDS : 0;     // [n] posenc(n)
+  static constexpr int COND_IN = VD_FEATS + NM_FEATS;
   static constexpr int MASK_KC = chunks(MASK_IN), WARP_KC = chunks(WARP_IN), HYP_KC = chunks(HYP_IN);
   static constexpr int TRUNK_KC = chunks(TRUNK_IN), COND_KC = chunks(COND_IN);
   static constexpr int ALPHA_OUT = 1 + (G::PREDICT_NORM ? 3 : 0);
-  static constexpr int RGB_IN = G::TRUNK_W + 6 * G::VD_BANDS + (G::X_IN_RGB ? G::TRUNK_W : 0) + 6 * G::NM_BANDS;
+  static constexpr int RGB_IN = G::TRUNK_W + VD_FEATS + (G::X_IN_RGB ? G::TRUNK_W : 0) + NM_FEATS;
 
   // fragment / bias-tile counts of the two weight streams
   static constexpr int MASK_FRAGS = G::HAS_MASK ? mlp_frags(G::MASK_DEPTH, G::MASK_W, MASK_KC, G::MASK_SKIP, true) : 0;

@@ -25,6 +25,9 @@ void nerfds_launch_nerfds_f32(const KArgs&, int, void*);
 void nerfds_launch_static_bf16(const KArgs&, int, void*);
 void nerfds_launch_static_bf16x3(const KArgs&, int, void*);
 void nerfds_launch_static_f32(const KArgs&, int, void*);
+void nerfds_launch_hyper_bf16(const KArgs&, int, void*);
+void nerfds_launch_hyper_bf16x3(const KArgs&, int, void*);
+void nerfds_launch_hyper_f32(const KArgs&, int, void*);
 void nerfds_launch_camera_rays(const nerfds::CameraParams&, long long, long long, const float*, float*, float*, float*, void*);
 void nerfds_launch_frame_images(const float*, int, int, float, float, const double*, uint8_t*, uint8_t*, void*);
 }
@@ -78,10 +81,12 @@ template <class G> bool cfg_matches(const nerfds_model_cfg& c) {
             (c.use_x_in_rgb_condition != 0) == G::X_IN_RGB && c.use_viewdirs != 0 &&
             c.nerf_trunk_depth == G::TRUNK_DEPTH && c.nerf_trunk_width == G::TRUNK_W && c.nerf_skip == G::TRUNK_SKIP &&
             c.nerf_rgb_branch_depth == 1 && c.nerf_rgb_branch_width == G::RGB_W &&
-            c.spatial_point_max_deg == G::SP_BANDS && c.viewdir_max_deg == G::VD_BANDS;
+            c.spatial_point_max_deg == G::SP_BANDS && c.viewdir_max_deg == G::VD_BANDS &&
+            (c.use_posenc_identity != 0) == G::IDENT;
   if (G::HAS_WARP)
     ok = ok && c.warp_max_deg == G::WARP_BANDS && c.warp_trunk_depth == G::WARP_DEPTH && c.warp_trunk_width == G::WARP_W &&
-         c.warp_skip == G::WARP_SKIP && c.glo_num_dims == G::GLO && (c.use_mask_in_warp != 0) == G::HAS_MASK;
+         c.warp_skip == G::WARP_SKIP && c.glo_num_dims == G::GLO && (c.use_mask_in_warp != 0) == G::HAS_MASK &&
+         (c.warp_use_posenc_identity != 0) == G::WARP_IDENT;
   if (G::HAS_HYPER)
     ok = ok && c.hyper_sheet_max_deg == G::HYP_BANDS && c.hyper_sheet_depth == G::HYP_DEPTH && c.hyper_sheet_width == G::HYP_W &&
          c.hyper_sheet_skip == G::HYP_SKIP && c.hyper_num_dims == G::HYP_DIMS && c.hyper_point_max_deg == G::HP_BANDS &&
@@ -97,6 +102,7 @@ template <class G> bool cfg_matches(const nerfds_model_cfg& c) {
 int graph_of(const nerfds_model_cfg& c) {
   if (cfg_matches<GraphNerfDS>(c)) return GraphNerfDS::ID;
   if (cfg_matches<GraphStatic>(c)) return GraphStatic::ID;
+  if (cfg_matches<GraphHyperNeRF>(c)) return GraphHyperNeRF::ID;
   return -1;
 }
 
@@ -155,6 +161,12 @@ template <class G> bool take_weights(Weights& W, const nerfds_model_cfg& c, cons
   return true;
 }
 
+bool take_weights_dispatch(int graph, Weights& W, const nerfds_model_cfg& c, const nerfds_weights& w, std::string& err) {
+  if (graph == GraphNerfDS::ID) return take_weights<GraphNerfDS>(W, c, w, err);
+  if (graph == GraphStatic::ID) return take_weights<GraphStatic>(W, c, w, err);
+  return take_weights<GraphHyperNeRF>(W, c, w, err);
+}
+
 SharedNets shared_views(const Weights& W) {
   SharedNets n;
   for (int i = 0; i < NERFDS_MAX_DEPTH; ++i) {
@@ -176,7 +188,9 @@ template <class G> void pack_which(StreamWriter& sw, const Weights& W, int which
   if (which == 0) pack_shared<G>(sw, shared_views(W)); else pack_nerf<G>(sw, nerf_views(W.nerf[level]));
 }
 void pack_dispatch(int graph, StreamWriter& sw, const Weights& W, int which, int level) {
-  if (graph == GraphNerfDS::ID) pack_which<GraphNerfDS>(sw, W, which, level); else pack_which<GraphStatic>(sw, W, which, level);
+  if (graph == GraphNerfDS::ID) pack_which<GraphNerfDS>(sw, W, which, level);
+  else if (graph == GraphStatic::ID) pack_which<GraphStatic>(sw, W, which, level);
+  else pack_which<GraphHyperNeRF>(sw, W, which, level);
 }
 template <class G> void stream_dims(int which, int prec, int64_t* wbytes, int64_t* bfloats) {
   using D = Dims<G>;
@@ -184,7 +198,9 @@ template <class G> void stream_dims(int which, int prec, int64_t* wbytes, int64_
   *bfloats = (int64_t)(which == 0 ? D::SHARED_BIAS_TILES : D::NERF_BIAS_TILES) * 32;
 }
 void stream_dims_dispatch(int graph, int which, int prec, int64_t* wb, int64_t* bf) {
-  if (graph == GraphNerfDS::ID) stream_dims<GraphNerfDS>(which, prec, wb, bf); else stream_dims<GraphStatic>(which, prec, wb, bf);
+  if (graph == GraphNerfDS::ID) stream_dims<GraphNerfDS>(which, prec, wb, bf);
+  else if (graph == GraphStatic::ID) stream_dims<GraphStatic>(which, prec, wb, bf);
+  else stream_dims<GraphHyperNeRF>(which, prec, wb, bf);
 }
 
 void window(float* out, int bands, float alpha) {   // model_utils.py:420-436
@@ -224,9 +240,10 @@ struct nerfds_ctx {
 };
 
 static launch_fn launcher(int graph, uint32_t prec) {
-  static const launch_fn tab[2][3] = {
+  static const launch_fn tab[3][3] = {
       {nerfds_launch_nerfds_bf16, nerfds_launch_nerfds_bf16x3, nerfds_launch_nerfds_f32},
-      {nerfds_launch_static_bf16, nerfds_launch_static_bf16x3, nerfds_launch_static_f32}};
+      {nerfds_launch_static_bf16, nerfds_launch_static_bf16x3, nerfds_launch_static_f32},
+      {nerfds_launch_hyper_bf16, nerfds_launch_hyper_bf16x3, nerfds_launch_hyper_f32}};
   return tab[graph][prec];
 }
 
@@ -248,7 +265,8 @@ int nerfds_ctx_create(nerfds_ctx** out, int device, const nerfds_model_cfg* cfg)
   const int graph = graph_of(*cfg);
   if (graph < 0) {
     g_create_error = "render graph not built as a HIP kernel: supported are the configs/nerf_ds.gin graph "
-                     "(mask + SE3 warp + hyper sheet + predicted normal) and the static coarse/fine NeRF graph";
+                     "(mask + SE3 warp + hyper sheet + predicted normal), the configs/base.gin HyperNeRF graph "
+                     "(SE3 warp + hyper sheet, posenc identity) and the static coarse/fine NeRF graph";
     return NERFDS_ENOTSUP;
   }
   int ndev = 0;
@@ -279,8 +297,7 @@ int nerfds_ctx_load_weights(nerfds_ctx* ctx, const nerfds_weights* w) {
   if (!ctx || !w) return NERFDS_EINVAL;
   std::string err;
   ctx->W = Weights();
-  bool ok = ctx->graph == GraphNerfDS::ID ? take_weights<GraphNerfDS>(ctx->W, ctx->cfg, *w, err)
-                                          : take_weights<GraphStatic>(ctx->W, ctx->cfg, *w, err);
+  bool ok = take_weights_dispatch(ctx->graph, ctx->W, ctx->cfg, *w, err);
   if (!ok) return ctx->fail(NERFDS_EINVAL, "load_weights: %s", err.c_str());
   for (bool& p : ctx->packed) p = false;
   ctx->bias_uploaded = false;
@@ -474,7 +491,7 @@ int nerfds_pack_stream(const nerfds_model_cfg* cfg, const nerfds_weights* w, int
   if (g < 0) return NERFDS_ENOTSUP;
   Weights W;
   std::string err;
-  bool ok = g == GraphNerfDS::ID ? take_weights<GraphNerfDS>(W, *cfg, *w, err) : take_weights<GraphStatic>(W, *cfg, *w, err);
+  bool ok = take_weights_dispatch(g, W, *cfg, *w, err);
   if (!ok) { g_create_error = err; return NERFDS_EINVAL; }
   StreamWriter sw{(int)prec, static_cast<uint8_t*>(stream_out), bias_out};
   pack_dispatch(g, sw, W, which, level);

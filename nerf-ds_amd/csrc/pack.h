@@ -196,7 +196,7 @@ template <class G> void pack_nerf(StreamWriter& sw, const NerfNet& n) {
      //   with bottleneck = trunk_output @ Wb + bb.  Hence, with F = Wb @ K[bottleneck rows] (+ K[trunk_output rows]):
      //   rgb_pre = trunk_output @ F + [viewdir | normal] @ K[cond rows] + (b + bb @ K[bottleneck rows]).
      // Kernel K order: [trunk_output tiles | cond chunks = viewdir ++ normal]; virtual rows 0..TW-1 = F, TW.. = cond.
-    constexpr int VD = 6 * G::VD_BANDS, NM = 6 * G::NM_BANDS;
+    constexpr int VD = D::VD_FEATS, NM = D::NM_FEATS;
     constexpr int row_vd = TW, row_x = TW + VD, row_nm = TW + VD + (G::X_IN_RGB ? TW : 0);
     const DenseView K = n.rgb_hidden[0], B = n.bottleneck;
     const int W = G::RGB_W;

@@ -499,7 +499,7 @@ template <int P, int KCH, class F> DEVI void build_chunks(Chunk<P> (&out)[KCH], 
 // ------------------------------------------------------------------------------------------------
 enum { SV_SIGMA = 0, SV_RGB = 1, SV_MASK = 4, SV_NORM = 5, SV_WP = 8, SV_ROT = 13, SV_TRN = 16,
        SV_AX = 19, SV_SN = 22, SV_OMC = 23, SV_COUNT = 24 };
-enum { RC_WEMB = 0, RC_MEMB = 8, RC_VDENC = 16, RC_COUNT = 64 };
+enum { RC_WEMB = 0, RC_MEMB = 8, RC_VDENC = 16, RC_VD = 40, RC_COUNT = 64 };
 
 template <int MAXS> struct WaveLdsT {
   static constexpr int MAX_S = MAXS;
@@ -603,9 +603,11 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       build_chunks<P, D::WARP_KC>(in0[nt], h, [&](int f) {
-        if (f < 6 * G::WARP_BANDS) return posenc_feat<3>(f, x[nt], ka.win_warp);
-        if (f < 6 * G::WARP_BANDS + 8) return val_feat(L.rayc[RC_WEMB + ((f - 6 * G::WARP_BANDS) & 7)]);
-        if (f == 6 * G::WARP_BANDS + 8) return val_feat(maskv[nt]);         // models.py:729-730
+        constexpr int I3 = D::WARP_ID3, PE = I3 + 6 * G::WARP_BANDS;      // [x] | posenc(x) | warp_embed | [mask]
+        if (f < I3) return val_feat(x[nt][f < 3 ? f : 0]);                 // identity prefix (model_utils.py:414-417)
+        if (f < PE) return posenc_feat<3>(f - I3, x[nt], ka.win_warp);
+        if (f < PE + 8) return val_feat(L.rayc[RC_WEMB + ((f - PE) & 7)]);
+        if (G::HAS_MASK && f == PE + 8) return val_feat(maskv[nt]);        // models.py:729-730
         return zero_feat();
       });
     static_assert(G::WARP_DEPTH == 6 || !G::HAS_WARP, "warp trunk is unrolled for depth 6, skip 4");
@@ -689,7 +691,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
       build_chunks<P, D::HYP_KC>(in0[nt], h, [&](int f) {
         if (f < 6 * G::HYP_BANDS) return posenc_feat<3>(f, x[nt], ka.win_hyp);
         if (f < 6 * G::HYP_BANDS + 8) return val_feat(L.rayc[RC_WEMB + ((f - 6 * G::HYP_BANDS) & 7)]);   // hyper_use_warp_embed
-        if (f == 6 * G::HYP_BANDS + 8) return val_feat(maskv[nt]);                                        // models.py:731-732
+        if (G::HAS_MASK && f == 6 * G::HYP_BANDS + 8) return val_feat(maskv[nt]);                         // models.py:731-732
         return zero_feat();
       });
     static_assert(G::HYP_DEPTH == 6 || !G::HAS_HYPER, "hyper sheet is unrolled for depth 6, skip 4");
@@ -720,8 +722,10 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       build_chunks<P, D::TRUNK_KC>(in0[nt], h, [&](int f) {
-        if (f < 6 * G::SP_BANDS) return posenc_feat<3>(f, xw[nt], ka.win_sp);                    // models.py:502-507
-        if (f < D::TRUNK_IN) return posenc_feat<2>(f - 6 * G::SP_BANDS, wamb[nt], ka.win_hp);    // models.py:510-516
+        constexpr int I3 = D::ID3, PE = I3 + 6 * G::SP_BANDS;
+        if (f < I3) return val_feat(xw[nt][f < 3 ? f : 0]);                                      // identity prefix
+        if (f < PE) return posenc_feat<3>(f - I3, xw[nt], ka.win_sp);                            // models.py:502-507
+        if (f < D::TRUNK_IN) return posenc_feat<2>(f - PE, wamb[nt], ka.win_hp);                 // models.py:510-516 (no identity)
         return zero_feat();
       });
     static_assert(G::TRUNK_DEPTH == 8 && G::TRUNK_SKIP == 4, "trunk is unrolled for depth 8, skip 4");
@@ -768,8 +772,11 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
         }
       }
       build_chunks<P, D::COND_KC>(cond[nt], h, [&](int f) {
-        if (f < 6 * G::VD_BANDS) return val_feat(L.rayc[RC_VDENC + (f < 24 ? f : 0)]);
-        if (f < D::COND_IN) return posenc_feat<3>(f - 6 * G::VD_BANDS, nin, ka.win_nm);         // models.py:1142-1148
+        constexpr int I3 = D::ID3, VD = D::VD_FEATS;
+        if (f < I3) return val_feat(L.rayc[RC_VD + (f < 3 ? f : 0)]);                           // identity prefix of posenc(viewdir)
+        if (f < VD) return val_feat(L.rayc[RC_VDENC + ((f - I3) < 24 ? (f - I3) : 0)]);
+        if (G::PREDICT_NORM && f < VD + I3) return val_feat(nin[(f - VD) < 3 ? (f - VD) : 0]);                     // identity prefix of posenc(normal)
+        if (G::PREDICT_NORM && f < D::COND_IN) return posenc_feat<3>(f - VD - I3, nin, ka.win_nm);   // models.py:1142-1148
         return zero_feat();
       });
     }
@@ -1040,6 +1047,7 @@ __global__ __launch_bounds__(64 * wg_waves<P>(), wg_waves<P>() / 4) void render_
         const float vdc = ch == 0 ? vdir[0] : (ch == 1 ? vdir[1] : vdir[2]);
         L.rayc[RC_VDENC + lane] = sin_cw(fmaf(vdc, (float)(1 << band), sc ? 1.57079637f : 0.0f));
       }
+      if (lane < 3) L.rayc[RC_VD + lane] = lane == 0 ? vdir[0] : (lane == 1 ? vdir[1] : vdir[2]);
     }
 
     // ---- coarse z (model_utils.py:75-89) ----

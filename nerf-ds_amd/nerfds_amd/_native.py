@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFDS_LIB', os.path.join(_HERE, '_lib', 'libnerfds_hip.so'))   # NERFDS_LIB: development builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_DEPTH = 16
 RAY_REC = 26
 SAMPLE_REC = 18
@@ -40,7 +40,8 @@ class ModelCfg(C.Structure):
       'warp_max_deg', 'warp_trunk_depth', 'warp_trunk_width', 'warp_skip',
       'hyper_sheet_max_deg', 'hyper_sheet_depth', 'hyper_sheet_width', 'hyper_sheet_skip', 'hyper_num_dims',
       'mask_max_deg', 'mask_depth', 'mask_width', 'mask_skip',
-      'glo_num_dims', 'num_warp_embeds', 'use_white_background', 'use_sample_at_infinity')]
+      'glo_num_dims', 'num_warp_embeds', 'use_white_background', 'use_sample_at_infinity',
+      'use_posenc_identity', 'warp_use_posenc_identity')]
 
 
 class Dense(C.Structure):

@@ -194,6 +194,19 @@ def nerf_ds_config(near: float = 0.3, far: float = 1.7, num_warp_embeds: int = 2
   return cfg.replace(**kw) if kw else cfg
 
 
+def hypernerf_config(near: float = 0.3, far: float = 1.7, num_warp_embeds: int = 256, **kw) -> NerfModelConfig:
+  """configs/base.gin over configs/defaults.gin (the HyperNeRF graph; BASELINE config 5 per SURVEY 8d): SE(3) warp with 6 bands
+  and posenc identity, bendy-sheet hyper slicing, posenc identity on x' and the view direction, 128 + 128 samples; no mask
+  network, no predicted normal, no trunk output in the rgb condition."""
+  cfg = NerfModelConfig(
+      near=near, far=far, num_warp_embeds=num_warp_embeds, num_coarse_samples=128, num_fine_samples=128,
+      use_posenc_identity=True, warp_use_posenc_identity=True, warp_max_deg=6,
+      predict_norm=False, use_x_in_rgb_condition=False, use_mask_in_warp=False, use_mask_in_hyper=False,
+      use_predicted_mask=False, use_3d_mask=False, use_mask_sharp_weights=False,
+      mask_mlp=MLPSpec(6, 64, (4,)), mask_output_relu=False)      # MaskMLP defaults (unused: no mask network)
+  return cfg.replace(**kw) if kw else cfg
+
+
 def static_config(near: float = 2.0, far: float = 6.0, num_coarse_samples: int = 64, **kw) -> NerfModelConfig:
   """BASELINE.json configs[0]: static scene, coarse only, warp/hyper/mask/normal disabled.
 

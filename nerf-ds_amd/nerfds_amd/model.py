@@ -57,8 +57,7 @@ def _cfg_struct(cfg: NerfModelConfig) -> N.ModelCfg:
                'warp_min_deg', 'hyper_sheet_min_deg', 'mask_min_deg'):
     if getattr(cfg, name) != 0:
       raise NotImplementedError(f'{name} != 0 is not configured by any shipped gin file')
-  if cfg.use_posenc_identity or cfg.warp_use_posenc_identity:
-    raise NotImplementedError('use_posenc_identity=True (configs/base.gin graph) has no HIP kernel yet')
+  c.use_posenc_identity, c.warp_use_posenc_identity = int(cfg.use_posenc_identity), int(cfg.warp_use_posenc_identity)
   return c
 
 

@@ -50,3 +50,11 @@ def test_reference_nerf_ds_gin_resolves_to_the_compiled_graph():
   assert cfg == nerf_ds_config(near=0.3, far=1.7, num_warp_embeds=256)
   assert extra_params_from_gin('/root/reference/configs/nerf_ds.gin') == {
       'nerf_alpha': 8.0, 'warp_alpha': 4.0, 'hyper_alpha': 1.0, 'hyper_sheet_alpha': 6.0, 'norm_input_alpha': 4.0}
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/configs/base.gin'), reason='reference tree only exists in the authoring container')
+def test_reference_base_gin_resolves_to_the_hypernerf_graph():
+  from nerfds_amd import hypernerf_config
+  cfg = config_from_gin('/root/reference/configs/base.gin', near=0.3, far=1.7, num_warp_embeds=256)
+  assert cfg == hypernerf_config(near=0.3, far=1.7, num_warp_embeds=256)
+  assert (cfg.warp_in_dim, cfg.hyper_in_dim, cfg.trunk_in_dim, cfg.rgb_in_dim) == (47, 44, 55, 283)

@@ -185,6 +185,27 @@ def test_static_graph_config1(prec):
   assert 'ray_rotation_field' not in out['coarse'] and out['coarse']['ray_hyper_points'].shape == (R, 0)
 
 
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16'])
+@pytest.mark.parametrize('Nc,Nf', [(16, 16), (128, 128)])
+def test_hypernerf_base_gin_graph(prec, Nc, Nf):
+  """configs/base.gin graph (BASELINE config 5 per SURVEY 8d): posenc identity, SE3 warp (6 bands), hyper sheet, no mask / normal;
+  at its own 128 + 128 samples (wide kernel shape) and at a small count."""
+  from nerfds_amd import hypernerf_config
+  cfg = hypernerf_config(num_warp_embeds=5, num_coarse_samples=Nc, num_fine_samples=Nf)
+  params = init_params(cfg, 2, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  R = 9 if Nc > 64 else 37
+  rays, rng = _rays(R, 5, 21, spread=0.2)
+  t, u = rng.random((R, Nc)), rng.random((R, Nf))
+  extra = dict(EXTRA, warp_alpha=6.0)
+  ref = O.NerfModel(cfg, params).apply(rays, extra, t_rand=t, u_rand=u, return_weights=True, return_points=True, compute_sigma_gradient=False)
+  out = _model(cfg).apply({'params': params}, rays, extra, t_rand=t, u_rand=u, precision=prec, return_samples=True)
+  for level in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'acc', 'ray_delta_x', 'ray_hyper_points', 'ray_rotation_field'):
+      e = _relerr(out[level][k].cpu().numpy().reshape(ref[level][k].shape), ref[level][k].numpy())
+      assert e <= (RTOL[prec] if k == 'rgb' else 10 * RTOL[prec]), (level, k, e)
+    assert 'ray_predicted_mask' not in out[level] or float(out[level]['ray_predicted_mask'].abs().max()) == 0.0
+
+
 def test_edge_cases_empty_single_and_leading_shape():
   cfg = nerf_ds_config(num_warp_embeds=2, num_coarse_samples=8, num_fine_samples=8)
   params = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)

@@ -25,7 +25,7 @@ def test_library_loads_and_exports_header_symbols():
   assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
   for s in declared:
     assert hasattr(lib, s), s
-  assert lib.nerfds_abi_version() == 1
+  assert lib.nerfds_abi_version() == 2
 
 
 def test_ctx_create_errors_without_touching_a_gpu():
@@ -104,13 +104,16 @@ def test_shared_nets_stream_matches_oracle(prec, tol):
   _assert_consumed(s)
 
 
-@pytest.mark.parametrize('graph', ['nerf_ds', 'static'])
+@pytest.mark.parametrize('graph', ['nerf_ds', 'static', 'hypernerf'])
 @pytest.mark.parametrize('level', [0, 1])
 def test_nerf_mlp_stream_matches_oracle(graph, level):
   if graph == 'static':
     if level == 1:
       pytest.skip('static graph is coarse only')
     cfg = static_config()
+  elif graph == 'hypernerf':
+    from nerfds_amd import hypernerf_config
+    cfg = hypernerf_config(num_warp_embeds=2)
   else:
     cfg = nerf_ds_config(num_warp_embeds=2)
   p = init_params(cfg, 5, bias_scale=0.1)
@@ -120,10 +123,10 @@ def test_nerf_mlp_stream_matches_oracle(graph, level):
   s = _pack(cfg, p, 1, level, 'f32')
   T = lambda a: torch.as_tensor(a, dtype=torch.float64)
   f = rng.normal(size=(n, cfg.trunk_in_dim))
-  vd, nm = rng.normal(size=(n, 24)), rng.normal(size=(n, cfg.norm_feat_dim))
+  vd, nm = rng.normal(size=(n, cfg.viewdir_dim)), rng.normal(size=(n, cfg.norm_feat_dim))
   trunk = E.mlp(s, f, 8, 256, 4)
   alpha = E.head(s, [trunk], cfg.alpha_out_dim)
-  cond = E.linear_chunks(np.concatenate([vd, nm], 1), -(-(24 + cfg.norm_feat_dim) // 16))
+  cond = E.linear_chunks(np.concatenate([vd, nm], 1), -(-(cfg.viewdir_dim + cfg.norm_feat_dim) // 16))
   hid = E.dense(s, [trunk, cond], 4, True)          # the activation-free bottleneck Dense is folded into rgb hidden_0
   rgb = E.head(s, [hid], 3)
   _assert_consumed(s)

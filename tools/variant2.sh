@@ -9,6 +9,6 @@ for v in "$@"; do
       -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_PREC=$P -DNERFDS_NAME=nerfds_$p -Rpass-analysis=kernel-resource-usage -o build/abl/kv_$n.o 2>&1 | grep -E "error|VGPRs Spill" | sed "s/^/$n: /"
     others=$(for q in bf16 bf16x3 f32; do [ $q != $p ] && echo build/k_nerfds_$q.o; done)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../nerfds_amd/_lib/abl/libnerfds_hip_$n.so build/abl/kv_$n.o $others \
-      build/k_static_bf16.o build/k_static_bf16x3.o build/k_static_f32.o build/host.o build/camera.o build/frame.o build/train_k.o build/train.o -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib ) &
+      build/k_static_bf16.o build/k_static_bf16x3.o build/k_static_f32.o build/k_hyper_bf16.o build/k_hyper_bf16x3.o build/k_hyper_f32.o build/host.o build/camera.o build/frame.o build/train_k.o build/train.o -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib ) &
 done
 wait
