@@ -53,3 +53,35 @@ def test_hip_matches_golden(name, prec, tol):
         continue
       err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6)
       assert err <= (tol if k == 'rgb' else 10 * tol), (level, k, err)        # 1e-4 rel on composited RGB (north_star)
+
+
+def test_train_oracle_reproduces_golden():
+  z = np.load(os.path.join(HERE, 'golden', 'train_' + G.TRAIN_CASE + '.npz'))
+  losses, grads = G.run_train_oracle()
+  for k, v in losses.items():
+    assert abs(v - float(z['loss/' + k])) < 1e-12
+  for name, g in grads.items():
+    idx, vals, norm, amax = G.grad_digest(name, g)
+    assert np.array_equal(idx, z['idx/' + name]) and np.allclose(vals, z['val/' + name], rtol=1e-10, atol=1e-14), name
+    assert abs(norm - float(z['norm/' + name])) <= 1e-10 * max(norm, 1e-30)
+
+
+@pytest.mark.gpu
+def test_hip_training_step_matches_golden():
+  """The HIP training step against COMMITTED gradient digests (the oracle is not run): per leaf a seeded subsample of
+  256 entries, the L2 norm and the max-abs value of the fp64 autograd gradient."""
+  from nerfds_amd.training import Trainer
+  from nerfds_amd.params import tree_leaves
+  z = np.load(os.path.join(HERE, 'golden', 'train_' + G.TRAIN_CASE + '.npz'))
+  cfg, params, rays, t, u, target = G.train_case()
+  tr = Trainer(cfg, params, max_rays=rays['origins'].shape[0])
+  stats = tr.step(dict(rays, rgb=target), G.EXTRA, 0.0, t_rand=t, u_rand=u, grads_only=True)
+  assert abs(stats['loss/fine'] - float(z['loss/fine'])) < 2e-5 and abs(stats['loss/coarse'] - float(z['loss/coarse'])) < 2e-5
+  got = dict(tree_leaves(tr.get_grads()))
+  gmax = max(float(z[k]) for k in z.files if k.startswith('max/'))
+  for name, g in got.items():
+    idx, want, norm, amax = z['idx/' + name], z['val/' + name], float(z['norm/' + name]), float(z['max/' + name])
+    flat = np.asarray(g, np.float64).ravel()
+    scale = max(amax, 1e-3 * gmax)
+    assert np.abs(flat[idx] - want).max() / scale < 1e-2, name          # fp32 path vs fp64 fixture (yardstick: tests/test_training.py)
+    assert abs(np.linalg.norm(flat) - norm) <= 4e-3 * max(norm, 1e-3 * gmax * np.sqrt(flat.size)), name
