@@ -227,6 +227,7 @@ int nerfds_frame_images(int device, const float* ray_records, int32_t height, in
  * objective (training.py:276-438) are not part of config 4 and not built. */
 typedef struct nerfds_trainer nerfds_trainer;
 #define NERFDS_TRAIN_GRADS_ONLY 1u
+#define NERFDS_TRAIN_SIGMA_GRAD 2u   /* also evaluate the sigma gradient (models.py:1035-1077) -> nerfds_trainer_target_norm */
 int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_cfg* cfg, int64_t max_rays);
 int nerfds_trainer_destroy(nerfds_trainer* t);
 int64_t nerfds_trainer_param_count(const nerfds_trainer* t);
@@ -237,6 +238,9 @@ float* nerfds_trainer_grads(nerfds_trainer* t);    /* DEVICE [param_count], vali
 /* HOST <-> DEVICE copies of a whole vector; which: 0 parameters, 1 gradients, 2 / 3 Adam first / second moments */
 int nerfds_trainer_download(nerfds_trainer* t, int which, float* host);
 int nerfds_trainer_upload(nerfds_trainer* t, int which, const float* host);
+/* target_norm = normalize(R normalize(-d sigma_raw / d x)) per sample (models.py:1069-1077, 1273-1277, 1328; 'warped' supervision) of the
+ * last step run with NERFDS_TRAIN_SIGMA_GRAD: HOST [num_rays][S][3], S = Nc (level 0) or Nc + Nf (level 1). */
+int nerfds_trainer_target_norm(nerfds_trainer* t, int level, int64_t num_rays, float* host);
 int nerfds_trainer_reset_optimizer(nerfds_trainer* t);   /* zero the Adam moments and the step count */
 int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* extra,
                         const nerfds_rand* rnd, float learning_rate, uint32_t flags, float* loss_host, void* hip_stream);

@@ -56,6 +56,10 @@ struct nerfds_trainer {
   float* ws = nullptr;      // one workspace allocation
   size_t ws_floats = 0;
   float* loss_dev = nullptr;
+  float* tws = nullptr;     // tangent workspace of the sigma gradient (allocated on first use)
+  float *t_warp_in, *t_hyper_in, *tA, *tB, *t_wv, *t_xw, *t_wamb, *t_tin, *t_alpha;
+  float* tn[2] = {nullptr, nullptr};      // target_norm of the coarse / fine level of the last step
+  bool tn_valid = false;
   float* part = nullptr;    // split-K partials of the weight-gradient GEMMs
   size_t part_floats = 0;
   std::string err;
@@ -75,7 +79,7 @@ struct nerfds_trainer {
     return code;
   }
   ~nerfds_trainer() {
-    for (float* p : {theta, grad, m1, m2, ws, loss_dev, part}) if (p) (void)hipFree(p);
+    for (float* p : {theta, grad, m1, m2, ws, loss_dev, part, tws}) if (p) (void)hipFree(p);
     if (blas) (void)rocblas_destroy_handle(blas);
   }
 };
@@ -171,6 +175,26 @@ struct Run {
       k0 += s.K;
     }
   }
+  // tangents (3 rows per sample, no bias): y[3M x N] = sum_s t_s W[rows of s]
+  void dense_jvp(const LayerP& L, const std::vector<Seg>& segs, float* y, int ldy) {
+    int k0 = 0;
+    for (size_t i = 0; i < segs.size(); ++i) {
+      chk(gemm_nn(t.blas, 3 * M, L.N, segs[i].K, segs[i].x, segs[i].ld, t.theta + L.w + (int64_t)k0 * L.N, L.N, i ? 1.f : 0.f, y, ldy));
+      k0 += segs[i].K;
+    }
+  }
+  // returns the tangent of the last hidden layer (in cur or other)
+  float* mlp_jvp(const MlpP& m, const float* t_in0, const std::vector<float*>& h, float* cur, float* other) {
+    for (int l = 0; l < m.depth; ++l) {
+      std::vector<Seg> segs;
+      if (l > 0) segs.push_back({cur, m.width, m.width, nullptr, 0, false});
+      if (l == 0 || l == m.skip) segs.push_back({t_in0, m.in_dim, m.in_dim, nullptr, 0, false});
+      dense_jvp(m.hidden[l], segs, other, m.width);
+      relu_mask3(st, other, h[l], M, m.width);
+      std::swap(cur, other);
+    }
+    return cur;
+  }
   void mlp_fwd(const MlpP& m, const float* in0, const std::vector<float*>& h) {
     for (int l = 0; l < m.depth; ++l) {
       std::vector<Seg> segs;
@@ -219,8 +243,46 @@ void carve(nerfds_trainer& t) {
   for (auto& v : views) { *v.first = base; base += (v.second + 63) & ~(size_t)63; }
 }
 
+bool ensure_tangent_ws(nerfds_trainer& t) {
+  if (t.tws) return true;
+  const int64_t R = t.max_rays, Nc = t.cfg.num_coarse_samples, S = Nc + t.cfg.num_fine_samples, M3 = 3 * R * S;
+  const Dims& D = t.D;
+  const int TW = t.trunk[0].width;
+  size_t need = 0;
+  std::vector<std::pair<float**, size_t>> views;
+  auto take = [&](float** p, size_t n) { views.push_back({p, n}); need += (n + 63) & ~(size_t)63; };
+  take(&t.t_warp_in, M3 * D.warp_in); take(&t.t_hyper_in, M3 * D.hyper_in); take(&t.tA, M3 * TW); take(&t.tB, M3 * TW);
+  take(&t.t_wv, M3 * 6); take(&t.t_xw, M3 * 3); take(&t.t_wamb, M3 * 2); take(&t.t_tin, M3 * D.trunk_in); take(&t.t_alpha, M3 * 4);
+  take(&t.tn[0], R * Nc * 3); take(&t.tn[1], R * S * 3);
+  if (hipMalloc(&t.tws, need * sizeof(float)) != hipSuccess) return false;
+  float* base = t.tws;
+  for (auto& v : views) { *v.first = base; base += (v.second + 63) & ~(size_t)63; }
+  return true;
+}
+
+// d sigma_raw / d x by forward-mode tangents through warp MLP -> exp_se3, hyper sheet, posenc, trunk, alpha head
+// (the mask is a constant input, models.py:1035-1069), then target_norm (models.py:1077, 1273-1277, 1328).  Uses the
+// activations of the forward pass that has just run for this level.
+void sigma_gradient(nerfds_trainer& t, Run& r, int level, const Windows& W) {
+  const Dims& D = t.D;
+  hipStream_t st = r.st;
+  const int64_t M = r.M;
+  encode_tangents(st, D, M, t.x, W, t.t_warp_in, t.t_hyper_in);
+  float* tw = r.mlp_jvp(t.warp, t.t_warp_in, t.warp_h, t.tA, t.tB);
+  r.dense_jvp(t.warp_w, {{tw, t.warp.width, t.warp.width, nullptr, 0, false}}, t.t_wv, 6);
+  r.dense_jvp(t.warp_v, {{tw, t.warp.width, t.warp.width, nullptr, 0, false}}, t.t_wv + 3, 6);
+  se3_jvp(st, M, t.wv, t.x, t.t_wv, t.t_xw);
+  float* th = r.mlp_jvp(t.hyper, t.t_hyper_in, t.hyper_h, t.tA, t.tB);
+  r.dense_jvp(t.hyper_out, {{th, t.hyper.width, t.hyper.width, nullptr, 0, false}}, t.t_wamb, 2);
+  trunk_in_jvp(st, D, M, t.xw, t.wamb, t.t_xw, t.t_wamb, W, t.t_tin);
+  const MlpP& trunk = t.trunk[level];
+  float* tt = r.mlp_jvp(trunk, t.t_tin, t.trunk_h, t.tA, t.tB);
+  r.dense_jvp(t.alpha[level], {{tt, trunk.width, trunk.width, nullptr, 0, false}}, t.t_alpha, 4);
+  target_norm(st, M, t.t_alpha, t.wv, t.tn[level]);
+}
+
 int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const float* z, const nerfds_rays* rays, const float* target,
-              const nerfds_extra* ex, const Windows& W, float* weights_out) {
+              const nerfds_extra* ex, const Windows& W, float* weights_out, bool want_sigma_gradient) {
   const Dims& D = t.D;
   Run r{t, st, (int64_t)R * S};
   const int64_t M = r.M;
@@ -251,6 +313,7 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   r.dense_fwd(t.rgb_out[level], {{t.rgb_hv, t.rgb_h[level].N, t.rgb_h[level].N, nullptr, 0, false}}, t.rgb_logit, 3, false);
   composite_loss(st, R, S, z, rays->directions, t.sigma, t.rgb_logit, target, t.cfg.use_sample_at_infinity, t.cfg.use_white_background, t.rgb_ray,
                  weights_out, t.loss_dev + level, t.d_rgb_logit, t.d_alpha);
+  if (want_sigma_gradient) sigma_gradient(t, r, level, W);
   // ---------------- backward ----------------
   const int RW = t.rgb_h[level].N;
   r.dense_bwd(t.rgb_out[level], {{t.rgb_hv, RW, RW, t.g0, RW, false}}, t.d_rgb_logit, 3, nullptr);
@@ -384,6 +447,17 @@ int nerfds_trainer_upload(nerfds_trainer* t, int which, const float* host) {
   return NERFDS_OK;
 }
 
+int nerfds_trainer_target_norm(nerfds_trainer* t, int level, int64_t num_rays, float* host) {
+  if (!t || !host || level < 0 || level > 1 || num_rays <= 0 || num_rays > t->max_rays) return NERFDS_EINVAL;
+  if (!t->tn_valid || !t->tws) return t->fail(NERFDS_EINVAL, "the last step did not run with NERFDS_TRAIN_SIGMA_GRAD");
+  if (level == 1 && t->cfg.num_fine_samples == 0) return t->fail(NERFDS_EINVAL, "no fine level");
+  const int64_t S = t->cfg.num_coarse_samples + (level ? t->cfg.num_fine_samples : 0);
+  (void)hipSetDevice(t->device);
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, t->tn[level], (size_t)num_rays * S * 3 * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return t->fail(NERFDS_EDEVICE, "download failed");
+  return NERFDS_OK;
+}
+
 int nerfds_trainer_reset_optimizer(nerfds_trainer* t) {
   if (!t) return NERFDS_EINVAL;
   (void)hipSetDevice(t->device);
@@ -430,11 +504,14 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   (void)hipMemsetAsync(t->loss_dev, 0, 2 * sizeof(float), st);
   const int strat = ex->use_stratified_sampling;
   coarse_z(st, R, Nc, ex->near, ex->far, strat, rnd ? rnd->t_rand : nullptr, t->zc);
-  int rc = run_level(*t, st, 0, R, Nc, t->zc, rays, target_rgb, ex, W, t->wc);
+  const bool want_sg = (flags & NERFDS_TRAIN_SIGMA_GRAD) != 0;
+  if (want_sg && !ensure_tangent_ws(*t)) return t->fail(NERFDS_ENOMEM, "hipMalloc of the tangent workspace failed");
+  t->tn_valid = want_sg;
+  int rc = run_level(*t, st, 0, R, Nc, t->zc, rays, target_rgb, ex, W, t->wc, want_sg);
   if (rc != NERFDS_OK) return rc;
   if (Nf > 0) {
     resample(st, R, Nc, Nf, t->zc, t->wc, strat, rnd ? rnd->u_rand : nullptr, t->zf, t->rs_scratch);
-    rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights);
+    rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights, want_sg);
     if (rc != NERFDS_OK) return rc;
   }
   if (!(flags & NERFDS_TRAIN_GRADS_ONLY)) adam_update(t, learning_rate, st);

@@ -34,6 +34,11 @@ void shared_in_bwd(hipStream_t, const Dims&, int R, int S, const float* d_warp_i
 void mask_in_bwd(hipStream_t, const Dims&, int R, int S, const float* d_mask_in, const uint32_t* warp_id, int n_embeds, float* d_mask_tbl);
 void sum_partials(hipStream_t, const float* part, int slabs, long long n, float* out);
 void fill(hipStream_t, float* p, long long n, float v);
+void encode_tangents(hipStream_t, const Dims&, long long M, const float* x, const Windows&, float* t_warp_in, float* t_hyper_in);
+void relu_mask3(hipStream_t, float* t, const float* y, long long M, int N);
+void se3_jvp(hipStream_t, long long M, const float* wv, const float* x, const float* t_wv, float* t_xw);
+void trunk_in_jvp(hipStream_t, const Dims&, long long M, const float* xw, const float* wamb, const float* t_xw, const float* t_wamb, const Windows&, float* t_tin);
+void target_norm(hipStream_t, long long M, const float* t_alpha, const float* wv, float* out);
 void adam(hipStream_t, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2);
 
 }  // namespace nerfds_train

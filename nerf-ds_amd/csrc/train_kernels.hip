@@ -249,6 +249,76 @@ __global__ void k_alpha_post(Dims D, int R, int S, const float* __restrict__ alp
   for (int g = 0; g < 6 * D.nm_bands; ++g) c[6 * D.vd_bands + g] = posenc_val<3>(g, nin, W.nm);
 }
 
+// ---- sigma gradient (models.py:1035-1077): forward-mode tangents of sigma_raw w.r.t. the observation-space
+// point, 3 directions per sample, tangent row 3 m + j <-> d / d x_j.  The mask is a constant input (cal_single_pt_sigma takes
+// it as an argument), the GLO columns have zero tangents.
+__global__ void k_encode_tangents(Dims D, long long M, const float* __restrict__ x, Windows W, float* __restrict__ t_warp_in,
+                                  float* __restrict__ t_hyper_in) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= 3 * M) return;
+  const long long m = i / 3;
+  const int j = (int)(i % 3);
+  const float p[3] = {x[3 * m], x[3 * m + 1], x[3 * m + 2]};
+  float* tw = t_warp_in + i * D.warp_in;
+  for (int g = 0; g < D.warp_in; ++g) tw[g] = (g < 6 * D.warp_bands && g % 3 == j) ? posenc_dval<3>(g, p, W.warp) : 0.f;
+  float* th = t_hyper_in + i * D.hyper_in;
+  for (int g = 0; g < D.hyper_in; ++g) th[g] = (g < 6 * D.hyp_bands && g % 3 == j) ? posenc_dval<3>(g, p, W.hyp) : 0.f;
+}
+// tangent through a ReLU: t[3 m + j][n] = 0 where y[m][n] <= 0
+__global__ void k_relu_mask3(float* __restrict__ t, const float* __restrict__ y, long long M, int N) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= 3 * M * N) return;
+  const long long row = i / N;
+  const int n = (int)(i % N);
+  if (!(y[(row / 3) * N + n] > 0.f)) t[i] = 0.f;
+}
+// d x' = R e_j + (d x' / d (w, v)) d(w, v)_j
+__global__ void k_se3_jvp(long long M, const float* __restrict__ wv, const float* __restrict__ x, const float* __restrict__ t_wv,
+                          float* __restrict__ t_xw) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  Dual w[3], v[3];
+  for (int i = 0; i < 3; ++i) { w[i] = dconst(wv[6 * m + i]); w[i].g[i] = 1.f; v[i] = dconst(wv[6 * m + 3 + i]); v[i].g[3 + i] = 1.f; }
+  Dual Rm[9], p[3];
+  se3_Rp<Dual>(w, v, Rm, p);
+  for (int r = 0; r < 3; ++r) {
+    const Dual xr = Rm[3 * r] * x[3 * m] + Rm[3 * r + 1] * x[3 * m + 1] + Rm[3 * r + 2] * x[3 * m + 2] + p[r];
+    for (int j = 0; j < 3; ++j) {
+      float acc = Rm[3 * r + j].v;
+      for (int i = 0; i < 6; ++i) acc += xr.g[i] * t_wv[(3 * m + j) * 6 + i];
+      t_xw[(3 * m + j) * 3 + r] = acc;
+    }
+  }
+}
+__global__ void k_trunk_in_jvp(Dims D, long long M, const float* __restrict__ xw, const float* __restrict__ wamb, const float* __restrict__ t_xw,
+                               const float* __restrict__ t_wamb, Windows W, float* __restrict__ t_tin) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= 3 * M) return;
+  const long long m = i / 3;
+  const float p[3] = {xw[3 * m], xw[3 * m + 1], xw[3 * m + 2]}, a[2] = {wamb[2 * m], wamb[2 * m + 1]};
+  float* t = t_tin + i * D.trunk_in;
+  for (int g = 0; g < 6 * D.sp_bands; ++g) t[g] = posenc_dval<3>(g, p, W.sp) * t_xw[3 * i + g % 3];
+  for (int g = 0; g < 4 * D.hp_bands; ++g) t[6 * D.sp_bands + g] = posenc_dval<2>(g, a, W.hp) * t_wamb[2 * i + g % 2];
+}
+// sigma_gradient = normalize(-grad) (models.py:1069, 1077); target_norm = normalize(R sigma_gradient) ('warped', models.py:1273-1277)
+__global__ void k_target_norm(long long M, const float* __restrict__ t_alpha, const float* __restrict__ wv, float* __restrict__ target_norm) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float g[3] = {-t_alpha[(3 * m) * 4], -t_alpha[(3 * m + 1) * 4], -t_alpha[(3 * m + 2) * 4]};
+  auto normalize = [](float (&v)[3]) {
+    const float inv = 1.0f / sqrtf(fmaxf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2], 1.1920929e-07f));
+    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+  };
+  normalize(g);
+  const float w[3] = {wv[6 * m], wv[6 * m + 1], wv[6 * m + 2]}, v[3] = {wv[6 * m + 3], wv[6 * m + 4], wv[6 * m + 5]};
+  float Rm[9], p[3];
+  se3_Rp<float>(w, v, Rm, p);
+  float r[3];
+  for (int c = 0; c < 3; ++c) r[c] = Rm[3 * c] * g[0] + Rm[3 * c + 1] * g[1] + Rm[3 * c + 2] * g[2];
+  normalize(r);
+  for (int c = 0; c < 3; ++c) target_norm[3 * m + c] = r[c];
+}
+
 // ---- compositing (model_utils.py:95-159), MSE loss (training.py:265-274) and the backward of both; one thread per ray ----
 __global__ void k_composite_loss(int R, int S, const float* __restrict__ z, const float* __restrict__ dirs, const float* __restrict__ sigma,
                                  const float* __restrict__ rgb_logit, const float* __restrict__ target, int at_infinity, int white,
@@ -459,6 +529,16 @@ void mask_in_bwd(hipStream_t st, const Dims& D, int R, int S, const float* d_mas
 }
 void sum_partials(hipStream_t st, const float* part, int slabs, long long n, float* out) { LAUNCH(k_sum_partials, n, st, part, slabs, n, out); }
 void fill(hipStream_t st, float* p, long long n, float v) { LAUNCH(k_fill, n, st, p, n, v); }
+void encode_tangents(hipStream_t st, const Dims& D, long long M, const float* x, const Windows& W, float* t_warp_in, float* t_hyper_in) {
+  LAUNCH(k_encode_tangents, 3 * M, st, D, M, x, W, t_warp_in, t_hyper_in);
+}
+void relu_mask3(hipStream_t st, float* t, const float* y, long long M, int N) { LAUNCH(k_relu_mask3, 3 * M * N, st, t, y, M, N); }
+void se3_jvp(hipStream_t st, long long M, const float* wv, const float* x, const float* t_wv, float* t_xw) { LAUNCH(k_se3_jvp, M, st, M, wv, x, t_wv, t_xw); }
+void trunk_in_jvp(hipStream_t st, const Dims& D, long long M, const float* xw, const float* wamb, const float* t_xw, const float* t_wamb,
+                  const Windows& W, float* t_tin) {
+  LAUNCH(k_trunk_in_jvp, 3 * M, st, D, M, xw, wamb, t_xw, t_wamb, W, t_tin);
+}
+void target_norm(hipStream_t st, long long M, const float* t_alpha, const float* wv, float* out) { LAUNCH(k_target_norm, M, st, M, t_alpha, wv, out); }
 void adam(hipStream_t st, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2) {
   LAUNCH(k_adam, n, st, p, g, m1, m2, n, lr, b1, b2, eps, c1, c2);
 }

@@ -14,6 +14,7 @@ from .config import NerfModelConfig
 from .model import _cfg_struct
 
 GRADS_ONLY = 1
+SIGMA_GRAD = 2
 
 
 class _DevVec:
@@ -51,6 +52,7 @@ def _bind(lib):
   lib.nerfds_trainer_step.argtypes = [C.c_void_p, C.POINTER(N.Rays), C.c_void_p, C.POINTER(N.Extra), C.POINTER(N.Rand), C.c_float, C.c_uint32,
                                       C.POINTER(C.c_float), C.c_void_p]
   lib.nerfds_trainer_apply.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+  lib.nerfds_trainer_target_norm.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
   lib.nerfds_trainer_last_error.argtypes = [C.c_void_p]
   lib.nerfds_trainer_last_error.restype = C.c_char_p
   lib._trainer_bound = True
@@ -140,6 +142,16 @@ class Trainer:
     if rc != 0:
       raise RuntimeError(f'nerfds_trainer_apply failed ({rc})')
 
+  def target_norm(self, level: str = 'fine') -> np.ndarray:
+    """out[level]['target_norm'] (models.py:1328) of the last step run with sigma_gradient=True: [R, S, 3]."""
+    lv = 1 if level == 'fine' else 0
+    S = self.cfg.num_coarse_samples + (self.cfg.num_fine_samples if lv else 0)
+    out = np.empty((self._last_rays, S, 3), np.float32)
+    rc = self._lib.nerfds_trainer_target_norm(self._h, lv, self._last_rays, out.ctypes.data)
+    if rc != 0:
+      raise RuntimeError(f'nerfds_trainer_target_norm failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
+    return out
+
   def get_params(self) -> Dict[str, Any]:
     return self._tree(self._download(0))
 
@@ -149,6 +161,7 @@ class Trainer:
   # -- one step ------------------------------------------------------------------------------------------
   def step(self, batch: Dict[str, Any], extra_params: Dict[str, Any], learning_rate: float = 0.0, *, t_rand=None, u_rand=None,
            mask_ratio: float = 1.0, near: Optional[float] = None, far: Optional[float] = None, grads_only: bool = False,
+           sigma_gradient: bool = False,
            stream: Optional[torch.cuda.Stream] = None) -> Dict[str, float]:
     dev = self.device
     f32 = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).to(dev, torch.float32).contiguous()
@@ -177,7 +190,9 @@ class Trainer:
     import torch.distributed as dist
     data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rc = self._lib.nerfds_trainer_step(self._h, C.byref(rays), target.data_ptr(), C.byref(ex), C.byref(rnd), float(learning_rate),
-                                       GRADS_ONLY if (grads_only or data_parallel) else 0, loss, C.c_void_p(s.cuda_stream))
+                                       (GRADS_ONLY if (grads_only or data_parallel) else 0) | (SIGMA_GRAD if sigma_gradient else 0), loss,
+                                       C.c_void_p(s.cuda_stream))
+    self._last_rays = R
     if rc != 0:
       raise RuntimeError(f'nerfds_trainer_step failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
     if data_parallel:       # one rank per GPU, each with its own rays: ONE all-reduce of the 6 MB gradient vector (training.py:502)
