@@ -66,7 +66,8 @@ struct nerfds_trainer {
   // workspace views (set by carve())
   float *zc, *zf, *wc, *rs_scratch, *x, *mask_in, *mask_logit, *warp_in, *wv, *xw, *hyper_in, *wamb, *trunk_in, *bottv, *alphav, *sigma,
       *cond, *rgb_hv, *rgb_logit, *weights, *rgb_ray, *g0, *g1, *g2, *d_trunk_in, *d_rgb_logit, *d_alpha, *dxw, *dwamb, *dwv, *d_warp_in,
-      *d_hyper_in, *d_mask_in, *d_mask_logit;
+      *d_hyper_in, *d_mask_in, *d_mask_logit, *dxw_reg, *d_pm;
+  float* terms_dev = nullptr;   // [2 levels][4]: weighted warp_reg, back_facing, mask terms of the last step
   std::vector<float*> mask_h, warp_h, hyper_h, trunk_h;
 
   int fail(int code, const char* fmt, ...) {
@@ -79,7 +80,7 @@ struct nerfds_trainer {
     return code;
   }
   ~nerfds_trainer() {
-    for (float* p : {theta, grad, m1, m2, ws, loss_dev, part, tws}) if (p) (void)hipFree(p);
+    for (float* p : {theta, grad, m1, m2, ws, loss_dev, part, tws, terms_dev}) if (p) (void)hipFree(p);
     if (blas) (void)rocblas_destroy_handle(blas);
   }
 };
@@ -235,7 +236,7 @@ void carve(nerfds_trainer& t) {
   take(&t.g0, M * t.trunk[0].width); take(&t.g1, M * t.trunk[0].width); take(&t.g2, M * t.trunk[0].width);
   take(&t.d_trunk_in, M * D.trunk_in); take(&t.d_rgb_logit, M * 3); take(&t.d_alpha, M * 4); take(&t.dxw, M * 3); take(&t.dwamb, M * 2);
   take(&t.dwv, M * 6); take(&t.d_warp_in, M * D.warp_in); take(&t.d_hyper_in, M * D.hyper_in); take(&t.d_mask_in, M * D.mask_in);
-  take(&t.d_mask_logit, M);
+  take(&t.d_mask_logit, M); take(&t.dxw_reg, M * 3); take(&t.d_pm, M);
   t.ws_floats = need;
   // (pointers into vectors: the vectors are not resized after this point)
   float* base = t.ws;
@@ -282,7 +283,7 @@ void sigma_gradient(nerfds_trainer& t, Run& r, int level, const Windows& W) {
 }
 
 int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const float* z, const nerfds_rays* rays, const float* target,
-              const nerfds_extra* ex, const Windows& W, float* weights_out, bool want_sigma_gradient) {
+              const nerfds_extra* ex, const Windows& W, float* weights_out, bool want_sigma_gradient, const Objective* ob) {
   const Dims& D = t.D;
   Run r{t, st, (int64_t)R * S};
   const int64_t M = r.M;
@@ -314,6 +315,9 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   composite_loss(st, R, S, z, rays->directions, t.sigma, t.rgb_logit, target, t.cfg.use_sample_at_infinity, t.cfg.use_white_background, t.rgb_ray,
                  weights_out, t.loss_dev + level, t.d_rgb_logit, t.d_alpha);
   if (want_sigma_gradient) sigma_gradient(t, r, level, W);
+  if (ob)     // auxiliary first-order losses: extra upstream gradients for x', the raw normal and the predicted mask
+    aux_losses(st, R, S, *ob, z, weights_out, t.x, t.xw, t.alphav, viewdirs, t.mask_logit, rays->gt_mask, t.terms_dev + 4 * level, t.dxw_reg,
+               t.d_alpha, t.d_pm);
   // ---------------- backward ----------------
   const int RW = t.rgb_h[level].N;
   r.dense_bwd(t.rgb_out[level], {{t.rgb_hv, RW, RW, t.g0, RW, false}}, t.d_rgb_logit, 3, nullptr);
@@ -322,14 +326,14 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   r.dense_bwd(t.bott[level], {{tout, TW, TW, t.g2, TW, true}}, t.g1, TW, nullptr);
   r.dense_bwd(t.alpha[level], {{tout, TW, TW, t.g2, TW, true}}, t.d_alpha, 4, nullptr);
   r.mlp_bwd(trunk, t.trunk_in, t.trunk_h, t.g2, t.g0, t.d_trunk_in);
-  trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, t.dxw, t.dwamb);
+  trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, t.dxw, t.dwamb);
   r.dense_bwd(t.hyper_out, {{t.hyper_h.back(), t.hyper.width, t.hyper.width, t.g0, t.hyper.width, false}}, t.dwamb, 2, nullptr);
   r.mlp_bwd(t.hyper, t.hyper_in, t.hyper_h, t.g0, t.g1, t.d_hyper_in);
   se3_bwd(st, M, t.wv, t.x, t.dxw, t.dwv);
   r.dense_bwd(t.warp_w, {{t.warp_h.back(), t.warp.width, t.warp.width, t.g0, t.warp.width, false}}, t.dwv, 6, nullptr);
   r.dense_bwd(t.warp_v, {{t.warp_h.back(), t.warp.width, t.warp.width, t.g0, t.warp.width, true}}, t.dwv + 3, 6, nullptr);
   r.mlp_bwd(t.warp, t.warp_in, t.warp_h, t.g0, t.g1, t.d_warp_in);
-  shared_in_bwd(st, D, R, S, t.d_warp_in, t.d_hyper_in, t.mask_logit, ex->mask_ratio, rays->warp_id, t.cfg.num_warp_embeds,
+  shared_in_bwd(st, D, R, S, t.d_warp_in, t.d_hyper_in, t.mask_logit, ex->mask_ratio, ob ? t.d_pm : nullptr, rays->warp_id, t.cfg.num_warp_embeds,
                 t.grad + t.warp_tbl, t.d_mask_logit);
   r.dense_bwd(t.mask_out, {{t.mask_h.back(), t.mask.width, t.mask.width, t.g0, t.mask.width, false}}, t.d_mask_logit, 1, nullptr);
   r.mlp_bwd(t.mask, t.mask_in, t.mask_h, t.g0, t.g1, t.d_mask_in);
@@ -388,7 +392,7 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
   carve(*t);      // sizes only
   const size_t pbytes = (size_t)t->P * sizeof(float);
   if (hipMalloc(&t->theta, pbytes) != hipSuccess || hipMalloc(&t->grad, pbytes) != hipSuccess || hipMalloc(&t->m1, pbytes) != hipSuccess ||
-      hipMalloc(&t->m2, pbytes) != hipSuccess || hipMalloc(&t->loss_dev, 2 * sizeof(float)) != hipSuccess ||
+      hipMalloc(&t->m2, pbytes) != hipSuccess || hipMalloc(&t->loss_dev, 2 * sizeof(float)) != hipSuccess || hipMalloc(&t->terms_dev, 8 * sizeof(float)) != hipSuccess ||
       hipMalloc(&t->ws, t->ws_floats * sizeof(float)) != hipSuccess) {
     g_train_error = "hipMalloc failed (workspace of " + std::to_string(t->ws_floats * 4 >> 20) + " MiB)";
     return NERFDS_ENOMEM;
@@ -484,7 +488,7 @@ int nerfds_trainer_apply(nerfds_trainer* t, float learning_rate, void* hip_strea
 }
 
 int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* ex, const nerfds_rand* rnd,
-                        float learning_rate, uint32_t flags, float* loss_host, void* hip_stream) {
+                        const nerfds_train_objective* objective, float learning_rate, uint32_t flags, float* loss_host, void* hip_stream) {
   if (!t) return NERFDS_EINVAL;
   if (!rays || !target_rgb || !ex || !rays->origins || !rays->directions || !rays->warp_id) return t->fail(NERFDS_EINVAL, "null argument");
   if (rays->num_rays <= 0 || rays->num_rays > t->max_rays) return t->fail(NERFDS_EINVAL, "num_rays must be in [1, max_rays = %lld]", (long long)t->max_rays);
@@ -504,14 +508,27 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   (void)hipMemsetAsync(t->loss_dev, 0, 2 * sizeof(float), st);
   const int strat = ex->use_stratified_sampling;
   coarse_z(st, R, Nc, ex->near, ex->far, strat, rnd ? rnd->t_rand : nullptr, t->zc);
+  Objective ob{};
+  const Objective* obp = nullptr;
+  if (objective) {
+    if (objective->norm_loss_weight != 0.f)
+      return t->fail(NERFDS_ENOTSUP, "the norm loss (training.py:323-332) differentiates through target_norm and is not built yet");
+    ob.warp_reg_weight = objective->warp_reg_loss_weight; ob.warp_reg_alpha = objective->warp_reg_loss_alpha; ob.warp_reg_scale = objective->warp_reg_loss_scale;
+    ob.back_facing_weight = objective->back_facing_reg_weight; ob.mask_loss_weight = objective->predicted_mask_loss_weight;
+    ob.sharp_weights_std = objective->sharp_weights_std; ob.use_sharp_weights = objective->use_mask_sharp_weights;
+    if (ob.mask_loss_weight != 0.f && !rays->gt_mask) return t->fail(NERFDS_EINVAL, "the mask loss needs rays_dict['mask']");
+    if (ob.use_sharp_weights && !(ob.sharp_weights_std > 0.f)) return t->fail(NERFDS_EINVAL, "sharp_weights_std must be > 0");
+    obp = &ob;
+  }
+  (void)hipMemsetAsync(t->terms_dev, 0, 8 * sizeof(float), st);
   const bool want_sg = (flags & NERFDS_TRAIN_SIGMA_GRAD) != 0;
   if (want_sg && !ensure_tangent_ws(*t)) return t->fail(NERFDS_ENOMEM, "hipMalloc of the tangent workspace failed");
   t->tn_valid = want_sg;
-  int rc = run_level(*t, st, 0, R, Nc, t->zc, rays, target_rgb, ex, W, t->wc, want_sg);
+  int rc = run_level(*t, st, 0, R, Nc, t->zc, rays, target_rgb, ex, W, t->wc, want_sg, obp);
   if (rc != NERFDS_OK) return rc;
   if (Nf > 0) {
     resample(st, R, Nc, Nf, t->zc, t->wc, strat, rnd ? rnd->u_rand : nullptr, t->zf, t->rs_scratch);
-    rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights, want_sg);
+    rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights, want_sg, obp);
     if (rc != NERFDS_OK) return rc;
   }
   if (!(flags & NERFDS_TRAIN_GRADS_ONLY)) adam_update(t, learning_rate, st);
@@ -521,8 +538,12 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     float l[2];
     if (hipMemcpyAsync(l, t->loss_dev, sizeof l, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       return t->fail(NERFDS_EDEVICE, "loss read-back failed");
-    loss_host[0] = Nf > 0 ? l[1] : l[0];     // fine (the level render_image returns), coarse
+    float tm[8];
+    if (hipMemcpy(tm, t->terms_dev, sizeof tm, hipMemcpyDeviceToHost) != hipSuccess) return t->fail(NERFDS_EDEVICE, "loss read-back failed");
+    const int fl = Nf > 0 ? 1 : 0;
+    loss_host[0] = l[fl];     // rgb loss of the fine level (the level render_image returns; coarse if there is none), of the coarse level
     loss_host[1] = l[0];
+    for (int k = 0; k < 3; ++k) { loss_host[2 + k] = tm[4 * fl + k]; loss_host[5 + k] = tm[k]; }   // weighted warp_reg / back_facing / mask terms: fine, coarse
   }
   return NERFDS_OK;
 }

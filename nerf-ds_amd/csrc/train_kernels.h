@@ -13,6 +13,11 @@ struct Windows {   // posenc windows (model_utils.py:420-436), one weight per ba
   float mask[8], warp[8], hyp[8], sp[8], hp[8], nm[8];
 };
 
+struct Objective {   // weights of the auxiliary losses (0 = off); mirrors nerfds_train_objective
+  float warp_reg_weight, warp_reg_alpha, warp_reg_scale, back_facing_weight, mask_loss_weight, sharp_weights_std;
+  int use_sharp_weights;
+};
+
 void coarse_z(hipStream_t, int R, int Nc, float near_, float far_, int stratified, const float* t_rand, float* z);
 void resample(hipStream_t, int R, int Nc, int Nf, const float* zc, const float* wc, int stratified, const float* u_rand, float* zf, float* scratch);
 void encode_inputs(hipStream_t, const Dims&, int R, int S, const float* o, const float* d, const float* z, const uint32_t* warp_id, int n_embeds,
@@ -22,7 +27,10 @@ void mask_post(hipStream_t, const Dims&, int R, int S, const float* logit, const
 void se3_fwd(hipStream_t, long long M, const float* wv, const float* x, float* xw);
 void se3_bwd(hipStream_t, long long M, const float* wv, const float* x, const float* dxw, float* dwv);
 void trunk_in(hipStream_t, const Dims&, long long M, const float* xw, const float* wamb, const Windows&, float* tin);
-void trunk_in_bwd(hipStream_t, const Dims&, long long M, const float* dtin, const float* xw, const float* wamb, const Windows&, float* dxw, float* dwamb);
+void trunk_in_bwd(hipStream_t, const Dims&, long long M, const float* dtin, const float* xw, const float* wamb, const Windows&, const float* dxw_extra,
+                  float* dxw, float* dwamb);
+void aux_losses(hipStream_t, int R, int S, const Objective&, const float* z, const float* weights, const float* x, const float* xw, const float* alpha,
+                const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg, float* d_alpha, float* d_pm);
 void alpha_post(hipStream_t, const Dims&, int R, int S, const float* alpha, const float* wv, const float* viewdirs, const Windows&, float* sigma, float* cond);
 void composite_loss(hipStream_t, int R, int S, const float* z, const float* dirs, const float* sigma, const float* rgb_logit, const float* target,
                     int at_infinity, int white, float* rgb_ray, float* weights, float* loss, float* d_rgb_logit, float* d_alpha);
@@ -30,7 +38,7 @@ void relu_bwd(hipStream_t, float* dy, const float* y, long long n);
 void relu_bwd_colsum(hipStream_t, float* dy, const float* y, long long M, int N, float* db);
 void colsum_add(hipStream_t, const float* dz, long long M, int N, int ld, float* db);
 void shared_in_bwd(hipStream_t, const Dims&, int R, int S, const float* d_warp_in, const float* d_hyper_in, const float* mask_logit, float ratio,
-                   const uint32_t* warp_id, int n_embeds, float* d_warp_tbl, float* d_mask_logit);
+                   const float* d_pm_extra, const uint32_t* warp_id, int n_embeds, float* d_warp_tbl, float* d_mask_logit);
 void mask_in_bwd(hipStream_t, const Dims&, int R, int S, const float* d_mask_in, const uint32_t* warp_id, int n_embeds, float* d_mask_tbl);
 void sum_partials(hipStream_t, const float* part, int slabs, long long n, float* out);
 void fill(hipStream_t, float* p, long long n, float v);

@@ -205,7 +205,7 @@ __global__ void k_trunk_in(Dims D, long long M, const float* __restrict__ xw, co
   for (int g = 0; g < 4 * D.hp_bands; ++g) t[6 * D.sp_bands + g] = posenc_val<2>(g, a, W.hp);
 }
 __global__ void k_trunk_in_bwd(Dims D, long long M, const float* __restrict__ dtin, const float* __restrict__ xw, const float* __restrict__ wamb,
-                               Windows W, float* __restrict__ dxw, float* __restrict__ dwamb) {
+                               Windows W, const float* __restrict__ dxw_extra, float* __restrict__ dxw, float* __restrict__ dwamb) {
   const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (m >= M) return;
   const float p[3] = {xw[3 * m], xw[3 * m + 1], xw[3 * m + 2]}, a[2] = {wamb[2 * m], wamb[2 * m + 1]};
@@ -213,7 +213,7 @@ __global__ void k_trunk_in_bwd(Dims D, long long M, const float* __restrict__ dt
   for (int c = 0; c < 3; ++c) {
     float acc = 0.f;
     for (int bs = 0; bs < 2 * D.sp_bands; ++bs) acc += t[3 * bs + c] * posenc_dval<3>(3 * bs + c, p, W.sp);
-    dxw[3 * m + c] = acc;
+    dxw[3 * m + c] = acc + (dxw_extra ? dxw_extra[3 * m + c] : 0.f);
   }
   for (int c = 0; c < 2; ++c) {
     float acc = 0.f;
@@ -375,6 +375,100 @@ __global__ void k_composite_loss(int R, int S, const float* __restrict__ z, cons
   }
 }
 
+// ---- the first-order auxiliary losses of the reference objective (training.py:297-310, 334-339, 386-408), per level, one
+// thread per ray; all of them read the compositing weights as constants (lax.stop_gradient(model_out['weights'])):
+//   warp_reg   : general_loss_with_squared_residual(|x - x'|^2 at the median-depth sample, alpha, scale).mean()   (utils.py:208-263)
+//   back_facing: mean(w * relu(n . viewdir)^2)                                                (models.py:1340-1343)
+//   3-D mask   : mean((gt_mask - sum_s sw_s * predicted_mask_s)^2), sw = sharpen_weights(w, z, std) (incl. its row-gather
+//                quirk, model_utils.py:180-190) or w
+// Outputs: the weighted loss terms (atomicAdd into terms[0..2]) and their gradients w.r.t. x' (dxw_reg, dense, zero except the
+// median sample), the raw normal (added into d_alpha[:, 1:4]) and the predicted mask (d_pm).
+__device__ __forceinline__ float general_loss_sq(float x_sq, float alpha, float scale, float& dloss) {
+  const float eps = 1.1920929e-07f;
+  scale = fmaxf(eps, scale);
+  const float inv_s2 = 1.0f / (scale * scale);
+  const float loss_two = 0.5f * x_sq * inv_s2;
+  if (alpha == 2.0f) { dloss = scale * 0.5f * inv_s2; return scale * loss_two; }
+  if (alpha == 0.0f) { const float c = fminf(loss_two, 3e37f); dloss = scale * 0.5f * inv_s2 / (1.0f + c); return scale * log1pf(c); }
+  const float a = (alpha >= 0.f ? 1.f : -1.f) * fmaxf(eps, fabsf(alpha));
+  const float b = fmaxf(eps, fabsf(alpha - 2.0f));
+  const float base = loss_two / (0.5f * b) + 1.0f;
+  const float pw = powf(base, 0.5f * alpha);
+  dloss = scale * (b / a) * (0.5f * alpha) * (pw / base) * (1.0f / (0.5f * b)) * 0.5f * inv_s2;
+  return scale * (b / a) * (pw - 1.0f);
+}
+__global__ void k_aux_losses(int R, int S, Objective ob, const float* __restrict__ z, const float* __restrict__ weights, const float* __restrict__ x,
+                             const float* __restrict__ xw, const float* __restrict__ alpha, const float* __restrict__ viewdirs,
+                             const float* __restrict__ mask_logit, const float* __restrict__ gt_mask, float* __restrict__ terms,
+                             float* __restrict__ dxw_reg, float* __restrict__ d_alpha, float* __restrict__ d_pm) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* w = weights + (size_t)r * S;
+  // median-depth index (model_utils.py:272-299): first s with cumsum(w) >= 0.5, else 0; arg-max of the weights
+  int med = 0, amax = 0;
+  {
+    float cum = 0.f, best = w[0];
+    bool found = false;
+    for (int s = 0; s < S; ++s) {
+      cum += w[s];
+      if (!found && cum >= 0.5f) { med = s; found = true; }
+      if (w[s] > best) { best = w[s]; amax = s; }
+    }
+  }
+  // warp regularisation
+  for (int s = 0; s < S; ++s) { const size_t m = (size_t)r * S + s; dxw_reg[3 * m] = 0.f; dxw_reg[3 * m + 1] = 0.f; dxw_reg[3 * m + 2] = 0.f; }
+  if (ob.warp_reg_weight != 0.f) {
+    const size_t m = (size_t)r * S + med;
+    float dvec[3], sq = 0.f;
+    for (int c = 0; c < 3; ++c) { dvec[c] = x[3 * m + c] - xw[3 * m + c]; sq += dvec[c] * dvec[c]; }
+    float dl;
+    const float l = general_loss_sq(sq, ob.warp_reg_alpha, ob.warp_reg_scale, dl);
+    atomicAdd(terms + 0, ob.warp_reg_weight * l / (float)R);
+    for (int c = 0; c < 3; ++c) dxw_reg[3 * m + c] = ob.warp_reg_weight / (float)R * dl * (-2.0f * dvec[c]);
+  }
+  // back-facing regulariser on the RAW predicted normal
+  if (ob.back_facing_weight != 0.f) {
+    const float v[3] = {viewdirs[3 * r], viewdirs[3 * r + 1], viewdirs[3 * r + 2]};
+    const float k = ob.back_facing_weight / ((float)R * (float)S);
+    float l = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const size_t m = (size_t)r * S + s;
+      const float d = fmaxf(alpha[4 * m + 1] * v[0] + alpha[4 * m + 2] * v[1] + alpha[4 * m + 3] * v[2], 0.f);
+      l += w[s] * d * d;
+      for (int c = 0; c < 3; ++c) d_alpha[4 * m + 1 + c] += k * w[s] * 2.0f * d * v[c];
+    }
+    atomicAdd(terms + 1, k * l);
+  }
+  // 3-D mask supervision
+  for (int s = 0; s < S; ++s) d_pm[(size_t)r * S + s] = 0.f;
+  if (ob.mask_loss_weight != 0.f && gt_mask != nullptr) {
+    const float* zr = z + (size_t)r * S;
+    float rpm = 0.f, norm = 1.f;
+    if (ob.use_sharp_weights) {
+      const int row = amax < R ? amax : R - 1;                    // z_vals[max_weights_idx]: a ROW gather (model_utils.py:182), jnp clamps
+      const float* zq = z + (size_t)row * S;
+      const float inv = 1.0f / ob.sharp_weights_std, c0 = inv * 0.3989422804f;
+      norm = 0.f;
+      for (int s = 0; s < S; ++s) { const float t = (zr[s] - zq[s]) * inv; norm += w[s] * expf(-0.5f * t * t) * c0; }
+      for (int s = 0; s < S; ++s) {
+        const float t = (zr[s] - zq[s]) * inv;
+        rpm += w[s] * expf(-0.5f * t * t) * c0 / norm * fmaxf(mask_logit[(size_t)r * S + s], 0.f);
+      }
+      const float e = rpm - gt_mask[r];
+      atomicAdd(terms + 2, ob.mask_loss_weight * e * e / (float)R);
+      for (int s = 0; s < S; ++s) {
+        const float t = (zr[s] - zq[s]) * inv;
+        d_pm[(size_t)r * S + s] = ob.mask_loss_weight * 2.0f * e / (float)R * (w[s] * expf(-0.5f * t * t) * c0 / norm);
+      }
+    } else {
+      for (int s = 0; s < S; ++s) rpm += w[s] * fmaxf(mask_logit[(size_t)r * S + s], 0.f);
+      const float e = rpm - gt_mask[r];
+      atomicAdd(terms + 2, ob.mask_loss_weight * e * e / (float)R);
+      for (int s = 0; s < S; ++s) d_pm[(size_t)r * S + s] = ob.mask_loss_weight * 2.0f * e / (float)R * w[s];
+    }
+  }
+}
+
 __global__ void k_relu_bwd(float* __restrict__ dy, const float* __restrict__ y, long long n) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i < n && !(y[i] > 0.f)) dy[i] = 0.f;
@@ -425,8 +519,8 @@ __global__ void k_relu_bwd_colsum(float* __restrict__ dy, const float* __restric
 
 // gradient of the shared-net inputs: the mask column (models.py:729-732) -> mask head, the GLO columns -> embedding rows
 __global__ void k_shared_in_bwd(Dims D, int R, int S, const float* __restrict__ d_warp_in, const float* __restrict__ d_hyper_in,
-                                const float* __restrict__ mask_logit, float ratio, const uint32_t* __restrict__ warp_id, int n_embeds,
-                                float* __restrict__ d_warp_tbl, float* __restrict__ d_mask_logit) {
+                                const float* __restrict__ mask_logit, float ratio, const float* __restrict__ d_pm_extra,
+                                const uint32_t* __restrict__ warp_id, int n_embeds, float* __restrict__ d_warp_tbl, float* __restrict__ d_mask_logit) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   uint32_t id = warp_id ? warp_id[r] : 0u;
@@ -438,7 +532,7 @@ __global__ void k_shared_in_bwd(Dims D, int R, int S, const float* __restrict__ 
     const float* dh = d_hyper_in + m * D.hyper_in;
     for (int g = 0; g < 8; ++g) e[g] += dw[6 * D.warp_bands + g] + dh[6 * D.hyp_bands + g];
     const float dmask = dw[D.warp_in - 1] + dh[D.hyper_in - 1];
-    d_mask_logit[m] = (mask_logit[m] > 0.f) ? dmask * ratio : 0.f;
+    d_mask_logit[m] = (mask_logit[m] > 0.f) ? dmask * ratio + (d_pm_extra ? d_pm_extra[m] : 0.f) : 0.f;
   }
   for (int g = 0; g < 8; ++g) atomicAdd(d_warp_tbl + id * 8 + g, e[g]);
 }
@@ -502,8 +596,15 @@ void se3_bwd(hipStream_t st, long long M, const float* wv, const float* x, const
 void trunk_in(hipStream_t st, const Dims& D, long long M, const float* xw, const float* wamb, const Windows& W, float* tin) {
   LAUNCH(k_trunk_in, M, st, D, M, xw, wamb, W, tin);
 }
-void trunk_in_bwd(hipStream_t st, const Dims& D, long long M, const float* dtin, const float* xw, const float* wamb, const Windows& W, float* dxw, float* dwamb) {
-  LAUNCH(k_trunk_in_bwd, M, st, D, M, dtin, xw, wamb, W, dxw, dwamb);
+void trunk_in_bwd(hipStream_t st, const Dims& D, long long M, const float* dtin, const float* xw, const float* wamb, const Windows& W,
+                  const float* dxw_extra, float* dxw, float* dwamb) {
+  LAUNCH(k_trunk_in_bwd, M, st, D, M, dtin, xw, wamb, W, dxw_extra, dxw, dwamb);
+}
+void aux_losses(hipStream_t st, int R, int S, const Objective& ob, const float* z, const float* weights, const float* x, const float* xw,
+                const float* alpha, const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg,
+                float* d_alpha, float* d_pm) {
+  hipLaunchKernelGGL(k_aux_losses, grid1(R, 64), dim3(64), 0, st, R, S, ob, z, weights, x, xw, alpha, viewdirs, mask_logit, gt_mask, terms, dxw_reg,
+                     d_alpha, d_pm);
 }
 void alpha_post(hipStream_t st, const Dims& D, int R, int S, const float* alpha, const float* wv, const float* viewdirs, const Windows& W, float* sigma, float* cond) {
   LAUNCH(k_alpha_post, (long long)R * S, st, D, R, S, alpha, wv, viewdirs, W, sigma, cond);
@@ -521,8 +622,9 @@ void relu_bwd_colsum(hipStream_t st, float* dy, const float* y, long long M, int
   hipLaunchKernelGGL(k_relu_bwd_colsum, dim3((unsigned)((M + 127) / 128)), dim3(256), 0, st, dy, y, M, N, db);
 }
 void shared_in_bwd(hipStream_t st, const Dims& D, int R, int S, const float* d_warp_in, const float* d_hyper_in, const float* mask_logit, float ratio,
-                   const uint32_t* warp_id, int n_embeds, float* d_warp_tbl, float* d_mask_logit) {
-  hipLaunchKernelGGL(k_shared_in_bwd, grid1(R, 64), dim3(64), 0, st, D, R, S, d_warp_in, d_hyper_in, mask_logit, ratio, warp_id, n_embeds, d_warp_tbl, d_mask_logit);
+                   const float* d_pm_extra, const uint32_t* warp_id, int n_embeds, float* d_warp_tbl, float* d_mask_logit) {
+  hipLaunchKernelGGL(k_shared_in_bwd, grid1(R, 64), dim3(64), 0, st, D, R, S, d_warp_in, d_hyper_in, mask_logit, ratio, d_pm_extra, warp_id, n_embeds,
+                     d_warp_tbl, d_mask_logit);
 }
 void mask_in_bwd(hipStream_t st, const Dims& D, int R, int S, const float* d_mask_in, const uint32_t* warp_id, int n_embeds, float* d_mask_tbl) {
   hipLaunchKernelGGL(k_mask_in_bwd, grid1(R, 64), dim3(64), 0, st, D, R, S, d_mask_in, warp_id, n_embeds, d_mask_tbl);

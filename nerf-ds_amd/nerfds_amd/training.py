@@ -17,6 +17,12 @@ GRADS_ONLY = 1
 SIGMA_GRAD = 2
 
 
+class Objective(C.Structure):
+  _fields_ = [('warp_reg_loss_weight', C.c_float), ('warp_reg_loss_alpha', C.c_float), ('warp_reg_loss_scale', C.c_float),
+              ('back_facing_reg_weight', C.c_float), ('predicted_mask_loss_weight', C.c_float), ('sharp_weights_std', C.c_float),
+              ('use_mask_sharp_weights', C.c_int32), ('norm_loss_weight', C.c_float)]
+
+
 class _DevVec:
   """Zero-copy torch view of a library-owned fp32 device vector (through __cuda_array_interface__)."""
 
@@ -49,8 +55,8 @@ def _bind(lib):
   lib.nerfds_trainer_reset_optimizer.argtypes = [C.c_void_p]
   lib.nerfds_trainer_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
   lib.nerfds_trainer_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-  lib.nerfds_trainer_step.argtypes = [C.c_void_p, C.POINTER(N.Rays), C.c_void_p, C.POINTER(N.Extra), C.POINTER(N.Rand), C.c_float, C.c_uint32,
-                                      C.POINTER(C.c_float), C.c_void_p]
+  lib.nerfds_trainer_step.argtypes = [C.c_void_p, C.POINTER(N.Rays), C.c_void_p, C.POINTER(N.Extra), C.POINTER(N.Rand), C.POINTER(Objective),
+                                      C.c_float, C.c_uint32, C.POINTER(C.c_float), C.c_void_p]
   lib.nerfds_trainer_apply.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
   lib.nerfds_trainer_target_norm.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
   lib.nerfds_trainer_last_error.argtypes = [C.c_void_p]
@@ -161,7 +167,7 @@ class Trainer:
   # -- one step ------------------------------------------------------------------------------------------
   def step(self, batch: Dict[str, Any], extra_params: Dict[str, Any], learning_rate: float = 0.0, *, t_rand=None, u_rand=None,
            mask_ratio: float = 1.0, near: Optional[float] = None, far: Optional[float] = None, grads_only: bool = False,
-           sigma_gradient: bool = False,
+           sigma_gradient: bool = False, objective: Optional[Dict[str, float]] = None,
            stream: Optional[torch.cuda.Stream] = None) -> Dict[str, float]:
     dev = self.device
     f32 = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).to(dev, torch.float32).contiguous()
@@ -185,11 +191,18 @@ class Trainer:
       t = f32(t_rand).reshape(R, self.cfg.num_coarse_samples); keep.append(t); rnd.t_rand = t.data_ptr()
     if u_rand is not None and self.cfg.num_fine_samples > 0:
       u = f32(u_rand).reshape(R, self.cfg.num_fine_samples); keep.append(u); rnd.u_rand = u.data_ptr()
-    loss = (C.c_float * 2)()
+    loss = (C.c_float * 8)()
+    ob = None
+    if objective:       # scalar_params / SpecularConfig names (training.py:36-56)
+      ob = Objective(warp_reg_loss_weight=objective.get('warp_reg_loss_weight', 0.0), warp_reg_loss_alpha=objective.get('warp_reg_loss_alpha', -2.0),
+                     warp_reg_loss_scale=objective.get('warp_reg_loss_scale', 0.001), back_facing_reg_weight=objective.get('back_facing_reg_weight', 0.0),
+                     predicted_mask_loss_weight=objective.get('predicted_mask_loss_weight', 0.0), sharp_weights_std=objective.get('sharp_weights_std', 1.0),
+                     use_mask_sharp_weights=int(self.cfg.use_mask_sharp_weights), norm_loss_weight=objective.get('norm_loss_weight', 0.0))
     s = stream if stream is not None else torch.cuda.current_stream(dev)
     import torch.distributed as dist
     data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    rc = self._lib.nerfds_trainer_step(self._h, C.byref(rays), target.data_ptr(), C.byref(ex), C.byref(rnd), float(learning_rate),
+    rc = self._lib.nerfds_trainer_step(self._h, C.byref(rays), target.data_ptr(), C.byref(ex), C.byref(rnd), C.byref(ob) if ob is not None else None,
+                                       float(learning_rate),
                                        (GRADS_ONLY if (grads_only or data_parallel) else 0) | (SIGMA_GRAD if sigma_gradient else 0), loss,
                                        C.c_void_p(s.cuda_stream))
     self._last_rays = R
@@ -202,8 +215,14 @@ class Trainer:
         self.apply_gradients(learning_rate, s)
     del keep
     fine, coarse = float(loss[0]), float(loss[1])
-    total = fine + coarse if self.cfg.num_fine_samples > 0 else coarse
-    return {'loss/fine': fine, 'loss/coarse': coarse, 'loss/total': total}
+    two = self.cfg.num_fine_samples > 0
+    stats = {'loss/fine': fine, 'loss/coarse': coarse}
+    aux = 0.0
+    for k, name in enumerate(('warp_reg', 'back_facing', 'predicted_mask')):
+      stats[f'loss/{name}/fine'], stats[f'loss/{name}/coarse'] = float(loss[2 + k]), float(loss[5 + k])
+      aux += (float(loss[2 + k]) if two else 0.0) + float(loss[5 + k])
+    stats['loss/total'] = (fine + coarse if two else coarse) + aux
+    return stats
 
 
 def train_step(trainer: Trainer, rng_key, state, batch, scalar_params, **static_flags):

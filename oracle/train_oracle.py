@@ -22,18 +22,54 @@ def _leaves(tree, prefix=''):
       yield prefix + k, v
 
 
+def general_loss_with_squared_residual(x_sq, alpha, scale):
+  """utils.py:208-263 (Barron's general robust loss), for the finite alpha values not equal to 0 or 2 plus those two."""
+  eps = float(np.finfo(np.float32).eps)
+  scale = max(eps, scale)
+  loss_two = 0.5 * x_sq / scale ** 2
+  if alpha == 2:
+    return scale * loss_two
+  if alpha == 0:
+    return scale * torch.log1p(torch.clamp(loss_two, max=3e37))
+  a = (1.0 if alpha >= 0 else -1.0) * max(eps, abs(alpha))
+  b = max(eps, abs(alpha - 2))
+  return scale * (b / a) * ((loss_two / (0.5 * b) + 1) ** (0.5 * alpha) - 1)
+
+
+def auxiliary_losses(cfg, out, rays_dict, objective, dtype):
+  """The first-order auxiliary terms of _compute_loss_and_stats for one level (training.py:297-310, 334-339, 386-408)."""
+  terms = {}
+  weights = out['weights'].detach()                                            # lax.stop_gradient(model_out['weights'])
+  if objective.get('warp_reg_loss_weight', 0.0):
+    idx = O.compute_depth_index(weights)
+    warp_mag = ((out['points'] - out['warped_points'][..., :3]) ** 2).sum(-1)
+    resid = torch.take_along_dim(warp_mag, idx[..., None], dim=-1)
+    terms['warp_reg'] = objective['warp_reg_loss_weight'] * general_loss_with_squared_residual(
+        resid, objective.get('warp_reg_loss_alpha', -2.0), objective.get('warp_reg_loss_scale', 0.001)).mean()
+  if objective.get('back_facing_reg_weight', 0.0):
+    terms['back_facing'] = objective['back_facing_reg_weight'] * (weights * out['back_facing']).mean()
+  if objective.get('predicted_mask_loss_weight', 0.0):
+    pm = out['predicted_mask'].squeeze(-1)
+    gt = torch.as_tensor(np.asarray(rays_dict['mask'])).to(dtype).reshape(-1)
+    w = out['sharp_weights'].detach() if cfg.use_mask_sharp_weights else weights
+    terms['predicted_mask'] = objective['predicted_mask_loss_weight'] * ((gt - (w * pm).sum(-1)) ** 2).mean()
+  return terms
+
+
 def loss_and_grads(cfg, params, rays_dict, target_rgb, extra_params, t_rand, u_rand, dtype=torch.float64,
-                   use_predicted_norm=True, mask_ratio=1.0):
+                   use_predicted_norm=True, mask_ratio=1.0, objective=None):
   """Returns (loss dict {'fine','coarse','total'}, grads tree shaped like ``params``, model outputs)."""
   model = O.NerfModel(cfg, params, dtype=dtype)
   leaves = list(_leaves(model.params))
   for _, v in leaves:
     v.requires_grad_(True)
   out = model.apply(rays_dict, extra_params, t_rand=t_rand, u_rand=u_rand, use_predicted_norm=use_predicted_norm,
-                    mask_ratio=mask_ratio, return_weights=True, return_points=True, compute_sigma_gradient=False)
+                    mask_ratio=mask_ratio, return_weights=True, return_points=True, compute_sigma_gradient=False,
+                    sharp_weights_std=(objective or {}).get('sharp_weights_std', 1.0))
   gt = torch.as_tensor(np.asarray(target_rgb)).to(dtype)
   losses = {level: ((out[level]['rgb'][..., :3] - gt) ** 2).mean() for level in out}      # training.py:265-274
-  total = sum(losses.values())                                                             # training.py:481
+  aux = {level: auxiliary_losses(cfg, out[level], rays_dict, objective, dtype) for level in out} if objective else {}
+  total = sum(losses.values()) + sum(v for a in aux.values() for v in a.values())           # training.py:481
   grads = torch.autograd.grad(total, [v for _, v in leaves], allow_unused=True)
   flat = {n: (g if g is not None else torch.zeros_like(v)).detach().cpu().numpy() for (n, v), g in zip(leaves, grads)}
   tree = {}
@@ -44,6 +80,9 @@ def loss_and_grads(cfg, params, rays_dict, target_rgb, extra_params, t_rand, u_r
       node = node.setdefault(p, {})
     node[parts[-1]] = g
   losses = {k: float(v) for k, v in losses.items()}
+  for level, a in aux.items():
+    for k, v in a.items():
+      losses[f'{k}/{level}'] = float(v)
   losses['total'] = float(total)
   return losses, tree, {lvl: {k: v.detach() for k, v in o.items() if torch.is_tensor(v)} for lvl, o in out.items()}
 

@@ -169,3 +169,39 @@ def test_sigma_gradient_target_norm_matches_oracle():
   with pytest.raises(RuntimeError):
     tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True)
     tr.target_norm('fine')                      # the last step did not evaluate it
+
+
+OBJECTIVE = dict(warp_reg_loss_weight=0.001, warp_reg_loss_alpha=-2.0, warp_reg_loss_scale=0.001, back_facing_reg_weight=0.1,
+                 predicted_mask_loss_weight=0.1, sharp_weights_std=0.1)      # configs/nerf_ds.gin:62-63, 86-87, 108, 120-126
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sharp', [True, False])
+def test_auxiliary_losses_match_the_oracle(sharp):
+  """warp regulariser, back-facing regulariser and 3-D mask supervision of the reference objective (everything but the
+  second-order norm loss): loss terms and the full gradient vs autograd."""
+  from nerfds_amd.training import Trainer
+  from oracle import train_oracle as T
+  cfg, params, batch, t, u = _problem(40, 12, 12)
+  cfg = cfg.replace(use_mask_sharp_weights=sharp)
+  # give the mask / normal heads something to supervise (the init regime has relu(mask logit) == 0 everywhere)
+  params['mask_mlp']['MLP_0']['logit']['bias'] = np.asarray(params['mask_mlp']['MLP_0']['logit']['bias']) + 0.7      # logits span [-1.0, -0.35] at init: make relu(logit) a mix of zeros and positives
+  L, G, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=OBJECTIVE)
+  tr = Trainer(cfg, params, max_rays=40)
+  stats = tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=OBJECTIVE)
+  for level in ('fine', 'coarse'):
+    for k in ('warp_reg', 'back_facing', 'predicted_mask'):
+      want = L[f'{k}/{level}']
+      assert abs(stats[f'loss/{k}/{level}'] - want) <= 2e-4 * max(abs(want), 1e-4), (k, level, stats[f'loss/{k}/{level}'], want)
+  assert abs(stats['loss/total'] - L['total']) < 1e-4 * L['total']
+  got, want = dict(tree_leaves(tr.get_grads())), dict(tree_leaves(G))
+  gmax = max(np.abs(v).max() for v in want.values())
+  for name, w in want.items():
+    g = got[name].reshape(w.shape)
+    l2 = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
+    assert l2 < 5e-3, (name, l2)
+  # the normal channels of the alpha head now DO receive gradient (back-facing regulariser), the mask net too
+  assert np.abs(got['nerf_mlps_fine/alpha_mlp/logit/kernel'][:, 1:]).max() > 0
+  assert np.abs(got['mask_mlp/MLP_0/hidden_0/kernel']).max() > 0
+  with pytest.raises(RuntimeError):
+    tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=dict(OBJECTIVE, norm_loss_weight=1.0))
