@@ -221,16 +221,17 @@ int nerfds_frame_images(int device, const float* ray_records, int32_t height, in
  * nerfds_trainer_leaf), their gradient, the Adam moments (flax.optim.Adam: b1 0.9, b2 0.999, eps 1e-8) and an HBM workspace
  * sized for max_rays.  nerfds_trainer_step: forward + backward of both levels into the gradient vector, then (unless
  * NERFDS_TRAIN_GRADS_ONLY) one Adam update with `learning_rate`.  rays / target_rgb ([R][3]) / rnd->t_rand,u_rand are DEVICE
- * pointers; rnd == NULL or NULL uniforms = non-stratified sampling.  loss_host (optional, HOST float[8]) receives
- * {rgb loss fine (coarse if there is no fine level), rgb loss coarse, weighted warp_reg / back_facing / mask terms of the fine level,
- * the same three of the coarse level} and synchronises the stream.
+ * pointers; rnd == NULL or NULL uniforms = non-stratified sampling.  loss_host (optional, HOST float[10]) receives
+ * {rgb loss fine (coarse if there is no fine level), rgb loss coarse, weighted warp_reg / back_facing / mask / norm terms of the fine level,
+ * the same four of the coarse level} and synchronises the stream.
  * Only the configs/nerf_ds.gin graph is built (NERFDS_ENOTSUP otherwise).  The norm / mask / regulariser losses of the full
  * objective (training.py:276-438) are not part of config 4 and not built. */
 typedef struct nerfds_trainer nerfds_trainer;
 /* Weights of the auxiliary first-order losses added to the rgb loss of EACH level (0 = off): warp regulariser at the median-depth
  * sample (training.py:297-310, utils.general_loss_with_squared_residual), back-facing regulariser on the raw predicted normal
  * (training.py:334-339), 3-D predicted-mask supervision on sharpened or plain compositing weights (training.py:386-408).
- * norm_loss_weight must be 0: the norm loss (training.py:323-332) is second order and not built. */
+ * norm_loss_weight: the norm loss mean(w |n - target_norm|) (training.py:323-332); like the reference it does NOT stop the gradient
+ * at target_norm, i.e. it is second order (backward of the tangent pass); costs ~4x the step and ~3x the workspace. */
 typedef struct nerfds_train_objective {
   float warp_reg_loss_weight, warp_reg_loss_alpha, warp_reg_loss_scale;
   float back_facing_reg_weight;
@@ -256,7 +257,7 @@ int nerfds_trainer_target_norm(nerfds_trainer* t, int level, int64_t num_rays, f
 int nerfds_trainer_reset_optimizer(nerfds_trainer* t);   /* zero the Adam moments and the step count */
 int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* extra,
                         const nerfds_rand* rnd, const nerfds_train_objective* objective /* NULL = rgb loss only */, float learning_rate,
-                        uint32_t flags, float* loss_host /* HOST float[8] or NULL */, void* hip_stream);
+                        uint32_t flags, float* loss_host /* HOST float[10] or NULL */, void* hip_stream);
 /* One Adam update with the gradient vector as it stands (after a NERFDS_TRAIN_GRADS_ONLY step and, on N GPUs, after the
  * all-reduce of nerfds_trainer_grads that replaces jax.lax.pmean(grad), training.py:502). */
 int nerfds_trainer_apply(nerfds_trainer* t, float learning_rate, void* hip_stream);

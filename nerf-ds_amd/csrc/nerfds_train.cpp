@@ -59,7 +59,11 @@ struct nerfds_trainer {
   float* tws = nullptr;     // tangent workspace of the sigma gradient (allocated on first use)
   float *t_warp_in, *t_hyper_in, *tA, *tB, *t_wv, *t_xw, *t_wamb, *t_tin, *t_alpha;
   float* tn[2] = {nullptr, nullptr};      // target_norm of the coarse / fine level of the last step
+  float* nws = nullptr;     // norm-loss workspace: stored tangents of every layer + tangent gradients (allocated on first use)
+  std::vector<float*> tw_h, th_h, tt_h;
+  float *d_t_alpha, *d_t_tin, *d_t_xw, *d_t_wamb, *d_t_wv, *du, *ghat, *dwamb_extra, *dwv_extra;
   bool tn_valid = false;
+  bool keep_tangents = false;
   float* part = nullptr;    // split-K partials of the weight-gradient GEMMs
   size_t part_floats = 0;
   std::string err;
@@ -80,7 +84,7 @@ struct nerfds_trainer {
     return code;
   }
   ~nerfds_trainer() {
-    for (float* p : {theta, grad, m1, m2, ws, loss_dev, part, tws, terms_dev}) if (p) (void)hipFree(p);
+    for (float* p : {theta, grad, m1, m2, ws, loss_dev, part, tws, terms_dev, nws}) if (p) (void)hipFree(p);
     if (blas) (void)rocblas_destroy_handle(blas);
   }
 };
@@ -149,7 +153,8 @@ struct Run {
   // dW[K x N] += X[M x K]^T dY[M x N].  The output is tiny and the contraction is the sample axis (up to 524 288): a
   // single GEMM runs on a handful of workgroups (measured 3 ms per layer), so the sample axis is cut into slabs of
   // SLAB rows, each slab is one problem of a strided-batched GEMM into a partial, and a small kernel adds the partials.
-  void weight_grad(const float* X, int ldx, int K, const float* dy, int ldy, int N, float* dW) {
+  void weight_grad(const float* X, int ldx, int K, const float* dy, int ldy, int N, float* dW, int64_t rows = -1) {
+    const int64_t M = rows < 0 ? this->M : rows;
     const int64_t slabs = M / SLAB;
     const float one = 1.f, zero = 0.f;
     if (slabs >= 2 && (size_t)slabs * K * N <= t.part_floats) {
@@ -185,16 +190,40 @@ struct Run {
     }
   }
   // returns the tangent of the last hidden layer (in cur or other)
-  float* mlp_jvp(const MlpP& m, const float* t_in0, const std::vector<float*>& h, float* cur, float* other) {
+  float* mlp_jvp(const MlpP& m, const float* t_in0, const std::vector<float*>& h, float* cur, float* other,
+                 const std::vector<float*>* store = nullptr) {
     for (int l = 0; l < m.depth; ++l) {
       std::vector<Seg> segs;
       if (l > 0) segs.push_back({cur, m.width, m.width, nullptr, 0, false});
       if (l == 0 || l == m.skip) segs.push_back({t_in0, m.in_dim, m.in_dim, nullptr, 0, false});
-      dense_jvp(m.hidden[l], segs, other, m.width);
-      relu_mask3(st, other, h[l], M, m.width);
-      std::swap(cur, other);
+      float* dst = store ? (*store)[l] : other;
+      dense_jvp(m.hidden[l], segs, dst, m.width);
+      relu_mask3(st, dst, h[l], M, m.width);
+      if (store) cur = dst; else std::swap(cur, other);
     }
     return cur;
+  }
+  // backward of a tangent layer: dy[3M x N] is d loss / d tangent output (masked with the PRIMAL activation when relu_y != nullptr)
+  void dense_jvp_bwd(const LayerP& L, const std::vector<Seg>& segs, float* dy, int ldy, const float* relu_y) {
+    if (relu_y) relu_mask3(st, dy, relu_y, M, L.N);
+    int k0 = 0;
+    for (const Seg& s : segs) {
+      weight_grad(s.x, s.ld, s.K, dy, ldy, L.N, t.grad + L.w + (int64_t)k0 * L.N, 3 * M);
+      if (s.dx) chk(gemm_nt(t.blas, 3 * M, L.N, s.K, dy, ldy, t.theta + L.w + (int64_t)k0 * L.N, L.N, s.acc ? 1.f : 0.f, s.dx, s.dld));
+      k0 += s.K;
+    }
+  }
+  // cur holds d loss / d tangent of h[depth-1]; th = the stored tangents of every layer
+  void mlp_jvp_bwd(const MlpP& m, const float* t_in0, const std::vector<float*>& th, const std::vector<float*>& h, float* cur, float* other,
+                   float* d_t_in0) {
+    bool in0_written = false;
+    for (int l = m.depth - 1; l >= 0; --l) {
+      std::vector<Seg> segs;
+      if (l > 0) segs.push_back({th[l - 1], m.width, m.width, other, m.width, false});
+      if (l == 0 || l == m.skip) { segs.push_back({t_in0, m.in_dim, m.in_dim, d_t_in0, m.in_dim, in0_written}); in0_written = d_t_in0 != nullptr; }
+      dense_jvp_bwd(m.hidden[l], segs, cur, m.width, h[l]);
+      std::swap(cur, other);
+    }
   }
   void mlp_fwd(const MlpP& m, const float* in0, const std::vector<float*>& h) {
     for (int l = 0; l < m.depth; ++l) {
@@ -261,6 +290,28 @@ bool ensure_tangent_ws(nerfds_trainer& t) {
   return true;
 }
 
+bool ensure_norm_ws(nerfds_trainer& t) {
+  if (t.nws) return true;
+  const int64_t R = t.max_rays, S = t.cfg.num_coarse_samples + t.cfg.num_fine_samples, M = R * S, M3 = 3 * M;
+  const Dims& D = t.D;
+  size_t need = 0;
+  std::vector<std::pair<float**, size_t>> views;
+  auto take = [&](float** p, size_t n) { views.push_back({p, n}); need += (n + 63) & ~(size_t)63; };
+  t.tw_h.assign(t.warp.depth, nullptr); for (auto& p : t.tw_h) take(&p, M3 * t.warp.width);
+  t.th_h.assign(t.hyper.depth, nullptr); for (auto& p : t.th_h) take(&p, M3 * t.hyper.width);
+  t.tt_h.assign(t.trunk[0].depth, nullptr); for (auto& p : t.tt_h) take(&p, M3 * t.trunk[0].width);
+  take(&t.d_t_alpha, M3 * 4); take(&t.d_t_tin, M3 * D.trunk_in); take(&t.d_t_xw, M3 * 3); take(&t.d_t_wamb, M3 * 2); take(&t.d_t_wv, M3 * 6);
+  take(&t.du, M * 3); take(&t.ghat, M * 3); take(&t.dwamb_extra, M * 2); take(&t.dwv_extra, M * 6);
+  if (hipMalloc(&t.nws, need * sizeof(float)) != hipSuccess) return false;
+  float* base = t.nws;
+  for (auto& v : views) { *v.first = base; base += (v.second + 63) & ~(size_t)63; }
+  // the split-K partials of the weight gradients now cover 3 M rows
+  if (t.part) (void)hipFree(t.part);
+  t.part = nullptr;
+  t.part_floats *= 3;
+  return hipMalloc(&t.part, t.part_floats * sizeof(float)) == hipSuccess;
+}
+
 // d sigma_raw / d x by forward-mode tangents through warp MLP -> exp_se3, hyper sheet, posenc, trunk, alpha head
 // (the mask is a constant input, models.py:1035-1069), then target_norm (models.py:1077, 1273-1277, 1328).  Uses the
 // activations of the forward pass that has just run for this level.
@@ -269,21 +320,23 @@ void sigma_gradient(nerfds_trainer& t, Run& r, int level, const Windows& W) {
   hipStream_t st = r.st;
   const int64_t M = r.M;
   encode_tangents(st, D, M, t.x, W, t.t_warp_in, t.t_hyper_in);
-  float* tw = r.mlp_jvp(t.warp, t.t_warp_in, t.warp_h, t.tA, t.tB);
+  const bool keep = t.nws != nullptr && t.keep_tangents;
+  float* tw = r.mlp_jvp(t.warp, t.t_warp_in, t.warp_h, t.tA, t.tB, keep ? &t.tw_h : nullptr);
   r.dense_jvp(t.warp_w, {{tw, t.warp.width, t.warp.width, nullptr, 0, false}}, t.t_wv, 6);
   r.dense_jvp(t.warp_v, {{tw, t.warp.width, t.warp.width, nullptr, 0, false}}, t.t_wv + 3, 6);
   se3_jvp(st, M, t.wv, t.x, t.t_wv, t.t_xw);
-  float* th = r.mlp_jvp(t.hyper, t.t_hyper_in, t.hyper_h, t.tA, t.tB);
+  float* th = r.mlp_jvp(t.hyper, t.t_hyper_in, t.hyper_h, t.tA, t.tB, keep ? &t.th_h : nullptr);
   r.dense_jvp(t.hyper_out, {{th, t.hyper.width, t.hyper.width, nullptr, 0, false}}, t.t_wamb, 2);
   trunk_in_jvp(st, D, M, t.xw, t.wamb, t.t_xw, t.t_wamb, W, t.t_tin);
   const MlpP& trunk = t.trunk[level];
-  float* tt = r.mlp_jvp(trunk, t.t_tin, t.trunk_h, t.tA, t.tB);
+  float* tt = r.mlp_jvp(trunk, t.t_tin, t.trunk_h, t.tA, t.tB, keep ? &t.tt_h : nullptr);
   r.dense_jvp(t.alpha[level], {{tt, trunk.width, trunk.width, nullptr, 0, false}}, t.t_alpha, 4);
   target_norm(st, M, t.t_alpha, t.wv, t.tn[level]);
 }
 
 int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const float* z, const nerfds_rays* rays, const float* target,
-              const nerfds_extra* ex, const Windows& W, float* weights_out, bool want_sigma_gradient, const Objective* ob) {
+              const nerfds_extra* ex, const Windows& W, float* weights_out, bool want_sigma_gradient, const Objective* ob,
+              float norm_weight) {
   const Dims& D = t.D;
   Run r{t, st, (int64_t)R * S};
   const int64_t M = r.M;
@@ -318,6 +371,9 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   if (ob)     // auxiliary first-order losses: extra upstream gradients for x', the raw normal and the predicted mask
     aux_losses(st, R, S, *ob, z, weights_out, t.x, t.xw, t.alphav, viewdirs, t.mask_logit, rays->gt_mask, t.terms_dev + 4 * level, t.dxw_reg,
                t.d_alpha, t.d_pm);
+  const bool nl = norm_weight != 0.f;
+  if (nl) norm_loss(st, R, S, norm_weight, weights_out, t.alphav, t.t_alpha, t.wv, t.tn[level], t.terms_dev + 4 * level + 3, t.d_alpha, t.d_t_alpha,
+                    t.du, t.ghat);
   // ---------------- backward ----------------
   const int RW = t.rgb_h[level].N;
   r.dense_bwd(t.rgb_out[level], {{t.rgb_hv, RW, RW, t.g0, RW, false}}, t.d_rgb_logit, 3, nullptr);
@@ -326,10 +382,25 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   r.dense_bwd(t.bott[level], {{tout, TW, TW, t.g2, TW, true}}, t.g1, TW, nullptr);
   r.dense_bwd(t.alpha[level], {{tout, TW, TW, t.g2, TW, true}}, t.d_alpha, 4, nullptr);
   r.mlp_bwd(trunk, t.trunk_in, t.trunk_h, t.g2, t.g0, t.d_trunk_in);
-  trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, t.dxw, t.dwamb);
+  if (nl) {   // backward of the tangent pass, part 1: alpha head, trunk, trunk input (adds second-derivative terms to d x', d w)
+    r.dense_jvp_bwd(t.alpha[level], {{t.tt_h.back(), TW, TW, t.tA, TW, false}}, t.d_t_alpha, 4, nullptr);
+    r.mlp_jvp_bwd(trunk, t.t_tin, t.tt_h, t.trunk_h, t.tA, t.tB, t.d_t_tin);
+    trunk_in_jvp_bwd(st, D, M, t.d_t_tin, t.xw, t.wamb, t.t_xw, t.t_wamb, W, t.d_t_xw, t.d_t_wamb, t.dxw_reg, t.dwamb_extra);
+  }
+  trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, nl ? t.dwamb_extra : nullptr, t.dxw, t.dwamb);
+  if (nl) {   // part 2: hyper sheet tangents
+    r.dense_jvp_bwd(t.hyper_out, {{t.th_h.back(), t.hyper.width, t.hyper.width, t.tA, t.hyper.width, false}}, t.d_t_wamb, 2, nullptr);
+    r.mlp_jvp_bwd(t.hyper, t.t_hyper_in, t.th_h, t.hyper_h, t.tA, t.tB, nullptr);
+  }
   r.dense_bwd(t.hyper_out, {{t.hyper_h.back(), t.hyper.width, t.hyper.width, t.g0, t.hyper.width, false}}, t.dwamb, 2, nullptr);
   r.mlp_bwd(t.hyper, t.hyper_in, t.hyper_h, t.g0, t.g1, t.d_hyper_in);
-  se3_bwd(st, M, t.wv, t.x, t.dxw, t.dwv);
+  if (nl) {   // part 3: exp_se3 tangents (second derivatives) and the warp net's tangents
+    se3_jvp_bwd(st, M, t.wv, t.x, t.t_wv, t.d_t_xw, t.du, t.ghat, t.d_t_wv, t.dwv_extra);
+    r.dense_jvp_bwd(t.warp_w, {{t.tw_h.back(), t.warp.width, t.warp.width, t.tA, t.warp.width, false}}, t.d_t_wv, 6, nullptr);
+    r.dense_jvp_bwd(t.warp_v, {{t.tw_h.back(), t.warp.width, t.warp.width, t.tA, t.warp.width, true}}, t.d_t_wv + 3, 6, nullptr);
+    r.mlp_jvp_bwd(t.warp, t.t_warp_in, t.tw_h, t.warp_h, t.tA, t.tB, nullptr);
+  }
+  se3_bwd(st, M, t.wv, t.x, t.dxw, nl ? t.dwv_extra : nullptr, t.dwv);
   r.dense_bwd(t.warp_w, {{t.warp_h.back(), t.warp.width, t.warp.width, t.g0, t.warp.width, false}}, t.dwv, 6, nullptr);
   r.dense_bwd(t.warp_v, {{t.warp_h.back(), t.warp.width, t.warp.width, t.g0, t.warp.width, true}}, t.dwv + 3, 6, nullptr);
   r.mlp_bwd(t.warp, t.warp_in, t.warp_h, t.g0, t.g1, t.d_warp_in);
@@ -511,8 +582,6 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   Objective ob{};
   const Objective* obp = nullptr;
   if (objective) {
-    if (objective->norm_loss_weight != 0.f)
-      return t->fail(NERFDS_ENOTSUP, "the norm loss (training.py:323-332) differentiates through target_norm and is not built yet");
     ob.warp_reg_weight = objective->warp_reg_loss_weight; ob.warp_reg_alpha = objective->warp_reg_loss_alpha; ob.warp_reg_scale = objective->warp_reg_loss_scale;
     ob.back_facing_weight = objective->back_facing_reg_weight; ob.mask_loss_weight = objective->predicted_mask_loss_weight;
     ob.sharp_weights_std = objective->sharp_weights_std; ob.use_sharp_weights = objective->use_mask_sharp_weights;
@@ -521,14 +590,17 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     obp = &ob;
   }
   (void)hipMemsetAsync(t->terms_dev, 0, 8 * sizeof(float), st);
-  const bool want_sg = (flags & NERFDS_TRAIN_SIGMA_GRAD) != 0;
+  const float norm_weight = objective ? objective->norm_loss_weight : 0.f;
+  const bool want_sg = (flags & NERFDS_TRAIN_SIGMA_GRAD) != 0 || norm_weight != 0.f;
+  t->keep_tangents = norm_weight != 0.f;
+  if (norm_weight != 0.f && (!ensure_tangent_ws(*t) || !ensure_norm_ws(*t))) return t->fail(NERFDS_ENOMEM, "hipMalloc of the norm-loss workspace failed");
   if (want_sg && !ensure_tangent_ws(*t)) return t->fail(NERFDS_ENOMEM, "hipMalloc of the tangent workspace failed");
   t->tn_valid = want_sg;
-  int rc = run_level(*t, st, 0, R, Nc, t->zc, rays, target_rgb, ex, W, t->wc, want_sg, obp);
+  int rc = run_level(*t, st, 0, R, Nc, t->zc, rays, target_rgb, ex, W, t->wc, want_sg, obp, norm_weight);
   if (rc != NERFDS_OK) return rc;
   if (Nf > 0) {
     resample(st, R, Nc, Nf, t->zc, t->wc, strat, rnd ? rnd->u_rand : nullptr, t->zf, t->rs_scratch);
-    rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights, want_sg, obp);
+    rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights, want_sg, obp, norm_weight);
     if (rc != NERFDS_OK) return rc;
   }
   if (!(flags & NERFDS_TRAIN_GRADS_ONLY)) adam_update(t, learning_rate, st);
@@ -543,7 +615,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     const int fl = Nf > 0 ? 1 : 0;
     loss_host[0] = l[fl];     // rgb loss of the fine level (the level render_image returns; coarse if there is none), of the coarse level
     loss_host[1] = l[0];
-    for (int k = 0; k < 3; ++k) { loss_host[2 + k] = tm[4 * fl + k]; loss_host[5 + k] = tm[k]; }   // weighted warp_reg / back_facing / mask terms: fine, coarse
+    for (int k = 0; k < 4; ++k) { loss_host[2 + k] = tm[4 * fl + k]; loss_host[6 + k] = tm[k]; }   // weighted warp_reg / back_facing / mask / norm terms: fine, coarse
   }
   return NERFDS_OK;
 }

@@ -25,10 +25,16 @@ void encode_inputs(hipStream_t, const Dims&, int R, int S, const float* o, const
 void bias_act(hipStream_t, float* y, const float* b, long long M, int N, int ld, int relu);
 void mask_post(hipStream_t, const Dims&, int R, int S, const float* logit, const float* gt, float ratio, float* warp_in, float* hyper_in);
 void se3_fwd(hipStream_t, long long M, const float* wv, const float* x, float* xw);
-void se3_bwd(hipStream_t, long long M, const float* wv, const float* x, const float* dxw, float* dwv);
+void se3_bwd(hipStream_t, long long M, const float* wv, const float* x, const float* dxw, const float* dwv_extra, float* dwv);
 void trunk_in(hipStream_t, const Dims&, long long M, const float* xw, const float* wamb, const Windows&, float* tin);
 void trunk_in_bwd(hipStream_t, const Dims&, long long M, const float* dtin, const float* xw, const float* wamb, const Windows&, const float* dxw_extra,
-                  float* dxw, float* dwamb);
+                  const float* dwamb_extra, float* dxw, float* dwamb);
+void norm_loss(hipStream_t, int R, int S, float weight, const float* weights, const float* alpha, const float* t_alpha, const float* wv,
+               const float* target_norm, float* term, float* d_alpha, float* d_t_alpha, float* du, float* ghat);
+void trunk_in_jvp_bwd(hipStream_t, const Dims&, long long M, const float* d_t_tin, const float* xw, const float* wamb, const float* t_xw,
+                      const float* t_wamb, const Windows&, float* d_t_xw, float* d_t_wamb, float* dxw_extra, float* dwamb_extra);
+void se3_jvp_bwd(hipStream_t, long long M, const float* wv, const float* x, const float* t_wv, const float* d_t_xw, const float* du,
+                 const float* ghat, float* d_t_wv, float* dwv_extra);
 void aux_losses(hipStream_t, int R, int S, const Objective&, const float* z, const float* weights, const float* x, const float* xw, const float* alpha,
                 const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg, float* d_alpha, float* d_pm);
 void alpha_post(hipStream_t, const Dims&, int R, int S, const float* alpha, const float* wv, const float* viewdirs, const Windows&, float* sigma, float* cond);

@@ -180,7 +180,7 @@ __global__ void k_se3_fwd(long long M, const float* __restrict__ wv, const float
 
 // d loss / d (w, v) from d loss / d x'   (x is a constant: the observation-space sample point)
 __global__ void k_se3_bwd(long long M, const float* __restrict__ wv, const float* __restrict__ x, const float* __restrict__ dxw,
-                          float* __restrict__ dwv) {
+                          const float* __restrict__ dwv_extra, float* __restrict__ dwv) {
   const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (m >= M) return;
   Dual w[3], v[3];
@@ -192,7 +192,7 @@ __global__ void k_se3_bwd(long long M, const float* __restrict__ wv, const float
     const Dual xr = Rm[3 * r] * x[3 * m] + Rm[3 * r + 1] * x[3 * m + 1] + Rm[3 * r + 2] * x[3 * m + 2] + p[r];
     for (int i = 0; i < 6; ++i) acc[i] += dxw[3 * m + r] * xr.g[i];
   }
-  for (int i = 0; i < 6; ++i) dwv[6 * m + i] = acc[i];
+  for (int i = 0; i < 6; ++i) dwv[6 * m + i] = acc[i] + (dwv_extra ? dwv_extra[6 * m + i] : 0.f);
 }
 
 // ---- NerfMLP trunk input: posenc(x') | posenc(ambient coords) (models.py:493-523) and its backward -------------------
@@ -205,7 +205,8 @@ __global__ void k_trunk_in(Dims D, long long M, const float* __restrict__ xw, co
   for (int g = 0; g < 4 * D.hp_bands; ++g) t[6 * D.sp_bands + g] = posenc_val<2>(g, a, W.hp);
 }
 __global__ void k_trunk_in_bwd(Dims D, long long M, const float* __restrict__ dtin, const float* __restrict__ xw, const float* __restrict__ wamb,
-                               Windows W, const float* __restrict__ dxw_extra, float* __restrict__ dxw, float* __restrict__ dwamb) {
+                               Windows W, const float* __restrict__ dxw_extra, const float* __restrict__ dwamb_extra, float* __restrict__ dxw,
+                               float* __restrict__ dwamb) {
   const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (m >= M) return;
   const float p[3] = {xw[3 * m], xw[3 * m + 1], xw[3 * m + 2]}, a[2] = {wamb[2 * m], wamb[2 * m + 1]};
@@ -218,7 +219,7 @@ __global__ void k_trunk_in_bwd(Dims D, long long M, const float* __restrict__ dt
   for (int c = 0; c < 2; ++c) {
     float acc = 0.f;
     for (int bs = 0; bs < 2 * D.hp_bands; ++bs) acc += t[6 * D.sp_bands + 2 * bs + c] * posenc_dval<2>(2 * bs + c, a, W.hp);
-    dwamb[2 * m + c] = acc;
+    dwamb[2 * m + c] = acc + (dwamb_extra ? dwamb_extra[2 * m + c] : 0.f);
   }
 }
 
@@ -317,6 +318,160 @@ __global__ void k_target_norm(long long M, const float* __restrict__ t_alpha, co
   for (int c = 0; c < 3; ++c) r[c] = Rm[3 * c] * g[0] + Rm[3 * c + 1] * g[1] + Rm[3 * c + 2] * g[2];
   normalize(r);
   for (int c = 0; c < 3; ++c) target_norm[3 * m + c] = r[c];
+}
+
+// ---- norm loss (training.py:323-332): mean(w * |n - target_norm|), w = stop_gradient(weights), n the RAW predicted normal.  The
+// reference does not stop the gradient at target_norm, so the loss is second order: its backward runs through the tangent pass.
+// This kernel: the loss term, d / d n (into d_alpha[:, 1:4]), and d / d target_norm pulled back through the two normalisations
+// and the rotation to  d g (tangent of the alpha head, column 0 of t_alpha)  and to the pair (du, ghat) from which the SE(3)
+// kernel forms d / d (w, v) of <du, R ghat>.
+__device__ __forceinline__ void normalize_bwd(const float (&v)[3], const float (&dy)[3], float (&dv)[3]) {   // y = v / sqrt(max(|v|^2, eps))
+  const float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  if (n2 > 1.1920929e-07f) {
+    const float inv = 1.0f / sqrtf(n2);
+    const float dot = (v[0] * dy[0] + v[1] * dy[1] + v[2] * dy[2]) * inv * inv;
+    for (int c = 0; c < 3; ++c) dv[c] = (dy[c] - v[c] * dot) * inv;
+  } else {
+    const float inv = 1.0f / sqrtf(1.1920929e-07f);
+    for (int c = 0; c < 3; ++c) dv[c] = dy[c] * inv;
+  }
+}
+__global__ void k_norm_loss(int R, int S, float weight, const float* __restrict__ weights, const float* __restrict__ alpha,
+                            const float* __restrict__ t_alpha, const float* __restrict__ wv, const float* __restrict__ target_norm,
+                            float* __restrict__ term, float* __restrict__ d_alpha, float* __restrict__ d_t_alpha, float* __restrict__ du_out,
+                            float* __restrict__ ghat_out) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= (long long)R * S) return;
+  const float k = weight * weights[m] / ((float)R * (float)S);
+  float diff[3], nrm = 0.f;
+  for (int c = 0; c < 3; ++c) { diff[c] = alpha[4 * m + 1 + c] - target_norm[3 * m + c]; nrm += diff[c] * diff[c]; }
+  nrm = sqrtf(nrm);
+  atomicAdd(term, k * nrm);
+  float dt[3];
+  for (int c = 0; c < 3; ++c) {
+    const float gdir = nrm > 0.f ? diff[c] / nrm : 0.f;
+    d_alpha[4 * m + 1 + c] += k * gdir;
+    dt[c] = -k * gdir;
+  }
+  // target_norm = N(u), u = R ghat, ghat = N(hv), hv = -g
+  float hv[3] = {-t_alpha[(3 * m) * 4], -t_alpha[(3 * m + 1) * 4], -t_alpha[(3 * m + 2) * 4]};
+  float ghat[3];
+  {
+    const float inv = 1.0f / sqrtf(fmaxf(hv[0] * hv[0] + hv[1] * hv[1] + hv[2] * hv[2], 1.1920929e-07f));
+    for (int c = 0; c < 3; ++c) ghat[c] = hv[c] * inv;
+  }
+  const float w[3] = {wv[6 * m], wv[6 * m + 1], wv[6 * m + 2]}, v[3] = {wv[6 * m + 3], wv[6 * m + 4], wv[6 * m + 5]};
+  float Rm[9], p[3];
+  se3_Rp<float>(w, v, Rm, p);
+  float u[3];
+  for (int r = 0; r < 3; ++r) u[r] = Rm[3 * r] * ghat[0] + Rm[3 * r + 1] * ghat[1] + Rm[3 * r + 2] * ghat[2];
+  float du[3], dgh[3], dhv[3];
+  normalize_bwd(u, dt, du);
+  for (int c = 0; c < 3; ++c) dgh[c] = Rm[c] * du[0] + Rm[3 + c] * du[1] + Rm[6 + c] * du[2];       // R^T du
+  normalize_bwd(hv, dgh, dhv);
+  for (int j = 0; j < 3; ++j) {
+    d_t_alpha[(3 * m + j) * 4] = -dhv[j];
+    d_t_alpha[(3 * m + j) * 4 + 1] = 0.f; d_t_alpha[(3 * m + j) * 4 + 2] = 0.f; d_t_alpha[(3 * m + j) * 4 + 3] = 0.f;
+  }
+  for (int c = 0; c < 3; ++c) { du_out[3 * m + c] = du[c]; ghat_out[3 * m + c] = ghat[c]; }
+}
+
+// backward of k_trunk_in_jvp: d tangent(x'), d tangent(w), and - because the features' derivative factors depend on x' and w
+// themselves - second-derivative contributions to the PRIMAL gradients of x' and the ambient coordinates
+__global__ void k_trunk_in_jvp_bwd(Dims D, long long M, const float* __restrict__ d_t_tin, const float* __restrict__ xw, const float* __restrict__ wamb,
+                                   const float* __restrict__ t_xw, const float* __restrict__ t_wamb, Windows W, float* __restrict__ d_t_xw,
+                                   float* __restrict__ d_t_wamb, float* __restrict__ dxw_extra, float* __restrict__ dwamb_extra) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float p[3] = {xw[3 * m], xw[3 * m + 1], xw[3 * m + 2]}, a[2] = {wamb[2 * m], wamb[2 * m + 1]};
+  float ex[3] = {0.f, 0.f, 0.f}, ea[2] = {0.f, 0.f};
+  for (int j = 0; j < 3; ++j) {
+    const long long i = 3 * m + j;
+    const float* dt = d_t_tin + i * D.trunk_in;
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.f;
+      for (int bs = 0; bs < 2 * D.sp_bands; ++bs) {
+        const int g = 3 * bs + c, band = g / 6, sc = (g % 6) / 3;
+        const float arg = p[c] * (float)(1 << band) + (sc ? 1.57079637f : 0.0f), sc2 = (float)(1 << band);
+        acc += dt[g] * W.sp[band] * sc2 * cosf(arg);
+        ex[c] += dt[g] * t_xw[3 * i + c] * (-W.sp[band] * sc2 * sc2 * sinf(arg));
+      }
+      d_t_xw[3 * i + c] = acc;
+    }
+    for (int c = 0; c < 2; ++c) {
+      float acc = 0.f;
+      for (int bs = 0; bs < 2 * D.hp_bands; ++bs) {
+        const int g = 2 * bs + c, band = g / 4, sc = (g % 4) / 2;
+        const float arg = a[c] * (float)(1 << band) + (sc ? 1.57079637f : 0.0f), sc2 = (float)(1 << band);
+        acc += dt[6 * D.sp_bands + g] * W.hp[band] * sc2 * cosf(arg);
+        ea[c] += dt[6 * D.sp_bands + g] * t_wamb[2 * i + c] * (-W.hp[band] * sc2 * sc2 * sinf(arg));
+      }
+      d_t_wamb[2 * i + c] = acc;
+    }
+  }
+  for (int c = 0; c < 3; ++c) dxw_extra[3 * m + c] += ex[c];
+  dwamb_extra[2 * m] = ea[0]; dwamb_extra[2 * m + 1] = ea[1];
+}
+
+// single-direction dual over any scalar T (float or Dual): the nested type D1<Dual> differentiates a directional derivative
+template <class T> struct D1 { T v, d; };
+template <class T> __device__ __forceinline__ D1<T> operator+(const D1<T>& a, const D1<T>& b) { return {a.v + b.v, a.d + b.d}; }
+template <class T> __device__ __forceinline__ D1<T> operator-(const D1<T>& a, const D1<T>& b) { return {a.v - b.v, a.d - b.d}; }
+template <class T> __device__ __forceinline__ D1<T> operator-(const D1<T>& a) { return {-a.v, -a.d}; }
+template <class T> __device__ __forceinline__ D1<T> operator*(const D1<T>& a, const D1<T>& b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+template <class T> __device__ __forceinline__ D1<T> operator/(const D1<T>& a, const D1<T>& b) {
+  const T q = a.v / b.v;
+  return {q, (a.d - q * b.d) / b.v};
+}
+template <class T> __device__ __forceinline__ D1<T> operator*(const D1<T>& a, float b) { return {a.v * b, a.d * b}; }
+template <class T> __device__ __forceinline__ D1<T> dsqrt(const D1<T>& a) { const T r = dsqrt(a.v); return {r, a.d / (r + r)}; }
+template <class T> __device__ __forceinline__ D1<T> dsin(const D1<T>& a) { return {dsin(a.v), a.d * dcos(a.v)}; }
+template <class T> __device__ __forceinline__ D1<T> dcos(const D1<T>& a) { return {dcos(a.v), -(a.d * dsin(a.v))}; }
+__device__ __forceinline__ D1<Dual> tconst(float c, const D1<Dual>*) { return {dconst(c), dconst(0.f)}; }
+
+// backward of k_se3_jvp (t_xw_j = R e_j + J t_wv_j) for upstream a_j = d t_xw_j, plus the rotation used by target_norm (<du, R ghat>):
+//   d t_wv_j = J^T a_j,   d (w, v) += grad_{(w,v)} [ sum_j <a_j, R e_j + DF[t_wv_j]> + <du, R ghat> ]     (second derivatives of exp_se3)
+__global__ void k_se3_jvp_bwd(long long M, const float* __restrict__ wv, const float* __restrict__ x, const float* __restrict__ t_wv,
+                              const float* __restrict__ d_t_xw, const float* __restrict__ du, const float* __restrict__ ghat,
+                              float* __restrict__ d_t_wv, float* __restrict__ dwv_extra) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float extra[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  {  // first-order pieces from the 6-direction dual
+    Dual w[3], v[3];
+    for (int i = 0; i < 3; ++i) { w[i] = dconst(wv[6 * m + i]); w[i].g[i] = 1.f; v[i] = dconst(wv[6 * m + 3 + i]); v[i].g[3 + i] = 1.f; }
+    Dual Rm[9], p[3];
+    se3_Rp<Dual>(w, v, Rm, p);
+    for (int j = 0; j < 3; ++j) {
+      float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < 3; ++r) {
+        const Dual xr = Rm[3 * r] * x[3 * m] + Rm[3 * r + 1] * x[3 * m + 1] + Rm[3 * r + 2] * x[3 * m + 2] + p[r];
+        const float a = d_t_xw[(3 * m + j) * 3 + r];
+        for (int i = 0; i < 6; ++i) { acc[i] += a * xr.g[i]; extra[i] += a * Rm[3 * r + j].g[i]; }     // J^T a_j ; grad <a_j, R e_j>
+      }
+      for (int i = 0; i < 6; ++i) d_t_wv[(3 * m + j) * 6 + i] = acc[i];
+    }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        const float k = du[3 * m + r] * ghat[3 * m + c];
+        for (int i = 0; i < 6; ++i) extra[i] += k * Rm[3 * r + c].g[i];                                  // grad <du, R ghat>
+      }
+  }
+  for (int j = 0; j < 3; ++j) {  // grad_{(w,v)} <a_j, DF[t_wv_j]>: the directional derivative along t_wv_j, differentiated again
+    D1<Dual> w[3], v[3];
+    for (int i = 0; i < 3; ++i) {
+      w[i].v = dconst(wv[6 * m + i]); w[i].v.g[i] = 1.f; w[i].d = dconst(t_wv[(3 * m + j) * 6 + i]);
+      v[i].v = dconst(wv[6 * m + 3 + i]); v[i].v.g[3 + i] = 1.f; v[i].d = dconst(t_wv[(3 * m + j) * 6 + 3 + i]);
+    }
+    D1<Dual> Rm[9], p[3];
+    se3_Rp<D1<Dual>>(w, v, Rm, p);
+    for (int r = 0; r < 3; ++r) {
+      const D1<Dual> xr = Rm[3 * r] * x[3 * m] + Rm[3 * r + 1] * x[3 * m + 1] + Rm[3 * r + 2] * x[3 * m + 2] + p[r];
+      const float a = d_t_xw[(3 * m + j) * 3 + r];
+      for (int i = 0; i < 6; ++i) extra[i] += a * xr.d.g[i];
+    }
+  }
+  for (int i = 0; i < 6; ++i) dwv_extra[6 * m + i] = extra[i];
 }
 
 // ---- compositing (model_utils.py:95-159), MSE loss (training.py:265-274) and the backward of both; one thread per ray ----
@@ -592,13 +747,27 @@ void mask_post(hipStream_t st, const Dims& D, int R, int S, const float* logit, 
   LAUNCH(k_mask_post, (long long)R * S, st, D, R, S, logit, gt, ratio, warp_in, hyper_in);
 }
 void se3_fwd(hipStream_t st, long long M, const float* wv, const float* x, float* xw) { LAUNCH(k_se3_fwd, M, st, M, wv, x, xw); }
-void se3_bwd(hipStream_t st, long long M, const float* wv, const float* x, const float* dxw, float* dwv) { LAUNCH(k_se3_bwd, M, st, M, wv, x, dxw, dwv); }
+void se3_bwd(hipStream_t st, long long M, const float* wv, const float* x, const float* dxw, const float* dwv_extra, float* dwv) {
+  LAUNCH(k_se3_bwd, M, st, M, wv, x, dxw, dwv_extra, dwv);
+}
 void trunk_in(hipStream_t st, const Dims& D, long long M, const float* xw, const float* wamb, const Windows& W, float* tin) {
   LAUNCH(k_trunk_in, M, st, D, M, xw, wamb, W, tin);
 }
 void trunk_in_bwd(hipStream_t st, const Dims& D, long long M, const float* dtin, const float* xw, const float* wamb, const Windows& W,
-                  const float* dxw_extra, float* dxw, float* dwamb) {
-  LAUNCH(k_trunk_in_bwd, M, st, D, M, dtin, xw, wamb, W, dxw_extra, dxw, dwamb);
+                  const float* dxw_extra, const float* dwamb_extra, float* dxw, float* dwamb) {
+  LAUNCH(k_trunk_in_bwd, M, st, D, M, dtin, xw, wamb, W, dxw_extra, dwamb_extra, dxw, dwamb);
+}
+void norm_loss(hipStream_t st, int R, int S, float weight, const float* weights, const float* alpha, const float* t_alpha, const float* wv,
+               const float* target_norm, float* term, float* d_alpha, float* d_t_alpha, float* du, float* ghat) {
+  LAUNCH(k_norm_loss, (long long)R * S, st, R, S, weight, weights, alpha, t_alpha, wv, target_norm, term, d_alpha, d_t_alpha, du, ghat);
+}
+void trunk_in_jvp_bwd(hipStream_t st, const Dims& D, long long M, const float* d_t_tin, const float* xw, const float* wamb, const float* t_xw,
+                      const float* t_wamb, const Windows& W, float* d_t_xw, float* d_t_wamb, float* dxw_extra, float* dwamb_extra) {
+  LAUNCH(k_trunk_in_jvp_bwd, M, st, D, M, d_t_tin, xw, wamb, t_xw, t_wamb, W, d_t_xw, d_t_wamb, dxw_extra, dwamb_extra);
+}
+void se3_jvp_bwd(hipStream_t st, long long M, const float* wv, const float* x, const float* t_wv, const float* d_t_xw, const float* du,
+                 const float* ghat, float* d_t_wv, float* dwv_extra) {
+  hipLaunchKernelGGL(k_se3_jvp_bwd, grid1(M, 64), dim3(64), 0, st, M, wv, x, t_wv, d_t_xw, du, ghat, d_t_wv, dwv_extra);
 }
 void aux_losses(hipStream_t st, int R, int S, const Objective& ob, const float* z, const float* weights, const float* x, const float* xw,
                 const float* alpha, const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg,

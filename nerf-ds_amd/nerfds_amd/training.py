@@ -191,7 +191,7 @@ class Trainer:
       t = f32(t_rand).reshape(R, self.cfg.num_coarse_samples); keep.append(t); rnd.t_rand = t.data_ptr()
     if u_rand is not None and self.cfg.num_fine_samples > 0:
       u = f32(u_rand).reshape(R, self.cfg.num_fine_samples); keep.append(u); rnd.u_rand = u.data_ptr()
-    loss = (C.c_float * 8)()
+    loss = (C.c_float * 10)()
     ob = None
     if objective:       # scalar_params / SpecularConfig names (training.py:36-56)
       ob = Objective(warp_reg_loss_weight=objective.get('warp_reg_loss_weight', 0.0), warp_reg_loss_alpha=objective.get('warp_reg_loss_alpha', -2.0),
@@ -218,9 +218,9 @@ class Trainer:
     two = self.cfg.num_fine_samples > 0
     stats = {'loss/fine': fine, 'loss/coarse': coarse}
     aux = 0.0
-    for k, name in enumerate(('warp_reg', 'back_facing', 'predicted_mask')):
-      stats[f'loss/{name}/fine'], stats[f'loss/{name}/coarse'] = float(loss[2 + k]), float(loss[5 + k])
-      aux += (float(loss[2 + k]) if two else 0.0) + float(loss[5 + k])
+    for k, name in enumerate(('warp_reg', 'back_facing', 'predicted_mask', 'norm')):
+      stats[f'loss/{name}/fine'], stats[f'loss/{name}/coarse'] = float(loss[2 + k]), float(loss[6 + k])
+      aux += (float(loss[2 + k]) if two else 0.0) + float(loss[6 + k])
     stats['loss/total'] = (fine + coarse if two else coarse) + aux
     return stats
 

@@ -427,7 +427,16 @@ class NerfModel:
       mask = gt_mask_b
 
     # value_and_grad(cal_single_pt_sigma) (models.py:1065-1077); mask enters as a constant input.
-    if compute_sigma_gradient:
+    if compute_sigma_gradient == 'differentiable':
+      # The reference keeps the whole value_and_grad result in the graph (no stop_gradient on target_norm): the
+      # norm loss is second order in the warp / hyper / trunk weights.  Used by oracle/train_oracle.py only.
+      pts = points.clone().requires_grad_(True)
+      with torch.enable_grad():
+        sigma, norm, warped_points, trunk_output, bottleneck, rgb_condition = self._sigma_of_points(
+            level, pts, warp_embed, hyper_embed, viewdirs, mask, extra_params, use_warp)
+        grad, = torch.autograd.grad(sigma.sum(), pts, create_graph=True)
+      sigma_gradient = normalize_vector(-grad)
+    elif compute_sigma_gradient:
       pts = points.detach().clone().requires_grad_(True)
       mask_c = mask.detach() if mask is not None else None
       with torch.enable_grad():

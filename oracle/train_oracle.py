@@ -53,6 +53,9 @@ def auxiliary_losses(cfg, out, rays_dict, objective, dtype):
     gt = torch.as_tensor(np.asarray(rays_dict['mask'])).to(dtype).reshape(-1)
     w = out['sharp_weights'].detach() if cfg.use_mask_sharp_weights else weights
     terms['predicted_mask'] = objective['predicted_mask_loss_weight'] * ((gt - (w * pm).sum(-1)) ** 2).mean()
+  if objective.get('norm_loss_weight', 0.0):                                   # training.py:323-332 (second order: target_norm is NOT detached)
+    diff = out['predicted_norm'] - out['target_norm']
+    terms['norm'] = objective['norm_loss_weight'] * (weights * torch.sqrt((diff ** 2).sum(-1))).mean()
   return terms
 
 
@@ -64,7 +67,8 @@ def loss_and_grads(cfg, params, rays_dict, target_rgb, extra_params, t_rand, u_r
   for _, v in leaves:
     v.requires_grad_(True)
   out = model.apply(rays_dict, extra_params, t_rand=t_rand, u_rand=u_rand, use_predicted_norm=use_predicted_norm,
-                    mask_ratio=mask_ratio, return_weights=True, return_points=True, compute_sigma_gradient=False,
+                    mask_ratio=mask_ratio, return_weights=True, return_points=True,
+                    compute_sigma_gradient='differentiable' if (objective or {}).get('norm_loss_weight', 0.0) else False,
                     sharp_weights_std=(objective or {}).get('sharp_weights_std', 1.0))
   gt = torch.as_tensor(np.asarray(target_rgb)).to(dtype)
   losses = {level: ((out[level]['rgb'][..., :3] - gt) ** 2).mean() for level in out}      # training.py:265-274

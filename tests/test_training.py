@@ -203,5 +203,34 @@ def test_auxiliary_losses_match_the_oracle(sharp):
   # the normal channels of the alpha head now DO receive gradient (back-facing regulariser), the mask net too
   assert np.abs(got['nerf_mlps_fine/alpha_mlp/logit/kernel'][:, 1:]).max() > 0
   assert np.abs(got['mask_mlp/MLP_0/hidden_0/kernel']).max() > 0
-  with pytest.raises(RuntimeError):
-    tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=dict(OBJECTIVE, norm_loss_weight=1.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('only_norm', [True, False])
+def test_norm_loss_second_order_matches_the_oracle(only_norm):
+  """training.py:323-332: mean(w |n - target_norm|) with NO stop_gradient on target_norm = d sigma / d x, i.e. second order in
+  the warp / hyper / trunk weights: backward of the forward-mode tangent pass, vs torch double-backward in the oracle."""
+  from nerfds_amd.training import Trainer
+  from oracle import train_oracle as T
+  # (16 + 16 samples: at 8 + 8 one sample of this seed sits on a ReLU boundary of the fp32 primal pass, which flips its mask
+  # w.r.t. the fp64 oracle and moves a few leaves by 1 % - inherent to comparing fp32 with fp64 at a kink, not a bug)
+  cfg, params, batch, t, u = _problem(24, 16, 16)
+  ob = dict(norm_loss_weight=0.05) if only_norm else dict(OBJECTIVE, norm_loss_weight=0.05)
+  L, G, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=ob)
+  L0, G0, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective={k: v for k, v in ob.items() if k != 'norm_loss_weight'} or None)
+  tr = Trainer(cfg, params, max_rays=24)
+  stats = tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=ob)
+  for level in ('fine', 'coarse'):
+    want = L[f'norm/{level}']
+    assert abs(stats[f'loss/norm/{level}'] - want) <= 2e-3 * want, (level, stats[f'loss/norm/{level}'], want)
+  got, want, base = dict(tree_leaves(tr.get_grads())), dict(tree_leaves(G)), dict(tree_leaves(G0))
+  gmax = max(np.abs(v).max() for v in want.values())
+  moved = 0
+  for name, w in want.items():
+    g = got[name].reshape(w.shape)
+    l2 = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
+    assert l2 < 5e-3, (name, l2)
+    # the norm loss must actually have contributed to this leaf's gradient for the check to mean something
+    if np.linalg.norm(w - base[name]) > 0.05 * max(np.linalg.norm(w), 1e-12):
+      moved += 1
+  assert moved >= 20, moved      # trunk, warp and hyper leaves all move (second-order path), not only the alpha head
