@@ -41,6 +41,14 @@ class Camera:
   def image_shape(self):
     return int(self.image_size[1]), int(self.image_size[0])
 
+  def scale(self, scale: float) -> 'Camera':
+    """camera.py:370-387 (render.py:183 renders at ``image_scale``): intrinsics and image size scaled, pose and distortion kept."""
+    if scale <= 0:
+      raise ValueError('scale needs to be positive.')
+    w, h = (int(round(float(v) * scale)) for v in self.image_size)
+    return Camera(self.orientation, self.position, self.focal_length * scale, self.principal_point * scale, (w, h), self.skew,
+                  self.pixel_aspect_ratio, self.radial_distortion, self.tangential_distortion)
+
   def _struct(self) -> N.CameraStruct:
     s = N.CameraStruct()
     s.orientation[:] = self.orientation.reshape(-1).tolist()

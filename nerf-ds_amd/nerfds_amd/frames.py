@@ -73,6 +73,36 @@ def frame_images(records: torch.Tensor, height: int, width: int, near: float, fa
   return rgb, dbg
 
 
+def render_frame(model, variables, camera, warp_id: int, extra_params, *, gt_mask=None, chunk: int = 65536, colormap='magma',
+                 precision: Optional[str] = None, seed: int = 0, want_debug: bool = True):
+  """One iteration of render.py's frame loop (render.py:196-268) without leaving the GPU: pixel centres -> rays
+  (camera.py:245-270) -> the fused ray kernel, chunk by chunk -> ray records -> uint8 frames.  Nothing per-ray crosses PCIe:
+  the camera goes in as 27 scalars, the frames come out as bytes.
+
+  Returns (rgb_u8 [H, W, 3], debug_u8 [2H, 3W, 3] or None, records [H * W, 26]).  ``gt_mask``: optional [H, W] / [H * W] mask
+  (``batch['mask']``, render.py:215-216)."""
+  cfg = model.cfg
+  H, W = camera.image_shape
+  n = H * W
+  dev = model.device
+  records = torch.empty((n, N.RAY_REC), dtype=torch.float32, device=dev)
+  mask = None
+  if gt_mask is not None:
+    mask = (gt_mask if isinstance(gt_mask, torch.Tensor) else torch.as_tensor(np.asarray(gt_mask))).to(dev, torch.float32).reshape(-1)
+  level = 'fine' if cfg.num_fine_samples > 0 else 'coarse'
+  for ci, first in enumerate(range(0, n, chunk)):
+    cnt = min(chunk, n - first)
+    rays = {'camera': camera, 'pixel_range': (first, cnt),
+            'metadata': {'warp': torch.full((cnt, 1), int(warp_id), dtype=torch.int32, device=dev)}}
+    if mask is not None:
+      rays['mask'] = mask[first:first + cnt]
+    model.apply(variables, rays, extra_params, rngs={'coarse': seed * 1000 + ci, 'fine': seed * 1000 + ci + 500},
+                use_predicted_norm=cfg.predict_norm, precision=precision)
+    records[first:first + cnt] = model.last_records[level]
+  rgb, dbg = frame_images(records, H, W, cfg.near, cfg.far, colormap=colormap, want_debug=want_debug)
+  return rgb, dbg, records
+
+
 def raw_result(render: Dict[str, torch.Tensor]) -> Dict[str, np.ndarray]:
   """The per-frame dict render.py:222-229 appends to ``raw_result_list`` (host numpy copies of the relevant keys)."""
   return {k: render[k].detach().cpu().numpy() for k in RELEVANT_KEYS if k in render}

@@ -92,3 +92,30 @@ def test_frame_images_from_a_render_dict():
   assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
   raw = raw_result(render)
   assert set(raw) == {'rgb', 'med_depth', 'ray_norm', 'ray_delta_x', 'med_points', 'ray_predicted_mask', 'ray_rotation_field'}
+
+
+@pytest.mark.gpu
+def test_render_frame_composes_camera_render_and_frame_output():
+  """camera -> rays -> fused render -> uint8 frames in one call equals the three steps done separately."""
+  import json
+  import torch
+  from nerfds_amd import init_params, nerf_ds_config
+  from nerfds_amd.camera import Camera, camera_to_rays
+  from nerfds_amd.frames import frame_images, render_frame
+  from nerfds_amd.model import NerfModel
+  cam = Camera.from_json(os.path.join(ROOT, 'tests', 'golden', 'reference_testdata_camera.json')).scale(0.05)
+  H, W = cam.image_shape
+  cfg = nerf_ds_config(num_warp_embeds=3, num_coarse_samples=8, num_fine_samples=8, use_stratified_sampling=False)
+  params = init_params(cfg, 1, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  model = NerfModel(cfg, device=torch.device('cuda', 0), precision='f32')
+  EX = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
+  rgb, dbg, rec = render_frame(model, {'params': params}, cam, 2, EX, chunk=97, colormap='sinebow')
+  assert rgb.shape == (H, W, 3) and dbg.shape == (2 * H, 3 * W, 3) and rgb.dtype == torch.uint8
+  rays = camera_to_rays(cam, torch.device('cuda', 0))
+  rd = dict(origins=rays['origins'], directions=rays['directions'], viewdirs=rays['directions'],
+            metadata={'warp': torch.full((H, W, 1), 2, dtype=torch.int32)})
+  model.apply({'params': params}, rd, EX, use_predicted_norm=True)
+  rec2 = model.last_records['fine']
+  assert float((rec - rec2).abs().max()) < 1e-5
+  rgb2, dbg2 = frame_images(rec2, H, W, cfg.near, cfg.far, colormap='sinebow')
+  assert int((rgb.int() - rgb2.int()).abs().max()) <= 1 and int((dbg.int() - dbg2.int()).abs().max()) <= 1
