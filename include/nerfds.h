@@ -261,6 +261,9 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
 /* One Adam update with the gradient vector as it stands (after a NERFDS_TRAIN_GRADS_ONLY step and, on N GPUs, after the
  * all-reduce of nerfds_trainer_grads that replaces jax.lax.pmean(grad), training.py:502). */
 int nerfds_trainer_apply(nerfds_trainer* t, float learning_rate, void* hip_stream);
+/* utils.clip_gradients (utils.py:32-47, training.py:503-504) on the gradient vector: clip by value (if > 0), then scale so that the global
+ * L2 norm is at most grad_max_norm (if > 0).  Call between a NERFDS_TRAIN_GRADS_ONLY step (and the all-reduce) and nerfds_trainer_apply. */
+int nerfds_trainer_clip_gradients(nerfds_trainer* t, float grad_max_val, float grad_max_norm, void* hip_stream);
 const char* nerfds_trainer_last_error(const nerfds_trainer* t);
 
 /* Timing aid for bench.py: average device time (ms) of the render kernel launches recorded with HIP events

@@ -549,6 +549,16 @@ static void adam_update(nerfds_trainer* t, float learning_rate, hipStream_t st) 
   t->adam_t += 1;
 }
 
+int nerfds_trainer_clip_gradients(nerfds_trainer* t, float grad_max_val, float grad_max_norm, void* hip_stream) {
+  if (!t) return NERFDS_EINVAL;
+  if (!(grad_max_val > 0.f) && !(grad_max_norm > 0.f)) return NERFDS_OK;
+  if (hipSetDevice(t->device) != hipSuccess) return t->fail(NERFDS_EDEVICE, "hipSetDevice failed");
+  clip_gradients(static_cast<hipStream_t>(hip_stream), t->grad, t->P, grad_max_val, grad_max_norm, t->loss_dev);   // loss_dev[0] doubles as scratch between steps
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return t->fail(NERFDS_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+  return NERFDS_OK;
+}
+
 int nerfds_trainer_apply(nerfds_trainer* t, float learning_rate, void* hip_stream) {
   if (!t) return NERFDS_EINVAL;
   if (hipSetDevice(t->device) != hipSuccess) return t->fail(NERFDS_EDEVICE, "hipSetDevice failed");

@@ -53,6 +53,7 @@ void relu_mask3(hipStream_t, float* t, const float* y, long long M, int N);
 void se3_jvp(hipStream_t, long long M, const float* wv, const float* x, const float* t_wv, float* t_xw);
 void trunk_in_jvp(hipStream_t, const Dims&, long long M, const float* xw, const float* wamb, const float* t_xw, const float* t_wamb, const Windows&, float* t_tin);
 void target_norm(hipStream_t, long long M, const float* t_alpha, const float* wv, float* out);
+void clip_gradients(hipStream_t, float* g, long long n, float max_val, float max_norm, float* sumsq_scratch);
 void adam(hipStream_t, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2);
 
 }  // namespace nerfds_train

@@ -729,6 +729,27 @@ __global__ void k_fill(float* __restrict__ p, long long n, float v) {
   if (i < n) p[i] = v;
 }
 
+// utils.clip_gradients (utils.py:32-47): clip by value, then scale so that the global L2 norm is at most max_norm
+__global__ void k_clip_val_sumsq(float* __restrict__ g, long long n, float max_val, float* __restrict__ sumsq) {
+  __shared__ float red[256];
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  float v = 0.f;
+  if (i < n) {
+    v = g[i];
+    if (max_val > 0.f) { v = fminf(fmaxf(v, -max_val), max_val); g[i] = v; }
+  }
+  red[threadIdx.x] = v * v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) atomicAdd(sumsq, red[0]);
+}
+__global__ void k_clip_norm(float* __restrict__ g, long long n, float max_norm, float eps, const float* __restrict__ sumsq) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float mult = fminf(1.0f, max_norm / (eps + sqrtf(*sumsq)));
+  g[i] *= mult;
+}
+
 static inline dim3 grid1(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 #define LAUNCH(kern, n, stream, ...) hipLaunchKernelGGL(kern, grid1(n), dim3(256), 0, stream, __VA_ARGS__)
 
@@ -810,6 +831,11 @@ void trunk_in_jvp(hipStream_t st, const Dims& D, long long M, const float* xw, c
   LAUNCH(k_trunk_in_jvp, 3 * M, st, D, M, xw, wamb, t_xw, t_wamb, W, t_tin);
 }
 void target_norm(hipStream_t st, long long M, const float* t_alpha, const float* wv, float* out) { LAUNCH(k_target_norm, M, st, M, t_alpha, wv, out); }
+void clip_gradients(hipStream_t st, float* g, long long n, float max_val, float max_norm, float* sumsq_scratch) {
+  (void)hipMemsetAsync(sumsq_scratch, 0, sizeof(float), st);
+  LAUNCH(k_clip_val_sumsq, n, st, g, n, max_val, sumsq_scratch);
+  if (max_norm > 0.f) LAUNCH(k_clip_norm, n, st, g, n, max_norm, 1e-7f, sumsq_scratch);
+}
 void adam(hipStream_t st, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2) {
   LAUNCH(k_adam, n, st, p, g, m1, m2, n, lr, b1, b2, eps, c1, c2);
 }

@@ -58,6 +58,7 @@ def _bind(lib):
   lib.nerfds_trainer_step.argtypes = [C.c_void_p, C.POINTER(N.Rays), C.c_void_p, C.POINTER(N.Extra), C.POINTER(N.Rand), C.POINTER(Objective),
                                       C.c_float, C.c_uint32, C.POINTER(C.c_float), C.c_void_p]
   lib.nerfds_trainer_apply.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+  lib.nerfds_trainer_clip_gradients.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
   lib.nerfds_trainer_target_norm.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
   lib.nerfds_trainer_last_error.argtypes = [C.c_void_p]
   lib.nerfds_trainer_last_error.restype = C.c_char_p
@@ -167,7 +168,8 @@ class Trainer:
   # -- one step ------------------------------------------------------------------------------------------
   def step(self, batch: Dict[str, Any], extra_params: Dict[str, Any], learning_rate: float = 0.0, *, t_rand=None, u_rand=None,
            mask_ratio: float = 1.0, near: Optional[float] = None, far: Optional[float] = None, grads_only: bool = False,
-           sigma_gradient: bool = False, objective: Optional[Dict[str, float]] = None,
+           sigma_gradient: bool = False, objective: Optional[Dict[str, float]] = None, grad_max_val: float = 0.0,
+           grad_max_norm: float = 0.0,
            stream: Optional[torch.cuda.Stream] = None) -> Dict[str, float]:
     dev = self.device
     f32 = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).to(dev, torch.float32).contiguous()
@@ -201,9 +203,10 @@ class Trainer:
     s = stream if stream is not None else torch.cuda.current_stream(dev)
     import torch.distributed as dist
     data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    clip = grad_max_val > 0.0 or grad_max_norm > 0.0
     rc = self._lib.nerfds_trainer_step(self._h, C.byref(rays), target.data_ptr(), C.byref(ex), C.byref(rnd), C.byref(ob) if ob is not None else None,
                                        float(learning_rate),
-                                       (GRADS_ONLY if (grads_only or data_parallel) else 0) | (SIGMA_GRAD if sigma_gradient else 0), loss,
+                                       (GRADS_ONLY if (grads_only or data_parallel or clip) else 0) | (SIGMA_GRAD if sigma_gradient else 0), loss,
                                        C.c_void_p(s.cuda_stream))
     self._last_rays = R
     if rc != 0:
@@ -211,8 +214,12 @@ class Trainer:
     if data_parallel:       # one rank per GPU, each with its own rays: ONE all-reduce of the 6 MB gradient vector (training.py:502)
       with torch.cuda.stream(s):
         allreduce_mean_(self.grads_tensor())
-      if not grads_only:
-        self.apply_gradients(learning_rate, s)
+    if clip:                # utils.clip_gradients after the pmean (training.py:502-504)
+      rc = self._lib.nerfds_trainer_clip_gradients(self._h, float(grad_max_val), float(grad_max_norm), C.c_void_p(s.cuda_stream))
+      if rc != 0:
+        raise RuntimeError(f'nerfds_trainer_clip_gradients failed ({rc})')
+    if (data_parallel or clip) and not grads_only:
+      self.apply_gradients(learning_rate, s)
     del keep
     fine, coarse = float(loss[0]), float(loss[1])
     two = self.cfg.num_fine_samples > 0

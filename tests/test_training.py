@@ -234,3 +234,26 @@ def test_norm_loss_second_order_matches_the_oracle(only_norm):
     if np.linalg.norm(w - base[name]) > 0.05 * max(np.linalg.norm(w), 1e-12):
       moved += 1
   assert moved >= 20, moved      # trunk, warp and hyper leaves all move (second-order path), not only the alpha head
+
+
+@pytest.mark.gpu
+def test_gradient_clipping_matches_utils_clip_gradients():
+  """utils.clip_gradients (utils.py:32-47): by value, then by global norm; applied between the gradient and the Adam update."""
+  from nerfds_amd.training import Trainer
+  cfg, params, batch, t, u = _problem(16, 8, 8)
+  tr = Trainer(cfg, params, max_rays=16)
+  tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True)
+  g = tr._download(1).astype(np.float64)
+  max_val, max_norm = float(np.abs(g).max() * 0.3), float(np.linalg.norm(g) * 0.1)
+  want = np.clip(g, -max_val, max_val)
+  want = want * min(1.0, max_norm / (1e-7 + np.sqrt((want ** 2).sum())))
+  tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, grad_max_val=max_val, grad_max_norm=max_norm)
+  got = tr._download(1)
+  np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-9 * np.abs(g).max())
+  assert abs(np.linalg.norm(got) - max_norm) < 1e-4 * max_norm
+  # and a clipped training step = clipped gradient fed to Adam
+  a, b = Trainer(cfg, params, max_rays=16), Trainer(cfg, params, max_rays=16)
+  a.step(batch, EX, 1e-3, t_rand=t, u_rand=u, grad_max_norm=max_norm)
+  b.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, grad_max_norm=max_norm)
+  b.apply_gradients(1e-3)
+  np.testing.assert_allclose(a._download(0), b._download(0), rtol=0, atol=1e-7)
