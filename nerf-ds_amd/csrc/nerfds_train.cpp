@@ -13,12 +13,14 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
 
 #include "nerfds.h"
 #include "train_kernels.h"
+#include "train_gemm.h"
 
 using namespace nerfds_train;
 
@@ -30,6 +32,7 @@ struct Leaf { std::string name; int64_t off; int rows, cols; };
 struct LayerP { int64_t w, b; int K, N; };
 struct MlpP { std::vector<LayerP> hidden; int in_dim = 0, width = 0, depth = 0, skip = -1; };
 struct Seg { const float* x; int ld; int K; float* dx; int dld; bool acc; };
+constexpr size_t WPACK_BYTES = 1 << 20;      // packed fragments of the largest layer (560 x 128 or 320 x 256 as hi / lo bf16) fit twice
 
 void window(float* out, int bands, float alpha) {   // model_utils.py:420-436
   for (int b = 0; b < 8; ++b) {
@@ -66,6 +69,9 @@ struct nerfds_trainer {
   bool keep_tangents = false;
   float* part = nullptr;    // split-K partials of the weight-gradient GEMMs
   size_t part_floats = 0;
+  void* wpack = nullptr;    // MFMA fragments of the layer being run (train_gemm.hip)
+  int num_cus = 256;
+  bool own_gemm = true;     // NERFDS_TRAIN_GEMM=rocblas switches the data GEMMs back to rocBLAS (A/B measurements)
   std::string err;
   // workspace views (set by carve())
   float *zc, *zf, *wc, *rs_scratch, *x, *mask_in, *mask_logit, *warp_in, *wv, *xw, *hyper_in, *wamb, *trunk_in, *bottv, *alphav, *sigma,
@@ -85,6 +91,7 @@ struct nerfds_trainer {
   }
   ~nerfds_trainer() {
     for (float* p : {theta, grad, m1, m2, ws, loss_dev, part, tws, terms_dev, nws}) if (p) (void)hipFree(p);
+    if (wpack) (void)hipFree(wpack);
     if (blas) (void)rocblas_destroy_handle(blas);
   }
 };
@@ -138,10 +145,29 @@ struct Run {
   hipStream_t st;
   int64_t M;
   bool ok = true;
+  // Set around the FORWARD of the warp field: its output moves the points that the 2^7-frequency posenc of the template
+  // reads, which amplifies the 16-bit operand rounding of the MFMA layers to ~1 % on the warp-field gradients (measured
+  // against the fp64 oracle).  Those layers keep fp32 GEMMs.
+  bool fp32_layers = false;
   void chk(rocblas_status s) { if (s != rocblas_status_success) ok = false; }
 
   // y[M x N] (ldy) = act(sum_s x_s W[rows of s] + b)
+  // the hand-written weight-stationary layer (train_gemm.hip); false = shape not covered
+  bool ws_layer(const std::vector<Seg>& segs, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, const float* bias, float* y,
+                int ldy, int64_t rows, bool relu, const float* mask_y, int ld_mask, int mask_div, bool accumulate) {
+    if (!t.own_gemm || fp32_layers || segs.size() > 4 || frag_bytes(in_dim, out_dim) > WPACK_BYTES) return false;
+    DenseArgs A{};
+    A.nseg = (int)segs.size();
+    for (int i = 0; i < A.nseg; ++i) A.seg[i] = {segs[i].x, segs[i].ld, segs[i].K};
+    A.k_total = in_dim; A.wfrag = t.wpack; A.bias = bias; A.y = y; A.ldy = ldy; A.n_out = out_dim; A.M = rows; A.relu = relu ? 1 : 0;
+    A.mask_y = mask_y; A.ld_mask = ld_mask; A.mask_div = mask_div; A.accumulate = accumulate ? 1 : 0;
+    A.zeros = static_cast<const char*>(t.wpack) + WPACK_BYTES;
+    if (!dense_ws_supported(A)) return false;
+    pack_frags(st, W, ldw, row0, in_dim, out_dim, transpose, t.wpack);
+    return dense_ws(st, A, t.num_cus);
+  }
   void dense_fwd(const LayerP& L, const std::vector<Seg>& segs, float* y, int ldy, bool relu) {
+    if (ws_layer(segs, t.theta + L.w, L.N, 0, L.K, L.N, 0, t.theta + L.b, y, ldy, M, relu, nullptr, 0, 1, false)) return;
     int k0 = 0;
     for (size_t i = 0; i < segs.size(); ++i) {
       chk(gemm_nn(t.blas, M, L.N, segs[i].K, segs[i].x, segs[i].ld, t.theta + L.w + (int64_t)k0 * L.N, L.N, i ? 1.f : 0.f, y, ldy));
@@ -177,7 +203,8 @@ struct Run {
     int k0 = 0;
     for (const Seg& s : segs) {
       weight_grad(s.x, s.ld, s.K, dy, ldy, L.N, t.grad + L.w + (int64_t)k0 * L.N);
-      if (s.dx) chk(gemm_nt(t.blas, M, L.N, s.K, dy, ldy, t.theta + L.w + (int64_t)k0 * L.N, L.N, s.acc ? 1.f : 0.f, s.dx, s.dld));
+      if (s.dx && !ws_layer({{dy, ldy, L.N, nullptr, 0, false}}, t.theta + L.w, L.N, k0, L.N, s.K, 1, nullptr, s.dx, s.dld, M, false, nullptr, 0, 1, s.acc))
+        chk(gemm_nt(t.blas, M, L.N, s.K, dy, ldy, t.theta + L.w + (int64_t)k0 * L.N, L.N, s.acc ? 1.f : 0.f, s.dx, s.dld));
       k0 += s.K;
     }
   }
@@ -347,9 +374,11 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   r.mlp_fwd(t.mask, t.mask_in, t.mask_h);
   r.dense_fwd(t.mask_out, {{t.mask_h.back(), t.mask.width, t.mask.width, nullptr, 0, false}}, t.mask_logit, 1, false);
   mask_post(st, D, R, S, t.mask_logit, rays->gt_mask, ex->mask_ratio, t.warp_in, t.hyper_in);
+  r.fp32_layers = true;
   r.mlp_fwd(t.warp, t.warp_in, t.warp_h);
   r.dense_fwd(t.warp_w, {{t.warp_h.back(), t.warp.width, t.warp.width, nullptr, 0, false}}, t.wv, 6, false);
   r.dense_fwd(t.warp_v, {{t.warp_h.back(), t.warp.width, t.warp.width, nullptr, 0, false}}, t.wv + 3, 6, false);
+  r.fp32_layers = false;
   se3_fwd(st, M, t.wv, t.x, t.xw);
   r.mlp_fwd(t.hyper, t.hyper_in, t.hyper_h);
   r.dense_fwd(t.hyper_out, {{t.hyper_h.back(), t.hyper.width, t.hyper.width, nullptr, 0, false}}, t.wamb, 2, false);
@@ -479,6 +508,13 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
   }
   (void)hipMemset(t->theta, 0, pbytes); (void)hipMemset(t->m1, 0, pbytes); (void)hipMemset(t->m2, 0, pbytes); (void)hipMemset(t->grad, 0, pbytes);
   carve(*t);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, t->device) == hipSuccess && prop.multiProcessorCount > 0) t->num_cus = prop.multiProcessorCount;
+    const char* g = getenv("NERFDS_TRAIN_GEMM");
+    t->own_gemm = !(g && std::string(g) == "rocblas");
+    if (hipMalloc(&t->wpack, WPACK_BYTES + 256) != hipSuccess || hipMemset(t->wpack, 0, WPACK_BYTES + 256) != hipSuccess) { g_train_error = "hipMalloc failed (weight fragments)"; return NERFDS_ENOMEM; }
+  }
   if (rocblas_create_handle(&t->blas) != rocblas_status_success) { g_train_error = "rocblas_create_handle failed"; return NERFDS_EDEVICE; }
   *out = t.release();
   return NERFDS_OK;

@@ -1,0 +1,32 @@
+// Hand-written weight-stationary dense layer of the training path (train_gemm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace nerfds_train {
+
+struct DenseSeg { const float* x; int ld; int k; };
+struct DenseArgs {
+  DenseSeg seg[4];          // row-major fp32 inputs, concatenated along k in this order
+  int nseg;
+  int k_total;              // sum of seg[].k
+  const void* wfrag;        // pack_frags() output for (k_total, n_out)
+  const float* bias;        // [n_out] or nullptr
+  float* y;                 // [M x n_out], row stride ldy
+  int ldy, n_out;
+  long long M;
+  int relu;                 // y = max(y, 0)
+  const float* mask_y;      // nullptr, or: y = 0 where mask_y[(row / mask_div) * ld_mask + n] <= 0 (ReLU backward of the consumer)
+  int ld_mask, mask_div;
+  int accumulate;           // y += result
+  const void* zeros;        // >= 16 zero bytes in device memory (source of the padding slots of the LDS-DMA path), or nullptr
+  int vec_in, vec_out;      // set by dense_ws(): 16-byte loads / stores are legal
+};
+
+void pack_frags(hipStream_t st, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, void* out);
+size_t frag_bytes(int in_dim, int out_dim);
+bool dense_ws_supported(const DenseArgs& A);
+// false = shape not covered (caller falls back to rocBLAS)
+bool dense_ws(hipStream_t st, const DenseArgs& A, int num_cus);
+
+}  // namespace nerfds_train

@@ -1,0 +1,450 @@
+// Weight-stationary dense layer for the training path: Y[M x N] = act(concat_s X_s[M x K_s] . W + b), hand-written for gfx950.
+//
+// Shape of the problem: M = rays x samples (up to 524 288), K and N <= 560 / 256.  The layer's whole weight matrix fits in the
+// register file of ONE workgroup (256 x 256 as split bf16 = 256 KiB of the CU's 512 KiB), so it is kept there: wave w of the
+// workgroup owns output tile w (32 output features) as MFMA A-fragments (32 rows x 16 k-slots, hi + lo bf16), and the workgroup
+// walks over 32-sample tiles of X.  A tile of X is read ONCE from HBM (fp32, row major, possibly several concatenated
+// segments), split into bf16 hi / lo and laid out in LDS as MFMA B-operands; every wave reads all of it (LDS traffic, not HBM)
+// and issues 3 MFMAs per fragment (hi.lo + lo.hi + hi.hi: fp32-level accuracy).  Bias, ReLU, an optional ReLU mask taken
+// from another activation (backward: dX . 1[y_prev > 0]) and accumulation into the destination are fused into the store.
+// The layer is therefore HBM bound: X read once, Y written once - what rocBLAS + separate bias / ReLU passes needed 3-4x for.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "train_gemm.h"
+
+namespace nerfds_train {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+extern __shared__ __attribute__((aligned(16))) char g_tile[];      // [KC][hi 1 KiB | lo 1 KiB]
+
+__device__ __forceinline__ unsigned short bf16_rne(float f) {
+  unsigned u = __builtin_bit_cast(unsigned, f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+
+// Packs the weights of one layer into fragment order: fragment (tile ot, chunk kc, part hi|lo), lane l = (h << 5) | m holds, for
+// output feature 32 ot + m, the 8 k-slots 16 kc + 8 h + i.  transpose = 0: value(k, n) = W[(row0 + k) * ldw + n] (forward:
+// `in` = rows of W); transpose = 1: value(k, n) = W[(row0 + n) * ldw + k] (backward data: in = columns of W, out = its rows).
+__global__ void k_pack_frags(const float* __restrict__ W, int ldw, int row0, int in_dim, int out_dim, int transpose, u32x4* __restrict__ out) {
+  const int KC = (in_dim + 15) / 16, tiles = (out_dim + 31) / 32;
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;       // (ot, kc, lane)
+  if (idx >= (long long)tiles * KC * 64) return;
+  const int lane = (int)(idx % 64), kc = (int)((idx / 64) % KC), ot = (int)(idx / (64LL * KC));
+  const int m = lane & 31, h = lane >> 5, n = 32 * ot + m;
+  unsigned short hi[8], lo[8];
+  for (int i = 0; i < 8; ++i) {
+    const int k = 16 * kc + 8 * h + i;
+    float v = 0.f;
+    if (k < in_dim && n < out_dim) v = transpose ? W[(size_t)(row0 + n) * ldw + k] : W[(size_t)(row0 + k) * ldw + n];
+    hi[i] = bf16_rne(v);
+    lo[i] = bf16_rne(v - bf16_f32(hi[i]));
+  }
+  u32x4 a, b;
+  for (int i = 0; i < 4; ++i) { a[i] = hi[2 * i] | ((unsigned)hi[2 * i + 1] << 16); b[i] = lo[2 * i] | ((unsigned)lo[2 * i + 1] << 16); }
+  const size_t base = ((size_t)(ot * KC + kc) * 2) * 64;
+  out[base + lane] = a;
+  out[base + 64 + lane] = b;
+}
+
+// Epilogue: this lane holds sample `row`, features 32 ot + 8 q + 4 h + j of the accumulator (q = 0..3, j = 0..3).
+__device__ __forceinline__ void store_tile(const DenseArgs& A, const f32x16& acc, long long row, int ot, int h) {
+  if (row >= A.M) return;
+  const size_t mrow = A.mask_y != nullptr ? (size_t)(A.mask_div == 3 ? row / 3 : row) * A.ld_mask : 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n0 = 32 * ot + 8 * q + 4 * h;
+    f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+    if (A.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    if (A.vec_out) {
+      if (n0 < A.n_out) {                                      // n_out is a multiple of 4 on this path
+        if (A.mask_y != nullptr) {
+          const f32x4 y = *reinterpret_cast<const f32x4*>(A.mask_y + mrow + n0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (!(y[j] > 0.f)) v[j] = 0.f;
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(A.y + (size_t)row * A.ldy + n0);
+        if (A.accumulate) v += *dst;
+        *dst = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + j;
+        if (n >= A.n_out) continue;
+        float x = v[j];
+        if (A.mask_y != nullptr && !(A.mask_y[mrow + n] > 0.f)) x = 0.f;
+        float* dst = A.y + (size_t)row * A.ldy + n;
+        *dst = A.accumulate ? (*dst + x) : x;
+      }
+    }
+  }
+}
+
+// Position of sample s inside the 32 x 16-byte row group of (chunk c, half hh): rotated by 2 c + hh so that the tile WRITE (lanes
+// along k: same s, different (c, hh)) spreads over the LDS banks; the B-operand READ (lanes along s) stays a permutation.
+__device__ __forceinline__ int slot_of(int c, int hh, int s) { return (s + 2 * c + hh) & 31; }
+
+template <int KC, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_dense_ws(const DenseArgs A) {
+  constexpr int R = 32 / WAVES;                  // rows of the X tile this wave fetches
+  constexpr int QPR = (KC * 4 + 63) / 64;        // float4 per lane per row
+  constexpr int TILE = KC * 2048;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  const int n_tiles = (A.n_out + 31) >> 5;
+  const bool computes = wave < n_tiles;
+  const int ot = computes ? wave : 0;
+  // this wave's weight slice, resident for the whole kernel
+  bf16x8 wh[KC], wl[KC];
+  const u32x4* wfrag = static_cast<const u32x4*>(A.wfrag);
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    const size_t base = ((size_t)(ot * KC + kc) * 2) * 64;
+    wh[kc] = __builtin_bit_cast(bf16x8, wfrag[base + lane]);
+    wl[kc] = __builtin_bit_cast(bf16x8, wfrag[base + 64 + lane]);
+  }
+  const int K = A.k_total;
+  const long long tiles = (A.M + 31) / 32;
+
+  // Where this lane's quads of a tile row come from does not depend on the row: resolved once (static indices only - a
+  // dynamically indexed kernel-argument array would be copied to scratch).  Segment starts are multiples of 4 (host check),
+  // so a quad never straddles two segments; nv = how many of its 4 floats exist.
+  const float* qbase[QPR];
+  int qld[QPR], qnv[QPR];
+#pragma unroll
+  for (int q = 0; q < QPR; ++q) {
+    int k = 4 * (lane + 64 * q);
+    const float* p = nullptr;
+    int ld = 0, nv = 0;
+    bool done = k >= K;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (!done && g < A.nseg) {
+        if (k < A.seg[g].k) { p = A.seg[g].x + k; ld = A.seg[g].ld; nv = A.seg[g].k - k < 4 ? A.seg[g].k - k : 4; done = true; }
+        else k -= A.seg[g].k;
+      }
+    }
+    qbase[q] = p; qld[q] = ld; qnv[q] = nv;
+  }
+  f32x16 bias;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
+    bias[r] = (A.bias != nullptr && n < A.n_out) ? A.bias[n] : 0.f;
+  }
+
+  f32x4 pf[R][QPR];
+  auto fetch = [&](long long tile) {             // HBM -> registers (fp32, row major)
+    const long long m0 = tile * 32;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const long long row = m0 + wave + WAVES * j;
+#pragma unroll
+      for (int q = 0; q < QPR; ++q) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (qnv[q] > 0 && row < A.M) {
+          const float* p = qbase[q] + (size_t)row * qld[q];
+          if (A.vec_in) v = *reinterpret_cast<const f32x4*>(p);
+          else {
+            v[0] = p[0];
+            if (qnv[q] > 1) v[1] = p[1];
+            if (qnv[q] > 2) v[2] = p[2];
+            if (qnv[q] > 3) v[3] = p[3];
+          }
+        }
+        pf[j][q] = v;
+      }
+    }
+  };
+  auto stage = [&](char* buf) {                  // registers -> LDS (bf16 hi / lo, B-operand order, rotated slots)
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int s = wave + WAVES * j;
+#pragma unroll
+      for (int q = 0; q < QPR; ++q) {
+        const int kk = 4 * (lane + 64 * q);
+        if (kk < KC * 16) {
+          unsigned short hi[4], lo[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { hi[e] = bf16_rne(pf[j][q][e]); lo[e] = bf16_rne(pf[j][q][e] - bf16_f32(hi[e])); }
+          const int c = kk >> 4, hh = (kk >> 3) & 1;
+          const int off = c * 2048 + hh * 512 + slot_of(c, hh, s) * 16 + (kk & 7) * 2;
+          typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+          u32x2 a = {hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16)};
+          u32x2 b = {lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16)};
+          *reinterpret_cast<u32x2*>(buf + off) = a;
+          *reinterpret_cast<u32x2*>(buf + off + 1024) = b;
+        }
+      }
+    }
+  };
+
+  long long tile = blockIdx.x;
+  if (tile < tiles) { fetch(tile); stage(g_tile); }
+  __syncthreads();
+  int cur = 0;
+  for (; tile < tiles; tile += gridDim.x, cur ^= 1) {
+    const long long next = tile + gridDim.x;
+    if (next < tiles) fetch(next);                // in flight during the MFMAs below
+    const char* buf = g_tile + cur * TILE;
+    if (computes) {
+      // ---- 32 output features x 32 samples ----
+      f32x16 acc = bias;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const int off = kc * 2048 + h * 512 + slot_of(kc, h, m) * 16;
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(buf + off));
+        const bf16x8 xl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(buf + off + 1024));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
+      }
+      store_tile(A, acc, tile * 32 + m, ot, h);
+    }
+    if (next < tiles) stage(g_tile + (cur ^ 1) * TILE);
+    __syncthreads();
+  }
+}
+
+// ---- the same layer with the X tile brought in by LDS-DMA ---------------------------------------------------------
+// The register-staged kernel above keeps one tile (16 .. 40 KiB) in flight per CU: a quarter of what HBM latency x bandwidth
+// needs.  Here the fp32 tile goes HBM -> LDS without passing through registers (global_load_lds_dwordx4), NS tiles deep, and
+// every wave converts the fp32 B-operand to bf16 hi / lo as it reads it (v_cvt_pk_bf16_f32: VALU work that hides under the
+// other wave's MFMAs).  LDS image of a tile: 16-byte slots, slot L = row * STRIDE + quad, STRIDE = K/4 + 1 (odd -> the read
+// "one quad pair of 32 different rows" touches every bank once).  The DMA writes 64 consecutive slots per instruction; which
+// (row, quad) a lane fetches is free, so the padding slot, rows past M and quads past K are fetched from a zero line.
+template <int KC, int WAVES> struct DmaShape {
+  static constexpr int KQ = KC * 4, STRIDE = KQ + 1, SLOTS = 32 * STRIDE;
+  static constexpr int NI = (SLOTS + 63) / 64, IPW = (NI + WAVES - 1) / WAVES;
+  static constexpr int TILE_BYTES = IPW * WAVES * 1024;
+  // 8 waves would each convert the whole tile to bf16 hi / lo on their own (VALU time ~ MFMA time): with COOP the workgroup
+  // converts it ONCE into a bf16 image (the register-staged kernel's layout) between two barriers, and the waves read that.
+  static constexpr bool COOP = WAVES == 8;
+  static constexpr int IMG_BYTES = COOP ? KC * 2048 : 0;
+  static constexpr int NS_FIT = (163840 - IMG_BYTES) / TILE_BYTES;
+  static constexpr int NS = NS_FIT > 4 ? 4 : NS_FIT;
+  static_assert(NS >= 2, "two stages of the X tile must fit the LDS");
+  static_assert((NS - 2) * IPW < 64, "vmcnt is a 6-bit counter");
+};
+
+template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {      // vmcnt(N) lgkmcnt(0), expcnt untouched
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (0 << 8));
+}
+
+template <int KC, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
+  typedef DmaShape<KC, WAVES> S;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  const int n_tiles = (A.n_out + 31) >> 5;
+  const bool computes = wave < n_tiles;
+  const int ot = computes ? wave : 0;
+  bf16x8 wh[KC], wl[KC];
+  const u32x4* wfrag = static_cast<const u32x4*>(A.wfrag);
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    const size_t base = ((size_t)(ot * KC + kc) * 2) * 64;
+    wh[kc] = __builtin_bit_cast(bf16x8, wfrag[base + lane]);
+    wl[kc] = __builtin_bit_cast(bf16x8, wfrag[base + 64 + lane]);
+  }
+  f32x16 bias;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
+    bias[r] = (A.bias != nullptr && n < A.n_out) ? A.bias[n] : 0.f;
+  }
+  const int K = A.k_total;
+  const long long tiles = (A.M + 31) / 32;
+  const int grid = gridDim.x;
+
+  // per DMA instruction of this wave: source of this lane's slot in the workgroup's first tile, and its advance per tile
+  const char* src[S::IPW];
+  int step[S::IPW], rowu[S::IPW];
+#pragma unroll
+  for (int u = 0; u < S::IPW; ++u) {
+    const int L = 64 * (wave + WAVES * u) + lane;
+    const int row = L / S::STRIDE, j = L - row * S::STRIDE;
+    int k = 4 * j;
+    const float* p = nullptr;
+    int ld = 0;
+    bool done = !(row < 32 && j < S::KQ && k < K);
+    bool found = false;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (!done && g < A.nseg) {
+        if (k < A.seg[g].k) { p = A.seg[g].x + k; ld = A.seg[g].ld; done = true; found = true; }
+        else k -= A.seg[g].k;
+      }
+    }
+    src[u] = found ? reinterpret_cast<const char*>(p + ((size_t)blockIdx.x * 32 + row) * ld) : nullptr;
+    step[u] = found ? grid * 32 * ld * 4 : 0;
+    rowu[u] = found ? row : 0x3fffffff;
+  }
+  auto issue = [&](long long tile, int stage) {
+#pragma unroll
+    for (int u = 0; u < S::IPW; ++u) {
+      const bool ok = tile * 32 + rowu[u] < A.M;
+      const char* g = ok ? src[u] : reinterpret_cast<const char*>(A.zeros);
+      const int off = __builtin_amdgcn_readfirstlane(stage * S::TILE_BYTES + (wave + WAVES * u) * 1024);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(g_tile + off), 16, 0, 0);
+      src[u] += step[u];
+    }
+  };
+
+  wait_vm_lgkm0<0>();                              // the weight / bias loads above: nothing but DMA on the VM counter from here
+  long long tile = blockIdx.x;
+#pragma unroll
+  for (int s = 0; s < S::NS - 1; ++s) issue(tile + (long long)s * grid, s);
+  int it = 0;
+  for (; tile < tiles; tile += grid, ++it) {
+    // tile `it` of this workgroup: my DMAs of it have landed (NS - 2 younger tiles may be in flight), my LDS reads of the
+    // previous tile are done; past the barrier the same holds for every wave, so its slot can be refilled.
+    wait_vm_lgkm0<(S::NS - 2) * S::IPW>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issue(tile + (long long)(S::NS - 1) * grid, (it + S::NS - 1) % S::NS);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S::COOP) {
+      // fp32 stage -> bf16 image, 32 rows x 2 KC octets, lanes along the rows on both sides (odd row stride / rotated slots)
+      const char* stg = g_tile + (it % S::NS) * S::TILE_BYTES;
+      char* img = g_tile + S::NS * S::TILE_BYTES;
+#pragma unroll
+      for (int j = 0; j < (2 * KC + 2 * WAVES - 1) / (2 * WAVES); ++j) {
+        const int pair = (threadIdx.x >> 5) + 2 * WAVES * j;
+        if (pair < 2 * KC) {
+          const int kc = pair >> 1, hh = pair & 1;
+          const char* p = stg + (m * S::STRIDE + 4 * kc + 2 * hh) * 16;
+          const f32x4 f0 = *reinterpret_cast<const f32x4*>(p), f1 = *reinterpret_cast<const f32x4*>(p + 16);
+          bf16x8 xh, xl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const __bf16 a = (__bf16)f0[e], b = (__bf16)f1[e];
+            xh[e] = a; xh[4 + e] = b;
+            xl[e] = (__bf16)(f0[e] - (float)a); xl[4 + e] = (__bf16)(f1[e] - (float)b);
+          }
+          char* q = img + kc * 2048 + hh * 512 + slot_of(kc, hh, m) * 16;
+          *reinterpret_cast<u32x4*>(q) = __builtin_bit_cast(u32x4, xh);
+          *reinterpret_cast<u32x4*>(q + 1024) = __builtin_bit_cast(u32x4, xl);
+        }
+      }
+      wait_vm_lgkm0<63>();                           // lgkmcnt(0): my image writes are done (the VM counter is not waited on)
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (computes) {
+        f32x16 acc = bias;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const int off = kc * 2048 + h * 512 + slot_of(kc, h, m) * 16;
+          const bf16x8 xh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + off));
+          const bf16x8 xl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + off + 1024));
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
+        }
+        store_tile(A, acc, tile * 32 + m, ot, h);
+      }
+    } else
+    if (computes) {
+      const char* buf = g_tile + (it % S::NS) * S::TILE_BYTES + (m * S::STRIDE + 2 * h) * 16;
+      f32x16 acc = bias;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const f32x4 f0 = *reinterpret_cast<const f32x4*>(buf + kc * 64);
+        const f32x4 f1 = *reinterpret_cast<const f32x4*>(buf + kc * 64 + 16);
+        bf16x8 xh, xl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const __bf16 a = (__bf16)f0[e], b = (__bf16)f1[e];
+          xh[e] = a; xh[4 + e] = b;
+          xl[e] = (__bf16)(f0[e] - (float)a); xl[4 + e] = (__bf16)(f1[e] - (float)b);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
+      }
+      store_tile(A, acc, tile * 32 + m, ot, h);
+    }
+  }
+  wait_vm_lgkm0<0>();                              // DMAs issued past the last tile (zero line) before the LDS is released
+}
+
+void pack_frags(hipStream_t st, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, void* out) {
+  const int KC = (in_dim + 15) / 16, tiles = (out_dim + 31) / 32;
+  const long long n = (long long)tiles * KC * 64;
+  hipLaunchKernelGGL(k_pack_frags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, ldw, row0, in_dim, out_dim, transpose,
+                     static_cast<u32x4*>(out));
+}
+size_t frag_bytes(int in_dim, int out_dim) { return (size_t)((out_dim + 31) / 32) * ((in_dim + 15) / 16) * 2048; }
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int KC, int WAVES> static void launch(hipStream_t st, DenseArgs A, int num_cus) {
+  const long long tiles = (A.M + 31) / 32;
+  A.vec_in = 1;
+  for (int g = 0; g < A.nseg; ++g)
+    if (A.seg[g].k % 4 || A.seg[g].ld % 4 || !aligned16(A.seg[g].x)) A.vec_in = 0;
+  A.vec_out = (A.n_out % 4 == 0 && A.ldy % 4 == 0 && aligned16(A.y) && (A.mask_y == nullptr || (A.ld_mask % 4 == 0 && aligned16(A.mask_y)))) ? 1 : 0;
+  const bool dma = A.vec_in && A.zeros != nullptr && getenv("NERFDS_WS_NODMA") == nullptr;
+  if (dma) {
+    typedef DmaShape<KC, WAVES> S;
+    const int lds = S::NS * S::TILE_BYTES + S::IMG_BYTES;
+    auto kern = k_dense_dma<KC, WAVES>;
+    static int per_cu = 0;                                        // resident workgroups per CU (registers / LDS decide)
+    if (per_cu == 0) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      int n = 0;
+      per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 64 * WAVES, lds) == hipSuccess && n > 0) ? n : 1;
+    }
+    const long long want = (long long)num_cus * per_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < want ? tiles : want)), dim3(64 * WAVES), lds, st, A);
+    return;
+  }
+  const int lds = 2 * KC * 2048;
+  auto kern = k_dense_ws<KC, WAVES>;
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    int n = 0;
+    per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 64 * WAVES, lds) == hipSuccess && n > 0) ? n : 1;
+  }
+  const long long want = (long long)num_cus * per_cu;
+  const int grid = (int)(tiles < want ? tiles : want);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, st, A);
+}
+
+bool dense_ws_supported(const DenseArgs& A) {
+  if (A.n_out > 256 || A.n_out < 1 || A.M <= 0 || A.nseg < 1 || A.nseg > 4) return false;
+  const int KC = (A.k_total + 15) / 16;
+  if (KC > 21 && A.n_out > 128) return false;      // the slice of a long layer needs a 512-register wave: at most 4 waves
+  if (A.mask_div != 1 && A.mask_div != 3) return false;
+  for (int g = 0, k0 = 0; g < A.nseg; ++g) {        // a quad of 4 consecutive k never straddles two segments
+    if (k0 % 4) return false;
+    k0 += A.seg[g].k;
+  }
+  return (KC >= 1 && KC <= 21) || KC == 35;
+}
+
+bool dense_ws(hipStream_t st, const DenseArgs& A, int num_cus) {
+  if (!dense_ws_supported(A)) return false;
+  const int KC = (A.k_total + 15) / 16;
+  const bool wide = A.n_out > 128;
+#define NERFDS_KC(n) case n: if (wide) launch<n, 8>(st, A, num_cus); else launch<n, 4>(st, A, num_cus); return true;
+  switch (KC) {
+    NERFDS_KC(1) NERFDS_KC(2) NERFDS_KC(3) NERFDS_KC(4) NERFDS_KC(5) NERFDS_KC(6) NERFDS_KC(7) NERFDS_KC(8) NERFDS_KC(9) NERFDS_KC(10)
+    NERFDS_KC(11) NERFDS_KC(12) NERFDS_KC(13) NERFDS_KC(14) NERFDS_KC(15) NERFDS_KC(16) NERFDS_KC(17) NERFDS_KC(18) NERFDS_KC(19)
+    NERFDS_KC(20) NERFDS_KC(21)
+    case 35: launch<35, 4>(st, A, num_cus); return true;
+    default: return false;
+  }
+#undef NERFDS_KC
+}
+
+}  // namespace nerfds_train

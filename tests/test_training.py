@@ -52,9 +52,24 @@ def test_oracle_gradient_matches_finite_differences_where_no_stop_gradient_appli
     np.testing.assert_allclose(g[idx], (vals[0] - vals[1]) / 2e-6, rtol=1e-4)
 
 
+# The trainer's data GEMMs run in one of two modes, and every gradient test runs in both:
+#   'mfma'    the hand-written weight-stationary layers (train_gemm.hip): split-bf16 operands = 16-bit mantissas, fp32 accumulation.
+#             That is finer than what the reference's own matmuls use at jnp's default precision (one bf16 pass on TPU, TF32 on
+#             NVIDIA GPUs), but coarser than fp32: through the 2^7 posenc frequencies of the warped points the warp-field leaves
+#             differ from the fp64 oracle by up to 6e-3 relative L2 - the bound for this mode is 1e-2;
+#   'rocblas' fp32 library GEMMs (NERFDS_TRAIN_GEMM=rocblas), the strict pin: 4e-3 / 5e-3.
+L2_TOL = {'mfma': 1e-2, 'rocblas': 4e-3}
+
+
+@pytest.fixture(params=['mfma', 'rocblas'])
+def gemm(request, monkeypatch):
+  monkeypatch.setenv('NERFDS_TRAIN_GEMM', request.param)
+  return request.param
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('R,Nc,Nf,ratio', [(6, 8, 8, 1.0), (64, 16, 16, 0.7), (33, 12, 0, 1.0)])
-def test_hip_gradients_match_autograd_oracle(R, Nc, Nf, ratio):
+def test_hip_gradients_match_autograd_oracle(R, Nc, Nf, ratio, gemm):
   from nerfds_amd.training import Trainer
   from oracle import train_oracle as T
   cfg, params, batch, t, u = _problem(R, Nc, Nf)
@@ -80,7 +95,10 @@ def test_hip_gradients_match_autograd_oracle(R, Nc, Nf, ratio):
     err = np.abs(g - w).max() / scale
     noise = np.abs(w32[name] - w).max() / scale
     l2 = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
-    assert l2 < 4e-3 and err < max(1e-2, 6 * noise), f'{name}: l2 {l2:.2e}, max {err:.2e} (oracle fp32 noise {noise:.2e})'
+    # a ReLU whose pre-activation is ~0 can land on the other side with 16-bit operands; at 96 .. 2048 samples one flipped
+    # unit is visible in the max-abs error of a leaf (not in its L2 error), so the mfma mode bounds max-abs at 5e-2
+    max_tol = max(1e-2, 6 * noise) if gemm == 'rocblas' else 5e-2
+    assert l2 < L2_TOL[gemm] and err < max_tol, f'{name}: l2 {l2:.2e}, max {err:.2e} (oracle fp32 noise {noise:.2e})'
   # the normal channels of the alpha head receive no gradient (stop_gradient, models.py:1132-1133)
   for lv in (['coarse', 'fine'] if Nf else ['coarse']):
     assert np.abs(got[f'nerf_mlps_{lv}/alpha_mlp/logit/kernel'][:, 1:]).max() == 0.0
@@ -177,7 +195,7 @@ OBJECTIVE = dict(warp_reg_loss_weight=0.001, warp_reg_loss_alpha=-2.0, warp_reg_
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('sharp', [True, False])
-def test_auxiliary_losses_match_the_oracle(sharp):
+def test_auxiliary_losses_match_the_oracle(sharp, gemm):
   """warp regulariser, back-facing regulariser and 3-D mask supervision of the reference objective (everything but the
   second-order norm loss): loss terms and the full gradient vs autograd."""
   from nerfds_amd.training import Trainer
@@ -199,7 +217,7 @@ def test_auxiliary_losses_match_the_oracle(sharp):
   for name, w in want.items():
     g = got[name].reshape(w.shape)
     l2 = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
-    assert l2 < 5e-3, (name, l2)
+    assert l2 < max(5e-3, L2_TOL[gemm]), (name, l2)
   # the normal channels of the alpha head now DO receive gradient (back-facing regulariser), the mask net too
   assert np.abs(got['nerf_mlps_fine/alpha_mlp/logit/kernel'][:, 1:]).max() > 0
   assert np.abs(got['mask_mlp/MLP_0/hidden_0/kernel']).max() > 0
@@ -207,7 +225,7 @@ def test_auxiliary_losses_match_the_oracle(sharp):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('only_norm', [True, False])
-def test_norm_loss_second_order_matches_the_oracle(only_norm):
+def test_norm_loss_second_order_matches_the_oracle(only_norm, gemm):
   """training.py:323-332: mean(w |n - target_norm|) with NO stop_gradient on target_norm = d sigma / d x, i.e. second order in
   the warp / hyper / trunk weights: backward of the forward-mode tangent pass, vs torch double-backward in the oracle."""
   from nerfds_amd.training import Trainer
@@ -229,7 +247,7 @@ def test_norm_loss_second_order_matches_the_oracle(only_norm):
   for name, w in want.items():
     g = got[name].reshape(w.shape)
     l2 = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
-    assert l2 < 5e-3, (name, l2)
+    assert l2 < max(5e-3, L2_TOL[gemm]), (name, l2)
     # the norm loss must actually have contributed to this leaf's gradient for the check to mean something
     if np.linalg.norm(w - base[name]) > 0.05 * max(np.linalg.norm(w), 1e-12):
       moved += 1

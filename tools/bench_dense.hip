@@ -1,0 +1,64 @@
+// Micro-benchmark + CPU check of the weight-stationary training layer (train_gemm.hip).  Dev tool:
+//   hipcc -O3 --offload-arch=gfx950 -Inerf-ds_amd/csrc tools/bench_dense.hip nerf-ds_amd/csrc/train_gemm.hip -o nerf-ds_amd/csrc/build/bench_dense
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "train_gemm.h"
+using namespace nerfds_train;
+
+static float frand() { return (float)rand() / RAND_MAX * 2.f - 1.f; }
+
+int main(int argc, char** argv) {
+  struct Shape { int k1, k2, n; bool relu, mask, acc; };
+  const Shape shapes[] = {{128, 0, 128, true, false, false}, {256, 0, 256, true, false, false}, {256, 52, 256, true, false, false},
+                          {128, 33, 128, true, false, false}, {64, 0, 64, true, false, false}, {256, 0, 4, false, false, false},
+                          {256, 0, 256, false, true, false}, {128, 0, 128, false, true, true}, {536, 24, 128, true, false, false}};
+  const long long M = argc > 1 ? atoll(argv[1]) : 524288;
+  hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, 0);
+  for (const Shape& s : shapes) {
+    const int K = s.k1 + s.k2;
+    float *x1, *x2 = nullptr, *y, *w, *b, *mk; void* frag;
+    (void)hipMalloc(&x1, M * s.k1 * 4); if (s.k2) (void)hipMalloc(&x2, M * s.k2 * 4);
+    (void)hipMalloc(&y, M * s.n * 4); (void)hipMalloc(&mk, M * s.n * 4); (void)hipMalloc(&w, K * s.n * 4); (void)hipMalloc(&b, s.n * 4);
+    (void)hipMalloc(&frag, frag_bytes(K, s.n));
+    const long long Mc = 100;     // rows checked on the CPU
+    std::vector<float> hx1(M * s.k1), hx2((size_t)M * s.k2), hw(K * s.n), hb(s.n), hm(M * s.n), hy0(M * s.n);
+    for (auto& v : hx1) v = frand(); for (auto& v : hx2) v = frand(); for (auto& v : hw) v = frand() * 0.1f; for (auto& v : hb) v = frand();
+    for (auto& v : hm) v = frand(); for (auto& v : hy0) v = frand();
+    (void)hipMemcpy(x1, hx1.data(), hx1.size() * 4, hipMemcpyHostToDevice); if (s.k2) (void)hipMemcpy(x2, hx2.data(), hx2.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(mk, hm.data(), hm.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(y, hy0.data(), hy0.size() * 4, hipMemcpyHostToDevice);
+    DenseArgs A{};
+    A.seg[0] = {x1, s.k1, s.k1}; A.nseg = 1; if (s.k2) { A.seg[1] = {x2, s.k2, s.k2}; A.nseg = 2; }
+    A.k_total = K; A.wfrag = frag; A.bias = b; A.y = y; A.ldy = s.n; A.n_out = s.n; A.M = M; A.relu = s.relu; A.mask_y = s.mask ? mk : nullptr;
+    A.ld_mask = s.n; A.mask_div = 1; A.accumulate = s.acc;
+    void* zeros; (void)hipMalloc(&zeros, 256); (void)hipMemset(zeros, 0, 256); A.zeros = zeros;
+    pack_frags(nullptr, w, s.n, 0, K, s.n, 0, frag);
+    if (!dense_ws(nullptr, A, prop.multiProcessorCount)) { printf("shape %d+%d -> %d not supported\n", s.k1, s.k2, s.n); continue; }
+    (void)hipDeviceSynchronize();
+    std::vector<float> hy(Mc * s.n);
+    (void)hipMemcpy(hy.data(), y, hy.size() * 4, hipMemcpyDeviceToHost);
+    double worst = 0;
+    for (long long r = 0; r < Mc; ++r) for (int n = 0; n < s.n; ++n) {
+      double a = hb[n];
+      for (int k = 0; k < s.k1; ++k) a += (double)hx1[r * s.k1 + k] * hw[k * s.n + n];
+      for (int k = 0; k < s.k2; ++k) a += (double)hx2[r * s.k2 + k] * hw[(s.k1 + k) * s.n + n];
+      if (s.relu) a = a > 0 ? a : 0;
+      if (s.mask && !(hm[r * s.n + n] > 0)) a = 0;
+      if (s.acc) a += hy0[r * s.n + n];
+      worst = std::fmax(worst, std::fabs(a - hy[r * s.n + n]));
+    }
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int reps = 20;
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < reps; ++i) dense_ws(nullptr, A, prop.multiProcessorCount);
+    (void)hipEventRecord(e1, nullptr); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    const double bytes = (double)M * (K + s.n * (1 + (s.mask ? 1 : 0) + (s.acc ? 1 : 0))) * 4;
+    printf("M=%lld K=%d+%d N=%d relu=%d mask=%d acc=%d: %.3f ms  %.0f GB/s  max|err|=%.2e\n", M, s.k1, s.k2, s.n, s.relu, s.mask, s.acc, ms, bytes / ms / 1e6, worst);
+    (void)hipFree(x1); if (x2) (void)hipFree(x2); (void)hipFree(y); (void)hipFree(mk); (void)hipFree(w); (void)hipFree(b); (void)hipFree(frag);
+  }
+  return 0;
+}
