@@ -31,7 +31,11 @@ thread_local std::string g_train_error;
 struct Leaf { std::string name; int64_t off; int rows, cols; };
 struct LayerP { int64_t w, b; int K, N; };
 struct MlpP { std::vector<LayerP> hidden; int in_dim = 0, width = 0, depth = 0, skip = -1; };
-struct Seg { const float* x; int ld; int K; float* dx; int dld; bool acc; };
+struct Seg {
+  const float* x; int ld; int K; float* dx; int dld; bool acc;
+  const float* dx_relu_y = nullptr;   // dx is the dY of a ReLU layer whose output is dx_relu_y: mask it and add its column sums to dx_bias_grad
+  float* dx_bias_grad = nullptr;
+};
 constexpr size_t WPACK_BYTES = 1 << 20;      // packed fragments of the largest layer (560 x 128 or 320 x 256 as hi / lo bf16) fit twice
 
 void window(float* out, int bands, float alpha) {   // model_utils.py:420-436
@@ -154,14 +158,14 @@ struct Run {
   // y[M x N] (ldy) = act(sum_s x_s W[rows of s] + b)
   // the hand-written weight-stationary layer (train_gemm.hip); false = shape not covered
   bool ws_layer(const std::vector<Seg>& segs, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, const float* bias, float* y,
-                int ldy, int64_t rows, bool relu, const float* mask_y, int ld_mask, int mask_div, bool accumulate) {
+                int ldy, int64_t rows, bool relu, const float* mask_y, int ld_mask, int mask_div, bool accumulate, float* colsum = nullptr) {
     if (!t.own_gemm || fp32_layers || segs.size() > 4 || frag_bytes(in_dim, out_dim) > WPACK_BYTES) return false;
     DenseArgs A{};
     A.nseg = (int)segs.size();
     for (int i = 0; i < A.nseg; ++i) A.seg[i] = {segs[i].x, segs[i].ld, segs[i].K};
     A.k_total = in_dim; A.wfrag = t.wpack; A.bias = bias; A.y = y; A.ldy = ldy; A.n_out = out_dim; A.M = rows; A.relu = relu ? 1 : 0;
     A.mask_y = mask_y; A.ld_mask = ld_mask; A.mask_div = mask_div; A.accumulate = accumulate ? 1 : 0;
-    A.zeros = static_cast<const char*>(t.wpack) + WPACK_BYTES;
+    A.zeros = static_cast<const char*>(t.wpack) + WPACK_BYTES; A.colsum = colsum;
     if (!dense_ws_supported(A)) return false;
     pack_frags(st, W, ldw, row0, in_dim, out_dim, transpose, t.wpack);
     return dense_ws(st, A, t.num_cus);
@@ -181,6 +185,10 @@ struct Run {
   // SLAB rows, each slab is one problem of a strided-batched GEMM into a partial, and a small kernel adds the partials.
   void weight_grad(const float* X, int ldx, int K, const float* dy, int ldy, int N, float* dW, int64_t rows = -1) {
     const int64_t M = rows < 0 ? this->M : rows;
+    if (t.own_gemm) {                                   // hand-written MFMA kernel (train_gemm.hip): one partial per workgroup
+      WgradArgs A{X, ldx, K, dy, ldy, N, M, nullptr, dW, static_cast<const char*>(t.wpack) + WPACK_BYTES};
+      if (wgrad_supported(A) && wgrad(st, A, wgrad_grid(A, t.num_cus))) return;
+    }
     const int64_t slabs = M / SLAB;
     const float one = 1.f, zero = 0.f;
     if (slabs >= 2 && (size_t)slabs * K * N <= t.part_floats) {
@@ -194,19 +202,29 @@ struct Run {
       chk(gemm_tn(t.blas, M, N, K, X, ldx, dy, ldy, 1.f, dW, N));
     }
   }
-  void dense_bwd(const LayerP& L, const std::vector<Seg>& segs, float* dy, int ldy, const float* relu_y) {
-    if (relu_y && L.N <= 256) relu_bwd_colsum(st, dy, relu_y, M, L.N, t.grad + L.b);      // mask with y > 0, db[N] += dY^T 1
-    else {
-      if (relu_y) relu_bwd(st, dy, relu_y, M * L.N);
-      colsum_add(st, dy, M, L.N, ldy, t.grad + L.b);
+  // premasked: the kernel that produced dy already applied this layer's ReLU mask and added the bias gradient.
+  // Returns true when the dx of the segment that asked for it (Seg::dx_relu_y) was masked / column-summed by the MFMA layer.
+  bool dense_bwd(const LayerP& L, const std::vector<Seg>& segs, float* dy, int ldy, const float* relu_y, bool premasked = false) {
+    if (!premasked) {
+      if (relu_y && L.N <= 256) relu_bwd_colsum(st, dy, relu_y, M, L.N, t.grad + L.b);      // mask with y > 0, db[N] += dY^T 1
+      else {
+        if (relu_y) relu_bwd(st, dy, relu_y, M * L.N);
+        colsum_add(st, dy, M, L.N, ldy, t.grad + L.b);
+      }
     }
+    bool fused = false;
     int k0 = 0;
     for (const Seg& s : segs) {
       weight_grad(s.x, s.ld, s.K, dy, ldy, L.N, t.grad + L.w + (int64_t)k0 * L.N);
-      if (s.dx && !ws_layer({{dy, ldy, L.N, nullptr, 0, false}}, t.theta + L.w, L.N, k0, L.N, s.K, 1, nullptr, s.dx, s.dld, M, false, nullptr, 0, 1, s.acc))
-        chk(gemm_nt(t.blas, M, L.N, s.K, dy, ldy, t.theta + L.w + (int64_t)k0 * L.N, L.N, s.acc ? 1.f : 0.f, s.dx, s.dld));
+      if (s.dx) {
+        const bool want = s.dx_relu_y != nullptr && !s.acc;
+        if (ws_layer({{dy, ldy, L.N, nullptr, 0, false}}, t.theta + L.w, L.N, k0, L.N, s.K, 1, nullptr, s.dx, s.dld, M, false, want ? s.dx_relu_y : nullptr,
+                     s.dld, 1, s.acc, want ? s.dx_bias_grad : nullptr)) fused = fused || want;
+        else chk(gemm_nt(t.blas, M, L.N, s.K, dy, ldy, t.theta + L.w + (int64_t)k0 * L.N, L.N, s.acc ? 1.f : 0.f, s.dx, s.dld));
+      }
       k0 += s.K;
     }
+    return fused;
   }
   // tangents (3 rows per sample, no bias): y[3M x N] = sum_s t_s W[rows of s]
   void dense_jvp(const LayerP& L, const std::vector<Seg>& segs, float* y, int ldy) {
@@ -262,12 +280,13 @@ struct Run {
   }
   // cur holds d loss / d h[depth-1] on entry; other is a second [M x width] buffer; d_in0 receives d loss / d in0
   void mlp_bwd(const MlpP& m, const float* in0, const std::vector<float*>& h, float* cur, float* other, float* d_in0) {
-    bool in0_written = false;
+    bool in0_written = false, premasked = false;
     for (int l = m.depth - 1; l >= 0; --l) {
       std::vector<Seg> segs;
-      if (l > 0) segs.push_back({h[l - 1], m.width, m.width, other, m.width, false});
+      // d h[l-1] is the dY of layer l-1: its ReLU mask and bias gradient ride on the epilogue of the kernel that writes it
+      if (l > 0) segs.push_back({h[l - 1], m.width, m.width, other, m.width, false, h[l - 1], t.grad + m.hidden[l - 1].b});
       if (l == 0 || l == m.skip) { segs.push_back({in0, m.in_dim, m.in_dim, d_in0, m.in_dim, in0_written}); in0_written = true; }
-      dense_bwd(m.hidden[l], segs, cur, m.width, h[l]);
+      premasked = dense_bwd(m.hidden[l], segs, cur, m.width, h[l], premasked);
       std::swap(cur, other);
     }
   }

@@ -19,9 +19,24 @@ struct DenseArgs {
   const float* mask_y;      // nullptr, or: y = 0 where mask_y[(row / mask_div) * ld_mask + n] <= 0 (ReLU backward of the consumer)
   int ld_mask, mask_div;
   int accumulate;           // y += result
+  float* colsum;            // nullptr, or [n_out]: += column sums of the (masked) result - the bias gradient of the layer that consumes y as dY
   const void* zeros;        // >= 16 zero bytes in device memory (source of the padding slots of the LDS-DMA path), or nullptr
   int vec_in, vec_out;      // set by dense_ws(): 16-byte loads / stores are legal
 };
+
+// Weight gradient dW[K x N] += X[M x K]^T dY[M x N] (contraction over the M samples).
+struct WgradArgs {
+  const float* x; int ldx; int k;      // K <= 256, multiple of 4, ldx multiple of 4, 16-byte aligned
+  const float* dy; int ldy; int n;     // N <= 256, same conditions
+  long long M;
+  float* part;                         // [grid][K x N] per-workgroup partial sums (the caller reduces them), used when dw == nullptr
+  float* dw;                           // [K x N]: every workgroup adds its partial with hardware float atomics
+  const void* zeros;
+};
+bool wgrad_supported(const WgradArgs& A);
+// Launches on `grid` workgroups chosen by wgrad_grid(); part must hold grid * K * N floats.  false = shape not covered.
+int wgrad_grid(const WgradArgs& A, int num_cus);
+bool wgrad(hipStream_t st, const WgradArgs& A, int grid);
 
 void pack_frags(hipStream_t st, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, void* out);
 size_t frag_bytes(int in_dim, int out_dim);

@@ -55,7 +55,7 @@ __global__ void k_pack_frags(const float* __restrict__ W, int ldw, int row0, int
 }
 
 // Epilogue: this lane holds sample `row`, features 32 ot + 8 q + 4 h + j of the accumulator (q = 0..3, j = 0..3).
-__device__ __forceinline__ void store_tile(const DenseArgs& A, const f32x16& acc, long long row, int ot, int h) {
+__device__ __forceinline__ void store_tile(const DenseArgs& A, const f32x16& acc, long long row, int ot, int h, f32x16& csum) {
   if (row >= A.M) return;
   const size_t mrow = A.mask_y != nullptr ? (size_t)(A.mask_div == 3 ? row / 3 : row) * A.ld_mask : 0;
 #pragma unroll
@@ -70,6 +70,7 @@ __device__ __forceinline__ void store_tile(const DenseArgs& A, const f32x16& acc
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (!(y[j] > 0.f)) v[j] = 0.f;
         }
+        csum[4 * q] += v[0]; csum[4 * q + 1] += v[1]; csum[4 * q + 2] += v[2]; csum[4 * q + 3] += v[3];
         f32x4* dst = reinterpret_cast<f32x4*>(A.y + (size_t)row * A.ldy + n0);
         if (A.accumulate) v += *dst;
         *dst = v;
@@ -81,10 +82,24 @@ __device__ __forceinline__ void store_tile(const DenseArgs& A, const f32x16& acc
         if (n >= A.n_out) continue;
         float x = v[j];
         if (A.mask_y != nullptr && !(A.mask_y[mrow + n] > 0.f)) x = 0.f;
+        csum[4 * q + j] += x;
         float* dst = A.y + (size_t)row * A.ldy + n;
         *dst = A.accumulate ? (*dst + x) : x;
       }
     }
+  }
+}
+
+// End of the kernel: the per-lane column sums of this wave's 32 features (16 per lane, over the samples the lane stored) are
+// reduced over the 32 lanes of a half and added to colsum[] (one atomic per feature and wave).
+__device__ __forceinline__ void flush_colsum(const DenseArgs& A, f32x16 csum, int ot, int h, int m) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = csum[r];
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    const int n = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (m == 0 && n < A.n_out) atomicAdd(A.colsum + n, v);
   }
 }
 
@@ -113,6 +128,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_ws(const DenseArgs A) {
   }
   const int K = A.k_total;
   const long long tiles = (A.M + 31) / 32;
+  f32x16 csum = {};
 
   // Where this lane's quads of a tile row come from does not depend on the row: resolved once (static indices only - a
   // dynamically indexed kernel-argument array would be copied to scratch).  Segment starts are multiples of 4 (host check),
@@ -207,11 +223,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_ws(const DenseArgs A) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
       }
-      store_tile(A, acc, tile * 32 + m, ot, h);
+      store_tile(A, acc, tile * 32 + m, ot, h, csum);
     }
     if (next < tiles) stage(g_tile + (cur ^ 1) * TILE);
     __syncthreads();
   }
+  if (A.colsum != nullptr && computes) flush_colsum(A, csum, ot, h, m);
 }
 
 // ---- the same layer with the X tile brought in by LDS-DMA ---------------------------------------------------------
@@ -264,6 +281,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
   const int K = A.k_total;
   const long long tiles = (A.M + 31) / 32;
   const int grid = gridDim.x;
+  f32x16 csum = {};
 
   // per DMA instruction of this wave: source of this lane's slot in the workgroup's first tile, and its advance per tile
   const char* src[S::IPW];
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
         }
-        store_tile(A, acc, tile * 32 + m, ot, h);
+        store_tile(A, acc, tile * 32 + m, ot, h, csum);
       }
     } else
     if (computes) {
@@ -370,10 +388,153 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
       }
-      store_tile(A, acc, tile * 32 + m, ot, h);
+      store_tile(A, acc, tile * 32 + m, ot, h, csum);
     }
   }
   wait_vm_lgkm0<0>();                              // DMAs issued past the last tile (zero line) before the LDS is released
+  if (A.colsum != nullptr && computes) flush_colsum(A, csum, ot, h, m);
+}
+
+// ---- weight gradient: dW[K x N] = X^T dY, contraction over the samples ------------------------------------------------
+// The contraction index is the SAMPLE, so both MFMA operands want 8 consecutive samples of one feature per lane - the
+// transpose of how X and dY lie in HBM (row major, one sample per row).  A 16-sample tile of both ([16][K] and [16][N] fp32)
+// comes in by LDS-DMA (NS deep); between two barriers the workgroup turns it ONCE into bf16 hi / lo fragment images (thread =
+// one feature x 8 samples: 8 conflict-free 4-byte reads down a column, one 16-byte write each for hi and lo); every wave then
+// reads whole fragments and accumulates its share of the (K/32) x (N/32) output tiles in registers for the whole kernel.
+// Each workgroup ends with a full K x N partial sum, written to part[blockIdx]; the caller adds the partials.
+template <int IPW> struct WgShape {
+  static constexpr int STAGE_BYTES = IPW * 8 * 1024;          // 8 waves x IPW DMA instructions x 1 KiB
+  static constexpr int IMG_BYTES = 16 * 2048;                 // up to 8 + 8 fragments of hi | lo
+  static constexpr int NS = 3;
+  static constexpr int LDS = NS * STAGE_BYTES + IMG_BYTES;
+};
+
+template <int TPW, int IPW>
+__global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
+  typedef WgShape<IPW> S;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = A.k, N = A.n, KQ = K >> 2, NQ = N >> 2;
+  const int KT = (K + 31) >> 5, NT = (N + 31) >> 5, TT = KT * NT;
+  const long long tiles = (A.M + 15) / 16;
+  const int grid = gridDim.x;
+
+  // DMA descriptors: slot L of the stage = (row, quad) of X for L < 16 KQ, of dY after that, zero line past the end
+  const char* src[IPW];
+  int step[IPW], rowu[IPW];
+#pragma unroll
+  for (int u = 0; u < IPW; ++u) {
+    const int L = 64 * (wave + 8 * u) + lane;
+    const char* p = nullptr;
+    int st = 0, row = 0x3fffffff;
+    if (L < 16 * KQ) {
+      row = L / KQ;
+      p = reinterpret_cast<const char*>(A.x + ((size_t)blockIdx.x * 16 + row) * A.ldx + 4 * (L - row * KQ));
+      st = grid * 16 * A.ldx * 4;
+    } else if (L < 16 * (KQ + NQ)) {
+      const int L2 = L - 16 * KQ;
+      row = L2 / NQ;
+      p = reinterpret_cast<const char*>(A.dy + ((size_t)blockIdx.x * 16 + row) * A.ldy + 4 * (L2 - row * NQ));
+      st = grid * 16 * A.ldy * 4;
+    }
+    src[u] = p; step[u] = st; rowu[u] = row;
+  }
+  auto issue = [&](long long tile, int stage) {
+#pragma unroll
+    for (int u = 0; u < IPW; ++u) {
+      const bool ok = tile * 16 + rowu[u] < A.M;
+      const char* g = ok ? src[u] : reinterpret_cast<const char*>(A.zeros);
+      const int off = __builtin_amdgcn_readfirstlane(stage * S::STAGE_BYTES + (wave + 8 * u) * 1024);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(g_tile + off), 16, 0, 0);
+      src[u] += step[u];
+    }
+  };
+  // conversion items of this thread: (feature f, sample octet o) of X (idx < 2 K) or dY; 2 (K + N) <= 1024 items
+  int c_src[2], c_dst[2], c_stride[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = threadIdx.x + 512 * j;
+    c_src[j] = -1; c_dst[j] = 0; c_stride[j] = 0;
+    if (idx < 2 * K) {
+      const int o = idx / K, f = idx - o * K;
+      c_src[j] = (8 * o * K + f) * 4; c_stride[j] = K * 4;
+      c_dst[j] = (f >> 5) * 2048 + ((o << 5) | (f & 31)) * 16;
+    } else if (idx < 2 * (K + N)) {
+      const int i2 = idx - 2 * K, o = i2 / N, f = i2 - o * N;
+      c_src[j] = 16 * K * 4 + (8 * o * N + f) * 4; c_stride[j] = N * 4;
+      c_dst[j] = (KT + (f >> 5)) * 2048 + ((o << 5) | (f & 31)) * 16;
+    }
+  }
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) acc[j] = f32x16{};
+  char* img = g_tile + S::NS * S::STAGE_BYTES;
+
+  long long tile = blockIdx.x;
+#pragma unroll
+  for (int s = 0; s < S::NS - 1; ++s) issue(tile + (long long)s * grid, s);
+  int it = 0;
+  for (; tile < tiles; tile += grid, ++it) {
+    wait_vm_lgkm0<(S::NS - 2) * IPW>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issue(tile + (long long)(S::NS - 1) * grid, (it + S::NS - 1) % S::NS);
+    __builtin_amdgcn_sched_barrier(0);
+    const char* stg = g_tile + (it % S::NS) * S::STAGE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (c_src[j] >= 0) {
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const float*>(stg + c_src[j] + i * c_stride[j]);
+        bf16x8 xh, xl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const __bf16 a = (__bf16)f[i];
+          xh[i] = a;
+          xl[i] = (__bf16)(f[i] - (float)a);
+        }
+        *reinterpret_cast<u32x4*>(img + c_dst[j]) = __builtin_bit_cast(u32x4, xh);
+        *reinterpret_cast<u32x4*>(img + c_dst[j] + 1024) = __builtin_bit_cast(u32x4, xl);
+      }
+    }
+    wait_vm_lgkm0<63>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const int t = wave * TPW + j;
+      if (t < TT) {
+        const int kt = t / NT, nt = t - kt * NT;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + kt * 2048 + lane * 16));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + kt * 2048 + 1024 + lane * 16));
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + (KT + nt) * 2048 + lane * 16));
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + (KT + nt) * 2048 + 1024 + lane * 16));
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  wait_vm_lgkm0<0>();
+  // this workgroup's partial: lane holds column n = 32 nt + (lane & 31), rows k = 32 kt + (r & 3) + 8 (r >> 2) + 4 h
+  float* part = A.dw != nullptr ? A.dw : A.part + (size_t)blockIdx.x * K * N;
+  const bool atomic = A.dw != nullptr;
+  const int m = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int t = wave * TPW + j;
+    if (t < TT) {
+      const int kt = t / NT, nt = t - kt * NT, n = 32 * nt + m;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (k < K && n < N) {
+          if (atomic) unsafeAtomicAdd(part + (size_t)k * N + n, acc[j][r]);
+          else part[(size_t)k * N + n] = acc[j][r];
+        }
+      }
+    }
+  }
 }
 
 void pack_frags(hipStream_t st, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, void* out) {
@@ -445,6 +606,36 @@ bool dense_ws(hipStream_t st, const DenseArgs& A, int num_cus) {
     default: return false;
   }
 #undef NERFDS_KC
+}
+
+bool wgrad_supported(const WgradArgs& A) {
+  return A.k >= 4 && A.n >= 4 && A.k <= 256 && A.n <= 256 && A.k % 4 == 0 && A.n % 4 == 0 && A.ldx % 4 == 0 && A.ldy % 4 == 0 && aligned16(A.x) &&
+         aligned16(A.dy) && A.M > 0 && A.zeros != nullptr;
+}
+int wgrad_grid(const WgradArgs& A, int num_cus) {
+  const long long tiles = (A.M + 15) / 16;
+  // one workgroup per CU for the big shapes (128 KiB of LDS); the small ones fit several, but more workgroups = more partials
+  const long long want = num_cus;
+  return (int)(tiles < want ? tiles : want);
+}
+template <int TPW, int IPW> static void launch_wgrad(hipStream_t st, const WgradArgs& A, int grid) {
+  auto kern = k_wgrad<TPW, IPW>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WgShape<IPW>::LDS); attr = true; }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WgShape<IPW>::LDS, st, A);
+}
+bool wgrad(hipStream_t st, const WgradArgs& A, int grid) {
+  if (!wgrad_supported(A) || grid < 1) return false;
+  const int TT = ((A.k + 31) / 32) * ((A.n + 31) / 32);
+  const int tpw = (TT + 7) / 8;                                     // 1 .. 8 output tiles per wave
+  const int ipw = (16 * (A.k + A.n) / 4 + 511) / 512;               // DMA instructions per wave and 16-sample tile: 1 .. 4
+#define NERFDS_WG(T, I) if (tpw <= T && ipw == I) { launch_wgrad<T, I>(st, A, grid); return true; }
+  NERFDS_WG(1, 1) NERFDS_WG(1, 2) NERFDS_WG(1, 3)
+  NERFDS_WG(2, 1) NERFDS_WG(2, 2) NERFDS_WG(2, 3) NERFDS_WG(2, 4)
+  NERFDS_WG(4, 2) NERFDS_WG(4, 3) NERFDS_WG(4, 4)
+  NERFDS_WG(8, 3) NERFDS_WG(8, 4)
+#undef NERFDS_WG
+  return false;
 }
 
 }  // namespace nerfds_train
