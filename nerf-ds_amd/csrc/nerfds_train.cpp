@@ -150,24 +150,26 @@ struct Run {
   int64_t M;
   bool ok = true;
   // Set around the FORWARD of the warp field: its output moves the points that the 2^7-frequency posenc of the template
-  // reads, which amplifies the 16-bit operand rounding of the MFMA layers to ~1 % on the warp-field gradients (measured
-  // against the fp64 oracle).  Those layers keep fp32 GEMMs.
-  bool fp32_layers = false;
+  // reads, which amplifies the 16-bit operand rounding of the two-way split to ~1 % on the warp-field gradients (measured
+  // against the fp64 oracle).  Those layers run the three-way split (fp32-level products), or rocBLAS fp32 where that
+  // kernel does not cover the shape (the 33-wide input rows are not 16-byte aligned).
+  bool precise_layers = false;
   void chk(rocblas_status s) { if (s != rocblas_status_success) ok = false; }
 
   // y[M x N] (ldy) = act(sum_s x_s W[rows of s] + b)
   // the hand-written weight-stationary layer (train_gemm.hip); false = shape not covered
   bool ws_layer(const std::vector<Seg>& segs, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, const float* bias, float* y,
                 int ldy, int64_t rows, bool relu, const float* mask_y, int ld_mask, int mask_div, bool accumulate, float* colsum = nullptr) {
-    if (!t.own_gemm || fp32_layers || segs.size() > 4 || frag_bytes(in_dim, out_dim) > WPACK_BYTES) return false;
+    const int parts = precise_layers ? 3 : 2;
+    if (!t.own_gemm || segs.size() > 4 || frag_bytes(in_dim, out_dim, parts) > WPACK_BYTES) return false;
     DenseArgs A{};
     A.nseg = (int)segs.size();
     for (int i = 0; i < A.nseg; ++i) A.seg[i] = {segs[i].x, segs[i].ld, segs[i].K};
     A.k_total = in_dim; A.wfrag = t.wpack; A.bias = bias; A.y = y; A.ldy = ldy; A.n_out = out_dim; A.M = rows; A.relu = relu ? 1 : 0;
     A.mask_y = mask_y; A.ld_mask = ld_mask; A.mask_div = mask_div; A.accumulate = accumulate ? 1 : 0;
-    A.zeros = static_cast<const char*>(t.wpack) + WPACK_BYTES; A.colsum = colsum;
+    A.zeros = static_cast<const char*>(t.wpack) + WPACK_BYTES; A.colsum = colsum; A.precise = precise_layers ? 1 : 0;
     if (!dense_ws_supported(A)) return false;
-    pack_frags(st, W, ldw, row0, in_dim, out_dim, transpose, t.wpack);
+    pack_frags(st, W, ldw, row0, in_dim, out_dim, transpose, t.wpack, parts);
     return dense_ws(st, A, t.num_cus);
   }
   void dense_fwd(const LayerP& L, const std::vector<Seg>& segs, float* y, int ldy, bool relu) {
@@ -393,11 +395,11 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   r.mlp_fwd(t.mask, t.mask_in, t.mask_h);
   r.dense_fwd(t.mask_out, {{t.mask_h.back(), t.mask.width, t.mask.width, nullptr, 0, false}}, t.mask_logit, 1, false);
   mask_post(st, D, R, S, t.mask_logit, rays->gt_mask, ex->mask_ratio, t.warp_in, t.hyper_in);
-  r.fp32_layers = true;
+  r.precise_layers = true;
   r.mlp_fwd(t.warp, t.warp_in, t.warp_h);
   r.dense_fwd(t.warp_w, {{t.warp_h.back(), t.warp.width, t.warp.width, nullptr, 0, false}}, t.wv, 6, false);
   r.dense_fwd(t.warp_v, {{t.warp_h.back(), t.warp.width, t.warp.width, nullptr, 0, false}}, t.wv + 3, 6, false);
-  r.fp32_layers = false;
+  r.precise_layers = false;
   se3_fwd(st, M, t.wv, t.x, t.xw);
   r.mlp_fwd(t.hyper, t.hyper_in, t.hyper_h);
   r.dense_fwd(t.hyper_out, {{t.hyper_h.back(), t.hyper.width, t.hyper.width, nullptr, 0, false}}, t.wamb, 2, false);

@@ -19,6 +19,7 @@ struct DenseArgs {
   const float* mask_y;      // nullptr, or: y = 0 where mask_y[(row / mask_div) * ld_mask + n] <= 0 (ReLU backward of the consumer)
   int ld_mask, mask_div;
   int accumulate;           // y += result
+  int precise;              // operands split three ways (hi / mid / lo bf16, 6 MFMAs per fragment): fp32-level products; wfrag packed with parts = 3
   float* colsum;            // nullptr, or [n_out]: += column sums of the (masked) result - the bias gradient of the layer that consumes y as dY
   const void* zeros;        // >= 16 zero bytes in device memory (source of the padding slots of the LDS-DMA path), or nullptr
   int vec_in, vec_out;      // set by dense_ws(): 16-byte loads / stores are legal
@@ -38,8 +39,8 @@ bool wgrad_supported(const WgradArgs& A);
 int wgrad_grid(const WgradArgs& A, int num_cus);
 bool wgrad(hipStream_t st, const WgradArgs& A, int grid);
 
-void pack_frags(hipStream_t st, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, void* out);
-size_t frag_bytes(int in_dim, int out_dim);
+void pack_frags(hipStream_t st, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, void* out, int parts = 2);
+size_t frag_bytes(int in_dim, int out_dim, int parts = 2);
 bool dense_ws_supported(const DenseArgs& A);
 // false = shape not covered (caller falls back to rocBLAS)
 bool dense_ws(hipStream_t st, const DenseArgs& A, int num_cus);

@@ -33,25 +33,32 @@ __device__ __forceinline__ float bf16_f32(unsigned short b) { return __builtin_b
 // Packs the weights of one layer into fragment order: fragment (tile ot, chunk kc, part hi|lo), lane l = (h << 5) | m holds, for
 // output feature 32 ot + m, the 8 k-slots 16 kc + 8 h + i.  transpose = 0: value(k, n) = W[(row0 + k) * ldw + n] (forward:
 // `in` = rows of W); transpose = 1: value(k, n) = W[(row0 + n) * ldw + k] (backward data: in = columns of W, out = its rows).
-__global__ void k_pack_frags(const float* __restrict__ W, int ldw, int row0, int in_dim, int out_dim, int transpose, u32x4* __restrict__ out) {
+__global__ void k_pack_frags(const float* __restrict__ W, int ldw, int row0, int in_dim, int out_dim, int transpose, int parts, u32x4* __restrict__ out) {
   const int KC = (in_dim + 15) / 16, tiles = (out_dim + 31) / 32;
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;       // (ot, kc, lane)
   if (idx >= (long long)tiles * KC * 64) return;
   const int lane = (int)(idx % 64), kc = (int)((idx / 64) % KC), ot = (int)(idx / (64LL * KC));
   const int m = lane & 31, h = lane >> 5, n = 32 * ot + m;
-  unsigned short hi[8], lo[8];
+  unsigned short hi[8], mid[8], lo[8];
   for (int i = 0; i < 8; ++i) {
     const int k = 16 * kc + 8 * h + i;
     float v = 0.f;
     if (k < in_dim && n < out_dim) v = transpose ? W[(size_t)(row0 + n) * ldw + k] : W[(size_t)(row0 + k) * ldw + n];
     hi[i] = bf16_rne(v);
-    lo[i] = bf16_rne(v - bf16_f32(hi[i]));
+    const float r = v - bf16_f32(hi[i]);
+    mid[i] = bf16_rne(r);                                   // parts == 2: this is the "lo" of the two-way split
+    lo[i] = bf16_rne(r - bf16_f32(mid[i]));
   }
-  u32x4 a, b;
-  for (int i = 0; i < 4; ++i) { a[i] = hi[2 * i] | ((unsigned)hi[2 * i + 1] << 16); b[i] = lo[2 * i] | ((unsigned)lo[2 * i + 1] << 16); }
-  const size_t base = ((size_t)(ot * KC + kc) * 2) * 64;
+  u32x4 a, b, c;
+  for (int i = 0; i < 4; ++i) {
+    a[i] = hi[2 * i] | ((unsigned)hi[2 * i + 1] << 16);
+    b[i] = mid[2 * i] | ((unsigned)mid[2 * i + 1] << 16);
+    c[i] = lo[2 * i] | ((unsigned)lo[2 * i + 1] << 16);
+  }
+  const size_t base = ((size_t)(ot * KC + kc) * parts) * 64;
   out[base + lane] = a;
   out[base + 64 + lane] = b;
+  if (parts == 3) out[base + 128 + lane] = c;
 }
 
 // Epilogue: this lane holds sample `row`, features 32 ot + 8 q + 4 h + j of the accumulator (q = 0..3, j = 0..3).
@@ -256,21 +263,28 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {      // vmcnt
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (0 << 8));
 }
 
-template <int KC, int WAVES>
+template <int KC, int WAVES, bool P3>
 __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
+  static_assert(!P3 || WAVES == 4, "the three-way split is built for the 4-wave shape only");
+  constexpr int PARTS = P3 ? 3 : 2;
   typedef DmaShape<KC, WAVES> S;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 31, h = lane >> 5;
   const int n_tiles = (A.n_out + 31) >> 5;
   const bool computes = wave < n_tiles;
   const int ot = computes ? wave : 0;
-  bf16x8 wh[KC], wl[KC];
+  bf16x8 wh[KC], wl[KC], wm[P3 ? KC : 1];          // P3: hi / mid / lo, else hi / lo
   const u32x4* wfrag = static_cast<const u32x4*>(A.wfrag);
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
-    const size_t base = ((size_t)(ot * KC + kc) * 2) * 64;
+    const size_t base = ((size_t)(ot * KC + kc) * PARTS) * 64;
     wh[kc] = __builtin_bit_cast(bf16x8, wfrag[base + lane]);
-    wl[kc] = __builtin_bit_cast(bf16x8, wfrag[base + 64 + lane]);
+    if constexpr (P3) {
+      wm[kc] = __builtin_bit_cast(bf16x8, wfrag[base + 64 + lane]);
+      wl[kc] = __builtin_bit_cast(bf16x8, wfrag[base + 128 + lane]);
+    } else {
+      wl[kc] = __builtin_bit_cast(bf16x8, wfrag[base + 64 + lane]);
+    }
   }
   f32x16 bias;
 #pragma unroll
@@ -378,15 +392,34 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
         const f32x4 f0 = *reinterpret_cast<const f32x4*>(buf + kc * 64);
         const f32x4 f1 = *reinterpret_cast<const f32x4*>(buf + kc * 64 + 16);
         bf16x8 xh, xl;
+        if constexpr (P3) {
+          // three-way split (24 mantissa bits on both operands), every product that is not below 2^-24: fp32-level layer
+          bf16x8 xm;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const __bf16 a = (__bf16)f0[e], b = (__bf16)f1[e];
-          xh[e] = a; xh[4 + e] = b;
-          xl[e] = (__bf16)(f0[e] - (float)a); xl[4 + e] = (__bf16)(f1[e] - (float)b);
+          for (int e = 0; e < 8; ++e) {
+            const float f = e < 4 ? f0[e] : f1[e - 4];
+            const __bf16 a = (__bf16)f;
+            const float r = f - (float)a;
+            const __bf16 b = (__bf16)r;
+            xh[e] = a; xm[e] = b; xl[e] = (__bf16)(r - (float)b);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[kc], xm, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xm, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[kc], xh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const __bf16 a = (__bf16)f0[e], b = (__bf16)f1[e];
+            xh[e] = a; xh[4 + e] = b;
+            xl[e] = (__bf16)(f0[e] - (float)a); xl[4 + e] = (__bf16)(f1[e] - (float)b);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
       }
       store_tile(A, acc, tile * 32 + m, ot, h, csum);
     }
@@ -537,17 +570,17 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
   }
 }
 
-void pack_frags(hipStream_t st, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, void* out) {
+void pack_frags(hipStream_t st, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, void* out, int parts) {
   const int KC = (in_dim + 15) / 16, tiles = (out_dim + 31) / 32;
   const long long n = (long long)tiles * KC * 64;
   hipLaunchKernelGGL(k_pack_frags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, ldw, row0, in_dim, out_dim, transpose,
-                     static_cast<u32x4*>(out));
+                     parts, static_cast<u32x4*>(out));
 }
-size_t frag_bytes(int in_dim, int out_dim) { return (size_t)((out_dim + 31) / 32) * ((in_dim + 15) / 16) * 2048; }
+size_t frag_bytes(int in_dim, int out_dim, int parts) { return (size_t)((out_dim + 31) / 32) * ((in_dim + 15) / 16) * 1024 * parts; }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <int KC, int WAVES> static void launch(hipStream_t st, DenseArgs A, int num_cus) {
+template <int KC, int WAVES, bool P3 = false> static void launch(hipStream_t st, DenseArgs A, int num_cus) {
   const long long tiles = (A.M + 31) / 32;
   A.vec_in = 1;
   for (int g = 0; g < A.nseg; ++g)
@@ -557,7 +590,7 @@ template <int KC, int WAVES> static void launch(hipStream_t st, DenseArgs A, int
   if (dma) {
     typedef DmaShape<KC, WAVES> S;
     const int lds = S::NS * S::TILE_BYTES + S::IMG_BYTES;
-    auto kern = k_dense_dma<KC, WAVES>;
+    auto kern = k_dense_dma<KC, WAVES, P3>;
     static int per_cu = 0;                                        // resident workgroups per CU (registers / LDS decide)
     if (per_cu == 0) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -568,6 +601,7 @@ template <int KC, int WAVES> static void launch(hipStream_t st, DenseArgs A, int
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < want ? tiles : want)), dim3(64 * WAVES), lds, st, A);
     return;
   }
+  if constexpr (P3) return;                                     // (dense_ws_supported() keeps the three-way split off this path)
   const int lds = 2 * KC * 2048;
   auto kern = k_dense_ws<KC, WAVES>;
   static int per_cu = 0;
@@ -586,6 +620,11 @@ bool dense_ws_supported(const DenseArgs& A) {
   const int KC = (A.k_total + 15) / 16;
   if (KC > 21 && A.n_out > 128) return false;      // the slice of a long layer needs a 512-register wave: at most 4 waves
   if (A.mask_div != 1 && A.mask_div != 3) return false;
+  if (A.precise) {                                              // three-way split: 4-wave LDS-DMA shape, K <= 192
+    if (A.n_out > 128 || KC > 12 || A.zeros == nullptr) return false;
+    for (int g = 0; g < A.nseg; ++g)
+      if (A.seg[g].k % 4 || A.seg[g].ld % 4 || !aligned16(A.seg[g].x)) return false;
+  }
   for (int g = 0, k0 = 0; g < A.nseg; ++g) {        // a quad of 4 consecutive k never straddles two segments
     if (k0 % 4) return false;
     k0 += A.seg[g].k;
@@ -597,6 +636,15 @@ bool dense_ws(hipStream_t st, const DenseArgs& A, int num_cus) {
   if (!dense_ws_supported(A)) return false;
   const int KC = (A.k_total + 15) / 16;
   const bool wide = A.n_out > 128;
+  if (A.precise) {
+#define NERFDS_KC3(n) case n: launch<n, 4, true>(st, A, num_cus); return true;
+    switch (KC) {
+      NERFDS_KC3(1) NERFDS_KC3(2) NERFDS_KC3(3) NERFDS_KC3(4) NERFDS_KC3(5) NERFDS_KC3(6) NERFDS_KC3(7) NERFDS_KC3(8) NERFDS_KC3(9) NERFDS_KC3(10)
+      NERFDS_KC3(11) NERFDS_KC3(12)
+      default: return false;
+    }
+#undef NERFDS_KC3
+  }
 #define NERFDS_KC(n) case n: if (wide) launch<n, 8>(st, A, num_cus); else launch<n, 4>(st, A, num_cus); return true;
   switch (KC) {
     NERFDS_KC(1) NERFDS_KC(2) NERFDS_KC(3) NERFDS_KC(4) NERFDS_KC(5) NERFDS_KC(6) NERFDS_KC(7) NERFDS_KC(8) NERFDS_KC(9) NERFDS_KC(10)

@@ -53,12 +53,15 @@ def test_oracle_gradient_matches_finite_differences_where_no_stop_gradient_appli
 
 
 # The trainer's data GEMMs run in one of two modes, and every gradient test runs in both:
-#   'mfma'    the hand-written weight-stationary layers (train_gemm.hip): split-bf16 operands = 16-bit mantissas, fp32 accumulation.
-#             That is finer than what the reference's own matmuls use at jnp's default precision (one bf16 pass on TPU, TF32 on
-#             NVIDIA GPUs), but coarser than fp32: through the 2^7 posenc frequencies of the warped points the warp-field leaves
-#             differ from the fp64 oracle by up to 6e-3 relative L2 - the bound for this mode is 1e-2;
-#   'rocblas' fp32 library GEMMs (NERFDS_TRAIN_GEMM=rocblas), the strict pin: 4e-3 / 5e-3.
-L2_TOL = {'mfma': 1e-2, 'rocblas': 4e-3}
+#   'mfma'    the hand-written MFMA layers (train_gemm.hip): split-bf16 operands, fp32 accumulation.  Operands carry 16 mantissa
+#             bits (hi + lo) - finer than the reference's own matmuls at jnp's default precision (one bf16 pass on TPU, TF32 on
+#             NVIDIA GPUs) - except in the forward of the warp field, whose output feeds the 2^7-frequency posenc of the
+#             template: there the three-way split (24 bits) or fp32 rocBLAS is used (with 16 bits the warp-field gradients
+#             were 1 % off the fp64 oracle).  First-order gradients meet the same 4e-3 bound as fp32; the second-order
+#             norm-loss gradients, which differentiate through the tangent pass, get 8e-3;
+#   'rocblas' fp32 library GEMMs (NERFDS_TRAIN_GEMM=rocblas), the strict pin.
+L2_TOL = {'mfma': 4e-3, 'rocblas': 4e-3}
+L2_TOL_2ND = {'mfma': 8e-3, 'rocblas': 5e-3}
 
 
 @pytest.fixture(params=['mfma', 'rocblas'])
@@ -225,7 +228,7 @@ def test_auxiliary_losses_match_the_oracle(sharp, gemm):
   for name, w in want.items():
     g = got[name].reshape(w.shape)
     l2 = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
-    assert l2 < max(5e-3, L2_TOL[gemm]), (name, l2)
+    assert l2 < L2_TOL_2ND[gemm], (name, l2)
   # the normal channels of the alpha head now DO receive gradient (back-facing regulariser), the mask net too
   assert np.abs(got['nerf_mlps_fine/alpha_mlp/logit/kernel'][:, 1:]).max() > 0
   assert np.abs(got['mask_mlp/MLP_0/hidden_0/kernel']).max() > 0
@@ -255,7 +258,7 @@ def test_norm_loss_second_order_matches_the_oracle(only_norm, gemm):
   for name, w in want.items():
     g = got[name].reshape(w.shape)
     l2 = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
-    assert l2 < max(5e-3, L2_TOL[gemm]), (name, l2)
+    assert l2 < L2_TOL_2ND[gemm], (name, l2)
     # the norm loss must actually have contributed to this leaf's gradient for the check to mean something
     if np.linalg.norm(w - base[name]) > 0.05 * max(np.linalg.norm(w), 1e-12):
       moved += 1
