@@ -188,7 +188,7 @@ struct Run {
   void weight_grad(const float* X, int ldx, int K, const float* dy, int ldy, int N, float* dW, int64_t rows = -1) {
     const int64_t M = rows < 0 ? this->M : rows;
     if (t.own_gemm) {                                   // hand-written MFMA kernel (train_gemm.hip): one partial per workgroup
-      WgradArgs A{X, ldx, K, dy, ldy, N, M, nullptr, dW, static_cast<const char*>(t.wpack) + WPACK_BYTES};
+      WgradArgs A{X, ldx, K, dy, ldy, N, M, nullptr, dW, static_cast<const char*>(t.wpack) + WPACK_BYTES, 0, 0};
       if (wgrad_supported(A) && wgrad(st, A, wgrad_grid(A, t.num_cus))) return;
     }
     const int64_t slabs = M / SLAB;

@@ -27,12 +27,13 @@ struct DenseArgs {
 
 // Weight gradient dW[K x N] += X[M x K]^T dY[M x N] (contraction over the M samples).
 struct WgradArgs {
-  const float* x; int ldx; int k;      // K <= 256, multiple of 4, ldx multiple of 4, 16-byte aligned
-  const float* dy; int ldy; int n;     // N <= 256, same conditions
+  const float* x; int ldx; int k;      // K <= 256
+  const float* dy; int ldy; int n;     // N <= 256
   long long M;
   float* part;                         // [grid][K x N] per-workgroup partial sums (the caller reduces them), used when dw == nullptr
   float* dw;                           // [K x N]: every workgroup adds its partial with hardware float atomics
   const void* zeros;
+  int x_scalar, dy_scalar;             // set by wgrad(): the part is fetched float by float (rows not 16-byte aligned)
 };
 bool wgrad_supported(const WgradArgs& A);
 // Launches on `grid` workgroups chosen by wgrad_grid(); part must hold grid * K * N floats.  false = shape not covered.

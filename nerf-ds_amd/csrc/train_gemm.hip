@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
 // reads whole fragments and accumulates its share of the (K/32) x (N/32) output tiles in registers for the whole kernel.
 // Each workgroup ends with a full K x N partial sum, written to part[blockIdx]; the caller adds the partials.
 template <int IPW> struct WgShape {
-  static constexpr int STAGE_BYTES = IPW * 8 * 1024;          // 8 waves x IPW DMA instructions x 1 KiB
+  static constexpr int STAGE_BYTES = IPW * 8 * 1024 + 1024;   // 8 waves x IPW DMA instructions x 1 KiB, + a spare KiB for idle instructions
   static constexpr int IMG_BYTES = 16 * 2048;                 // up to 8 + 8 fragments of hi | lo
   static constexpr int NS = 3;
   static constexpr int LDS = NS * STAGE_BYTES + IMG_BYTES;
@@ -451,33 +451,46 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
   const long long tiles = (A.M + 15) / 16;
   const int grid = gridDim.x;
 
-  // DMA descriptors: slot L of the stage = (row, quad) of X for L < 16 KQ, of dY after that, zero line past the end
+  // DMA descriptors.  The stage holds [16][K] floats of X, then [16][N] floats of dY; each part is fetched either in 16-byte
+  // pieces (rows 16-byte aligned) or, for the odd shapes (K = 33, N = 1 .. 6), float by float - one kind per instruction,
+  // so a part is rounded up to whole instructions.  Lanes past the end of a part / of M read the zero line.
+  const int NX = A.x_scalar ? (16 * K + 63) >> 6 : (16 * KQ + 63) >> 6;
+  const int NY = A.dy_scalar ? (16 * N + 63) >> 6 : (16 * NQ + 63) >> 6;
+  const int XBYTES = NX * (A.x_scalar ? 256 : 1024);
   const char* src[IPW];
-  int step[IPW], rowu[IPW];
+  int step[IPW], rowu[IPW], ldsoff[IPW];
+  bool scalar[IPW];
 #pragma unroll
   for (int u = 0; u < IPW; ++u) {
-    const int L = 64 * (wave + 8 * u) + lane;
+    const int i = wave + 8 * u;
     const char* p = nullptr;
-    int st = 0, row = 0x3fffffff;
-    if (L < 16 * KQ) {
-      row = L / KQ;
-      p = reinterpret_cast<const char*>(A.x + ((size_t)blockIdx.x * 16 + row) * A.ldx + 4 * (L - row * KQ));
-      st = grid * 16 * A.ldx * 4;
-    } else if (L < 16 * (KQ + NQ)) {
-      const int L2 = L - 16 * KQ;
-      row = L2 / NQ;
-      p = reinterpret_cast<const char*>(A.dy + ((size_t)blockIdx.x * 16 + row) * A.ldy + 4 * (L2 - row * NQ));
-      st = grid * 16 * A.ldy * 4;
+    int st = 0, row = 0x3fffffff, off = S::STAGE_BYTES - 1024;            // spare KiB at the end of the stage: nobody reads it
+    bool sc = false;
+    if (i < NX + NY) {
+      const bool isx = i < NX;
+      const int ii = isx ? i : i - NX, W = isx ? K : N, ld = isx ? A.ldx : A.ldy;
+      const float* base = isx ? A.x : A.dy;
+      sc = isx ? A.x_scalar != 0 : A.dy_scalar != 0;
+      const int e = (64 * ii + lane) * (sc ? 1 : 4);                        // first float of this lane's piece, in [16][W]
+      off = (isx ? 0 : XBYTES) + ii * (sc ? 256 : 1024);
+      if (e < 16 * W) {
+        row = e / W;
+        p = reinterpret_cast<const char*>(base + ((size_t)blockIdx.x * 16 + row) * ld + (e - row * W));
+        st = grid * 16 * ld * 4;
+      }
     }
-    src[u] = p; step[u] = st; rowu[u] = row;
+    src[u] = p; step[u] = st; rowu[u] = row; ldsoff[u] = __builtin_amdgcn_readfirstlane(off); scalar[u] = __builtin_amdgcn_readfirstlane(sc);
   }
   auto issue = [&](long long tile, int stage) {
 #pragma unroll
     for (int u = 0; u < IPW; ++u) {
       const bool ok = tile * 16 + rowu[u] < A.M;
       const char* g = ok ? src[u] : reinterpret_cast<const char*>(A.zeros);
-      const int off = __builtin_amdgcn_readfirstlane(stage * S::STAGE_BYTES + (wave + 8 * u) * 1024);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(g_tile + off), 16, 0, 0);
+      const int off = __builtin_amdgcn_readfirstlane(stage * S::STAGE_BYTES + ldsoff[u]);
+      if (scalar[u])
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(g_tile + off), 4, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(g_tile + off), 16, 0, 0);
       src[u] += step[u];
     }
   };
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
       c_dst[j] = (f >> 5) * 2048 + ((o << 5) | (f & 31)) * 16;
     } else if (idx < 2 * (K + N)) {
       const int i2 = idx - 2 * K, o = i2 / N, f = i2 - o * N;
-      c_src[j] = 16 * K * 4 + (8 * o * N + f) * 4; c_stride[j] = N * 4;
+      c_src[j] = XBYTES + (8 * o * N + f) * 4; c_stride[j] = N * 4;
       c_dst[j] = (KT + (f >> 5)) * 2048 + ((o << 5) | (f & 31)) * 16;
     }
   }
@@ -656,9 +669,16 @@ bool dense_ws(hipStream_t st, const DenseArgs& A, int num_cus) {
 #undef NERFDS_KC
 }
 
+static void wgrad_kinds(const WgradArgs& A, int& xs, int& ys, int& ninstr) {
+  xs = (A.k % 4 || A.ldx % 4 || !aligned16(A.x)) ? 1 : 0;
+  ys = (A.n % 4 || A.ldy % 4 || !aligned16(A.dy)) ? 1 : 0;
+  ninstr = (xs ? (16 * A.k + 63) / 64 : (4 * A.k + 63) / 64) + (ys ? (16 * A.n + 63) / 64 : (4 * A.n + 63) / 64);
+}
 bool wgrad_supported(const WgradArgs& A) {
-  return A.k >= 4 && A.n >= 4 && A.k <= 256 && A.n <= 256 && A.k % 4 == 0 && A.n % 4 == 0 && A.ldx % 4 == 0 && A.ldy % 4 == 0 && aligned16(A.x) &&
-         aligned16(A.dy) && A.M > 0 && A.zeros != nullptr;
+  if (A.k < 1 || A.n < 1 || A.k > 256 || A.n > 256 || A.M <= 0 || A.zeros == nullptr) return false;
+  int xs, ys, ninstr;
+  wgrad_kinds(A, xs, ys, ninstr);
+  return ninstr <= 32;                                              // at most 4 DMA instructions per wave and tile
 }
 int wgrad_grid(const WgradArgs& A, int num_cus) {
   const long long tiles = (A.M + 15) / 16;
@@ -672,14 +692,17 @@ template <int TPW, int IPW> static void launch_wgrad(hipStream_t st, const Wgrad
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WgShape<IPW>::LDS); attr = true; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WgShape<IPW>::LDS, st, A);
 }
-bool wgrad(hipStream_t st, const WgradArgs& A, int grid) {
-  if (!wgrad_supported(A) || grid < 1) return false;
+bool wgrad(hipStream_t st, const WgradArgs& A0, int grid) {
+  if (!wgrad_supported(A0) || grid < 1) return false;
+  WgradArgs A = A0;
+  int ninstr;
+  wgrad_kinds(A, A.x_scalar, A.dy_scalar, ninstr);
   const int TT = ((A.k + 31) / 32) * ((A.n + 31) / 32);
   const int tpw = (TT + 7) / 8;                                     // 1 .. 8 output tiles per wave
-  const int ipw = (16 * (A.k + A.n) / 4 + 511) / 512;               // DMA instructions per wave and 16-sample tile: 1 .. 4
-#define NERFDS_WG(T, I) if (tpw <= T && ipw == I) { launch_wgrad<T, I>(st, A, grid); return true; }
-  NERFDS_WG(1, 1) NERFDS_WG(1, 2) NERFDS_WG(1, 3)
-  NERFDS_WG(2, 1) NERFDS_WG(2, 2) NERFDS_WG(2, 3) NERFDS_WG(2, 4)
+  const int ipw = (ninstr + 7) / 8;                                 // DMA instructions per wave and 16-sample tile: 1 .. 4
+#define NERFDS_WG(T, I) if (tpw <= T && ipw <= I) { launch_wgrad<T, I>(st, A, grid); return true; }
+  NERFDS_WG(1, 1) NERFDS_WG(1, 2) NERFDS_WG(1, 4)
+  NERFDS_WG(2, 2) NERFDS_WG(2, 4)
   NERFDS_WG(4, 2) NERFDS_WG(4, 3) NERFDS_WG(4, 4)
   NERFDS_WG(8, 3) NERFDS_WG(8, 4)
 #undef NERFDS_WG
