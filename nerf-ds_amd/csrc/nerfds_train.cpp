@@ -229,7 +229,13 @@ struct Run {
     return fused;
   }
   // tangents (3 rows per sample, no bias): y[3M x N] = sum_s t_s W[rows of s]
-  void dense_jvp(const LayerP& L, const std::vector<Seg>& segs, float* y, int ldy) {
+  // relu_y != nullptr: the rows are masked with the PRIMAL activation of their sample (y_t = 0 where relu_y[row / 3] <= 0)
+  void dense_jvp(const LayerP& L, const std::vector<Seg>& segs, float* y, int ldy, const float* relu_y = nullptr) {
+    if (ws_layer(segs, t.theta + L.w, L.N, 0, L.K, L.N, 0, nullptr, y, ldy, 3 * M, false, relu_y, L.N, 3, false)) return;
+    dense_jvp_rocblas(L, segs, y, ldy);
+    if (relu_y) relu_mask3(st, y, relu_y, M, L.N);
+  }
+  void dense_jvp_rocblas(const LayerP& L, const std::vector<Seg>& segs, float* y, int ldy) {
     int k0 = 0;
     for (size_t i = 0; i < segs.size(); ++i) {
       chk(gemm_nn(t.blas, 3 * M, L.N, segs[i].K, segs[i].x, segs[i].ld, t.theta + L.w + (int64_t)k0 * L.N, L.N, i ? 1.f : 0.f, y, ldy));
@@ -244,31 +250,38 @@ struct Run {
       if (l > 0) segs.push_back({cur, m.width, m.width, nullptr, 0, false});
       if (l == 0 || l == m.skip) segs.push_back({t_in0, m.in_dim, m.in_dim, nullptr, 0, false});
       float* dst = store ? (*store)[l] : other;
-      dense_jvp(m.hidden[l], segs, dst, m.width);
-      relu_mask3(st, dst, h[l], M, m.width);
+      dense_jvp(m.hidden[l], segs, dst, m.width, h[l]);
       if (store) cur = dst; else std::swap(cur, other);
     }
     return cur;
   }
   // backward of a tangent layer: dy[3M x N] is d loss / d tangent output (masked with the PRIMAL activation when relu_y != nullptr)
-  void dense_jvp_bwd(const LayerP& L, const std::vector<Seg>& segs, float* dy, int ldy, const float* relu_y) {
-    if (relu_y) relu_mask3(st, dy, relu_y, M, L.N);
+  // premasked / return value: as dense_bwd (no bias gradient here: tangent layers have no bias)
+  bool dense_jvp_bwd(const LayerP& L, const std::vector<Seg>& segs, float* dy, int ldy, const float* relu_y, bool premasked = false) {
+    if (relu_y && !premasked) relu_mask3(st, dy, relu_y, M, L.N);
+    bool fused = false;
     int k0 = 0;
     for (const Seg& s : segs) {
       weight_grad(s.x, s.ld, s.K, dy, ldy, L.N, t.grad + L.w + (int64_t)k0 * L.N, 3 * M);
-      if (s.dx) chk(gemm_nt(t.blas, 3 * M, L.N, s.K, dy, ldy, t.theta + L.w + (int64_t)k0 * L.N, L.N, s.acc ? 1.f : 0.f, s.dx, s.dld));
+      if (s.dx) {
+        const bool want = s.dx_relu_y != nullptr && !s.acc;
+        if (ws_layer({{dy, ldy, L.N, nullptr, 0, false}}, t.theta + L.w, L.N, k0, L.N, s.K, 1, nullptr, s.dx, s.dld, 3 * M, false,
+                     want ? s.dx_relu_y : nullptr, s.dld, 3, s.acc)) fused = fused || want;
+        else chk(gemm_nt(t.blas, 3 * M, L.N, s.K, dy, ldy, t.theta + L.w + (int64_t)k0 * L.N, L.N, s.acc ? 1.f : 0.f, s.dx, s.dld));
+      }
       k0 += s.K;
     }
+    return fused;
   }
   // cur holds d loss / d tangent of h[depth-1]; th = the stored tangents of every layer
   void mlp_jvp_bwd(const MlpP& m, const float* t_in0, const std::vector<float*>& th, const std::vector<float*>& h, float* cur, float* other,
                    float* d_t_in0) {
-    bool in0_written = false;
+    bool in0_written = false, premasked = false;
     for (int l = m.depth - 1; l >= 0; --l) {
       std::vector<Seg> segs;
-      if (l > 0) segs.push_back({th[l - 1], m.width, m.width, other, m.width, false});
+      if (l > 0) segs.push_back({th[l - 1], m.width, m.width, other, m.width, false, h[l - 1], nullptr});
       if (l == 0 || l == m.skip) { segs.push_back({t_in0, m.in_dim, m.in_dim, d_t_in0, m.in_dim, in0_written}); in0_written = d_t_in0 != nullptr; }
-      dense_jvp_bwd(m.hidden[l], segs, cur, m.width, h[l]);
+      premasked = dense_jvp_bwd(m.hidden[l], segs, cur, m.width, h[l], premasked);
       std::swap(cur, other);
     }
   }
@@ -369,9 +382,11 @@ void sigma_gradient(nerfds_trainer& t, Run& r, int level, const Windows& W) {
   const int64_t M = r.M;
   encode_tangents(st, D, M, t.x, W, t.t_warp_in, t.t_hyper_in);
   const bool keep = t.nws != nullptr && t.keep_tangents;
+  r.precise_layers = true;       // as the primal warp field: its tangent goes through the 2^7-frequency posenc
   float* tw = r.mlp_jvp(t.warp, t.t_warp_in, t.warp_h, t.tA, t.tB, keep ? &t.tw_h : nullptr);
   r.dense_jvp(t.warp_w, {{tw, t.warp.width, t.warp.width, nullptr, 0, false}}, t.t_wv, 6);
   r.dense_jvp(t.warp_v, {{tw, t.warp.width, t.warp.width, nullptr, 0, false}}, t.t_wv + 3, 6);
+  r.precise_layers = false;
   se3_jvp(st, M, t.wv, t.x, t.t_wv, t.t_xw);
   float* th = r.mlp_jvp(t.hyper, t.t_hyper_in, t.hyper_h, t.tA, t.tB, keep ? &t.th_h : nullptr);
   r.dense_jvp(t.hyper_out, {{th, t.hyper.width, t.hyper.width, nullptr, 0, false}}, t.t_wamb, 2);
