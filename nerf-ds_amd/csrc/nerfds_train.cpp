@@ -219,7 +219,7 @@ struct Run {
     for (const Seg& s : segs) {
       weight_grad(s.x, s.ld, s.K, dy, ldy, L.N, t.grad + L.w + (int64_t)k0 * L.N);
       if (s.dx) {
-        const bool want = s.dx_relu_y != nullptr && !s.acc;
+        const bool want = s.dx_relu_y != nullptr;          // (with acc: this is the last contribution to dx, the mask covers the total)
         if (ws_layer({{dy, ldy, L.N, nullptr, 0, false}}, t.theta + L.w, L.N, k0, L.N, s.K, 1, nullptr, s.dx, s.dld, M, false, want ? s.dx_relu_y : nullptr,
                      s.dld, 1, s.acc, want ? s.dx_bias_grad : nullptr)) fused = fused || want;
         else chk(gemm_nt(t.blas, M, L.N, s.K, dy, ldy, t.theta + L.w + (int64_t)k0 * L.N, L.N, s.acc ? 1.f : 0.f, s.dx, s.dld));
@@ -264,7 +264,7 @@ struct Run {
     for (const Seg& s : segs) {
       weight_grad(s.x, s.ld, s.K, dy, ldy, L.N, t.grad + L.w + (int64_t)k0 * L.N, 3 * M);
       if (s.dx) {
-        const bool want = s.dx_relu_y != nullptr && !s.acc;
+        const bool want = s.dx_relu_y != nullptr;
         if (ws_layer({{dy, ldy, L.N, nullptr, 0, false}}, t.theta + L.w, L.N, k0, L.N, s.K, 1, nullptr, s.dx, s.dld, 3 * M, false,
                      want ? s.dx_relu_y : nullptr, s.dld, 3, s.acc)) fused = fused || want;
         else chk(gemm_nt(t.blas, 3 * M, L.N, s.K, dy, ldy, t.theta + L.w + (int64_t)k0 * L.N, L.N, s.acc ? 1.f : 0.f, s.dx, s.dld));
@@ -275,8 +275,8 @@ struct Run {
   }
   // cur holds d loss / d tangent of h[depth-1]; th = the stored tangents of every layer
   void mlp_jvp_bwd(const MlpP& m, const float* t_in0, const std::vector<float*>& th, const std::vector<float*>& h, float* cur, float* other,
-                   float* d_t_in0) {
-    bool in0_written = false, premasked = false;
+                   float* d_t_in0, bool premasked = false) {
+    bool in0_written = false;
     for (int l = m.depth - 1; l >= 0; --l) {
       std::vector<Seg> segs;
       if (l > 0) segs.push_back({th[l - 1], m.width, m.width, other, m.width, false, h[l - 1], nullptr});
@@ -294,8 +294,8 @@ struct Run {
     }
   }
   // cur holds d loss / d h[depth-1] on entry; other is a second [M x width] buffer; d_in0 receives d loss / d in0
-  void mlp_bwd(const MlpP& m, const float* in0, const std::vector<float*>& h, float* cur, float* other, float* d_in0) {
-    bool in0_written = false, premasked = false;
+  void mlp_bwd(const MlpP& m, const float* in0, const std::vector<float*>& h, float* cur, float* other, float* d_in0, bool premasked = false) {
+    bool in0_written = false;
     for (int l = m.depth - 1; l >= 0; --l) {
       std::vector<Seg> segs;
       // d h[l-1] is the dY of layer l-1: its ReLU mask and bias gradient ride on the epilogue of the kernel that writes it
@@ -441,38 +441,39 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
                     t.du, t.ghat);
   // ---------------- backward ----------------
   const int RW = t.rgb_h[level].N;
-  r.dense_bwd(t.rgb_out[level], {{t.rgb_hv, RW, RW, t.g0, RW, false}}, t.d_rgb_logit, 3, nullptr);
+  // (the last writer of a ReLU layer's output gradient masks it and adds its bias gradient: Seg::dx_relu_y / dx_bias_grad)
+  bool pm = r.dense_bwd(t.rgb_out[level], {{t.rgb_hv, RW, RW, t.g0, RW, false, t.rgb_hv, t.grad + t.rgb_h[level].b}}, t.d_rgb_logit, 3, nullptr);
   r.dense_bwd(t.rgb_h[level], {{t.bottv, TW, TW, t.g1, TW, false}, {t.cond, CW, VD, nullptr, 0, false}, {tout, TW, TW, t.g2, TW, false},
-                               {t.cond + VD, CW, NM, nullptr, 0, false}}, t.g0, RW, t.rgb_hv);
+                               {t.cond + VD, CW, NM, nullptr, 0, false}}, t.g0, RW, t.rgb_hv, pm);
   r.dense_bwd(t.bott[level], {{tout, TW, TW, t.g2, TW, true}}, t.g1, TW, nullptr);
-  r.dense_bwd(t.alpha[level], {{tout, TW, TW, t.g2, TW, true}}, t.d_alpha, 4, nullptr);
-  r.mlp_bwd(trunk, t.trunk_in, t.trunk_h, t.g2, t.g0, t.d_trunk_in);
+  pm = r.dense_bwd(t.alpha[level], {{tout, TW, TW, t.g2, TW, true, tout, t.grad + trunk.hidden.back().b}}, t.d_alpha, 4, nullptr);
+  r.mlp_bwd(trunk, t.trunk_in, t.trunk_h, t.g2, t.g0, t.d_trunk_in, pm);
   if (nl) {   // backward of the tangent pass, part 1: alpha head, trunk, trunk input (adds second-derivative terms to d x', d w)
-    r.dense_jvp_bwd(t.alpha[level], {{t.tt_h.back(), TW, TW, t.tA, TW, false}}, t.d_t_alpha, 4, nullptr);
-    r.mlp_jvp_bwd(trunk, t.t_tin, t.tt_h, t.trunk_h, t.tA, t.tB, t.d_t_tin);
+    pm = r.dense_jvp_bwd(t.alpha[level], {{t.tt_h.back(), TW, TW, t.tA, TW, false, tout, nullptr}}, t.d_t_alpha, 4, nullptr);
+    r.mlp_jvp_bwd(trunk, t.t_tin, t.tt_h, t.trunk_h, t.tA, t.tB, t.d_t_tin, pm);
     trunk_in_jvp_bwd(st, D, M, t.d_t_tin, t.xw, t.wamb, t.t_xw, t.t_wamb, W, t.d_t_xw, t.d_t_wamb, t.dxw_reg, t.dwamb_extra);
   }
   trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, nl ? t.dwamb_extra : nullptr, t.dxw, t.dwamb);
   if (nl) {   // part 2: hyper sheet tangents
-    r.dense_jvp_bwd(t.hyper_out, {{t.th_h.back(), t.hyper.width, t.hyper.width, t.tA, t.hyper.width, false}}, t.d_t_wamb, 2, nullptr);
-    r.mlp_jvp_bwd(t.hyper, t.t_hyper_in, t.th_h, t.hyper_h, t.tA, t.tB, nullptr);
+    pm = r.dense_jvp_bwd(t.hyper_out, {{t.th_h.back(), t.hyper.width, t.hyper.width, t.tA, t.hyper.width, false, t.hyper_h.back(), nullptr}}, t.d_t_wamb, 2, nullptr);
+    r.mlp_jvp_bwd(t.hyper, t.t_hyper_in, t.th_h, t.hyper_h, t.tA, t.tB, nullptr, pm);
   }
-  r.dense_bwd(t.hyper_out, {{t.hyper_h.back(), t.hyper.width, t.hyper.width, t.g0, t.hyper.width, false}}, t.dwamb, 2, nullptr);
-  r.mlp_bwd(t.hyper, t.hyper_in, t.hyper_h, t.g0, t.g1, t.d_hyper_in);
+  pm = r.dense_bwd(t.hyper_out, {{t.hyper_h.back(), t.hyper.width, t.hyper.width, t.g0, t.hyper.width, false, t.hyper_h.back(), t.grad + t.hyper.hidden.back().b}}, t.dwamb, 2, nullptr);
+  r.mlp_bwd(t.hyper, t.hyper_in, t.hyper_h, t.g0, t.g1, t.d_hyper_in, pm);
   if (nl) {   // part 3: exp_se3 tangents (second derivatives) and the warp net's tangents
     se3_jvp_bwd(st, M, t.wv, t.x, t.t_wv, t.d_t_xw, t.du, t.ghat, t.d_t_wv, t.dwv_extra);
     r.dense_jvp_bwd(t.warp_w, {{t.tw_h.back(), t.warp.width, t.warp.width, t.tA, t.warp.width, false}}, t.d_t_wv, 6, nullptr);
-    r.dense_jvp_bwd(t.warp_v, {{t.tw_h.back(), t.warp.width, t.warp.width, t.tA, t.warp.width, true}}, t.d_t_wv + 3, 6, nullptr);
-    r.mlp_jvp_bwd(t.warp, t.t_warp_in, t.tw_h, t.warp_h, t.tA, t.tB, nullptr);
+    pm = r.dense_jvp_bwd(t.warp_v, {{t.tw_h.back(), t.warp.width, t.warp.width, t.tA, t.warp.width, true, t.warp_h.back(), nullptr}}, t.d_t_wv + 3, 6, nullptr);
+    r.mlp_jvp_bwd(t.warp, t.t_warp_in, t.tw_h, t.warp_h, t.tA, t.tB, nullptr, pm);
   }
   se3_bwd(st, M, t.wv, t.x, t.dxw, nl ? t.dwv_extra : nullptr, t.dwv);
   r.dense_bwd(t.warp_w, {{t.warp_h.back(), t.warp.width, t.warp.width, t.g0, t.warp.width, false}}, t.dwv, 6, nullptr);
-  r.dense_bwd(t.warp_v, {{t.warp_h.back(), t.warp.width, t.warp.width, t.g0, t.warp.width, true}}, t.dwv + 3, 6, nullptr);
-  r.mlp_bwd(t.warp, t.warp_in, t.warp_h, t.g0, t.g1, t.d_warp_in);
+  pm = r.dense_bwd(t.warp_v, {{t.warp_h.back(), t.warp.width, t.warp.width, t.g0, t.warp.width, true, t.warp_h.back(), t.grad + t.warp.hidden.back().b}}, t.dwv + 3, 6, nullptr);
+  r.mlp_bwd(t.warp, t.warp_in, t.warp_h, t.g0, t.g1, t.d_warp_in, pm);
   shared_in_bwd(st, D, R, S, t.d_warp_in, t.d_hyper_in, t.mask_logit, ex->mask_ratio, ob ? t.d_pm : nullptr, rays->warp_id, t.cfg.num_warp_embeds,
                 t.grad + t.warp_tbl, t.d_mask_logit);
-  r.dense_bwd(t.mask_out, {{t.mask_h.back(), t.mask.width, t.mask.width, t.g0, t.mask.width, false}}, t.d_mask_logit, 1, nullptr);
-  r.mlp_bwd(t.mask, t.mask_in, t.mask_h, t.g0, t.g1, t.d_mask_in);
+  pm = r.dense_bwd(t.mask_out, {{t.mask_h.back(), t.mask.width, t.mask.width, t.g0, t.mask.width, false, t.mask_h.back(), t.grad + t.mask.hidden.back().b}}, t.d_mask_logit, 1, nullptr);
+  r.mlp_bwd(t.mask, t.mask_in, t.mask_h, t.g0, t.g1, t.d_mask_in, pm);
   mask_in_bwd(st, D, R, S, t.d_mask_in, rays->warp_id, t.cfg.num_warp_embeds, t.grad + t.mask_tbl);
   if (!r.ok) return t.fail(NERFDS_EDEVICE, "rocBLAS sgemm failed");
   return NERFDS_OK;

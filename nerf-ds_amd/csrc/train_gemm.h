@@ -16,7 +16,8 @@ struct DenseArgs {
   int ldy, n_out;
   long long M;
   int relu;                 // y = max(y, 0)
-  const float* mask_y;      // nullptr, or: y = 0 where mask_y[(row / mask_div) * ld_mask + n] <= 0 (ReLU backward of the consumer)
+  const float* mask_y;      // nullptr, or: y = 0 where mask_y[(row / mask_div) * ld_mask + n] <= 0 (ReLU backward of the consumer);
+                            // with accumulate the mask (and colsum) apply to the total, i.e. this must be the last contribution
   int ld_mask, mask_div;
   int accumulate;           // y += result
   int precise;              // operands split three ways (hi / mid / lo bf16, 6 MFMAs per fragment): fp32-level products; wfrag packed with parts = 3

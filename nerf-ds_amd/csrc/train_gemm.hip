@@ -72,14 +72,14 @@ __device__ __forceinline__ void store_tile(const DenseArgs& A, const f32x16& acc
     if (A.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
     if (A.vec_out) {
       if (n0 < A.n_out) {                                      // n_out is a multiple of 4 on this path
+        f32x4* dst = reinterpret_cast<f32x4*>(A.y + (size_t)row * A.ldy + n0);
+        if (A.accumulate) v += *dst;                          // the mask and the column sums apply to the TOTAL
         if (A.mask_y != nullptr) {
           const f32x4 y = *reinterpret_cast<const f32x4*>(A.mask_y + mrow + n0);
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (!(y[j] > 0.f)) v[j] = 0.f;
         }
         csum[4 * q] += v[0]; csum[4 * q + 1] += v[1]; csum[4 * q + 2] += v[2]; csum[4 * q + 3] += v[3];
-        f32x4* dst = reinterpret_cast<f32x4*>(A.y + (size_t)row * A.ldy + n0);
-        if (A.accumulate) v += *dst;
         *dst = v;
       }
     } else {
@@ -88,10 +88,11 @@ __device__ __forceinline__ void store_tile(const DenseArgs& A, const f32x16& acc
         const int n = n0 + j;
         if (n >= A.n_out) continue;
         float x = v[j];
+        float* dst = A.y + (size_t)row * A.ldy + n;
+        if (A.accumulate) x += *dst;
         if (A.mask_y != nullptr && !(A.mask_y[mrow + n] > 0.f)) x = 0.f;
         csum[4 * q + j] += x;
-        float* dst = A.y + (size_t)row * A.ldy + n;
-        *dst = A.accumulate ? (*dst + x) : x;
+        *dst = x;
       }
     }
   }

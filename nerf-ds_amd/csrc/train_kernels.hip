@@ -79,6 +79,46 @@ __global__ void k_resample(int R, int Nc, int Nf, const float* __restrict__ zc, 
   }
 }
 
+// The same, one wavefront per ray (Nc, Nf <= 256): the running sums stay serial (lane 0: the cdf must round exactly as the
+// sequential cumsum does), the Nf inverse-cdf look-ups and the rank sort of the Nc + Nf depths are spread over the lanes.
+__global__ __launch_bounds__(64) void k_resample_wave(int R, int Nc, int Nf, const float* __restrict__ zc, const float* __restrict__ wc, int stratified,
+                                                      const float* __restrict__ u_rand, float* __restrict__ zf) {
+  __shared__ float cdf[256], bins[256], zall[512];
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const float* z = zc + (size_t)r * Nc;
+  const float* w = wc + (size_t)r * Nc;
+  const int nb = Nc - 1, nw = Nc - 2, n = Nc + Nf;
+  for (int i = lane; i < nb; i += 64) bins[i] = 0.5f * (z[i + 1] + z[i]);
+  for (int i = lane; i < Nc; i += 64) zall[i] = z[i];
+  if (lane == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < nw; ++i) tot += w[i + 1] + 1e-5f;
+    cdf[0] = 0.f;
+    float c = 0.f;
+    for (int i = 0; i < nw; ++i) { c += (w[i + 1] + 1e-5f) / tot; cdf[i + 1] = c; }
+  }
+  __syncthreads();
+  for (int k = lane; k < Nf; k += 64) {
+    const float u = (stratified && u_rand) ? u_rand[(size_t)r * Nf + k] : (Nf > 1 ? (float)k / (float)(Nf - 1) : 0.f);
+    int lo = 0, hi = nb;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+    int k0 = lo - 1; if (k0 < 0) k0 = 0;
+    const int k1 = (k0 + 1 < nb) ? k0 + 1 : nb - 1;
+    const float b0 = fminf(bins[k0], bins[nb - 2]), b1 = fmaxf(bins[k1], bins[1]);
+    const float c0 = fminf(cdf[k0], cdf[nb - 2]), c1 = fmaxf(cdf[k1], cdf[1]);
+    float denom = c1 - c0; if (denom < 1e-5f) denom = 1.0f;
+    zall[Nc + k] = b0 + (u - c0) / denom * (b1 - b0);
+  }
+  __syncthreads();
+  float* out = zf + (size_t)r * n;
+  for (int i = lane; i < n; i += 64) {
+    const float v = zall[i];
+    int rank = 0;
+    for (int q = 0; q < n; ++q) { const float o = zall[q]; rank += (o < v || (o == v && q < i)) ? 1 : 0; }
+    out[rank] = v;
+  }
+}
+
 // ---- inputs of the three shared nets (models.py:931-975, 729-732; modules.py:367-434; warping.py:200-237) --------
 __global__ void k_encode_inputs(Dims D, int R, int S, const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z,
                                 const uint32_t* __restrict__ warp_id, int n_embeds, const float* __restrict__ warp_tbl,
@@ -757,7 +797,8 @@ void coarse_z(hipStream_t st, int R, int Nc, float near_, float far_, int strati
   LAUNCH(k_coarse_z, (long long)R * Nc, st, R, Nc, near_, far_, stratified, t_rand, z);
 }
 void resample(hipStream_t st, int R, int Nc, int Nf, const float* zc, const float* wc, int stratified, const float* u_rand, float* zf, float* scratch) {
-  hipLaunchKernelGGL(k_resample, grid1(R, 64), dim3(64), 0, st, R, Nc, Nf, zc, wc, stratified, u_rand, zf, scratch);
+  if (Nc <= 256 && Nf <= 256) hipLaunchKernelGGL(k_resample_wave, dim3(R), dim3(64), 0, st, R, Nc, Nf, zc, wc, stratified, u_rand, zf);
+  else hipLaunchKernelGGL(k_resample, grid1(R, 64), dim3(64), 0, st, R, Nc, Nf, zc, wc, stratified, u_rand, zf, scratch);
 }
 void encode_inputs(hipStream_t st, const Dims& D, int R, int S, const float* o, const float* d, const float* z, const uint32_t* warp_id, int n_embeds,
                    const float* warp_tbl, const float* mask_tbl, const Windows& W, float* x, float* mask_in, float* warp_in, float* hyper_in) {

@@ -67,10 +67,14 @@ def test_train_oracle_reproduces_golden():
 
 
 @pytest.mark.gpu
-def test_hip_training_step_matches_golden():
+@pytest.mark.parametrize('gemm', ['mfma', 'rocblas'])
+def test_hip_training_step_matches_golden(gemm, monkeypatch):
   """The HIP training step against COMMITTED gradient digests (the oracle is not run): per leaf a seeded subsample of
-  256 entries, the L2 norm and the max-abs value of the fp64 autograd gradient."""
+  256 entries, the L2 norm and the max-abs value of the fp64 autograd gradient.  Both GEMM modes of the trainer
+  (tests/test_training.py: 'mfma' = hand-written split-bf16 layers, max-abs bound 5e-2 because a ReLU at ~0 may flip;
+  'rocblas' = fp32 library GEMMs, 1e-2)."""
   from nerfds_amd.training import Trainer
+  monkeypatch.setenv('NERFDS_TRAIN_GEMM', gemm)
   from nerfds_amd.params import tree_leaves
   z = np.load(os.path.join(HERE, 'golden', 'train_' + G.TRAIN_CASE + '.npz'))
   cfg, params, rays, t, u, target = G.train_case()
@@ -83,5 +87,5 @@ def test_hip_training_step_matches_golden():
     idx, want, norm, amax = z['idx/' + name], z['val/' + name], float(z['norm/' + name]), float(z['max/' + name])
     flat = np.asarray(g, np.float64).ravel()
     scale = max(amax, 1e-3 * gmax)
-    assert np.abs(flat[idx] - want).max() / scale < 1e-2, name          # fp32 path vs fp64 fixture (yardstick: tests/test_training.py)
+    assert np.abs(flat[idx] - want).max() / scale < (5e-2 if gemm == 'mfma' else 1e-2), name   # fp32 path vs fp64 fixture (yardstick: tests/test_training.py)
     assert abs(np.linalg.norm(flat) - norm) <= 4e-3 * max(norm, 1e-3 * gmax * np.sqrt(flat.size)), name
