@@ -46,8 +46,8 @@ int main(int argc, char** argv) {
       for (int k = 0; k < s.k1; ++k) a += (double)hx1[r * s.k1 + k] * hw[k * s.n + n];
       for (int k = 0; k < s.k2; ++k) a += (double)hx2[r * s.k2 + k] * hw[(s.k1 + k) * s.n + n];
       if (s.relu) a = a > 0 ? a : 0;
+      if (s.acc) a += hy0[r * s.n + n];                 // (the mask covers the accumulated total)
       if (s.mask && !(hm[r * s.n + n] > 0)) a = 0;
-      if (s.acc) a += hy0[r * s.n + n];
       worst = std::fmax(worst, std::fabs(a - hy[r * s.n + n]));
     }
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -59,6 +59,40 @@ int main(int argc, char** argv) {
     const double bytes = (double)M * (K + s.n * (1 + (s.mask ? 1 : 0) + (s.acc ? 1 : 0))) * 4;
     printf("M=%lld K=%d+%d N=%d relu=%d mask=%d acc=%d: %.3f ms  %.0f GB/s  max|err|=%.2e\n", M, s.k1, s.k2, s.n, s.relu, s.mask, s.acc, ms, bytes / ms / 1e6, worst);
     (void)hipFree(x1); if (x2) (void)hipFree(x2); (void)hipFree(y); (void)hipFree(mk); (void)hipFree(w); (void)hipFree(b); (void)hipFree(frag);
+  }
+  // ---- weight gradient dW = X^T dY ----
+  struct WS { int k, n; };
+  const WS wshapes[] = {{256, 256}, {128, 128}, {64, 64}, {52, 256}, {33, 128}, {128, 3}};
+  for (const WS& w : wshapes) {
+    float *x, *dy, *dw; void* zeros;
+    (void)hipMalloc(&x, M * w.k * 4); (void)hipMalloc(&dy, M * w.n * 4); (void)hipMalloc(&dw, w.k * w.n * 4); (void)hipMalloc(&zeros, 256);
+    (void)hipMemset(zeros, 0, 256); (void)hipMemset(dw, 0, w.k * w.n * 4);
+    const long long Mc = 4096;                      // rows that carry data (the rest are zero): the CPU check stays cheap
+    std::vector<float> hx(Mc * w.k), hd(Mc * w.n);
+    for (auto& v : hx) v = frand(); for (auto& v : hd) v = frand();
+    (void)hipMemset(x, 0, M * w.k * 4); (void)hipMemset(dy, 0, M * w.n * 4);
+    (void)hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(dy, hd.data(), hd.size() * 4, hipMemcpyHostToDevice);
+    WgradArgs A{x, w.k, w.k, dy, w.n, w.n, M, nullptr, dw, zeros, 0, 0};
+    if (!wgrad_supported(A)) { printf("wgrad %d x %d not supported\n", w.k, w.n); continue; }
+    const int grid = wgrad_grid(A, prop.multiProcessorCount);
+    wgrad(nullptr, A, grid);
+    (void)hipDeviceSynchronize();
+    std::vector<float> hw(w.k * w.n);
+    (void)hipMemcpy(hw.data(), dw, hw.size() * 4, hipMemcpyDeviceToHost);
+    double worst = 0, big = 0;
+    for (int k = 0; k < w.k; ++k) for (int n = 0; n < w.n; ++n) {
+      double a = 0;
+      for (long long r = 0; r < Mc; ++r) a += (double)hx[r * w.k + k] * hd[r * w.n + n];
+      worst = std::fmax(worst, std::fabs(a - hw[k * w.n + n])); big = std::fmax(big, std::fabs(a));
+    }
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int reps = 20;
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < reps; ++i) wgrad(nullptr, A, grid);
+    (void)hipEventRecord(e1, nullptr); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("wgrad M=%lld K=%d N=%d: %.3f ms  %.0f GB/s  max|err|=%.2e (max|dW|=%.1f)\n", M, w.k, w.n, ms, (double)M * (w.k + w.n) * 4 / ms / 1e6, worst, big);
+    (void)hipFree(x); (void)hipFree(dy); (void)hipFree(dw); (void)hipFree(zeros);
   }
   return 0;
 }
