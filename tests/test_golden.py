@@ -88,4 +88,4 @@ def test_hip_training_step_matches_golden(gemm, monkeypatch):
     flat = np.asarray(g, np.float64).ravel()
     scale = max(amax, 1e-3 * gmax)
     assert np.abs(flat[idx] - want).max() / scale < (5e-2 if gemm == 'mfma' else 1e-2), name   # fp32 path vs fp64 fixture (yardstick: tests/test_training.py)
-    assert abs(np.linalg.norm(flat) - norm) <= 4e-3 * max(norm, 1e-3 * gmax * np.sqrt(flat.size)), name
+    assert abs(np.linalg.norm(flat) - norm) <= (2e-2 if gemm == 'mfma' else 4e-3) * max(norm, 1e-3 * gmax * np.sqrt(flat.size)), name
