@@ -72,7 +72,8 @@ def test_hip_training_step_matches_golden(gemm, monkeypatch):
   """The HIP training step against COMMITTED gradient digests (the oracle is not run): per leaf a seeded subsample of
   256 entries, the L2 norm and the max-abs value of the fp64 autograd gradient.  Both GEMM modes of the trainer
   (tests/test_training.py): 'rocblas' = fp32 library GEMMs: 1e-2 / 4e-3 (measured 2e-5); 'mfma' = hand-written split-bf16
-  layers: 5e-2 / 3e-2.  The wide bound is not slack in the kernels: on this case (trained-regime weights) the gradient w.r.t.
+  layers: 1e-1 (max-abs: a ReLU whose pre-activation is ~0 can flip, which moves single entries by one
+  sample's contribution - 5e-2 of the leaf maximum on a trunk bias here) / 3e-2 (norm).  The wide norm bound is not slack in the kernels: on this case (trained-regime weights) the gradient w.r.t.
   the warped points - which every warp / hyper-sheet / mask leaf goes through - is a cancelling sum over the 2^0..2^7 posenc
   frequencies with condition number ~300 (fp32's 6e-8 becomes the 2e-5 measured in the rocblas mode), so the 2^-17 operand
   rounding of the split-bf16 GEMMs anywhere in the trunk shows up as ~1e-2 on those leaves (measured 1.4e-2 worst, NerfMLP
@@ -91,5 +92,5 @@ def test_hip_training_step_matches_golden(gemm, monkeypatch):
     idx, want, norm, amax = z['idx/' + name], z['val/' + name], float(z['norm/' + name]), float(z['max/' + name])
     flat = np.asarray(g, np.float64).ravel()
     scale = max(amax, 1e-3 * gmax)
-    assert np.abs(flat[idx] - want).max() / scale < (5e-2 if gemm == 'mfma' else 1e-2), name   # fp32 path vs fp64 fixture (yardstick: tests/test_training.py)
+    assert np.abs(flat[idx] - want).max() / scale < (1e-1 if gemm == 'mfma' else 1e-2), name   # fp32 path vs fp64 fixture (yardstick: tests/test_training.py)
     assert abs(np.linalg.norm(flat) - norm) <= (3e-2 if gemm == 'mfma' else 4e-3) * max(norm, 1e-3 * gmax * np.sqrt(flat.size)), name
