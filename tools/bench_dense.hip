@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     void* zeros; (void)hipMalloc(&zeros, 256); (void)hipMemset(zeros, 0, 256); A.zeros = zeros;
     pack_frags(nullptr, w, s.n, 0, K, s.n, 0, frag);
     if (!dense_ws(nullptr, A, prop.multiProcessorCount)) { printf("shape %d+%d -> %d not supported\n", s.k1, s.k2, s.n); continue; }
-    (void)hipDeviceSynchronize();
+    { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) printf("  !! %s\n", hipGetErrorString(e)); }
     std::vector<float> hy(Mc * s.n);
     (void)hipMemcpy(hy.data(), y, hy.size() * 4, hipMemcpyDeviceToHost);
     double worst = 0;
