@@ -115,24 +115,26 @@ __device__ __forceinline__ void flush_colsum(const DenseArgs& A, f32x16 csum, in
 // along k: same s, different (c, hh)) spreads over the LDS banks; the B-operand READ (lanes along s) stays a permutation.
 __device__ __forceinline__ int slot_of(int c, int hh, int s) { return (s + 2 * c + hh) & 31; }
 
-template <int KC, int WAVES>
+template <int KC, int WAVES, bool P3>
 __global__ __launch_bounds__(64 * WAVES) void k_dense_ws(const DenseArgs A) {
+  constexpr int PARTS = P3 ? 3 : 2;            // bf16 pieces per operand (P3: hi / mid / lo = fp32-level products, 6 MFMAs)
   constexpr int R = 32 / WAVES;                  // rows of the X tile this wave fetches
   constexpr int QPR = (KC * 4 + 63) / 64;        // float4 per lane per row
-  constexpr int TILE = KC * 2048;
+  constexpr int TILE = KC * 1024 * PARTS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 31, h = lane >> 5;
   const int n_tiles = (A.n_out + 31) >> 5;
   const bool computes = wave < n_tiles;
   const int ot = computes ? wave : 0;
   // this wave's weight slice, resident for the whole kernel
-  bf16x8 wh[KC], wl[KC];
+  bf16x8 wh[KC], wl[KC], wm[P3 ? KC : 1];
   const u32x4* wfrag = static_cast<const u32x4*>(A.wfrag);
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
-    const size_t base = ((size_t)(ot * KC + kc) * 2) * 64;
+    const size_t base = ((size_t)(ot * KC + kc) * PARTS) * 64;
     wh[kc] = __builtin_bit_cast(bf16x8, wfrag[base + lane]);
-    wl[kc] = __builtin_bit_cast(bf16x8, wfrag[base + 64 + lane]);
+    if constexpr (P3) { wm[kc] = __builtin_bit_cast(bf16x8, wfrag[base + 64 + lane]); wl[kc] = __builtin_bit_cast(bf16x8, wfrag[base + 128 + lane]); }
+    else wl[kc] = __builtin_bit_cast(bf16x8, wfrag[base + 64 + lane]);
   }
   const int K = A.k_total;
   const long long tiles = (A.M + 31) / 32;
@@ -196,16 +198,25 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_ws(const DenseArgs A) {
       for (int q = 0; q < QPR; ++q) {
         const int kk = 4 * (lane + 64 * q);
         if (kk < KC * 16) {
-          unsigned short hi[4], lo[4];
+          unsigned short hi[4], mid[4], lo[4];       // two-way split: hi, mid (= its "lo")
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { hi[e] = bf16_rne(pf[j][q][e]); lo[e] = bf16_rne(pf[j][q][e] - bf16_f32(hi[e])); }
+          for (int e = 0; e < 4; ++e) {
+            hi[e] = bf16_rne(pf[j][q][e]);
+            const float r = pf[j][q][e] - bf16_f32(hi[e]);
+            mid[e] = bf16_rne(r);
+            lo[e] = bf16_rne(r - bf16_f32(mid[e]));
+          }
           const int c = kk >> 4, hh = (kk >> 3) & 1;
-          const int off = c * 2048 + hh * 512 + slot_of(c, hh, s) * 16 + (kk & 7) * 2;
+          const int off = c * 1024 * PARTS + hh * 512 + slot_of(c, hh, s) * 16 + (kk & 7) * 2;
           typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
           u32x2 a = {hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16)};
-          u32x2 b = {lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16)};
+          u32x2 b = {mid[0] | ((unsigned)mid[1] << 16), mid[2] | ((unsigned)mid[3] << 16)};
           *reinterpret_cast<u32x2*>(buf + off) = a;
           *reinterpret_cast<u32x2*>(buf + off + 1024) = b;
+          if constexpr (P3) {
+            u32x2 c3 = {lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16)};
+            *reinterpret_cast<u32x2*>(buf + off + 2048) = c3;
+          }
         }
       }
     }
@@ -224,12 +235,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_ws(const DenseArgs A) {
       f32x16 acc = bias;
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
-        const int off = kc * 2048 + h * 512 + slot_of(kc, h, m) * 16;
+        const int off = kc * 1024 * PARTS + h * 512 + slot_of(kc, h, m) * 16;
         const bf16x8 xh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(buf + off));
-        const bf16x8 xl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(buf + off + 1024));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
+        const bf16x8 xl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(buf + off + 1024 * (PARTS - 1)));
+        if constexpr (P3) {
+          const bf16x8 xm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(buf + off + 1024));
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[kc], xm, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xm, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[kc], xh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
+        } else {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
+        }
       }
       store_tile(A, acc, tile * 32 + m, ot, h, csum);
     }
@@ -615,9 +636,8 @@ template <int KC, int WAVES, bool P3 = false> static void launch(hipStream_t st,
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < want ? tiles : want)), dim3(64 * WAVES), lds, st, A);
     return;
   }
-  if constexpr (P3) return;                                     // (dense_ws_supported() keeps the three-way split off this path)
-  const int lds = 2 * KC * 2048;
-  auto kern = k_dense_ws<KC, WAVES>;
+  const int lds = 2 * KC * 1024 * (P3 ? 3 : 2);
+  auto kern = k_dense_ws<KC, WAVES, P3>;
   static int per_cu = 0;
   if (per_cu == 0) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -635,9 +655,7 @@ bool dense_ws_supported(const DenseArgs& A) {
   if (KC > 21 && A.n_out > 128) return false;      // the slice of a long layer needs a 512-register wave: at most 4 waves
   if (A.mask_div != 1 && A.mask_div != 3) return false;
   if (A.precise) {                                              // three-way split: 4-wave LDS-DMA shape, K <= 192
-    if (A.n_out > 128 || KC > 12 || A.zeros == nullptr) return false;
-    for (int g = 0; g < A.nseg; ++g)
-      if (A.seg[g].k % 4 || A.seg[g].ld % 4 || !aligned16(A.seg[g].x)) return false;
+    if (A.n_out > 128 || KC > 12) return false;
   }
   for (int g = 0, k0 = 0; g < A.nseg; ++g) {        // a quad of 4 consecutive k never straddles two segments
     if (k0 % 4) return false;

@@ -17,7 +17,8 @@ int main(int argc, char** argv) {
   const Shape shapes[] = {{128, 0, 128, true, false, false, false}, {256, 0, 256, true, false, false, false}, {256, 52, 256, true, false, false, false},
                           {128, 33, 128, true, false, false, false}, {64, 0, 64, true, false, false, false}, {256, 0, 4, false, false, false, false},
                           {256, 0, 256, false, true, false, false}, {128, 0, 128, false, true, true, false}, {536, 24, 128, true, false, false, false},
-                          {128, 0, 128, true, false, false, true}, {128, 0, 3, false, false, false, true}};
+                          {128, 0, 128, true, false, false, true}, {128, 0, 3, false, false, false, true},
+                          {128, 33, 128, true, false, false, true}, {33, 0, 128, true, false, false, true}};
   const long long M = argc > 1 ? atoll(argv[1]) : 524288;
   hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, 0);
   for (const Shape& s : shapes) {
