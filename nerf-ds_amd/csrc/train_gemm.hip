@@ -62,24 +62,28 @@ __global__ void k_pack_frags(const float* __restrict__ W, int ldw, int row0, int
 }
 
 // Epilogue: this lane holds sample `row`, features 32 ot + 8 q + 4 h + j of the accumulator (q = 0..3, j = 0..3).
+// MODE: the 8-wave kernels have no registers to spare, so they are compiled twice - 1 = forward epilogue only (bias, ReLU),
+// 2 = backward epilogue only (accumulate, mask, column sums); 0 = everything (4-wave kernels).
+template <int MODE>
 __device__ __forceinline__ void store_tile(const DenseArgs& A, const f32x16& acc, long long row, int ot, int h, f32x16& csum) {
   if (row >= A.M) return;
-  const size_t mrow = A.mask_y != nullptr ? (size_t)(A.mask_div == 3 ? row / 3 : row) * A.ld_mask : 0;
+  constexpr bool FWD = MODE != 2, BWD = MODE != 1;
+  const size_t mrow = (BWD && A.mask_y != nullptr) ? (size_t)(A.mask_div == 3 ? row / 3 : row) * A.ld_mask : 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int n0 = 32 * ot + 8 * q + 4 * h;
     f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-    if (A.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    if (FWD && A.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
     if (A.vec_out) {
       if (n0 < A.n_out) {                                      // n_out is a multiple of 4 on this path
         f32x4* dst = reinterpret_cast<f32x4*>(A.y + (size_t)row * A.ldy + n0);
-        if (A.accumulate) v += *dst;                          // the mask and the column sums apply to the TOTAL
-        if (A.mask_y != nullptr) {
+        if (BWD && A.accumulate) v += *dst;                   // the mask and the column sums apply to the TOTAL
+        if (BWD && A.mask_y != nullptr) {
           const f32x4 y = *reinterpret_cast<const f32x4*>(A.mask_y + mrow + n0);
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (!(y[j] > 0.f)) v[j] = 0.f;
         }
-        csum[4 * q] += v[0]; csum[4 * q + 1] += v[1]; csum[4 * q + 2] += v[2]; csum[4 * q + 3] += v[3];
+        if constexpr (BWD) { csum[4 * q] += v[0]; csum[4 * q + 1] += v[1]; csum[4 * q + 2] += v[2]; csum[4 * q + 3] += v[3]; }
         *dst = v;
       }
     } else {
@@ -89,9 +93,9 @@ __device__ __forceinline__ void store_tile(const DenseArgs& A, const f32x16& acc
         if (n >= A.n_out) continue;
         float x = v[j];
         float* dst = A.y + (size_t)row * A.ldy + n;
-        if (A.accumulate) x += *dst;
-        if (A.mask_y != nullptr && !(A.mask_y[mrow + n] > 0.f)) x = 0.f;
-        csum[4 * q + j] += x;
+        if (BWD && A.accumulate) x += *dst;
+        if (BWD && A.mask_y != nullptr && !(A.mask_y[mrow + n] > 0.f)) x = 0.f;
+        if constexpr (BWD) csum[4 * q + j] += x;
         *dst = x;
       }
     }
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_ws(const DenseArgs A) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
         }
       }
-      store_tile(A, acc, tile * 32 + m, ot, h, csum);
+      store_tile<0>(A, acc, tile * 32 + m, ot, h, csum);
     }
     if (next < tiles) stage(g_tile + (cur ^ 1) * TILE);
     __syncthreads();
@@ -285,8 +289,9 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {      // vmcnt
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (0 << 8));
 }
 
-template <int KC, int WAVES, bool P3>
+template <int KC, int WAVES, bool P3, int MODE>
 __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
+  constexpr bool FWD = MODE != 2, BWD = MODE != 1;      // see store_tile
   static_assert(!P3 || WAVES == 4, "the three-way split is built for the 4-wave shape only");
   constexpr int PARTS = P3 ? 3 : 2;
   typedef DmaShape<KC, WAVES> S;
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int n = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
-    bias[r] = (A.bias != nullptr && n < A.n_out) ? A.bias[n] : 0.f;
+    bias[r] = (FWD && A.bias != nullptr && n < A.n_out) ? A.bias[n] : 0.f;
   }
   const int K = A.k_total;
   const long long tiles = (A.M + 31) / 32;
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       if (computes) {
-        f32x16 acc = bias;
+        f32x16 acc = FWD ? bias : f32x16{};
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
           const int off = kc * 2048 + h * 512 + slot_of(kc, h, m) * 16;
@@ -403,12 +408,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
         }
-        store_tile(A, acc, tile * 32 + m, ot, h, csum);
+        store_tile<MODE>(A, acc, tile * 32 + m, ot, h, csum);
       }
     } else
     if (computes) {
       const char* buf = g_tile + (it % S::NS) * S::TILE_BYTES + (m * S::STRIDE + 2 * h) * 16;
-      f32x16 acc = bias;
+      f32x16 acc = FWD ? bias : f32x16{};
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
         const f32x4 f0 = *reinterpret_cast<const f32x4*>(buf + kc * 64);
@@ -443,11 +448,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
         }
       }
-      store_tile(A, acc, tile * 32 + m, ot, h, csum);
+      store_tile<MODE>(A, acc, tile * 32 + m, ot, h, csum);
     }
   }
   wait_vm_lgkm0<0>();                              // DMAs issued past the last tile (zero line) before the LDS is released
-  if (A.colsum != nullptr && computes) flush_colsum(A, csum, ot, h, m);
+  if constexpr (BWD) if (A.colsum != nullptr && computes) flush_colsum(A, csum, ot, h, m);
 }
 
 // ---- weight gradient: dW[K x N] = X^T dY, contraction over the samples ------------------------------------------------
@@ -615,6 +620,20 @@ size_t frag_bytes(int in_dim, int out_dim, int parts) { return (size_t)((out_dim
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+template <int KC, int WAVES, bool P3, int MODE> static void launch_dma(hipStream_t st, const DenseArgs& A, int num_cus, long long tiles) {
+  typedef DmaShape<KC, WAVES> S;
+  const int lds = S::NS * S::TILE_BYTES + S::IMG_BYTES;
+  auto kern = k_dense_dma<KC, WAVES, P3, MODE>;
+  static int per_cu = 0;                                        // resident workgroups per CU (registers / LDS decide)
+  if (per_cu == 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    int n = 0;
+    per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 64 * WAVES, lds) == hipSuccess && n > 0) ? n : 1;
+  }
+  const long long want = (long long)num_cus * per_cu;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < want ? tiles : want)), dim3(64 * WAVES), lds, st, A);
+}
+
 template <int KC, int WAVES, bool P3 = false> static void launch(hipStream_t st, DenseArgs A, int num_cus) {
   const long long tiles = (A.M + 31) / 32;
   A.vec_in = 1;
@@ -623,17 +642,13 @@ template <int KC, int WAVES, bool P3 = false> static void launch(hipStream_t st,
   A.vec_out = (A.n_out % 4 == 0 && A.ldy % 4 == 0 && aligned16(A.y) && (A.mask_y == nullptr || (A.ld_mask % 4 == 0 && aligned16(A.mask_y)))) ? 1 : 0;
   const bool dma = A.vec_in && A.zeros != nullptr && getenv("NERFDS_WS_NODMA") == nullptr;
   if (dma) {
-    typedef DmaShape<KC, WAVES> S;
-    const int lds = S::NS * S::TILE_BYTES + S::IMG_BYTES;
-    auto kern = k_dense_dma<KC, WAVES, P3>;
-    static int per_cu = 0;                                        // resident workgroups per CU (registers / LDS decide)
-    if (per_cu == 0) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      int n = 0;
-      per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 64 * WAVES, lds) == hipSuccess && n > 0) ? n : 1;
+    // 8 waves: one instantiation per epilogue kind (registers); a layer has a forward epilogue or a backward one
+    const bool bwd = A.mask_y != nullptr || A.accumulate || A.colsum != nullptr;
+    if constexpr (WAVES == 8) {
+      if (bwd) launch_dma<KC, WAVES, P3, 2>(st, A, num_cus, tiles); else launch_dma<KC, WAVES, P3, 1>(st, A, num_cus, tiles);
+    } else {
+      launch_dma<KC, WAVES, P3, 0>(st, A, num_cus, tiles);
     }
-    const long long want = (long long)num_cus * per_cu;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < want ? tiles : want)), dim3(64 * WAVES), lds, st, A);
     return;
   }
   const int lds = 2 * KC * 1024 * (P3 ? 3 : 2);
@@ -654,6 +669,8 @@ bool dense_ws_supported(const DenseArgs& A) {
   const int KC = (A.k_total + 15) / 16;
   if (KC > 21 && A.n_out > 128) return false;      // the slice of a long layer needs a 512-register wave: at most 4 waves
   if (A.mask_div != 1 && A.mask_div != 3) return false;
+  if (A.n_out > 128 && (A.mask_y != nullptr || A.accumulate || A.colsum != nullptr) && (A.bias != nullptr || A.relu))
+    return false;                                               // 8-wave kernels: forward epilogue or backward epilogue, not both
   if (A.precise) {                                              // three-way split: 4-wave LDS-DMA shape, K <= 192
     if (A.n_out > 128 || KC > 12) return false;
   }

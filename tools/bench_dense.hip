@@ -36,7 +36,8 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(mk, hm.data(), hm.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(y, hy0.data(), hy0.size() * 4, hipMemcpyHostToDevice);
     DenseArgs A{};
     A.seg[0] = {x1, s.k1, s.k1}; A.nseg = 1; if (s.k2) { A.seg[1] = {x2, s.k2, s.k2}; A.nseg = 2; }
-    A.k_total = K; A.wfrag = frag; A.bias = b; A.y = y; A.ldy = s.n; A.n_out = s.n; A.M = M; A.relu = s.relu; A.mask_y = s.mask ? mk : nullptr;
+    A.k_total = K; A.wfrag = frag; A.bias = (s.mask || s.acc) ? nullptr : b;      // (a layer has a forward epilogue or a backward one)
+    A.y = y; A.ldy = s.n; A.n_out = s.n; A.M = M; A.relu = s.relu; A.mask_y = s.mask ? mk : nullptr;
     A.ld_mask = s.n; A.mask_div = 1; A.accumulate = s.acc;
     void* zeros; (void)hipMalloc(&zeros, 256); (void)hipMemset(zeros, 0, 256); A.zeros = zeros;
     A.precise = s.precise;
@@ -48,7 +49,7 @@ int main(int argc, char** argv) {
     double worst = 0;
     for (long long i = 0; i <= Mc; ++i) for (int n = 0; n < s.n; ++n) {
       const long long r = i == Mc ? M - 1 : i * M / Mc;
-      double a = hb[n];
+      double a = (s.mask || s.acc) ? 0.0 : hb[n];
       for (int k = 0; k < s.k1; ++k) a += (double)hx1[r * s.k1 + k] * hw[k * s.n + n];
       for (int k = 0; k < s.k2; ++k) a += (double)hx2[r * s.k2 + k] * hw[(s.k1 + k) * s.n + n];
       if (s.relu) a = a > 0 ? a : 0;
