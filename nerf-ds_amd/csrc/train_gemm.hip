@@ -469,7 +469,9 @@ template <int IPW> struct WgShape {
   static constexpr int LDS = NS * STAGE_BYTES + IMG_BYTES;
 };
 
-template <int TPW, int IPW>
+// ROW: the TPW output tiles of a wave lie in one row of tiles (N/32 is a multiple of TPW), so its X^T fragment is read once per
+// sample tile instead of once per output tile (a compile-time fact: as a run-time branch the two loop bodies cost 4x in spills).
+template <int TPW, int IPW, bool ROW>
 __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
   typedef WgShape<IPW> S;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -573,13 +575,21 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
     wait_vm_lgkm0<63>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    bf16x8 ah, al;
+    if constexpr (ROW) {
+      const int kt = (wave * TPW) / NT;
+      ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + kt * 2048 + lane * 16));
+      al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + kt * 2048 + 1024 + lane * 16));
+    }
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
       const int t = wave * TPW + j;
       if (t < TT) {
         const int kt = t / NT, nt = t - kt * NT;
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + kt * 2048 + lane * 16));
-        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + kt * 2048 + 1024 + lane * 16));
+        if constexpr (!ROW) {
+          ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + kt * 2048 + lane * 16));
+          al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + kt * 2048 + 1024 + lane * 16));
+        }
         const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + (KT + nt) * 2048 + lane * 16));
         const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + (KT + nt) * 2048 + 1024 + lane * 16));
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
@@ -722,8 +732,8 @@ int wgrad_grid(const WgradArgs& A, int num_cus) {
   const long long want = num_cus;
   return (int)(tiles < want ? tiles : want);
 }
-template <int TPW, int IPW> static void launch_wgrad(hipStream_t st, const WgradArgs& A, int grid) {
-  auto kern = k_wgrad<TPW, IPW>;
+template <int TPW, int IPW, bool ROW> static void launch_wgrad(hipStream_t st, const WgradArgs& A, int grid) {
+  auto kern = k_wgrad<TPW, IPW, ROW>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WgShape<IPW>::LDS); attr = true; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WgShape<IPW>::LDS, st, A);
@@ -736,7 +746,8 @@ bool wgrad(hipStream_t st, const WgradArgs& A0, int grid) {
   const int TT = ((A.k + 31) / 32) * ((A.n + 31) / 32);
   const int tpw = (TT + 7) / 8;                                     // 1 .. 8 output tiles per wave
   const int ipw = (ninstr + 7) / 8;                                 // DMA instructions per wave and 16-sample tile: 1 .. 4
-#define NERFDS_WG(T, I) if (tpw <= T && ipw <= I) { launch_wgrad<T, I>(st, A, grid); return true; }
+  const int NT = (A.n + 31) / 32;
+#define NERFDS_WG(T, I) if (tpw <= T && ipw <= I) { if (T > 1 && NT % T == 0) launch_wgrad<T, I, true>(st, A, grid); else launch_wgrad<T, I, false>(st, A, grid); return true; }
   NERFDS_WG(1, 1) NERFDS_WG(1, 2) NERFDS_WG(1, 4)
   NERFDS_WG(2, 2) NERFDS_WG(2, 4)
   NERFDS_WG(4, 2) NERFDS_WG(4, 3) NERFDS_WG(4, 4)
