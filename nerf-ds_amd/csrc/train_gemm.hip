@@ -1,13 +1,18 @@
-// Weight-stationary dense layer for the training path: Y[M x N] = act(concat_s X_s[M x K_s] . W + b), hand-written for gfx950.
+// The dense layers of the training step (nerfds_train.cpp), hand-written for gfx950.  Reference: the nn.Dense calls of
+// hypernerf/modules.py:56-88 (MLP), 228-289 (NerfMLP) under jax.value_and_grad (training.py:494).  Three kernels:
 //
-// Shape of the problem: M = rays x samples (up to 524 288), K and N <= 560 / 256.  The layer's whole weight matrix fits in the
-// register file of ONE workgroup (256 x 256 as split bf16 = 256 KiB of the CU's 512 KiB), so it is kept there: wave w of the
-// workgroup owns output tile w (32 output features) as MFMA A-fragments (32 rows x 16 k-slots, hi + lo bf16), and the workgroup
-// walks over 32-sample tiles of X.  A tile of X is read ONCE from HBM (fp32, row major, possibly several concatenated
-// segments), split into bf16 hi / lo and laid out in LDS as MFMA B-operands; every wave reads all of it (LDS traffic, not HBM)
-// and issues 3 MFMAs per fragment (hi.lo + lo.hi + hi.hi: fp32-level accuracy).  Bias, ReLU, an optional ReLU mask taken
-// from another activation (backward: dX . 1[y_prev > 0]) and accumulation into the destination are fused into the store.
-// The layer is therefore HBM bound: X read once, Y written once - what rocBLAS + separate bias / ReLU passes needed 3-4x for.
+//   k_dense_dma   Y[M x N] = epilogue(concat_s X_s[M x K_s] . W): forward layers and, on a transposed fragment pack, the data
+//                 gradient dX = dZ . W^T.  Weight stationary: M = rays x samples (up to 524 288), K and N <= 560 / 256, so the layer's
+//                 whole weight matrix fits the register file of ONE workgroup (256 x 256 as split bf16 = 256 KiB of the CU's
+//                 512 KiB): wave w keeps output tile w (32 features) as MFMA A-fragments and the persistent workgroup walks over
+//                 32-sample tiles of X, which arrive by LDS-DMA (fp32, 3-4 tiles deep) and are split into bf16 hi / lo on the way
+//                 to the MFMAs (3 MFMAs per fragment; P3: hi / mid / lo, 6 MFMAs, fp32-level products).
+//   k_dense_ws    the same layer with the X tile staged through registers (rows that are not 16-byte aligned: 33 / 45-wide inputs).
+//   k_wgrad       dW[K x N] += X^T dZ: 16-sample tiles of both operands by LDS-DMA, transposed + split once per workgroup into
+//                 fragment images, output tiles accumulated in registers for the whole kernel, float atomics at the end.
+//
+// Epilogue of the first two: bias, ReLU | accumulate, the consumer's ReLU mask (dX . 1[y_prev > 0]), column sums (bias gradient).
+// Every layer is HBM bound (X read once, Y written once); DESIGN.md section 8.1 has the measurements and what was tried.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -21,7 +26,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-extern __shared__ __attribute__((aligned(16))) char g_tile[];      // [KC][hi 1 KiB | lo 1 KiB]
+extern __shared__ __attribute__((aligned(16))) char g_tile[];      // the one LDS object of every kernel here (a second one de-pipelines LDS-DMA code)
 
 __device__ __forceinline__ unsigned short bf16_rne(float f) {
   unsigned u = __builtin_bit_cast(unsigned, f);
