@@ -36,6 +36,7 @@ struct Seg {
   const float* dx_relu_y = nullptr;   // dx is the dY of a ReLU layer whose output is dx_relu_y: mask it and add its column sums to dx_bias_grad
   float* dx_bias_grad = nullptr;
 };
+constexpr int GRAD_REPS = 16;
 constexpr size_t WPACK_BYTES = 1 << 20;      // packed fragments of the largest layer (560 x 128 or 320 x 256 as hi / lo bf16) fit twice
 
 void window(float* out, int bands, float alpha) {   // model_utils.py:420-436
@@ -74,7 +75,11 @@ struct nerfds_trainer {
   float* part = nullptr;    // split-K partials of the weight-gradient GEMMs
   size_t part_floats = 0;
   void* wpack = nullptr;    // MFMA fragments of the layer being run (train_gemm.hip)
+  // Gradient replicas: the MFMA kernels end with float atomics from every workgroup at once; on one copy of a small leaf they queue
+  // up per address (40-60 us per kernel).  Workgroup b adds into replica b % GRAD_REPS; the replicas are summed into grad once per step.
+  float* grad_rep = nullptr;
   int num_cus = 256;
+  bool fuse_bwd = true;     // NERFDS_TRAIN_FUSE_BWD=0: the narrow layers' backward as two kernels (A/B timing)
   bool own_gemm = true;     // NERFDS_TRAIN_GEMM=rocblas switches the data GEMMs back to rocBLAS (A/B measurements)
   std::string err;
   // workspace views (set by carve())
@@ -96,6 +101,7 @@ struct nerfds_trainer {
   ~nerfds_trainer() {
     for (float* p : {theta, grad, m1, m2, ws, loss_dev, part, tws, terms_dev, nws}) if (p) (void)hipFree(p);
     if (wpack) (void)hipFree(wpack);
+    if (grad_rep) (void)hipFree(grad_rep);
     if (blas) (void)rocblas_destroy_handle(blas);
   }
 };
@@ -157,6 +163,9 @@ struct Run {
   void chk(rocblas_status s) { if (s != rocblas_status_success) ok = false; }
 
   // y[M x N] (ldy) = act(sum_s x_s W[rows of s] + b)
+  // where the MFMA kernels add a gradient that lives at g in t.grad: replica 0 of the same offset (kernels add b % nrep replicas on)
+  float* rep(float* g) const { return (g && t.grad_rep) ? t.grad_rep + (g - t.grad) : g; }
+  int nrep() const { return t.grad_rep ? GRAD_REPS : 1; }
   // the hand-written weight-stationary layer (train_gemm.hip); false = shape not covered
   bool ws_layer(const std::vector<Seg>& segs, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, const float* bias, float* y,
                 int ldy, int64_t rows, bool relu, const float* mask_y, int ld_mask, int mask_div, bool accumulate, float* colsum = nullptr) {
@@ -167,7 +176,7 @@ struct Run {
     for (int i = 0; i < A.nseg; ++i) A.seg[i] = {segs[i].x, segs[i].ld, segs[i].K};
     A.k_total = in_dim; A.wfrag = t.wpack; A.bias = bias; A.y = y; A.ldy = ldy; A.n_out = out_dim; A.M = rows; A.relu = relu ? 1 : 0;
     A.mask_y = mask_y; A.ld_mask = ld_mask; A.mask_div = mask_div; A.accumulate = accumulate ? 1 : 0;
-    A.zeros = static_cast<const char*>(t.wpack) + WPACK_BYTES; A.colsum = colsum; A.precise = precise_layers ? 1 : 0;
+    A.zeros = static_cast<const char*>(t.wpack) + WPACK_BYTES; A.colsum = rep(colsum); A.rep_stride = t.P; A.nrep = nrep(); A.precise = precise_layers ? 1 : 0;
     if (!dense_ws_supported(A)) return false;
     pack_frags(st, W, ldw, row0, in_dim, out_dim, transpose, t.wpack, parts);
     return dense_ws(st, A, t.num_cus);
@@ -188,7 +197,7 @@ struct Run {
   void weight_grad(const float* X, int ldx, int K, const float* dy, int ldy, int N, float* dW, int64_t rows = -1) {
     const int64_t M = rows < 0 ? this->M : rows;
     if (t.own_gemm) {                                   // hand-written MFMA kernel (train_gemm.hip): one partial per workgroup
-      WgradArgs A{X, ldx, K, dy, ldy, N, M, nullptr, dW, static_cast<const char*>(t.wpack) + WPACK_BYTES, 0, 0};
+      WgradArgs A{X, ldx, K, dy, ldy, N, M, nullptr, rep(dW), static_cast<const char*>(t.wpack) + WPACK_BYTES, 0, 0, t.P, nrep()};
       if (wgrad_supported(A) && wgrad(st, A, wgrad_grid(A, t.num_cus))) return;
     }
     const int64_t slabs = M / SLAB;
@@ -217,6 +226,15 @@ struct Run {
     bool fused = false;
     int k0 = 0;
     for (const Seg& s : segs) {
+      // narrow hidden layer whose input is the ReLU output that also masks its gradient: dW, dX, mask and column sums in ONE pass
+      if (t.own_gemm && t.fuse_bwd && s.dx && !s.acc && s.dx_relu_y == s.x && s.dld == s.K && s.ld == s.K) {
+        BwdFusedArgs F{s.x, s.ld, s.K, dy, ldy, L.N, t.wpack, s.dx, s.dld, rep(s.dx_bias_grad), rep(t.grad + L.w + (int64_t)k0 * L.N), M,
+                       static_cast<const char*>(t.wpack) + WPACK_BYTES, t.P, nrep()};
+        if (bwd_fused_supported(F)) {
+          pack_frags(st, t.theta + L.w, L.N, k0, L.N, s.K, 1, t.wpack);
+          if (bwd_fused(st, F, t.num_cus)) { fused = true; k0 += s.K; continue; }
+        }
+      }
       weight_grad(s.x, s.ld, s.K, dy, ldy, L.N, t.grad + L.w + (int64_t)k0 * L.N);
       if (s.dx) {
         const bool want = s.dx_relu_y != nullptr;          // (with acc: this is the last contribution to dx, the mask covers the total)
@@ -550,6 +568,9 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
     if (hipGetDeviceProperties(&prop, t->device) == hipSuccess && prop.multiProcessorCount > 0) t->num_cus = prop.multiProcessorCount;
     const char* g = getenv("NERFDS_TRAIN_GEMM");
     t->own_gemm = !(g && std::string(g) == "rocblas");
+    const char* fb = getenv("NERFDS_TRAIN_FUSE_BWD");
+    t->fuse_bwd = !(fb && std::string(fb) == "0");
+    if (t->own_gemm && hipMalloc(&t->grad_rep, (size_t)GRAD_REPS * t->P * sizeof(float)) != hipSuccess) { g_train_error = "hipMalloc failed (gradient replicas)"; return NERFDS_ENOMEM; }
     if (hipMalloc(&t->wpack, WPACK_BYTES + 256) != hipSuccess || hipMemset(t->wpack, 0, WPACK_BYTES + 256) != hipSuccess) { g_train_error = "hipMalloc failed (weight fragments)"; return NERFDS_ENOMEM; }
   }
   if (rocblas_create_handle(&t->blas) != rocblas_status_success) { g_train_error = "rocblas_create_handle failed"; return NERFDS_EDEVICE; }
@@ -659,6 +680,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   window(W.hp, t->D.hp_bands, ex->hyper_alpha);
   window(W.nm, t->D.nm_bands, ex->norm_input_alpha);
   (void)hipMemsetAsync(t->grad, 0, (size_t)t->P * 4, st);
+  if (t->grad_rep) (void)hipMemsetAsync(t->grad_rep, 0, (size_t)GRAD_REPS * t->P * 4, st);
   (void)hipMemsetAsync(t->loss_dev, 0, 2 * sizeof(float), st);
   const int strat = ex->use_stratified_sampling;
   coarse_z(st, R, Nc, ex->near, ex->far, strat, rnd ? rnd->t_rand : nullptr, t->zc);
@@ -686,6 +708,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights, want_sg, obp, norm_weight);
     if (rc != NERFDS_OK) return rc;
   }
+  if (t->grad_rep) sum_partials(st, t->grad_rep, GRAD_REPS, t->P, t->grad);      // grad += the replicas of the MFMA kernels
   if (!(flags & NERFDS_TRAIN_GRADS_ONLY)) adam_update(t, learning_rate, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return t->fail(NERFDS_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));

@@ -22,6 +22,7 @@ struct DenseArgs {
   int accumulate;           // y += result
   int precise;              // operands split three ways (hi / mid / lo bf16, 6 MFMAs per fragment): fp32-level products; wfrag packed with parts = 3
   float* colsum;            // nullptr, or [n_out]: += column sums of the (masked) result - the bias gradient of the layer that consumes y as dY
+  long long rep_stride; int nrep;   // replicas of the colsum destination, as WgradArgs (nrep <= 1: none)
   const void* zeros;        // >= 16 zero bytes in device memory (source of the padding slots of the LDS-DMA path), or nullptr
   int vec_in, vec_out;      // set by dense_ws(): 16-byte loads / stores are legal
 };
@@ -35,11 +36,31 @@ struct WgradArgs {
   float* dw;                           // [K x N]: every workgroup adds its partial with hardware float atomics
   const void* zeros;
   int x_scalar, dy_scalar;             // set by wgrad(): the part is fetched float by float (rows not 16-byte aligned)
+  // Replicas of the destination: workgroup b adds into dw + (b % nrep) * rep_stride (floats).  All workgroups finish together and
+  // their atomics on one small region queue up on a few L2 channels (40-60 us per kernel, whatever its size); spread over
+  // nrep copies that tail goes away, and the caller sums the copies once per step.  nrep <= 1: no replicas.
+  long long rep_stride; int nrep;
 };
 bool wgrad_supported(const WgradArgs& A);
 // Launches on `grid` workgroups chosen by wgrad_grid(); part must hold grid * K * N floats.  false = shape not covered.
 int wgrad_grid(const WgradArgs& A, int num_cus);
 bool wgrad(hipStream_t st, const WgradArgs& A, int grid);
+
+// One backward pass of a narrow hidden layer (K, N in {64, 128}): dW[K x N] += X^T dZ  AND  dX = (dZ . W^T) . 1[X > 0] with the
+// column sums of dX, from ONE read of X and dZ (X is both the layer's input and, being a ReLU output, the mask of its own gradient).
+struct BwdFusedArgs {
+  const float* x; int ldx; int k;       // X [M x K] = ReLU output of the previous layer
+  const float* dz; int lddz; int n;     // dZ [M x N], already masked with this layer's ReLU
+  const void* wfrag;                    // pack_frags(W, ..., in = N, out = K, transpose = 1)
+  float* dx; int lddx;                  // [M x K]
+  float* colsum;                        // [K] += column sums of dX (bias gradient of the previous layer), or nullptr
+  float* dw;                            // [K x N] += (float atomics)
+  long long M;
+  const void* zeros;
+  long long rep_stride; int nrep;       // as WgradArgs
+};
+bool bwd_fused_supported(const BwdFusedArgs& A);
+bool bwd_fused(hipStream_t st, const BwdFusedArgs& A, int num_cus);
 
 void pack_frags(hipStream_t st, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, void* out, int parts = 2);
 size_t frag_bytes(int in_dim, int out_dim, int parts = 2);

@@ -116,7 +116,7 @@ __device__ __forceinline__ void flush_colsum(const DenseArgs& A, f32x16 csum, in
 #pragma unroll
     for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     const int n = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (m == 0 && n < A.n_out) atomicAdd(A.colsum + n, v);
+    if (m == 0 && n < A.n_out) atomicAdd(A.colsum + (A.nrep > 1 ? (size_t)(blockIdx.x % A.nrep) * A.rep_stride : 0) + n, v);
   }
 }
 
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
   }
   wait_vm_lgkm0<0>();
   // this workgroup's partial: lane holds column n = 32 nt + (lane & 31), rows k = 32 kt + (r & 3) + 8 (r >> 2) + 4 h
-  float* part = A.dw != nullptr ? A.dw : A.part + (size_t)blockIdx.x * K * N;
+  float* part = A.dw != nullptr ? A.dw + (A.nrep > 1 ? (size_t)(blockIdx.x % A.nrep) * A.rep_stride : 0) : A.part + (size_t)blockIdx.x * K * N;
   const bool atomic = A.dw != nullptr;
   const int m = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -621,6 +621,203 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
           else part[(size_t)k * N + n] = acc[j][r];
         }
       }
+    }
+  }
+}
+
+// ---- backward of a narrow hidden layer in one pass ---------------------------------------------------------------------
+// k_wgrad and the data-gradient kernel of a layer both read dZ, and the latter reads X again as its ReLU mask: 5 array passes per
+// layer.  For the 64 / 128-wide networks (mask MLP, warp field, hyper sheet: 34 layers per step) everything fits one 4-wave
+// workgroup - W^T as A-fragments (64 registers per wave), the K x N weight-gradient tiles (64 registers per wave) - so one kernel
+// reads X and dZ once (LDS-DMA, 32-sample tiles) and produces dX (masked, with its column sums) and dW: 3 passes.
+// LDS: NS stages of [32][N] + [32][K] fp32 (odd row strides), then the transposed bf16 hi / lo images of both for the dW product.
+template <int KCN, int IPW> struct BfShape {
+  static constexpr int STAGE_BYTES = IPW * 4 * 1024;
+  static constexpr int IMG_BYTES = 8 * 2 * 2048;                 // (K/32 + N/32 <= 8 feature tiles) x 2 sample chunks x (hi | lo)
+  static constexpr int NS = (3 * STAGE_BYTES + IMG_BYTES <= 163840) ? 3 : 2;
+  static_assert((NS - 2) * IPW < 64, "vmcnt is a 6-bit counter");
+  static constexpr int LDS = NS * STAGE_BYTES + IMG_BYTES;
+};
+
+template <int KCN, int IPW>
+__global__ __launch_bounds__(256) void k_bwd_fused(const BwdFusedArgs A) {
+  typedef BfShape<KCN, IPW> S;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  const int K = A.k, N = A.n;                                    // N == 16 KCN
+  const int SN = N / 4 + 1, SK = K / 4 + 1;                      // row strides in 16-byte slots (odd)
+  const int KT = K >> 5, NT = N >> 5, TT = KT * NT;              // dW tiles; TPW = 4 per wave at most
+  const int DY_SLOTS = 32 * SN;
+  const long long tiles = (A.M + 31) / 32;
+  const int grid = gridDim.x;
+  const bool dx_wave = wave < KT;                                // this wave owns dX output tile `wave`
+  const int ot = dx_wave ? wave : 0;
+  // W^T slice of this wave's dX tile
+  bf16x8 wh[KCN], wl[KCN];
+  const u32x4* wfrag = static_cast<const u32x4*>(A.wfrag);
+#pragma unroll
+  for (int kc = 0; kc < KCN; ++kc) {
+    const size_t base = ((size_t)(ot * KCN + kc) * 2) * 64;
+    wh[kc] = __builtin_bit_cast(bf16x8, wfrag[base + lane]);
+    wl[kc] = __builtin_bit_cast(bf16x8, wfrag[base + 64 + lane]);
+  }
+  // DMA descriptors: slots [0, 32 SN) = dZ rows, then 32 SK slots of X rows; padding slots / rows >= M read the zero line
+  const char* src[IPW];
+  int step[IPW], rowu[IPW];
+#pragma unroll
+  for (int u = 0; u < IPW; ++u) {
+    const int L = 64 * (wave + 4 * u) + lane;
+    const char* p = nullptr;
+    int st = 0, row = 0x3fffffff;
+    if (L < DY_SLOTS) {
+      const int r = L / SN, j = L - r * SN;
+      if (j < N / 4) { row = r; p = reinterpret_cast<const char*>(A.dz + ((size_t)blockIdx.x * 32 + r) * A.lddz + 4 * j); st = grid * 32 * A.lddz * 4; }
+    } else if (L < DY_SLOTS + 32 * SK) {
+      const int L2 = L - DY_SLOTS, r = L2 / SK, j = L2 - r * SK;
+      if (j < K / 4) { row = r; p = reinterpret_cast<const char*>(A.x + ((size_t)blockIdx.x * 32 + r) * A.ldx + 4 * j); st = grid * 32 * A.ldx * 4; }
+    }
+    src[u] = p; step[u] = st; rowu[u] = row;
+  }
+  auto issue = [&](long long tile, int stage) {
+#pragma unroll
+    for (int u = 0; u < IPW; ++u) {
+      const bool ok = tile * 32 + rowu[u] < A.M;
+      const char* g = ok ? src[u] : reinterpret_cast<const char*>(A.zeros);
+      const int off = __builtin_amdgcn_readfirstlane(stage * S::STAGE_BYTES + (wave + 4 * u) * 1024);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(g_tile + off), 16, 0, 0);
+      src[u] += step[u];
+    }
+  };
+  // conversion items (transposed images for dW): feature f of dZ (f < N) or X, sample octet o of the 32-sample tile; 4 (K + N) items
+  constexpr int CI = 4;                                           // items per thread: 4 (128 + 128) / 256
+  int c_src[CI], c_dst[CI], c_stride[CI];
+#pragma unroll
+  for (int j = 0; j < CI; ++j) {
+    const int idx = threadIdx.x + 256 * j;
+    c_src[j] = -1; c_dst[j] = 0; c_stride[j] = 0;
+    if (idx < 4 * N) {
+      const int o = idx / N, f = idx - o * N;
+      c_src[j] = (8 * o * SN + (f >> 2)) * 16 + (f & 3) * 4; c_stride[j] = SN * 16;
+      c_dst[j] = ((KT + (f >> 5)) * 2 + (o >> 1)) * 2048 + (((o & 1) << 5) | (f & 31)) * 16;
+    } else if (idx < 4 * (N + K)) {
+      const int i2 = idx - 4 * N, o = i2 / K, f = i2 - o * K;
+      c_src[j] = (DY_SLOTS + 8 * o * SK + (f >> 2)) * 16 + (f & 3) * 4; c_stride[j] = SK * 16;
+      c_dst[j] = ((f >> 5) * 2 + (o >> 1)) * 2048 + (((o & 1) << 5) | (f & 31)) * 16;
+    }
+  }
+  f32x16 wacc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wacc[j] = f32x16{};
+  f32x16 csum = {};
+  char* img = g_tile + S::NS * S::STAGE_BYTES;
+
+  wait_vm_lgkm0<0>();
+  long long tile = blockIdx.x;
+#pragma unroll
+  for (int s0 = 0; s0 < S::NS - 1; ++s0) issue(tile + (long long)s0 * grid, s0);
+  int it = 0;
+  for (; tile < tiles; tile += grid, ++it) {
+    wait_vm_lgkm0<(S::NS - 2) * IPW>();              // this tile's DMAs (NS - 2 younger tiles may still be in flight)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issue(tile + (long long)(S::NS - 1) * grid, (it + S::NS - 1) % S::NS);
+    __builtin_amdgcn_sched_barrier(0);
+    const char* stg = g_tile + (it % S::NS) * S::STAGE_BYTES;
+    // ---- transposed bf16 images of dZ and X (for dW) ----
+#pragma unroll
+    for (int j = 0; j < CI; ++j) {
+      if (c_src[j] >= 0) {
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const float*>(stg + c_src[j] + i * c_stride[j]);
+        bf16x8 xh, xl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const __bf16 a = (__bf16)f[i];
+          xh[i] = a;
+          xl[i] = (__bf16)(f[i] - (float)a);
+        }
+        *reinterpret_cast<u32x4*>(img + c_dst[j]) = __builtin_bit_cast(u32x4, xh);
+        *reinterpret_cast<u32x4*>(img + c_dst[j] + 1024) = __builtin_bit_cast(u32x4, xl);
+      }
+    }
+    wait_vm_lgkm0<63>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- dW tiles of this wave: t = 4 wave + j -> (kt, nt), two 16-sample chunks ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = wave * 4 + j;
+      if (t < TT) {
+        const int kt = t / NT, nt = t - kt * NT;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const char* pa = img + (kt * 2 + c) * 2048 + lane * 16;
+          const char* pb = img + ((KT + nt) * 2 + c) * 2048 + lane * 16;
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pa));
+          const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pa + 1024));
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pb));
+          const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pb + 1024));
+          wacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, wacc[j], 0, 0, 0);
+          wacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, wacc[j], 0, 0, 0);
+          wacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, wacc[j], 0, 0, 0);
+        }
+      }
+    }
+    // ---- dX tile of this wave: 32 features x 32 samples, masked with X > 0 (read from the stage), column sums, store ----
+    if (dx_wave) {
+      const char* bdz = stg + (m * SN + 2 * h) * 16;
+      f32x16 acc = {};
+#pragma unroll
+      for (int kc = 0; kc < KCN; ++kc) {
+        const f32x4 f0 = *reinterpret_cast<const f32x4*>(bdz + kc * 64);
+        const f32x4 f1 = *reinterpret_cast<const f32x4*>(bdz + kc * 64 + 16);
+        bf16x8 xh, xl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const __bf16 a = (__bf16)f0[e], b = (__bf16)f1[e];
+          xh[e] = a; xh[4 + e] = b;
+          xl[e] = (__bf16)(f0[e] - (float)a); xl[4 + e] = (__bf16)(f1[e] - (float)b);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kc], xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kc], xh, acc, 0, 0, 0);
+      }
+      const long long row = tile * 32 + m;
+      if (row < A.M) {
+        const char* bx = stg + (DY_SLOTS + m * SK) * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n0 = 32 * ot + 8 * q + 4 * h;
+          const f32x4 y = *reinterpret_cast<const f32x4*>(bx + n0 * 4);
+          f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (!(y[j] > 0.f)) v[j] = 0.f;
+          csum[4 * q] += v[0]; csum[4 * q + 1] += v[1]; csum[4 * q + 2] += v[2]; csum[4 * q + 3] += v[3];
+          *reinterpret_cast<f32x4*>(A.dx + (size_t)row * A.lddx + n0) = v;
+        }
+      }
+    }
+  }
+  wait_vm_lgkm0<0>();
+  if (A.colsum != nullptr && dx_wave) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = csum[r];
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+      if (m == 0) atomicAdd(A.colsum + (A.nrep > 1 ? (size_t)(blockIdx.x % A.nrep) * A.rep_stride : 0) + 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h, v);
+    }
+  }
+  float* dwr = A.dw + (A.nrep > 1 ? (size_t)(blockIdx.x % A.nrep) * A.rep_stride : 0);
+  if (A.dw != nullptr)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = wave * 4 + j;
+    if (t < TT) {
+      const int kt = t / NT, nt = t - kt * NT, n = 32 * nt + m;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) unsafeAtomicAdd(dwr + (size_t)(32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h) * N + n, wacc[j][r]);
     }
   }
 }
@@ -759,6 +956,34 @@ bool wgrad(hipStream_t st, const WgradArgs& A0, int grid) {
   NERFDS_WG(8, 3) NERFDS_WG(8, 4)
 #undef NERFDS_WG
   return false;
+}
+
+bool bwd_fused_supported(const BwdFusedArgs& A) {
+  if (!((A.k == 64 || A.k == 128) && (A.n == 64 || A.n == 128)) || A.M <= 0 || A.zeros == nullptr) return false;
+  if (A.ldx % 4 || A.lddz % 4 || A.lddx % 4 || !aligned16(A.x) || !aligned16(A.dz) || !aligned16(A.dx)) return false;
+  const int slots = 32 * (A.n / 4 + 1 + A.k / 4 + 1);
+  const int ipw = (slots + 255) / 256;
+  return (A.n == 128 && ipw == 9) || (A.n == 64 && ipw <= 7);
+}
+template <int KCN, int IPW> static void launch_bwd_fused(hipStream_t st, const BwdFusedArgs& A, int num_cus) {
+  typedef BfShape<KCN, IPW> S;
+  auto kern = k_bwd_fused<KCN, IPW>;
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS);
+    int n = 0;
+    per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, S::LDS) == hipSuccess && n > 0) ? n : 1;
+  }
+  const long long tiles = (A.M + 31) / 32, want = (long long)num_cus * per_cu;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < want ? tiles : want)), dim3(256), S::LDS, st, A);
+}
+bool bwd_fused(hipStream_t st, const BwdFusedArgs& A, int num_cus) {
+  if (!bwd_fused_supported(A)) return false;
+  const int ipw = (32 * (A.n / 4 + 1 + A.k / 4 + 1) + 255) / 256;
+  if (A.n == 128) launch_bwd_fused<8, 9>(st, A, num_cus);
+  else if (ipw <= 5) launch_bwd_fused<4, 5>(st, A, num_cus);
+  else launch_bwd_fused<4, 7>(st, A, num_cus);
+  return true;
 }
 
 }  // namespace nerfds_train

@@ -18,4 +18,4 @@ def test_mfma_layers_against_fp64(rows):
   out = subprocess.run([CHECK, str(rows)], capture_output=True, text=True, timeout=600)
   print(out.stdout)
   assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-  assert out.stdout.count('max|err|') == 19 and 'FAIL' not in out.stdout and '!!' not in out.stdout
+  assert out.stdout.count('max|err|') == 22 and 'FAIL' not in out.stdout and '!!' not in out.stdout

@@ -75,8 +75,9 @@ int main(int argc, char** argv) {
   const WS wshapes[] = {{256, 256}, {128, 128}, {64, 64}, {52, 256}, {33, 128}, {128, 3}};
   for (const WS& w : wshapes) {
     float *x, *dy, *dw; void* zeros;
-    (void)hipMalloc(&x, M * w.k * 4); (void)hipMalloc(&dy, M * w.n * 4); (void)hipMalloc(&dw, w.k * w.n * 4); (void)hipMalloc(&zeros, 256);
-    (void)hipMemset(zeros, 0, 256); (void)hipMemset(dw, 0, w.k * w.n * 4);
+    const int NREP = getenv("NREP") ? atoi(getenv("NREP")) : 1;
+    (void)hipMalloc(&x, M * w.k * 4); (void)hipMalloc(&dy, M * w.n * 4); (void)hipMalloc(&dw, (size_t)NREP * w.k * w.n * 4); (void)hipMalloc(&zeros, 256);
+    (void)hipMemset(zeros, 0, 256); (void)hipMemset(dw, 0, (size_t)NREP * w.k * w.n * 4);
     const long long Mc = M < 4096 ? M : 4096;       // rows that carry data, spread over the whole range (the rest are zero): the CPU check stays cheap
     std::vector<float> hx(Mc * w.k), hd(Mc * w.n);
     for (auto& v : hx) v = frand(); for (auto& v : hd) v = frand();
@@ -85,13 +86,17 @@ int main(int argc, char** argv) {
       const long long r = j * M / Mc;
       (void)hipMemcpy(x + r * w.k, hx.data() + j * w.k, w.k * 4, hipMemcpyHostToDevice); (void)hipMemcpy(dy + r * w.n, hd.data() + j * w.n, w.n * 4, hipMemcpyHostToDevice);
     }
-    WgradArgs A{x, w.k, w.k, dy, w.n, w.n, M, nullptr, dw, zeros, 0, 0};
+    WgradArgs A{x, w.k, w.k, dy, w.n, w.n, M, nullptr, dw, zeros, 0, 0, (long long)w.k * w.n, NREP};
     if (!wgrad_supported(A)) { printf("wgrad %d x %d not supported\n", w.k, w.n); continue; }
     const int grid = wgrad_grid(A, prop.multiProcessorCount);
     wgrad(nullptr, A, grid);
     (void)hipDeviceSynchronize();
-    std::vector<float> hw(w.k * w.n);
+    std::vector<float> hw(w.k * w.n), hrep(w.k * w.n);
     (void)hipMemcpy(hw.data(), dw, hw.size() * 4, hipMemcpyDeviceToHost);
+    for (int rp = 1; rp < NREP; ++rp) {            // the caller's part: sum the replicas
+      (void)hipMemcpy(hrep.data(), dw + (size_t)rp * w.k * w.n, hrep.size() * 4, hipMemcpyDeviceToHost);
+      for (size_t i = 0; i < hw.size(); ++i) hw[i] += hrep[i];
+    }
     double worst = 0, big = 0;
     for (int k = 0; k < w.k; ++k) for (int n = 0; n < w.n; ++n) {
       double a = 0;
@@ -108,6 +113,73 @@ int main(int argc, char** argv) {
     printf("wgrad M=%lld K=%d N=%d: %.3f ms  %.0f GB/s  max|err|=%.2e (max|dW|=%.1f)%s\n", M, w.k, w.n, ms, (double)M * (w.k + w.n) * 4 / ms / 1e6, worst, big,
            worst < 3e-5 * big ? "" : "  FAIL");
     (void)hipFree(x); (void)hipFree(dy); (void)hipFree(dw); (void)hipFree(zeros);
+  }
+  // ---- fused backward of a narrow layer: dW += X^T dZ and dX = (dZ . W^T) . 1[X > 0] with its column sums ----
+  struct FS { int k, n; };
+  const FS fshapes[] = {{128, 128}, {64, 64}, {128, 64}};
+  for (const FS& w : fshapes) {
+    float *x, *dz, *dx, *dw, *wt, *cs; void *zeros, *frag;
+    (void)hipMalloc(&x, M * w.k * 4); (void)hipMalloc(&dz, M * w.n * 4); (void)hipMalloc(&dx, M * w.k * 4); (void)hipMalloc(&dw, (size_t)16 * (w.k * w.n + w.k) * 4);
+    const int NREP = getenv("NREP") ? atoi(getenv("NREP")) : 1;
+    const long long RS = (long long)w.k * w.n + w.k;              // replica stride: [dW | colsum]
+    (void)hipMalloc(&wt, w.k * w.n * 4); (void)hipMalloc(&cs, w.k * 4); (void)hipMalloc(&zeros, 256); (void)hipMalloc(&frag, frag_bytes(w.n, w.k));
+    (void)hipMemset(zeros, 0, 256); (void)hipMemset(dw, 0, (size_t)16 * (w.k * w.n + w.k) * 4); (void)hipMemset(cs, 0, w.k * 4);
+    const long long Mc = M < 2048 ? M : 2048;       // rows that carry data, spread over the whole range
+    std::vector<float> hx(Mc * w.k), hd(Mc * w.n), hw(w.k * w.n);
+    for (auto& v : hx) v = frand(); for (auto& v : hd) v = frand(); for (auto& v : hw) v = frand() * 0.1f;
+    (void)hipMemset(x, 0, M * w.k * 4); (void)hipMemset(dz, 0, M * w.n * 4);
+    for (long long j = 0; j < Mc; ++j) {
+      const long long r = j * M / Mc;
+      (void)hipMemcpy(x + r * w.k, hx.data() + j * w.k, w.k * 4, hipMemcpyHostToDevice); (void)hipMemcpy(dz + r * w.n, hd.data() + j * w.n, w.n * 4, hipMemcpyHostToDevice);
+    }
+    (void)hipMemcpy(wt, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    pack_frags(nullptr, wt, w.n, 0, w.n, w.k, 1, frag);
+    BwdFusedArgs A{x, w.k, w.k, dz, w.n, w.n, frag, dx, w.k, NREP > 1 ? dw + (size_t)w.k * w.n : cs, dw, M, zeros, RS, NREP};
+    if (!bwd_fused(nullptr, A, prop.multiProcessorCount)) { printf("bwd_fused %d x %d not supported\n", w.k, w.n); ++bad; continue; }
+    { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) printf("  !! %s\n", hipGetErrorString(e)); }
+    std::vector<float> gw(w.k * w.n), gc(w.k), gx((size_t)M * w.k);
+    (void)hipMemcpy(gw.data(), dw, gw.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(gc.data(), NREP > 1 ? dw + (size_t)w.k * w.n : cs, gc.size() * 4, hipMemcpyDeviceToHost);
+    for (int rp = 1; rp < NREP; ++rp) {              // the caller's part: sum the replicas
+      std::vector<float> t1(gw.size()), t2(gc.size());
+      (void)hipMemcpy(t1.data(), dw + rp * RS, t1.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(t2.data(), dw + rp * RS + (size_t)w.k * w.n, t2.size() * 4, hipMemcpyDeviceToHost);
+      for (size_t i = 0; i < gw.size(); ++i) gw[i] += t1[i];
+      for (size_t i = 0; i < gc.size(); ++i) gc[i] += t2[i];
+    }
+    (void)hipMemcpy(gx.data(), dx, gx.size() * 4, hipMemcpyDeviceToHost);
+    double e_w = 0, big = 0, e_x = 0, e_c = 0, bigc = 0;
+    std::vector<double> cref(w.k, 0.0);
+    for (long long j = 0; j < Mc; ++j) {
+      const long long r = j * M / Mc;
+      for (int k = 0; k < w.k; ++k) {
+        double a = 0;
+        for (int n = 0; n < w.n; ++n) a += (double)hd[j * w.n + n] * hw[k * w.n + n];
+        if (!(hx[j * w.k + k] > 0)) a = 0;
+        cref[k] += a;
+        e_x = std::fmax(e_x, std::fabs(a - gx[r * w.k + k]));
+      }
+    }
+    for (int k = 0; k < w.k; ++k) {
+      e_c = std::fmax(e_c, std::fabs(cref[k] - gc[k])); bigc = std::fmax(bigc, std::fabs(cref[k]));
+      for (int n = 0; n < w.n; ++n) {
+        double a = 0;
+        for (long long j = 0; j < Mc; ++j) a += (double)hx[j * w.k + k] * hd[j * w.n + n];
+        e_w = std::fmax(e_w, std::fabs(a - gw[k * w.n + n])); big = std::fmax(big, std::fabs(a));
+      }
+    }
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int reps = 20;
+    (void)hipEventRecord(e0, nullptr);
+    if (getenv("NOATOM")) { A.dw = nullptr; A.colsum = nullptr; }
+    if (getenv("NODW")) A.dw = nullptr;
+    if (getenv("NOCS")) A.colsum = nullptr;
+    for (int i = 0; i < reps; ++i) bwd_fused(nullptr, A, prop.multiProcessorCount);
+    (void)hipEventRecord(e1, nullptr); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    const bool ok = e_x < 1e-4 && e_w < 3e-5 * big && e_c < 3e-5 * (bigc + 1.0);
+    if (!ok) ++bad;
+    printf("bwd_fused M=%lld K=%d N=%d: %.3f ms  %.0f GB/s  max|err| dX %.2e  dW %.2e (max %.1f)  colsum %.2e (max %.1f)%s\n", M, w.k, w.n, ms,
+           (double)M * (2 * w.k + w.n) * 4 / ms / 1e6, e_x, e_w, big, e_c, bigc, ok ? "" : "  FAIL");
+    (void)hipFree(x); (void)hipFree(dz); (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(wt); (void)hipFree(cs); (void)hipFree(zeros); (void)hipFree(frag);
   }
   if (bad) printf("%d shape(s) out of bounds\n", bad);
   return bad ? 1 : 0;
