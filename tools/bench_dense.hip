@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
   const WS wshapes[] = {{256, 256}, {128, 128}, {64, 64}, {52, 256}, {33, 128}, {128, 3}};
   for (const WS& w : wshapes) {
     float *x, *dy, *dw; void* zeros;
-    const int NREP = getenv("NREP") ? atoi(getenv("NREP")) : 1;
+    const int NREP = getenv("NREP") ? atoi(getenv("NREP")) : 16;      // destination replicas, as the trainer uses them
     (void)hipMalloc(&x, M * w.k * 4); (void)hipMalloc(&dy, M * w.n * 4); (void)hipMalloc(&dw, (size_t)NREP * w.k * w.n * 4); (void)hipMalloc(&zeros, 256);
     (void)hipMemset(zeros, 0, 256); (void)hipMemset(dw, 0, (size_t)NREP * w.k * w.n * 4);
     const long long Mc = M < 4096 ? M : 4096;       // rows that carry data, spread over the whole range (the rest are zero): the CPU check stays cheap
@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
   for (const FS& w : fshapes) {
     float *x, *dz, *dx, *dw, *wt, *cs; void *zeros, *frag;
     (void)hipMalloc(&x, M * w.k * 4); (void)hipMalloc(&dz, M * w.n * 4); (void)hipMalloc(&dx, M * w.k * 4); (void)hipMalloc(&dw, (size_t)16 * (w.k * w.n + w.k) * 4);
-    const int NREP = getenv("NREP") ? atoi(getenv("NREP")) : 1;
+    const int NREP = getenv("NREP") ? atoi(getenv("NREP")) : 16;      // destination replicas, as the trainer uses them
     const long long RS = (long long)w.k * w.n + w.k;              // replica stride: [dW | colsum]
     (void)hipMalloc(&wt, w.k * w.n * 4); (void)hipMalloc(&cs, w.k * 4); (void)hipMalloc(&zeros, 256); (void)hipMalloc(&frag, frag_bytes(w.n, w.k));
     (void)hipMemset(zeros, 0, 256); (void)hipMemset(dw, 0, (size_t)16 * (w.k * w.n + w.k) * 4); (void)hipMemset(cs, 0, w.k * 4);
