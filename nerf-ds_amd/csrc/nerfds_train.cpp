@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "nerfds.h"
@@ -37,6 +38,7 @@ struct Seg {
   float* dx_bias_grad = nullptr;
 };
 constexpr int GRAD_REPS = 16;
+constexpr size_t ARENA_BYTES = 96u << 20;     // fragment packs of every layer, both orientations
 constexpr size_t WPACK_BYTES = 1 << 20;      // packed fragments of the largest layer (560 x 128 or 320 x 256 as hi / lo bf16) fit twice
 
 void window(float* out, int bands, float alpha) {   // model_utils.py:420-436
@@ -78,6 +80,16 @@ struct nerfds_trainer {
   // Gradient replicas: the MFMA kernels end with float atomics from every workgroup at once; on one copy of a small leaf they queue
   // up per address (40-60 us per kernel).  Workgroup b adds into replica b % GRAD_REPS; the replicas are summed into grad once per step.
   float* grad_rep = nullptr;
+  // Fragment packs of the layers (train_gemm.h): the first step packs each (weight block, orientation, split) when it is first used and
+  // records it; from then on ONE kernel at the start of a step packs them all into the arena (150 small launches less per step).
+  std::vector<PackEntry> packs;
+  std::unordered_map<std::string, size_t> pack_index;
+  PackEntry* packs_dev = nullptr;
+  size_t packs_dev_n = 0, arena_used = 0;
+  int max_frag_lanes = 0;
+  char* arena = nullptr;
+  uint64_t pack_epoch = 0;
+  std::vector<uint64_t> pack_fresh;
   int num_cus = 256;
   bool fuse_bwd = true;     // NERFDS_TRAIN_FUSE_BWD=0: the narrow layers' backward as two kernels (A/B timing)
   bool own_gemm = true;     // NERFDS_TRAIN_GEMM=rocblas switches the data GEMMs back to rocBLAS (A/B measurements)
@@ -102,6 +114,8 @@ struct nerfds_trainer {
     for (float* p : {theta, grad, m1, m2, ws, loss_dev, part, tws, terms_dev, nws}) if (p) (void)hipFree(p);
     if (wpack) (void)hipFree(wpack);
     if (grad_rep) (void)hipFree(grad_rep);
+    if (arena) (void)hipFree(arena);
+    if (packs_dev) (void)hipFree(packs_dev);
     if (blas) (void)rocblas_destroy_handle(blas);
   }
 };
@@ -166,6 +180,29 @@ struct Run {
   // where the MFMA kernels add a gradient that lives at g in t.grad: replica 0 of the same offset (kernels add b % nrep replicas on)
   float* rep(float* g) const { return (g && t.grad_rep) ? t.grad_rep + (g - t.grad) : g; }
   int nrep() const { return t.grad_rep ? GRAD_REPS : 1; }
+  // fragment pack of W[row0.. , :] for (in_dim, out_dim, orientation, split): from the arena (packed at the start of the step) or,
+  // the first time this pack is asked for, packed now and recorded for the following steps; nullptr = arena full (caller packs into wpack)
+  const void* packed(const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, int parts) {
+    if (!t.arena) return nullptr;
+    char key[96];
+    snprintf(key, sizeof key, "%lld/%d/%d/%d/%d/%d/%d", (long long)(W - t.theta), ldw, row0, in_dim, out_dim, transpose, parts);
+    auto it = t.pack_index.find(key);
+    if (it != t.pack_index.end() && t.pack_fresh[it->second] == t.pack_epoch) return t.arena + t.packs[it->second].dst;
+    size_t idx;
+    if (it == t.pack_index.end()) {
+      const size_t bytes = (frag_bytes(in_dim, out_dim, parts) + 255) & ~(size_t)255;
+      if (t.arena_used + bytes > ARENA_BYTES) return nullptr;
+      idx = t.packs.size();
+      t.packs.push_back({(long long)(W - t.theta), (long long)t.arena_used, ldw, row0, in_dim, out_dim, transpose, parts});
+      t.pack_fresh.push_back(0);
+      t.pack_index[key] = idx;
+      t.arena_used += bytes;
+      t.max_frag_lanes = std::max(t.max_frag_lanes, ((out_dim + 31) / 32) * ((in_dim + 15) / 16) * 64);
+    } else idx = it->second;
+    pack_frags(st, W, ldw, row0, in_dim, out_dim, transpose, t.arena + t.packs[idx].dst, parts);
+    t.pack_fresh[idx] = t.pack_epoch;
+    return t.arena + t.packs[idx].dst;
+  }
   // the hand-written weight-stationary layer (train_gemm.hip); false = shape not covered
   bool ws_layer(const std::vector<Seg>& segs, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, const float* bias, float* y,
                 int ldy, int64_t rows, bool relu, const float* mask_y, int ld_mask, int mask_div, bool accumulate, float* colsum = nullptr) {
@@ -178,7 +215,8 @@ struct Run {
     A.mask_y = mask_y; A.ld_mask = ld_mask; A.mask_div = mask_div; A.accumulate = accumulate ? 1 : 0;
     A.zeros = static_cast<const char*>(t.wpack) + WPACK_BYTES; A.colsum = rep(colsum); A.rep_stride = t.P; A.nrep = nrep(); A.precise = precise_layers ? 1 : 0;
     if (!dense_ws_supported(A)) return false;
-    pack_frags(st, W, ldw, row0, in_dim, out_dim, transpose, t.wpack, parts);
+    if (const void* f = packed(W, ldw, row0, in_dim, out_dim, transpose, parts)) A.wfrag = f;
+    else pack_frags(st, W, ldw, row0, in_dim, out_dim, transpose, t.wpack, parts);
     return dense_ws(st, A, t.num_cus);
   }
   void dense_fwd(const LayerP& L, const std::vector<Seg>& segs, float* y, int ldy, bool relu) {
@@ -231,7 +269,8 @@ struct Run {
         BwdFusedArgs F{s.x, s.ld, s.K, dy, ldy, L.N, t.wpack, s.dx, s.dld, rep(s.dx_bias_grad), rep(t.grad + L.w + (int64_t)k0 * L.N), M,
                        static_cast<const char*>(t.wpack) + WPACK_BYTES, t.P, nrep()};
         if (bwd_fused_supported(F)) {
-          pack_frags(st, t.theta + L.w, L.N, k0, L.N, s.K, 1, t.wpack);
+          if (const void* f = packed(t.theta + L.w, L.N, k0, L.N, s.K, 1, 2)) F.wfrag = f;
+          else pack_frags(st, t.theta + L.w, L.N, k0, L.N, s.K, 1, t.wpack);
           if (bwd_fused(st, F, t.num_cus)) { fused = true; k0 += s.K; continue; }
         }
       }
@@ -570,6 +609,7 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
     t->own_gemm = !(g && std::string(g) == "rocblas");
     const char* fb = getenv("NERFDS_TRAIN_FUSE_BWD");
     t->fuse_bwd = !(fb && std::string(fb) == "0");
+    if (t->own_gemm && hipMalloc(&t->arena, ARENA_BYTES) != hipSuccess) { g_train_error = "hipMalloc failed (fragment arena)"; return NERFDS_ENOMEM; }
     if (t->own_gemm && hipMalloc(&t->grad_rep, (size_t)GRAD_REPS * t->P * sizeof(float)) != hipSuccess) { g_train_error = "hipMalloc failed (gradient replicas)"; return NERFDS_ENOMEM; }
     if (hipMalloc(&t->wpack, WPACK_BYTES + 256) != hipSuccess || hipMemset(t->wpack, 0, WPACK_BYTES + 256) != hipSuccess) { g_train_error = "hipMalloc failed (weight fragments)"; return NERFDS_ENOMEM; }
   }
@@ -681,6 +721,21 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   window(W.nm, t->D.nm_bands, ex->norm_input_alpha);
   (void)hipMemsetAsync(t->grad, 0, (size_t)t->P * 4, st);
   if (t->grad_rep) (void)hipMemsetAsync(t->grad_rep, 0, (size_t)GRAD_REPS * t->P * 4, st);
+  if (t->arena) {                      // every fragment pack recorded so far, from the current parameters, in one launch
+    ++t->pack_epoch;
+    if (!t->packs.empty()) {
+      if (t->packs_dev_n != t->packs.size()) {
+        if (t->packs_dev) (void)hipFree(t->packs_dev);
+        t->packs_dev = nullptr;
+        if (hipMalloc(&t->packs_dev, t->packs.size() * sizeof(PackEntry)) != hipSuccess) return t->fail(NERFDS_ENOMEM, "hipMalloc failed (pack table)");
+        if (hipMemcpy(t->packs_dev, t->packs.data(), t->packs.size() * sizeof(PackEntry), hipMemcpyHostToDevice) != hipSuccess)
+          return t->fail(NERFDS_EDEVICE, "pack table upload failed");
+        t->packs_dev_n = t->packs.size();
+      }
+      pack_frags_all(st, t->theta, t->packs_dev, (int)t->packs.size(), t->max_frag_lanes, t->arena);
+      std::fill(t->pack_fresh.begin(), t->pack_fresh.end(), t->pack_epoch);
+    }
+  }
   (void)hipMemsetAsync(t->loss_dev, 0, 2 * sizeof(float), st);
   const int strat = ex->use_stratified_sampling;
   coarse_z(st, R, Nc, ex->near, ex->far, strat, rnd ? rnd->t_rand : nullptr, t->zc);

@@ -64,6 +64,9 @@ bool bwd_fused(hipStream_t st, const BwdFusedArgs& A, int num_cus);
 
 void pack_frags(hipStream_t st, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, void* out, int parts = 2);
 size_t frag_bytes(int in_dim, int out_dim, int parts = 2);
+// All fragment packs of a step in one launch: entry e packs W = theta + e.woff into arena + e.dst (bytes).
+struct PackEntry { long long woff; long long dst; int ldw, row0, in_dim, out_dim, transpose, parts; };
+void pack_frags_all(hipStream_t st, const float* theta, const PackEntry* entries_dev, int n, int max_frag_lanes, void* arena);
 bool dense_ws_supported(const DenseArgs& A);
 // false = shape not covered (caller falls back to rocBLAS)
 bool dense_ws(hipStream_t st, const DenseArgs& A, int num_cus);

@@ -38,9 +38,9 @@ __device__ __forceinline__ float bf16_f32(unsigned short b) { return __builtin_b
 // Packs the weights of one layer into fragment order: fragment (tile ot, chunk kc, part hi|lo), lane l = (h << 5) | m holds, for
 // output feature 32 ot + m, the 8 k-slots 16 kc + 8 h + i.  transpose = 0: value(k, n) = W[(row0 + k) * ldw + n] (forward:
 // `in` = rows of W); transpose = 1: value(k, n) = W[(row0 + n) * ldw + k] (backward data: in = columns of W, out = its rows).
-__global__ void k_pack_frags(const float* __restrict__ W, int ldw, int row0, int in_dim, int out_dim, int transpose, int parts, u32x4* __restrict__ out) {
+__device__ __forceinline__ void pack_one(const float* __restrict__ W, int ldw, int row0, int in_dim, int out_dim, int transpose, int parts, u32x4* __restrict__ out,
+                                         long long idx) {
   const int KC = (in_dim + 15) / 16, tiles = (out_dim + 31) / 32;
-  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;       // (ot, kc, lane)
   if (idx >= (long long)tiles * KC * 64) return;
   const int lane = (int)(idx % 64), kc = (int)((idx / 64) % KC), ot = (int)(idx / (64LL * KC));
   const int m = lane & 31, h = lane >> 5, n = 32 * ot + m;
@@ -64,6 +64,16 @@ __global__ void k_pack_frags(const float* __restrict__ W, int ldw, int row0, int
   out[base + lane] = a;
   out[base + 64 + lane] = b;
   if (parts == 3) out[base + 128 + lane] = c;
+}
+
+__global__ void k_pack_frags(const float* __restrict__ W, int ldw, int row0, int in_dim, int out_dim, int transpose, int parts, u32x4* __restrict__ out) {
+  pack_one(W, ldw, row0, in_dim, out_dim, transpose, parts, out, blockIdx.x * (long long)blockDim.x + threadIdx.x);       // (ot, kc, lane)
+}
+// every pack of a training step in one launch: blockIdx.y = entry
+__global__ void k_pack_frags_all(const float* __restrict__ theta, const PackEntry* __restrict__ e, char* __restrict__ arena) {
+  const PackEntry E = e[blockIdx.y];
+  pack_one(theta + E.woff, E.ldw, E.row0, E.in_dim, E.out_dim, E.transpose, E.parts, reinterpret_cast<u32x4*>(arena + E.dst),
+           blockIdx.x * (long long)blockDim.x + threadIdx.x);
 }
 
 // Epilogue: this lane holds sample `row`, features 32 ot + 8 q + 4 h + j of the accumulator (q = 0..3, j = 0..3).
@@ -827,6 +837,10 @@ void pack_frags(hipStream_t st, const float* W, int ldw, int row0, int in_dim, i
   const long long n = (long long)tiles * KC * 64;
   hipLaunchKernelGGL(k_pack_frags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, ldw, row0, in_dim, out_dim, transpose,
                      parts, static_cast<u32x4*>(out));
+}
+void pack_frags_all(hipStream_t st, const float* theta, const PackEntry* entries_dev, int n, int max_frag_lanes, void* arena) {
+  if (n < 1) return;
+  hipLaunchKernelGGL(k_pack_frags_all, dim3((unsigned)((max_frag_lanes + 255) / 256), (unsigned)n), dim3(256), 0, st, theta, entries_dev, static_cast<char*>(arena));
 }
 size_t frag_bytes(int in_dim, int out_dim, int parts) { return (size_t)((out_dim + 31) / 32) * ((in_dim + 15) / 16) * 1024 * parts; }
 
