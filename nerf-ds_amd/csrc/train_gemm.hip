@@ -477,18 +477,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
 // one feature x 8 samples: 8 conflict-free 4-byte reads down a column, one 16-byte write each for hi and lo); every wave then
 // reads whole fragments and accumulates its share of the (K/32) x (N/32) output tiles in registers for the whole kernel.
 // Each workgroup ends with a full K x N partial sum, written to part[blockIdx]; the caller adds the partials.
-template <int IPW> struct WgShape {
-  static constexpr int STAGE_BYTES = IPW * 8 * 1024 + 1024;   // 8 waves x IPW DMA instructions x 1 KiB, + a spare KiB for idle instructions
+// FULL: every one of the 8 IPW DMA instructions of a tile carries data (256 x 256: 32 instructions), so the stage needs no spare KiB for
+// idle ones - and then a fourth stage fits the 160 KiB next to the images (3 tiles = 96 KiB in flight per CU instead of 2).
+template <int IPW, bool FULL = false> struct WgShape {
+  static constexpr int STAGE_BYTES = IPW * 8 * 1024 + (FULL ? 0 : 1024);   // 8 waves x IPW DMA instructions x 1 KiB (+ a spare KiB for idle instructions)
   static constexpr int IMG_BYTES = 16 * 2048;                 // up to 8 + 8 fragments of hi | lo
-  static constexpr int NS = 3;
+  static constexpr int NS_FIT = (163840 - IMG_BYTES) / STAGE_BYTES;
+  static constexpr int NS = NS_FIT > 4 ? 4 : NS_FIT;
+  static_assert(NS >= 3 && (NS - 2) * IPW < 64, "ring depth");
   static constexpr int LDS = NS * STAGE_BYTES + IMG_BYTES;
 };
 
 // ROW: the TPW output tiles of a wave lie in one row of tiles (N/32 is a multiple of TPW), so its X^T fragment is read once per
 // sample tile instead of once per output tile (a compile-time fact: as a run-time branch the two loop bodies cost 4x in spills).
-template <int TPW, int IPW, bool ROW>
+template <int TPW, int IPW, bool ROW, bool FULL>
 __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
-  typedef WgShape<IPW> S;
+  typedef WgShape<IPW, FULL> S;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int K = A.k, N = A.n, KQ = K >> 2, NQ = N >> 2;
   const int KT = (K + 31) >> 5, NT = (N + 31) >> 5, TT = KT * NT;
@@ -948,11 +952,12 @@ int wgrad_grid(const WgradArgs& A, int num_cus) {
   const long long want = num_cus;
   return (int)(tiles < want ? tiles : want);
 }
-template <int TPW, int IPW, bool ROW> static void launch_wgrad(hipStream_t st, const WgradArgs& A, int grid) {
-  auto kern = k_wgrad<TPW, IPW, ROW>;
+template <int TPW, int IPW, bool ROW, bool FULL = false> static void launch_wgrad(hipStream_t st, const WgradArgs& A, int grid) {
+  auto kern = k_wgrad<TPW, IPW, ROW, FULL>;
+  typedef WgShape<IPW, FULL> S;
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WgShape<IPW>::LDS); attr = true; }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WgShape<IPW>::LDS, st, A);
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS); attr = true; }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), S::LDS, st, A);
 }
 bool wgrad(hipStream_t st, const WgradArgs& A0, int grid) {
   if (!wgrad_supported(A0) || grid < 1) return false;
@@ -963,6 +968,10 @@ bool wgrad(hipStream_t st, const WgradArgs& A0, int grid) {
   const int tpw = (TT + 7) / 8;                                     // 1 .. 8 output tiles per wave
   const int ipw = (ninstr + 7) / 8;                                 // DMA instructions per wave and 16-sample tile: 1 .. 4
   const int NT = (A.n + 31) / 32;
+  if (tpw == 8 && ipw == 4 && ninstr == 32) {                       // 256 x 256: no idle DMA instruction, four stages
+    if (NT % 8 == 0) launch_wgrad<8, 4, true, true>(st, A, grid); else launch_wgrad<8, 4, false, true>(st, A, grid);
+    return true;
+  }
 #define NERFDS_WG(T, I) if (tpw <= T && ipw <= I) { if (T > 1 && NT % T == 0) launch_wgrad<T, I, true>(st, A, grid); else launch_wgrad<T, I, false>(st, A, grid); return true; }
   NERFDS_WG(1, 1) NERFDS_WG(1, 2) NERFDS_WG(1, 4)
   NERFDS_WG(2, 2) NERFDS_WG(2, 4)
