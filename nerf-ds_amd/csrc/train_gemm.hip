@@ -287,7 +287,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_ws(const DenseArgs A) {
 // "one quad pair of 32 different rows" touches every bank once).  The DMA writes 64 consecutive slots per instruction; which
 // (row, quad) a lane fetches is free, so the padding slot, rows past M and quads past K are fetched from a zero line.
 template <int KC, int WAVES> struct DmaShape {
-  static constexpr int KQ = KC * 4, STRIDE = KQ + 1, SLOTS = 32 * STRIDE;
+  // Bank spreading of "one quad pair of 32 different rows": K a multiple of 64 floats -> no padding, the quad index is XORed with
+  // row & 15 (the swizzle goes on the DMA's SOURCE address, the LDS image stays lane-linear; 256 x 256: 32 instructions per tile instead
+  // of 33, which is what lets a fourth stage fit); otherwise an odd row stride (one padding slot per row).
+  static constexpr bool SWZ = KC % 4 == 0;
+  static constexpr int KQ = KC * 4, STRIDE = SWZ ? KQ : KQ + 1, SLOTS = 32 * STRIDE;
   static constexpr int NI = (SLOTS + 63) / 64, IPW = (NI + WAVES - 1) / WAVES;
   static constexpr int TILE_BYTES = IPW * WAVES * 1024;
   // 8 waves would each convert the whole tile to bf16 hi / lo on their own (VALU time ~ MFMA time): with COOP the workgroup
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
   for (int u = 0; u < S::IPW; ++u) {
     const int L = 64 * (wave + WAVES * u) + lane;
     const int row = L / S::STRIDE, j = L - row * S::STRIDE;
-    int k = 4 * j;
+    int k = 4 * (S::SWZ ? (j ^ (row & 15)) : j);        // the quad this slot holds
     const float* p = nullptr;
     int ld = 0;
     bool done = !(row < 32 && j < S::KQ && k < K);
@@ -395,8 +399,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
         const int pair = (threadIdx.x >> 5) + 2 * WAVES * j;
         if (pair < 2 * KC) {
           const int kc = pair >> 1, hh = pair & 1;
-          const char* p = stg + (m * S::STRIDE + 4 * kc + 2 * hh) * 16;
-          const f32x4 f0 = *reinterpret_cast<const f32x4*>(p), f1 = *reinterpret_cast<const f32x4*>(p + 16);
+          const int q0 = 4 * kc + 2 * hh, sw = S::SWZ ? (m & 15) : 0;
+          const char* p = stg + m * S::STRIDE * 16;
+          const f32x4 f0 = *reinterpret_cast<const f32x4*>(p + (q0 ^ sw) * 16), f1 = *reinterpret_cast<const f32x4*>(p + ((q0 + 1) ^ sw) * 16);
           bf16x8 xh, xl;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -427,12 +432,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
       }
     } else
     if (computes) {
-      const char* buf = g_tile + (it % S::NS) * S::TILE_BYTES + (m * S::STRIDE + 2 * h) * 16;
+      const char* buf = g_tile + (it % S::NS) * S::TILE_BYTES + m * S::STRIDE * 16;
+      const int sw = S::SWZ ? (m & 15) : 0;
       f32x16 acc = FWD ? bias : f32x16{};
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
-        const f32x4 f0 = *reinterpret_cast<const f32x4*>(buf + kc * 64);
-        const f32x4 f1 = *reinterpret_cast<const f32x4*>(buf + kc * 64 + 16);
+        const f32x4 f0 = *reinterpret_cast<const f32x4*>(buf + ((4 * kc + 2 * h) ^ sw) * 16);
+        const f32x4 f1 = *reinterpret_cast<const f32x4*>(buf + ((4 * kc + 2 * h + 1) ^ sw) * 16);
         bf16x8 xh, xl;
         if constexpr (P3) {
           // three-way split (24 mantissa bits on both operands), every product that is not below 2^-24: fp32-level layer
