@@ -31,7 +31,7 @@ thread_local std::string g_train_error;
 
 struct Leaf { std::string name; int64_t off; int rows, cols; };
 struct LayerP { int64_t w, b; int K, N; };
-struct MlpP { std::vector<LayerP> hidden; int in_dim = 0, width = 0, depth = 0, skip = -1; };
+struct MlpP { std::vector<LayerP> hidden; int in_dim = 0, in_ld = 0, width = 0, depth = 0, skip = -1; };      // in_ld: row stride of the input buffer
 struct Seg {
   const float* x; int ld; int K; float* dx; int dld; bool acc;
   const float* dx_relu_y = nullptr;   // dx is the dY of a ReLU layer whose output is dx_relu_y: mask it and add its column sums to dx_bias_grad
@@ -137,7 +137,7 @@ LayerP add_dense(nerfds_trainer& t, const std::string& name, int K, int N) {
 }
 MlpP add_mlp(nerfds_trainer& t, const std::string& name, int in_dim, int width, int depth, int skip) {
   MlpP m;
-  m.in_dim = in_dim; m.width = width; m.depth = depth; m.skip = skip;
+  m.in_dim = in_dim; m.in_ld = in_dim; m.width = width; m.depth = depth; m.skip = skip;
   for (int l = 0; l < depth; ++l) {
     const int K = (l == 0 ? in_dim : width) + ((l == skip && l > 0) ? in_dim : 0);     // modules.py:66-67
     m.hidden.push_back(add_dense(t, name + "/hidden_" + std::to_string(l), K, width));
@@ -305,7 +305,7 @@ struct Run {
     for (int l = 0; l < m.depth; ++l) {
       std::vector<Seg> segs;
       if (l > 0) segs.push_back({cur, m.width, m.width, nullptr, 0, false});
-      if (l == 0 || l == m.skip) segs.push_back({t_in0, m.in_dim, m.in_dim, nullptr, 0, false});
+      if (l == 0 || l == m.skip) segs.push_back({t_in0, m.in_ld, m.in_dim, nullptr, 0, false});
       float* dst = store ? (*store)[l] : other;
       dense_jvp(m.hidden[l], segs, dst, m.width, h[l]);
       if (store) cur = dst; else std::swap(cur, other);
@@ -337,7 +337,7 @@ struct Run {
     for (int l = m.depth - 1; l >= 0; --l) {
       std::vector<Seg> segs;
       if (l > 0) segs.push_back({th[l - 1], m.width, m.width, other, m.width, false, h[l - 1], nullptr});
-      if (l == 0 || l == m.skip) { segs.push_back({t_in0, m.in_dim, m.in_dim, d_t_in0, m.in_dim, in0_written}); in0_written = d_t_in0 != nullptr; }
+      if (l == 0 || l == m.skip) { segs.push_back({t_in0, m.in_ld, m.in_dim, d_t_in0, m.in_ld, in0_written}); in0_written = d_t_in0 != nullptr; }
       premasked = dense_jvp_bwd(m.hidden[l], segs, cur, m.width, h[l], premasked);
       std::swap(cur, other);
     }
@@ -346,7 +346,7 @@ struct Run {
     for (int l = 0; l < m.depth; ++l) {
       std::vector<Seg> segs;
       if (l > 0) segs.push_back({h[l - 1], m.width, m.width, nullptr, 0, false});
-      if (l == 0 || l == m.skip) segs.push_back({in0, m.in_dim, m.in_dim, nullptr, 0, false});
+      if (l == 0 || l == m.skip) segs.push_back({in0, m.in_ld, m.in_dim, nullptr, 0, false});
       dense_fwd(m.hidden[l], segs, h[l], m.width, true);
     }
   }
@@ -357,7 +357,7 @@ struct Run {
       std::vector<Seg> segs;
       // d h[l-1] is the dY of layer l-1: its ReLU mask and bias gradient ride on the epilogue of the kernel that writes it
       if (l > 0) segs.push_back({h[l - 1], m.width, m.width, other, m.width, false, h[l - 1], t.grad + m.hidden[l - 1].b});
-      if (l == 0 || l == m.skip) { segs.push_back({in0, m.in_dim, m.in_dim, d_in0, m.in_dim, in0_written}); in0_written = true; }
+      if (l == 0 || l == m.skip) { segs.push_back({in0, m.in_ld, m.in_dim, d_in0, m.in_ld, in0_written}); in0_written = true; }
       premasked = dense_bwd(m.hidden[l], segs, cur, m.width, h[l], premasked);
       std::swap(cur, other);
     }
@@ -373,16 +373,16 @@ void carve(nerfds_trainer& t) {
   take(&t.zc, R * Nc); take(&t.zf, R * S); take(&t.wc, R * Nc); take(&t.rs_scratch, R * (2 * Nc + Nf));
   take(&t.x, M * 3); take(&t.mask_in, M * D.mask_in); take(&t.mask_logit, M);
   t.mask_h.assign(t.mask.depth, nullptr); for (auto& p : t.mask_h) take(&p, M * t.mask.width);
-  take(&t.warp_in, M * D.warp_in); t.warp_h.assign(t.warp.depth, nullptr); for (auto& p : t.warp_h) take(&p, M * t.warp.width);
+  take(&t.warp_in, M * D.warp_ld); t.warp_h.assign(t.warp.depth, nullptr); for (auto& p : t.warp_h) take(&p, M * t.warp.width);
   take(&t.wv, M * 6); take(&t.xw, M * 3);
-  take(&t.hyper_in, M * D.hyper_in); t.hyper_h.assign(t.hyper.depth, nullptr); for (auto& p : t.hyper_h) take(&p, M * t.hyper.width);
+  take(&t.hyper_in, M * D.hyper_ld); t.hyper_h.assign(t.hyper.depth, nullptr); for (auto& p : t.hyper_h) take(&p, M * t.hyper.width);
   take(&t.wamb, M * 2); take(&t.trunk_in, M * D.trunk_in);
   t.trunk_h.assign(t.trunk[0].depth, nullptr); for (auto& p : t.trunk_h) take(&p, M * t.trunk[0].width);
   take(&t.bottv, M * t.trunk[0].width); take(&t.alphav, M * 4); take(&t.sigma, M); take(&t.cond, M * (6 * D.vd_bands + 6 * D.nm_bands));
   take(&t.rgb_hv, M * t.rgb_h[0].N); take(&t.rgb_logit, M * 3); take(&t.weights, M); take(&t.rgb_ray, R * 3);
   take(&t.g0, M * t.trunk[0].width); take(&t.g1, M * t.trunk[0].width); take(&t.g2, M * t.trunk[0].width);
   take(&t.d_trunk_in, M * D.trunk_in); take(&t.d_rgb_logit, M * 3); take(&t.d_alpha, M * 4); take(&t.dxw, M * 3); take(&t.dwamb, M * 2);
-  take(&t.dwv, M * 6); take(&t.d_warp_in, M * D.warp_in); take(&t.d_hyper_in, M * D.hyper_in); take(&t.d_mask_in, M * D.mask_in);
+  take(&t.dwv, M * 6); take(&t.d_warp_in, M * D.warp_ld); take(&t.d_hyper_in, M * D.hyper_ld); take(&t.d_mask_in, M * D.mask_in);
   take(&t.d_mask_logit, M); take(&t.dxw_reg, M * 3); take(&t.d_pm, M);
   t.ws_floats = need;
   // (pointers into vectors: the vectors are not resized after this point)
@@ -399,7 +399,7 @@ bool ensure_tangent_ws(nerfds_trainer& t) {
   size_t need = 0;
   std::vector<std::pair<float**, size_t>> views;
   auto take = [&](float** p, size_t n) { views.push_back({p, n}); need += (n + 63) & ~(size_t)63; };
-  take(&t.t_warp_in, M3 * D.warp_in); take(&t.t_hyper_in, M3 * D.hyper_in); take(&t.tA, M3 * TW); take(&t.tB, M3 * TW);
+  take(&t.t_warp_in, M3 * D.warp_ld); take(&t.t_hyper_in, M3 * D.hyper_ld); take(&t.tA, M3 * TW); take(&t.tB, M3 * TW);
   take(&t.t_wv, M3 * 6); take(&t.t_xw, M3 * 3); take(&t.t_wamb, M3 * 2); take(&t.t_tin, M3 * D.trunk_in); take(&t.t_alpha, M3 * 4);
   take(&t.tn[0], R * Nc * 3); take(&t.tn[1], R * S * 3);
   if (hipMalloc(&t.tws, need * sizeof(float)) != hipSuccess) return false;
@@ -563,15 +563,18 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
   D.hp_bands = c->hyper_point_max_deg; D.vd_bands = c->viewdir_max_deg; D.nm_bands = c->norm_input_max_deg;
   if (std::max({D.mask_bands, D.warp_bands, D.hyp_bands, D.sp_bands, D.hp_bands, D.vd_bands, D.nm_bands}) > 8) { g_train_error = "more than 8 posenc bands"; return NERFDS_ENOTSUP; }
   D.mask_in = 6 * D.mask_bands + 8; D.warp_in = 6 * D.warp_bands + 8 + 1; D.hyper_in = 6 * D.hyp_bands + 8 + 1; D.trunk_in = 6 * D.sp_bands + 4 * D.hp_bands;
+  D.warp_ld = (D.warp_in + 3) & ~3; D.hyper_ld = (D.hyper_in + 3) & ~3;
   // flat parameter vector: leaves in this order, names = the Flax paths (params.py)
   t->warp_tbl = add_leaf(*t, "warp_embed/embed/embedding", c->num_warp_embeds, 8);
   t->warp = add_mlp(*t, "warp_field/trunk", D.warp_in, c->warp_trunk_width, c->warp_trunk_depth, c->warp_skip);
+  t->warp.in_ld = D.warp_ld;
   t->warp_w = add_dense(*t, "warp_field/branches_w/logit", c->warp_trunk_width, 3);
   t->warp_v = add_dense(*t, "warp_field/branches_v/logit", c->warp_trunk_width, 3);
   t->mask_tbl = add_leaf(*t, "mask_embed/embed/embedding", c->num_warp_embeds, 8);
   t->mask = add_mlp(*t, "mask_mlp/MLP_0", D.mask_in, c->mask_width, c->mask_depth, c->mask_skip);
   t->mask_out = add_dense(*t, "mask_mlp/MLP_0/logit", c->mask_width, 1);
   t->hyper = add_mlp(*t, "hyper_sheet_mlp/MLP_0", D.hyper_in, c->hyper_sheet_width, c->hyper_sheet_depth, c->hyper_sheet_skip);
+  t->hyper.in_ld = D.hyper_ld;
   t->hyper_out = add_dense(*t, "hyper_sheet_mlp/MLP_0/logit", c->hyper_sheet_width, 2);
   const int levels = c->num_fine_samples > 0 ? 2 : 1;
   const int TW = c->nerf_trunk_width, cond = 6 * D.vd_bands + 6 * D.nm_bands;

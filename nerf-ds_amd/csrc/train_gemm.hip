@@ -872,9 +872,13 @@ template <int KC, int WAVES, bool P3, int MODE> static void launch_dma(hipStream
 
 template <int KC, int WAVES, bool P3 = false> static void launch(hipStream_t st, DenseArgs A, int num_cus) {
   const long long tiles = (A.M + 31) / 32;
+  // 16-byte fetches: rows 16-byte aligned and every segment a whole number of quads - or, for the LAST segment, a row stride that
+  // covers its last quad (the pad floats exist and are finite; their weights are the zero padding of the fragment pack)
   A.vec_in = 1;
-  for (int g = 0; g < A.nseg; ++g)
-    if (A.seg[g].k % 4 || A.seg[g].ld % 4 || !aligned16(A.seg[g].x)) A.vec_in = 0;
+  for (int g = 0; g < A.nseg; ++g) {
+    const bool tail_ok = g == A.nseg - 1 && A.seg[g].ld >= ((A.seg[g].k + 3) & ~3);
+    if ((A.seg[g].k % 4 && !tail_ok) || A.seg[g].ld % 4 || !aligned16(A.seg[g].x)) A.vec_in = 0;
+  }
   A.vec_out = (A.n_out % 4 == 0 && A.ldy % 4 == 0 && aligned16(A.y) && (A.mask_y == nullptr || (A.ld_mask % 4 == 0 && aligned16(A.mask_y)))) ? 1 : 0;
   const bool dma = A.vec_in && A.zeros != nullptr && getenv("NERFDS_WS_NODMA") == nullptr;
   if (dma) {

@@ -8,6 +8,8 @@ namespace nerfds_train {
 struct Dims {      // the nerf_ds graph's widths (from nerfds_model_cfg)
   int mask_bands, warp_bands, hyp_bands, sp_bands, hp_bands, vd_bands, nm_bands;
   int mask_in, warp_in, hyper_in, trunk_in;     // 44, 33, 45, 52
+  int warp_ld, hyper_ld;                        // row strides of the warp / hyper-sheet input buffers (and their gradients / tangents): the
+                                                // widths rounded up to 4 floats, pad columns zero, so the rows are 16-byte aligned (LDS-DMA)
 };
 struct Windows {   // posenc windows (model_utils.py:420-436), one weight per band
   float mask[8], warp[8], hyp[8], sp[8], hp[8], nm[8];

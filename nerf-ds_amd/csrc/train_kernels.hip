@@ -134,12 +134,14 @@ __global__ void k_encode_inputs(Dims D, int R, int S, const float* __restrict__ 
   float* mi = mask_in + m * D.mask_in;
   for (int g = 0; g < 6 * D.mask_bands; ++g) mi[g] = posenc_val<3>(g, p, W.mask);
   for (int g = 0; g < 8; ++g) mi[6 * D.mask_bands + g] = mask_tbl[id * 8 + g];
-  float* wi = warp_in + m * D.warp_in;
+  float* wi = warp_in + m * D.warp_ld;
   for (int g = 0; g < 6 * D.warp_bands; ++g) wi[g] = posenc_val<3>(g, p, W.warp);
   for (int g = 0; g < 8; ++g) wi[6 * D.warp_bands + g] = warp_tbl[id * 8 + g];
-  float* hi = hyper_in + m * D.hyper_in;
+  for (int g = D.warp_in; g < D.warp_ld; ++g) wi[g] = 0.f;            // pad columns (the mask column D.warp_in - 1 is written by k_mask_post)
+  float* hi = hyper_in + m * D.hyper_ld;
   for (int g = 0; g < 6 * D.hyp_bands; ++g) hi[g] = posenc_val<3>(g, p, W.hyp);
   for (int g = 0; g < 8; ++g) hi[6 * D.hyp_bands + g] = warp_tbl[id * 8 + g];
+  for (int g = D.hyper_in; g < D.hyper_ld; ++g) hi[g] = 0.f;
 }
 
 __global__ void k_bias_act(float* __restrict__ y, const float* __restrict__ b, long long M, int N, int ld, int relu) {
@@ -159,8 +161,8 @@ __global__ void k_mask_post(Dims D, int R, int S, const float* __restrict__ logi
   const float pm = fmaxf(logit[m], 0.f);
   const float g = gt ? gt[m / S] : 0.f;
   const float v = pm * ratio + g * (1.0f - ratio);
-  warp_in[m * D.warp_in + D.warp_in - 1] = v;
-  hyper_in[m * D.hyper_in + D.hyper_in - 1] = v;
+  warp_in[m * D.warp_ld + D.warp_in - 1] = v;
+  hyper_in[m * D.hyper_ld + D.hyper_in - 1] = v;
 }
 
 // ---- SE(3): x' = exp_se3(w / |w|, v / |w|, |w|) x (warping.py:219-237, rigid_body.py:59-101), generic in the scalar -----
@@ -300,9 +302,11 @@ __global__ void k_encode_tangents(Dims D, long long M, const float* __restrict__
   const long long m = i / 3;
   const int j = (int)(i % 3);
   const float p[3] = {x[3 * m], x[3 * m + 1], x[3 * m + 2]};
-  float* tw = t_warp_in + i * D.warp_in;
+  float* tw = t_warp_in + i * D.warp_ld;
+  for (int g = D.warp_in; g < D.warp_ld; ++g) tw[g] = 0.f;
   for (int g = 0; g < D.warp_in; ++g) tw[g] = (g < 6 * D.warp_bands && g % 3 == j) ? posenc_dval<3>(g, p, W.warp) : 0.f;
-  float* th = t_hyper_in + i * D.hyper_in;
+  float* th = t_hyper_in + i * D.hyper_ld;
+  for (int g = D.hyper_in; g < D.hyper_ld; ++g) th[g] = 0.f;
   for (int g = 0; g < D.hyper_in; ++g) th[g] = (g < 6 * D.hyp_bands && g % 3 == j) ? posenc_dval<3>(g, p, W.hyp) : 0.f;
 }
 // tangent through a ReLU: t[3 m + j][n] = 0 where y[m][n] <= 0
@@ -723,8 +727,8 @@ __global__ void k_shared_in_bwd(Dims D, int R, int S, const float* __restrict__ 
   float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < S; ++s) {
     const size_t m = (size_t)r * S + s;
-    const float* dw = d_warp_in + m * D.warp_in;
-    const float* dh = d_hyper_in + m * D.hyper_in;
+    const float* dw = d_warp_in + m * D.warp_ld;
+    const float* dh = d_hyper_in + m * D.hyper_ld;
     for (int g = 0; g < 8; ++g) e[g] += dw[6 * D.warp_bands + g] + dh[6 * D.hyp_bands + g];
     const float dmask = dw[D.warp_in - 1] + dh[D.hyper_in - 1];
     d_mask_logit[m] = (mask_logit[m] > 0.f) ? dmask * ratio + (d_pm_extra ? d_pm_extra[m] : 0.f) : 0.f;
