@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NERFDS_ABI_VERSION 2
+#define NERFDS_ABI_VERSION 3
 
 /* error codes */
 #define NERFDS_OK         0
@@ -40,11 +40,16 @@ extern "C" {
 #define NERFDS_ENOTSUP  (-95)   /* graph / option not built as a HIP kernel */
 #define NERFDS_EDEVICE  (-5)    /* HIP runtime error (no device, launch failure, ...) */
 
-/* Arithmetic of the per-sample dense layers (flags bits 0-1 of nerfds_render_rays). */
+/* Arithmetic of the per-sample dense layers (flags bits 0-2 of nerfds_render_rays).  The reference's layers are
+ * fp32 nn.Dense (hypernerf/modules.py:61-65,74-78); every mode accumulates in fp32. */
 #define NERFDS_PREC_BF16    0u  /* bf16 x bf16 -> fp32 MFMA (v_mfma_f32_32x32x16_bf16): the throughput path   */
 #define NERFDS_PREC_BF16X3  1u  /* split-bf16 (hi+lo) x3 MFMA: ~fp32 accuracy at 1/3 of the bf16 MFMA rate   */
 #define NERFDS_PREC_F32     2u  /* fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fp32 fma chains, parity gate    */
-#define NERFDS_PREC_MASK    3u
+#define NERFDS_PREC_F16     3u  /* f16 x f16 -> fp32 MFMA (v_mfma_f32_32x32x16_f16): bf16 rate, 3 more significand bits */
+#define NERFDS_PREC_MIXED   4u  /* per-network plan (csrc/graphs.h plan_of): error-amplifying networks in split bf16,
+                                   the bulk of the FLOPs in one f16 MFMA per product - the fast parity-grade path */
+#define NERFDS_PREC_COUNT   5u
+#define NERFDS_PREC_MASK    7u
 /* Other flags. */
 #define NERFDS_FLAG_USE_WARP_OFF  (1u << 4)  /* NerfModel.__call__(use_warp=False), models.py:1468 - rejected if the graph has a warp */
 
@@ -190,6 +195,10 @@ typedef struct nerfds_out {
 typedef struct nerfds_ctx nerfds_ctx;
 
 int nerfds_abi_version(void);
+/* The arithmetic (NERFDS_PREC_BF16 / BF16X3 / F32 / F16) each network runs in under a NERFDS_PREC_* value of this build:
+ * plan_out = {MaskMLP, SE3 warp field, hyper sheet, NerfMLP trunk (+ alpha head), rgb branch}.  Uniform for every value
+ * but NERFDS_PREC_MIXED.  (No reference counterpart: the reference's layers are all fp32 nn.Dense, modules.py:61-65.) */
+int nerfds_precision_plan(uint32_t prec, int32_t plan_out[5]);
 int nerfds_ctx_create(nerfds_ctx** out, int device, const nerfds_model_cfg* cfg);
 int nerfds_ctx_load_weights(nerfds_ctx* ctx, const nerfds_weights* w);
 int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_extra* extra,

@@ -8,35 +8,73 @@
 
 namespace nerfds {
 
-enum Prec : int { P_BF16 = 0, P_BF16X3 = 1, P_F32 = 2 };
+// Arithmetic of one activation tensor (and of the weights it is multiplied with):
+//   bf16 / f16 : one v_mfma_f32_32x32x16_{bf16,f16} per product (8 / 11 significand bits)
+//   bf16x3     : split bf16 hi + lo operands, three MFMAs per product (16 bits, fp32-grade results)
+//   f32        : v_mfma_f32_32x32x2_f32, exact fp32 fma chains
+enum Prec : int { P_BF16 = 0, P_BF16X3 = 1, P_F32 = 2, P_F16 = 3 };
+constexpr bool is_single(int prec) { return prec == P_BF16 || prec == P_F16; }
 
 // One MFMA weight fragment = a [32 out rows] x [16 k-slots] block of a layer, laid out exactly as the
 // 64 lanes of a wave consume it (16 bytes per lane per part, lane-linear, so one coalesced 1 KiB load).
-//   bf16   : 1 part  (8 bf16 / lane)
-//   bf16x3 : 2 parts (hi bf16x8, lo bf16x8)
-//   f32    : 2 parts (k-slots 0-3, k-slots 4-7 as float4)
-constexpr int frag_parts(int prec) { return prec == P_BF16 ? 1 : 2; }
+// A part is one 1-KiB *unit* of the weight stream:
+//   bf16 / f16 : 1 unit  (8 halves / lane)
+//   bf16x3     : 2 units (hi bf16x8, then lo bf16x8)
+//   f32        : 2 units (k-slots 0-3, then k-slots 4-7 as float4)
+constexpr int frag_parts(int prec) { return is_single(prec) ? 1 : 2; }
 constexpr int frag_bytes(int prec) { return 1024 * frag_parts(prec); }
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 // The kernel stages the stream through LDS in 16 KiB stages; each of the two streams is zero-padded to a
 // whole number of stages so that a stage never straddles the shared -> NerfMLP seam.
 constexpr int STAGE_BYTES = 16384;
-constexpr int stage_frags(int prec) { return STAGE_BYTES / frag_bytes(prec); }
-constexpr int pad_frags(int n, int prec) { return cdiv(n, stage_frags(prec)) * stage_frags(prec); }
+constexpr int STAGE_UNITS = STAGE_BYTES / 1024;
+constexpr int pad_units(int n) { return cdiv(n, STAGE_UNITS) * STAGE_UNITS; }
 constexpr int chunks(int feats) { return cdiv(feats, 16); }   // k16 chunks needed for `feats` linear features
 
-// Number of fragments of a plain hidden stack: depth layers of `width`, input `in_chunks` k16-chunks,
-// skip re-concatenation of the raw input before layer `skip` (modules.py:66-67), plus one 32-row head tile.
-constexpr int mlp_frags(int depth, int width, int in_chunks, int skip, bool head) {
-  int n = 0;
-  for (int l = 0; l < depth; ++l) {
-    int k = (l == 0 ? in_chunks : width / 16) + ((l == skip && l > 0) ? in_chunks : 0);
-    n += (width / 32) * k;
-  }
-  if (head) n += width / 16;
-  return n;
+// Precision plan: which arithmetic each network of the graph runs in.  `trunk` covers the NerfMLP trunk, its raw input
+// and trunk_output (so also the alpha head and the trunk_output segment of rgb hidden_0); `rgb` covers the rgb
+// condition inputs, rgb hidden_0's output and the rgb head.  The uniform plans are the round-1 kernels; the mixed
+// plan (NERFDS_PREC_MIXED) keeps the networks whose error is amplified downstream (the warp field moves the points
+// that the 2^7-frequency encoding of the template reads) in split bf16 and runs the bulk of the FLOPs in one MFMA.
+struct Plan { int mask, warp, hyp, trunk, rgb; };
+constexpr Plan uniform_plan(int p) { return Plan{p, p, p, p, p}; }
+#ifndef NERFDS_MIX_MASK
+#define NERFDS_MIX_MASK P_F16
+#endif
+#ifndef NERFDS_MIX_WARP
+#define NERFDS_MIX_WARP P_BF16X3
+#endif
+#ifndef NERFDS_MIX_HYP
+#define NERFDS_MIX_HYP P_F16
+#endif
+#ifndef NERFDS_MIX_TRUNK
+#define NERFDS_MIX_TRUNK P_F16
+#endif
+#ifndef NERFDS_MIX_RGB
+#define NERFDS_MIX_RGB P_F16
+#endif
+constexpr int NUM_PLANS = 5;     // == number of NERFDS_PREC_* values of include/nerfds.h
+constexpr Plan plan_of(int prec_index) {
+  return prec_index == 4 ? Plan{NERFDS_MIX_MASK, NERFDS_MIX_WARP, NERFDS_MIX_HYP, NERFDS_MIX_TRUNK, NERFDS_MIX_RGB}
+                         : uniform_plan(prec_index);
 }
+// Stream position after a fragment segment of `kc` k16-chunks in precision p, starting at unit `pos`.  There is no
+// alignment: a two-unit fragment may start on an odd unit and even straddle two LDS stages (the kernel fetches
+// units, not fragments).
+constexpr int walk_seg(int pos, int kc, int p) { return pos + kc * frag_parts(p); }
+// A plain hidden stack: depth layers of `width`, input `in_chunks` k16-chunks, skip re-concatenation of the raw input
+// before layer `skip` (modules.py:66-67), plus an optional 32-row head tile; everything in precision p.
+constexpr int walk_mlp(int pos, int depth, int width, int in_chunks, int skip, bool head, int p) {
+  for (int l = 0; l < depth; ++l)
+    for (int t = 0; t < width / 32; ++t) {
+      pos = walk_seg(pos, l == 0 ? in_chunks : width / 16, p);
+      if (l == skip && l > 0) pos = walk_seg(pos, in_chunks, p);
+    }
+  if (head) pos = walk_seg(pos, width / 16, p);
+  return pos;
+}
+
 constexpr int mlp_bias_tiles(int depth, int width, bool head) { return depth * (width / 32) + (head ? 1 : 0); }
 
 // configs/nerf_ds.gin
@@ -94,11 +132,7 @@ template <class G> struct Dims {
   static constexpr int ALPHA_OUT = 1 + (G::PREDICT_NORM ? 3 : 0);
   static constexpr int RGB_IN = G::TRUNK_W + VD_FEATS + (G::X_IN_RGB ? G::TRUNK_W : 0) + NM_FEATS;
 
-  // fragment / bias-tile counts of the two weight streams
-  static constexpr int MASK_FRAGS = G::HAS_MASK ? mlp_frags(G::MASK_DEPTH, G::MASK_W, MASK_KC, G::MASK_SKIP, true) : 0;
-  static constexpr int WARP_FRAGS = G::HAS_WARP ? mlp_frags(G::WARP_DEPTH, G::WARP_W, WARP_KC, G::WARP_SKIP, true) : 0;
-  static constexpr int HYP_FRAGS = G::HAS_HYPER ? mlp_frags(G::HYP_DEPTH, G::HYP_W, HYP_KC, G::HYP_SKIP, true) : 0;
-  static constexpr int SHARED_FRAGS = MASK_FRAGS + WARP_FRAGS + HYP_FRAGS;
+  // bias-tile counts of the two weight streams (precision independent; stream lengths: shared_units / nerf_units below)
   static constexpr int SHARED_BIAS_TILES = (G::HAS_MASK ? mlp_bias_tiles(G::MASK_DEPTH, G::MASK_W, true) : 0) +
                                            (G::HAS_WARP ? mlp_bias_tiles(G::WARP_DEPTH, G::WARP_W, true) : 0) +
                                            (G::HAS_HYPER ? mlp_bias_tiles(G::HYP_DEPTH, G::HYP_W, true) : 0);
@@ -106,12 +140,28 @@ template <class G> struct Dims {
   // The bottleneck Dense has no activation (modules.py:255), so it is folded into rgb hidden_0 by the packer:
   //   rgb_pre = trunk_out @ (W_bn @ W_rgb[bottleneck rows] + W_rgb[trunk_out rows]) + cond @ W_rgb[cond rows] + b'
   // i.e. no bottleneck layer in the stream and one 256-wide segment (instead of two) in rgb hidden_0.
-  static constexpr int NERF_FRAGS =
-      mlp_frags(G::TRUNK_DEPTH, G::TRUNK_W, TRUNK_KC, G::TRUNK_SKIP, false) +   // trunk
-      TW16 +                                                                    // alpha head
-      (G::RGB_W / 32) * (TW16 + COND_KC) +                                      // rgb hidden_0 (bottleneck folded in)
-      G::RGB_W / 16;                                                            // rgb head
   static constexpr int NERF_BIAS_TILES = G::TRUNK_DEPTH * TW32 + 1 + G::RGB_W / 32 + 1;
 };
+
+// Lengths, in 1-KiB units, of the two weight streams under a precision plan.  The order of the walk is the order in
+// which pack.h emits and render_kernel.hip consumes the fragments.
+template <class G> constexpr int shared_units(Plan pl) {
+  using D = Dims<G>;
+  int pos = 0;
+  if (G::HAS_MASK) pos = walk_mlp(pos, G::MASK_DEPTH, G::MASK_W, D::MASK_KC, G::MASK_SKIP, true, pl.mask);
+  if (G::HAS_WARP) pos = walk_mlp(pos, G::WARP_DEPTH, G::WARP_W, D::WARP_KC, G::WARP_SKIP, true, pl.warp);
+  if (G::HAS_HYPER) pos = walk_mlp(pos, G::HYP_DEPTH, G::HYP_W, D::HYP_KC, G::HYP_SKIP, true, pl.hyp);
+  return pos;
+}
+template <class G> constexpr int nerf_units(Plan pl) {
+  using D = Dims<G>;
+  int pos = walk_mlp(0, G::TRUNK_DEPTH, G::TRUNK_W, D::TRUNK_KC, G::TRUNK_SKIP, false, pl.trunk);   // trunk
+  pos = walk_seg(pos, D::TW16, pl.trunk);                                                            // alpha head
+  for (int t = 0; t < G::RGB_W / 32; ++t) {                                                          // rgb hidden_0 (bottleneck folded in)
+    pos = walk_seg(pos, D::TW16, pl.trunk);
+    pos = walk_seg(pos, D::COND_KC, pl.rgb);
+  }
+  return walk_seg(pos, G::RGB_W / 16, pl.rgb);                                                       // rgb head
+}
 
 }  // namespace nerfds

@@ -28,6 +28,12 @@ void nerfds_launch_static_f32(const KArgs&, int, void*);
 void nerfds_launch_hyper_bf16(const KArgs&, int, void*);
 void nerfds_launch_hyper_bf16x3(const KArgs&, int, void*);
 void nerfds_launch_hyper_f32(const KArgs&, int, void*);
+void nerfds_launch_nerfds_f16(const KArgs&, int, void*);
+void nerfds_launch_static_f16(const KArgs&, int, void*);
+void nerfds_launch_hyper_f16(const KArgs&, int, void*);
+void nerfds_launch_nerfds_mixed(const KArgs&, int, void*);
+void nerfds_launch_static_mixed(const KArgs&, int, void*);
+void nerfds_launch_hyper_mixed(const KArgs&, int, void*);
 void nerfds_launch_camera_rays(const nerfds::CameraParams&, long long, long long, const float*, float*, float*, float*, void*);
 void nerfds_launch_frame_images(const float*, int, int, float, float, const double*, uint8_t*, uint8_t*, void*);
 }
@@ -184,17 +190,19 @@ NerfNet nerf_views(const Weights::Nerf& s) {
   return n;
 }
 
-template <class G> void pack_which(StreamWriter& sw, const Weights& W, int which, int level) {
-  if (which == 0) pack_shared<G>(sw, shared_views(W)); else pack_nerf<G>(sw, nerf_views(W.nerf[level]));
+template <class G> void pack_which(StreamWriter& sw, const Weights& W, int which, int level, Plan pl) {
+  if (which == 0) pack_shared<G>(sw, shared_views(W), pl); else pack_nerf<G>(sw, nerf_views(W.nerf[level]), pl);
 }
-void pack_dispatch(int graph, StreamWriter& sw, const Weights& W, int which, int level) {
-  if (graph == GraphNerfDS::ID) pack_which<GraphNerfDS>(sw, W, which, level);
-  else if (graph == GraphStatic::ID) pack_which<GraphStatic>(sw, W, which, level);
-  else pack_which<GraphHyperNeRF>(sw, W, which, level);
+void pack_dispatch(int graph, StreamWriter& sw, const Weights& W, int which, int level, int prec) {
+  const Plan pl = plan_of(prec);
+  if (graph == GraphNerfDS::ID) pack_which<GraphNerfDS>(sw, W, which, level, pl);
+  else if (graph == GraphStatic::ID) pack_which<GraphStatic>(sw, W, which, level, pl);
+  else pack_which<GraphHyperNeRF>(sw, W, which, level, pl);
 }
 template <class G> void stream_dims(int which, int prec, int64_t* wbytes, int64_t* bfloats) {
   using D = Dims<G>;
-  *wbytes = (int64_t)pad_frags(which == 0 ? D::SHARED_FRAGS : D::NERF_FRAGS, prec) * frag_bytes(prec);   // zero padded to whole stages
+  const Plan pl = plan_of(prec);
+  *wbytes = (int64_t)pad_units(which == 0 ? shared_units<G>(pl) : nerf_units<G>(pl)) * 1024;   // zero padded to whole stages
   *bfloats = (int64_t)(which == 0 ? D::SHARED_BIAS_TILES : D::NERF_BIAS_TILES) * 32;
 }
 void stream_dims_dispatch(int graph, int which, int prec, int64_t* wb, int64_t* bf) {
@@ -218,11 +226,11 @@ struct nerfds_ctx {
   int num_cus = 256;
   nerfds_model_cfg cfg{};
   Weights W;
-  DevBuf wstream[3][3];     // [prec][shared, coarse, fine]
+  DevBuf wstream[NUM_PLANS][3];     // [prec][shared, coarse, fine]
   DevBuf wbias[3];          // precision independent
   DevBuf warp_embed, mask_embed;
   DevBuf ray_scratch;       // origins | directions generated from a camera
-  bool packed[3] = {false, false, false};
+  bool packed[NUM_PLANS] = {};
   bool bias_uploaded = false;
   std::string err;
   // timing
@@ -240,16 +248,24 @@ struct nerfds_ctx {
 };
 
 static launch_fn launcher(int graph, uint32_t prec) {
-  static const launch_fn tab[3][3] = {
-      {nerfds_launch_nerfds_bf16, nerfds_launch_nerfds_bf16x3, nerfds_launch_nerfds_f32},
-      {nerfds_launch_static_bf16, nerfds_launch_static_bf16x3, nerfds_launch_static_f32},
-      {nerfds_launch_hyper_bf16, nerfds_launch_hyper_bf16x3, nerfds_launch_hyper_f32}};
+  static_assert(NUM_PLANS == NERFDS_PREC_COUNT, "graphs.h plan_of covers every NERFDS_PREC_* value");
+  static const launch_fn tab[3][NUM_PLANS] = {
+      {nerfds_launch_nerfds_bf16, nerfds_launch_nerfds_bf16x3, nerfds_launch_nerfds_f32, nerfds_launch_nerfds_f16, nerfds_launch_nerfds_mixed},
+      {nerfds_launch_static_bf16, nerfds_launch_static_bf16x3, nerfds_launch_static_f32, nerfds_launch_static_f16, nerfds_launch_static_mixed},
+      {nerfds_launch_hyper_bf16, nerfds_launch_hyper_bf16x3, nerfds_launch_hyper_f32, nerfds_launch_hyper_f16, nerfds_launch_hyper_mixed}};
   return tab[graph][prec];
 }
 
 extern "C" {
 
 int nerfds_abi_version(void) { return NERFDS_ABI_VERSION; }
+
+int nerfds_precision_plan(uint32_t prec, int32_t plan_out[5]) {
+  if (prec >= NERFDS_PREC_COUNT || !plan_out) return NERFDS_EINVAL;
+  const Plan pl = plan_of((int)prec);
+  plan_out[0] = pl.mask; plan_out[1] = pl.warp; plan_out[2] = pl.hyp; plan_out[3] = pl.trunk; plan_out[4] = pl.rgb;
+  return NERFDS_OK;
+}
 
 const char* nerfds_last_error(const nerfds_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -319,8 +335,8 @@ static int ensure_packed(nerfds_ctx* ctx, uint32_t prec) {
     stream_dims_dispatch(ctx->graph, which ? 1 : 0, (int)prec, &wb, &bf);
     std::vector<uint8_t> w((size_t)wb);
     std::vector<float> b((size_t)bf);
-    StreamWriter sw{(int)prec, w.data(), b.data()};
-    pack_dispatch(ctx->graph, sw, ctx->W, which ? 1 : 0, which ? which - 1 : 0);
+    StreamWriter sw{w.data(), b.data()};
+    pack_dispatch(ctx->graph, sw, ctx->W, which ? 1 : 0, which ? which - 1 : 0, (int)prec);
     if ((int64_t)sw.wbytes > wb || wb - (int64_t)sw.wbytes >= STAGE_BYTES || (int64_t)sw.bfloats != bf)
       return ctx->fail(NERFDS_EINVAL, "internal: packed stream %d has %zu bytes / %zu bias floats, kernel expects %lld / %lld",
                        which, sw.wbytes, sw.bfloats, (long long)wb, (long long)bf);
@@ -339,7 +355,7 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   if (!rays || !extra || !out) return ctx->fail(NERFDS_EINVAL, "null argument");
   if (!ctx->W.loaded) return ctx->fail(NERFDS_EINVAL, "nerfds_ctx_load_weights has not been called");
   const uint32_t prec = flags & NERFDS_PREC_MASK;
-  if (prec > NERFDS_PREC_F32) return ctx->fail(NERFDS_EINVAL, "unknown precision %u", prec);
+  if (prec >= NERFDS_PREC_COUNT) return ctx->fail(NERFDS_EINVAL, "unknown precision %u", prec);
   if ((flags & NERFDS_FLAG_USE_WARP_OFF) && ctx->cfg.use_warp)
     return ctx->fail(NERFDS_ENOTSUP, "use_warp=False on a warp model is not runnable in the reference either (SURVEY.md 8a quirk 2)");
   if (rays->num_rays < 0 || rays->num_rays > 0x7fffffff) return ctx->fail(NERFDS_EINVAL, "num_rays out of range");
@@ -469,7 +485,7 @@ int nerfds_kernel_time_ms(nerfds_ctx* ctx, int reset, double* total_ms) {
 
 // ---- host-only packing helpers -----------------------------------------------------------------------
 int64_t nerfds_pack_stream_bytes(const nerfds_model_cfg* cfg, int which, uint32_t prec) {
-  if (!cfg || prec > NERFDS_PREC_F32 || which < 0 || which > 1) return NERFDS_EINVAL;
+  if (!cfg || prec >= NERFDS_PREC_COUNT || which < 0 || which > 1) return NERFDS_EINVAL;
   const int g = graph_of(*cfg);
   if (g < 0) return NERFDS_ENOTSUP;
   int64_t wb, bf;
@@ -486,15 +502,15 @@ int64_t nerfds_pack_bias_floats(const nerfds_model_cfg* cfg, int which) {
 }
 int nerfds_pack_stream(const nerfds_model_cfg* cfg, const nerfds_weights* w, int which, int level, uint32_t prec,
                        void* stream_out, float* bias_out) {
-  if (!cfg || !w || prec > NERFDS_PREC_F32 || which < 0 || which > 1 || level < 0 || level > 1) return NERFDS_EINVAL;
+  if (!cfg || !w || prec >= NERFDS_PREC_COUNT || which < 0 || which > 1 || level < 0 || level > 1) return NERFDS_EINVAL;
   const int g = graph_of(*cfg);
   if (g < 0) return NERFDS_ENOTSUP;
   Weights W;
   std::string err;
   bool ok = take_weights_dispatch(g, W, *cfg, *w, err);
   if (!ok) { g_create_error = err; return NERFDS_EINVAL; }
-  StreamWriter sw{(int)prec, static_cast<uint8_t*>(stream_out), bias_out};
-  pack_dispatch(g, sw, W, which, level);
+  StreamWriter sw{static_cast<uint8_t*>(stream_out), bias_out};
+  pack_dispatch(g, sw, W, which, level, (int)prec);
   return NERFDS_OK;
 }
 

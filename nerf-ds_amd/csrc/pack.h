@@ -40,6 +40,26 @@ inline float bf16_to_f32(uint16_t b) {
   std::memcpy(&f, &u, 4);
   return f;
 }
+// fp32 -> IEEE binary16, round to nearest even (what v_cvt_pk_f16_f32 does on the device), subnormals kept.
+inline uint16_t f32_to_f16_rne(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+  const uint32_t a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                   // NaN
+  if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                  // >= 65520 rounds to inf
+  if (a < 0x33000001u) return sign;                                          // <= 2^-25 rounds to zero
+  const int e = (int)(a >> 23) - 127;
+  uint32_t m = (a & 0x7fffffu) | 0x800000u;                                  // 24-bit significand
+  int shift = (e < -14) ? (13 + (-14 - e)) : 13;                             // bits dropped
+  uint32_t q = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) ++q;
+  // normal: q has the hidden bit at position 10 -> adding (e + 14) << 10 yields the biased exponent; a carry out of
+  // the significand bumps the exponent by construction.  subnormal: exponent field 0, q < 2^10 (or exactly 2^10 = min normal).
+  const uint32_t h = (e < -14) ? q : (((uint32_t)(e + 14) << 10) + q);
+  return (uint16_t)(sign | h);
+}
 
 // k-slot -> kernel-row maps -------------------------------------------------------------------------
 inline void rows_linear(std::vector<int>& rm, int n_chunks, const std::function<int(int)>& feat_to_row) {
@@ -53,8 +73,12 @@ inline void rows_tile(std::vector<int>& rm, int width, int row0) {
 }
 inline int head_col(int m) { return (m & 3) + 4 * (m >> 3); }
 
-struct Layer {
+struct Seg {
   std::vector<int> rows;                       // per k-slot (chunk*16 + h*8 + i): kernel row or -1
+  int prec = P_BF16;                           // arithmetic of this input segment (graphs.h Plan)
+};
+struct Layer {
+  std::vector<Seg> segs;                       // input segments in K order (e.g. [previous layer | raw input] on a skip layer)
   int n_tiles = 0;                             // output tiles of 32 rows
   bool is_head = false;
   int n_out = 0;                               // logical outputs
@@ -63,44 +87,45 @@ struct Layer {
 };
 
 struct StreamWriter {
-  int prec;
   uint8_t* w;       // may be nullptr: count only
   float* b;
   size_t wbytes = 0, bfloats = 0;
 
   void emit(const Layer& L) {
-    const int kc_n = (int)L.rows.size() / 16;
     for (int ot = 0; ot < L.n_tiles; ++ot) {
-      for (int kc = 0; kc < kc_n; ++kc) {
-        if (w) {
-          uint8_t* frag = w + wbytes;
-          for (int lane = 0; lane < 64; ++lane) {
-            const int m = lane & 31, h = lane >> 5;
-            int col = L.is_head ? head_col(m) : 32 * ot + m;
-            if (col >= L.n_out) col = -1;
-            float v[8];
-            for (int i = 0; i < 8; ++i) {
-              const int r = L.rows[kc * 16 + h * 8 + i];
-              v[i] = (r < 0 || col < 0) ? 0.f : L.W(r, col);
-            }
-            if (prec == P_BF16) {
-              uint16_t* d = reinterpret_cast<uint16_t*>(frag + lane * 16);
-              for (int i = 0; i < 8; ++i) d[i] = f32_to_bf16_rne(v[i]);
-            } else if (prec == P_BF16X3) {
-              uint16_t* dh = reinterpret_cast<uint16_t*>(frag + lane * 16);
-              uint16_t* dl = reinterpret_cast<uint16_t*>(frag + 1024 + lane * 16);
+      for (const Seg& S : L.segs) {
+        const int kc_n = (int)S.rows.size() / 16, prec = S.prec;
+        for (int kc = 0; kc < kc_n; ++kc) {
+          if (w) {
+            uint8_t* frag = w + wbytes;
+            for (int lane = 0; lane < 64; ++lane) {
+              const int m = lane & 31, h = lane >> 5;
+              int col = L.is_head ? head_col(m) : 32 * ot + m;
+              if (col >= L.n_out) col = -1;
+              float v[8];
               for (int i = 0; i < 8; ++i) {
-                dh[i] = f32_to_bf16_rne(v[i]);
-                dl[i] = f32_to_bf16_rne(v[i] - bf16_to_f32(dh[i]));
+                const int r = S.rows[kc * 16 + h * 8 + i];
+                v[i] = (r < 0 || col < 0) ? 0.f : L.W(r, col);
               }
-            } else {
-              float* da = reinterpret_cast<float*>(frag + lane * 16);
-              float* db = reinterpret_cast<float*>(frag + 1024 + lane * 16);
-              for (int i = 0; i < 4; ++i) { da[i] = v[i]; db[i] = v[4 + i]; }
+              if (prec == P_BF16 || prec == P_F16) {
+                uint16_t* d = reinterpret_cast<uint16_t*>(frag + lane * 16);
+                for (int i = 0; i < 8; ++i) d[i] = prec == P_BF16 ? f32_to_bf16_rne(v[i]) : f32_to_f16_rne(v[i]);
+              } else if (prec == P_BF16X3) {
+                uint16_t* dh = reinterpret_cast<uint16_t*>(frag + lane * 16);
+                uint16_t* dl = reinterpret_cast<uint16_t*>(frag + 1024 + lane * 16);
+                for (int i = 0; i < 8; ++i) {
+                  dh[i] = f32_to_bf16_rne(v[i]);
+                  dl[i] = f32_to_bf16_rne(v[i] - bf16_to_f32(dh[i]));
+                }
+              } else {
+                float* da = reinterpret_cast<float*>(frag + lane * 16);
+                float* db = reinterpret_cast<float*>(frag + 1024 + lane * 16);
+                for (int i = 0; i < 4; ++i) { da[i] = v[i]; db[i] = v[4 + i]; }
+              }
             }
           }
+          wbytes += frag_bytes(prec);
         }
-        wbytes += frag_bytes(prec);
       }
       if (b) {
         for (int m = 0; m < 32; ++m) {
@@ -113,33 +138,40 @@ struct StreamWriter {
   }
 };
 
-inline Layer plain_layer(const DenseView& d, std::vector<int> rows, int width) {
+inline Layer plain_layer(const DenseView& d, std::vector<Seg> segs, int width) {
   Layer L;
-  L.rows = std::move(rows);
+  L.segs = std::move(segs);
   L.n_tiles = width / 32;
   L.n_out = d.out_dim;
   L.W = [d](int r, int c) { return d.W(r, c); };
   L.B = [d](int c) { return d.bias ? d.bias[c] : 0.f; };
   return L;
 }
-inline Layer head_layer(const DenseView& d, std::vector<int> rows) {
-  Layer L = plain_layer(d, std::move(rows), 32);
+inline Layer head_layer(const DenseView& d, std::vector<int> rows, int prec) {
+  Layer L = plain_layer(d, {Seg{std::move(rows), prec}}, 32);
   L.is_head = true;
   return L;
 }
 
 // A reference modules.MLP (modules.py:57-83) with `depth` hidden layers of `width`, raw input of `in_dim`
 // features in `in_chunks` linear chunks, skip re-concatenation [x, inputs] before layer `skip`.
-inline void emit_mlp(StreamWriter& sw, const DenseView* hidden, int depth, int width, int in_dim, int in_chunks, int skip) {
+inline void emit_mlp(StreamWriter& sw, const DenseView* hidden, int depth, int width, int in_dim, int in_chunks, int skip, int prec) {
   for (int l = 0; l < depth; ++l) {
+    std::vector<Seg> segs;
     std::vector<int> rows;
     if (l == 0) {
       rows_linear(rows, in_chunks, [&](int s) { return s < in_dim ? s : -1; });
+      segs.push_back(Seg{std::move(rows), prec});
     } else {
       rows_tile(rows, width, 0);
-      if (l == skip) rows_linear(rows, in_chunks, [&](int s) { return s < in_dim ? width + s : -1; });
+      segs.push_back(Seg{std::move(rows), prec});
+      if (l == skip) {
+        std::vector<int> raw;
+        rows_linear(raw, in_chunks, [&](int s) { return s < in_dim ? width + s : -1; });
+        segs.push_back(Seg{std::move(raw), prec});
+      }
     }
-    sw.emit(plain_layer(hidden[l], std::move(rows), width));
+    sw.emit(plain_layer(hidden[l], std::move(segs), width));
   }
 }
 
@@ -152,20 +184,20 @@ struct NerfNet {
   DenseView trunk[16], bottleneck, alpha, rgb_hidden[16], rgb;
 };
 
-template <class G> void pack_shared(StreamWriter& sw, const SharedNets& n) {
+template <class G> void pack_shared(StreamWriter& sw, const SharedNets& n, Plan pl) {
   using D = Dims<G>;
   if constexpr (G::HAS_MASK) {
-    emit_mlp(sw, n.mask_hidden, G::MASK_DEPTH, G::MASK_W, D::MASK_IN, D::MASK_KC, G::MASK_SKIP);
+    emit_mlp(sw, n.mask_hidden, G::MASK_DEPTH, G::MASK_W, D::MASK_IN, D::MASK_KC, G::MASK_SKIP, pl.mask);
     std::vector<int> rows;
     rows_tile(rows, G::MASK_W, 0);
-    sw.emit(head_layer(n.mask_out, std::move(rows)));
+    sw.emit(head_layer(n.mask_out, std::move(rows), pl.mask));
   }
   if constexpr (G::HAS_WARP) {
-    emit_mlp(sw, n.warp_hidden, G::WARP_DEPTH, G::WARP_W, D::WARP_IN, D::WARP_KC, G::WARP_SKIP);
+    emit_mlp(sw, n.warp_hidden, G::WARP_DEPTH, G::WARP_W, D::WARP_IN, D::WARP_KC, G::WARP_SKIP, pl.warp);
     std::vector<int> rows;
     rows_tile(rows, G::WARP_W, 0);
     Layer L;                                   // merged head: logical outputs 0-2 = w, 3-5 = v (warping.py:217-218)
-    L.rows = std::move(rows);
+    L.segs = {Seg{std::move(rows), pl.warp}};
     L.n_tiles = 1;
     L.is_head = true;
     L.n_out = 6;
@@ -175,21 +207,21 @@ template <class G> void pack_shared(StreamWriter& sw, const SharedNets& n) {
     sw.emit(L);
   }
   if constexpr (G::HAS_HYPER) {
-    emit_mlp(sw, n.hyper_hidden, G::HYP_DEPTH, G::HYP_W, D::HYP_IN, D::HYP_KC, G::HYP_SKIP);
+    emit_mlp(sw, n.hyper_hidden, G::HYP_DEPTH, G::HYP_W, D::HYP_IN, D::HYP_KC, G::HYP_SKIP, pl.hyp);
     std::vector<int> rows;
     rows_tile(rows, G::HYP_W, 0);
-    sw.emit(head_layer(n.hyper_out, std::move(rows)));
+    sw.emit(head_layer(n.hyper_out, std::move(rows), pl.hyp));
   }
 }
 
-template <class G> void pack_nerf(StreamWriter& sw, const NerfNet& n) {
+template <class G> void pack_nerf(StreamWriter& sw, const NerfNet& n, Plan pl) {
   using D = Dims<G>;
   constexpr int TW = G::TRUNK_W;
-  emit_mlp(sw, n.trunk, G::TRUNK_DEPTH, TW, D::TRUNK_IN, D::TRUNK_KC, G::TRUNK_SKIP);
+  emit_mlp(sw, n.trunk, G::TRUNK_DEPTH, TW, D::TRUNK_IN, D::TRUNK_KC, G::TRUNK_SKIP, pl.trunk);
   {  // alpha head on trunk_output (modules.py:273-274)
     std::vector<int> rows;
     rows_tile(rows, TW, 0);
-    sw.emit(head_layer(n.alpha, std::move(rows)));
+    sw.emit(head_layer(n.alpha, std::move(rows), pl.trunk));
   }
   {  // rgb hidden_0 with the (activation-free, modules.py:255) bottleneck Dense folded in.
      // Reference (modules.py:296-310): rgb_pre = [bottleneck TW | viewdir 6*VD | trunk_output TW (if X_IN_RGB) | normal 6*NM] @ K + b
@@ -214,11 +246,11 @@ template <class G> void pack_nerf(StreamWriter& sw, const NerfNet& n) {
       for (int k = 0; k < TW; ++k) bacc += (double)(B.bias ? B.bias[k] : 0.f) * (double)K.W(k, c);
       (*fbias)[c] = (float)bacc;
     }
-    std::vector<int> rows;
+    std::vector<int> rows, crows;
     rows_tile(rows, TW, 0);
-    rows_linear(rows, D::COND_KC, [&](int s) { return s < VD + NM ? TW + s : -1; });
+    rows_linear(crows, D::COND_KC, [&](int s) { return s < VD + NM ? TW + s : -1; });
     Layer L;
-    L.rows = std::move(rows);
+    L.segs = {Seg{std::move(rows), pl.trunk}, Seg{std::move(crows), pl.rgb}};   // trunk_output is a trunk-precision tensor
     L.n_tiles = W / 32;
     L.n_out = W;
     L.W = [fused, W](int r, int c) { return (*fused)[(size_t)r * W + c]; };
@@ -228,7 +260,7 @@ template <class G> void pack_nerf(StreamWriter& sw, const NerfNet& n) {
   {  // rgb head
     std::vector<int> rows;
     rows_tile(rows, G::RGB_W, 0);
-    sw.emit(head_layer(n.rgb, std::move(rows)));
+    sw.emit(head_layer(n.rgb, std::move(rows), pl.rgb));
   }
 }
 

@@ -38,6 +38,7 @@
 namespace nerfds {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -69,11 +70,13 @@ template <int P> struct Chunk;   // 16 k-slots x 32 samples of activations (this
 template <> struct Chunk<P_BF16> { bf16x8 v; };
 template <> struct Chunk<P_BF16X3> { bf16x8 hi, lo; };
 template <> struct Chunk<P_F32> { float v[8]; };
+template <> struct Chunk<P_F16> { f16x8 v; };
 
 template <int P> struct WFrag;   // 32 out rows x 16 k-slots of weights (this lane: 8 slots of 1 row)
 template <> struct WFrag<P_BF16> { bf16x8 v; };
 template <> struct WFrag<P_BF16X3> { bf16x8 hi, lo; };
 template <> struct WFrag<P_F32> { f32x4 a, b; };
+template <> struct WFrag<P_F16> { f16x8 v; };
 
 // relu on raw float bits: signed-integer max with 0 (one v_max_i32; fmaxf costs a canonicalising v_max on top).
 DEVI float relu_f(float x) {
@@ -105,32 +108,21 @@ template <> DEVI void make_chunk<P_F32>(Chunk<P_F32>& c, const float (&x)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) c.v[i] = x[i];
 }
+template <> DEVI void make_chunk<P_F16>(Chunk<P_F16>& c, const float (&x)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c.v[i] = (_Float16)x[i];      // v_cvt_pk_f16_f32: round to nearest even
+}
 
-// Weight fragments come through a buffer descriptor: the per-lane part of the address is the constant
-// voffset = lane * 16, the fragment position is a wave-uniform soffset (a compile-time constant after
-// unrolling), so streaming 1760 fragments costs no per-fragment VGPR address arithmetic.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 DEVI rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), /*stride*/ 0, (int)bytes, 0x00020000);
 }
 
-template <int P> DEVI WFrag<P> load_wfrag(rsrc_t rsrc, int lane16, int soff) {
-  WFrag<P> w;
-  if constexpr (P == P_BF16) {
-    w.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, soff, 0));
-  } else if constexpr (P == P_BF16X3) {
-    w.hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, soff, 0));
-    w.lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, soff + 1024, 0));
-  } else {
-    w.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, soff, 0));
-    w.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, soff + 1024, 0));
-  }
-  return w;
-}
-
 template <int P> DEVI void mma(f32x16& acc, const WFrag<P>& w, const Chunk<P>& c) {
   if constexpr (P == P_BF16) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v, c.v, acc, 0, 0, 0);
+  } else if constexpr (P == P_F16) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.v, c.v, acc, 0, 0, 0);
   } else if constexpr (P == P_BF16X3) {
     // (w_hi + w_lo)(x_hi + x_lo) ~= w_hi x_lo + w_lo x_hi + w_hi x_hi ; small terms first.
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, c.lo, acc, 0, 0, 0);
@@ -145,60 +137,54 @@ template <int P> DEVI void mma(f32x16& acc, const WFrag<P>& w, const Chunk<P>& c
 }
 
 // ------------------------------------------------------------------------------------------------
-// Weight pipe.  The fragments of one evaluation form ONE static stream: [shared mask|warp|hyper nets]
-// followed by [NerfMLP of the level].  The pipe keeps DEPTH fragments in flight in a register ring:
-// consuming fragment i issues the load of fragment i + DEPTH (wrapping into the next evaluation's stream,
-// so the pipeline never drains between layers, batches or rays).  Every index is a compile-time
-// constant after unrolling; sched_barrier pins the VMEM loads to their program position so the
-// scheduler cannot hoist hundreds of them (and spill), while MFMA / VALU stay free to move.
+// Weight pipe.  The fragments of one evaluation form ONE static stream of 1-KiB units: [shared mask|warp|hyper
+// nets] followed by [NerfMLP of the level]; a fragment is one unit (bf16 / f16) or two consecutive units (hi | lo of
+// split bf16, k 0-3 | k 4-7 of fp32) at any unit position, so networks of different precision can follow each other
+// in one stream (graphs.h Plan / walk_seg).  The stream is staged through an LDS ring by LDS-DMA; a register ring keeps the next RD
+// units in flight LDS -> VGPR: consuming unit u issues the read of unit u + RD, whatever fragments those units belong
+// to.  Every index is a compile-time constant after unrolling.
 // ------------------------------------------------------------------------------------------------
-// STAGE_BYTES (graphs.h): one ring stage = 16 bf16 fragments (8 in the 2-part precisions)
+template <int PM, int PW, int PH, int PT, int PR> struct PlanT {
+  static constexpr int MASK = PM, WARP = PW, HYP = PH, TRUNK = PT, RGB = PR;
+  static constexpr Plan value() { return Plan{PM, PW, PH, PT, PR}; }
+  // 8 waves (two per SIMD, 256 registers each) when the 256-wide trunk runs on one-unit operands; a trunk on two-unit
+  // operands needs > 256 registers of activations: one 512-register wave per SIMD.
+  static constexpr bool EIGHT_WAVES = is_single(PT);
+};
+// STAGE_BYTES (graphs.h): one ring stage = 16 units
 constexpr int NUM_STAGES = 4;          // ring depth
 constexpr int RING_BYTES = NUM_STAGES * STAGE_BYTES;
-// Work shape per precision.  NT = N-tiles (32 samples) per wave and evaluation; SPLIT = waves that share one ray's
-// batch of 32 * NT * SPLIT samples; RAYS = rays in flight per workgroup (each with its own RayLds block).
-//   bf16: 8 waves, two per SIMD at 256 registers each, so one wave's LDS/epilogue latency is covered by the other
-//         wave's MFMAs; the 2-part precisions need > 256 registers of operands: one 512-register wave per SIMD.
+// Work shape.  NT = N-tiles (32 samples) per wave and evaluation; SPLIT = waves that share one ray's batch of
+// 32 * NT * SPLIT samples; RAYS = rays in flight per workgroup (each with its own RayLds block).
+//   8 waves: two per SIMD, so one wave's LDS/epilogue latency is covered by the other wave's MFMAs.
 //   WIDE (Nc + Nf > 128, e.g. 128 + 128): half as many rays per workgroup, twice the waves per ray and a 256-sample
 //         LDS block per ray, so the LDS footprint is unchanged.
-#ifndef NERFDS_BF16_NT
-#define NERFDS_BF16_NT 1
-#endif
-#ifndef NERFDS_BF16_SPLIT
-#define NERFDS_BF16_SPLIT 2
-#endif
-template <int P, bool WIDE> struct Shape {
-  static constexpr int NT = 1, SPLIT = WIDE ? 2 : 1, RAYS = WIDE ? 2 : 4, MAXS = WIDE ? 256 : 128;
+template <class PL, bool WIDE> struct Shape {
+  static constexpr int NT = 1, SPLIT = (PL::EIGHT_WAVES ? 2 : 1) * (WIDE ? 2 : 1), RAYS = WIDE ? 2 : 4, MAXS = WIDE ? 256 : 128;
 };
-template <bool WIDE> struct Shape<P_BF16, WIDE> {
-  static constexpr int NT = NERFDS_BF16_NT, SPLIT = NERFDS_BF16_SPLIT * (WIDE ? 2 : 1), RAYS = WIDE ? 2 : 4, MAXS = WIDE ? 256 : 128;
-};
-template <int P> constexpr int wg_waves() { return Shape<P, false>::RAYS * Shape<P, false>::SPLIT; }
-static_assert(Shape<P_BF16, true>::RAYS * Shape<P_BF16, true>::SPLIT == wg_waves<P_BF16>() &&
-              Shape<P_F32, true>::RAYS * Shape<P_F32, true>::SPLIT == wg_waves<P_F32>(), "both shapes use the same workgroup size");
+template <class PL> constexpr int wg_waves() { return Shape<PL, false>::RAYS * Shape<PL, false>::SPLIT; }
 // LDS map: [0, RING_BYTES) weight ring | padded fp32 biases (shared, coarse NerfMLP, fine NerfMLP) | RAYS x WaveLds
 constexpr int BIAS_OFF = RING_BYTES;
 template <class G> constexpr int bias_bytes() { return (Dims<G>::SHARED_BIAS_TILES + 2 * Dims<G>::NERF_BIAS_TILES) * 128; }
 
-template <class G, int P> struct Pipe {
-  using Dm = Dims<G>;
-  static constexpr int FB = frag_bytes(P);
-  static constexpr int GF = STAGE_BYTES / FB;                     // fragments per stage
-  static constexpr int NS = NUM_STAGES;
-  // stream positions count the zero padding at the end of each stream (graphs.h pad_frags)
-  static constexpr int SHARED_PAD = pad_frags(Dm::SHARED_FRAGS, P), NERF_PAD = pad_frags(Dm::NERF_FRAGS, P);
-  static constexpr int SHARED_STAGES = SHARED_PAD / GF, USED_STAGES = (SHARED_PAD + NERF_PAD) / GF;
-  static constexpr int STAGES = cdiv(USED_STAGES, NS) * NS;       // per evaluation, padded so ring slots survive the wrap
-  static constexpr int WAVES = wg_waves<P>();
-  static constexpr int PIECES = STAGE_BYTES / 1024 / WAVES;       // 1 KiB LDS-DMA pieces per wave per stage
-  // LDS -> register prefetch distance in fragments: a ds_read_b128 takes ~100+ cycles to return, a bf16 fragment
-  // is consumed in 64 MFMA cycles, so the reads must run several fragments ahead of the MFMAs.
-#ifndef NERFDS_BF16_DEPTH
-#define NERFDS_BF16_DEPTH 4
+#ifndef NERFDS_RING_UNITS
+#define NERFDS_RING_UNITS 4
 #endif
-  static constexpr int DEPTH = (P == P_BF16) ? NERFDS_BF16_DEPTH : 2;
-  static_assert(GF % DEPTH == 0 && DEPTH <= GF, "ring slot = fragment index mod DEPTH; prefetch reaches at most one stage ahead");
-  WFrag<P> ring[DEPTH];
+template <class G, class PL> struct Pipe {
+  using Dm = Dims<G>;
+  static constexpr int SU = STAGE_UNITS;                          // units per stage
+  static constexpr int NS = NUM_STAGES;
+  // stream positions count the zero padding at the end of each stream (graphs.h pad_units)
+  static constexpr int SHARED_PAD = pad_units(shared_units<G>(PL::value())), NERF_PAD = pad_units(nerf_units<G>(PL::value()));
+  static constexpr int SHARED_STAGES = SHARED_PAD / SU, USED_STAGES = (SHARED_PAD + NERF_PAD) / SU;
+  static constexpr int STAGES = cdiv(USED_STAGES, NS) * NS;       // per evaluation, padded so ring slots survive the wrap
+  static constexpr int WAVES = wg_waves<PL>();
+  static constexpr int PIECES = SU / WAVES;                       // 1 KiB LDS-DMA pieces per wave per stage
+  // LDS -> register prefetch distance in units: a ds_read_b128 takes ~100+ cycles to return under load, a bf16 unit is
+  // consumed in 32-64 MFMA cycles, so the reads must run several units ahead of the MFMAs.
+  static constexpr int RD = NERFDS_RING_UNITS;
+  static_assert(RD <= SU && RD >= 2, "prefetch reaches at most one stage ahead");
+  u32x4 ring[RD];
   rsrc_t ws;        // shared stream
   rsrc_t wn;        // NerfMLP stream of the level being evaluated
   rsrc_t wn_next;   // NerfMLP stream of the level evaluated next (wrap-around prefetch)
@@ -242,30 +228,38 @@ template <class G, int P> struct Pipe {
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) issue_stage(t);
   }
-  DEVI WFrag<P> frag(int i) const {
+  DEVI u32x4 unit(int u) const {
 #if (NERFDS_ABLATE & 32) && defined(__HIP_DEVICE_COMPILE__)
-    { WFrag<P> z{}; u32x4 t = {0u, 0u, 0u, (unsigned)i}; asm volatile("" : "+v"(t)); if constexpr (P == P_BF16) z.v = __builtin_bit_cast(bf16x8, t); return z; }
+    { u32x4 t = {0u, 0u, 0u, (unsigned)u}; asm volatile("" : "+v"(t)); return t; }
 #endif
-    const int off = ((i / GF) % NS) * STAGE_BYTES + (i % GF) * FB;
+    const int off = ((u / SU) % NS) * STAGE_BYTES + (u % SU) * 1024;
+    return *reinterpret_cast<const u32x4*>(g_smem + off + lane16);
+  }
+  DEVI void begin_stage(int u0) {   // u0: first unit of the stage
+    boundary(u0 / SU);
+    if (u0 == 0 || u0 == SHARED_PAD) {        // cold start of a stream segment: fill the register ring
+#pragma unroll
+      for (int d = 0; d < RD; ++d) ring[(u0 + d) % RD] = unit(u0 + d);
+    }
+  }
+  // unit u has been consumed (or skipped): its ring slot takes unit u + RD (stage (u / SU) + 1 is resident)
+  DEVI void refill(int u) {
+    if ((u + RD) / SU < USED_STAGES) ring[u % RD] = unit(u + RD);
+  }
+  template <int P> DEVI WFrag<P> frag(int u) const {
     WFrag<P> w;
-    const u32x4* p = reinterpret_cast<const u32x4*>(g_smem + off + lane16);
     if constexpr (P == P_BF16) {
-      w.v = __builtin_bit_cast(bf16x8, p[0]);
+      w.v = __builtin_bit_cast(bf16x8, ring[u % RD]);
+    } else if constexpr (P == P_F16) {
+      w.v = __builtin_bit_cast(f16x8, ring[u % RD]);
     } else if constexpr (P == P_BF16X3) {
-      w.hi = __builtin_bit_cast(bf16x8, p[0]);
-      w.lo = __builtin_bit_cast(bf16x8, p[64]);
+      w.hi = __builtin_bit_cast(bf16x8, ring[u % RD]);
+      w.lo = __builtin_bit_cast(bf16x8, ring[(u + 1) % RD]);
     } else {
-      w.a = __builtin_bit_cast(f32x4, p[0]);
-      w.b = __builtin_bit_cast(f32x4, p[64]);
+      w.a = __builtin_bit_cast(f32x4, ring[u % RD]);
+      w.b = __builtin_bit_cast(f32x4, ring[(u + 1) % RD]);
     }
     return w;
-  }
-  DEVI void begin_stage(int i0) {   // i0: first fragment of the stage
-    boundary(i0 / GF);
-    if (i0 == 0 || i0 == SHARED_PAD) {        // cold start of a stream segment: fill the register ring
-#pragma unroll
-      for (int d = 0; d < DEPTH; ++d) ring[(i0 + d) % DEPTH] = frag(i0 + d);
-    }
   }
   DEVI void finish_eval() {    // boundaries of the hole stages keep the barrier count and the ring in step
 #pragma unroll
@@ -274,7 +268,7 @@ template <class G, int P> struct Pipe {
 };
 
 struct Cursor {
-  int fi;       // stream index of the next fragment
+  int pos;      // stream position (unit index) of the next fragment
   int boff;     // LDS byte offset of the next bias tile
 };
 
@@ -296,21 +290,25 @@ DEVI f32x16 load_bias(int boff, int h) {
   return bv;
 }
 
-// `hook` (the deferred epilogue of the previous output tile) is dropped into the MFMA stream right after the
-// second fragment of the segment when `hook_here`: its VALU work then overlaps this tile's MFMA chain.
-template <class G, int P, int NT, int K, class H>
-DEVI void accum(f32x16 (&acc)[NT], Pipe<G, P>& pipe, Cursor& cur, const Chunk<P> (&in)[NT][K], bool hook_here, H&& hook) {
+// One input segment (K k16-chunks of precision P) of an output tile: K fragments from the stream.
+template <class G, class PL, int NT, int P, int K>
+DEVI void accum(f32x16 (&acc)[NT], Pipe<G, PL>& pipe, Cursor& cur, const Chunk<P> (&in)[NT][K]) {
+  using PP = Pipe<G, PL>;
+  constexpr int NP = frag_parts(P);
 #pragma unroll
   for (int kc = 0; kc < K; ++kc) {
-    const int i = cur.fi + kc;
-    using PP = Pipe<G, P>;
-    if (i % PP::GF == 0) pipe.begin_stage(i);
+    const int u = cur.pos;
+    // First fragment that touches a new stage (a two-unit fragment may straddle: its first unit is in the register
+    // ring already, and so is every other unit of the stage that is being retired - the ring runs RD units ahead).
+    if (u % PP::SU == 0) pipe.begin_stage(u);
+    else if (NP == 2 && (u + 1) % PP::SU == 0) pipe.begin_stage(u + 1);
+    const WFrag<P> w = pipe.template frag<P>(u);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) mma<P>(acc[nt], pipe.ring[i % PP::DEPTH], in[nt][kc]);
-    if ((i + PP::DEPTH) / PP::GF < PP::USED_STAGES) pipe.ring[i % PP::DEPTH] = pipe.frag(i + PP::DEPTH);   // stage (i / GF) + 1 is resident
-    if (hook_here && kc == (K > 1 ? 1 : 0)) hook();
+    for (int nt = 0; nt < NT; ++nt) mma<P>(acc[nt], w, in[nt][kc]);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) pipe.refill(u + q);
+    cur.pos += NP;
   }
-  cur.fi += K;
 }
 
 template <int P, int NT, bool RELU, int W>
@@ -330,13 +328,12 @@ DEVI void tile_epilogue(Chunk<P> (&out)[NT][W], int ot, const f32x16 (&acc)[NT])
   }
 }
 
-// One dense layer with OT output tiles of 32 features; inputs are one or more chunk arrays in stream order.
-// The accumulators start from the bias (the first MFMA of a tile reads the bias registers as its C operand).
-// Software pipeline over the tiles of the layer: the bias of tile t + 1 is fetched from LDS before the MFMA chain
-// of tile t, and the epilogue (ReLU + pack to the next layer's B operand) of tile t runs inside the chain of tile
-// t + 1, so a wave keeps issuing MFMAs back to back instead of draining the matrix pipe at every tile.
-template <class G, int P, int NT, int OT, bool RELU, class... Ins>
-DEVI void dense(Pipe<G, P>& pipe, Cursor& cur, int h, Chunk<P> (&out)[NT][2 * OT], const Ins&... ins) {
+// One dense layer with OT output tiles of 32 features; inputs are one or more chunk arrays in stream order (each in
+// its own precision), the output chunks are produced in the precision PO of the tensor they form.
+// The accumulators start from the bias (the first MFMA of a tile reads the bias registers as its C operand); the
+// bias of tile t + 1 is fetched from LDS before the MFMA chain of tile t.
+template <class G, class PL, int NT, int OT, bool RELU, int PO, class... Ins>
+DEVI void dense(Pipe<G, PL>& pipe, Cursor& cur, int h, Chunk<PO> (&out)[NT][2 * OT], const Ins&... ins) {
   f32x16 acc[OT][NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[0][nt] = load_bias(cur.boff, h);
@@ -346,27 +343,18 @@ DEVI void dense(Pipe<G, P>& pipe, Cursor& cur, int h, Chunk<P> (&out)[NT][2 * OT
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[ot + 1][nt] = load_bias(cur.boff + 128 * (ot + 1), h);
     }
-    int seg = 0;
-#ifndef NERFDS_EPILOGUE_PIPELINE      // measured: with two waves per SIMD the second wave already covers the epilogue (-1.5 % when pipelined)
-    (accum<G, P, NT>(acc[ot], pipe, cur, ins, false, [] {}), ...);
-    tile_epilogue<P, NT, RELU>(out, ot, acc[ot]);
-    (void)seg;
+    (accum<G, PL, NT>(acc[ot], pipe, cur, ins), ...);
+    tile_epilogue<PO, NT, RELU>(out, ot, acc[ot]);
   }
-#else
-    auto hook = [&]() { if (ot > 0) tile_epilogue<P, NT, RELU>(out, ot - 1, acc[ot > 0 ? ot - 1 : 0]); };
-    (accum<G, P, NT>(acc[ot], pipe, cur, ins, seg++ == 0, hook), ...);
-  }
-  tile_epilogue<P, NT, RELU>(out, OT - 1, acc[OT - 1]);
-#endif
   cur.boff += 128 * OT;
 }
 
 // Output head (<= 16 logical outputs, duplicated in both lane halves by the packer): logical output j = acc[j].
-template <class G, int P, int NT, class... Ins>
-DEVI void head(Pipe<G, P>& pipe, Cursor& cur, int h, f32x16 (&acc)[NT], const Ins&... ins) {
+template <class G, class PL, int NT, class... Ins>
+DEVI void head(Pipe<G, PL>& pipe, Cursor& cur, int h, f32x16 (&acc)[NT], const Ins&... ins) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = load_bias(cur.boff, h);
-  (accum<G, P, NT>(acc, pipe, cur, ins, false, [] {}), ...);
+  (accum<G, PL, NT>(acc, pipe, cur, ins), ...);
   cur.boff += 128;
 }
 
@@ -462,11 +450,11 @@ template <int C> DEVI FeatV posenc_feat(int g, const float (&x)[C], const float*
 DEVI FeatV val_feat(float v) { FeatV f; f.kind = 2; f.arg = 0.f; f.win = 0.f; f.val = v; return f; }
 DEVI FeatV zero_feat() { FeatV f; f.kind = 0; f.arg = 0.f; f.win = 0.f; f.val = 0.f; return f; }
 
-// sin for the network-input encodings.  The bf16 kernel rounds every feature to 8 mantissa bits anyway, so it uses
-// the hardware v_sin_f32 (argument in revolutions, abs error ~1e-6); the parity-grade kernels use sin_cw.
+// sin for the network-input encodings.  One-unit operands (bf16 / f16) round every feature to 8 / 11 significand bits
+// anyway, so they use the hardware v_sin_f32 (argument in revolutions, abs error ~1e-6); the others use sin_cw.
 template <int P> DEVI float sin_enc(float a) {
   if (NERFDS_ABLATE & 8) return a;
-  if constexpr (P == P_BF16) {
+  if constexpr (is_single(P)) {
     return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(a * 0.159154943f));
   } else {
     return sin_cw(a);
@@ -533,8 +521,8 @@ DEVI void rodrigues(float (&R)[9], const float (&w)[3], float st, float omc) {
 // the next network is parked in the wave's LDS block at once (it is going there for compositing anyway),
 // so the 8x256 trunk runs with (almost) only MFMA operands in registers.
 // ------------------------------------------------------------------------------------------------
-template <class G, int P, int NT, class LT>
-DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int level, int lane, int s_base, int S, LT& L) {
+template <class G, class PL, int NT, class LT>
+DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int level, int lane, int s_base, int S, LT& L) {
   // s_base already includes this wave's share of a split batch (32 * NT * q)
   using D = Dims<G>;
   const int h = lane >> 5, ln = lane & 31;
@@ -565,7 +553,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) maskv[nt] = rc.gt_mask;
   if constexpr (G::HAS_MASK) {
-    constexpr int W16 = G::MASK_W / 16, W32 = G::MASK_W / 32;
+    constexpr int W16 = G::MASK_W / 16, W32 = G::MASK_W / 32, P = PL::MASK;
     Chunk<P> in0[NT][D::MASK_KC], a[NT][W16], b[NT][W16];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -575,16 +563,16 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
         return zero_feat();
       });
     static_assert(G::MASK_DEPTH == 8 || !G::HAS_MASK, "mask net is unrolled for depth 8, skip 4");
-    dense<G, P, NT, W32, true>(pipe, cur, h, a, in0);
-    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, P, NT, W32, true>(pipe, cur, h, a, b);
-    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, P, NT, W32, true>(pipe, cur, h, a, b, in0);      // skip: [x, inputs] (modules.py:66-67)
-    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, P, NT, W32, true>(pipe, cur, h, a, b);
-    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, a, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b, in0);      // skip: [x, inputs] (modules.py:66-67)
+    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
     f32x16 hacc[NT];
-    head<G, P, NT>(pipe, cur, h, hacc, b);
+    head<G, PL, NT>(pipe, cur, h, hacc, b);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const float pm = fmaxf(hacc[nt][0], 0.f);                              // MaskMLP.output_activation = relu
@@ -598,7 +586,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
 
   // ---- SE3Field (warping.py:200-237) + exp_se3 (rigid_body.py:77-101) ----
   if constexpr (G::HAS_WARP) {
-    constexpr int W16 = G::WARP_W / 16, W32 = G::WARP_W / 32;
+    constexpr int W16 = G::WARP_W / 16, W32 = G::WARP_W / 32, P = PL::WARP;
     Chunk<P> in0[NT][D::WARP_KC], a[NT][W16], b[NT][W16];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -611,14 +599,14 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
         return zero_feat();
       });
     static_assert(G::WARP_DEPTH == 6 || !G::HAS_WARP, "warp trunk is unrolled for depth 6, skip 4");
-    dense<G, P, NT, W32, true>(pipe, cur, h, a, in0);
-    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, P, NT, W32, true>(pipe, cur, h, a, b);
-    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, P, NT, W32, true>(pipe, cur, h, a, b, in0);
-    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, a, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
     f32x16 hacc[NT];
-    head<G, P, NT>(pipe, cur, h, hacc, b);      // logical outputs: w = 0..2, v = 3..5
+    head<G, PL, NT>(pipe, cur, h, hacc, b);      // logical outputs: w = 0..2, v = 3..5
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float w[3] = {hacc[nt][0], hacc[nt][1], hacc[nt][2]};
@@ -684,7 +672,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) wamb[nt][0] = wamb[nt][1] = 0.f;
   if constexpr (G::HAS_HYPER) {
-    constexpr int W16 = G::HYP_W / 16, W32 = G::HYP_W / 32;
+    constexpr int W16 = G::HYP_W / 16, W32 = G::HYP_W / 32, P = PL::HYP;
     Chunk<P> in0[NT][D::HYP_KC], a[NT][W16], b[NT][W16];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -695,14 +683,14 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
         return zero_feat();
       });
     static_assert(G::HYP_DEPTH == 6 || !G::HAS_HYPER, "hyper sheet is unrolled for depth 6, skip 4");
-    dense<G, P, NT, W32, true>(pipe, cur, h, a, in0);
-    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, P, NT, W32, true>(pipe, cur, h, a, b);
-    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, P, NT, W32, true>(pipe, cur, h, a, b, in0);
-    dense<G, P, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, a, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
     f32x16 hacc[NT];
-    head<G, P, NT>(pipe, cur, h, hacc, b);
+    head<G, PL, NT>(pipe, cur, h, hacc, b);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { wamb[nt][0] = hacc[nt][0]; wamb[nt][1] = hacc[nt][1]; }
   }
@@ -714,10 +702,11 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
     }
 
   // ---- NerfMLP of this level (modules.py:243-313; models.py:1043-1047, 1268-1270) ----
-  cur.fi = Pipe<G, P>::SHARED_PAD;      // skip the zero padding of the shared stream
+  cur.pos = Pipe<G, PL>::SHARED_PAD;    // skip the zero padding of the shared stream
   cur.boff = BIAS_OFF + (D::SHARED_BIAS_TILES + level * D::NERF_BIAS_TILES) * 128;
   constexpr int TW16 = G::TRUNK_W / 16, TW32 = G::TRUNK_W / 32;
   {
+    constexpr int P = PL::TRUNK, PR = PL::RGB;
     Chunk<P> in0[NT][D::TRUNK_KC], a[NT][TW16], b[NT][TW16];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -729,19 +718,19 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
         return zero_feat();
       });
     static_assert(G::TRUNK_DEPTH == 8 && G::TRUNK_SKIP == 4, "trunk is unrolled for depth 8, skip 4");
-    dense<G, P, NT, TW32, true>(pipe, cur, h, a, in0);
-    dense<G, P, NT, TW32, true>(pipe, cur, h, b, a);
-    dense<G, P, NT, TW32, true>(pipe, cur, h, a, b);
-    dense<G, P, NT, TW32, true>(pipe, cur, h, b, a);
-    dense<G, P, NT, TW32, true>(pipe, cur, h, a, b, in0);
-    dense<G, P, NT, TW32, true>(pipe, cur, h, b, a);
-    dense<G, P, NT, TW32, true>(pipe, cur, h, a, b);
-    dense<G, P, NT, TW32, true>(pipe, cur, h, b, a);          // b = trunk_output
+    dense<G, PL, NT, TW32, true>(pipe, cur, h, a, in0);
+    dense<G, PL, NT, TW32, true>(pipe, cur, h, b, a);
+    dense<G, PL, NT, TW32, true>(pipe, cur, h, a, b);
+    dense<G, PL, NT, TW32, true>(pipe, cur, h, b, a);
+    dense<G, PL, NT, TW32, true>(pipe, cur, h, a, b, in0);
+    dense<G, PL, NT, TW32, true>(pipe, cur, h, b, a);
+    dense<G, PL, NT, TW32, true>(pipe, cur, h, a, b);
+    dense<G, PL, NT, TW32, true>(pipe, cur, h, b, a);          // b = trunk_output
     // (the activation-free bottleneck Dense, modules.py:255, is folded into rgb hidden_0 by the packer)
     f32x16 hacc[NT];
-    head<G, P, NT>(pipe, cur, h, hacc, b);                    // alpha_mlp on trunk_output (modules.py:273-274)
+    head<G, PL, NT>(pipe, cur, h, hacc, b);                    // alpha_mlp on trunk_output (modules.py:273-274)
     // rgb condition chunks: [posenc(viewdir) | posenc(normal in observation frame)]
-    Chunk<P> cond[NT][D::COND_KC];
+    Chunk<PR> cond[NT][D::COND_KC];
     WAVE_SYNC();                                              // parked SE3 state was written by the h == 0 lanes
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -771,7 +760,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
           for (int c = 0; c < 3; ++c) L.sv[SV_NORM + c][slot_of(nt)] = 0.f;
         }
       }
-      build_chunks<P, D::COND_KC>(cond[nt], h, [&](int f) {
+      build_chunks<PR, D::COND_KC>(cond[nt], h, [&](int f) {
         constexpr int I3 = D::ID3, VD = D::VD_FEATS;
         if (f < I3) return val_feat(L.rayc[RC_VD + (f < 3 ? f : 0)]);                           // identity prefix of posenc(viewdir)
         if (f < VD) return val_feat(L.rayc[RC_VDENC + ((f - I3) < 24 ? (f - I3) : 0)]);
@@ -780,9 +769,9 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, P>& pipe, int 
         return zero_feat();
       });
     }
-    Chunk<P> c[NT][G::RGB_W / 16];
-    dense<G, P, NT, G::RGB_W / 32, true>(pipe, cur, h, c, b, cond);        // K order [trunk_output | cond]
-    head<G, P, NT>(pipe, cur, h, hacc, c);
+    Chunk<PR> c[NT][G::RGB_W / 16];
+    dense<G, PL, NT, G::RGB_W / 32, true>(pipe, cur, h, c, b, cond);       // K order [trunk_output | cond]
+    head<G, PL, NT>(pipe, cur, h, hacc, c);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       {
@@ -976,11 +965,11 @@ template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int n
 // ------------------------------------------------------------------------------------------------
 // Kernel: persistent waves, one ray per wave per iteration.
 // ------------------------------------------------------------------------------------------------
-template <class G, int P, bool WIDE>
-__global__ __launch_bounds__(64 * wg_waves<P>(), wg_waves<P>() / 4) void render_rays_kernel(const KArgs ka) {
-  using SH = Shape<P, WIDE>;
+template <class G, class PL, bool WIDE>
+__global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void render_rays_kernel(const KArgs ka) {
+  using SH = Shape<PL, WIDE>;
   using WaveLds = WaveLdsT<SH::MAXS>;
-  constexpr int NT = SH::NT, SPLIT = SH::SPLIT, RAYS_PER_WG = SH::RAYS, WAVES = wg_waves<P>(), BATCH = 32 * NT * SPLIT;
+  constexpr int NT = SH::NT, SPLIT = SH::SPLIT, RAYS_PER_WG = SH::RAYS, WAVES = wg_waves<PL>(), BATCH = 32 * NT * SPLIT;
   using Dm = Dims<G>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -998,10 +987,10 @@ __global__ __launch_bounds__(64 * wg_waves<P>(), wg_waves<P>() / 4) void render_
     for (int i = threadIdx.x; i < total / 4; i += 64 * WAVES) reinterpret_cast<float*>(g_smem)[i] = 0.f;
     __syncthreads();
   }
-  Pipe<G, P> pipe;
-  const rsrc_t rs_nerf[2] = {make_rsrc(ka.wstream[1], Pipe<G, P>::NERF_PAD * frag_bytes(P)),
-                             make_rsrc(ka.wstream[2], Pipe<G, P>::NERF_PAD * frag_bytes(P))};
-  pipe.ws = make_rsrc(ka.wstream[0], Pipe<G, P>::SHARED_PAD * frag_bytes(P));
+  Pipe<G, PL> pipe;
+  const rsrc_t rs_nerf[2] = {make_rsrc(ka.wstream[1], Pipe<G, PL>::NERF_PAD * 1024),
+                             make_rsrc(ka.wstream[2], Pipe<G, PL>::NERF_PAD * 1024)};
+  pipe.ws = make_rsrc(ka.wstream[0], Pipe<G, PL>::SHARED_PAD * 1024);
   pipe.wn = pipe.wn_next = rs_nerf[0];
   pipe.lane16 = lane * 16;
   pipe.wave1k = wave * 1024;
@@ -1081,7 +1070,7 @@ __global__ __launch_bounds__(64 * wg_waves<P>(), wg_waves<P>() / 4) void render_
     // ---- coarse level ----
     for (int sb = 0; sb < nc; sb += BATCH) {
       set_level(0, (sb + BATCH < nc) ? 0 : (nf > 0 ? 1 : 0));
-      eval_batch<G, P, NT>(ka, rc, pipe, 0, lane, sb + 32 * NT * q, nc, L);
+      eval_batch<G, PL, NT>(ka, rc, pipe, 0, lane, sb + 32 * NT * q, nc, L);
     }
     ray_sync();
     if (q == 0 && !(NERFDS_ABLATE & 16)) {
@@ -1100,7 +1089,7 @@ __global__ __launch_bounds__(64 * wg_waves<P>(), wg_waves<P>() / 4) void render_
       const int n = nc + nf;
       for (int sb = 0; sb < n; sb += BATCH) {
         set_level(1, (sb + BATCH < n) ? 1 : 0);
-        eval_batch<G, P, NT>(ka, rc, pipe, 1, lane, sb + 32 * NT * q, n, L);
+        eval_batch<G, PL, NT>(ka, rc, pipe, 1, lane, sb + 32 * NT * q, n, L);
       }
       ray_sync();
       if (q == 0 && !(NERFDS_ABLATE & 16))
@@ -1114,20 +1103,29 @@ __global__ __launch_bounds__(64 * wg_waves<P>(), wg_waves<P>() / 4) void render_
 
 }  // namespace nerfds
 
-// One translation unit per (graph, precision): -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_PREC=P_BF16 -DNERFDS_NAME=nerfds_bf16
+// One translation unit per (graph, precision plan):
+//   -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_PREC=P_BF16 -DNERFDS_NAME=nerfds_bf16        uniform plan
+//   -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_MIXED -DNERFDS_NAME=nerfds_mixed            graphs.h NERFDS_MIX_* plan
 #ifndef NERFDS_GRAPH
-#error "compile with -DNERFDS_GRAPH=<GraphNerfDS|GraphStatic> -DNERFDS_PREC=<P_BF16|P_BF16X3|P_F32> -DNERFDS_NAME=<suffix>"
+#error "compile with -DNERFDS_GRAPH=<GraphNerfDS|GraphStatic|GraphHyperNeRF> -DNERFDS_PREC=<P_BF16|P_BF16X3|P_F32|P_F16> (or -DNERFDS_MIXED) -DNERFDS_NAME=<suffix>"
 #endif
 #define NERFDS_CAT2(a, b) a##b
 #define NERFDS_CAT(a, b) NERFDS_CAT2(a, b)
+namespace nerfds {
+#ifdef NERFDS_MIXED
+using KernelPlan = PlanT<NERFDS_MIX_MASK, NERFDS_MIX_WARP, NERFDS_MIX_HYP, NERFDS_MIX_TRUNK, NERFDS_MIX_RGB>;
+#else
+using KernelPlan = PlanT<NERFDS_PREC, NERFDS_PREC, NERFDS_PREC, NERFDS_PREC, NERFDS_PREC>;
+#endif
+}  // namespace nerfds
 
 template <bool WIDE> static void launch_shape(const nerfds::KArgs& ka, int num_cus, void* stream) {
   using namespace nerfds;
-  using SH = Shape<NERFDS_PREC, WIDE>;
+  using SH = Shape<KernelPlan, WIDE>;
   constexpr int lds = BIAS_OFF + bias_bytes<NERFDS_GRAPH>() + SH::RAYS * (int)sizeof(WaveLdsT<SH::MAXS>);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = render_rays_kernel<NERFDS_GRAPH, NERFDS_PREC, WIDE>;
+  auto kern = render_rays_kernel<NERFDS_GRAPH, KernelPlan, WIDE>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
@@ -1135,10 +1133,10 @@ template <bool WIDE> static void launch_shape(const nerfds::KArgs& ka, int num_c
   // one persistent workgroup per CU (LDS-bound), SH::RAYS rays per workgroup iteration
   const long long groups = ((long long)ka.num_rays + SH::RAYS - 1) / SH::RAYS;
   const int grid = (int)(groups < num_cus ? groups : num_cus);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wg_waves<NERFDS_PREC>()), lds, static_cast<hipStream_t>(stream), ka);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wg_waves<KernelPlan>()), lds, static_cast<hipStream_t>(stream), ka);
 }
 
 extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::KArgs& ka, int num_cus, void* stream) {
-  if (ka.nc + ka.nf > nerfds::Shape<nerfds::NERFDS_PREC, false>::MAXS) launch_shape<true>(ka, num_cus, stream);
+  if (ka.nc + ka.nf > nerfds::Shape<nerfds::KernelPlan, false>::MAXS) launch_shape<true>(ka, num_cus, stream);
   else launch_shape<false>(ka, num_cus, stream);
 }

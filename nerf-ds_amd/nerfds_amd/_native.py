@@ -11,11 +11,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFDS_LIB', os.path.join(_HERE, '_lib', 'libnerfds_hip.so'))   # NERFDS_LIB: development builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_DEPTH = 16
 RAY_REC = 26
 SAMPLE_REC = 18
-PREC = {'bf16': 0, 'bf16x3': 1, 'f32': 2}
+PREC = {'bf16': 0, 'bf16x3': 1, 'f32': 2, 'f16': 3, 'mixed': 4}
 
 # per-ray record slices (enum nerfds_ray_field)
 RAY_FIELDS = {
@@ -90,7 +90,7 @@ class Out(C.Structure):
 
 
 # every symbol include/nerfds.h declares
-SYMBOLS = ('nerfds_abi_version', 'nerfds_ctx_create', 'nerfds_ctx_load_weights', 'nerfds_render_rays',
+SYMBOLS = ('nerfds_abi_version', 'nerfds_precision_plan', 'nerfds_ctx_create', 'nerfds_ctx_load_weights', 'nerfds_render_rays',
            'nerfds_ctx_destroy', 'nerfds_last_error', 'nerfds_kernel_time_ms', 'nerfds_pack_stream_bytes',
            'nerfds_pack_bias_floats', 'nerfds_pack_stream', 'nerfds_debug_mfma', 'nerfds_camera_to_rays',
            'nerfds_frame_images', 'nerfds_trainer_create', 'nerfds_trainer_destroy', 'nerfds_trainer_param_count',
@@ -110,6 +110,7 @@ def load():
     raise RuntimeError(f'{LIB_PATH} is not built: run `make -C nerf-ds_amd/csrc -j8` (there is no CPU fallback)')
   lib = C.CDLL(LIB_PATH)
   lib.nerfds_abi_version.restype = C.c_int
+  lib.nerfds_precision_plan.argtypes = [C.c_uint32, C.POINTER(C.c_int32)]
   lib.nerfds_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(ModelCfg)]
   lib.nerfds_ctx_load_weights.argtypes = [C.c_void_p, C.POINTER(Weights)]
   lib.nerfds_render_rays.argtypes = [C.c_void_p, C.POINTER(Rays), C.POINTER(Extra), C.POINTER(Rand), C.POINTER(Out),

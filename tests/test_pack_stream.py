@@ -25,7 +25,7 @@ def test_library_loads_and_exports_header_symbols():
   assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
   for s in declared:
     assert hasattr(lib, s), s
-  assert lib.nerfds_abi_version() == 2
+  assert lib.nerfds_abi_version() == N.ABI_VERSION == 3
 
 
 def test_ctx_create_errors_without_touching_a_gpu():
@@ -57,7 +57,7 @@ def _pack(cfg, params, which, level, prec):
 
 def _assert_consumed(s):
   """Whole stream consumed in order; what remains is the zero padding to a whole 16 KiB LDS stage."""
-  rest = s.w[s.fi * s.fb:]
+  rest = s.w[s.pos * 1024:]
   assert len(s.w) % 16384 == 0 and len(rest) < 16384 and not rest.any() and s.bt * 32 == len(s.bias)
 
 
@@ -73,40 +73,60 @@ def _unchunk_tiles(ch):
   return out
 
 
-@pytest.mark.parametrize('prec,tol', [('f32', 1e-6), ('bf16x3', 3e-5), ('bf16', 2e-2)])
-def test_shared_nets_stream_matches_oracle(prec, tol):
+WTOL = {'f32': 1e-6, 'bf16x3': 3e-5, 'bf16': 2e-2, 'f16': 2.5e-3}      # weight rounding only (activations stay fp64 here)
+
+
+def _plan(prec):
+  """The per-network precisions of a NERFDS_PREC_* value, as the library was built (csrc/graphs.h plan_of)."""
+  out = (C.c_int32 * 5)()
+  assert N.load().nerfds_precision_plan(N.PREC[prec], out) == 0
+  return dict(zip(('mask', 'warp', 'hyp', 'trunk', 'rgb'), (E.PREC_NAMES[v] for v in out)))
+
+
+def test_precision_plans():
+  for prec in ('bf16', 'bf16x3', 'f32', 'f16'):
+    assert set(_plan(prec).values()) == {prec}
+  mixed = _plan('mixed')
+  assert mixed['trunk'] in ('f16', 'bf16') and mixed['warp'] in ('bf16x3', 'f32'), mixed   # one MFMA per product in the trunk
+  assert N.load().nerfds_precision_plan(99, (C.c_int32 * 5)()) == -22
+
+
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
+def test_shared_nets_stream_matches_oracle(prec):
   cfg = nerf_ds_config(num_warp_embeds=3)
   p = init_params(cfg, 3, warp_head_scale=0.05, small_head_scale=0.3, bias_scale=0.1)
   P = O.to_torch(p)
   rng = np.random.default_rng(0)
   n = 7
   s = _pack(cfg, p, 0, 0, prec)
+  plan = _plan(prec)
   T = lambda a: torch.as_tensor(a, dtype=torch.float64)
   # MaskMLP
   f = rng.normal(size=(n, cfg.mask_in_dim))
-  x = E.mlp(s, f, 8, 128, 4)
-  got = E.head(s, [x], 1)
+  x = E.mlp(s, f, 8, 128, 4, plan['mask'])
+  got = E.head(s, [x], 1, [plan['mask']])
   ref = O.mlp(P['mask_mlp']['MLP_0'], T(f), 8, (4,), output_channels=1).numpy().T
-  assert np.abs(got - ref).max() <= tol * max(np.abs(ref).max(), 1e-3)
+  assert np.abs(got - ref).max() <= WTOL[plan['mask']] * max(np.abs(ref).max(), 1e-3)
   # SE3 trunk + merged (w, v) head
   f = rng.normal(size=(n, cfg.warp_in_dim))
-  x = E.mlp(s, f, 6, 128, 4)
-  got = E.head(s, [x], 6)
+  x = E.mlp(s, f, 6, 128, 4, plan['warp'])
+  got = E.head(s, [x], 6, [plan['warp']])
   tr = O.mlp(P['warp_field']['trunk'], T(f), 6, (4,))
   ref = torch.cat([O.dense(P['warp_field']['branches_w']['logit'], tr), O.dense(P['warp_field']['branches_v']['logit'], tr)], -1).numpy().T
-  assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+  assert np.abs(got - ref).max() <= WTOL[plan['warp']] * np.abs(ref).max()
   # hyper sheet
   f = rng.normal(size=(n, cfg.hyper_in_dim))
-  x = E.mlp(s, f, 6, 64, 4)
-  got = E.head(s, [x], 2)
+  x = E.mlp(s, f, 6, 64, 4, plan['hyp'])
+  got = E.head(s, [x], 2, [plan['hyp']])
   ref = O.mlp(P['hyper_sheet_mlp']['MLP_0'], T(f), 6, (4,), output_channels=2).numpy().T
-  assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+  assert np.abs(got - ref).max() <= WTOL[plan['hyp']] * np.abs(ref).max()
   _assert_consumed(s)
 
 
+@pytest.mark.parametrize('prec', ['f32', 'mixed'])
 @pytest.mark.parametrize('graph', ['nerf_ds', 'static', 'hypernerf'])
 @pytest.mark.parametrize('level', [0, 1])
-def test_nerf_mlp_stream_matches_oracle(graph, level):
+def test_nerf_mlp_stream_matches_oracle(graph, level, prec):
   if graph == 'static':
     if level == 1:
       pytest.skip('static graph is coarse only')
@@ -120,15 +140,17 @@ def test_nerf_mlp_stream_matches_oracle(graph, level):
   P = O.to_torch(p)[f"nerf_mlps_{'fine' if level else 'coarse'}"]
   rng = np.random.default_rng(1)
   n = 5
-  s = _pack(cfg, p, 1, level, 'f32')
+  s = _pack(cfg, p, 1, level, prec)
+  plan = _plan(prec)
+  pt, pr = plan['trunk'], plan['rgb']
   T = lambda a: torch.as_tensor(a, dtype=torch.float64)
   f = rng.normal(size=(n, cfg.trunk_in_dim))
   vd, nm = rng.normal(size=(n, cfg.viewdir_dim)), rng.normal(size=(n, cfg.norm_feat_dim))
-  trunk = E.mlp(s, f, 8, 256, 4)
-  alpha = E.head(s, [trunk], cfg.alpha_out_dim)
+  trunk = E.mlp(s, f, 8, 256, 4, pt)
+  alpha = E.head(s, [trunk], cfg.alpha_out_dim, [pt])
   cond = E.linear_chunks(np.concatenate([vd, nm], 1), -(-(cfg.viewdir_dim + cfg.norm_feat_dim) // 16))
-  hid = E.dense(s, [trunk, cond], 4, True)          # the activation-free bottleneck Dense is folded into rgb hidden_0
-  rgb = E.head(s, [hid], 3)
+  hid = E.dense(s, [trunk, cond], 4, True, [pt, pr])   # the activation-free bottleneck Dense is folded into rgb hidden_0
+  rgb = E.head(s, [hid], 3, [pr])
   _assert_consumed(s)
 
   t_ref = O.mlp(P['trunk_mlp'], T(f), 8, (4,))
@@ -136,6 +158,7 @@ def test_nerf_mlp_stream_matches_oracle(graph, level):
   a_ref = O.dense(P['alpha_mlp']['logit'], t_ref)
   parts = [b_ref, T(vd)] + ([t_ref] if cfg.use_x_in_rgb_condition else []) + ([T(nm)] if cfg.norm_feat_dim else [])
   r_ref = O.mlp(P['rgb_mlp'], torch.cat(parts, -1), 1, (), output_channels=3)
-  assert np.allclose(_unchunk_tiles(trunk), t_ref.numpy(), atol=1e-5)
-  assert np.allclose(alpha.T, a_ref.numpy(), atol=1e-5)
-  assert np.allclose(rgb.T, r_ref.numpy(), atol=1e-5)
+  atol = 1e-5 if prec == 'f32' else 4 * WTOL[pt] * float(np.abs(t_ref.numpy()).max())
+  assert np.allclose(_unchunk_tiles(trunk), t_ref.numpy(), atol=atol)
+  assert np.allclose(alpha.T, a_ref.numpy(), atol=atol)
+  assert np.allclose(rgb.T, r_ref.numpy(), atol=atol)

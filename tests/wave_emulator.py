@@ -1,7 +1,9 @@
 """Numpy emulation of how render_kernel.hip consumes the packed MFMA weight stream.
 
 It restates, independently of the C++ packer, the conventions of the device code:
-  * fragment = [32 rows m] x [16 k-slots (h, i)], lane = (h << 5) | m, fp32 stream: part 0 = slots i<4, part 1 = i>=4;
+  * fragment = [32 rows m] x [16 k-slots (h, i)], lane = (h << 5) | m; the stream is a sequence of 1-KiB units: a bf16 / f16
+    fragment is one unit, a split-bf16 fragment two (hi, lo), an fp32 fragment two (slots i<4, slots i>=4), back to
+    back without alignment, so networks of different precision can follow each other in one stream (csrc/graphs.h Plan);
   * an output tile's accumulator register r of lane half h is row (r & 3) + 8 (r >> 2) + 4 h, and registers
     8c .. 8c+7 become k-slots (h, 0..7) of activation chunk 2*tile + c of the next layer;
   * linear input chunks: slot (c, h, i) <-> feature 16 c + 8 h + i;
@@ -11,29 +13,36 @@ Used by the CPU tests to check the packer + stream order against the oracle's ML
 import numpy as np
 
 
+PREC_NAMES = ('bf16', 'bf16x3', 'f32', 'f16')     # csrc/graphs.h enum Prec
+
+
 class Stream:
   def __init__(self, wbytes: np.ndarray, bias: np.ndarray, prec: str):
+    """prec: the precision of every fragment unless a call names another one (mixed plans)."""
     self.prec = prec
-    self.fb = 1024 if prec == 'bf16' else 2048
     self.w = wbytes
     self.bias = bias
-    self.fi = 0
+    self.pos = 0          # stream position in 1-KiB units
     self.bt = 0
 
-  def next_frag(self) -> np.ndarray:
+  def next_frag(self, prec=None) -> np.ndarray:
     """Returns A[32 rows][2 halves][8 slots] as float64."""
-    raw = self.w[self.fi * self.fb:(self.fi + 1) * self.fb]
-    self.fi += 1
+    prec = prec or self.prec
+    units = 1 if prec in ('bf16', 'f16') else 2
+    raw = self.w[self.pos * 1024:(self.pos + units) * 1024]
+    self.pos += units
     A = np.zeros((32, 2, 8))
-    if self.prec == 'f32':
+    if prec == 'f32':
       p0 = raw[:1024].view(np.float32).reshape(64, 4)
       p1 = raw[1024:].view(np.float32).reshape(64, 4)
       v = np.concatenate([p0, p1], axis=1)
+    elif prec == 'f16':
+      v = raw.view(np.float16).astype(np.float64).reshape(64, 8)
     else:
       def bf(x):
         return (x.view(np.uint16).astype(np.uint32) << 16).view(np.float32).reshape(64, 8)
       v = bf(raw[:1024])
-      if self.prec == 'bf16x3':
+      if prec == 'bf16x3':
         v = v.astype(np.float64) + bf(raw[1024:])
     for lane in range(64):
       A[lane & 31, lane >> 5] = v[lane]
@@ -64,46 +73,47 @@ def tile_to_chunks(acc: np.ndarray) -> np.ndarray:
   return out
 
 
-def mma_tile(stream: Stream, inputs) -> np.ndarray:
-  """One output tile: sum over all chunks of all input arrays, in stream order; + bias.  Returns [32, N]."""
+def mma_tile(stream: Stream, inputs, precs=None) -> np.ndarray:
+  """One output tile: sum over all chunks of all input arrays, in stream order; + bias.  Returns [32, N].
+  precs: per input array, the precision of its weight fragments (default: the stream's)."""
   acc = None
   bias = stream.next_bias()
-  for chunks in inputs:
+  for j, chunks in enumerate(inputs):
     for kc in range(chunks.shape[0]):
-      A = stream.next_frag()
+      A = stream.next_frag(precs[j] if precs else None)
       part = np.einsum('mhi,hin->mn', A, chunks[kc])
       acc = part if acc is None else acc + part
   return acc + bias[:, None]
 
 
-def dense(stream: Stream, inputs, n_tiles: int, relu: bool) -> np.ndarray:
+def dense(stream: Stream, inputs, n_tiles: int, relu: bool, precs=None) -> np.ndarray:
   outs = []
   for _ in range(n_tiles):
-    acc = mma_tile(stream, inputs)
+    acc = mma_tile(stream, inputs, precs)
     if relu:
       acc = np.maximum(acc, 0.0)
     outs.append(tile_to_chunks(acc))
   return np.concatenate(outs, axis=0)
 
 
-def head(stream: Stream, inputs, n_out: int) -> np.ndarray:
+def head(stream: Stream, inputs, n_out: int, precs=None) -> np.ndarray:
   """Returns [n_out, N]: logical output j = accumulator register j of the lower half = row (j&3) + 8(j>>2);
   also checks the duplicate in the upper half."""
-  acc = mma_tile(stream, inputs)
+  acc = mma_tile(stream, inputs, precs)
   out = np.stack([acc[(j & 3) + 8 * (j >> 2)] for j in range(n_out)])
   dup = np.stack([acc[(j & 3) + 8 * (j >> 2) + 4] for j in range(n_out)])
   assert np.array_equal(out, dup), 'head outputs must be duplicated in both lane halves'
   return out
 
 
-def mlp(stream: Stream, feats: np.ndarray, depth: int, width: int, skip: int) -> np.ndarray:
+def mlp(stream: Stream, feats: np.ndarray, depth: int, width: int, skip: int, prec=None) -> np.ndarray:
   in0 = linear_chunks(feats, -(-feats.shape[1] // 16))
   x = None
   for l in range(depth):
     if l == 0:
-      x = dense(stream, [in0], width // 32, True)
+      x = dense(stream, [in0], width // 32, True, [prec])
     elif l == skip:
-      x = dense(stream, [x, in0], width // 32, True)
+      x = dense(stream, [x, in0], width // 32, True, [prec, prec])
     else:
-      x = dense(stream, [x], width // 32, True)
+      x = dense(stream, [x], width // 32, True, [prec])
   return x
