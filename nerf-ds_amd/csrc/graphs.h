@@ -28,6 +28,12 @@ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 // The kernel stages the stream through LDS in 16 KiB stages; each of the two streams is zero-padded to a
 // whole number of stages so that a stage never straddles the shared -> NerfMLP seam.
 constexpr int STAGE_BYTES = 16384;
+// Output tiles of a hidden layer are computed TILE_PAIR at a time: within a pair the stream holds, chunk by chunk, one
+// fragment of each tile, so that consecutive MFMAs of a wave go to different accumulators (render_kernel.hip accum).
+#ifndef NERFDS_TILE_PAIR
+#define NERFDS_TILE_PAIR 2
+#endif
+constexpr int TILE_PAIR = NERFDS_TILE_PAIR;
 constexpr int STAGE_UNITS = STAGE_BYTES / 1024;
 constexpr int pad_units(int n) { return cdiv(n, STAGE_UNITS) * STAGE_UNITS; }
 constexpr int chunks(int feats) { return cdiv(feats, 16); }   // k16 chunks needed for `feats` linear features

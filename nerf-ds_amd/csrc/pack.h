@@ -91,49 +91,57 @@ struct StreamWriter {
   float* b;
   size_t wbytes = 0, bfloats = 0;
 
-  void emit(const Layer& L) {
-    for (int ot = 0; ot < L.n_tiles; ++ot) {
-      for (const Seg& S : L.segs) {
-        const int kc_n = (int)S.rows.size() / 16, prec = S.prec;
-        for (int kc = 0; kc < kc_n; ++kc) {
-          if (w) {
-            uint8_t* frag = w + wbytes;
-            for (int lane = 0; lane < 64; ++lane) {
-              const int m = lane & 31, h = lane >> 5;
-              int col = L.is_head ? head_col(m) : 32 * ot + m;
-              if (col >= L.n_out) col = -1;
-              float v[8];
-              for (int i = 0; i < 8; ++i) {
-                const int r = S.rows[kc * 16 + h * 8 + i];
-                v[i] = (r < 0 || col < 0) ? 0.f : L.W(r, col);
-              }
-              if (prec == P_BF16 || prec == P_F16) {
-                uint16_t* d = reinterpret_cast<uint16_t*>(frag + lane * 16);
-                for (int i = 0; i < 8; ++i) d[i] = prec == P_BF16 ? f32_to_bf16_rne(v[i]) : f32_to_f16_rne(v[i]);
-              } else if (prec == P_BF16X3) {
-                uint16_t* dh = reinterpret_cast<uint16_t*>(frag + lane * 16);
-                uint16_t* dl = reinterpret_cast<uint16_t*>(frag + 1024 + lane * 16);
-                for (int i = 0; i < 8; ++i) {
-                  dh[i] = f32_to_bf16_rne(v[i]);
-                  dl[i] = f32_to_bf16_rne(v[i] - bf16_to_f32(dh[i]));
-                }
-              } else {
-                float* da = reinterpret_cast<float*>(frag + lane * 16);
-                float* db = reinterpret_cast<float*>(frag + 1024 + lane * 16);
-                for (int i = 0; i < 4; ++i) { da[i] = v[i]; db[i] = v[4 + i]; }
-              }
-            }
-          }
-          wbytes += frag_bytes(prec);
+  void frag_out(const Layer& L, const Seg& S, int ot, int kc) {
+    const int prec = S.prec;
+    if (w) {
+      uint8_t* frag = w + wbytes;
+      for (int lane = 0; lane < 64; ++lane) {
+        const int m = lane & 31, h = lane >> 5;
+        int col = L.is_head ? head_col(m) : 32 * ot + m;
+        if (col >= L.n_out) col = -1;
+        float v[8];
+        for (int i = 0; i < 8; ++i) {
+          const int r = S.rows[kc * 16 + h * 8 + i];
+          v[i] = (r < 0 || col < 0) ? 0.f : L.W(r, col);
         }
+        if (prec == P_BF16 || prec == P_F16) {
+          uint16_t* d = reinterpret_cast<uint16_t*>(frag + lane * 16);
+          for (int i = 0; i < 8; ++i) d[i] = prec == P_BF16 ? f32_to_bf16_rne(v[i]) : f32_to_f16_rne(v[i]);
+        } else if (prec == P_BF16X3) {
+          uint16_t* dh = reinterpret_cast<uint16_t*>(frag + lane * 16);
+          uint16_t* dl = reinterpret_cast<uint16_t*>(frag + 1024 + lane * 16);
+          for (int i = 0; i < 8; ++i) {
+            dh[i] = f32_to_bf16_rne(v[i]);
+            dl[i] = f32_to_bf16_rne(v[i] - bf16_to_f32(dh[i]));
+          }
+        } else {
+          float* da = reinterpret_cast<float*>(frag + lane * 16);
+          float* db = reinterpret_cast<float*>(frag + 1024 + lane * 16);
+          for (int i = 0; i < 4; ++i) { da[i] = v[i]; db[i] = v[4 + i]; }
+        }
+      }
+    }
+    wbytes += frag_bytes(prec);
+  }
+
+  // Stream order of a layer: tiles in groups of TILE_PAIR (heads: one tile); within a group, segment by segment and
+  // chunk by chunk, one fragment per tile of the group - the order render_kernel.hip's accum consumes them in.
+  void emit(const Layer& L) {
+    const int tp = (L.n_tiles % TILE_PAIR == 0) ? TILE_PAIR : 1;
+    for (int ot = 0; ot < L.n_tiles; ot += tp) {
+      for (const Seg& S : L.segs) {
+        const int kc_n = (int)S.rows.size() / 16;
+        for (int kc = 0; kc < kc_n; ++kc)
+          for (int t = 0; t < tp; ++t) frag_out(L, S, ot + t, kc);
       }
       if (b) {
-        for (int m = 0; m < 32; ++m) {
-          int col = L.is_head ? head_col(m) : 32 * ot + m;
-          b[bfloats + m] = (col < L.n_out) ? L.B(col) : 0.f;
-        }
+        for (int t = 0; t < tp; ++t)
+          for (int m = 0; m < 32; ++m) {
+            int col = L.is_head ? head_col(m) : 32 * (ot + t) + m;
+            b[bfloats + 32 * t + m] = (col < L.n_out) ? L.B(col) : 0.f;
+          }
       }
-      bfloats += 32;
+      bfloats += 32 * tp;
     }
   }
 };

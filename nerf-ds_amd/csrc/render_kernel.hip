@@ -144,12 +144,18 @@ template <int P> DEVI void mma(f32x16& acc, const WFrag<P>& w, const Chunk<P>& c
 // units in flight LDS -> VGPR: consuming unit u issues the read of unit u + RD, whatever fragments those units belong
 // to.  Every index is a compile-time constant after unrolling.
 // ------------------------------------------------------------------------------------------------
+// NERFDS_NT = 2 (one-unit trunks only): two N-tiles per wave, i.e. every weight fragment read from LDS feeds two
+// MFMAs; the activations of the 256-wide trunk then need 256 registers, so one 512-register wave per SIMD.
+#ifndef NERFDS_NT
+#define NERFDS_NT 1
+#endif
 template <int PM, int PW, int PH, int PT, int PR> struct PlanT {
   static constexpr int MASK = PM, WARP = PW, HYP = PH, TRUNK = PT, RGB = PR;
   static constexpr Plan value() { return Plan{PM, PW, PH, PT, PR}; }
-  // 8 waves (two per SIMD, 256 registers each) when the 256-wide trunk runs on one-unit operands; a trunk on two-unit
-  // operands needs > 256 registers of activations: one 512-register wave per SIMD.
-  static constexpr bool EIGHT_WAVES = is_single(PT);
+  static constexpr int NT = is_single(PT) ? NERFDS_NT : 1;
+  // 8 waves (two per SIMD, 256 registers each) when the 256-wide trunk runs on one-unit operands with one N-tile; a
+  // trunk on two-unit operands (or two N-tiles) needs > 256 registers of activations: one 512-register wave per SIMD.
+  static constexpr bool EIGHT_WAVES = is_single(PT) && NT == 1;
 };
 // STAGE_BYTES (graphs.h): one ring stage = 16 units
 constexpr int NUM_STAGES = 4;          // ring depth
@@ -160,12 +166,13 @@ constexpr int RING_BYTES = NUM_STAGES * STAGE_BYTES;
 //   WIDE (Nc + Nf > 128, e.g. 128 + 128): half as many rays per workgroup, twice the waves per ray and a 256-sample
 //         LDS block per ray, so the LDS footprint is unchanged.
 template <class PL, bool WIDE> struct Shape {
-  static constexpr int NT = 1, SPLIT = (PL::EIGHT_WAVES ? 2 : 1) * (WIDE ? 2 : 1), RAYS = WIDE ? 2 : 4, MAXS = WIDE ? 256 : 128;
+  static constexpr int NT = PL::NT, SPLIT = (PL::EIGHT_WAVES ? 2 : 1) * (WIDE ? 2 : 1), RAYS = WIDE ? 2 : 4, MAXS = WIDE ? 256 : 128;
 };
 template <class PL> constexpr int wg_waves() { return Shape<PL, false>::RAYS * Shape<PL, false>::SPLIT; }
 // LDS map: [0, RING_BYTES) weight ring | padded fp32 biases (shared, coarse NerfMLP, fine NerfMLP) | RAYS x WaveLds
 constexpr int BIAS_OFF = RING_BYTES;
-template <class G> constexpr int bias_bytes() { return (Dims<G>::SHARED_BIAS_TILES + 2 * Dims<G>::NERF_BIAS_TILES) * 128; }
+template <class G> constexpr int bias_tiles() { return Dims<G>::SHARED_BIAS_TILES + 2 * Dims<G>::NERF_BIAS_TILES; }
+template <class G> constexpr int bias_bytes() { return cdiv(bias_tiles<G>(), 8) * 1024; }
 
 #ifndef NERFDS_RING_UNITS
 #define NERFDS_RING_UNITS 4
@@ -217,9 +224,15 @@ template <class G, class PL> struct Pipe {
     // A COUNTED vmcnt(N) is NOT safe here: on gfx9-family VM_CNT, loads and stores complete out of order with respect
     // to each other, so a younger store (ray-record store, register spill) retiring early lets the count drop below N
     // while an older LDS-DMA is still in flight -> stale weights (seen as 2e-2 errors on the fine level).
-    // lgkmcnt(0): this wave's reads of stage s - 1 have returned before its slot is overwritten.
+    // No lgkmcnt wait: the slot that is refilled belongs to stage s - 1, whose last unit this wave has already fed to
+    // an MFMA (DS returns in order, so every older read of that stage has returned as well); what is still in flight
+    // LDS -> VGPR are units of stage s, and draining them here would expose one full LDS latency per stage.
     static_assert(NS == 4, "protocol is written for a 4-stage ring");
+#ifdef NERFDS_BOUNDARY_LGKM
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     if (!(NERFDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();      // raw barrier (no compiler-added fences)
     if (NERFDS_DBG & 2) __builtin_amdgcn_s_sleep(4);
     issue_stage(s + NS - 1);
@@ -269,45 +282,62 @@ template <class G, class PL> struct Pipe {
 
 struct Cursor {
   int pos;      // stream position (unit index) of the next fragment
-  int boff;     // LDS byte offset of the next bias tile
+  int bt;       // index of the next bias tile (0 = first tile of the shared nets)
 };
 
-// Bias of a tile for this lane, as an MFMA C operand: register r <-> row (r & 3) + 8 (r >> 2) + 4 h.
-DEVI f32x16 load_bias(int boff, int h) {
-  f32x16 bv;
-  // 16 * h, recomputed from the lane id at every use (4 VALU): as a loop-invariant value it is the first thing the
-  // register allocator spills, and its reload (scratch_load + vmcnt(0)) then also waits for the LDS-DMA in flight.
-  // Being opaque, it also gives each accumulator its own ds_read_b128 x4 (no CSE -> no register copies).
-  int hoff = 16 * h;
+// LDS image of the biases: tile t, lane half h, accumulator register r <-> row (r & 3) + 8 (r >> 2) + 4 h of the tile at
+// byte BIAS_OFF + (t >> 3) * 1024 + (t & 7) * 64 + 512 * h + 4 * r: the 16 values of a lane are one 64-byte run, the
+// half is selected by ONE per-lane address bit (lane16 & 512), everything else is an immediate offset.
+constexpr int bias_tile_off(int t) { return (t >> 3) * 1024 + (t & 7) * 64; }
+constexpr int bias_lds_bytes(int tiles) { return cdiv(tiles, 8) * 1024; }
+// Per-lane base of the bias reads: BIAS_OFF + 512 * (lane >> 5).  Recomputed (2 VALU) at the start of every layer and
+// opaque to the compiler: as a kernel-lifetime value it is the first thing the register allocator spills, and its
+// reload (scratch_load + vmcnt(0)) then also waits for the LDS-DMA in flight.
+DEVI int bias_base(int lane16) {
+  int hb = lane16;
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_and_b32 %0, 32, %0\n\tv_lshrrev_b32 %0, 1, %0" : "=v"(hoff));
+  asm volatile("v_and_b32 %0, 0x200, %0\n\tv_add_u32 %0, %1, %0" : "+v"(hb) : "s"(BIAS_OFF));
+#else
+  hb = (lane16 & 512) + BIAS_OFF;
 #endif
+  return hb;
+}
+// Bias of tile t for this lane, as an MFMA C operand.
+DEVI f32x16 load_bias(int t, int hb) {
+  f32x16 bv;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(g_smem + boff + 32 * g + hoff);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(g_smem + hb + bias_tile_off(t) + 16 * g);
     bv[4 * g + 0] = b[0]; bv[4 * g + 1] = b[1]; bv[4 * g + 2] = b[2]; bv[4 * g + 3] = b[3];
   }
   return bv;
 }
 
-// One input segment (K k16-chunks of precision P) of an output tile: K fragments from the stream.
-template <class G, class PL, int NT, int P, int K>
-DEVI void accum(f32x16 (&acc)[NT], Pipe<G, PL>& pipe, Cursor& cur, const Chunk<P> (&in)[NT][K]) {
+// TP output tiles at once over one input segment (K k16-chunks of precision P): for every chunk, one fragment per tile
+// from the stream, each feeding its own accumulator.  TP = 2 is the point: consecutive MFMAs of a wave then never hit
+// the same accumulator, and anything issued between two MFMAs on the SAME accumulator (here: the LDS reads of the
+// weight ring and their waits) costs ~43 cycles on gfx950 instead of its issue slot (MI355X_MICROARCH.md, cycle
+// constants).  The B operand (activation chunk) is shared by the TP MFMAs.
+template <class G, class PL, int NT, int TP, int P, int K>
+DEVI void accum(f32x16 (&acc)[TP][NT], Pipe<G, PL>& pipe, Cursor& cur, const Chunk<P> (&in)[NT][K]) {
   using PP = Pipe<G, PL>;
   constexpr int NP = frag_parts(P);
 #pragma unroll
   for (int kc = 0; kc < K; ++kc) {
-    const int u = cur.pos;
-    // First fragment that touches a new stage (a two-unit fragment may straddle: its first unit is in the register
-    // ring already, and so is every other unit of the stage that is being retired - the ring runs RD units ahead).
-    if (u % PP::SU == 0) pipe.begin_stage(u);
-    else if (NP == 2 && (u + 1) % PP::SU == 0) pipe.begin_stage(u + 1);
-    const WFrag<P> w = pipe.template frag<P>(u);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) mma<P>(acc[nt], w, in[nt][kc]);
+    for (int tp = 0; tp < TP; ++tp) {
+      const int u = cur.pos;
+      // First fragment that touches a new stage (a two-unit fragment may straddle: its first unit is in the register
+      // ring already, and so is every other unit of the stage that is being retired - the ring runs RD units ahead).
+      if (u % PP::SU == 0) pipe.begin_stage(u);
+      else if (NP == 2 && (u + 1) % PP::SU == 0) pipe.begin_stage(u + 1);
+      const WFrag<P> w = pipe.template frag<P>(u);
 #pragma unroll
-    for (int q = 0; q < NP; ++q) pipe.refill(u + q);
-    cur.pos += NP;
+      for (int nt = 0; nt < NT; ++nt) mma<P>(acc[tp][nt], w, in[nt][kc]);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) pipe.refill(u + q);
+      cur.pos += NP;
+    }
   }
 }
 
@@ -328,34 +358,89 @@ DEVI void tile_epilogue(Chunk<P> (&out)[NT][W], int ot, const f32x16 (&acc)[NT])
   }
 }
 
-// One dense layer with OT output tiles of 32 features; inputs are one or more chunk arrays in stream order (each in
-// its own precision), the output chunks are produced in the precision PO of the tensor they form.
-// The accumulators start from the bias (the first MFMA of a tile reads the bias registers as its C operand); the
-// bias of tile t + 1 is fetched from LDS before the MFMA chain of tile t.
-template <class G, class PL, int NT, int OT, bool RELU, int PO, class... Ins>
-DEVI void dense(Pipe<G, PL>& pipe, Cursor& cur, int h, Chunk<PO> (&out)[NT][2 * OT], const Ins&... ins) {
-  f32x16 acc[OT][NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) acc[0][nt] = load_bias(cur.boff, h);
-#pragma unroll
-  for (int ot = 0; ot < OT; ++ot) {
-    if (ot + 1 < OT) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[ot + 1][nt] = load_bias(cur.boff + 128 * (ot + 1), h);
-    }
-    (accum<G, PL, NT>(acc[ot], pipe, cur, ins), ...);
-    tile_epilogue<PO, NT, RELU>(out, ot, acc[ot]);
+// ReLU + conversion of one tile for the one-unit operand formats, as ONE asm block: convert pairs first
+// (v_cvt_pk_{bf16,f16}_f32), then ReLU on the packed pairs (v_pk_max_i16 with 0: a negative half has its sign bit
+// set) - 16 VALU per tile where the source form (v_max on fp32, then convert) needs 24, and hipcc un-pairs the
+// conversions when the packed max is written in C++.  hipcc does not pad the MFMA -> VALU hazard for an asm that
+// reads accumulators (checked in the ISA), so the block opens with the 12 wait states itself when `wait` is set (the
+// first block of a tile group; dense() pins the last MFMA of every accumulator of the group above it, so the later
+// blocks are covered by the first one's instructions).
+#ifndef NERFDS_ASM_EPILOGUE
+#define NERFDS_ASM_EPILOGUE 1
+#endif
+template <int P> DEVI void tile_epilogue_asm(Chunk<P>& c0, Chunk<P>& c1, const f32x16& a, bool wait) {
+  static_assert(is_single(P), "packed-half epilogue");
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned o0, o1, o2, o3, o4, o5, o6, o7;
+#define NERFDS_EPI_BODY(CVT)                                                                                              \
+  CVT " %0, %8, %9\n\t" CVT " %1, %10, %11\n\t" CVT " %2, %12, %13\n\t" CVT " %3, %14, %15\n\t"                            \
+  CVT " %4, %16, %17\n\t" CVT " %5, %18, %19\n\t" CVT " %6, %20, %21\n\t" CVT " %7, %22, %23\n\t"                          \
+  "v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0\n\tv_pk_max_i16 %2, %2, 0\n\tv_pk_max_i16 %3, %3, 0\n\t"              \
+  "v_pk_max_i16 %4, %4, 0\n\tv_pk_max_i16 %5, %5, 0\n\tv_pk_max_i16 %6, %6, 0\n\tv_pk_max_i16 %7, %7, 0"
+#define NERFDS_EPI_OPS                                                                                                    \
+  : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4), "=&v"(o5), "=&v"(o6), "=&v"(o7)                                \
+  : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),          \
+    "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15])
+  if constexpr (P == P_BF16) {
+    if (wait) asm volatile("s_nop 11\n\t" NERFDS_EPI_BODY("v_cvt_pk_bf16_f32") NERFDS_EPI_OPS);
+    else asm volatile(NERFDS_EPI_BODY("v_cvt_pk_bf16_f32") NERFDS_EPI_OPS);
+  } else {
+    if (wait) asm volatile("s_nop 11\n\t" NERFDS_EPI_BODY("v_cvt_pk_f16_f32") NERFDS_EPI_OPS);
+    else asm volatile(NERFDS_EPI_BODY("v_cvt_pk_f16_f32") NERFDS_EPI_OPS);
   }
-  cur.boff += 128 * OT;
+#undef NERFDS_EPI_BODY
+#undef NERFDS_EPI_OPS
+  const u32x4 r0 = {o0, o1, o2, o3}, r1 = {o4, o5, o6, o7};
+  c0.v = __builtin_bit_cast(decltype(c0.v), r0);
+  c1.v = __builtin_bit_cast(decltype(c1.v), r1);
+#endif
+}
+
+// One dense layer with OT output tiles of 32 features, computed TILE_PAIR tiles at a time (the stream interleaves the
+// fragments of the tiles of a pair chunk by chunk, pack.h); inputs are one or more chunk arrays in stream order (each
+// in its own precision), the output chunks are produced in the precision PO of the tensor they form.
+// The accumulators start from the bias (the first MFMA of a tile reads the bias registers as its C operand).
+template <class G, class PL, int NT, int OT, bool RELU, int PO, class... Ins>
+DEVI void dense(Pipe<G, PL>& pipe, Cursor& cur, Chunk<PO> (&out)[NT][2 * OT], const Ins&... ins) {
+  constexpr int TP = TILE_PAIR;
+  static_assert(OT % TP == 0, "layers have an even number of 32-feature tiles");
+  const int hb = bias_base(pipe.lane16);
+#pragma unroll
+  for (int ot = 0; ot < OT; ot += TP) {
+    f32x16 acc[TP][NT];
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[tp][nt] = load_bias(cur.bt + ot + tp, hb);
+    (accum<G, PL, NT, TP>(acc, pipe, cur, ins), ...);
+    if constexpr (NERFDS_ASM_EPILOGUE && !(NERFDS_ABLATE & 4) && is_single(PO) && RELU) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(acc[tp][nt]));     // every chain of the group ends above the epilogue blocks
+#endif
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          tile_epilogue_asm<PO>(out[nt][2 * (ot + tp)], out[nt][2 * (ot + tp) + 1], acc[tp][nt], tp == 0 && nt == 0);
+    } else {
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) tile_epilogue<PO, NT, RELU>(out, ot + tp, acc[tp]);
+    }
+  }
+  cur.bt += OT;
 }
 
 // Output head (<= 16 logical outputs, duplicated in both lane halves by the packer): logical output j = acc[j].
 template <class G, class PL, int NT, class... Ins>
-DEVI void head(Pipe<G, PL>& pipe, Cursor& cur, int h, f32x16 (&acc)[NT], const Ins&... ins) {
+DEVI void head(Pipe<G, PL>& pipe, Cursor& cur, f32x16 (&acc)[1][NT], const Ins&... ins) {
+  const int hb = bias_base(pipe.lane16);
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) acc[nt] = load_bias(cur.boff, h);
-  (accum<G, PL, NT>(acc, pipe, cur, ins), ...);
-  cur.boff += 128;
+  for (int nt = 0; nt < NT; ++nt) acc[0][nt] = load_bias(cur.bt, hb);
+  (accum<G, PL, NT, 1>(acc, pipe, cur, ins), ...);
+  cur.bt += 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -546,7 +631,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
     }
   }
 
-  Cursor cur{0, BIAS_OFF};
+  Cursor cur{0, 0};
 
   // ---- MaskMLP (modules.py:409-434; models.py:967-975) ----
   float maskv[NT];
@@ -563,19 +648,19 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
         return zero_feat();
       });
     static_assert(G::MASK_DEPTH == 8 || !G::HAS_MASK, "mask net is unrolled for depth 8, skip 4");
-    dense<G, PL, NT, W32, true>(pipe, cur, h, a, in0);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b, in0);      // skip: [x, inputs] (modules.py:66-67)
-    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
-    f32x16 hacc[NT];
-    head<G, PL, NT>(pipe, cur, h, hacc, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, a, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, a, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, a, b, in0);      // skip: [x, inputs] (modules.py:66-67)
+    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, a, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
+    f32x16 hacc[1][NT];
+    head<G, PL, NT>(pipe, cur, hacc, b);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const float pm = fmaxf(hacc[nt][0], 0.f);                              // MaskMLP.output_activation = relu
+      const float pm = fmaxf(hacc[0][nt][0], 0.f);                              // MaskMLP.output_activation = relu
       maskv[nt] = pm * ka.mask_ratio + rc.gt_mask * (1.0f - ka.mask_ratio);  // models.py:975
       L.sv[SV_MASK][slot_of(nt)] = pm;
     }
@@ -599,18 +684,18 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
         return zero_feat();
       });
     static_assert(G::WARP_DEPTH == 6 || !G::HAS_WARP, "warp trunk is unrolled for depth 6, skip 4");
-    dense<G, PL, NT, W32, true>(pipe, cur, h, a, in0);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b, in0);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
-    f32x16 hacc[NT];
-    head<G, PL, NT>(pipe, cur, h, hacc, b);      // logical outputs: w = 0..2, v = 3..5
+    dense<G, PL, NT, W32, true>(pipe, cur, a, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, a, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, a, b, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
+    f32x16 hacc[1][NT];
+    head<G, PL, NT>(pipe, cur, hacc, b);      // logical outputs: w = 0..2, v = 3..5
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      float w[3] = {hacc[nt][0], hacc[nt][1], hacc[nt][2]};
-      float v0 = hacc[nt][3], v1 = hacc[nt][4], v2 = hacc[nt][5];
+      float w[3] = {hacc[0][nt][0], hacc[0][nt][1], hacc[0][nt][2]};
+      float v0 = hacc[0][nt][3], v1 = hacc[0][nt][4], v2 = hacc[0][nt][5];
       const float theta = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);     // warping.py:219 (no epsilon, as the reference)
       w[0] /= theta; w[1] /= theta; w[2] /= theta;
       v0 /= theta; v1 /= theta; v2 /= theta;
@@ -683,16 +768,16 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
         return zero_feat();
       });
     static_assert(G::HYP_DEPTH == 6 || !G::HAS_HYPER, "hyper sheet is unrolled for depth 6, skip 4");
-    dense<G, PL, NT, W32, true>(pipe, cur, h, a, in0);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, a, b, in0);
-    dense<G, PL, NT, W32, true>(pipe, cur, h, b, a);
-    f32x16 hacc[NT];
-    head<G, PL, NT>(pipe, cur, h, hacc, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, a, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, a, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, a, b, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
+    f32x16 hacc[1][NT];
+    head<G, PL, NT>(pipe, cur, hacc, b);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { wamb[nt][0] = hacc[nt][0]; wamb[nt][1] = hacc[nt][1]; }
+    for (int nt = 0; nt < NT; ++nt) { wamb[nt][0] = hacc[0][nt][0]; wamb[nt][1] = hacc[0][nt][1]; }
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
@@ -703,7 +788,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
 
   // ---- NerfMLP of this level (modules.py:243-313; models.py:1043-1047, 1268-1270) ----
   cur.pos = Pipe<G, PL>::SHARED_PAD;    // skip the zero padding of the shared stream
-  cur.boff = BIAS_OFF + (D::SHARED_BIAS_TILES + level * D::NERF_BIAS_TILES) * 128;
+  cur.bt = D::SHARED_BIAS_TILES + level * D::NERF_BIAS_TILES;
   constexpr int TW16 = G::TRUNK_W / 16, TW32 = G::TRUNK_W / 32;
   {
     constexpr int P = PL::TRUNK, PR = PL::RGB;
@@ -718,26 +803,26 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
         return zero_feat();
       });
     static_assert(G::TRUNK_DEPTH == 8 && G::TRUNK_SKIP == 4, "trunk is unrolled for depth 8, skip 4");
-    dense<G, PL, NT, TW32, true>(pipe, cur, h, a, in0);
-    dense<G, PL, NT, TW32, true>(pipe, cur, h, b, a);
-    dense<G, PL, NT, TW32, true>(pipe, cur, h, a, b);
-    dense<G, PL, NT, TW32, true>(pipe, cur, h, b, a);
-    dense<G, PL, NT, TW32, true>(pipe, cur, h, a, b, in0);
-    dense<G, PL, NT, TW32, true>(pipe, cur, h, b, a);
-    dense<G, PL, NT, TW32, true>(pipe, cur, h, a, b);
-    dense<G, PL, NT, TW32, true>(pipe, cur, h, b, a);          // b = trunk_output
+    dense<G, PL, NT, TW32, true>(pipe, cur, a, in0);
+    dense<G, PL, NT, TW32, true>(pipe, cur, b, a);
+    dense<G, PL, NT, TW32, true>(pipe, cur, a, b);
+    dense<G, PL, NT, TW32, true>(pipe, cur, b, a);
+    dense<G, PL, NT, TW32, true>(pipe, cur, a, b, in0);
+    dense<G, PL, NT, TW32, true>(pipe, cur, b, a);
+    dense<G, PL, NT, TW32, true>(pipe, cur, a, b);
+    dense<G, PL, NT, TW32, true>(pipe, cur, b, a);          // b = trunk_output
     // (the activation-free bottleneck Dense, modules.py:255, is folded into rgb hidden_0 by the packer)
-    f32x16 hacc[NT];
-    head<G, PL, NT>(pipe, cur, h, hacc, b);                    // alpha_mlp on trunk_output (modules.py:273-274)
+    f32x16 hacc[1][NT];
+    head<G, PL, NT>(pipe, cur, hacc, b);                    // alpha_mlp on trunk_output (modules.py:273-274)
     // rgb condition chunks: [posenc(viewdir) | posenc(normal in observation frame)]
     Chunk<PR> cond[NT][D::COND_KC];
     WAVE_SYNC();                                              // parked SE3 state was written by the h == 0 lanes
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float nin[3] = {0.f, 0.f, 0.f};
-      L.sv[SV_SIGMA][slot_of(nt)] = softplus_f(hacc[nt][0]);                    // models.py:577
+      L.sv[SV_SIGMA][slot_of(nt)] = softplus_f(hacc[0][nt][0]);                    // models.py:577
       if constexpr (G::PREDICT_NORM) {
-        float n[3] = {hacc[nt][1], hacc[nt][2], hacc[nt][3]};
+        float n[3] = {hacc[0][nt][1], hacc[0][nt][2], hacc[0][nt][3]};
         {
 #pragma unroll
           for (int c = 0; c < 3; ++c) L.sv[SV_NORM + c][slot_of(nt)] = n[c];
@@ -770,15 +855,15 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
       });
     }
     Chunk<PR> c[NT][G::RGB_W / 16];
-    dense<G, PL, NT, G::RGB_W / 32, true>(pipe, cur, h, c, b, cond);       // K order [trunk_output | cond]
-    head<G, PL, NT>(pipe, cur, h, hacc, c);
+    dense<G, PL, NT, G::RGB_W / 32, true>(pipe, cur, c, b, cond);       // K order [trunk_output | cond]
+    head<G, PL, NT>(pipe, cur, hacc, c);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       {
         const int s = slot_of(nt);
-        L.sv[SV_RGB + 0][s] = sigmoid_f(hacc[nt][0]);                       // models.py:576
-        L.sv[SV_RGB + 1][s] = sigmoid_f(hacc[nt][1]);
-        L.sv[SV_RGB + 2][s] = sigmoid_f(hacc[nt][2]);
+        L.sv[SV_RGB + 0][s] = sigmoid_f(hacc[0][nt][0]);                       // models.py:576
+        L.sv[SV_RGB + 1][s] = sigmoid_f(hacc[0][nt][1]);
+        L.sv[SV_RGB + 2][s] = sigmoid_f(hacc[0][nt][2]);
       }
   }
   pipe.finish_eval();
@@ -979,8 +1064,8 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
   // barrier sequence, so these interleave consistently with the per-stage barriers of the weight pipe).
   auto ray_sync = [&]() { if constexpr (SPLIT > 1) __syncthreads(); else WAVE_SYNC(); };
 
-#ifdef NERFDS_SETPRIO
-  if (q == NERFDS_SETPRIO - 1) __builtin_amdgcn_s_setprio(1);
+#ifdef NERFDS_SETPRIO_HALF      // static priority for the second-dispatched half of an 8-wave workgroup (cdna guide T5, static form)
+  if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(NERFDS_SETPRIO_HALF);
 #endif
   if (NERFDS_DBG & 1) {
     constexpr int total = BIAS_OFF + bias_bytes<G>() + RAYS_PER_WG * (int)sizeof(WaveLds);
@@ -999,12 +1084,14 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
     pipe.wn = level ? rs_nerf[1] : rs_nerf[0];
     pipe.wn_next = next_level ? rs_nerf[1] : rs_nerf[0];
   };
-  {  // padded biases -> LDS, once per workgroup
-    f32x4* dst = reinterpret_cast<f32x4*>(g_smem + BIAS_OFF);
-    constexpr int n0 = Dm::SHARED_BIAS_TILES * 8, n1 = Dm::NERF_BIAS_TILES * 8;     // float4 counts
-    for (int i = threadIdx.x; i < n0; i += 64 * WAVES) dst[i] = reinterpret_cast<const f32x4*>(ka.bias[0])[i];
-    for (int i = threadIdx.x; i < n1; i += 64 * WAVES) dst[n0 + i] = reinterpret_cast<const f32x4*>(ka.bias[1])[i];
-    for (int i = threadIdx.x; i < n1; i += 64 * WAVES) dst[n0 + n1 + i] = reinterpret_cast<const f32x4*>(ka.bias[2])[i];
+  {  // padded biases ([tile][32 rows] from the packer) -> LDS in the bias_tile_off layout, once per workgroup
+    constexpr int n0 = Dm::SHARED_BIAS_TILES * 32, n1 = Dm::NERF_BIAS_TILES * 32;     // float counts
+    float* dst = reinterpret_cast<float*>(g_smem + BIAS_OFF);
+    for (int i = threadIdx.x; i < n0 + 2 * n1; i += 64 * WAVES) {
+      const float v = i < n0 ? ka.bias[0][i] : (i < n0 + n1 ? ka.bias[1][i - n0] : ka.bias[2][i - n0 - n1]);
+      const int t = i >> 5, m = i & 31;                      // row m = (r & 3) + 8 (r >> 2) + 4 h  ->  h = (m >> 2) & 1, r = (m & 3) + 4 (m >> 3)
+      dst[bias_tile_off(t) / 4 + 128 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)] = v;
+    }
     __syncthreads();
   }
 

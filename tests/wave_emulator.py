@@ -4,6 +4,9 @@ It restates, independently of the C++ packer, the conventions of the device code
   * fragment = [32 rows m] x [16 k-slots (h, i)], lane = (h << 5) | m; the stream is a sequence of 1-KiB units: a bf16 / f16
     fragment is one unit, a split-bf16 fragment two (hi, lo), an fp32 fragment two (slots i<4, slots i>=4), back to
     back without alignment, so networks of different precision can follow each other in one stream (csrc/graphs.h Plan);
+  * the output tiles of a hidden layer come TILE_PAIR = 2 at a time: within a pair the stream holds, segment by segment
+    and chunk by chunk, one fragment of each tile (consecutive MFMAs of a wave go to different accumulators); heads
+    are single tiles;
   * an output tile's accumulator register r of lane half h is row (r & 3) + 8 (r >> 2) + 4 h, and registers
     8c .. 8c+7 become k-slots (h, 0..7) of activation chunk 2*tile + c of the next layer;
   * linear input chunks: slot (c, h, i) <-> feature 16 c + 8 h + i;
@@ -73,26 +76,35 @@ def tile_to_chunks(acc: np.ndarray) -> np.ndarray:
   return out
 
 
-def mma_tile(stream: Stream, inputs, precs=None) -> np.ndarray:
-  """One output tile: sum over all chunks of all input arrays, in stream order; + bias.  Returns [32, N].
-  precs: per input array, the precision of its weight fragments (default: the stream's)."""
-  acc = None
-  bias = stream.next_bias()
+TILE_PAIR = 2
+
+
+def mma_tiles(stream: Stream, inputs, precs=None, tp: int = 1):
+  """tp output tiles at once: for every chunk of every input array (stream order), one fragment per tile; + bias.
+  Returns tp arrays [32, N].  precs: per input array, the precision of its weight fragments (default: the stream's)."""
+  acc = [None] * tp
+  bias = [stream.next_bias() for _ in range(tp)]
   for j, chunks in enumerate(inputs):
     for kc in range(chunks.shape[0]):
-      A = stream.next_frag(precs[j] if precs else None)
-      part = np.einsum('mhi,hin->mn', A, chunks[kc])
-      acc = part if acc is None else acc + part
-  return acc + bias[:, None]
+      for t in range(tp):
+        A = stream.next_frag(precs[j] if precs else None)
+        part = np.einsum('mhi,hin->mn', A, chunks[kc])
+        acc[t] = part if acc[t] is None else acc[t] + part
+  return [a + b[:, None] for a, b in zip(acc, bias)]
+
+
+def mma_tile(stream: Stream, inputs, precs=None) -> np.ndarray:
+  return mma_tiles(stream, inputs, precs, 1)[0]
 
 
 def dense(stream: Stream, inputs, n_tiles: int, relu: bool, precs=None) -> np.ndarray:
   outs = []
-  for _ in range(n_tiles):
-    acc = mma_tile(stream, inputs, precs)
-    if relu:
-      acc = np.maximum(acc, 0.0)
-    outs.append(tile_to_chunks(acc))
+  assert n_tiles % TILE_PAIR == 0
+  for _ in range(n_tiles // TILE_PAIR):
+    for acc in mma_tiles(stream, inputs, precs, TILE_PAIR):
+      if relu:
+        acc = np.maximum(acc, 0.0)
+      outs.append(tile_to_chunks(acc))
   return np.concatenate(outs, axis=0)
 
 
