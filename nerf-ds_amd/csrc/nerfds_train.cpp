@@ -6,7 +6,6 @@
 // after the other through the same workspace: their losses are independent sums and the fine z samples carry a
 // stop_gradient (model_utils.py:241), so no gradient crosses from the fine level into the coarse one.
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
 
 #include <algorithm>
 #include <cmath>
@@ -62,7 +61,6 @@ struct nerfds_trainer {
   int64_t warp_tbl = -1, mask_tbl = -1;
   float *theta = nullptr, *grad = nullptr, *m1 = nullptr, *m2 = nullptr;
   int64_t adam_t = 0;
-  rocblas_handle blas = nullptr;
   float* ws = nullptr;      // one workspace allocation
   size_t ws_floats = 0;
   float* loss_dev = nullptr;
@@ -74,8 +72,6 @@ struct nerfds_trainer {
   float *d_t_alpha, *d_t_tin, *d_t_xw, *d_t_wamb, *d_t_wv, *du, *ghat, *dwamb_extra, *dwv_extra;
   bool tn_valid = false;
   bool keep_tangents = false;
-  float* part = nullptr;    // split-K partials of the weight-gradient GEMMs
-  size_t part_floats = 0;
   void* wpack = nullptr;    // MFMA fragments of the layer being run (train_gemm.hip)
   // Gradient replicas: the MFMA kernels end with float atomics from every workgroup at once; on one copy of a small leaf they queue
   // up per address (40-60 us per kernel).  Workgroup b adds into replica b % GRAD_REPS; the replicas are summed into grad once per step.
@@ -92,7 +88,6 @@ struct nerfds_trainer {
   std::vector<uint64_t> pack_fresh;
   int num_cus = 256;
   bool fuse_bwd = true;     // NERFDS_TRAIN_FUSE_BWD=0: the narrow layers' backward as two kernels (A/B timing)
-  bool own_gemm = true;     // NERFDS_TRAIN_GEMM=rocblas switches the data GEMMs back to rocBLAS (A/B measurements)
   std::string err;
   // workspace views (set by carve())
   float *zc, *zf, *wc, *rs_scratch, *x, *mask_in, *mask_logit, *warp_in, *wv, *xw, *hyper_in, *wamb, *trunk_in, *bottv, *alphav, *sigma,
@@ -111,12 +106,11 @@ struct nerfds_trainer {
     return code;
   }
   ~nerfds_trainer() {
-    for (float* p : {theta, grad, m1, m2, ws, loss_dev, part, tws, terms_dev, nws}) if (p) (void)hipFree(p);
+    for (float* p : {theta, grad, m1, m2, ws, loss_dev, tws, terms_dev, nws}) if (p) (void)hipFree(p);
     if (wpack) (void)hipFree(wpack);
     if (grad_rep) (void)hipFree(grad_rep);
     if (arena) (void)hipFree(arena);
     if (packs_dev) (void)hipFree(packs_dev);
-    if (blas) (void)rocblas_destroy_handle(blas);
   }
 };
 
@@ -145,25 +139,6 @@ MlpP add_mlp(nerfds_trainer& t, const std::string& name, int in_dim, int width, 
   return m;
 }
 
-// ---- row-major GEMM helpers over column-major rocBLAS -------------------------------------------------------------
-// C[M x N] (ldc) = A[M x K] (lda) * B[K x N] (ldb) + beta * C
-rocblas_status gemm_nn(rocblas_handle h, int64_t M, int N, int K, const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc) {
-  const float one = 1.f;
-  return rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, N, (rocblas_int)M, K, &one, B, ldb, A, lda, &beta, C, ldc);
-}
-// C[K x N] (ldc) = A[M x K]^T (lda) * B[M x N] (ldb) + beta * C        (contraction over the M rows)
-rocblas_status gemm_tn(rocblas_handle h, int64_t M, int N, int K, const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc) {
-  const float one = 1.f;
-  return rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, N, K, (rocblas_int)M, &one, B, ldb, A, lda, &beta, C, ldc);
-}
-// C[M x K] (ldc) = A[M x N] (lda) * B[K x N]^T (ldb) + beta * C
-rocblas_status gemm_nt(rocblas_handle h, int64_t M, int N, int K, const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc) {
-  const float one = 1.f;
-  return rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, K, (rocblas_int)M, N, &one, B, ldb, A, lda, &beta, C, ldc);
-}
-
-constexpr int64_t SLAB = 4096;     // rows per split-K slab of the weight-gradient GEMMs
-
 struct Run {
   nerfds_trainer& t;
   hipStream_t st;
@@ -171,10 +146,19 @@ struct Run {
   bool ok = true;
   // Set around the FORWARD of the warp field: its output moves the points that the 2^7-frequency posenc of the template
   // reads, which amplifies the 16-bit operand rounding of the two-way split to ~1 % on the warp-field gradients (measured
-  // against the fp64 oracle).  Those layers run the three-way split (fp32-level products), or rocBLAS fp32 where that
-  // kernel does not cover the shape (the 33-wide input rows are not 16-byte aligned).
+  // against the fp64 oracle).  Those layers run the three-way split (fp32-level products).
   bool precise_layers = false;
-  void chk(rocblas_status s) { if (s != rocblas_status_success) ok = false; }
+  // Every dense layer of the step runs on the hand-written MFMA kernels of train_gemm.hip.  A shape they do not cover is an
+  // error (NERFDS_ENOTSUP from the step), never a detour through a library GEMM.
+  std::string unsupported_what;
+  void unsupported(const char* what, int K, int N, int64_t rows) {
+    if (ok) {
+      char buf[160];
+      snprintf(buf, sizeof buf, "%s: shape K=%d N=%d rows=%lld is not covered by the MFMA layer kernels", what, K, N, (long long)rows);
+      unsupported_what = buf;
+    }
+    ok = false;
+  }
 
   // y[M x N] (ldy) = act(sum_s x_s W[rows of s] + b)
   // where the MFMA kernels add a gradient that lives at g in t.grad: replica 0 of the same offset (kernels add b % nrep replicas on)
@@ -207,7 +191,7 @@ struct Run {
   bool ws_layer(const std::vector<Seg>& segs, const float* W, int ldw, int row0, int in_dim, int out_dim, int transpose, const float* bias, float* y,
                 int ldy, int64_t rows, bool relu, const float* mask_y, int ld_mask, int mask_div, bool accumulate, float* colsum = nullptr) {
     const int parts = precise_layers ? 3 : 2;
-    if (!t.own_gemm || segs.size() > 4 || frag_bytes(in_dim, out_dim, parts) > WPACK_BYTES) return false;
+    if (segs.size() > 4 || frag_bytes(in_dim, out_dim, parts) > WPACK_BYTES) return false;
     DenseArgs A{};
     A.nseg = (int)segs.size();
     for (int i = 0; i < A.nseg; ++i) A.seg[i] = {segs[i].x, segs[i].ld, segs[i].K};
@@ -220,36 +204,16 @@ struct Run {
     return dense_ws(st, A, t.num_cus);
   }
   void dense_fwd(const LayerP& L, const std::vector<Seg>& segs, float* y, int ldy, bool relu) {
-    if (ws_layer(segs, t.theta + L.w, L.N, 0, L.K, L.N, 0, t.theta + L.b, y, ldy, M, relu, nullptr, 0, 1, false)) return;
-    int k0 = 0;
-    for (size_t i = 0; i < segs.size(); ++i) {
-      chk(gemm_nn(t.blas, M, L.N, segs[i].K, segs[i].x, segs[i].ld, t.theta + L.w + (int64_t)k0 * L.N, L.N, i ? 1.f : 0.f, y, ldy));
-      k0 += segs[i].K;
-    }
-    bias_act(st, y, t.theta + L.b, M, L.N, ldy, relu ? 1 : 0);
+    if (!ws_layer(segs, t.theta + L.w, L.N, 0, L.K, L.N, 0, t.theta + L.b, y, ldy, M, relu, nullptr, 0, 1, false))
+      unsupported("dense forward", L.K, L.N, M);
   }
   // dy[M x N] (ldy) is d loss / d (post-activation output y); relu_y != nullptr -> mask with y > 0 first (needs ldy == N)
-  // dW[K x N] += X[M x K]^T dY[M x N].  The output is tiny and the contraction is the sample axis (up to 524 288): a
-  // single GEMM runs on a handful of workgroups (measured 3 ms per layer), so the sample axis is cut into slabs of
-  // SLAB rows, each slab is one problem of a strided-batched GEMM into a partial, and a small kernel adds the partials.
+  // dW[K x N] += X[M x K]^T dY[M x N] (contraction over the sample axis): train_gemm.hip k_wgrad, one partial per workgroup
+  // accumulated in registers and added to a gradient replica with float atomics.
   void weight_grad(const float* X, int ldx, int K, const float* dy, int ldy, int N, float* dW, int64_t rows = -1) {
     const int64_t M = rows < 0 ? this->M : rows;
-    if (t.own_gemm) {                                   // hand-written MFMA kernel (train_gemm.hip): one partial per workgroup
-      WgradArgs A{X, ldx, K, dy, ldy, N, M, nullptr, rep(dW), static_cast<const char*>(t.wpack) + WPACK_BYTES, 0, 0, t.P, nrep()};
-      if (wgrad_supported(A) && wgrad(st, A, wgrad_grid(A, t.num_cus))) return;
-    }
-    const int64_t slabs = M / SLAB;
-    const float one = 1.f, zero = 0.f;
-    if (slabs >= 2 && (size_t)slabs * K * N <= t.part_floats) {
-      chk(rocblas_sgemm_strided_batched(t.blas, rocblas_operation_none, rocblas_operation_transpose, N, K, SLAB, &one, dy, ldy,
-                                        (rocblas_stride)SLAB * ldy, X, ldx, (rocblas_stride)SLAB * ldx, &zero, t.part, N,
-                                        (rocblas_stride)K * N, (rocblas_int)slabs));
-      sum_partials(st, t.part, (int)slabs, (long long)K * N, dW);
-      const int64_t done = slabs * SLAB;
-      if (done < M) chk(gemm_tn(t.blas, M - done, N, K, X + done * ldx, ldx, dy + done * ldy, ldy, 1.f, dW, N));
-    } else {
-      chk(gemm_tn(t.blas, M, N, K, X, ldx, dy, ldy, 1.f, dW, N));
-    }
+    WgradArgs A{X, ldx, K, dy, ldy, N, M, nullptr, rep(dW), static_cast<const char*>(t.wpack) + WPACK_BYTES, 0, 0, t.P, nrep()};
+    if (!(wgrad_supported(A) && wgrad(st, A, wgrad_grid(A, t.num_cus)))) unsupported("weight gradient", K, N, M);
   }
   // premasked: the kernel that produced dy already applied this layer's ReLU mask and added the bias gradient.
   // Returns true when the dx of the segment that asked for it (Seg::dx_relu_y) was masked / column-summed by the MFMA layer.
@@ -265,7 +229,7 @@ struct Run {
     int k0 = 0;
     for (const Seg& s : segs) {
       // narrow hidden layer whose input is the ReLU output that also masks its gradient: dW, dX, mask and column sums in ONE pass
-      if (t.own_gemm && t.fuse_bwd && s.dx && !s.acc && s.dx_relu_y == s.x && s.dld == s.K && s.ld == s.K) {
+      if (t.fuse_bwd && s.dx && !s.acc && s.dx_relu_y == s.x && s.dld == s.K && s.ld == s.K) {
         BwdFusedArgs F{s.x, s.ld, s.K, dy, ldy, L.N, t.wpack, s.dx, s.dld, rep(s.dx_bias_grad), rep(t.grad + L.w + (int64_t)k0 * L.N), M,
                        static_cast<const char*>(t.wpack) + WPACK_BYTES, t.P, nrep()};
         if (bwd_fused_supported(F)) {
@@ -279,7 +243,7 @@ struct Run {
         const bool want = s.dx_relu_y != nullptr;          // (with acc: this is the last contribution to dx, the mask covers the total)
         if (ws_layer({{dy, ldy, L.N, nullptr, 0, false}}, t.theta + L.w, L.N, k0, L.N, s.K, 1, nullptr, s.dx, s.dld, M, false, want ? s.dx_relu_y : nullptr,
                      s.dld, 1, s.acc, want ? s.dx_bias_grad : nullptr)) fused = fused || want;
-        else chk(gemm_nt(t.blas, M, L.N, s.K, dy, ldy, t.theta + L.w + (int64_t)k0 * L.N, L.N, s.acc ? 1.f : 0.f, s.dx, s.dld));
+        else unsupported("data gradient", L.N, s.K, M);
       }
       k0 += s.K;
     }
@@ -288,16 +252,8 @@ struct Run {
   // tangents (3 rows per sample, no bias): y[3M x N] = sum_s t_s W[rows of s]
   // relu_y != nullptr: the rows are masked with the PRIMAL activation of their sample (y_t = 0 where relu_y[row / 3] <= 0)
   void dense_jvp(const LayerP& L, const std::vector<Seg>& segs, float* y, int ldy, const float* relu_y = nullptr) {
-    if (ws_layer(segs, t.theta + L.w, L.N, 0, L.K, L.N, 0, nullptr, y, ldy, 3 * M, false, relu_y, L.N, 3, false)) return;
-    dense_jvp_rocblas(L, segs, y, ldy);
-    if (relu_y) relu_mask3(st, y, relu_y, M, L.N);
-  }
-  void dense_jvp_rocblas(const LayerP& L, const std::vector<Seg>& segs, float* y, int ldy) {
-    int k0 = 0;
-    for (size_t i = 0; i < segs.size(); ++i) {
-      chk(gemm_nn(t.blas, 3 * M, L.N, segs[i].K, segs[i].x, segs[i].ld, t.theta + L.w + (int64_t)k0 * L.N, L.N, i ? 1.f : 0.f, y, ldy));
-      k0 += segs[i].K;
-    }
+    if (!ws_layer(segs, t.theta + L.w, L.N, 0, L.K, L.N, 0, nullptr, y, ldy, 3 * M, false, relu_y, L.N, 3, false))
+      unsupported("tangent forward", L.K, L.N, 3 * M);
   }
   // returns the tangent of the last hidden layer (in cur or other)
   float* mlp_jvp(const MlpP& m, const float* t_in0, const std::vector<float*>& h, float* cur, float* other,
@@ -324,7 +280,7 @@ struct Run {
         const bool want = s.dx_relu_y != nullptr;
         if (ws_layer({{dy, ldy, L.N, nullptr, 0, false}}, t.theta + L.w, L.N, k0, L.N, s.K, 1, nullptr, s.dx, s.dld, 3 * M, false,
                      want ? s.dx_relu_y : nullptr, s.dld, 3, s.acc)) fused = fused || want;
-        else chk(gemm_nt(t.blas, 3 * M, L.N, s.K, dy, ldy, t.theta + L.w + (int64_t)k0 * L.N, L.N, s.acc ? 1.f : 0.f, s.dx, s.dld));
+        else unsupported("tangent data gradient", L.N, s.K, 3 * M);
       }
       k0 += s.K;
     }
@@ -423,11 +379,7 @@ bool ensure_norm_ws(nerfds_trainer& t) {
   if (hipMalloc(&t.nws, need * sizeof(float)) != hipSuccess) return false;
   float* base = t.nws;
   for (auto& v : views) { *v.first = base; base += (v.second + 63) & ~(size_t)63; }
-  // the split-K partials of the weight gradients now cover 3 M rows
-  if (t.part) (void)hipFree(t.part);
-  t.part = nullptr;
-  t.part_floats *= 3;
-  return hipMalloc(&t.part, t.part_floats * sizeof(float)) == hipSuccess;
+  return true;
 }
 
 // d sigma_raw / d x by forward-mode tangents through warp MLP -> exp_se3, hyper sheet, posenc, trunk, alpha head
@@ -532,7 +484,7 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   pm = r.dense_bwd(t.mask_out, {{t.mask_h.back(), t.mask.width, t.mask.width, t.g0, t.mask.width, false, t.mask_h.back(), t.grad + t.mask.hidden.back().b}}, t.d_mask_logit, 1, nullptr);
   r.mlp_bwd(t.mask, t.mask_in, t.mask_h, t.g0, t.g1, t.d_mask_in, pm);
   mask_in_bwd(st, D, R, S, t.d_mask_in, rays->warp_id, t.cfg.num_warp_embeds, t.grad + t.mask_tbl);
-  if (!r.ok) return t.fail(NERFDS_EDEVICE, "rocBLAS sgemm failed");
+  if (!r.ok) return t.fail(NERFDS_ENOTSUP, "%s", r.unsupported_what.c_str());
   return NERFDS_OK;
 }
 
@@ -594,29 +546,17 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
     g_train_error = "hipMalloc failed (workspace of " + std::to_string(t->ws_floats * 4 >> 20) + " MiB)";
     return NERFDS_ENOMEM;
   }
-  {
-    const int64_t Mmax = max_rays * (c->num_coarse_samples + c->num_fine_samples);
-    const int maxK = std::max({2 * TW + cond, TW + D.trunk_in, c->mask_width + D.mask_in}), maxN = std::max(TW, c->mask_width);
-    t->part_floats = (size_t)std::max<int64_t>(Mmax / SLAB, 1) * maxK * maxN;
-    if (hipMalloc(&t->part, t->part_floats * sizeof(float)) != hipSuccess) {
-      g_train_error = "hipMalloc failed (split-K partials)";
-      return NERFDS_ENOMEM;
-    }
-  }
   (void)hipMemset(t->theta, 0, pbytes); (void)hipMemset(t->m1, 0, pbytes); (void)hipMemset(t->m2, 0, pbytes); (void)hipMemset(t->grad, 0, pbytes);
   carve(*t);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, t->device) == hipSuccess && prop.multiProcessorCount > 0) t->num_cus = prop.multiProcessorCount;
-    const char* g = getenv("NERFDS_TRAIN_GEMM");
-    t->own_gemm = !(g && std::string(g) == "rocblas");
     const char* fb = getenv("NERFDS_TRAIN_FUSE_BWD");
     t->fuse_bwd = !(fb && std::string(fb) == "0");
-    if (t->own_gemm && hipMalloc(&t->arena, ARENA_BYTES) != hipSuccess) { g_train_error = "hipMalloc failed (fragment arena)"; return NERFDS_ENOMEM; }
-    if (t->own_gemm && hipMalloc(&t->grad_rep, (size_t)GRAD_REPS * t->P * sizeof(float)) != hipSuccess) { g_train_error = "hipMalloc failed (gradient replicas)"; return NERFDS_ENOMEM; }
+    if (hipMalloc(&t->arena, ARENA_BYTES) != hipSuccess) { g_train_error = "hipMalloc failed (fragment arena)"; return NERFDS_ENOMEM; }
+    if (hipMalloc(&t->grad_rep, (size_t)GRAD_REPS * t->P * sizeof(float)) != hipSuccess) { g_train_error = "hipMalloc failed (gradient replicas)"; return NERFDS_ENOMEM; }
     if (hipMalloc(&t->wpack, WPACK_BYTES + 256) != hipSuccess || hipMemset(t->wpack, 0, WPACK_BYTES + 256) != hipSuccess) { g_train_error = "hipMalloc failed (weight fragments)"; return NERFDS_ENOMEM; }
   }
-  if (rocblas_create_handle(&t->blas) != rocblas_status_success) { g_train_error = "rocblas_create_handle failed"; return NERFDS_EDEVICE; }
   *out = t.release();
   return NERFDS_OK;
 }
@@ -713,7 +653,6 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   if (ex->mask_ratio != 1.0f && !rays->gt_mask) return t->fail(NERFDS_EINVAL, "rays_dict['mask'] is required when mask_ratio != 1");
   if (hipSetDevice(t->device) != hipSuccess) return t->fail(NERFDS_EDEVICE, "hipSetDevice failed");
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  if (rocblas_set_stream(t->blas, st) != rocblas_status_success) return t->fail(NERFDS_EDEVICE, "rocblas_set_stream failed");
   const int R = (int)rays->num_rays, Nc = t->cfg.num_coarse_samples, Nf = t->cfg.num_fine_samples;
   Windows W;
   window(W.mask, t->D.mask_bands, ex->warp_alpha);          // models.py:967

@@ -67,19 +67,18 @@ def test_train_oracle_reproduces_golden():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('gemm', ['mfma', 'rocblas'])
-def test_hip_training_step_matches_golden(gemm, monkeypatch):
+def test_hip_training_step_matches_golden():
   """The HIP training step against COMMITTED gradient digests (the oracle is not run): per leaf a seeded subsample of
-  256 entries, the L2 norm and the max-abs value of the fp64 autograd gradient.  Both GEMM modes of the trainer
-  (tests/test_training.py): 'rocblas' = fp32 library GEMMs: 1e-2 / 4e-3 (measured 2e-5); 'mfma' = hand-written split-bf16
-  layers: 1e-1 (max-abs: a ReLU whose pre-activation is ~0 can flip, which moves single entries by one
-  sample's contribution - 5e-2 of the leaf maximum on a trunk bias here) / 3e-2 (norm).  The wide norm bound is not slack in the kernels: on this case (trained-regime weights) the gradient w.r.t.
-  the warped points - which every warp / hyper-sheet / mask leaf goes through - is a cancelling sum over the 2^0..2^7 posenc
-  frequencies with condition number ~300 (fp32's 6e-8 becomes the 2e-5 measured in the rocblas mode), so the 2^-17 operand
-  rounding of the split-bf16 GEMMs anywhere in the trunk shows up as ~1e-2 on those leaves (measured 1.4e-2 worst, NerfMLP
-  leaves 1e-4).  The reference's own matmuls (bf16 on TPU, TF32 on NVIDIA GPUs at jnp's default precision) round coarser."""
+  256 entries, the L2 norm and the max-abs value of the fp64 autograd gradient.  The trainer's layers are the hand-written
+  split-bf16 MFMA kernels (tests/test_training.py): bounds 1e-1 (max-abs: a ReLU whose pre-activation is ~0 can flip, which
+  moves single entries by one sample's contribution - 5e-2 of the leaf maximum on a trunk bias here) / 3e-2 (norm).  The wide
+  norm bound is not slack in the kernels: on this case (trained-regime weights) the gradient w.r.t. the warped points - which
+  every warp / hyper-sheet / mask leaf goes through - is a cancelling sum over the 2^0..2^7 posenc frequencies with condition
+  number ~300 (fp32 GEMMs land at 2e-5, not 6e-8, here), so the 2^-17 operand rounding of the split-bf16 GEMMs anywhere in the
+  trunk shows up as ~1e-2 on those leaves (measured 1.4e-2 worst, NerfMLP leaves 1e-4).  The reference's own matmuls (bf16 on
+  TPU, TF32 on NVIDIA GPUs at jnp's default precision) round coarser."""
   from nerfds_amd.training import Trainer
-  monkeypatch.setenv('NERFDS_TRAIN_GEMM', gemm)
+  gemm = 'mfma'
   from nerfds_amd.params import tree_leaves
   z = np.load(os.path.join(HERE, 'golden', 'train_' + G.TRAIN_CASE + '.npz'))
   cfg, params, rays, t, u, target = G.train_case()

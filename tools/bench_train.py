@@ -33,6 +33,6 @@ for _ in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 flop = 3 * 333.15e6 * R          # fwd + bwd ~ 3 x forward
-print(json.dumps({'config': 'BASELINE config 4: train step, %d rays, 64+64 samples, nerf_ds graph, %s%s' % (R, 'fp32 rocBLAS GEMMs + HIP kernels' if os.environ.get('NERFDS_TRAIN_GEMM') == 'rocblas' else 'hand-written MFMA layers (split-bf16 operands, fp32 accumulation) + HIP kernels', ', full nerf_ds.gin objective incl. second-order norm loss' if full else ', rgb loss only'),
+print(json.dumps({'config': 'BASELINE config 4: train step, %d rays, 64+64 samples, nerf_ds graph, %s%s' % (R, 'hand-written MFMA layers (split-bf16 operands, fp32 accumulation) + HIP kernels', ', full nerf_ds.gin objective incl. second-order norm loss' if full else ', rgb loss only'),
                   'ms_per_step': dt * 1e3, 'rays_per_s': R / dt, 'algorithmic_tflops': flop / dt / 1e12,
                   'loss_first': losses[0], 'loss_last': losses[-1], 'params': tr.num_params}))

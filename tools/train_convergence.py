@@ -1,6 +1,6 @@
 """Teacher / student run of the trainer at BASELINE config-4 sizes (4096 random rays per step of a teacher frame, 64+64 samples,
-nerf_ds graph, rgb loss + the regularisers of configs/nerf_ds.gin), in both GEMM modes of the trainer: prints one JSON line with
-the loss every 25 steps and the held-out frame MSE before / after.  Evidence that the MFMA mode optimises like the fp32 one."""
+nerf_ds graph, rgb loss + the regularisers of configs/nerf_ds.gin): prints one JSON line with the loss every 25 steps and the
+held-out frame MSE before / after."""
 import json, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, os.path.join(ROOT, 'nerf-ds_amd'))
@@ -28,8 +28,7 @@ B = 4096
 lr = build({'type': 'exponential', 'initial_value': 1e-3, 'final_value': 1e-4, 'num_steps': STEPS})
 obj = dict(warp_reg_loss_weight=0.001, back_facing_reg_weight=0.1)
 out = {'config': f'{W}x{H} teacher frame, {B} rays/step, 64+64 samples, {STEPS} steps, lr 1e-3 -> 1e-4, grad clip 10', 'modes': {}}
-for mode in ('mfma', 'rocblas'):
-  os.environ['NERFDS_TRAIN_GEMM'] = mode
+for mode in ('mfma',):
   student = init_params(cfg, 12, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
   mse = lambda p: float(((render_frame(model, {'params': p}, cam, 1, EX, want_debug=False)[2][:, 0:3] - target) ** 2).mean())
   before = mse(student)

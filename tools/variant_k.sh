@@ -10,6 +10,6 @@ for v in "$@"; do
       -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_PREC=$P -DNERFDS_NAME=nerfds_$p -Rpass-analysis=kernel-resource-usage -o build/abl/kv_$n.o 2>&1 | grep -E "error|VGPRs Spill|ScratchSize" | sort | uniq -c | sed "s/^/$n: /"
     others=$(ls build/k_*.o | grep -v "k_nerfds_$p.o")
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../nerfds_amd/_lib/abl/libnerfds_hip_$n.so build/abl/kv_$n.o $others \
-      build/host.o build/camera.o build/frame.o build/train_k.o build/train_g.o build/train.o -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib ) &
+      build/host.o build/camera.o build/frame.o build/train_k.o build/train_g.o build/train.o ) &
 done
 wait

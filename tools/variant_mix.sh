@@ -11,6 +11,6 @@ for v in "$@"; do
     /opt/rocm/bin/hipcc $FL -x hip -c nerfds_host.cpp -o build/abl/host_$n.o 2>&1 | grep -E "error"
     others=$(ls build/k_*.o | grep -v k_nerfds_mixed.o)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../nerfds_amd/_lib/abl/libnerfds_hip_$n.so build/abl/km_$n.o build/abl/host_$n.o $others \
-      build/camera.o build/frame.o build/train_k.o build/train_g.o build/train.o -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib ) &
+      build/camera.o build/frame.o build/train_k.o build/train_g.o build/train.o ) &
 done
 wait
