@@ -137,7 +137,6 @@ def main():
   model = NerfModel(cfg, device=device, precision=args.precision)
   model.load_params(params)
   variables = {'params': params}
-  model._params_id = id(params)
   rays = synth_rays(args.rays, cfg.num_warp_embeds, 100 + rank, device)       # resident in HBM before timing
   chunks = [(lo, min(lo + args.chunk, args.rays)) for lo in range(0, args.rays, args.chunk)]
   chunk_rays = [{k: (v[lo:hi] if not isinstance(v, dict) else {kk: vv[lo:hi] for kk, vv in v.items()})

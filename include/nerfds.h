@@ -134,6 +134,8 @@ typedef struct nerfds_weights {
   nerfds_dense hyper_hidden[NERFDS_MAX_DEPTH];  /* hyper_sheet_mlp/MLP_0/hidden_i */
   nerfds_dense hyper_out;                       /* hyper_sheet_mlp/MLP_0/logit */
   nerfds_nerf_mlp nerf[2];                      /* nerf_mlps_coarse, nerf_mlps_fine */
+  int32_t embed_rows;                           /* rows of the GLO tables above; must equal cfg.num_warp_embeds (the
+                                                   library copies embed_rows * glo_num_dims floats from each pointer) */
 } nerfds_weights;
 
 /* Pinhole camera with radial / tangential distortion: the JSON fields of hypernerf/camera.py:140-161 (Camera.from_json;
@@ -177,11 +179,14 @@ typedef struct nerfds_extra {
 
 /* Sampling uniforms.  The reference draws them from JAX threefry streams (model_utils.py:84,217) which
  * cannot be reproduced outside JAX; for parity they are injected.  Either pointer NULL -> on-chip
- * Philox4x32-10 keyed by (seed, ray index). DEVICE pointers. */
+ * Philox4x32-10 keyed by (seed, first_ray + ray index in the call, sample index) - csrc/philox.h; the same stream in
+ * nerfds_render_rays and nerfds_trainer_step, so a frame rendered in chunks (first_ray = chunk offset) or a batch
+ * run through the trainer in blocks draws what one call over all rays would.  DEVICE pointers. */
 typedef struct nerfds_rand {
   const float* t_rand;        /* [R][num_coarse_samples] */
   const float* u_rand;        /* [R][num_fine_samples]   */
   uint64_t seed;
+  int64_t first_ray;          /* Philox counter of ray 0 of this call */
 } nerfds_rand;
 
 /* Outputs: DEVICE pointers; any may be NULL (not written). */
@@ -230,11 +235,14 @@ int nerfds_frame_images(int device, const float* ray_records, int32_t height, in
  * nerfds_trainer_leaf), their gradient, the Adam moments (flax.optim.Adam: b1 0.9, b2 0.999, eps 1e-8) and an HBM workspace
  * sized for max_rays.  nerfds_trainer_step: forward + backward of both levels into the gradient vector, then (unless
  * NERFDS_TRAIN_GRADS_ONLY) one Adam update with `learning_rate`.  rays / target_rgb ([R][3]) / rnd->t_rand,u_rand are DEVICE
- * pointers; rnd == NULL or NULL uniforms = non-stratified sampling.  loss_host (optional, HOST float[10]) receives
+ * pointers; NULL uniforms with extra->use_stratified_sampling = the on-chip Philox stream described at struct nerfds_rand - the reference always
+ * draws the jitter, model_utils.py:84,217 - so pass a new seed every step.  loss_host (optional, HOST float[10]) receives
  * {rgb loss fine (coarse if there is no fine level), rgb loss coarse, weighted warp_reg / back_facing / mask / norm terms of the fine level,
  * the same four of the coarse level} and synchronises the stream.
- * Only the configs/nerf_ds.gin graph is built (NERFDS_ENOTSUP otherwise).  The norm / mask / regulariser losses of the full
- * objective (training.py:276-438) are not part of config 4 and not built. */
+ * Only the configs/nerf_ds.gin graph is built (NERFDS_ENOTSUP otherwise), and every dense layer runs on the library's own MFMA
+ * kernels: a layer shape they do not cover is NERFDS_ENOTSUP as well (there is no library-GEMM detour).  The auxiliary losses of
+ * configs/nerf_ds.gin are selected by nerfds_train_objective; elastic / background / hyper-reg losses (off in every shipped gin)
+ * are not built. */
 typedef struct nerfds_trainer nerfds_trainer;
 /* Weights of the auxiliary first-order losses added to the rgb loss of EACH level (0 = off): warp regulariser at the median-depth
  * sample (training.py:297-310, utils.general_loss_with_squared_residual), back-facing regulariser on the raw predicted normal

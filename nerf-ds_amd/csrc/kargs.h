@@ -20,6 +20,7 @@ struct KArgs {
   const float* t_rand;
   const float* u_rand;
   uint64_t seed;
+  int64_t first_ray;       // Philox counter of ray 0 (philox.h)
   // packed weights: [0] shared (mask|warp|hyper) stream, [1] coarse NerfMLP, [2] fine NerfMLP
   const void* wstream[3];
   const float* bias[3];

@@ -133,6 +133,12 @@ template <class G> bool take_weights(Weights& W, const nerfds_model_cfg& c, cons
     return true;
   };
   const size_t glo = (size_t)c.num_warp_embeds * G::GLO;
+  if ((G::HAS_WARP || G::HAS_MASK) && w.embed_rows != c.num_warp_embeds) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "GLO tables have %d rows, the model configuration says num_warp_embeds = %d", w.embed_rows, c.num_warp_embeds);
+    err = buf;
+    return false;
+  }
   if (G::HAS_WARP) {
     if (!w.warp_embed || c.num_warp_embeds <= 0) { err = "warp_embed table missing"; return false; }
     W.warp_embed.assign(w.warp_embed, w.warp_embed + glo);
@@ -233,9 +239,11 @@ struct nerfds_ctx {
   bool packed[NUM_PLANS] = {};
   bool bias_uploaded = false;
   std::string err;
-  // timing
+  // timing: event pairs recorded around the launches since the last reset; reset returns them to the pool (no per-launch
+  // hipEventCreate, nothing accumulates), and at most MAX_TIMED launches are recorded between two resets
   bool timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  static constexpr size_t MAX_TIMED = 4096;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events, event_pool;
   int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -304,7 +312,8 @@ int nerfds_ctx_create(nerfds_ctx** out, int device, const nerfds_model_cfg* cfg)
 int nerfds_ctx_destroy(nerfds_ctx* ctx) {
   if (!ctx) return NERFDS_OK;
   (void)hipSetDevice(ctx->device);
-  for (auto& e : ctx->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto* v : {&ctx->events, &ctx->event_pool})
+    for (auto& e : *v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete ctx;
   return NERFDS_OK;
 }
@@ -377,6 +386,7 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   ka.t_rand = rnd ? rnd->t_rand : nullptr;
   ka.u_rand = rnd ? rnd->u_rand : nullptr;
   ka.seed = rnd ? rnd->seed : 0;
+  ka.first_ray = rnd ? rnd->first_ray : 0;
   for (int i = 0; i < 3; ++i) { ka.wstream[i] = ctx->wstream[prec][i].p; ka.bias[i] = static_cast<const float*>(ctx->wbias[i].p); }
   if (ctx->cfg.num_fine_samples == 0) { ka.wstream[2] = ka.wstream[1]; ka.bias[2] = ka.bias[1]; }
   ka.warp_embed = static_cast<const float*>(ctx->warp_embed.p);
@@ -417,14 +427,19 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
 
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-  if (ctx->timing) {
-    if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess)
+  const bool timed = ctx->timing && ctx->events.size() < nerfds_ctx::MAX_TIMED;
+  if (timed) {
+    if (!ctx->event_pool.empty()) {
+      ev = ctx->event_pool.back();
+      ctx->event_pool.pop_back();
+    } else if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) {
       return ctx->fail(NERFDS_EDEVICE, "hipEventCreate failed");
+    }
     (void)hipEventRecord(ev.first, stream);
   }
   launcher(ctx->graph, prec)(ka, ctx->num_cus, stream);   // grid = min(ray groups, CUs) persistent workgroups
   hipError_t e = hipGetLastError();
-  if (ctx->timing) {
+  if (timed) {
     (void)hipEventRecord(ev.second, stream);
     ctx->events.push_back(ev);
   }
@@ -476,7 +491,7 @@ int nerfds_kernel_time_ms(nerfds_ctx* ctx, int reset, double* total_ms) {
   }
   if (total_ms) *total_ms = tot;
   if (reset) {
-    for (auto& e : ctx->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& e : ctx->events) ctx->event_pool.push_back(e);
     ctx->events.clear();
     ctx->timing = true;
   }

@@ -680,7 +680,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   }
   (void)hipMemsetAsync(t->loss_dev, 0, 2 * sizeof(float), st);
   const int strat = ex->use_stratified_sampling;
-  coarse_z(st, R, Nc, ex->near, ex->far, strat, rnd ? rnd->t_rand : nullptr, t->zc);
+  coarse_z(st, R, Nc, ex->near, ex->far, strat, rnd ? rnd->t_rand : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->first_ray : 0, t->zc);
   Objective ob{};
   const Objective* obp = nullptr;
   if (objective) {
@@ -701,7 +701,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   int rc = run_level(*t, st, 0, R, Nc, t->zc, rays, target_rgb, ex, W, t->wc, want_sg, obp, norm_weight);
   if (rc != NERFDS_OK) return rc;
   if (Nf > 0) {
-    resample(st, R, Nc, Nf, t->zc, t->wc, strat, rnd ? rnd->u_rand : nullptr, t->zf, t->rs_scratch);
+    resample(st, R, Nc, Nf, t->zc, t->wc, strat, rnd ? rnd->u_rand : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->first_ray : 0, t->zf, t->rs_scratch);
     rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights, want_sg, obp, norm_weight);
     if (rc != NERFDS_OK) return rc;
   }

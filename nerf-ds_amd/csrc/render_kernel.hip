@@ -34,6 +34,7 @@
 
 #include "graphs.h"
 #include "kargs.h"
+#include "philox.h"
 
 namespace nerfds {
 
@@ -483,20 +484,6 @@ DEVI void normalize3(float (&v)[3]) {   // model_utils.py:438-442
   float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
   float inv = 1.0f / sqrtf(fmaxf(n2, 1.1920929e-07f));
   v[0] *= inv; v[1] *= inv; v[2] *= inv;
-}
-
-// Philox4x32-10 (Salmon et al. 2011) -> 4 uniforms in [0, 1).
-DEVI void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, float (&u)[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  u[0] = (c0 >> 8) * 5.9604645e-8f; u[1] = (c1 >> 8) * 5.9604645e-8f;
-  u[2] = (c2 >> 8) * 5.9604645e-8f; u[3] = (c3 >> 8) * 5.9604645e-8f;
 }
 
 // wave-wide helpers (64 lanes)
@@ -998,9 +985,7 @@ template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int n
       if (ka.u_rand != nullptr) {
         u = ka.u_rand[(size_t)ray * nf + k];
       } else {
-        float r4[4];
-        philox4((uint32_t)ray, 1u, (uint32_t)(k >> 2), 0u, (uint32_t)ka.seed, (uint32_t)(ka.seed >> 32), r4);
-        u = r4[k & 3];
+        u = sample_uniform(ka.seed, ka.first_ray + ray, 1, k);
       }
     } else {
       u = (nf > 1) ? (float)k / (float)(nf - 1) : 0.f;                       // linspace(0, 1, nf)
@@ -1143,9 +1128,7 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
           if (ka.t_rand != nullptr) {
             t = ka.t_rand[(size_t)ray * nc + i];
           } else {
-            float r4[4];
-            philox4((uint32_t)ray, 0u, (uint32_t)(i >> 2), 0u, (uint32_t)ka.seed, (uint32_t)(ka.seed >> 32), r4);
-            t = r4[i & 3];
+            t = sample_uniform(ka.seed, ka.first_ray + ray, 0, i);
           }
           z = zlo + (zhi - zlo) * t;
         }

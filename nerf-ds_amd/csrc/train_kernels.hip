@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "train_kernels.h"
+#include "philox.h"
 
 namespace nerfds_train {
 
@@ -24,7 +25,8 @@ template <int C> __device__ __forceinline__ float posenc_dval(int g, const float
 }
 
 // ---- sampling (model_utils.py:55-92) ---------------------------------------------------------------------------
-__global__ void k_coarse_z(int R, int Nc, float near_, float far_, int stratified, const float* __restrict__ t_rand, float* __restrict__ z) {
+// t_rand == nullptr with stratified sampling: the on-chip Philox stream of philox.h (the reference always draws, model_utils.py:84)
+__global__ void k_coarse_z(int R, int Nc, float near_, float far_, int stratified, const float* __restrict__ t_rand, uint64_t seed, long long first_ray, float* __restrict__ z) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= (long long)R * Nc) return;
   const int s = (int)(i % Nc);
@@ -33,16 +35,16 @@ __global__ void k_coarse_z(int R, int Nc, float near_, float far_, int stratifie
     return near_ * (1.0f - t) + far_ * t;
   };
   float v = zlin(s);
-  if (stratified && t_rand) {
+  if (stratified) {
     const float lo = s > 0 ? 0.5f * (v + zlin(s - 1)) : v, hi = s + 1 < Nc ? 0.5f * (zlin(s + 1) + v) : v;
-    v = lo + (hi - lo) * t_rand[i];
+    v = lo + (hi - lo) * (t_rand ? t_rand[i] : nerfds::sample_uniform(seed, first_ray + i / Nc, 0, s));
   }
   z[i] = v;
 }
 
 // ---- inverse-CDF resample + sorted union (model_utils.py:193-269), one thread per ray; no gradient (line 241) -----
 __global__ void k_resample(int R, int Nc, int Nf, const float* __restrict__ zc, const float* __restrict__ wc, int stratified,
-                           const float* __restrict__ u_rand, float* __restrict__ zf, float* __restrict__ scratch) {
+                           const float* __restrict__ u_rand, uint64_t seed, long long first_ray, float* __restrict__ zf, float* __restrict__ scratch) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const float* z = zc + (size_t)r * Nc;
@@ -58,7 +60,8 @@ __global__ void k_resample(int R, int Nc, int Nf, const float* __restrict__ zc, 
   for (int i = 0; i < nw; ++i) { c += (w[i + 1] + 1e-5f) / tot; cdf[i + 1] = c; }
   for (int i = 0; i < nb; ++i) bins[i] = 0.5f * (z[i + 1] + z[i]);
   for (int k = 0; k < Nf; ++k) {
-    const float u = (stratified && u_rand) ? u_rand[(size_t)r * Nf + k] : (Nf > 1 ? (float)k / (float)(Nf - 1) : 0.f);
+    const float u = stratified ? (u_rand ? u_rand[(size_t)r * Nf + k] : nerfds::sample_uniform(seed, first_ray + r, 1, k))
+                               : (Nf > 1 ? (float)k / (float)(Nf - 1) : 0.f);
     int lo = 0, hi = nb;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
     int k0 = lo - 1; if (k0 < 0) k0 = 0;
@@ -82,7 +85,7 @@ __global__ void k_resample(int R, int Nc, int Nf, const float* __restrict__ zc, 
 // The same, one wavefront per ray (Nc, Nf <= 256): the running sums stay serial (lane 0: the cdf must round exactly as the
 // sequential cumsum does), the Nf inverse-cdf look-ups and the rank sort of the Nc + Nf depths are spread over the lanes.
 __global__ __launch_bounds__(64) void k_resample_wave(int R, int Nc, int Nf, const float* __restrict__ zc, const float* __restrict__ wc, int stratified,
-                                                      const float* __restrict__ u_rand, float* __restrict__ zf) {
+                                                      const float* __restrict__ u_rand, uint64_t seed, long long first_ray, float* __restrict__ zf) {
   __shared__ float cdf[256], bins[256], zall[512];
   const int r = blockIdx.x, lane = threadIdx.x;
   const float* z = zc + (size_t)r * Nc;
@@ -99,7 +102,8 @@ __global__ __launch_bounds__(64) void k_resample_wave(int R, int Nc, int Nf, con
   }
   __syncthreads();
   for (int k = lane; k < Nf; k += 64) {
-    const float u = (stratified && u_rand) ? u_rand[(size_t)r * Nf + k] : (Nf > 1 ? (float)k / (float)(Nf - 1) : 0.f);
+    const float u = stratified ? (u_rand ? u_rand[(size_t)r * Nf + k] : nerfds::sample_uniform(seed, first_ray + r, 1, k))
+                               : (Nf > 1 ? (float)k / (float)(Nf - 1) : 0.f);
     int lo = 0, hi = nb;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
     int k0 = lo - 1; if (k0 < 0) k0 = 0;
@@ -797,12 +801,12 @@ __global__ void k_clip_norm(float* __restrict__ g, long long n, float max_norm, 
 static inline dim3 grid1(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 #define LAUNCH(kern, n, stream, ...) hipLaunchKernelGGL(kern, grid1(n), dim3(256), 0, stream, __VA_ARGS__)
 
-void coarse_z(hipStream_t st, int R, int Nc, float near_, float far_, int stratified, const float* t_rand, float* z) {
-  LAUNCH(k_coarse_z, (long long)R * Nc, st, R, Nc, near_, far_, stratified, t_rand, z);
+void coarse_z(hipStream_t st, int R, int Nc, float near_, float far_, int stratified, const float* t_rand, uint64_t seed, long long first_ray, float* z) {
+  LAUNCH(k_coarse_z, (long long)R * Nc, st, R, Nc, near_, far_, stratified, t_rand, seed, first_ray, z);
 }
-void resample(hipStream_t st, int R, int Nc, int Nf, const float* zc, const float* wc, int stratified, const float* u_rand, float* zf, float* scratch) {
-  if (Nc <= 256 && Nf <= 256) hipLaunchKernelGGL(k_resample_wave, dim3(R), dim3(64), 0, st, R, Nc, Nf, zc, wc, stratified, u_rand, zf);
-  else hipLaunchKernelGGL(k_resample, grid1(R, 64), dim3(64), 0, st, R, Nc, Nf, zc, wc, stratified, u_rand, zf, scratch);
+void resample(hipStream_t st, int R, int Nc, int Nf, const float* zc, const float* wc, int stratified, const float* u_rand, uint64_t seed, long long first_ray, float* zf, float* scratch) {
+  if (Nc <= 256 && Nf <= 256) hipLaunchKernelGGL(k_resample_wave, dim3(R), dim3(64), 0, st, R, Nc, Nf, zc, wc, stratified, u_rand, seed, first_ray, zf);
+  else hipLaunchKernelGGL(k_resample, grid1(R, 64), dim3(64), 0, st, R, Nc, Nf, zc, wc, stratified, u_rand, seed, first_ray, zf, scratch);
 }
 void encode_inputs(hipStream_t st, const Dims& D, int R, int S, const float* o, const float* d, const float* z, const uint32_t* warp_id, int n_embeds,
                    const float* warp_tbl, const float* mask_tbl, const Windows& W, float* x, float* mask_in, float* warp_in, float* hyper_in) {

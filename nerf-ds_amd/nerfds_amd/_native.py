@@ -58,7 +58,7 @@ class Weights(C.Structure):
               ('mask_hidden', Dense * MAX_DEPTH), ('mask_out', Dense),
               ('warp_hidden', Dense * MAX_DEPTH), ('warp_w', Dense), ('warp_v', Dense),
               ('hyper_hidden', Dense * MAX_DEPTH), ('hyper_out', Dense),
-              ('nerf', NerfMlp * 2)]
+              ('nerf', NerfMlp * 2), ('embed_rows', C.c_int32)]
 
 
 class CameraStruct(C.Structure):
@@ -81,7 +81,7 @@ class Extra(C.Structure):
 
 
 class Rand(C.Structure):
-  _fields_ = [('t_rand', C.c_void_p), ('u_rand', C.c_void_p), ('seed', C.c_uint64)]
+  _fields_ = [('t_rand', C.c_void_p), ('u_rand', C.c_void_p), ('seed', C.c_uint64), ('first_ray', C.c_int64)]
 
 
 class Out(C.Structure):

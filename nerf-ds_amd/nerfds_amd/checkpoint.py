@@ -14,7 +14,7 @@ The state dict of ``model_utils.TrainState`` (model_utils.py:24-52) is
 ``{'optimizer': {'target': {'model': <params>}, 'state': {'step': ..., 'param_states': ...}}, 'nerf_alpha': ..., ...}``.
 PARITY UNPINNED for the byte format: no checkpoint file ships with the reference and flax cannot be imported here, so
 the reader is pinned only by the published format above (hand-assembled byte vectors in tests/test_checkpoint.py) and by
-round trips through the writer below (which exists for the tests and for exporting weights back to the reference).
+round trips through the writer below (which exists for the tests and for this package's own save / restore; the reference cannot load its files, see save_checkpoint).
 """
 from __future__ import annotations
 
@@ -157,7 +157,10 @@ def restore_checkpoint(path: str) -> Tuple[Dict[str, Any], Dict[str, float], int
 
 
 def save_checkpoint(ckpt_dir: str, params_model: Dict[str, Any], extra_params: Dict[str, float], step: int) -> str:
-  """Writes ``checkpoint_<step>`` in the same format (parameters + schedule scalars; Adam moments are not kept)."""
+  """Writes ``checkpoint_<step>`` in the same msgpack layout (parameters + schedule scalars) for THIS package's
+  ``restore_checkpoint``.  It is not a file the reference's train.py / eval.py / render.py can restore: flax 0.3.4's
+  ``restore_checkpoint(target=TrainState)`` goes through ``from_state_dict``, which wants every dataclass field and the Adam
+  ``param_states`` (mu / nu per leaf), and those are not written."""
   os.makedirs(ckpt_dir, exist_ok=True)
   state = {'optimizer': {'target': {'model': params_model}, 'state': {'step': np.int32(step)}}}
   for k in EXTRA_PARAM_KEYS:

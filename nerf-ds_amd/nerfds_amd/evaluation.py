@@ -108,33 +108,57 @@ def records_to_dict(rec: torch.Tensor, cfg) -> Dict[str, torch.Tensor]:
 
 
 def make_model_fn(model, use_predicted_norm: Optional[bool] = None, sharp_weights_std: float = 0.1,
-                  precision: Optional[str] = None, render_fn: Optional[Callable] = None) -> Callable:
+                  precision: Optional[str] = None, render_fn: Optional[Callable] = None,
+                  gather_levels=('fine',)) -> Callable:
   """The ``_model_fn`` of render.py:139-155: render the local shard, all-gather the per-ray records.
 
   ``render_fn(params, rays, extra_params, key) -> (rec_fine [R,26], rec_coarse or None)`` may be injected
   (the gloo CPU tests use a deterministic stand-in so the sharding/gather logic runs without a GPU).
+  ``gather_levels``: which levels of a two-level model are exchanged between the ranks (render_image returns 'fine'
+  unless ``default_ret_key`` says otherwise; pass ``('coarse',)`` or both for that case).
+
+  The returned callable has the reference's signature.  It also carries ``render_local`` (the same without the
+  exchange, optionally writing the records straight into caller-owned buffers) which ``render_image`` uses to
+  overlap the exchange of chunk i with the rendering of chunk i + 1.
   """
   cfg = model.cfg if model is not None else None
   upn = (cfg.predict_norm if use_predicted_norm is None else use_predicted_norm) if cfg is not None else False
 
-  def _default_render(params, rays_dict, extra_params, keys):
+  def _default_render(params, rays_dict, extra_params, keys, records_out=None):
     model.apply({'params': params}, rays_dict, extra_params, rngs={'coarse': keys[0], 'fine': keys[1]},
                 use_predicted_norm=upn, return_points=False, return_nv_details=False, mask_ratio=1,
-                sharp_weights_std=sharp_weights_std, precision=precision)
-    return model.last_records['fine'], model.last_records['coarse']
+                sharp_weights_std=sharp_weights_std, precision=precision, records_out=records_out)
+    return model.last_records.get('fine'), model.last_records['coarse']
 
   render = render_fn or _default_render
 
-  def model_fn(key_0, key_1, key_2, params, rays_dict, extra_params):
-    rec_fine, rec_coarse = render(params, rays_dict, extra_params, (key_0, key_1, key_2))
-    out = {}
-    if rec_coarse is not None:
-      out['coarse'] = rec_coarse     # kept local: the reference gathers it too but evaluation.py:121-126 drops it
-      out['fine'] = all_gather_records(rec_fine)
+  def render_local(key_0, key_1, key_2, params, rays_dict, extra_params, records_out=None):
+    """{'fine': rec, 'coarse': rec} (single-level model: {'coarse': rec}) of this rank's rays, no exchange."""
+    if render_fn is None:
+      rec_fine, rec_coarse = render(params, rays_dict, extra_params, (key_0, key_1, key_2), records_out)
     else:
-      out['coarse'] = all_gather_records(rec_fine)
+      rec_fine, rec_coarse = render(params, rays_dict, extra_params, (key_0, key_1, key_2))
+    if rec_fine is None or rec_coarse is None:        # single-level model: its only record is the 'coarse' level
+      return {'coarse': rec_coarse if rec_coarse is not None else rec_fine}
+    return {'fine': rec_fine, 'coarse': rec_coarse}
+
+  def model_fn(key_0, key_1, key_2, params, rays_dict, extra_params):
+    out = render_local(key_0, key_1, key_2, params, rays_dict, extra_params)
+    if 'fine' not in out:
+      return {'coarse': all_gather_records(out['coarse']), '_gathered': ('coarse',)}
+    # The reference all-gathers both levels and evaluation.py:121-126 then drops 'coarse'.  Here only the levels in
+    # `gather_levels` cross xGMI (default: the one render_image returns); the others stay the local shard and
+    # render_image refuses to return them.
+    out['_gathered'] = tuple(gather_levels)
+    for lv in gather_levels:
+      out[lv] = all_gather_records(out[lv])
     return out
 
+  model_fn.render_local = render_local
+  model_fn.gather_levels = tuple(gather_levels)
+  model_fn.on_device = render_fn is None
+  model_fn.device = model.device if model is not None else None
+  model_fn.levels = (('coarse', 'fine') if cfg.num_fine_samples > 0 else ('coarse',)) if cfg is not None else ('coarse', 'fine')
   return model_fn
 
 
@@ -145,6 +169,11 @@ def render_image(state, rays_dict, model_fn, device_count, rng, chunk=8192, defa
   ``rays_dict`` leaves have leading shape [H, W]; returns a dict of [H, W, ...] maps of the fine level
   (coarse when there is no fine level).  ``device_count`` is the number of ranks the chunk is sharded over
   and must equal the torch.distributed world size (1 without a process group).
+
+  With a ``make_model_fn`` callable on the GPU the frame is assembled in ONE device buffer: rays and ids are converted
+  once, every chunk's local shard is rendered on the compute stream (world 1: straight into the frame buffer), the
+  all-gather of chunk i runs on a side stream while chunk i + 1 renders, and the host copy - if asked for - happens
+  once at the end (the reference copies every chunk to the host, evaluation.py:126).
   """
   rank, world = _world()
   if device_count != world:
@@ -157,25 +186,94 @@ def render_image(state, rays_dict, model_fn, device_count, rng, chunk=8192, defa
   seed = int(np.asarray(rng).ravel()[-1]) if rng is not None else 0
   key_0, key_1, key_2 = (seed * 4 + 1) * world + rank, (seed * 4 + 2) * world + rank, (seed * 4 + 3) * world + rank
   params = state.optimizer.target['model']
-  ret_chunks = []
   num_batches = int(math.ceil(num_rays / chunk))
-  for batch_idx in range(num_batches):
-    ray_idx = batch_idx * chunk
-    chunk_rays = tree_map(lambda x: x[ray_idx:ray_idx + chunk], rays_dict)
-    num_chunk_rays = chunk_rays['origins'].shape[0]
-    padding, lo, hi = shard_bounds(num_chunk_rays, device_count, rank)
-    chunk_rays = tree_map(lambda x: pad_edge(x, padding)[lo:hi], chunk_rays)         # evaluation.py:99-118
-    model_out = model_fn(key_0, key_1, key_2, params, chunk_rays, state.extra_params)   # evaluation.py:119
-    ret_key = default_ret_key or ('fine' if 'fine' in model_out else 'coarse')          # evaluation.py:121-124
-    rec = model_out[ret_key]
-    if padding:
-      rec = rec[:-padding]                                                               # utils.unshard (utils.py:307-312)
-    ret_chunks.append(rec.cpu() if to_host else rec)                                     # evaluation.py:126
-  rec = torch.cat(ret_chunks, dim=0)
+  fast = getattr(model_fn, 'on_device', False) and hasattr(model_fn, 'render_local')
+  if fast:
+    rec = _render_image_device(state, rays_dict, model_fn, params, (key_0, key_1, key_2), num_rays, num_batches, chunk,
+                               device_count, rank, default_ret_key)
+    if to_host:
+      rec = rec.cpu()
+  else:
+    ret_chunks = []
+    for batch_idx in range(num_batches):
+      ray_idx = batch_idx * chunk
+      chunk_rays = tree_map(lambda x: x[ray_idx:ray_idx + chunk], rays_dict)
+      num_chunk_rays = chunk_rays['origins'].shape[0]
+      padding, lo, hi = shard_bounds(num_chunk_rays, device_count, rank)
+      chunk_rays = tree_map(lambda x: pad_edge(x, padding)[lo:hi], chunk_rays)         # evaluation.py:99-118
+      model_out = model_fn(key_0, key_1, key_2, params, chunk_rays, state.extra_params)   # evaluation.py:119
+      ret_key = default_ret_key or ('fine' if 'fine' in model_out else 'coarse')          # evaluation.py:121-124
+      if world > 1 and ret_key not in model_out.get('_gathered', (ret_key,)):
+        raise ValueError(f"level '{ret_key}' was not all-gathered by this model_fn: build it with make_model_fn(..., gather_levels=('{ret_key}',))")
+      rec = model_out[ret_key]
+      if padding:
+        rec = rec[:-padding]                                                               # utils.unshard (utils.py:307-312)
+      ret_chunks.append(rec.cpu() if to_host else rec)                                     # evaluation.py:126
+    rec = torch.cat(ret_chunks, dim=0)
   if cfg is None:
     return {'records': rec.reshape(*batch_shape, rec.shape[-1])}
   out = records_to_dict(rec, cfg)
   return {k: v.reshape(*batch_shape, *v.shape[1:]) for k, v in out.items()}             # evaluation.py:143-147
+
+
+def _render_image_device(state, rays_dict, model_fn, params, keys, num_rays, num_batches, chunk, device_count, rank,
+                         default_ret_key):
+  """The chunk loop of render_image on the GPU: [num_rays, 26] records of the returned level, on the device."""
+  dev = model_fn.device
+  world = device_count
+  ret_key = default_ret_key or model_fn.levels[-1]                                        # evaluation.py:121-124
+  if ret_key not in model_fn.levels:
+    raise KeyError(ret_key)
+  if world > 1 and len(model_fn.levels) > 1 and ret_key not in model_fn.gather_levels:
+    raise ValueError(f"level '{ret_key}' was not all-gathered by this model_fn: build it with make_model_fn(..., gather_levels=('{ret_key}',))")
+
+  # one conversion for the whole frame: the per-chunk slices below are contiguous views, so NerfModel.apply launches no
+  # conversion kernels per chunk
+  def to_dev(x):
+    return x.to(dev, torch.int32 if not x.dtype.is_floating_point else torch.float32).contiguous()
+  rays_dict = tree_map(to_dev, rays_dict)
+  frame = torch.empty((num_rays, N.RAY_REC), dtype=torch.float32, device=dev)
+  compute = torch.cuda.current_stream(dev)
+  if world == 1:
+    for batch_idx in range(num_batches):
+      ray_idx = batch_idx * chunk
+      chunk_rays = tree_map(lambda x: x[ray_idx:ray_idx + chunk], rays_dict)
+      n = chunk_rays['origins'].shape[0]
+      model_fn.render_local(*keys, params, chunk_rays, state.extra_params, records_out={ret_key: frame[ray_idx:ray_idx + n]})
+    return frame
+  # world > 1: the local shard of chunk i is rendered into one of two staging buffers on the compute stream; its exchange
+  # (ONE all-gather of [R_c / D, 26], render.py:155) runs on a side stream while chunk i + 1 renders into the other buffer
+  comm = torch.cuda.Stream(dev)
+  per_max = (min(chunk, num_rays) + world - 1) // world
+  staging = [torch.empty((per_max, N.RAY_REC), dtype=torch.float32, device=dev) for _ in range(2)]
+  done = [None, None]
+  for batch_idx in range(num_batches):
+    ray_idx = batch_idx * chunk
+    chunk_rays = tree_map(lambda x: x[ray_idx:ray_idx + chunk], rays_dict)
+    n = chunk_rays['origins'].shape[0]
+    padding, lo, hi = shard_bounds(n, device_count, rank)
+    if padding:
+      chunk_rays = tree_map(lambda x: pad_edge(x, padding), chunk_rays)                 # evaluation.py:99-107
+    local = tree_map(lambda x: x[lo:hi], chunk_rays)
+    slot, per = batch_idx & 1, hi - lo
+    if done[slot] is not None:
+      compute.wait_event(done[slot])                         # the exchange of chunk i - 2 has read this buffer
+    rec = staging[slot][:per]
+    model_fn.render_local(*keys, params, local, state.extra_params, records_out={ret_key: rec})
+    ready = torch.cuda.Event()
+    ready.record(compute)
+    with torch.cuda.stream(comm):
+      comm.wait_event(ready)
+      if padding == 0:
+        dist.all_gather_into_tensor(frame[ray_idx:ray_idx + n], rec)
+      else:
+        full = torch.empty((world * per, N.RAY_REC), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(full, rec)
+        frame[ray_idx:ray_idx + n].copy_(full[:n])                                       # utils.unshard: drop the padding
+      done[slot] = torch.cuda.Event()
+      done[slot].record(comm)
+  compute.wait_stream(comm)
+  return frame
 
 
 render_image_on_rays = render_image   # the name BASELINE.json's north_star uses for the same surface

@@ -89,7 +89,7 @@ def render_frame(model, variables, camera, warp_id: int, extra_params, *, gt_mas
   mask = None
   if gt_mask is not None:
     mask = (gt_mask if isinstance(gt_mask, torch.Tensor) else torch.as_tensor(np.asarray(gt_mask))).to(dev, torch.float32).reshape(-1)
-  level = 'fine' if cfg.num_fine_samples > 0 else 'coarse'
+  level = 'fine' if cfg.num_fine_samples > 0 else 'coarse'      # NerfModel.last_records is keyed by the real level names
   for ci, first in enumerate(range(0, n, chunk)):
     cnt = min(chunk, n - first)
     rays = {'camera': camera, 'pixel_range': (first, cnt),

@@ -76,20 +76,32 @@ class _WeightsHolder:
 
     def dense(dst, p):
       k, b = arr(p['kernel']), arr(p['bias'])
+      if k.ndim != 2 or b.shape != (k.shape[1],):
+        raise ValueError(f'Dense parameters must be a [in, out] kernel and an [out] bias, got {k.shape} and {b.shape}')
       dst.kernel, dst.bias = k.ctypes.data, b.ctypes.data
       dst.in_dim, dst.out_dim = k.shape
+
+    def table(p, name):
+      # the library copies num_warp_embeds * glo_num_dims floats from this pointer: a smaller table would be over-read
+      e = arr(p['embed']['embedding'])
+      if e.shape != (cfg.num_warp_embeds, cfg.glo_num_dims):
+        raise ValueError(f'{name}/embed/embedding has shape {e.shape}, the model configuration says '
+                         f'({cfg.num_warp_embeds}, {cfg.glo_num_dims}) (num_warp_embeds, glo_num_dims)')
+      return e
 
     def mlp(dst_hidden, tree, depth):
       for i in range(depth):
         dense(dst_hidden[i], tree[f'hidden_{i}'])
 
     if cfg.use_warp:
-      w.warp_embed = arr(params['warp_embed']['embed']['embedding']).ctypes.data
+      w.warp_embed = table(params['warp_embed'], 'warp_embed').ctypes.data
+      w.embed_rows = cfg.num_warp_embeds
       mlp(w.warp_hidden, params['warp_field']['trunk'], cfg.warp_trunk.depth)
       dense(w.warp_w, params['warp_field']['branches_w']['logit'])
       dense(w.warp_v, params['warp_field']['branches_v']['logit'])
     if cfg.use_predicted_mask:
-      w.mask_embed = arr(params['mask_embed']['embed']['embedding']).ctypes.data
+      w.mask_embed = table(params['mask_embed'], 'mask_embed').ctypes.data
+      w.embed_rows = cfg.num_warp_embeds
       mlp(w.mask_hidden, params['mask_mlp']['MLP_0'], cfg.mask_mlp.depth)
       dense(w.mask_out, params['mask_mlp']['MLP_0']['logit'])
     if cfg.has_hyper:
@@ -141,7 +153,7 @@ class NerfModel:
         raise NotImplementedError(msg)
       raise RuntimeError(f'nerfds_ctx_create failed ({rc}): {msg}')
     self._ctx = ctx
-    self._params_id = None
+    self._params_ref = None       # the parameter tree the weight streams were packed from (strong reference)
     self._holder = None
 
   def __del__(self):
@@ -156,13 +168,16 @@ class NerfModel:
     return init_params(self.cfg, seed, **kw)
 
   def load_params(self, params: Dict[str, Any]) -> None:
-    """Packs ``params`` (the 'model' sub-tree of the checkpoint) into the MFMA weight streams."""
+    """Packs ``params`` (the 'model' sub-tree of the checkpoint) into the MFMA weight streams.  ``apply`` calls this
+    when it is handed a different tree OBJECT than the one packed last (the tree is kept alive, so an ``is`` test cannot
+    be fooled by a recycled address); leaves updated in place are not detected - call ``load_params`` again (or pass
+    ``reload_params=True`` to ``apply``)."""
     holder = _WeightsHolder(self.cfg, params)
     rc = self._lib.nerfds_ctx_load_weights(self._ctx, C.byref(holder.struct))
     if rc != 0:
       raise ValueError(f'nerfds_ctx_load_weights failed ({rc}): {N.last_error(self._ctx)}')
     self._holder = holder
-    self._params_id = id(params)
+    self._params_ref = params
 
   # -- NerfModel.__call__ -------------------------------------------------------------------------------
   def apply(self, variables: Dict[str, Any], rays_dict: Dict[str, Any], extra_params: Dict[str, Any], *,
@@ -170,17 +185,24 @@ class NerfModel:
             return_weights=False, return_samples=False, return_nv_details=True, near=None, far=None,
             use_sample_at_infinity=None, render_opts=None, use_sigma_gradient=False, use_predicted_norm=False,
             mask_ratio=1, sharp_weights_std=1.0, t_rand=None, u_rand=None, precision: Optional[str] = None,
-            stream: Optional[torch.cuda.Stream] = None):
+            stream: Optional[torch.cuda.Stream] = None, reload_params: bool = False, ray_offset: int = 0,
+            records_out: Optional[Dict[str, torch.Tensor]] = None):
+    """``records_out``: optional {'fine' | 'coarse': float32 device tensor [R, 26]} the per-ray records of that level are
+    written into (e.g. a slice of a frame buffer) instead of a fresh allocation.  ``ray_offset``: Philox counter of the first
+    ray (csrc/philox.h), so that a frame rendered in chunks draws what one call over all its rays would."""
     cfg = self.cfg
+    nf = cfg.num_fine_samples
     params = variables['params'] if 'params' in variables else variables
-    if id(params) != self._params_id:
+    reloaded = reload_params or params is not self._params_ref
+    if reloaded:
       self.load_params(params)
     if metadata_encoded:
       raise NotImplementedError('metadata_encoded=True (pre-encoded GLO vectors) is not built')
     if render_opts is not None:
       raise NotImplementedError('render_opts (dust_threshold / bounding_box, models.py:38-66) is not built')
-    if use_sigma_gradient:
-      raise NotImplementedError('use_sigma_gradient=True needs d sigma/dx, which the HIP path does not compute yet')
+    if use_sigma_gradient and not (cfg.use_warp and cfg.use_predicted_mask and cfg.has_hyper and nf > 0):
+      raise NotImplementedError('use_sigma_gradient=True (target_norm, models.py:1065-1077) is built for the nerf_ds graph: '
+                                'the tangent pass lives in the trainer, which covers only that graph')
     if bool(use_predicted_norm) != bool(cfg.predict_norm):
       raise ValueError('use_predicted_norm must equal NerfModel.predict_norm: the rgb branch width depends on it '
                        '(models.py:2707-2739 initialises the parameters with the same flag)')
@@ -218,8 +240,15 @@ class NerfModel:
     want_samples = bool(return_samples or return_weights or return_points)
     nc, nf = cfg.num_coarse_samples, cfg.num_fine_samples
     two = nf > 0
-    rec_fine = torch.empty((R, N.RAY_REC), device=dev, dtype=torch.float32)
-    rec_coarse = torch.empty((R, N.RAY_REC), device=dev, dtype=torch.float32) if two else None
+    def rec_buf(level):
+      buf = (records_out or {}).get(level)
+      if buf is None:
+        return torch.empty((R, N.RAY_REC), device=dev, dtype=torch.float32)
+      if buf.shape != (R, N.RAY_REC) or buf.dtype != torch.float32 or buf.device != dev or not buf.is_contiguous():
+        raise ValueError(f'records_out[{level!r}] must be a contiguous float32 [{R}, {N.RAY_REC}] tensor on {dev}')
+      return buf
+    rec_fine = rec_buf('fine' if two else 'coarse')            # the finest level of the model
+    rec_coarse = rec_buf('coarse') if two else None
     smp_fine = torch.empty((R, nc + nf, N.SAMPLE_REC), device=dev, dtype=torch.float32) if want_samples else None
     smp_coarse = torch.empty((R, nc, N.SAMPLE_REC), device=dev, dtype=torch.float32) if (want_samples and two) else None
     if t_rand is not None:
@@ -234,7 +263,7 @@ class NerfModel:
     extra = N.Extra(g('nerf_alpha'), g('warp_alpha'), g('hyper_alpha'), g('hyper_sheet_alpha'), g('norm_input_alpha'),
                     float(mask_ratio), float(cfg.near if near is None else near), float(cfg.far if far is None else far),
                     int(cfg.use_stratified_sampling))
-    rnd = N.Rand(ptr(t_rand), ptr(u_rand), _seed_from_rngs(rngs))
+    rnd = N.Rand(ptr(t_rand), ptr(u_rand), _seed_from_rngs(rngs), int(ray_offset))
     out = N.Out(ptr(rec_fine), ptr(rec_coarse), ptr(smp_fine), ptr(smp_coarse))
     flags = N.PREC[precision or self.precision]
     s = stream if stream is not None else torch.cuda.current_stream(dev)
@@ -254,7 +283,18 @@ class NerfModel:
         directions = cr['directions'].reshape(-1, 3)[first_pixel:first_pixel + R]
       ret[level] = self._unpack(rec, smp, S, batch_shape, origins, directions, return_points, return_weights,
                                 sharp_weights_std)
-    self.last_records = {'fine': rec_fine, 'coarse': rec_coarse}
+    if use_sigma_gradient:
+      # target_norm = normalize(R normalize(-d sigma / d x)) per sample (models.py:1065-1077, 1273-1277, 1328).  The fused render
+      # kernel does not carry tangents; the trainer's forward-mode pass does (csrc/nerfds_train.cpp sigma_gradient), on the same
+      # depths: injected uniforms are passed on, and the on-chip Philox stream is keyed identically in both (csrc/philox.h).
+      if camera is not None:
+        raise NotImplementedError('use_sigma_gradient with fused camera rays: pass origins / directions')
+      tn = self._target_norm(params, reloaded, origins, directions, viewdirs, warp_id, gt_mask, extra_params, float(mask_ratio),
+                             near, far, t_rand, u_rand, rnd.seed, int(ray_offset))
+      for level in ret:
+        ret[level]['target_norm'] = tn[level].reshape(*batch_shape, *tn[level].shape[1:])
+    # per-ray records by REAL level name (a single-level model has only 'coarse', as the reference's out dict)
+    self.last_records = {'fine': rec_fine, 'coarse': rec_coarse} if two else {'coarse': rec_fine}
     return ret
 
   __call__ = apply
@@ -292,6 +332,30 @@ class NerfModel:
       if not return_points:
         pass
     return {k: v.reshape(*batch_shape, *v.shape[1:]) for k, v in o.items()}
+
+  def _target_norm(self, params, reloaded, origins, directions, viewdirs, warp_id, gt_mask, extra_params, mask_ratio, near, far,
+                   t_rand, u_rand, seed, ray_offset):
+    from .training import Trainer
+    block = getattr(self, 'sigma_gradient_block', 4096)      # rays per pass of the trainer (its workspace is ~2.8 MB per ray)
+    tr = getattr(self, '_sg_trainer', None)
+    if tr is None:
+      tr = self._sg_trainer = Trainer(self.cfg, params, max_rays=block, device=self.device)
+    elif reloaded or getattr(self, '_sg_params', None) is not params:
+      tr.set_params(params)
+    self._sg_params = params
+    R = origins.shape[0]
+    out = {'coarse': [], 'fine': []}
+    for lo in range(0, R, block):
+      hi = min(lo + block, R)
+      sl = lambda t: None if t is None else t[lo:hi]
+      batch = dict(origins=origins[lo:hi], directions=directions[lo:hi], viewdirs=sl(viewdirs), metadata={'warp': warp_id[lo:hi]},
+                   mask=sl(gt_mask), rgb=torch.zeros((hi - lo, 3), device=self.device))
+      # one gradient-only step at lr 0: the parameters do not move; ray_offset keeps the Philox counters of the block in step
+      tr.step(batch, extra_params, 0.0, t_rand=sl(t_rand), u_rand=sl(u_rand), mask_ratio=mask_ratio, near=near, far=far,
+              grads_only=True, sigma_gradient=True, seed=int(seed), ray_offset=ray_offset + lo)
+      for level in out:
+        out[level].append(torch.as_tensor(tr.target_norm(level), device=self.device))
+    return {k: torch.cat(v, 0) for k, v in out.items()}
 
   # timing hooks for bench.py -------------------------------------------------------------------------
   def kernel_time_ms(self, reset: bool = False):

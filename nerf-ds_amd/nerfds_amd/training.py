@@ -169,8 +169,11 @@ class Trainer:
   def step(self, batch: Dict[str, Any], extra_params: Dict[str, Any], learning_rate: float = 0.0, *, t_rand=None, u_rand=None,
            mask_ratio: float = 1.0, near: Optional[float] = None, far: Optional[float] = None, grads_only: bool = False,
            sigma_gradient: bool = False, objective: Optional[Dict[str, float]] = None, grad_max_val: float = 0.0,
-           grad_max_norm: float = 0.0,
+           grad_max_norm: float = 0.0, seed: Optional[int] = None, ray_offset: int = 0,
            stream: Optional[torch.cuda.Stream] = None) -> Dict[str, float]:
+    """One optimisation step.  Sampling jitter (cfg.use_stratified_sampling; the reference always draws it,
+    model_utils.py:84,217): injected ``t_rand`` / ``u_rand``, else the on-chip Philox stream keyed by ``seed``; with
+    ``seed=None`` the trainer's own step counter is used, so that successive steps never sample the same depths."""
     dev = self.device
     f32 = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).to(dev, torch.float32).contiguous()
     origins = f32(batch['origins']).reshape(-1, 3)
@@ -188,7 +191,10 @@ class Trainer:
     ex = N.Extra(nerf_alpha=g('nerf_alpha'), warp_alpha=g('warp_alpha'), hyper_alpha=g('hyper_alpha'), hyper_sheet_alpha=g('hyper_sheet_alpha'),
                  norm_input_alpha=g('norm_input_alpha'), mask_ratio=float(mask_ratio), near=float(self.cfg.near if near is None else near),
                  far=float(self.cfg.far if far is None else far), use_stratified_sampling=int(self.cfg.use_stratified_sampling))
-    rnd = N.Rand(t_rand=None, u_rand=None, seed=0)
+    if seed is None:
+      self._auto_seed = getattr(self, '_auto_seed', 0) + 1
+      seed = (0x5DEECE66D * self._auto_seed + 0xB) & 0xFFFFFFFFFFFFFFFF
+    rnd = N.Rand(t_rand=None, u_rand=None, seed=int(seed) & 0xFFFFFFFFFFFFFFFF, first_ray=int(ray_offset))
     if t_rand is not None:
       t = f32(t_rand).reshape(R, self.cfg.num_coarse_samples); keep.append(t); rnd.t_rand = t.data_ptr()
     if u_rand is not None and self.cfg.num_fine_samples > 0:
@@ -237,5 +243,10 @@ def train_step(trainer: Trainer, rng_key, state, batch, scalar_params, **static_
   ``extra_params`` (evaluation.TrainState); ``scalar_params`` needs ``learning_rate`` and optionally ``mask_ratio``."""
   lr = float(getattr(scalar_params, 'learning_rate', scalar_params['learning_rate'] if isinstance(scalar_params, dict) else 0.0))
   mr = getattr(scalar_params, 'mask_ratio', scalar_params.get('mask_ratio', 1.0) if isinstance(scalar_params, dict) else 1.0)
-  stats = trainer.step(batch, state.extra_params, lr, mask_ratio=float(mr), t_rand=static_flags.get('t_rand'), u_rand=static_flags.get('u_rand'))
-  return state, stats, rng_key, None
+  # training.py:228 splits rng_key into (rng_key, fine_key, coarse_key, reg_key) every step: here the key is an integer, the
+  # sampling seed of this step is derived from it and the advanced key is returned.
+  key = int(np.asarray(rng_key).ravel()[-1]) if rng_key is not None else 0
+  key = (key * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+  stats = trainer.step(batch, state.extra_params, lr, mask_ratio=float(mr), t_rand=static_flags.get('t_rand'), u_rand=static_flags.get('u_rand'),
+                       seed=key)
+  return state, stats, key, None

@@ -2,8 +2,10 @@
 on identical rays, weights and injected sampling uniforms.
 
 Tolerance (BASELINE.json north_star): composited RGB within 1e-4 relative of the reference semantics.  The
-fp32-MFMA kernel (exact fp32 fma chains) and the split-bf16 kernel are held to that bar; the plain-bf16 MFMA
-kernel's measured error is reported and bounded loosely (it cannot meet 1e-4 - see DESIGN.md "Precision").
+fp32-MFMA kernel (exact fp32 fma chains) and the split-bf16 kernel are held to that bar.  The one-MFMA-per-product
+kernels cannot meet it (profiles/r2_precision_budget.md: >= 16 significand bits are needed on both operands of every
+layer); their measured error is printed and bounded just above what was measured: bf16 3e-2 (8 significand bits: 2.0e-2 is
+the worst of these cases, 3.9e-2 the worst ray of 4096), f16 3e-3 (11 bits), mixed (f16 with the warp field in split bf16) 2e-3.
 """
 import ctypes as C
 import sys
@@ -18,7 +20,8 @@ from oracle import nerfds_oracle as O
 pytestmark = pytest.mark.gpu
 
 EXTRA = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
-RTOL = {'f32': 1e-4, 'bf16x3': 1e-4, 'bf16': 6e-2}
+RTOL = {'f32': 1e-4, 'bf16x3': 1e-4, 'bf16': 3e-2, 'f16': 3e-3, 'mixed': 2e-3}
+FAST = ('bf16', 'f16', 'mixed')      # throughput arithmetic: composited maps only, bounded by RTOL
 
 
 def _rays(R, n_ids, seed, spread=0.1):
@@ -53,7 +56,7 @@ def test_extension_is_loaded_and_mfma_layout():
   assert any('libnerfds_hip' in l for l in open('/proc/self/maps'))
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
 def test_nerf_ds_graph_tiny(prec):
   cfg = nerf_ds_config(num_warp_embeds=4, num_coarse_samples=8, num_fine_samples=8)
   params = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
@@ -67,11 +70,11 @@ def test_nerf_ds_graph_tiny(prec):
   tol = RTOL[prec]
   for level in ('coarse', 'fine'):
     r, g = ref[level], {k: v.cpu().numpy() for k, v in out[level].items()}
-    if prec == 'bf16':       # throughput arithmetic: only the composited maps, loosely (measured error is printed)
+    if prec in FAST:         # throughput arithmetic: only the composited maps (measured error is printed)
       for k in ('rgb', 'depth', 'acc', 'ray_delta_x', 'ray_predicted_mask'):
         e = _relerr(g[k], r[k].numpy())
         print(f'{prec} {level} {k}: {e:.2e}', file=sys.stderr)
-        assert e <= tol, (level, k, e)
+        assert e <= (tol if k == 'rgb' else 4 * tol), (level, k, e)
       continue
     assert np.allclose(g['z_vals'], r['z_vals'].numpy(), rtol=2e-6, atol=1e-6), level
     for k in ('sigma', 'predicted_mask', 'warped_points', 'predicted_norm', 'sample_rgb', 'weights', 'alpha',
@@ -87,7 +90,7 @@ def test_nerf_ds_graph_tiny(prec):
       assert e <= lim, (level, k, e)
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
 def test_nerf_ds_graph_full_samples_init_regime(prec):
   """64 + 64 samples (nerf_ds.gin), freshly initialised weights: theta ~ 1e-4 stresses exp_se3 (quirk 5)."""
   cfg = nerf_ds_config(num_warp_embeds=8)
@@ -104,7 +107,7 @@ def test_nerf_ds_graph_full_samples_init_regime(prec):
     assert torch.isfinite(out[level]['ray_delta_x']).all()
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
 def test_nerf_ds_graph_256_samples_per_ray(prec):
   """BASELINE.json configs[4] shape: 128 coarse + 128 fine (256 on the fine pass) - the WIDE kernel shape
   (2 rays per workgroup, twice the waves per ray)."""
@@ -139,7 +142,8 @@ def test_nerf_ds_trained_regime_and_deterministic_sampling():
         assert e <= (1e-4 if k == 'rgb' else 1e-3), (prec, level, k, e)
 
 
-def test_windows_partially_open():
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'f16'])
+def test_windows_partially_open(prec):
   """warp_alpha / nerf_alpha mid-schedule: fractional Hann windows on the top bands (model_utils.py:420-436)."""
   cfg = nerf_ds_config(num_warp_embeds=2, num_coarse_samples=16, num_fine_samples=16)
   params = init_params(cfg, 4, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
@@ -148,8 +152,44 @@ def test_windows_partially_open():
   rays, rng = _rays(R, 2, 5)
   t, u = rng.random((R, 16)), rng.random((R, 16))
   ref = O.NerfModel(cfg, params).apply(rays, extra, t_rand=t, u_rand=u, use_predicted_norm=True, compute_sigma_gradient=False)
-  out = _model(cfg).apply({'params': params}, rays, extra, t_rand=t, u_rand=u, use_predicted_norm=True, precision='f32')
-  assert _relerr(out['fine']['rgb'].cpu().numpy(), ref['fine']['rgb'].numpy()) <= 1e-4
+  out = _model(cfg).apply({'params': params}, rays, extra, t_rand=t, u_rand=u, use_predicted_norm=True, precision=prec)
+  for level in ('coarse', 'fine'):
+    e = _relerr(out[level]['rgb'].cpu().numpy(), ref[level]['rgb'].numpy())
+    print(f'windows {prec} {level} rgb: {e:.2e}', file=sys.stderr)
+    assert e <= RTOL[prec], (level, e)
+
+
+@pytest.mark.parametrize('graph', ['nerf_ds', 'static', 'hypernerf'])
+@pytest.mark.parametrize('white,infinity', [(True, True), (False, False), (True, False)])
+def test_white_background_and_no_sample_at_infinity(graph, white, infinity):
+  """use_white_background (model_utils.py:144-145; BASELINE config 1 is a Lego-style, i.e. white-background, scene) and
+  use_sample_at_infinity=False (last delta 1e-19 instead of 1e10, model_utils.py:124-126; acc then includes the last
+  sample, :147-148) on all three compiled graphs, fp32-MFMA and split-bf16 kernels against the oracle."""
+  from nerfds_amd import hypernerf_config
+  kw = dict(use_white_background=white, use_sample_at_infinity=infinity)
+  if graph == 'static':
+    cfg = static_config(**kw)
+  elif graph == 'hypernerf':
+    cfg = hypernerf_config(num_warp_embeds=3, num_coarse_samples=16, num_fine_samples=16, **kw)
+  else:
+    cfg = nerf_ds_config(num_warp_embeds=3, num_coarse_samples=16, num_fine_samples=16, **kw)
+  params = init_params(cfg, 7, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  R = 21
+  rays, rng = _rays(R, 3, 31, spread=0.2)
+  nc, nf = cfg.num_coarse_samples, cfg.num_fine_samples
+  t, u = rng.random((R, nc)), rng.random((R, max(nf, 1)))
+  ref = O.NerfModel(cfg, params).apply(rays, EXTRA, t_rand=t, u_rand=u if nf else None, use_predicted_norm=cfg.predict_norm,
+                                       compute_sigma_gradient=False)
+  m = _model(cfg)
+  for prec in ('f32', 'bf16x3'):
+    out = m.apply({'params': params}, rays, EXTRA, t_rand=t, u_rand=u if nf else None, use_predicted_norm=cfg.predict_norm,
+                  precision=prec)
+    for level in ref:
+      for k in ('rgb', 'depth', 'med_depth', 'acc'):
+        e = _relerr(out[level][k].cpu().numpy(), ref[level][k].numpy())
+        assert e <= (1e-4 if k == 'rgb' else 1e-3), (prec, level, k, e)
+    if white:       # a ray that hits nothing is white, not black
+      assert float(out[sorted(ref)[-1]]['rgb'].max()) <= 1.0 + 1e-5
 
 
 def test_mask_ratio_blends_gt_mask():
@@ -271,3 +311,49 @@ def test_frame_properties_at_config2_size():
   rp = {k: (v[perm] if k != 'metadata' else {'warp': v['warp'][perm]}) for k, v in rays.items()}
   b = m.apply({'params': params}, rp, EXTRA, t_rand=t[perm], u_rand=u[perm], use_predicted_norm=True)['fine']['rgb']
   assert torch.equal(a[perm], b)
+
+
+def test_render_frame_of_a_coarse_only_model():
+  """frames.render_frame on the static coarse-only graph (NerfModel.last_records is keyed by the real level names)."""
+  from nerfds_amd.camera import Camera
+  from nerfds_amd.frames import render_frame
+  import os
+  cam = Camera.from_json(os.path.join(os.path.dirname(__file__), 'golden', 'reference_testdata_camera.json')).scale(0.05)
+  cfg = static_config(near=0.5, far=3.0)
+  params = init_params(cfg, 0, bias_scale=0.05)
+  m = _model(cfg)
+  rgb, dbg, rec = render_frame(m, {'params': params}, cam, 0, EXTRA, want_debug=False, precision='f32')
+  H, W = cam.image_shape
+  assert rgb.shape == (H, W, 3) and rec.shape == (H * W, 26) and torch.isfinite(rec).all()
+  assert set(m.last_records) == {'coarse'}
+
+
+def test_params_are_repacked_for_a_new_tree_and_tables_are_shape_checked():
+  """apply() re-packs when it is handed another parameter tree object (temporaries included: the packed tree is kept alive,
+  so a recycled address cannot alias it), reload_params=True covers in-place edits, and GLO tables / biases whose shapes
+  disagree with the configuration are rejected before the library reads them."""
+  import copy
+  cfg = nerf_ds_config(num_warp_embeds=3, num_coarse_samples=8, num_fine_samples=8)
+  p0 = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  m = _model(cfg)
+  rays, rng = _rays(5, 3, 2)
+  kw = dict(use_predicted_norm=True, t_rand=np.full((5, 8), .5), u_rand=np.full((5, 8), .5), precision='f32')
+  a = m.apply({'params': p0}, rays, EXTRA, **kw)['fine']['rgb'].clone()
+  outs = []
+  for seed in (1, 2, 3):       # temporaries: each tree is freed after the call, CPython readily reuses the address
+    outs.append(m.apply({'params': init_params(cfg, seed, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)}, rays, EXTRA, **kw)['fine']['rgb'].clone())
+  assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2]) and not torch.equal(a, outs[0])
+  p1 = copy.deepcopy(p0)
+  b = m.apply({'params': p1}, rays, EXTRA, **kw)['fine']['rgb'].clone()
+  assert torch.equal(a, b)
+  p1['nerf_mlps_fine']['rgb_mlp']['logit']['bias'] = np.asarray(p1['nerf_mlps_fine']['rgb_mlp']['logit']['bias']) + 1.0
+  c = m.apply({'params': p1}, rays, EXTRA, reload_params=True, **kw)['fine']['rgb']
+  assert not torch.equal(b, c)
+  bad = copy.deepcopy(p0)
+  bad['warp_embed']['embed']['embedding'] = np.zeros((2, cfg.glo_num_dims), np.float32)       # fewer rows than num_warp_embeds
+  with pytest.raises(ValueError, match='num_warp_embeds'):
+    m.apply({'params': bad}, rays, EXTRA, **kw)
+  bad = copy.deepcopy(p0)
+  bad['mask_mlp']['MLP_0']['hidden_0']['bias'] = np.zeros((7,), np.float32)
+  with pytest.raises(ValueError, match='bias'):
+    m.apply({'params': bad}, rays, EXTRA, **kw)

@@ -162,3 +162,27 @@ def test_nerf_mlp_stream_matches_oracle(graph, level, prec):
   assert np.allclose(_unchunk_tiles(trunk), t_ref.numpy(), atol=atol)
   assert np.allclose(alpha.T, a_ref.numpy(), atol=atol)
   assert np.allclose(rgb.T, r_ref.numpy(), atol=atol)
+
+
+def test_weights_holder_rejects_tables_and_biases_of_the_wrong_shape():
+  """The render path copies num_warp_embeds * glo_num_dims floats from the GLO table pointers: a table of another shape must
+  be refused before the library reads it (and nerfds_weights.embed_rows lets the library check it again)."""
+  import copy
+  cfg = nerf_ds_config(num_warp_embeds=5)
+  p = init_params(cfg, 0)
+  h = _WeightsHolder(cfg, p)
+  assert h.struct.embed_rows == 5
+  bad = copy.deepcopy(p)
+  bad['warp_embed']['embed']['embedding'] = np.zeros((3, 8), np.float32)
+  with pytest.raises(ValueError, match='num_warp_embeds'):
+    _WeightsHolder(cfg, bad)
+  bad = copy.deepcopy(p)
+  bad['nerf_mlps_coarse']['alpha_mlp']['logit']['bias'] = np.zeros((7,), np.float32)
+  with pytest.raises(ValueError, match='bias'):
+    _WeightsHolder(cfg, bad)
+  # the library's own check (host-only entry point): a holder whose row count disagrees with the configuration
+  lib = N.load()
+  cs = _cfg_struct(cfg)
+  h.struct.embed_rows = 4
+  assert lib.nerfds_pack_stream(C.byref(cs), C.byref(h.struct), 0, 0, 0, None, None) == -22
+  assert 'num_warp_embeds' in N.last_error(None)

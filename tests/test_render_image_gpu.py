@@ -1,0 +1,179 @@
+"""The drop-in top level on the GPU: evaluation.render_image + make_model_fn(model) with the real fused kernel
+(hypernerf/evaluation.py:53-149, render.py:139-174), on one rank and - BASELINE config 3 - with a chunk split over two ranks
+and exchanged by ONE RCCL all-gather of the per-ray records; the trainer's on-chip sampling jitter; target_norm on the
+render surface."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.join(os.path.dirname(__file__), '..')
+sys.path.insert(0, os.path.join(ROOT, 'nerf-ds_amd'))
+sys.path.insert(0, ROOT)
+from nerfds_amd import init_params, nerf_ds_config                  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+EXTRA = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
+
+
+def _frame_rays(H, W, n_ids, seed):
+  rng = np.random.default_rng(seed)
+  d = rng.normal(size=(H, W, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+  return dict(origins=(rng.normal(size=(H, W, 3)) * 0.1).astype(np.float32), directions=d.astype(np.float32), viewdirs=d.astype(np.float32),
+              metadata={'warp': rng.integers(0, n_ids, (H, W, 1))}, mask=(rng.random((H, W, 1)) < 0.3).astype(np.float32))
+
+
+def _setup(stratified):
+  cfg = nerf_ds_config(num_warp_embeds=4, num_coarse_samples=16, num_fine_samples=16, use_stratified_sampling=stratified)
+  params = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  return cfg, params
+
+
+def test_render_image_top_level_matches_model_apply_and_the_oracle():
+  """render_image(state, rays[H, W], make_model_fn(model), device_count=1, chunk) with the real kernel: equals one model.apply
+  over the frame bit for bit (deterministic sampling; chunking must not change a ray), and the oracle on a sub-grid within 1e-4."""
+  from nerfds_amd.evaluation import TrainState, make_model_fn, render_image
+  from nerfds_amd.model import NerfModel
+  from oracle import nerfds_oracle as O
+  cfg, params = _setup(False)
+  H, W = 37, 53                                        # 1961 rays: chunks of 512 leave a ragged last chunk
+  rays = _frame_rays(H, W, 4, 0)
+  model = NerfModel(cfg, device=torch.device('cuda', 0), precision='f32')
+  state = TrainState.create(params, **EXTRA)
+  fn = make_model_fn(model, precision='f32')
+  out = render_image(state, rays, fn, device_count=1, rng=np.array([0, 3]), chunk=512, cfg=cfg)
+  assert out['rgb'].shape == (H, W, 3) and out['med_points'].shape == (H, W, 1, 5) and not out['rgb'].is_cuda   # host copy, once
+  whole = model.apply({'params': params}, rays, EXTRA, use_predicted_norm=True, precision='f32')['fine']
+  for k in ('rgb', 'depth', 'med_depth', 'acc', 'ray_delta_x', 'ray_predicted_mask', 'med_points'):
+    assert torch.equal(out[k], whole[k].cpu()), k
+  dev_out = render_image(state, rays, fn, device_count=1, rng=np.array([0, 3]), chunk=512, cfg=cfg, to_host=False)
+  assert dev_out['rgb'].is_cuda and torch.equal(dev_out['rgb'].cpu(), out['rgb'])
+  coarse = render_image(state, rays, fn, device_count=1, rng=None, chunk=700, cfg=cfg, default_ret_key='coarse')
+  grid = lambda v: v[::6, ::7].reshape(-1, v.shape[-1])
+  sub = {k: (grid(v) if k != 'metadata' else {'warp': grid(v['warp'])}) for k, v in rays.items()}
+  ref = O.NerfModel(cfg, params).apply(sub, EXTRA, use_predicted_norm=True, compute_sigma_gradient=False)
+  for level, got in (('fine', out), ('coarse', coarse)):
+    e = float((grid(got['rgb']) - ref[level]['rgb'].float()).abs().max() / ref[level]['rgb'].abs().max())
+    assert e <= 1e-4, (level, e)
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _nccl_worker(rank, world, port, q):
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+  import torch.distributed as dist
+  torch.cuda.set_device(rank)
+  dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+  try:
+    from nerfds_amd.evaluation import TrainState, make_model_fn, render_image
+    from nerfds_amd.model import NerfModel
+    cfg, params = _setup(False)
+    rays = _frame_rays(23, 41, 4, 1)                     # 943 rays: chunk 300 -> odd chunk sizes, padding on the last chunk
+    model = NerfModel(cfg, device=torch.device('cuda', rank), precision='f32')
+    out = render_image(TrainState.create(params, **EXTRA), rays, make_model_fn(model, precision='f32'), device_count=world,
+                       rng=np.array([0, 1]), chunk=300, cfg=cfg)
+    q.put((rank, out['rgb'].numpy(), out['depth'].numpy()))
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='BASELINE config 3 needs two GPUs (ray shard + RCCL all-gather)')
+def test_render_image_two_ranks_nccl():
+  import torch.multiprocessing as mp
+  from nerfds_amd.model import NerfModel
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  got = dict((r, (a, b)) for r, a, b in (q.get(timeout=300) for _ in range(2)))
+  for p in procs:
+    p.join(60)
+  cfg, params = _setup(False)
+  rays = _frame_rays(23, 41, 4, 1)
+  whole = NerfModel(cfg, device=torch.device('cuda', 0), precision='f32').apply({'params': params}, rays, EXTRA, use_predicted_norm=True,
+                                                                                 precision='f32')['fine']
+  for r in range(2):     # every rank holds the whole frame, identical to the unsharded render
+    assert np.array_equal(got[r][0], whole['rgb'].cpu().numpy()) and np.array_equal(got[r][1], whole['depth'].cpu().numpy())
+
+
+def test_chunked_philox_frame_equals_one_call():
+  """nerfds_rand.first_ray: a frame rendered in chunks with ray_offset draws the jitter one call over all rays draws."""
+  from nerfds_amd.model import NerfModel
+  cfg, params = _setup(True)
+  rays = {k: (v.reshape(-1, v.shape[-1]) if k != 'metadata' else {'warp': v['warp'].reshape(-1, 1)}) for k, v in _frame_rays(9, 11, 4, 2).items()}
+  m = NerfModel(cfg, device=torch.device('cuda', 0), precision='f32')
+  kw = dict(use_predicted_norm=True, precision='f32', rngs={'coarse': 5, 'fine': 6})
+  whole = m.apply({'params': params}, rays, EXTRA, **kw)['fine']['rgb']
+  parts = []
+  for lo in range(0, 99, 40):
+    sl = {k: (v[lo:lo + 40] if k != 'metadata' else {'warp': v['warp'][lo:lo + 40]}) for k, v in rays.items()}
+    parts.append(m.apply({'params': params}, sl, EXTRA, ray_offset=lo, **kw)['fine']['rgb'])
+  assert torch.equal(torch.cat(parts), whole)
+
+
+def test_trainer_draws_the_stratified_jitter_on_chip():
+  """Trainer.step without injected uniforms (the reference always draws them, model_utils.py:84,217): the Philox stream of
+  csrc/philox.h - every step other depths, the same depths as the render kernel for the same seed, one sample per stratum."""
+  from nerfds_amd.model import NerfModel
+  from nerfds_amd.training import Trainer
+  cfg, params = _setup(True)
+  R = 64
+  f = _frame_rays(8, 8, 4, 3)
+  batch = {k: (v.reshape(R, -1) if k != 'metadata' else {'warp': v['warp'].reshape(R, 1)}) for k, v in f.items()}
+  batch['rgb'] = np.random.default_rng(0).random((R, 3)).astype(np.float32)
+  tr = Trainer(cfg, params, max_rays=R)
+  a = tr.step(batch, EXTRA, 0.0, grads_only=True)['loss/total']
+  b = tr.step(batch, EXTRA, 0.0, grads_only=True)['loss/total']
+  c = tr.step(batch, EXTRA, 0.0, grads_only=True, seed=1234)['loss/total']
+  d = tr.step(batch, EXTRA, 0.0, grads_only=True, seed=1234)['loss/total']
+  assert a != b and c == d                                # new jitter every step unless the seed is pinned
+  # same seed, same rays -> the fused render kernel composites the same depths: its MSE equals the trainer's loss
+  m = NerfModel(cfg, device=torch.device('cuda', 0), precision='f32')
+  import nerfds_amd.model as M
+  old = M._seed_from_rngs
+  M._seed_from_rngs = lambda rngs: 1234
+  try:
+    out = m.apply({'params': params}, batch, EXTRA, use_predicted_norm=True, precision='f32', rngs=None, return_samples=True)
+  finally:
+    M._seed_from_rngs = old
+  tgt = torch.as_tensor(batch['rgb'], device='cuda')
+  mse = float(((out['fine']['rgb'] - tgt) ** 2).mean() + ((out['coarse']['rgb'] - tgt) ** 2).mean())
+  assert abs(mse - c) < 2e-5 * max(1.0, mse), (mse, c)
+  z = out['coarse']['z_vals'].cpu().numpy()
+  edges = np.linspace(cfg.near, cfg.far, 16)
+  mids = 0.5 * (edges[1:] + edges[:-1])
+  assert np.all(z >= np.r_[edges[0], mids] - 1e-6) and np.all(z <= np.r_[mids, edges[-1]] + 1e-6) and np.ptp(z, axis=0).min() > 0
+
+
+def test_target_norm_on_the_render_surface():
+  """NerfModel.apply(use_sigma_gradient=True) (models.py:1065-1077, 1107-1111, 1328): out[level]['target_norm'] through the
+  trainer's tangent pass, in blocks, against the oracle's autograd."""
+  from nerfds_amd.model import NerfModel
+  from oracle import nerfds_oracle as O
+  cfg = nerf_ds_config(num_warp_embeds=4, num_coarse_samples=12, num_fine_samples=12)
+  params = init_params(cfg, 3, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  f = _frame_rays(5, 6, 4, 4)
+  rng = np.random.default_rng(1)
+  t, u = rng.random((30, 12)), rng.random((30, 12))
+  flat = {k: (v.reshape(30, -1) if k != 'metadata' else {'warp': v['warp'].reshape(30, 1)}) for k, v in f.items()}
+  ref = O.NerfModel(cfg, params).apply(flat, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, compute_sigma_gradient=True)
+  m = NerfModel(cfg, device=torch.device('cuda', 0), precision='f32')
+  m.sigma_gradient_block = 16                            # two blocks of 16 / 14 rays
+  out = m.apply({'params': params}, f, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, use_sigma_gradient=True, precision='f32')
+  for level, S in (('coarse', 12), ('fine', 24)):
+    got = out[level]['target_norm'].cpu().numpy()
+    assert got.shape == (5, 6, S, 3)
+    cos = (got.reshape(30, S, 3) * ref[level]['target_norm'].numpy()).sum(-1)
+    assert float((1 - cos > 1e-4).mean()) < 0.03 and np.median(1 - cos) < 1e-6, level
+    assert float((out[level]['rgb'].cpu() - ref[level]['rgb'].reshape(5, 6, 3).float()).abs().max()) <= 1e-4

@@ -1,8 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-A=$PWD/nerf-ds_amd/nerfds_amd/_lib/abl
 {
- timeout 900 python tools/ab.py bf16 3 main $A/libnerfds_hip_b_prio.so $A/libnerfds_hip_b_prio3.so $A/libnerfds_hip_b_r2.so
- timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline
-} > gpurun_out/ab.log 2>&1
-cat gpurun_out/ab.log
+ timeout 2400 python -m pytest tests/test_render_image_gpu.py "tests/test_gpu_parity.py::test_nerf_ds_graph_tiny" tests/test_training.py -k "top_level or tiny or multi_tile" -q -m gpu --tb=short 2>&1 | grep -v "^  " | tail -80
+} > gpurun_out/gputests.log 2>&1
+tail -90 gpurun_out/gputests.log
