@@ -31,6 +31,7 @@
 // A wave carries NT "N-tiles" of 32 samples (NT = 2 in bf16 mode: one weight fragment feeds two MFMAs).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "graphs.h"
 #include "kargs.h"
@@ -145,15 +146,22 @@ template <int P> DEVI void mma(f32x16& acc, const WFrag<P>& w, const Chunk<P>& c
 // units in flight LDS -> VGPR: consuming unit u issues the read of unit u + RD, whatever fragments those units belong
 // to.  Every index is a compile-time constant after unrolling.
 // ------------------------------------------------------------------------------------------------
-// NERFDS_NT = 2 (one-unit trunks only): two N-tiles per wave, i.e. every weight fragment read from LDS feeds two
-// MFMAs; the activations of the 256-wide trunk then need 256 registers, so one 512-register wave per SIMD.
+// NERFDS_NT = 2 (plans of one-unit networks only): two N-tiles per wave, i.e. every weight fragment read from LDS feeds two
+// MFMAs; the activations of the 256-wide trunk then need 256 registers, so one 512-register wave per SIMD, and with one wave
+// per SIMD the tile epilogues have to be software-pipelined into the MFMA chains (NERFDS_PIPE_EPI).  Built, correct
+// (deterministic, parity green) and measured: 16.2 ms (no pipelining) / 16.6 ms (pipelined, with the ordering point that makes
+// the MFMA -> VALU hazard safe by construction) per 65 536 rays against 15.8 ms for the default below on the same box;
+// an earlier build whose first piece could be scheduled right behind the previous group's last MFMA ran 15.2 ms - and gave
+// 1-2 % of the rays different values from run to run.  Default: one N-tile, 8 waves.
 #ifndef NERFDS_NT
 #define NERFDS_NT 1
 #endif
 template <int PM, int PW, int PH, int PT, int PR> struct PlanT {
   static constexpr int MASK = PM, WARP = PW, HYP = PH, TRUNK = PT, RGB = PR;
   static constexpr Plan value() { return Plan{PM, PW, PH, PT, PR}; }
-  static constexpr int NT = is_single(PT) ? NERFDS_NT : 1;
+  static constexpr bool UNIFORM = PM == PW && PW == PH && PH == PT && PT == PR;
+  // (plans that mix two-unit networks in keep one N-tile: a 128-wide split-bf16 network with two N-tiles is 256 registers of activations too)
+  static constexpr int NT = (is_single(PM) && is_single(PW) && is_single(PH) && is_single(PT) && is_single(PR)) ? NERFDS_NT : 1;
   // 8 waves (two per SIMD, 256 registers each) when the 256-wide trunk runs on one-unit operands with one N-tile; a
   // trunk on two-unit operands (or two N-tiles) needs > 256 registers of activations: one 512-register wave per SIMD.
   static constexpr bool EIGHT_WAVES = is_single(PT) && NT == 1;
@@ -225,14 +233,16 @@ template <class G, class PL> struct Pipe {
     // A COUNTED vmcnt(N) is NOT safe here: on gfx9-family VM_CNT, loads and stores complete out of order with respect
     // to each other, so a younger store (ray-record store, register spill) retiring early lets the count drop below N
     // while an older LDS-DMA is still in flight -> stale weights (seen as 2e-2 errors on the fine level).
-    // No lgkmcnt wait: the slot that is refilled belongs to stage s - 1, whose last unit this wave has already fed to
-    // an MFMA (DS returns in order, so every older read of that stage has returned as well); what is still in flight
-    // LDS -> VGPR are units of stage s, and draining them here would expose one full LDS latency per stage.
+    // lgkmcnt(0): every LDS read this wave has issued has returned before the barrier.  In program order the reads of the
+    // retiring stage s - 1 are all consumed by MFMAs above this point, but hipcc may sink a register-only MFMA - and with it the
+    // s_waitcnt of its operand read - BELOW the asm and the barrier; another wave's DMA into that slot would then race the read.
+    // (Waiting with vmcnt(0) only was 1.5 % faster and ran clean on the uniform kernels, but the mixed-precision kernel showed
+    // run-to-run differences with it: kept safe.)
     static_assert(NS == 4, "protocol is written for a 4-stage ring");
-#ifdef NERFDS_BOUNDARY_LGKM
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
+#ifdef NERFDS_BOUNDARY_NO_LGKM
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
     if (!(NERFDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();      // raw barrier (no compiler-added fences)
     if (NERFDS_DBG & 2) __builtin_amdgcn_s_sleep(4);
@@ -319,8 +329,10 @@ DEVI f32x16 load_bias(int t, int hb) {
 // the same accumulator, and anything issued between two MFMAs on the SAME accumulator (here: the LDS reads of the
 // weight ring and their waits) costs ~43 cycles on gfx950 instead of its issue slot (MI355X_MICROARCH.md, cycle
 // constants).  The B operand (activation chunk) is shared by the TP MFMAs.
-template <class G, class PL, int NT, int TP, int P, int K>
-DEVI void accum(f32x16 (&acc)[TP][NT], Pipe<G, PL>& pipe, Cursor& cur, const Chunk<P> (&in)[NT][K]) {
+// `slot(j, tp)` runs after the MFMAs of the j-th (chunk, tile) step of the tile group - the place where the previous group's
+// epilogue is issued when it is software-pipelined (dense()).
+template <class G, class PL, int NT, int TP, int P, int K, class SLOT>
+DEVI void accum(f32x16 (&acc)[TP][NT], Pipe<G, PL>& pipe, Cursor& cur, const Chunk<P> (&in)[NT][K], int& j, SLOT&& slot) {
   using PP = Pipe<G, PL>;
   constexpr int NP = frag_parts(P);
 #pragma unroll
@@ -338,6 +350,8 @@ DEVI void accum(f32x16 (&acc)[TP][NT], Pipe<G, PL>& pipe, Cursor& cur, const Chu
 #pragma unroll
       for (int q = 0; q < NP; ++q) pipe.refill(u + q);
       cur.pos += NP;
+      slot(j, tp);
+      ++j;
     }
   }
 }
@@ -369,6 +383,11 @@ DEVI void tile_epilogue(Chunk<P> (&out)[NT][W], int ot, const f32x16 (&acc)[NT])
 #ifndef NERFDS_ASM_EPILOGUE
 #define NERFDS_ASM_EPILOGUE 1
 #endif
+#ifdef NERFDS_EPI_TAIL_NOP
+#define NERFDS_EPI_TAIL "\n\ts_nop 1"
+#else
+#define NERFDS_EPI_TAIL ""
+#endif
 template <int P> DEVI void tile_epilogue_asm(Chunk<P>& c0, Chunk<P>& c1, const f32x16& a, bool wait) {
   static_assert(is_single(P), "packed-half epilogue");
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -377,7 +396,7 @@ template <int P> DEVI void tile_epilogue_asm(Chunk<P>& c0, Chunk<P>& c1, const f
   CVT " %0, %8, %9\n\t" CVT " %1, %10, %11\n\t" CVT " %2, %12, %13\n\t" CVT " %3, %14, %15\n\t"                            \
   CVT " %4, %16, %17\n\t" CVT " %5, %18, %19\n\t" CVT " %6, %20, %21\n\t" CVT " %7, %22, %23\n\t"                          \
   "v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0\n\tv_pk_max_i16 %2, %2, 0\n\tv_pk_max_i16 %3, %3, 0\n\t"              \
-  "v_pk_max_i16 %4, %4, 0\n\tv_pk_max_i16 %5, %5, 0\n\tv_pk_max_i16 %6, %6, 0\n\tv_pk_max_i16 %7, %7, 0"
+  "v_pk_max_i16 %4, %4, 0\n\tv_pk_max_i16 %5, %5, 0\n\tv_pk_max_i16 %6, %6, 0\n\tv_pk_max_i16 %7, %7, 0" NERFDS_EPI_TAIL
 #define NERFDS_EPI_OPS                                                                                                    \
   : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4), "=&v"(o5), "=&v"(o6), "=&v"(o7)                                \
   : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),          \
@@ -397,50 +416,223 @@ template <int P> DEVI void tile_epilogue_asm(Chunk<P>& c0, Chunk<P>& c1, const f
 #endif
 }
 
+template <class T> struct seg_chunks;
+template <int P, int NT, int K> struct seg_chunks<Chunk<P>[NT][K]> { static constexpr int value = K; };
+template <class... Ins> struct seg_total { static constexpr int value = (seg_chunks<Ins>::value + ... + 0); };
+
+// A quarter of tile_epilogue_asm: accumulator elements [4q, 4q + 4) -> two packed registers.  `order` is the accumulator the
+// MFMAs of the current slot have just written: as an in/out operand of this volatile asm it keeps the piece BELOW that MFMA and
+// above the next MFMA on the same accumulator, i.e. inside the chain (the wave's other MFMAs float around it freely).
+template <int P> DEVI void epilogue_piece_asm(unsigned& o0, unsigned& o1, float a0, float a1, float a2, float a3, f32x16& order) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (P == P_BF16)
+    asm volatile("v_cvt_pk_bf16_f32 %0, %3, %4\n\tv_cvt_pk_bf16_f32 %1, %5, %6\n\tv_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0"
+                 : "=&v"(o0), "=&v"(o1), "+v"(order) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+  else
+    asm volatile("v_cvt_pk_f16_f32 %0, %3, %4\n\tv_cvt_pk_f16_f32 %1, %5, %6\n\tv_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0"
+                 : "=&v"(o0), "=&v"(o1), "+v"(order) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+#endif
+}
+
 // One dense layer with OT output tiles of 32 features, computed TILE_PAIR tiles at a time (the stream interleaves the
 // fragments of the tiles of a pair chunk by chunk, pack.h); inputs are one or more chunk arrays in stream order (each
 // in its own precision), the output chunks are produced in the precision PO of the tensor they form.
-// The accumulators start from the bias (the first MFMA of a tile reads the bias registers as its C operand).
+// The accumulators start from the bias (the first MFMA of a tile reads the bias registers as its C operand; the N-tiles of
+// a wave share one copy).
+// NERFDS_PIPE_EPI (one-unit output formats): the epilogue of tile group g is cut into pieces of 4 VALU and issued inside the
+// MFMA chain of group g + 1, from its third slot on, each piece ordered behind the MFMA of its slot through that MFMA's
+// accumulator.  With ONE wave per SIMD (two N-tiles per wave) nothing else covers the ~100 instructions between two groups;
+// with two waves per SIMD the partner wave does, and it is off.
+#ifndef NERFDS_PIPE_EPI
+#define NERFDS_PIPE_EPI (NERFDS_NT > 1)
+#endif
+// Carrying a layer's last group into the next layer's first chain (dense(): Carry) is built and correct, but measured slower:
+// hipcc parks the 64 carried accumulators in scratch (857 scratch loads, each with a vmcnt(0) that also drains the LDS-DMA):
+// 19.9 ms (128-wide layers only) / 22.2 ms (all layers) against 15.2 ms without.  0 = every layer finishes its last group at once.
+#ifndef NERFDS_PIPE_J0
+#define NERFDS_PIPE_J0 2
+#endif
+#ifndef NERFDS_CARRY_MAX_OT
+#define NERFDS_CARRY_MAX_OT 0
+#endif
+// The epilogue of a layer's LAST tile group, carried into the first MFMA chain that follows (the next layer's first group, or
+// the head): its accumulators; the chunks it produces are the last 2 * TP chunks of that chain's first input array.
+template <int NT> struct Carry {
+  f32x16 acc[TILE_PAIR][NT];
+  bool live = false;
+};
+// issues pieces [q0, q1) of a pending group; chunk destination: dst[nt][first_chunk + 2 * tp + half]
+template <int P, int NT, int W>
+DEVI void pending_pieces(int q0, int q1, const f32x16 (&src)[TILE_PAIR][NT], unsigned (&pk)[TILE_PAIR][NT][8], Chunk<P> (&dst)[NT][W], int first_chunk,
+                         f32x16& order) {
+#pragma unroll
+  for (int q = q0; q < q1; ++q) {
+    if (q >= TILE_PAIR * NT * 4) break;
+    const int a = q / 4, i4 = q % 4, ptp = a / NT, pnt = a % NT;
+    const f32x16& x = src[ptp][pnt];
+    epilogue_piece_asm<P>(pk[ptp][pnt][2 * i4], pk[ptp][pnt][2 * i4 + 1], x[4 * i4], x[4 * i4 + 1], x[4 * i4 + 2], x[4 * i4 + 3], order);
+    if (i4 & 1) {          // a chunk (8 values) of the pending group is complete
+      const int hf = i4 >> 1;
+      const u32x4 r = {pk[ptp][pnt][4 * hf], pk[ptp][pnt][4 * hf + 1], pk[ptp][pnt][4 * hf + 2], pk[ptp][pnt][4 * hf + 3]};
+      dst[pnt][first_chunk + 2 * ptp + hf].v = __builtin_bit_cast(decltype(dst[0][0].v), r);
+    }
+  }
+}
+// Finishes a carried epilogue outside any chain (before code that reads the chunks with VALU, or at the end of a network whose
+// consumer is not a dense layer / head over those chunks).
+template <int P, int NT, int W> DEVI void flush_carry(Carry<NT>& carry, Chunk<P> (&dst)[NT][W]) {
+  if constexpr (is_single(P) && NERFDS_PIPE_EPI && NERFDS_ASM_EPILOGUE && !(NERFDS_ABLATE & 4)) {
+    if (carry.live) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+      for (int tp = 0; tp < TILE_PAIR; ++tp)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(carry.acc[tp][nt]));
+#endif
+#pragma unroll
+      for (int tp = 0; tp < TILE_PAIR; ++tp)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          tile_epilogue_asm<P>(dst[nt][W - 2 * TILE_PAIR + 2 * tp], dst[nt][W - 2 * TILE_PAIR + 2 * tp + 1], carry.acc[tp][nt], tp == 0 && nt == 0);
+    }
+  }
+  carry.live = false;
+}
+
+template <class A, class... Rest> DEVI A& first_of(A& a, Rest&...) { return a; }
+template <class T> struct chunk_prec;
+template <int P, int NT, int K> struct chunk_prec<Chunk<P>[NT][K]> { static constexpr int value = P; static constexpr int chunks = K; };
+
 template <class G, class PL, int NT, int OT, bool RELU, int PO, class... Ins>
-DEVI void dense(Pipe<G, PL>& pipe, Cursor& cur, Chunk<PO> (&out)[NT][2 * OT], const Ins&... ins) {
+DEVI void dense(Pipe<G, PL>& pipe, Cursor& cur, Carry<NT>& carry, Chunk<PO> (&out)[NT][2 * OT], Ins&... ins) {
   constexpr int TP = TILE_PAIR;
   static_assert(OT % TP == 0, "layers have an even number of 32-feature tiles");
+  // (uniform one-unit plans only: in the mixed plan - f16 networks around a split-bf16 warp field - the asm epilogue build gave
+  // run-to-run differences on ~1 % of the rays of the fine level; the C++ epilogue build of the same kernel is clean)
+  constexpr bool ASM_EPI = NERFDS_ASM_EPILOGUE && !(NERFDS_ABLATE & 4) && is_single(PO) && RELU && PL::UNIFORM;
   const int hb = bias_base(pipe.lane16);
+  auto no_slot = [](int, int) {};
+  if constexpr (ASM_EPI && NERFDS_PIPE_EPI) {
+    constexpr int SLOTS = TP * seg_total<Ins...>::value;       // (chunk, tile) steps per group
+    constexpr int NPIECE = TP * NT * 4, J0 = NERFDS_PIPE_J0;
+    constexpr int PPS = cdiv(NPIECE, SLOTS - J0 > 0 ? SLOTS - J0 : 1);
+    using In0 = std::remove_reference_t<decltype(first_of(ins...))>;
+    constexpr int PIN = chunk_prec<In0>::value, KIN = chunk_prec<In0>::chunks;
+    f32x16 prev[TP][NT];
+    unsigned pk[TP][NT][8];
 #pragma unroll
-  for (int ot = 0; ot < OT; ot += TP) {
-    f32x16 acc[TP][NT];
+    for (int ot = 0; ot < OT; ot += TP) {
+      f32x16 acc[TP][NT];
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) {
+        const f32x16 bv = load_bias(cur.bt + ot + tp, hb);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[tp][nt] = bv;
+      }
+      // Ordering point: the previous group's chains end above it, this group's chains (they read these bias-initialised
+      // accumulators as their first C operand) start below it.  The pieces are volatile asm ordered behind the MFMA of slot
+      // J0, i.e. at least 2 * J0 + 1 MFMAs below this point: the MFMA -> VALU hazard of the accumulators they read (12 wait
+      // states, not padded by hipcc for asm) is covered by construction, not by the scheduler's mood (with the previous
+      // group's last MFMA free to sink next to the first piece, 1-2 % of the rays came out different from run to run).
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (ot > 0) {
+        static_assert(TP == 2 && (NT == 1 || NT == 2), "ordering point written for 2 x NT accumulators");
+        if constexpr (NT == 2)
+          asm volatile("" : "+v"(prev[0][0]), "+v"(prev[0][1]), "+v"(prev[1][0]), "+v"(prev[1][1]),
+                            "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        else
+          asm volatile("" : "+v"(prev[0][0]), "+v"(prev[1][0]), "+v"(acc[0][0]), "+v"(acc[1][0]));
+      }
+#endif
+      int j = 0;
+      auto slot = [&](int jj, int tp_now) {
+        if (jj < J0) return;
+        if (ot == 0) {
+          // the previous layer's last group: its chunks are the tail of this layer's first input (consumed at the end of the chain)
+          if constexpr (is_single(PIN) && (KIN - 2 * TP) * TP - J0 > 0) {
+            // every piece must be issued before the slot that consumes the first carried chunk, (KIN - 2 TP) * TP
+            constexpr int CPPS = cdiv(NPIECE, (KIN - 2 * TP) * TP - J0);
+            if (carry.live) pending_pieces<PIN, NT>((jj - J0) * CPPS, (jj - J0 + 1) * CPPS, carry.acc, pk, first_of(ins...), KIN - 2 * TP, acc[tp_now][NT - 1]);
+          }
+        } else {
+          pending_pieces<PO, NT>((jj - J0) * PPS, (jj - J0 + 1) * PPS, prev, pk, out, 2 * (ot - TP), acc[tp_now][NT - 1]);
+        }
+      };
+      (accum<G, PL, NT, TP>(acc, pipe, cur, ins, j, slot), ...);
+      if (ot == 0) carry.live = false;
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) prev[tp][nt] = acc[tp][nt];
+    }
+    // the last group of the layer is finished inside whatever chain comes next - if that chain reads other chunks first
+    // (layers of more than one tile group); a single-group layer's output is needed by the very first MFMA that follows
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[tp][nt] = load_bias(cur.bt + ot + tp, hb);
-    (accum<G, PL, NT, TP>(acc, pipe, cur, ins), ...);
-    if constexpr (NERFDS_ASM_EPILOGUE && !(NERFDS_ABLATE & 4) && is_single(PO) && RELU) {
+      for (int nt = 0; nt < NT; ++nt) carry.acc[tp][nt] = prev[tp][nt];
+    carry.live = true;
+    // (NERFDS_CARRY_MAX_OT: layers wider than that finish their last group at once - the carried accumulators are 64 more
+    // live registers on top of the 256 that the activations of a 256-wide layer take with two N-tiles)
+    if constexpr ((2 * OT - 2 * TP) - 2 <= 0 || OT > NERFDS_CARRY_MAX_OT) flush_carry<PO, NT>(carry, out);
+  } else {
+#pragma unroll
+    for (int ot = 0; ot < OT; ot += TP) {
+      f32x16 acc[TP][NT];
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) {
+        const f32x16 bv = load_bias(cur.bt + ot + tp, hb);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[tp][nt] = bv;
+      }
+      int j = 0;
+      (accum<G, PL, NT, TP>(acc, pipe, cur, ins, j, no_slot), ...);
+      if constexpr (ASM_EPI) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-      for (int tp = 0; tp < TP; ++tp)
+        for (int tp = 0; tp < TP; ++tp)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(acc[tp][nt]));     // every chain of the group ends above the epilogue blocks
+          for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(acc[tp][nt]));     // every chain of the group ends above the epilogue blocks
 #endif
 #pragma unroll
-      for (int tp = 0; tp < TP; ++tp)
+        for (int tp = 0; tp < TP; ++tp)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          tile_epilogue_asm<PO>(out[nt][2 * (ot + tp)], out[nt][2 * (ot + tp) + 1], acc[tp][nt], tp == 0 && nt == 0);
-    } else {
+          for (int nt = 0; nt < NT; ++nt)
+            tile_epilogue_asm<PO>(out[nt][2 * (ot + tp)], out[nt][2 * (ot + tp) + 1], acc[tp][nt], tp == 0 && nt == 0);
+      } else {
 #pragma unroll
-      for (int tp = 0; tp < TP; ++tp) tile_epilogue<PO, NT, RELU>(out, ot + tp, acc[tp]);
+        for (int tp = 0; tp < TP; ++tp) tile_epilogue<PO, NT, RELU>(out, ot + tp, acc[tp]);
+      }
     }
   }
   cur.bt += OT;
 }
 
 // Output head (<= 16 logical outputs, duplicated in both lane halves by the packer): logical output j = acc[j].
-template <class G, class PL, int NT, class... Ins>
-DEVI void head(Pipe<G, PL>& pipe, Cursor& cur, f32x16 (&acc)[1][NT], const Ins&... ins) {
+template <class G, class PL, int NT, int P, int K>
+DEVI void head(Pipe<G, PL>& pipe, Cursor& cur, Carry<NT>& carry, f32x16 (&acc)[1][NT], Chunk<P> (&in)[NT][K]) {
   const int hb = bias_base(pipe.lane16);
+  {
+    const f32x16 bv = load_bias(cur.bt, hb);
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) acc[0][nt] = load_bias(cur.bt, hb);
-  (accum<G, PL, NT, 1>(acc, pipe, cur, ins), ...);
+    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = bv;
+  }
+  int j = 0;
+  if constexpr (is_single(P) && NERFDS_PIPE_EPI && NERFDS_ASM_EPILOGUE && !(NERFDS_ABLATE & 4) && (K - 2 * TILE_PAIR - 2 > 0)) {
+    // the hidden layer before a head leaves its last tile group pending: its chunks are the tail of `in` (a single-group
+    // layer does not carry); every piece before the slot that consumes the first carried chunk, K - 2 * TILE_PAIR
+    constexpr int NPIECE = TILE_PAIR * NT * 4, J0 = 2, PPS = cdiv(NPIECE, K - 2 * TILE_PAIR - J0);
+    unsigned pk[TILE_PAIR][NT][8];
+    auto slot = [&](int jj, int) {
+      if (jj < J0 || !carry.live) return;
+      pending_pieces<P, NT>((jj - J0) * PPS, (jj - J0 + 1) * PPS, carry.acc, pk, in, K - 2 * TILE_PAIR, acc[0][NT - 1]);
+    };
+    accum<G, PL, NT, 1>(acc, pipe, cur, in, j, slot);
+    carry.live = false;
+  } else {
+    auto no_slot = [](int, int) {};
+    accum<G, PL, NT, 1>(acc, pipe, cur, in, j, no_slot);
+  }
   cur.bt += 1;
 }
 
@@ -619,6 +811,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
   }
 
   Cursor cur{0, 0};
+  Carry<NT> carry;
 
   // ---- MaskMLP (modules.py:409-434; models.py:967-975) ----
   float maskv[NT];
@@ -635,16 +828,16 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
         return zero_feat();
       });
     static_assert(G::MASK_DEPTH == 8 || !G::HAS_MASK, "mask net is unrolled for depth 8, skip 4");
-    dense<G, PL, NT, W32, true>(pipe, cur, a, in0);
-    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, a, b);
-    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, a, b, in0);      // skip: [x, inputs] (modules.py:66-67)
-    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, a, b);
-    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, a, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b, in0);      // skip: [x, inputs] (modules.py:66-67)
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
     f32x16 hacc[1][NT];
-    head<G, PL, NT>(pipe, cur, hacc, b);
+    head<G, PL, NT>(pipe, cur, carry, hacc, b);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const float pm = fmaxf(hacc[0][nt][0], 0.f);                              // MaskMLP.output_activation = relu
@@ -671,14 +864,14 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
         return zero_feat();
       });
     static_assert(G::WARP_DEPTH == 6 || !G::HAS_WARP, "warp trunk is unrolled for depth 6, skip 4");
-    dense<G, PL, NT, W32, true>(pipe, cur, a, in0);
-    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, a, b);
-    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, a, b, in0);
-    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, a, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
     f32x16 hacc[1][NT];
-    head<G, PL, NT>(pipe, cur, hacc, b);      // logical outputs: w = 0..2, v = 3..5
+    head<G, PL, NT>(pipe, cur, carry, hacc, b);      // logical outputs: w = 0..2, v = 3..5
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float w[3] = {hacc[0][nt][0], hacc[0][nt][1], hacc[0][nt][2]};
@@ -755,14 +948,14 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
         return zero_feat();
       });
     static_assert(G::HYP_DEPTH == 6 || !G::HAS_HYPER, "hyper sheet is unrolled for depth 6, skip 4");
-    dense<G, PL, NT, W32, true>(pipe, cur, a, in0);
-    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, a, b);
-    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
-    dense<G, PL, NT, W32, true>(pipe, cur, a, b, in0);
-    dense<G, PL, NT, W32, true>(pipe, cur, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, a, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b, in0);
+    dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
     f32x16 hacc[1][NT];
-    head<G, PL, NT>(pipe, cur, hacc, b);
+    head<G, PL, NT>(pipe, cur, carry, hacc, b);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { wamb[nt][0] = hacc[0][nt][0]; wamb[nt][1] = hacc[0][nt][1]; }
   }
@@ -790,17 +983,17 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
         return zero_feat();
       });
     static_assert(G::TRUNK_DEPTH == 8 && G::TRUNK_SKIP == 4, "trunk is unrolled for depth 8, skip 4");
-    dense<G, PL, NT, TW32, true>(pipe, cur, a, in0);
-    dense<G, PL, NT, TW32, true>(pipe, cur, b, a);
-    dense<G, PL, NT, TW32, true>(pipe, cur, a, b);
-    dense<G, PL, NT, TW32, true>(pipe, cur, b, a);
-    dense<G, PL, NT, TW32, true>(pipe, cur, a, b, in0);
-    dense<G, PL, NT, TW32, true>(pipe, cur, b, a);
-    dense<G, PL, NT, TW32, true>(pipe, cur, a, b);
-    dense<G, PL, NT, TW32, true>(pipe, cur, b, a);          // b = trunk_output
+    dense<G, PL, NT, TW32, true>(pipe, cur, carry, a, in0);
+    dense<G, PL, NT, TW32, true>(pipe, cur, carry, b, a);
+    dense<G, PL, NT, TW32, true>(pipe, cur, carry, a, b);
+    dense<G, PL, NT, TW32, true>(pipe, cur, carry, b, a);
+    dense<G, PL, NT, TW32, true>(pipe, cur, carry, a, b, in0);
+    dense<G, PL, NT, TW32, true>(pipe, cur, carry, b, a);
+    dense<G, PL, NT, TW32, true>(pipe, cur, carry, a, b);
+    dense<G, PL, NT, TW32, true>(pipe, cur, carry, b, a);          // b = trunk_output
     // (the activation-free bottleneck Dense, modules.py:255, is folded into rgb hidden_0 by the packer)
     f32x16 hacc[1][NT];
-    head<G, PL, NT>(pipe, cur, hacc, b);                    // alpha_mlp on trunk_output (modules.py:273-274)
+    head<G, PL, NT>(pipe, cur, carry, hacc, b);                    // alpha_mlp on trunk_output (modules.py:273-274)
     // rgb condition chunks: [posenc(viewdir) | posenc(normal in observation frame)]
     Chunk<PR> cond[NT][D::COND_KC];
     WAVE_SYNC();                                              // parked SE3 state was written by the h == 0 lanes
@@ -842,8 +1035,8 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
       });
     }
     Chunk<PR> c[NT][G::RGB_W / 16];
-    dense<G, PL, NT, G::RGB_W / 32, true>(pipe, cur, c, b, cond);       // K order [trunk_output | cond]
-    head<G, PL, NT>(pipe, cur, hacc, c);
+    dense<G, PL, NT, G::RGB_W / 32, true>(pipe, cur, carry, c, b, cond);       // K order [trunk_output | cond]
+    head<G, PL, NT>(pipe, cur, carry, hacc, c);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       {

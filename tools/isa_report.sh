@@ -5,6 +5,6 @@ set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 n=$1; f=$2; pat=${3:-Lb0}
 mkdir -p /tmp/isa
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I$ROOT/include -Wno-unused-value --cuda-device-only -S \
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I$ROOT/include -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1 --cuda-device-only -S \
   $ROOT/nerf-ds_amd/csrc/render_kernel.hip $f -o /tmp/isa/$n.s 2>&1 | grep -v "hip-link" || true
 python $ROOT/tools/isa_stats.py /tmp/isa/$n.s $pat --top ${TOP:-16}

@@ -6,7 +6,7 @@ mkdir -p build/abl ../nerfds_amd/_lib/abl
 for v in "$@"; do
   n=${v%%:*}; f=${v#*:}
   ( FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-value $f"
-    /opt/rocm/bin/hipcc $FL -c render_kernel.hip -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_PREC=P_BF16 -DNERFDS_MIXED -DNERFDS_NAME=nerfds_mixed \
+    /opt/rocm/bin/hipcc $FL -mllvm -amdgpu-mfma-vgpr-form=1 -c render_kernel.hip -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_PREC=P_BF16 -DNERFDS_MIXED -DNERFDS_NAME=nerfds_mixed \
       -Rpass-analysis=kernel-resource-usage -o build/abl/km_$n.o 2>&1 | grep -E "error|VGPRs Spill|ScratchSize" | sort | uniq -c | sed "s/^/$n: /"
     /opt/rocm/bin/hipcc $FL -x hip -c nerfds_host.cpp -o build/abl/host_$n.o 2>&1 | grep -E "error"
     others=$(ls build/k_*.o | grep -v k_nerfds_mixed.o)
