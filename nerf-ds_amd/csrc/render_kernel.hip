@@ -449,12 +449,49 @@ template <int P> DEVI void epilogue_piece_asm(unsigned& o0, unsigned& o1, float 
 // Carrying a layer's last group into the next layer's first chain (dense(): Carry) is built and correct, but measured slower:
 // hipcc parks the 64 carried accumulators in scratch (857 scratch loads, each with a vmcnt(0) that also drains the LDS-DMA):
 // 19.9 ms (128-wide layers only) / 22.2 ms (all layers) against 15.2 ms without.  0 = every layer finishes its last group at once.
+// Pipelined epilogue for the split-bf16 kernel (dense(): third branch): built, parity green and deterministic, and measured
+// at 46.8 ms against 46.3 ms without per 65 536 rays - that kernel sits at the power limit as well.  Off.
+#ifndef NERFDS_PIPE_EPI_X3
+#define NERFDS_PIPE_EPI_X3 0
+#endif
 #ifndef NERFDS_PIPE_J0
 #define NERFDS_PIPE_J0 2
 #endif
 #ifndef NERFDS_CARRY_MAX_OT
 #define NERFDS_CARRY_MAX_OT 0
 #endif
+// Split-bf16 piece: accumulator elements (2q, 2q + 1) -> one packed hi pair and one packed lo pair, the arithmetic of
+// make_act_chunk<P_BF16X3, true>: r = relu(x); hi = bf16(r); lo = bf16(r - float(hi)).  8 VALU; `order` as in epilogue_piece_asm.
+DEVI void epilogue_piece_x3_asm(unsigned& hi, unsigned& lo, float a0, float a1, f32x16& order) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float t0, t1;
+  unsigned h0, h1;
+  asm volatile("v_max_i32 %2, 0, %7\n\tv_max_i32 %3, 0, %8\n\tv_cvt_pk_bf16_f32 %0, %2, %3\n\t"
+               "v_lshlrev_b32 %4, 16, %0\n\tv_and_b32 %5, 0xffff0000, %0\n\tv_sub_f32 %2, %2, %4\n\tv_sub_f32 %3, %3, %5\n\t"
+               "v_cvt_pk_bf16_f32 %1, %2, %3"
+               : "=&v"(hi), "=&v"(lo), "=&v"(t0), "=&v"(t1), "=&v"(h0), "=&v"(h1), "+v"(order) : "v"(a0), "v"(a1));
+#endif
+}
+// issues pieces [q0, q1) of a pending split-bf16 group (8 pieces per accumulator)
+template <int NT, int W>
+DEVI void pending_pieces_x3(int q0, int q1, const f32x16 (&src)[TILE_PAIR][NT], unsigned (&ph)[TILE_PAIR][NT][8], unsigned (&pl)[TILE_PAIR][NT][8],
+                            Chunk<P_BF16X3> (&dst)[NT][W], int first_chunk, f32x16& order) {
+#pragma unroll
+  for (int q = q0; q < q1; ++q) {
+    if (q >= TILE_PAIR * NT * 8) break;
+    const int a = q / 8, i8 = q % 8, ptp = a / NT, pnt = a % NT;
+    const f32x16& x = src[ptp][pnt];
+    epilogue_piece_x3_asm(ph[ptp][pnt][i8], pl[ptp][pnt][i8], x[2 * i8], x[2 * i8 + 1], order);
+    if ((i8 & 3) == 3) {          // a chunk (8 values) of the pending group is complete
+      const int hf = i8 >> 2;
+      const u32x4 rh = {ph[ptp][pnt][4 * hf], ph[ptp][pnt][4 * hf + 1], ph[ptp][pnt][4 * hf + 2], ph[ptp][pnt][4 * hf + 3]};
+      const u32x4 rl = {pl[ptp][pnt][4 * hf], pl[ptp][pnt][4 * hf + 1], pl[ptp][pnt][4 * hf + 2], pl[ptp][pnt][4 * hf + 3]};
+      dst[pnt][first_chunk + 2 * ptp + hf].hi = __builtin_bit_cast(bf16x8, rh);
+      dst[pnt][first_chunk + 2 * ptp + hf].lo = __builtin_bit_cast(bf16x8, rl);
+    }
+  }
+}
+
 // The epilogue of a layer's LAST tile group, carried into the first MFMA chain that follows (the next layer's first group, or
 // the head): its accumulators; the chunks it produces are the last 2 * TP chunks of that chain's first input array.
 template <int NT> struct Carry {
@@ -575,6 +612,43 @@ DEVI void dense(Pipe<G, PL>& pipe, Cursor& cur, Carry<NT>& carry, Chunk<PO> (&ou
     // (NERFDS_CARRY_MAX_OT: layers wider than that finish their last group at once - the carried accumulators are 64 more
     // live registers on top of the 256 that the activations of a 256-wide layer take with two N-tiles)
     if constexpr ((2 * OT - 2 * TP) - 2 <= 0 || OT > NERFDS_CARRY_MAX_OT) flush_carry<PO, NT>(carry, out);
+  } else if constexpr (PO == P_BF16X3 && RELU && NERFDS_PIPE_EPI_X3 && PL::UNIFORM && !(NERFDS_ABLATE & 4) && (OT > TP)) {
+    // Split bf16 runs one 512-register wave per SIMD: nothing covers a tile group's epilogue (2 x 64 VALU against 48 - 96 MFMAs),
+    // so the epilogue of group g is issued as 8-VALU asm pieces inside the MFMA chains of group g + 1 (same ordering rules as the
+    // one-unit branch above); the layer's last group is finished by the compiler-scheduled C++ epilogue.
+    constexpr int SLOTS = TP * seg_total<Ins...>::value;
+    constexpr int NPIECE = TP * NT * 8, J0 = NERFDS_PIPE_J0;
+    constexpr int PPS = cdiv(NPIECE, SLOTS - J0 > 0 ? SLOTS - J0 : 1);
+    f32x16 prev[TP][NT];
+    unsigned ph[TP][NT][8], pl[TP][NT][8];
+#pragma unroll
+    for (int ot = 0; ot < OT; ot += TP) {
+      f32x16 acc[TP][NT];
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) {
+        const f32x16 bv = load_bias(cur.bt + ot + tp, hb);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[tp][nt] = bv;
+      }
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (ot > 0) {          // ordering point (see the one-unit branch): previous chains end above, this group's chains start below
+        static_assert(TP == 2 && NT == 1, "ordering point written for 2 accumulators");
+        asm volatile("" : "+v"(prev[0][0]), "+v"(prev[1][0]), "+v"(acc[0][0]), "+v"(acc[1][0]));
+      }
+#endif
+      int j = 0;
+      auto slot = [&](int jj, int tp_now) {
+        if (jj < J0 || ot == 0) return;
+        pending_pieces_x3<NT>((jj - J0) * PPS, (jj - J0 + 1) * PPS, prev, ph, pl, out, 2 * (ot - TP), acc[tp_now][NT - 1]);
+      };
+      (accum<G, PL, NT, TP>(acc, pipe, cur, ins, j, slot), ...);
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) prev[tp][nt] = acc[tp][nt];
+    }
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) tile_epilogue<PO, NT, RELU>(out, OT - TP + tp, prev[tp]);
   } else {
 #pragma unroll
     for (int ot = 0; ot < OT; ot += TP) {

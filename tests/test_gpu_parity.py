@@ -207,7 +207,7 @@ def test_mask_ratio_blends_gt_mask():
     assert _relerr(out['fine'][k].cpu().numpy(), ref['fine'][k].numpy()) <= 1e-4, k
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
 def test_static_graph_config1(prec):
   """BASELINE.json configs[0]: 64 samples/ray, coarse only, warp disabled."""
   cfg = static_config()
@@ -225,7 +225,7 @@ def test_static_graph_config1(prec):
   assert 'ray_rotation_field' not in out['coarse'] and out['coarse']['ray_hyper_points'].shape == (R, 0)
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
 @pytest.mark.parametrize('Nc,Nf', [(16, 16), (128, 128)])
 def test_hypernerf_base_gin_graph(prec, Nc, Nf):
   """configs/base.gin graph (BASELINE config 5 per SURVEY 8d): posenc identity, SE3 warp (6 bands), hyper sheet, no mask / normal;
