@@ -140,6 +140,50 @@ def test_trainer_forward_agrees_with_the_fused_render_kernel():
 
 
 @pytest.mark.gpu
+def test_training_step_at_config4_size():
+  """BASELINE configs[3] at its own size: 4096 random rays x (64 + 64) samples, nerf_ds graph, jitter drawn on chip.  No oracle at
+  786 432 field evaluations; the size-independent properties: the trainer's two losses equal the fused render kernel's MSE on the
+  same rays and the same Philox seed (fp32-MFMA kernel: 1e-5), every gradient leaf is finite and the gradient is not zero, the same
+  seed gives the same loss again (to the order of its atomic summation), another seed another one, and a few Adam steps on the fixed batch bring the loss down."""
+  import torch
+  from nerfds_amd.model import NerfModel
+  import nerfds_amd.model as M
+  from nerfds_amd.training import Trainer
+  R = 4096
+  cfg = nerf_ds_config(num_warp_embeds=64, near=0.3, far=1.7)          # 64 + 64 samples, stratified
+  assert cfg.num_coarse_samples == 64 and cfg.num_fine_samples == 64 and cfg.use_stratified_sampling
+  params = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  rng = np.random.default_rng(2)
+  d = rng.normal(size=(R, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+  batch = dict(origins=(rng.normal(size=(R, 3)) * 0.2).astype(np.float32), directions=d.astype(np.float32), viewdirs=d.astype(np.float32),
+               metadata={'warp': rng.integers(0, 64, (R, 1))}, mask=(rng.random((R, 1)) < 0.3).astype(np.float32),
+               rgb=rng.random((R, 3)).astype(np.float32))
+  tr = Trainer(cfg, params, max_rays=R)
+  a = tr.step(batch, EX, 0.0, grads_only=True, seed=77)
+  g = dict(tree_leaves(tr.get_grads()))
+  assert all(np.isfinite(v).all() for v in g.values()) and sum(float(np.abs(v).sum()) for v in g.values()) > 0
+  b = tr.step(batch, EX, 0.0, grads_only=True, seed=77)
+  c = tr.step(batch, EX, 0.0, grads_only=True, seed=78)
+  # (the per-ray losses are summed with float atomics: equal up to the summation order)
+  assert abs(a['loss/fine'] - b['loss/fine']) < 1e-6 and abs(a['loss/coarse'] - b['loss/coarse']) < 1e-6 and abs(a['loss/fine'] - c['loss/fine']) > 1e-5
+  m = NerfModel(cfg, device=torch.device('cuda', 0), precision='f32')
+  old = M._seed_from_rngs
+  M._seed_from_rngs = lambda rngs: 77
+  try:
+    out = m.apply({'params': params}, batch, EX, use_predicted_norm=True, precision='f32')
+  finally:
+    M._seed_from_rngs = old
+  gt = torch.as_tensor(batch['rgb'], device='cuda')
+  for lv in ('fine', 'coarse'):
+    mse = float(((out[lv]['rgb'] - gt) ** 2).mean())
+    assert abs(mse - a[f'loss/{lv}']) < 1e-5 * max(1.0, mse), (lv, mse, a)
+  first = tr.step(batch, EX, 1e-3, seed=1)['loss/total']
+  for i in range(8):
+    last = tr.step(batch, EX, 1e-3, seed=2 + i)['loss/total']
+  assert last < first, (first, last)
+
+
+@pytest.mark.gpu
 def test_trainer_rejects_what_it_cannot_do():
   from nerfds_amd import static_config
   from nerfds_amd.training import Trainer
