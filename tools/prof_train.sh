@@ -1,17 +1,20 @@
 #!/bin/bash
-# Kernel trace of the training step (GPU box). Usage: tools/prof_train.sh <tag>
-TAG=${1:-train}
+# Kernel trace of the training step (GPU box): rocprofv3 --kernel-trace --stats of `bench.py --train`. Usage: tools/prof_train.sh <tag>
+TAG=${1:-train_r2}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $GRAFT_REPO_ROOT/tools/bench_train.py 4096 3 > $OUT/trace.log 2>&1
-python - <<PY
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $GRAFT_REPO_ROOT/bench.py --train --steps 6 --warmup 3 --no-cpu-baseline > $OUT/trace.log 2>&1
+python - <<PY > $OUT/summary.txt
 import glob, sqlite3
 for db in glob.glob('$OUT/trace/**/*_results.db', recursive=True):
     cur = sqlite3.connect(db).cursor()
-    rows = cur.execute('select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 25').fetchall()
+    rows = cur.execute('select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 60').fetchall()
     tot = sum(r[2] for r in cur.execute('select name,total_calls,total_duration from top_kernels').fetchall())
-    print('total kernel time ms', tot / 1e3, '(6 steps: 3 warm-up + 3 timed)')   # top_kernels durations are microseconds
+    print('total kernel time ms', tot / 1e3, '(9 steps of bench.py --train: 3 warm-up + 6 timed)')   # top_kernels durations are microseconds
     for name, calls, t, avg, pct in rows:
-        print(f'{name[:100]:100s} calls={calls:5d} total_ms={t/1e3:9.3f} avg_ms={avg/1e3:8.4f} pct={pct:5.1f}')
+        print(f'{name[:110]:110s} calls={calls:5d} total_ms={t/1e3:9.3f} avg_ms={avg/1e3:8.4f} pct={pct:5.1f}')
 PY
+grep -h '"metric"' $OUT/trace.log | tail -1 > $OUT/bench_under_rocprof.json
+rm -rf $OUT/trace
+cat $OUT/summary.txt
