@@ -229,6 +229,11 @@ def main():
     raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+  # NERFDS_DIST_BACKEND=gloo (tests only): the N > 1 code path with every rank on whatever GPUs the box has, the exchange
+  # staged through the host; the numbers of such a run mean nothing
+  backend = os.environ.get('NERFDS_DIST_BACKEND', 'nccl')
+  if backend != 'nccl':
+    local_rank %= torch.cuda.device_count()
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
   if args.train:
@@ -237,11 +242,14 @@ def main():
     return run_train(args, device)
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', device_id=device)      # "nccl" is RCCL on ROCm
+    if backend == 'nccl':
+      dist.init_process_group('nccl', device_id=device)      # "nccl" is RCCL on ROCm
+    else:
+      dist.init_process_group(backend)
 
   from nerfds_amd import nerf_ds_config, hypernerf_config, init_params
   from nerfds_amd.model import NerfModel
-  from nerfds_amd.evaluation import TrainState, make_model_fn, render_image
+  from nerfds_amd.evaluation import TrainState, make_model_fn, render_image, all_gather_into
   from nerfds_amd import _native as N
 
   make_cfg = nerf_ds_config if args.graph == 'nerf_ds' else hypernerf_config
@@ -275,7 +283,7 @@ def main():
         ready.record(compute)
         with torch.cuda.stream(comm):
           comm.wait_event(ready)
-          dist.all_gather_into_tensor(gathered[slot][:world * (hi - lo)], frame[lo:hi])
+          all_gather_into(gathered[slot][:world * (hi - lo)], frame[lo:hi])
     if world > 1:
       compute.wait_stream(comm)
 

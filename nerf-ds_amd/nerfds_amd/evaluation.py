@@ -75,6 +75,20 @@ def tree_map(fn, tree):
   return fn(tree)
 
 
+def all_gather_into(out: torch.Tensor, rec: torch.Tensor) -> None:
+  """``out[D * R_local, 26]`` <- every rank's ``rec[R_local, 26]`` in rank order (render.py:155 ``all_gather``), one collective,
+  issued on the current stream.  RCCL ("nccl") gathers straight into ``out``; any other backend (gloo: the CPU tests, and the
+  two-processes-on-one-GPU tests of the N > 1 code paths) goes through the list API on host copies."""
+  world = dist.get_world_size()
+  if dist.get_backend() == 'nccl':
+    dist.all_gather_into_tensor(out, rec)
+    return
+  host = rec.contiguous().cpu()
+  parts = [torch.empty_like(host) for _ in range(world)]
+  dist.all_gather(parts, host)
+  out.copy_(torch.cat(parts, dim=0))
+
+
 def all_gather_records(rec: torch.Tensor) -> torch.Tensor:
   """[R_local, 26] on every rank -> [D * R_local, 26] on every rank (render.py:155 ``all_gather``), one collective."""
   rank, world = _world()
@@ -82,10 +96,7 @@ def all_gather_records(rec: torch.Tensor) -> torch.Tensor:
     return rec
   rec = rec.contiguous()
   out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
-  if dist.get_backend() == 'nccl':             # RCCL: one collective straight into the output tensor
-    dist.all_gather_into_tensor(out, rec)
-  else:                                        # gloo (CPU tests): same result through the list API
-    dist.all_gather(list(out.chunk(world, dim=0)), rec)
+  all_gather_into(out, rec)
   return out
 
 
@@ -265,10 +276,10 @@ def _render_image_device(state, rays_dict, model_fn, params, keys, num_rays, num
     with torch.cuda.stream(comm):
       comm.wait_event(ready)
       if padding == 0:
-        dist.all_gather_into_tensor(frame[ray_idx:ray_idx + n], rec)
+        all_gather_into(frame[ray_idx:ray_idx + n], rec)
       else:
         full = torch.empty((world * per, N.RAY_REC), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(full, rec)
+        all_gather_into(full, rec)
         frame[ray_idx:ray_idx + n].copy_(full[:n])                                       # utils.unshard: drop the padding
       done[slot] = torch.cuda.Event()
       done[slot].record(comm)

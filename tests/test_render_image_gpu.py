@@ -68,17 +68,21 @@ def _free_port():
   return p
 
 
-def _nccl_worker(rank, world, port, q):
+def _rank_worker(rank, world, port, q, backend):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
   import torch.distributed as dist
-  torch.cuda.set_device(rank)
-  dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+  gpu = rank if backend == 'nccl' else 0
+  torch.cuda.set_device(gpu)
+  if backend == 'nccl':
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', gpu))
+  else:
+    dist.init_process_group(backend, rank=rank, world_size=world)
   try:
     from nerfds_amd.evaluation import TrainState, make_model_fn, render_image
     from nerfds_amd.model import NerfModel
     cfg, params = _setup(False)
     rays = _frame_rays(23, 41, 4, 1)                     # 943 rays: chunk 300 -> odd chunk sizes, padding on the last chunk
-    model = NerfModel(cfg, device=torch.device('cuda', rank), precision='f32')
+    model = NerfModel(cfg, device=torch.device('cuda', gpu), precision='f32')
     out = render_image(TrainState.create(params, **EXTRA), rays, make_model_fn(model, precision='f32'), device_count=world,
                        rng=np.array([0, 1]), chunk=300, cfg=cfg)
     q.put((rank, out['rgb'].numpy(), out['depth'].numpy()))
@@ -86,25 +90,59 @@ def _nccl_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='BASELINE config 3 needs two GPUs (ray shard + RCCL all-gather)')
-def test_render_image_two_ranks_nccl():
+def _two_rank_frame(backend):
   import torch.multiprocessing as mp
   from nerfds_amd.model import NerfModel
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
   port = _free_port()
-  procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+  procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q, backend)) for r in range(2)]
   for p in procs:
     p.start()
-  got = dict((r, (a, b)) for r, a, b in (q.get(timeout=300) for _ in range(2)))
-  for p in procs:
-    p.join(60)
+  try:
+    got = dict((r, (a, b)) for r, a, b in (q.get(timeout=300) for _ in range(2)))
+  finally:
+    for p in procs:
+      p.join(60)
+      if p.is_alive():
+        p.kill()
   cfg, params = _setup(False)
   rays = _frame_rays(23, 41, 4, 1)
   whole = NerfModel(cfg, device=torch.device('cuda', 0), precision='f32').apply({'params': params}, rays, EXTRA, use_predicted_norm=True,
                                                                                  precision='f32')['fine']
   for r in range(2):     # every rank holds the whole frame, identical to the unsharded render
     assert np.array_equal(got[r][0], whole['rgb'].cpu().numpy()) and np.array_equal(got[r][1], whole['depth'].cpu().numpy())
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='BASELINE config 3 needs two GPUs (ray shard + RCCL all-gather)')
+def test_render_image_two_ranks_nccl():
+  _two_rank_frame('nccl')
+
+
+def test_render_image_two_ranks_sharing_one_gpu():
+  """The N > 1 code path of render_image on a one-GPU box: two processes on cuda:0, chunk shards, staging buffers, side-stream
+  exchange, padding of the ragged chunk - everything but RCCL itself (the exchange goes through gloo on host copies)."""
+  _two_rank_frame('gloo')
+
+
+@pytest.mark.parametrize('mode', ['weak', 'strong'])
+def test_bench_two_ranks_sharing_one_gpu(mode):
+  """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), both ranks on cuda:0 with the
+  exchange staged through gloo: the run finishes and rank 0 prints ONE JSON line with the aggregate of both ranks."""
+  import json
+  import subprocess
+  env = dict(os.environ, NERFDS_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+         '--rays', '20000', '--chunk', '8192', '--no-cpu-baseline'] + (['--strong'] if mode == 'strong' else [])
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+  assert len(lines) == 1, r.stdout
+  rec = json.loads(lines[0])
+  assert rec['n_gpus'] == 2 and rec['scaling'] == mode and rec['value'] > 0
+  total = 20000 * (2 if mode == 'weak' else 1)
+  assert abs(rec['value'] - total / (rec['ms_per_step'] * 1e-3)) <= 1e-3 * rec['value']
 
 
 def test_chunked_philox_frame_equals_one_call():
