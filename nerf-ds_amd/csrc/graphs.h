@@ -65,6 +65,10 @@ constexpr Plan plan_of(int prec_index) {
   return prec_index == 4 ? Plan{NERFDS_MIX_MASK, NERFDS_MIX_WARP, NERFDS_MIX_HYP, NERFDS_MIX_TRUNK, NERFDS_MIX_RGB}
                          : uniform_plan(prec_index);
 }
+// The plan of the fused training forward (render_kernel.hip train_forward_kernel): split bf16 operands as the trainer's layer
+// kernels (train_gemm.hip), exact fp32 products in the warp field (its 16-bit rounding is amplified to ~1 % on the warp-field
+// gradients by the 2^7-frequency encoding of the warped point).  Every network is two units per fragment.
+constexpr Plan TRAIN_PLAN = Plan{P_BF16X3, P_F32, P_BF16X3, P_BF16X3, P_BF16X3};
 // Stream position after a fragment segment of `kc` k16-chunks in precision p, starting at unit `pos`.  There is no
 // alignment: a two-unit fragment may start on an odd unit and even straddle two LDS stages (the kernel fetches
 // units, not fragments).

@@ -48,6 +48,24 @@ struct KArgs {
   float win_nm[MAX_BANDS];     // alpha = norm_input_alpha  (models.py:1147)
 };
 
+// Where the training forward writes what the backward pass reads (nerfds_train.cpp workspace, row-major [R * S][width] fp32).
+// Passed by value to train_forward_kernel (render_kernel.hip).
+struct TrainOut {
+  static constexpr bool ON = true;
+  float* mask_h[8];
+  float* warp_h[6];
+  float* hyper_h[6];
+  float* trunk_h[8];
+  float* rgb_h;
+  float* mask_logit;   // [M]     raw logit (the ReLU is mask_post's)
+  float* wv;           // [M][6]  screw axis w | v (warping.py:217-218)
+  float* wamb;         // [M][2]
+  float* alphav;       // [M][4]  sigma_raw | raw normal
+  float* rgb_logit;    // [M][3]
+  const float* z;      // [R][S]  sample depths of this level
+  int level;
+};
+
 typedef void (*launch_fn)(const KArgs& ka, int num_cus, void* stream);
 
 }  // namespace nerfds

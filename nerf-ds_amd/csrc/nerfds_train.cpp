@@ -21,6 +21,12 @@
 #include "nerfds.h"
 #include "train_kernels.h"
 #include "train_gemm.h"
+#include "graphs.h"
+#include "kargs.h"
+#include "pack.h"
+
+// render_kernel.hip compiled with -DNERFDS_TRAIN_FWD: the fused forward of one level (TRAIN_PLAN arithmetic)
+extern "C" void nerfds_launch_train_fwd_nerfds(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream);
 
 using namespace nerfds_train;
 
@@ -88,6 +94,16 @@ struct nerfds_trainer {
   std::vector<uint64_t> pack_fresh;
   int num_cus = 256;
   bool fuse_bwd = true;     // NERFDS_TRAIN_FUSE_BWD=0: the narrow layers' backward as two kernels (A/B timing)
+  // Fused forward (render_kernel.hip train_forward_kernel): the whole field evaluation of a level in ONE launch, activations written once
+  // for the backward pass.  Its weight streams [shared, coarse, fine] are re-packed on the device from theta at the start of every step
+  // through index maps built once (build_fused_forward).  NERFDS_TRAIN_FUSED_FWD=0 runs the forward layer by layer (A/B timing).
+  bool fused_fwd = false;
+  int* fmap[3] = {nullptr, nullptr, nullptr};       // per float slot of the fp32-layout stream: 1 + parameter index (past P: fold), 0 = zero
+  int* fbmap[3] = {nullptr, nullptr, nullptr};
+  void* fstream[3] = {nullptr, nullptr, nullptr};
+  float* fbias[3] = {nullptr, nullptr, nullptr};
+  float* fold = nullptr;    // [2 levels][(TW + 1) x RGB_W]: rgb hidden_0 with the bottleneck folded in, then its bias
+  int fstream_frags[3] = {0, 0, 0}, fbias_n[3] = {0, 0, 0}, f32_lo = 0, f32_hi = 0;
   std::string err;
   // workspace views (set by carve())
   float *zc, *zf, *wc, *rs_scratch, *x, *mask_in, *mask_logit, *warp_in, *wv, *xw, *hyper_in, *wamb, *trunk_in, *bottv, *alphav, *sigma,
@@ -111,6 +127,13 @@ struct nerfds_trainer {
     if (grad_rep) (void)hipFree(grad_rep);
     if (arena) (void)hipFree(arena);
     if (packs_dev) (void)hipFree(packs_dev);
+    for (int i = 0; i < 3; ++i) {
+      if (fmap[i]) (void)hipFree(fmap[i]);
+      if (fbmap[i]) (void)hipFree(fbmap[i]);
+      if (fstream[i]) (void)hipFree(fstream[i]);
+      if (fbias[i]) (void)hipFree(fbias[i]);
+    }
+    if (fold) (void)hipFree(fold);
   }
 };
 
@@ -406,6 +429,119 @@ void sigma_gradient(nerfds_trainer& t, Run& r, int level, const Windows& W) {
   target_norm(st, M, t.t_alpha, t.wv, t.tn[level]);
 }
 
+// ---- fused forward: index maps, built once ----
+// The render packer (pack.h) is run over a fake parameter vector whose values are their own indices + 1, in the uniform fp32
+// plan (raw floats in the stream, same fragment positions as TRAIN_PLAN: both are two units per fragment): what comes out is,
+// for every float slot of the stream, WHICH parameter belongs there.  k_pack_stream then gathers the current values every step.
+bool build_fused_forward(nerfds_trainer& t) {
+  using G = nerfds::GraphNerfDS;
+  using Dm = nerfds::Dims<G>;
+  const nerfds_model_cfg& c = t.cfg;
+  const bool same_graph = c.mask_max_deg == G::MASK_BANDS && c.mask_depth == G::MASK_DEPTH && c.mask_width == G::MASK_W && c.mask_skip == G::MASK_SKIP &&
+                          c.warp_max_deg == G::WARP_BANDS && c.warp_trunk_depth == G::WARP_DEPTH && c.warp_trunk_width == G::WARP_W && c.warp_skip == G::WARP_SKIP &&
+                          c.hyper_sheet_max_deg == G::HYP_BANDS && c.hyper_sheet_depth == G::HYP_DEPTH && c.hyper_sheet_width == G::HYP_W &&
+                          c.hyper_sheet_skip == G::HYP_SKIP && c.spatial_point_max_deg == G::SP_BANDS && c.hyper_point_max_deg == G::HP_BANDS &&
+                          c.viewdir_max_deg == G::VD_BANDS && c.norm_input_max_deg == G::NM_BANDS && c.nerf_trunk_depth == G::TRUNK_DEPTH &&
+                          c.nerf_trunk_width == G::TRUNK_W && c.nerf_skip == G::TRUNK_SKIP && c.nerf_rgb_branch_width == G::RGB_W &&
+                          c.num_coarse_samples + c.num_fine_samples <= nerfds::MAX_SAMPLES;
+  if (!same_graph) return false;       // other widths: the layer-by-layer forward
+  constexpr nerfds::Plan F32 = nerfds::uniform_plan(nerfds::P_F32);
+  static_assert(nerfds::shared_units<G>(F32) == nerfds::shared_units<G>(nerfds::TRAIN_PLAN) && nerfds::nerf_units<G>(F32) == nerfds::nerf_units<G>(nerfds::TRAIN_PLAN),
+                "index maps are packed in the fp32 layout: every network of TRAIN_PLAN must be two units per fragment");
+  constexpr int TW = G::TRUNK_W, RW = G::RGB_W, VD = Dm::VD_FEATS, NM = Dm::NM_FEATS, FL = (TW + 1) * RW;
+  const int levels = c.num_fine_samples > 0 ? 2 : 1;
+  if (t.P + 2 * FL + 1 >= (1 << 24)) return false;     // indices travel through the packer as floats
+  std::vector<float> idx((size_t)t.P);
+  for (int64_t i = 0; i < t.P; ++i) idx[(size_t)i] = (float)(i + 1);
+  auto view = [&](const LayerP& L) { nerfds::DenseView d; d.kernel = idx.data() + L.w; d.bias = idx.data() + L.b; d.in_dim = L.K; d.out_dim = L.N; return d; };
+  nerfds::SharedNets sn;
+  for (int l = 0; l < t.mask.depth; ++l) sn.mask_hidden[l] = view(t.mask.hidden[l]);
+  for (int l = 0; l < t.warp.depth; ++l) sn.warp_hidden[l] = view(t.warp.hidden[l]);
+  for (int l = 0; l < t.hyper.depth; ++l) sn.hyper_hidden[l] = view(t.hyper.hidden[l]);
+  sn.mask_out = view(t.mask_out); sn.warp_w = view(t.warp_w); sn.warp_v = view(t.warp_v); sn.hyper_out = view(t.hyper_out);
+  // fragments of the warp field keep fp32 (TRAIN_PLAN.warp): they follow the mask net in the shared stream
+  const int mask_units = nerfds::walk_mlp(0, G::MASK_DEPTH, G::MASK_W, Dm::MASK_KC, G::MASK_SKIP, true, nerfds::P_F32);
+  const int warp_units = nerfds::walk_mlp(mask_units, G::WARP_DEPTH, G::WARP_W, Dm::WARP_KC, G::WARP_SKIP, true, nerfds::P_F32);
+  t.f32_lo = mask_units / 2; t.f32_hi = warp_units / 2;
+  if (hipMalloc(&t.fold, (size_t)2 * FL * sizeof(float)) != hipSuccess) return false;
+  for (int which = 0; which < 1 + levels; ++which) {
+    const int64_t wb = (int64_t)nerfds::pad_units(which == 0 ? nerfds::shared_units<G>(F32) : nerfds::nerf_units<G>(F32)) * 1024;
+    const int64_t bf = (int64_t)(which == 0 ? Dm::SHARED_BIAS_TILES : Dm::NERF_BIAS_TILES) * 32;
+    std::vector<uint8_t> w((size_t)wb, 0);
+    std::vector<float> b((size_t)bf, 0.f);
+    nerfds::StreamWriter sw{w.data(), b.data()};
+    std::vector<float> pf, pfb;
+    if (which == 0) {
+      nerfds::pack_shared<G>(sw, sn, F32);
+    } else {
+      const int lv = which - 1;
+      nerfds::NerfNet nn;
+      for (int l = 0; l < t.trunk[lv].depth; ++l) nn.trunk[l] = view(t.trunk[lv].hidden[l]);
+      nn.bottleneck = view(t.bott[lv]); nn.alpha = view(t.alpha[lv]); nn.rgb_hidden[0] = view(t.rgb_h[lv]); nn.rgb = view(t.rgb_out[lv]);
+      // rgb hidden_0 in the kernel's K order [trunk_output (folded rows, in `fold`) | viewdir | normal (rows of the parameter itself)]
+      const LayerP& K = t.rgb_h[lv];
+      const int row_vd = TW, row_nm = TW + VD + TW;
+      pf.resize((size_t)(TW + VD + NM) * RW);
+      pfb.resize(RW);
+      for (int cc = 0; cc < RW; ++cc) {
+        for (int r = 0; r < TW; ++r) pf[(size_t)r * RW + cc] = (float)(t.P + (int64_t)lv * FL + (int64_t)r * RW + cc + 1);
+        for (int q = 0; q < VD; ++q) pf[(size_t)(TW + q) * RW + cc] = (float)(K.w + (int64_t)(row_vd + q) * RW + cc + 1);
+        for (int q = 0; q < NM; ++q) pf[(size_t)(TW + VD + q) * RW + cc] = (float)(K.w + (int64_t)(row_nm + q) * RW + cc + 1);
+        pfb[cc] = (float)(t.P + (int64_t)lv * FL + (int64_t)TW * RW + cc + 1);
+      }
+      nn.prefolded = pf.data(); nn.prefolded_bias = pfb.data();
+      nerfds::pack_nerf<G>(sw, nn, F32);
+    }
+    if ((int64_t)sw.wbytes > wb || (int64_t)sw.bfloats != bf) return false;
+    std::vector<int> map((size_t)wb / 4), bmap((size_t)bf);
+    const float* wf = reinterpret_cast<const float*>(w.data());
+    for (size_t i = 0; i < map.size(); ++i) map[i] = (int)wf[i];
+    for (size_t i = 0; i < bmap.size(); ++i) bmap[i] = (int)b[i];
+    if (hipMalloc(&t.fmap[which], map.size() * 4) != hipSuccess || hipMalloc(&t.fbmap[which], bmap.size() * 4) != hipSuccess ||
+        hipMalloc(&t.fstream[which], (size_t)wb) != hipSuccess || hipMalloc(&t.fbias[which], bmap.size() * 4) != hipSuccess ||
+        hipMemcpy(t.fmap[which], map.data(), map.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(t.fbmap[which], bmap.data(), bmap.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return false;
+    t.fstream_frags[which] = (int)(wb / 2048);
+    t.fbias_n[which] = (int)bf;
+  }
+  return true;
+}
+
+// every step: fold, then the three streams and their biases from the current theta
+void pack_fused_forward(nerfds_trainer& t, hipStream_t st) {
+  using G = nerfds::GraphNerfDS;
+  using Dm = nerfds::Dims<G>;
+  constexpr int TW = G::TRUNK_W, RW = G::RGB_W, FL = (TW + 1) * RW;
+  const int levels = t.cfg.num_fine_samples > 0 ? 2 : 1;
+  for (int lv = 0; lv < levels; ++lv)
+    fold_rgb(st, t.theta + t.bott[lv].w, t.theta + t.bott[lv].b, t.theta + t.rgb_h[lv].w, t.theta + t.rgb_h[lv].b, TW, RW, TW + Dm::VD_FEATS,
+             t.fold + (size_t)lv * FL);
+  for (int which = 0; which < 1 + levels; ++which) {
+    pack_stream(st, t.theta, t.fold, t.P, t.fmap[which], t.fstream[which], t.fstream_frags[which], which == 0 ? t.f32_lo : 0, which == 0 ? t.f32_hi : 0);
+    pack_bias(st, t.theta, t.fold, t.P, t.fbmap[which], t.fbias[which], t.fbias_n[which]);
+  }
+}
+
+void fused_forward(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const float* z, const nerfds_rays* rays, const nerfds_extra* ex, const Windows& W) {
+  nerfds::KArgs ka{};
+  ka.origins = rays->origins; ka.directions = rays->directions; ka.viewdirs = rays->viewdirs;
+  ka.warp_id = rays->warp_id; ka.gt_mask = rays->gt_mask;
+  ka.wstream[0] = t.fstream[0]; ka.wstream[1] = ka.wstream[2] = t.fstream[1 + level];
+  ka.bias[0] = t.fbias[0]; ka.bias[1] = ka.bias[2] = t.fbias[1 + level];
+  ka.warp_embed = t.theta + t.warp_tbl; ka.mask_embed = t.theta + t.mask_tbl;
+  ka.num_rays = R; ka.num_embeds = t.cfg.num_warp_embeds; ka.nc = S; ka.nf = 0;
+  ka.mask_ratio = ex->mask_ratio; ka.near_ = ex->near; ka.far_ = ex->far;
+  std::memcpy(ka.win_mask, W.mask, sizeof W.mask); std::memcpy(ka.win_warp, W.warp, sizeof W.warp); std::memcpy(ka.win_hyp, W.hyp, sizeof W.hyp);
+  std::memcpy(ka.win_sp, W.sp, sizeof W.sp); std::memcpy(ka.win_hp, W.hp, sizeof W.hp); std::memcpy(ka.win_nm, W.nm, sizeof W.nm);
+  nerfds::TrainOut to{};
+  for (int l = 0; l < 8; ++l) { to.mask_h[l] = t.mask_h[l]; to.trunk_h[l] = t.trunk_h[l]; }
+  for (int l = 0; l < 6; ++l) { to.warp_h[l] = t.warp_h[l]; to.hyper_h[l] = t.hyper_h[l]; }
+  to.rgb_h = t.rgb_hv; to.mask_logit = t.mask_logit; to.wv = t.wv; to.wamb = t.wamb; to.alphav = t.alphav; to.rgb_logit = t.rgb_logit;
+  to.z = z; to.level = level;
+  nerfds_launch_train_fwd_nerfds(ka, to, t.num_cus, st);
+}
+
 int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const float* z, const nerfds_rays* rays, const float* target,
               const nerfds_extra* ex, const Windows& W, float* weights_out, bool want_sigma_gradient, const Objective* ob,
               float norm_weight) {
@@ -416,6 +552,19 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   // ---------------- forward ----------------
   encode_inputs(st, D, R, S, rays->origins, rays->directions, z, rays->warp_id, t.cfg.num_warp_embeds, t.theta + t.warp_tbl, t.theta + t.mask_tbl,
                 W, t.x, t.mask_in, t.warp_in, t.hyper_in);
+  const MlpP& trunk = t.trunk[level];
+  const int TW = trunk.width, VD = 6 * D.vd_bands, NM = 6 * D.nm_bands, CW = VD + NM;
+  float* tout = t.trunk_h.back();
+  if (t.fused_fwd) {
+    // ONE launch evaluates the five networks on the level's samples and writes every hidden layer + head output (render_kernel.hip
+    // train_forward_kernel); what follows only materialises the layer INPUTS the backward pass differentiates through.
+    fused_forward(t, st, level, R, S, z, rays, ex, W);
+    mask_post(st, D, R, S, t.mask_logit, rays->gt_mask, ex->mask_ratio, t.warp_in, t.hyper_in);
+    se3_fwd(st, M, t.wv, t.x, t.xw);
+    trunk_in(st, D, M, t.xw, t.wamb, W, t.trunk_in);
+    r.dense_fwd(t.bott[level], {{tout, TW, TW, nullptr, 0, false}}, t.bottv, TW, false);          // the kernel folds it; dW of rgb hidden_0 reads it
+    alpha_post(st, D, R, S, t.alphav, t.wv, viewdirs, W, t.sigma, t.cond);
+  } else {
   r.mlp_fwd(t.mask, t.mask_in, t.mask_h);
   r.dense_fwd(t.mask_out, {{t.mask_h.back(), t.mask.width, t.mask.width, nullptr, 0, false}}, t.mask_logit, 1, false);
   mask_post(st, D, R, S, t.mask_logit, rays->gt_mask, ex->mask_ratio, t.warp_in, t.hyper_in);
@@ -428,10 +577,7 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   r.mlp_fwd(t.hyper, t.hyper_in, t.hyper_h);
   r.dense_fwd(t.hyper_out, {{t.hyper_h.back(), t.hyper.width, t.hyper.width, nullptr, 0, false}}, t.wamb, 2, false);
   trunk_in(st, D, M, t.xw, t.wamb, W, t.trunk_in);
-  const MlpP& trunk = t.trunk[level];
-  const int TW = trunk.width, VD = 6 * D.vd_bands, NM = 6 * D.nm_bands, CW = VD + NM;
   r.mlp_fwd(trunk, t.trunk_in, t.trunk_h);
-  float* tout = t.trunk_h.back();
   r.dense_fwd(t.bott[level], {{tout, TW, TW, nullptr, 0, false}}, t.bottv, TW, false);          // modules.py:255 (no activation)
   r.dense_fwd(t.alpha[level], {{tout, TW, TW, nullptr, 0, false}}, t.alphav, 4, false);          // modules.py:273-274
   alpha_post(st, D, R, S, t.alphav, t.wv, viewdirs, W, t.sigma, t.cond);
@@ -439,6 +585,7 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   r.dense_fwd(t.rgb_h[level], {{t.bottv, TW, TW, nullptr, 0, false}, {t.cond, CW, VD, nullptr, 0, false}, {tout, TW, TW, nullptr, 0, false},
                                {t.cond + VD, CW, NM, nullptr, 0, false}}, t.rgb_hv, t.rgb_h[level].N, true);
   r.dense_fwd(t.rgb_out[level], {{t.rgb_hv, t.rgb_h[level].N, t.rgb_h[level].N, nullptr, 0, false}}, t.rgb_logit, 3, false);
+  }
   composite_loss(st, R, S, z, rays->directions, t.sigma, t.rgb_logit, target, t.cfg.use_sample_at_infinity, t.cfg.use_white_background, t.rgb_ray,
                  weights_out, t.loss_dev + level, t.d_rgb_logit, t.d_alpha);
   if (want_sigma_gradient) sigma_gradient(t, r, level, W);
@@ -553,6 +700,8 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
     if (hipGetDeviceProperties(&prop, t->device) == hipSuccess && prop.multiProcessorCount > 0) t->num_cus = prop.multiProcessorCount;
     const char* fb = getenv("NERFDS_TRAIN_FUSE_BWD");
     t->fuse_bwd = !(fb && std::string(fb) == "0");
+    const char* ff = getenv("NERFDS_TRAIN_FUSED_FWD");
+    t->fused_fwd = !(ff && std::string(ff) == "0") && build_fused_forward(*t);
     if (hipMalloc(&t->arena, ARENA_BYTES) != hipSuccess) { g_train_error = "hipMalloc failed (fragment arena)"; return NERFDS_ENOMEM; }
     if (hipMalloc(&t->grad_rep, (size_t)GRAD_REPS * t->P * sizeof(float)) != hipSuccess) { g_train_error = "hipMalloc failed (gradient replicas)"; return NERFDS_ENOMEM; }
     if (hipMalloc(&t->wpack, WPACK_BYTES + 256) != hipSuccess || hipMemset(t->wpack, 0, WPACK_BYTES + 256) != hipSuccess) { g_train_error = "hipMalloc failed (weight fragments)"; return NERFDS_ENOMEM; }
@@ -678,6 +827,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
       std::fill(t->pack_fresh.begin(), t->pack_fresh.end(), t->pack_epoch);
     }
   }
+  if (t->fused_fwd) pack_fused_forward(*t, st);
   (void)hipMemsetAsync(t->loss_dev, 0, 2 * sizeof(float), st);
   const int strat = ex->use_stratified_sampling;
   coarse_z(st, R, Nc, ex->near, ex->far, strat, rnd ? rnd->t_rand : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->first_ray : 0, t->zc);

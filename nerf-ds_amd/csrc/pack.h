@@ -9,6 +9,7 @@
 // and, for output heads, the row -> logical-output map j = (m & 3) + 4 (m >> 3) (each logical output is
 // present in both lane halves so no cross-lane traffic is needed to read it).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -190,6 +191,11 @@ struct SharedNets {       // views into nerfds_weights
 };
 struct NerfNet {
   DenseView trunk[16], bottleneck, alpha, rgb_hidden[16], rgb;
+  // Optional: rgb hidden_0 with the bottleneck already folded in, [(TRUNK_W + cond) x RGB_W] in the kernel's K order
+  // [trunk_output | viewdir | normal] plus its bias [RGB_W]; pack_nerf then does not fold (the trainer packs parameter INDICES
+  // through this packer and folds on the device every step, nerfds_train.cpp build_fused_forward).
+  const float* prefolded = nullptr;
+  const float* prefolded_bias = nullptr;
 };
 
 template <class G> void pack_shared(StreamWriter& sw, const SharedNets& n, Plan pl) {
@@ -242,7 +248,11 @@ template <class G> void pack_nerf(StreamWriter& sw, const NerfNet& n, Plan pl) {
     const int W = G::RGB_W;
     auto fused = std::make_shared<std::vector<float>>((size_t)(TW + VD + NM) * W);
     auto fbias = std::make_shared<std::vector<float>>(W);
-    for (int c = 0; c < W; ++c) {
+    if (n.prefolded) {
+      std::copy(n.prefolded, n.prefolded + fused->size(), fused->begin());
+      std::copy(n.prefolded_bias, n.prefolded_bias + W, fbias->begin());
+    }
+    for (int c = 0; c < W && !n.prefolded; ++c) {
       for (int r = 0; r < TW; ++r) {
         double acc = G::X_IN_RGB ? (double)K.W(row_x + r, c) : 0.0;
         for (int k = 0; k < TW; ++k) acc += (double)B.W(r, k) * (double)K.W(k, c);

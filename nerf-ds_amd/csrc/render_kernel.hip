@@ -180,11 +180,18 @@ template <class PL, bool WIDE> struct Shape {
 template <class PL> constexpr int wg_waves() { return Shape<PL, false>::RAYS * Shape<PL, false>::SPLIT; }
 // LDS map: [0, RING_BYTES) weight ring | padded fp32 biases (shared, coarse NerfMLP, fine NerfMLP) | RAYS x WaveLds
 constexpr int BIAS_OFF = RING_BYTES;
+#ifdef NERFDS_TRAIN_FWD      // one level per launch: the shared nets and ONE NerfMLP
+template <class G> constexpr int bias_tiles() { return Dims<G>::SHARED_BIAS_TILES + Dims<G>::NERF_BIAS_TILES; }
+#else
 template <class G> constexpr int bias_tiles() { return Dims<G>::SHARED_BIAS_TILES + 2 * Dims<G>::NERF_BIAS_TILES; }
+#endif
 template <class G> constexpr int bias_bytes() { return cdiv(bias_tiles<G>(), 8) * 1024; }
 
 #ifndef NERFDS_RING_UNITS
 #define NERFDS_RING_UNITS 4
+#endif
+#ifndef NERFDS_TRAIN_VMCNT
+#define NERFDS_TRAIN_VMCNT 1      // 0: the training forward waits with vmcnt(0) at stage boundaries like the render kernels (A/B timing)
 #endif
 template <class G, class PL> struct Pipe {
   using Dm = Dims<G>;
@@ -239,7 +246,21 @@ template <class G, class PL> struct Pipe {
     // (Waiting with vmcnt(0) only was 1.5 % faster and ran clean on the uniform kernels, but the mixed-precision kernel showed
     // run-to-run differences with it: kept safe.)
     static_assert(NS == 4, "protocol is written for a 4-stage ring");
-#ifdef NERFDS_BOUNDARY_NO_LGKM
+#if defined(NERFDS_TRAIN_FWD) && NERFDS_TRAIN_VMCNT
+    // Training forward: the activation stores share VM_CNT with the LDS-DMA, and with vmcnt(0) every boundary also waits for the
+    // wave's youngest stores to be acknowledged.  vmcnt(PIECES) is enough and safe: loads complete in order AMONG LOADS, so "at
+    // most PIECES operations outstanding" means every load older than the PIECES youngest loads has landed - and the PIECES youngest
+    // loads are (at least as young as) the pieces of stage s + 2 that the previous boundary issued, which this boundary does not
+    // need (stages s and s + 1 are older).  That argument needs the previous boundary to have issued a stage: after a hole (nothing
+    // issued) the wait is vmcnt(0).  Measured: -0.75 ms per training step against vmcnt(0).
+    {
+      static_assert(PIECES == 4, "vmcnt(4) below");
+      const int tprev = s + NS - 2;              // the stage the previous boundary (s - 1) issued
+      const bool prev_issued = (tprev % STAGES) < USED_STAGES;
+      if (prev_issued) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+#elif defined(NERFDS_BOUNDARY_NO_LGKM)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -295,6 +316,24 @@ struct Cursor {
   int pos;      // stream position (unit index) of the next fragment
   int bt;       // index of the next bias tile (0 = first tile of the shared nets)
 };
+// Training forward (train_forward_kernel below): every hidden layer also writes its fp32 post-activation output to HBM, row-major
+// [sample][width], for the backward pass.  `row` = this lane's sample row of the layer being computed, + 4 * (lane >> 5) floats.
+struct TrainCursor : Cursor {
+  float* row;
+};
+// Accumulator registers 4g .. 4g + 3 of a lane are output features 32 * tile + 8g + 4h + 0..3 of its sample: four 16-byte stores.
+// (Tried and measured, DESIGN 8.1: staging the tile through LDS so that every store instruction writes whole 128-byte lines,
+// non-temporal stores, a quarter of the bytes per line - none of them changes the cost of the stores, ~3.5 ms per step on top of
+// 2.7 ms of arithmetic; only writing every layer into one L2-resident array does.)
+template <bool RELU> DEVI void store_tile(float* row_tile, const f32x16& acc) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = RELU ? relu_f(acc[4 * g + i]) : acc[4 * g + i];
+    *reinterpret_cast<f32x4*>(row_tile + 8 * g) = v;
+  }
+}
 
 // LDS image of the biases: tile t, lane half h, accumulator register r <-> row (r & 3) + 8 (r >> 2) + 4 h of the tile at
 // byte BIAS_OFF + (t >> 3) * 1024 + (t & 7) * 64 + 512 * h + 4 * r: the 16 values of a lane are one 64-byte run, the
@@ -540,9 +579,11 @@ template <class A, class... Rest> DEVI A& first_of(A& a, Rest&...) { return a; }
 template <class T> struct chunk_prec;
 template <int P, int NT, int K> struct chunk_prec<Chunk<P>[NT][K]> { static constexpr int value = P; static constexpr int chunks = K; };
 
-template <class G, class PL, int NT, int OT, bool RELU, int PO, class... Ins>
-DEVI void dense(Pipe<G, PL>& pipe, Cursor& cur, Carry<NT>& carry, Chunk<PO> (&out)[NT][2 * OT], Ins&... ins) {
+template <class G, class PL, int NT, int OT, bool RELU, class CUR, int PO, class... Ins>
+DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Carry<NT>& carry, Chunk<PO> (&out)[NT][2 * OT], Ins&... ins) {
   constexpr int TP = TILE_PAIR;
+  constexpr bool TRAIN = std::is_same_v<CUR, TrainCursor>;
+  static_assert(!TRAIN || (NT == 1 && !PL::UNIFORM), "the training forward runs a mixed two-unit plan: one N-tile, C++ epilogue");
   static_assert(OT % TP == 0, "layers have an even number of 32-feature tiles");
   // (uniform one-unit plans only: in the mixed plan - f16 networks around a split-bf16 warp field - the asm epilogue build gave
   // run-to-run differences on ~1 % of the rays of the fine level; the C++ epilogue build of the same kernel is clean)
@@ -676,6 +717,10 @@ DEVI void dense(Pipe<G, PL>& pipe, Cursor& cur, Carry<NT>& carry, Chunk<PO> (&ou
       } else {
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) tile_epilogue<PO, NT, RELU>(out, ot + tp, acc[tp]);
+        if constexpr (TRAIN) {
+#pragma unroll
+          for (int tp = 0; tp < TP; ++tp) store_tile<RELU>(cur.row + 32 * (ot + tp), acc[tp][0]);
+        }
       }
     }
   }
@@ -859,8 +904,13 @@ DEVI void rodrigues(float (&R)[9], const float (&w)[3], float st, float omc) {
 // the next network is parked in the wave's LDS block at once (it is going there for compositing anyway),
 // so the 8x256 trunk runs with (almost) only MFMA operands in registers.
 // ------------------------------------------------------------------------------------------------
-template <class G, class PL, int NT, class LT>
-DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int level, int lane, int s_base, int S, LT& L) {
+struct NoTrain { static constexpr bool ON = false; };
+DEVI void set_row(Cursor&, float*) {}
+DEVI void set_row(TrainCursor& c, float* p) { c.row = p; }
+
+template <class G, class PL, int NT, class LT, class TO = NoTrain>
+DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int level, int lane, int s_base, int S, LT& L,
+                     const TO& to = TO(), long long row_base = 0) {
   // s_base already includes this wave's share of a split batch (32 * NT * q)
   using D = Dims<G>;
   const int h = lane >> 5, ln = lane & 31;
@@ -884,8 +934,15 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
     }
   }
 
-  Cursor cur{0, 0};
+  std::conditional_t<TO::ON, TrainCursor, Cursor> cur;
+  cur.pos = 0;
+  cur.bt = 0;
   Carry<NT> carry;
+  // training forward: this lane's row of the [R * S][width] activation arrays (tail lanes repeat sample S - 1: same values, same address)
+  size_t row = 0;
+  if constexpr (TO::ON) row = (size_t)row_base + (size_t)slot_of(0);
+#define NERFDS_TRAIN_ROW(base, W) do { if constexpr (TO::ON) set_row(cur, (base) + row * (size_t)(W) + 4 * h); } while (0)
+#define NERFDS_TRAIN_HEAD(base, n) do { if constexpr (TO::ON) { _Pragma("unroll") for (int j_ = 0; j_ < (n); ++j_) (base)[row * (n) + j_] = hacc[0][0][j_]; } } while (0)
 
   // ---- MaskMLP (modules.py:409-434; models.py:967-975) ----
   float maskv[NT];
@@ -902,16 +959,25 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
         return zero_feat();
       });
     static_assert(G::MASK_DEPTH == 8 || !G::HAS_MASK, "mask net is unrolled for depth 8, skip 4");
+    NERFDS_TRAIN_ROW(to.mask_h[0], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, in0);
+    NERFDS_TRAIN_ROW(to.mask_h[1], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    NERFDS_TRAIN_ROW(to.mask_h[2], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b);
+    NERFDS_TRAIN_ROW(to.mask_h[3], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    NERFDS_TRAIN_ROW(to.mask_h[4], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b, in0);      // skip: [x, inputs] (modules.py:66-67)
+    NERFDS_TRAIN_ROW(to.mask_h[5], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    NERFDS_TRAIN_ROW(to.mask_h[6], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b);
+    NERFDS_TRAIN_ROW(to.mask_h[7], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
     f32x16 hacc[1][NT];
     head<G, PL, NT>(pipe, cur, carry, hacc, b);
+    NERFDS_TRAIN_HEAD(to.mask_logit, 1);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const float pm = fmaxf(hacc[0][nt][0], 0.f);                              // MaskMLP.output_activation = relu
@@ -938,14 +1004,21 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
         return zero_feat();
       });
     static_assert(G::WARP_DEPTH == 6 || !G::HAS_WARP, "warp trunk is unrolled for depth 6, skip 4");
+    NERFDS_TRAIN_ROW(to.warp_h[0], G::WARP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, in0);
+    NERFDS_TRAIN_ROW(to.warp_h[1], G::WARP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    NERFDS_TRAIN_ROW(to.warp_h[2], G::WARP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b);
+    NERFDS_TRAIN_ROW(to.warp_h[3], G::WARP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    NERFDS_TRAIN_ROW(to.warp_h[4], G::WARP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b, in0);
+    NERFDS_TRAIN_ROW(to.warp_h[5], G::WARP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
     f32x16 hacc[1][NT];
     head<G, PL, NT>(pipe, cur, carry, hacc, b);      // logical outputs: w = 0..2, v = 3..5
+    NERFDS_TRAIN_HEAD(to.wv, 6);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float w[3] = {hacc[0][nt][0], hacc[0][nt][1], hacc[0][nt][2]};
@@ -1022,14 +1095,21 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
         return zero_feat();
       });
     static_assert(G::HYP_DEPTH == 6 || !G::HAS_HYPER, "hyper sheet is unrolled for depth 6, skip 4");
+    NERFDS_TRAIN_ROW(to.hyper_h[0], G::HYP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, in0);
+    NERFDS_TRAIN_ROW(to.hyper_h[1], G::HYP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    NERFDS_TRAIN_ROW(to.hyper_h[2], G::HYP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b);
+    NERFDS_TRAIN_ROW(to.hyper_h[3], G::HYP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
+    NERFDS_TRAIN_ROW(to.hyper_h[4], G::HYP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b, in0);
+    NERFDS_TRAIN_ROW(to.hyper_h[5], G::HYP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
     f32x16 hacc[1][NT];
     head<G, PL, NT>(pipe, cur, carry, hacc, b);
+    NERFDS_TRAIN_HEAD(to.wamb, 2);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { wamb[nt][0] = hacc[0][nt][0]; wamb[nt][1] = hacc[0][nt][1]; }
   }
@@ -1057,17 +1137,26 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
         return zero_feat();
       });
     static_assert(G::TRUNK_DEPTH == 8 && G::TRUNK_SKIP == 4, "trunk is unrolled for depth 8, skip 4");
+    NERFDS_TRAIN_ROW(to.trunk_h[0], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, a, in0);
+    NERFDS_TRAIN_ROW(to.trunk_h[1], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, b, a);
+    NERFDS_TRAIN_ROW(to.trunk_h[2], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, a, b);
+    NERFDS_TRAIN_ROW(to.trunk_h[3], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, b, a);
+    NERFDS_TRAIN_ROW(to.trunk_h[4], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, a, b, in0);
+    NERFDS_TRAIN_ROW(to.trunk_h[5], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, b, a);
+    NERFDS_TRAIN_ROW(to.trunk_h[6], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, a, b);
+    NERFDS_TRAIN_ROW(to.trunk_h[7], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, b, a);          // b = trunk_output
     // (the activation-free bottleneck Dense, modules.py:255, is folded into rgb hidden_0 by the packer)
     f32x16 hacc[1][NT];
     head<G, PL, NT>(pipe, cur, carry, hacc, b);                    // alpha_mlp on trunk_output (modules.py:273-274)
+    NERFDS_TRAIN_HEAD(to.alphav, Dims<G>::ALPHA_OUT);
     // rgb condition chunks: [posenc(viewdir) | posenc(normal in observation frame)]
     Chunk<PR> cond[NT][D::COND_KC];
     WAVE_SYNC();                                              // parked SE3 state was written by the h == 0 lanes
@@ -1109,8 +1198,10 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
       });
     }
     Chunk<PR> c[NT][G::RGB_W / 16];
+    NERFDS_TRAIN_ROW(to.rgb_h, G::RGB_W);
     dense<G, PL, NT, G::RGB_W / 32, true>(pipe, cur, carry, c, b, cond);       // K order [trunk_output | cond]
     head<G, PL, NT>(pipe, cur, carry, hacc, c);
+    NERFDS_TRAIN_HEAD(to.rgb_logit, 3);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       {
@@ -1121,6 +1212,8 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
       }
   }
   pipe.finish_eval();
+#undef NERFDS_TRAIN_ROW
+#undef NERFDS_TRAIN_HEAD
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1438,6 +1531,78 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
   }
 }
 
+#ifdef NERFDS_TRAIN_FWD
+// ------------------------------------------------------------------------------------------------
+// Training forward of ONE level (training.py:198-511 -> models.py:867-1417 on the level's samples): the same field evaluation as
+// render_rays_kernel - same weight pipe, same register-chained layers - on depths the trainer has already drawn (to.z), with every
+// hidden layer's fp32 output and every head's raw output written to the trainer's workspace for the backward pass.  No
+// compositing here: the loss kernel composites from sigma / rgb (train_kernels.hip).  The host passes the level's NerfMLP
+// stream and biases in slot 1, so the kernel always evaluates "level 0".
+// ------------------------------------------------------------------------------------------------
+template <class G, class PL, bool WIDE>
+__global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train_forward_kernel(const KArgs ka, const TrainOut to) {
+  using SH = Shape<PL, WIDE>;
+  using WaveLds = WaveLdsT<SH::MAXS>;
+  constexpr int NT = SH::NT, SPLIT = SH::SPLIT, RAYS_PER_WG = SH::RAYS, WAVES = wg_waves<PL>(), BATCH = 32 * NT * SPLIT;
+  using Dm = Dims<G>;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int slot = wave / SPLIT, q = wave % SPLIT;
+  WaveLds& L = *reinterpret_cast<WaveLds*>(g_smem + BIAS_OFF + bias_bytes<G>() + slot * (int)sizeof(WaveLds));
+  auto ray_sync = [&]() { if constexpr (SPLIT > 1) __syncthreads(); else WAVE_SYNC(); };
+  Pipe<G, PL> pipe;
+  pipe.ws = make_rsrc(ka.wstream[0], Pipe<G, PL>::SHARED_PAD * 1024);
+  pipe.wn = pipe.wn_next = make_rsrc(ka.wstream[1], Pipe<G, PL>::NERF_PAD * 1024);
+  pipe.lane16 = lane * 16;
+  pipe.wave1k = wave * 1024;
+  pipe.prologue();
+  {  // biases -> LDS (as render_rays_kernel; only the shared nets and slot 1 are used)
+    constexpr int n0 = Dm::SHARED_BIAS_TILES * 32, n1 = Dm::NERF_BIAS_TILES * 32;
+    float* dst = reinterpret_cast<float*>(g_smem + BIAS_OFF);
+    for (int i = threadIdx.x; i < n0 + n1; i += 64 * WAVES) {
+      const float v = i < n0 ? ka.bias[0][i] : ka.bias[1][i - n0];
+      const int t = i >> 5, m = i & 31;
+      dst[bias_tile_off(t) / 4 + 128 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)] = v;
+    }
+    __syncthreads();
+  }
+  const int S = ka.nc;
+  const int groups = (ka.num_rays + RAYS_PER_WG - 1) / RAYS_PER_WG;
+  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const int ray_raw = grp * RAYS_PER_WG + slot;
+    const int ray = (ray_raw < ka.num_rays) ? ray_raw : ka.num_rays - 1;     // tail slots redo the last ray: same values to the same rows
+    RayConst rc;
+    float vdir[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      rc.o[c] = ka.origins[3 * (size_t)ray + c];
+      rc.d[c] = ka.directions[3 * (size_t)ray + c];
+      vdir[c] = (ka.viewdirs ? ka.viewdirs : ka.directions)[3 * (size_t)ray + c];
+    }
+    rc.gt_mask = (ka.gt_mask != nullptr) ? ka.gt_mask[ray] : 0.f;
+    if (q == 0) {
+      uint32_t wid = (G::HAS_WARP && ka.warp_id != nullptr) ? ka.warp_id[ray] : 0u;
+      wid = wid < (uint32_t)ka.num_embeds ? wid : (uint32_t)(ka.num_embeds - 1);
+      if (lane < 8) {
+        L.rayc[RC_WEMB + lane] = G::HAS_WARP ? ka.warp_embed[(size_t)wid * 8 + lane] : 0.f;
+        L.rayc[RC_MEMB + lane] = G::HAS_MASK ? ka.mask_embed[(size_t)wid * 8 + lane] : 0.f;
+      }
+      if (lane < 24) {
+        const int band = lane / 6, sc = (lane % 6) / 3, ch = lane % 3;
+        const float vdc = ch == 0 ? vdir[0] : (ch == 1 ? vdir[1] : vdir[2]);
+        L.rayc[RC_VDENC + lane] = sin_cw(fmaf(vdc, (float)(1 << band), sc ? 1.57079637f : 0.0f));
+      }
+      if (lane < 3) L.rayc[RC_VD + lane] = lane == 0 ? vdir[0] : (lane == 1 ? vdir[1] : vdir[2]);
+      for (int i = lane; i < S; i += 64) L.zs[i] = to.z[(size_t)ray * S + i];
+    }
+    ray_sync();
+    for (int sb = 0; sb < S; sb += BATCH)
+      eval_batch<G, PL, NT, WaveLds, TrainOut>(ka, rc, pipe, 0, lane, sb + 32 * NT * q, S, L, to, (long long)ray * S);
+    ray_sync();
+  }
+}
+#endif  // NERFDS_TRAIN_FWD
+
 }  // namespace nerfds
 
 // One translation unit per (graph, precision plan):
@@ -1449,13 +1614,38 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
 #define NERFDS_CAT2(a, b) a##b
 #define NERFDS_CAT(a, b) NERFDS_CAT2(a, b)
 namespace nerfds {
-#ifdef NERFDS_MIXED
+#if defined(NERFDS_TRAIN_FWD)
+// the trainer's arithmetic: 16-bit split operands everywhere, fp32 products in the warp field
+using KernelPlan = PlanT<TRAIN_PLAN.mask, TRAIN_PLAN.warp, TRAIN_PLAN.hyp, TRAIN_PLAN.trunk, TRAIN_PLAN.rgb>;
+#elif defined(NERFDS_MIXED)
 using KernelPlan = PlanT<NERFDS_MIX_MASK, NERFDS_MIX_WARP, NERFDS_MIX_HYP, NERFDS_MIX_TRUNK, NERFDS_MIX_RGB>;
 #else
 using KernelPlan = PlanT<NERFDS_PREC, NERFDS_PREC, NERFDS_PREC, NERFDS_PREC, NERFDS_PREC>;
 #endif
 }  // namespace nerfds
 
+#ifdef NERFDS_TRAIN_FWD
+template <bool WIDE> static void launch_train(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream) {
+  using namespace nerfds;
+  using SH = Shape<KernelPlan, WIDE>;
+  constexpr int lds = BIAS_OFF + bias_bytes<NERFDS_GRAPH>() + SH::RAYS * (int)sizeof(WaveLdsT<SH::MAXS>);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  auto kern = train_forward_kernel<NERFDS_GRAPH, KernelPlan, WIDE>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const long long groups = ((long long)ka.num_rays + SH::RAYS - 1) / SH::RAYS;
+  const int grid = (int)(groups < num_cus ? groups : num_cus);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wg_waves<KernelPlan>()), lds, static_cast<hipStream_t>(stream), ka, to);
+}
+// ka.nc = samples of the level (ka.nf unused); ka.wstream[1] / ka.bias[1] = the level's NerfMLP
+extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream) {
+  if (ka.nc > nerfds::Shape<nerfds::KernelPlan, false>::MAXS) launch_train<true>(ka, to, num_cus, stream);
+  else launch_train<false>(ka, to, num_cus, stream);
+}
+#else
 template <bool WIDE> static void launch_shape(const nerfds::KArgs& ka, int num_cus, void* stream) {
   using namespace nerfds;
   using SH = Shape<KernelPlan, WIDE>;
@@ -1477,3 +1667,4 @@ extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::KArgs& ka,
   if (ka.nc + ka.nf > nerfds::Shape<nerfds::KernelPlan, false>::MAXS) launch_shape<true>(ka, num_cus, stream);
   else launch_shape<false>(ka, num_cus, stream);
 }
+#endif

@@ -57,5 +57,9 @@ void trunk_in_jvp(hipStream_t, const Dims&, long long M, const float* xw, const 
 void target_norm(hipStream_t, long long M, const float* t_alpha, const float* wv, float* out);
 void clip_gradients(hipStream_t, float* g, long long n, float max_val, float max_norm, float* sumsq_scratch);
 void adam(hipStream_t, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2);
+// fused forward: weight streams / biases / folded rgb layer from the current parameters (see train_kernels.hip)
+void pack_stream(hipStream_t, const float* theta, const float* fold, long long P, const int* map, void* stream, int nfrag, int f32_lo, int f32_hi);
+void pack_bias(hipStream_t, const float* theta, const float* fold, long long P, const int* map, float* out, int n);
+void fold_rgb(hipStream_t, const float* B, const float* Bb, const float* K, const float* Kb, int TW, int W, int row_x, float* fold);
 
 }  // namespace nerfds_train

@@ -889,4 +889,76 @@ void adam(hipStream_t st, float* p, const float* g, float* m1, float* m2, long l
   LAUNCH(k_adam, n, st, p, g, m1, m2, n, lr, b1, b2, eps, c1, c2);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight streams of the fused forward (render_kernel.hip train_forward_kernel) from the CURRENT parameters, every step.
+// The host packs the streams once with the parameters replaced by their own indices (nerfds_train.cpp build_fused_forward):
+// map[i] = 1 + index into theta (or, past P, into `fold`) of the value at float slot i of the fp32-layout stream, 0 = padding.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float map_value(const float* theta, const float* fold, long long P, int m) {
+  if (m == 0) return 0.f;
+  const long long i = (long long)m - 1;
+  return i < P ? theta[i] : fold[i - P];
+}
+__device__ __forceinline__ unsigned short bf16_rne(float f) {      // pack.h f32_to_bf16_rne
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+// One thread per (fragment, lane): 8 k-slots of one output row.  Fragments [f32_lo, f32_hi) keep fp32 (slots 0-3 in the first
+// 1-KiB unit, 4-7 in the second), the others become split bf16 (hi in the first unit, lo = bf16(v - hi) in the second): pack.h frag_out.
+__global__ void k_pack_stream(const float* __restrict__ theta, const float* __restrict__ fold, long long P, const int* __restrict__ map,
+                              unsigned char* __restrict__ stream, int nfrag, int f32_lo, int f32_hi) {
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long long)nfrag * 64) return;
+  const int frag = (int)(tid >> 6), lane = (int)(tid & 63);
+  const int4 ma = *reinterpret_cast<const int4*>(map + (size_t)frag * 512 + lane * 4);
+  const int4 mb = *reinterpret_cast<const int4*>(map + (size_t)frag * 512 + 256 + lane * 4);
+  const int mi[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = map_value(theta, fold, P, mi[i]);
+  unsigned char* fa = stream + (size_t)frag * 2048 + lane * 16;
+  if (frag >= f32_lo && frag < f32_hi) {
+    *reinterpret_cast<float4*>(fa) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(fa + 1024) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned short h0 = bf16_rne(v[2 * i]), h1 = bf16_rne(v[2 * i + 1]);
+      const unsigned short l0 = bf16_rne(v[2 * i] - __uint_as_float((unsigned)h0 << 16)), l1 = bf16_rne(v[2 * i + 1] - __uint_as_float((unsigned)h1 << 16));
+      hi[i] = (unsigned)h0 | ((unsigned)h1 << 16);
+      lo[i] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+    *reinterpret_cast<uint4*>(fa) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *reinterpret_cast<uint4*>(fa + 1024) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+__global__ void k_pack_bias(const float* __restrict__ theta, const float* __restrict__ fold, long long P, const int* __restrict__ map, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = map_value(theta, fold, P, map[i]);
+}
+// The activation-free bottleneck Dense folded into rgb hidden_0 (pack.h pack_nerf; modules.py:255, 296-310), in double like the host packer:
+//   fold[r][c] = K[row_x + r][c] + sum_k B[r][k] K[k][c]   (r < TW),   fold[TW][c] = Kb[c] + sum_k Bb[k] K[k][c]
+__global__ void k_fold_rgb(const float* __restrict__ B, const float* __restrict__ Bb, const float* __restrict__ K, const float* __restrict__ Kb,
+                           int TW, int W, int row_x, float* __restrict__ fold) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (TW + 1) * W) return;
+  const int r = i / W, c = i % W;
+  double acc = r < TW ? (double)K[(size_t)(row_x + r) * W + c] : (double)Kb[c];
+  const float* left = r < TW ? B + (size_t)r * TW : Bb;
+  for (int k = 0; k < TW; ++k) acc += (double)left[k] * (double)K[(size_t)k * W + c];
+  fold[i] = (float)acc;
+}
+void pack_stream(hipStream_t st, const float* theta, const float* fold, long long P, const int* map, void* stream, int nfrag, int f32_lo, int f32_hi) {
+  LAUNCH(k_pack_stream, (long long)nfrag * 64, st, theta, fold, P, map, static_cast<unsigned char*>(stream), nfrag, f32_lo, f32_hi);
+}
+void pack_bias(hipStream_t st, const float* theta, const float* fold, long long P, const int* map, float* out, int n) {
+  LAUNCH(k_pack_bias, n, st, theta, fold, P, map, out, n);
+}
+void fold_rgb(hipStream_t st, const float* B, const float* Bb, const float* K, const float* Kb, int TW, int W, int row_x, float* fold) {
+  LAUNCH(k_fold_rgb, (long long)(TW + 1) * W, st, B, Bb, K, Kb, TW, W, row_x, fold);
+}
+
 }  // namespace nerfds_train

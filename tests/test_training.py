@@ -184,6 +184,37 @@ def test_training_step_at_config4_size():
 
 
 @pytest.mark.gpu
+def test_fused_forward_equals_the_layer_by_layer_forward(monkeypatch):
+  """The step's forward is ONE launch per level (render_kernel.hip train_forward_kernel: the render kernel's field evaluation writing
+  every activation); NERFDS_TRAIN_FUSED_FWD=0 runs the same forward as ~50 layer kernels.  Same parameters, rays and jitter: the two
+  losses agree to 1e-5, every gradient leaf to 2.5e-2 of its largest entry and the median leaf to 2e-3 (both forwards round operands
+  to split bf16 in a different order, and a ReLU unit within that rounding of zero switches its whole gradient path: the same
+  bounds as against the fp64 oracle above), with the ragged sizes (48 + 16 samples, 1000 rays: tail lanes and a tail workgroup) that the kernel has to clamp."""
+  from nerfds_amd.training import Trainer
+  cfg = nerf_ds_config(num_warp_embeds=16, near=0.3, far=1.7, num_coarse_samples=48, num_fine_samples=16)
+  params = init_params(cfg, 3, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  R = 1001
+  rng = np.random.default_rng(5)
+  d = rng.normal(size=(R, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+  batch = dict(origins=(rng.normal(size=(R, 3)) * 0.2).astype(np.float32), directions=d.astype(np.float32), viewdirs=d.astype(np.float32),
+               metadata={'warp': rng.integers(0, 16, (R, 1))}, mask=(rng.random((R, 1)) < 0.3).astype(np.float32),
+               rgb=rng.random((R, 3)).astype(np.float32))
+  objective = dict(warp_reg_loss_weight=0.001, back_facing_reg_weight=0.1, predicted_mask_loss_weight=0.1, sharp_weights_std=0.1)
+  res = {}
+  for mode in ('1', '0'):
+    monkeypatch.setenv('NERFDS_TRAIN_FUSED_FWD', mode)
+    tr = Trainer(cfg, params, max_rays=R)
+    stats = tr.step(batch, EX, 0.0, mask_ratio=0.7, grads_only=True, seed=11, objective=objective)
+    res[mode] = (stats, dict(tree_leaves(tr.get_grads())))
+    del tr
+  (sa, ga), (sb, gb) = res['1'], res['0']
+  for k in ('loss/fine', 'loss/coarse', 'loss/total'):
+    assert abs(sa[k] - sb[k]) <= 1e-5 * max(1.0, abs(sb[k])), (k, sa[k], sb[k])
+  errs = sorted((float(np.abs(ga[k] - gb[k]).max() / max(np.abs(gb[k]).max(), 1e-12)), k) for k in gb)
+  assert errs[-1][0] <= 2.5e-2 and errs[len(errs) // 2][0] <= 2e-3, errs[-3:]
+
+
+@pytest.mark.gpu
 def test_trainer_rejects_what_it_cannot_do():
   from nerfds_amd import static_config
   from nerfds_amd.training import Trainer
