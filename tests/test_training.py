@@ -184,16 +184,16 @@ def test_training_step_at_config4_size():
 
 
 @pytest.mark.gpu
-def test_fused_forward_equals_the_layer_by_layer_forward(monkeypatch):
+@pytest.mark.parametrize('R,nc,nf', [(1001, 48, 16), (70, 128, 128), (301, 24, 0)])
+def test_fused_forward_equals_the_layer_by_layer_forward(monkeypatch, R, nc, nf):
   """The step's forward is ONE launch per level (render_kernel.hip train_forward_kernel: the render kernel's field evaluation writing
   every activation); NERFDS_TRAIN_FUSED_FWD=0 runs the same forward as ~50 layer kernels.  Same parameters, rays and jitter: the two
   losses agree to 1e-5, every gradient leaf to 2.5e-2 of its largest entry and the median leaf to 2e-3 (both forwards round operands
   to split bf16 in a different order, and a ReLU unit within that rounding of zero switches its whole gradient path: the same
   bounds as against the fp64 oracle above), with the ragged sizes (48 + 16 samples, 1000 rays: tail lanes and a tail workgroup) that the kernel has to clamp."""
   from nerfds_amd.training import Trainer
-  cfg = nerf_ds_config(num_warp_embeds=16, near=0.3, far=1.7, num_coarse_samples=48, num_fine_samples=16)
+  cfg = nerf_ds_config(num_warp_embeds=16, near=0.3, far=1.7, num_coarse_samples=nc, num_fine_samples=nf)
   params = init_params(cfg, 3, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
-  R = 1001
   rng = np.random.default_rng(5)
   d = rng.normal(size=(R, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
   batch = dict(origins=(rng.normal(size=(R, 3)) * 0.2).astype(np.float32), directions=d.astype(np.float32), viewdirs=d.astype(np.float32),
@@ -209,9 +209,14 @@ def test_fused_forward_equals_the_layer_by_layer_forward(monkeypatch):
     del tr
   (sa, ga), (sb, gb) = res['1'], res['0']
   for k in ('loss/fine', 'loss/coarse', 'loss/total'):
-    assert abs(sa[k] - sb[k]) <= 1e-5 * max(1.0, abs(sb[k])), (k, sa[k], sb[k])
-  errs = sorted((float(np.abs(ga[k] - gb[k]).max() / max(np.abs(gb[k]).max(), 1e-12)), k) for k in gb)
-  assert errs[-1][0] <= 2.5e-2 and errs[len(errs) // 2][0] <= 2e-3, errs[-3:]
+    if k in sb:
+      assert abs(sa[k] - sb[k]) <= 1e-5 * max(1.0, abs(sb[k])), (k, sa[k], sb[k])
+  # per leaf, relative L2 with the denominator floored as in the oracle test above (near-zero leaves compare absolutely); each forward is
+  # within L2_TOL_2ND = 1.5e-2 of the fp64 oracle under this objective (the warp-field leaves, through the posenc backward), so two of
+  # them are within 3e-2 of each other; the median leaf agrees to 2e-3
+  gmax = max(float(np.abs(v).max()) for v in gb.values())
+  errs = sorted((float(np.linalg.norm(ga[k] - gb[k]) / max(np.linalg.norm(gb[k]), 1e-3 * gmax * np.sqrt(gb[k].size))), k) for k in gb)
+  assert errs[-1][0] <= 2 * L2_TOL_2ND['mfma'] and errs[len(errs) // 2][0] <= 2e-3, errs[-3:]
 
 
 @pytest.mark.gpu
