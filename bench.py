@@ -51,6 +51,7 @@ PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f32': 157.3, 'f16': 2500.0, 'm
 EXTRA = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
 # where the committed PMC measurement of the headline kernel lives (separate rocprofv3 passes of this command, tools/prof_bench.sh)
 TRAFFIC_FILE = 'profiles/r2_bf16_hbm_traffic.json'
+TRAIN_TRAFFIC_FILE = 'profiles/r2_train_hbm_traffic.json'
 
 
 def synth_rays(R, n_ids, seed, device):
@@ -169,9 +170,16 @@ def run_train(args, device):
   S = 3 * 64                                     # field evaluations per ray: 64 coarse + 128 fine
   M = R * S
   dims = layer_dims(cfg)
-  # traffic model of the layer-by-layer step (fp32 activations in HBM): forward X + Y; weight gradient X + dY; data gradient
-  # dY + Y (ReLU mask) + dX  ->  (2K + 2N) + (K + 3N) floats per sample and layer, 4 bytes each
-  hbm_bytes = 4.0 * M * sum(3 * K + 4 * N for K, N in dims)
+  # traffic model of the step (fp32 activations in HBM): forward Y only (ONE fused launch per level keeps X on chip; layer by layer,
+  # NERFDS_TRAIN_FUSED_FWD=0, it is X + Y); weight gradient X + dY; data gradient dY + Y (ReLU mask) + dX
+  #   ->  N (+ K) + (K + N) + (K + 2N) floats per sample and layer, 4 bytes each
+  fused_fwd = os.environ.get('NERFDS_TRAIN_FUSED_FWD', '1') != '0'
+  hbm_bytes = 4.0 * M * sum((2 if fused_fwd else 3) * K + 4 * N for K, N in dims)
+  traffic, traffic_source = None, None
+  tpath = os.path.join(ROOT, TRAIN_TRAFFIC_FILE)
+  if os.path.exists(tpath) and R == 4096 and fused_fwd:
+    tj = json.load(open(tpath))
+    traffic, traffic_source = tj['hbm_bytes_per_step'], f"{TRAIN_TRAFFIC_FILE} ({tj['measured_on']})"
   flop = 3 * FLOP_PER_RAY * R                    # fwd + bwd ~ 3 x forward
   result = {
       'metric': 'training rays/sec (batch 4096, MSE of both levels + backward + Adam, full warp+NerfMLP)',
@@ -182,9 +190,11 @@ def run_train(args, device):
                              'loss = MSE(fine) + MSE(coarse), backward through every network, Adam; sampling jitter drawn on chip',
                  'rays_per_step': R, 'parallelism': 'single GPU', 'exchange': 'none (1 GPU)'},
       'roofline': {'bound': 'hbm', 'achieved': hbm_bytes / dt / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': hbm_bytes / dt / 8e12,
-                   'traffic': None, 'traffic_source': 'profiles/r1_train_hbm_traffic.txt (per-kernel PMC passes: the layer kernels move exactly X + Y)',
-                   'kernel': 'whole step (about 150 layer kernels; each is HBM-bound)', 'algorithmic_bytes_per_step': hbm_bytes,
-                   'traffic_model': 'layer by layer, fp32 activations: forward X + Y, weight gradient X + dY, data gradient dY + Y + dX',
+                   'traffic': traffic, 'traffic_source': traffic_source,
+                   'kernel': 'whole step (one fused forward launch per level + about 100 backward layer kernels; each is HBM-bound)' if fused_fwd
+                             else 'whole step (about 150 layer kernels; each is HBM-bound)',
+                   'algorithmic_bytes_per_step': hbm_bytes,
+                   'traffic_model': 'fp32 activations: forward ' + ('Y (fused: X stays on chip)' if fused_fwd else 'X + Y') + ', weight gradient X + dY, data gradient dY + Y + dX',
                    'algorithmic_tflops': flop / dt / 1e12, 'mfma_frac_of_2500': flop / dt / 2.5e15},
       'loss_first': losses[0], 'loss_last': losses[-1],
   }
