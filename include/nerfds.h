@@ -239,8 +239,10 @@ int nerfds_frame_images(int device, const float* ray_records, int32_t height, in
  * draws the jitter, model_utils.py:84,217 - so pass a new seed every step.  loss_host (optional, HOST float[10]) receives
  * {rgb loss fine (coarse if there is no fine level), rgb loss coarse, weighted warp_reg / back_facing / mask / norm terms of the fine level,
  * the same four of the coarse level} and synchronises the stream.
- * Only the configs/nerf_ds.gin graph is built (NERFDS_ENOTSUP otherwise), and every dense layer runs on the library's own MFMA
- * kernels: a layer shape they do not cover is NERFDS_ENOTSUP as well (there is no library-GEMM detour).  The auxiliary losses of
+ * Only the configs/nerf_ds.gin graph is built (NERFDS_ENOTSUP otherwise).  With the widths of that gin file the forward of a level is
+ * ONE launch of the fused field kernel (the render kernel's evaluation, writing every activation the backward reads; its weight streams
+ * are re-packed on the device from the parameter vector at the start of every step); other widths, and the whole backward, run layer by
+ * layer on the library's own MFMA kernels: a layer shape they do not cover is NERFDS_ENOTSUP (there is no library-GEMM detour).  The auxiliary losses of
  * configs/nerf_ds.gin are selected by nerfds_train_objective; elastic / background / hyper-reg losses (off in every shipped gin)
  * are not built. */
 typedef struct nerfds_trainer nerfds_trainer;
