@@ -160,6 +160,32 @@ def test_chunked_philox_frame_equals_one_call():
   assert torch.equal(torch.cat(parts), whole)
 
 
+def test_large_launch_and_64_bit_ray_counter():
+  """One launch of 300 001 rays (more workgroup iterations than CUs, a ragged last group) starting at Philox ray counter 2^40 + 5
+  equals the same rays rendered as two launches split at an odd ray: per-ray results do not depend on the launch they are in, and the
+  ray counter is 64 bits wide end to end (a 32-bit counter would alias first_ray = 2^40 + 5 with 5)."""
+  from nerfds_amd.model import NerfModel
+  cfg, params = _setup(True)
+  R = 300001
+  g = torch.Generator(device='cpu').manual_seed(3)
+  d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+  rays = dict(origins=torch.randn(R, 3, generator=g) * 0.1, directions=d, viewdirs=d, metadata={'warp': torch.randint(0, 4, (R, 1), generator=g)})
+  m = NerfModel(cfg, device=torch.device('cuda', 0), precision='bf16')
+  kw = dict(use_predicted_norm=True, precision='bf16', rngs={'coarse': 5, 'fine': 6})
+  base = (1 << 40) + 5
+  whole = m.apply({'params': params}, rays, EXTRA, ray_offset=base, **kw)['fine']
+  cut = 123457
+  parts = []
+  for lo, hi in ((0, cut), (cut, R)):
+    sl = {k: (v[lo:hi] if k != 'metadata' else {'warp': v['warp'][lo:hi]}) for k, v in rays.items()}
+    parts.append(m.apply({'params': params}, sl, EXTRA, ray_offset=base + lo, **kw)['fine'])
+  for k in ('rgb', 'depth', 'acc'):
+    assert torch.equal(torch.cat([p[k] for p in parts]), whole[k]), k
+  low = m.apply({'params': params}, {k: (v[:64] if k != 'metadata' else {'warp': v['warp'][:64]}) for k, v in rays.items()}, EXTRA, ray_offset=5, **kw)['fine']
+  assert not torch.equal(low['rgb'], whole['rgb'][:64])
+  assert bool(torch.isfinite(whole['rgb']).all())
+
+
 def test_trainer_draws_the_stratified_jitter_on_chip():
   """Trainer.step without injected uniforms (the reference always draws them, model_utils.py:84,217): the Philox stream of
   csrc/philox.h - every step other depths, the same depths as the render kernel for the same seed, one sample per stratum."""
