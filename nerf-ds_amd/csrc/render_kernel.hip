@@ -168,6 +168,7 @@ template <int PM, int PW, int PH, int PT, int PR> struct PlanT {
 };
 // STAGE_BYTES (graphs.h): one ring stage = 16 units
 constexpr int NUM_STAGES = 4;          // ring depth
+enum { SEG_SHARED = 0, SEG_NERF = 1 };  // the two weight streams (Pipe)
 constexpr int RING_BYTES = NUM_STAGES * STAGE_BYTES;
 // Work shape.  NT = N-tiles (32 samples) per wave and evaluation; SPLIT = waves that share one ray's batch of
 // 32 * NT * SPLIT samples; RAYS = rays in flight per workgroup (each with its own RayLds block).
@@ -197,10 +198,20 @@ template <class G, class PL> struct Pipe {
   using Dm = Dims<G>;
   static constexpr int SU = STAGE_UNITS;                          // units per stage
   static constexpr int NS = NUM_STAGES;
+  // The fragments of the graph are TWO streams, each walked as a "segment": SEG_SHARED = [mask | warp | hyper] nets (the same
+  // weights for both levels), SEG_NERF = the NerfMLP of one level.  A segment's stage count is padded to a multiple of the ring
+  // depth (hole stages: a barrier, no DMA), so every segment starts in ring slot 0 and any segment can follow any other: which
+  // stream the last NS - 1 boundaries of a segment prefetch from is a run-time descriptor (`next`).  Sequence per ray group:
+  // shared, nerf(coarse) per coarse batch; then shared on the NEW fine samples only (the coarse samples' warp / hyper / mask
+  // results are reused: same networks, same inputs - models.py:1291-1300 evaluates them again and gets the same values) and
+  // nerf(fine) on every batch of the sorted union.
+  static constexpr int SHARED_UNITS = shared_units<G>(PL::value()), NERF_UNITS = nerf_units<G>(PL::value());
+  static constexpr bool HAS_SHARED = SHARED_UNITS > 0;
   // stream positions count the zero padding at the end of each stream (graphs.h pad_units)
-  static constexpr int SHARED_PAD = pad_units(shared_units<G>(PL::value())), NERF_PAD = pad_units(nerf_units<G>(PL::value()));
-  static constexpr int SHARED_STAGES = SHARED_PAD / SU, USED_STAGES = (SHARED_PAD + NERF_PAD) / SU;
-  static constexpr int STAGES = cdiv(USED_STAGES, NS) * NS;       // per evaluation, padded so ring slots survive the wrap
+  static constexpr int SHARED_PAD = pad_units(SHARED_UNITS), NERF_PAD = pad_units(NERF_UNITS);
+  static constexpr int seg_used(int seg) { return (seg == SEG_SHARED ? SHARED_PAD : NERF_PAD) / SU; }       // stages that hold data
+  static constexpr int seg_stages(int seg) { return cdiv(seg_used(seg), NS) * NS; }                          // incl. hole stages
+  static_assert((!HAS_SHARED || seg_used(SEG_SHARED) >= NS - 1) && seg_used(SEG_NERF) >= NS - 1, "the wrap prefetch needs NS - 1 stages in every segment");
   static constexpr int WAVES = wg_waves<PL>();
   static constexpr int PIECES = SU / WAVES;                       // 1 KiB LDS-DMA pieces per wave per stage
   // LDS -> register prefetch distance in units: a ds_read_b128 takes ~100+ cycles to return under load, a bf16 unit is
@@ -208,34 +219,33 @@ template <class G, class PL> struct Pipe {
   static constexpr int RD = NERFDS_RING_UNITS;
   static_assert(RD <= SU && RD >= 2, "prefetch reaches at most one stage ahead");
   u32x4 ring[RD];
-  rsrc_t ws;        // shared stream
-  rsrc_t wn;        // NerfMLP stream of the level being evaluated
-  rsrc_t wn_next;   // NerfMLP stream of the level evaluated next (wrap-around prefetch)
+  rsrc_t cur;       // stream of the segment being walked
+  rsrc_t next;      // stream of the segment walked next (wrap-around prefetch)
   int lane16;
   int wave1k;       // wave index in the workgroup * 1024 (SGPR)
 
-  // This wave's share of stage t: LDS-DMA (buffer_load ... lds), 1 KiB per instruction, no VGPRs.  Which
-  // stream a stage comes from is a compile-time fact; only "+ wave * 1024" is run-time (one s_add).
-  DEVI void issue_stage(int t) {
+  // This wave's share of stage t of segment `seg` (t >= seg_stages: stage t - seg_stages of the next segment): LDS-DMA
+  // (buffer_load ... lds), 1 KiB per instruction, no VGPRs.  Everything but "+ wave * 1024" (one s_add) and the descriptor is a
+  // compile-time fact.
+  DEVI void issue_stage(int seg, int t) {
     if (NERFDS_ABLATE & 1) return;
-    const bool wrap = t >= STAGES;
-    const int tt = t % STAGES, slot = t % NS;
-    if (tt >= USED_STAGES) return;                                 // hole stage
-    const bool shared = tt < SHARED_STAGES;
-    const int base = (shared ? tt : tt - SHARED_STAGES) * STAGE_BYTES;
+    const bool wrap = t >= seg_stages(seg);
+    const int tt = wrap ? t - seg_stages(seg) : t, slot = t % NS;
+    if (!wrap && tt >= seg_used(seg)) return;                      // hole stage
+    const int base = tt * STAGE_BYTES;
 #pragma unroll
     for (int k = 0; k < PIECES; ++k) {
       // readfirstlane makes the uniformity of the scalar operands provable: without it hipcc may keep them in
       // VGPRs under SGPR pressure and wrap every LDS-DMA in a waterfall loop (cdna guide T20).
       const int off = __builtin_amdgcn_readfirstlane(WAVES * k * 1024 + wave1k);
       auto dst = (__attribute__((address_space(3))) void*)(g_smem + slot * STAGE_BYTES + off);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(shared ? ws : (wrap ? wn_next : wn), dst, 16, lane16, base + off, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrap ? next : cur, dst, 16, lane16, base + off, 0, 0);
     }
   }
   // Entering stage s: stages s and s + 1 are complete in LDS (so the LDS->register prefetch can run ahead across the
   // next boundary without a cold start), stage s + 2 may still be in flight, every wave is done with stage s - 1,
   // whose slot is refilled with stage s + NS - 1.
-  DEVI void boundary(int s) {
+  DEVI void boundary(int seg, int s) {
     // vmcnt(0): every LDS-DMA this wave has issued (stages <= s + 2, the youngest a full stage ago) has landed.
     // A COUNTED vmcnt(N) is NOT safe here: on gfx9-family VM_CNT, loads and stores complete out of order with respect
     // to each other, so a younger store (ray-record store, register spill) retiring early lets the count drop below N
@@ -255,8 +265,8 @@ template <class G, class PL> struct Pipe {
     // issued) the wait is vmcnt(0).  Measured: -0.75 ms per training step against vmcnt(0).
     {
       static_assert(PIECES == 4, "vmcnt(4) below");
-      const int tprev = s + NS - 2;              // the stage the previous boundary (s - 1) issued
-      const bool prev_issued = (tprev % STAGES) < USED_STAGES;
+      const int tprev = s + NS - 2;              // the stage the previous boundary issued (s == 0: the previous segment's last boundary)
+      const bool prev_issued = tprev >= seg_stages(seg) || tprev < seg_used(seg);
       if (prev_issued) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
@@ -267,11 +277,12 @@ template <class G, class PL> struct Pipe {
 #endif
     if (!(NERFDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();      // raw barrier (no compiler-added fences)
     if (NERFDS_DBG & 2) __builtin_amdgcn_s_sleep(4);
-    issue_stage(s + NS - 1);
+    issue_stage(seg, s + NS - 1);
   }
-  DEVI void prologue() {
+  // the first NS - 1 stages of the first segment of the kernel
+  DEVI void prologue(int seg) {
 #pragma unroll
-    for (int t = 0; t < NS - 1; ++t) issue_stage(t);
+    for (int t = 0; t < NS - 1; ++t) issue_stage(seg, t);
   }
   DEVI u32x4 unit(int u) const {
 #if (NERFDS_ABLATE & 32) && defined(__HIP_DEVICE_COMPILE__)
@@ -280,16 +291,16 @@ template <class G, class PL> struct Pipe {
     const int off = ((u / SU) % NS) * STAGE_BYTES + (u % SU) * 1024;
     return *reinterpret_cast<const u32x4*>(g_smem + off + lane16);
   }
-  DEVI void begin_stage(int u0) {   // u0: first unit of the stage
-    boundary(u0 / SU);
-    if (u0 == 0 || u0 == SHARED_PAD) {        // cold start of a stream segment: fill the register ring
+  DEVI void begin_stage(int seg, int u0) {   // u0: first unit of the stage
+    boundary(seg, u0 / SU);
+    if (u0 == 0) {                           // cold start of a segment: fill the register ring
 #pragma unroll
-      for (int d = 0; d < RD; ++d) ring[(u0 + d) % RD] = unit(u0 + d);
+      for (int d = 0; d < RD; ++d) ring[d % RD] = unit(d);
     }
   }
   // unit u has been consumed (or skipped): its ring slot takes unit u + RD (stage (u / SU) + 1 is resident)
-  DEVI void refill(int u) {
-    if ((u + RD) / SU < USED_STAGES) ring[u % RD] = unit(u + RD);
+  DEVI void refill(int seg, int u) {
+    if ((u + RD) / SU < seg_used(seg)) ring[u % RD] = unit(u + RD);
   }
   template <int P> DEVI WFrag<P> frag(int u) const {
     WFrag<P> w;
@@ -306,14 +317,15 @@ template <class G, class PL> struct Pipe {
     }
     return w;
   }
-  DEVI void finish_eval() {    // boundaries of the hole stages keep the barrier count and the ring in step
+  DEVI void finish_segment(int seg) {    // boundaries of the hole stages keep the barrier count and the ring in step
 #pragma unroll
-    for (int s = USED_STAGES; s < STAGES; ++s) boundary(s);
+    for (int s = seg_used(seg); s < seg_stages(seg); ++s) boundary(seg, s);
   }
 };
 
 struct Cursor {
-  int pos;      // stream position (unit index) of the next fragment
+  int seg;      // SEG_SHARED / SEG_NERF: the stream being walked
+  int pos;      // position (unit index) of the next fragment in that stream
   int bt;       // index of the next bias tile (0 = first tile of the shared nets)
 };
 // Training forward (train_forward_kernel below): every hidden layer also writes its fp32 post-activation output to HBM, row-major
@@ -381,13 +393,13 @@ DEVI void accum(f32x16 (&acc)[TP][NT], Pipe<G, PL>& pipe, Cursor& cur, const Chu
       const int u = cur.pos;
       // First fragment that touches a new stage (a two-unit fragment may straddle: its first unit is in the register
       // ring already, and so is every other unit of the stage that is being retired - the ring runs RD units ahead).
-      if (u % PP::SU == 0) pipe.begin_stage(u);
-      else if (NP == 2 && (u + 1) % PP::SU == 0) pipe.begin_stage(u + 1);
+      if (u % PP::SU == 0) pipe.begin_stage(cur.seg, u);
+      else if (NP == 2 && (u + 1) % PP::SU == 0) pipe.begin_stage(cur.seg, u + 1);
       const WFrag<P> w = pipe.template frag<P>(u);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) mma<P>(acc[tp][nt], w, in[nt][kc]);
 #pragma unroll
-      for (int q = 0; q < NP; ++q) pipe.refill(u + q);
+      for (int q = 0; q < NP; ++q) pipe.refill(cur.seg, u + q);
       cur.pos += NP;
       slot(j, tp);
       ++j;
@@ -760,7 +772,7 @@ DEVI void head(Pipe<G, PL>& pipe, Cursor& cur, Carry<NT>& carry, f32x16 (&acc)[1
 // ------------------------------------------------------------------------------------------------
 // sin / cos with a 3-term Cody-Waite reduction (fma) and degree-9/8 minimax kernels on [-pi/4, pi/4]: ~1-2 ulp while
 // the quadrant count stays exact in fp32 (|a| < ~1e7; posenc arguments are |x| * 2^7 at most).  Branch-free on purpose:
-// eval_batch must not contain divergent regions (see the note at eval_batch), which rules out libm's sinf/cosf.
+// the field evaluation must not contain divergent regions (see the note in eval_shared), which rules out libm's sinf/cosf.
 DEVI void sincos_cw(float a, float& sn_out, float& cs_out) {
   float k = rintf(a * 0.636619772f);
   int q = (int)k;
@@ -908,41 +920,47 @@ struct NoTrain { static constexpr bool ON = false; };
 DEVI void set_row(Cursor&, float*) {}
 DEVI void set_row(TrainCursor& c, float* p) { c.row = p; }
 
+// Which samples the N-tiles of this lane evaluate: depth z and the slot of the ray's LDS block (SoA by sample) that receives /
+// holds the sample's per-sample state.  Tail lanes repeat the last sample (same values to the same slot).
+template <int NT> struct Samples {
+  float z[NT];
+  int slot[NT];
+};
+
+#define NERFDS_TRAIN_ROW(base, W) do { if constexpr (TO::ON) set_row(cur, (base) + row * (size_t)(W) + 4 * h); } while (0)
+#define NERFDS_TRAIN_HEAD(base, n) do { if constexpr (TO::ON) { _Pragma("unroll") for (int j_ = 0; j_ < (n); ++j_) (base)[row * (n) + j_] = hacc[0][0][j_]; } } while (0)
+
+// ---- The level-independent networks on one batch of 32 * NT samples: MaskMLP -> SE(3) field + exp_se3 -> hyper sheet.
+// Results are parked in the ray's LDS block at the sample's slot: predicted mask, warped point + ambient coordinates (SV_WP),
+// rotation / translation fields, and the rotation itself (axis, sin, 1 - cos) for the normal conditioning of eval_nerf.
+// `next`-stream bookkeeping is the caller's (pipe.cur / pipe.next).  `row` (training forward): this lane's row of the
+// [R * S][width] activation arrays.
 template <class G, class PL, int NT, class LT, class TO = NoTrain>
-DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int level, int lane, int s_base, int S, LT& L,
-                     const TO& to = TO(), long long row_base = 0) {
-  // s_base already includes this wave's share of a split batch (32 * NT * q)
+DEVI void eval_shared(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int lane, const Samples<NT>& sm, LT& L,
+                      const TO& to = TO(), size_t row = 0) {
   using D = Dims<G>;
-  const int h = lane >> 5, ln = lane & 31;
-  auto sample_of = [&](int nt) { return s_base + 32 * nt + ln; };
-  auto slot_of = [&](int nt) { const int s = sample_of(nt); return s < S ? s : S - 1; };   // clamp: tail lanes redo the last sample
-  // Per-sample results are stored by EVERY lane, unconditionally, to slot_of(nt): the two lane halves of a sample
-  // (and the clamped tail lanes, which recompute sample S - 1) hold bit-identical values, so the duplicate stores are
-  // harmless.  They must not be predicated: eval_batch has to stay free of divergent (partial-EXEC) regions, because
+  const int h = lane >> 5;
+  // Per-sample results are stored by EVERY lane, unconditionally, to the sample's slot: the two lane halves of a sample
+  // (and the clamped tail lanes, which recompute the last sample) hold bit-identical values, so the duplicate stores are
+  // harmless.  They must not be predicated: the evaluation has to stay free of divergent (partial-EXEC) regions, because
   // this hipcc places VGPR->AGPR live-range-split copies at the top of the join block, BEFORE exec is restored; the
   // copy then saves only the active lanes and the later full-EXEC reload returns garbage in the others (seen as
   // run-to-run varying rgb in the split-bf16 kernel).  Same reason for the branch-free sincos_cw above.
-
   float x[NT][3], xw[NT][3];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const float z = L.zs[slot_of(nt)];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      x[nt][c] = __fadd_rn(rc.o[c], __fmul_rn(z, rc.d[c]));   // model_utils.py:91-92
+      x[nt][c] = __fadd_rn(rc.o[c], __fmul_rn(sm.z[nt], rc.d[c]));   // model_utils.py:91-92
       xw[nt][c] = x[nt][c];
     }
   }
 
   std::conditional_t<TO::ON, TrainCursor, Cursor> cur;
+  cur.seg = SEG_SHARED;
   cur.pos = 0;
   cur.bt = 0;
   Carry<NT> carry;
-  // training forward: this lane's row of the [R * S][width] activation arrays (tail lanes repeat sample S - 1: same values, same address)
-  size_t row = 0;
-  if constexpr (TO::ON) row = (size_t)row_base + (size_t)slot_of(0);
-#define NERFDS_TRAIN_ROW(base, W) do { if constexpr (TO::ON) set_row(cur, (base) + row * (size_t)(W) + 4 * h); } while (0)
-#define NERFDS_TRAIN_HEAD(base, n) do { if constexpr (TO::ON) { _Pragma("unroll") for (int j_ = 0; j_ < (n); ++j_) (base)[row * (n) + j_] = hacc[0][0][j_]; } } while (0)
 
   // ---- MaskMLP (modules.py:409-434; models.py:967-975) ----
   float maskv[NT];
@@ -982,11 +1000,11 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
     for (int nt = 0; nt < NT; ++nt) {
       const float pm = fmaxf(hacc[0][nt][0], 0.f);                              // MaskMLP.output_activation = relu
       maskv[nt] = pm * ka.mask_ratio + rc.gt_mask * (1.0f - ka.mask_ratio);  // models.py:975
-      L.sv[SV_MASK][slot_of(nt)] = pm;
+      L.sv[SV_MASK][sm.slot[nt]] = pm;
     }
   } else {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) L.sv[SV_MASK][slot_of(nt)] = 0.f;
+    for (int nt = 0; nt < NT; ++nt) L.sv[SV_MASK][sm.slot[nt]] = 0.f;
   }
 
   // ---- SE3Field (warping.py:200-237) + exp_se3 (rigid_body.py:77-101) ----
@@ -1048,7 +1066,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
       for (int r = 0; r < 3; ++r)
         xw[nt][r] = Rm[3 * r] * x[nt][0] + Rm[3 * r + 1] * x[nt][1] + Rm[3 * r + 2] * x[nt][2] + pt[r];
       {
-        const int s = slot_of(nt);
+        const int s = sm.slot[nt];
         // rotation field: normalize(R @ normalize(1,1,1)) (models.py:1292-1296); translation field: R @ 0 + p
         float rf[3];
 #pragma unroll
@@ -1069,7 +1087,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       {
-        const int s = slot_of(nt);
+        const int s = sm.slot[nt];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           L.sv[SV_WP + c][s] = x[nt][c];
@@ -1116,13 +1134,34 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
     {
-      L.sv[SV_WP + 3][slot_of(nt)] = wamb[nt][0];
-      L.sv[SV_WP + 4][slot_of(nt)] = wamb[nt][1];
+      L.sv[SV_WP + 3][sm.slot[nt]] = wamb[nt][0];
+      L.sv[SV_WP + 4][sm.slot[nt]] = wamb[nt][1];
     }
+  if constexpr (Pipe<G, PL>::HAS_SHARED) pipe.finish_segment(SEG_SHARED);
+}
 
-  // ---- NerfMLP of this level (modules.py:243-313; models.py:1043-1047, 1268-1270) ----
-  cur.pos = Pipe<G, PL>::SHARED_PAD;    // skip the zero padding of the shared stream
+// ---- NerfMLP of one level (modules.py:243-313; models.py:1043-1047, 1268-1270) on one batch of 32 * NT samples whose warped
+// point, ambient coordinates and rotation are parked at their slots (eval_shared, possibly of an earlier pass: the coarse
+// samples of the fine level).  Parks sigma, rgb and the raw predicted normal at the slots.
+template <class G, class PL, int NT, class LT, class TO = NoTrain>
+DEVI void eval_nerf(const KArgs& ka, Pipe<G, PL>& pipe, int level, int lane, const Samples<NT>& sm, LT& L,
+                    const TO& to = TO(), size_t row = 0) {
+  using D = Dims<G>;
+  const int h = lane >> 5;
+  std::conditional_t<TO::ON, TrainCursor, Cursor> cur;
+  cur.seg = SEG_NERF;
+  cur.pos = 0;
   cur.bt = D::SHARED_BIAS_TILES + level * D::NERF_BIAS_TILES;
+  Carry<NT> carry;
+  WAVE_SYNC();                                                // the parked state was written by the twin lane / an earlier pass
+  float xw[NT][3], wamb[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xw[nt][c] = L.sv[SV_WP + c][sm.slot[nt]];
+    wamb[nt][0] = L.sv[SV_WP + 3][sm.slot[nt]];
+    wamb[nt][1] = L.sv[SV_WP + 4][sm.slot[nt]];
+  }
   constexpr int TW16 = G::TRUNK_W / 16, TW32 = G::TRUNK_W / 32;
   {
     constexpr int P = PL::TRUNK, PR = PL::RGB;
@@ -1159,20 +1198,19 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
     NERFDS_TRAIN_HEAD(to.alphav, Dims<G>::ALPHA_OUT);
     // rgb condition chunks: [posenc(viewdir) | posenc(normal in observation frame)]
     Chunk<PR> cond[NT][D::COND_KC];
-    WAVE_SYNC();                                              // parked SE3 state was written by the h == 0 lanes
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float nin[3] = {0.f, 0.f, 0.f};
-      L.sv[SV_SIGMA][slot_of(nt)] = softplus_f(hacc[0][nt][0]);                    // models.py:577
+      const int sl = sm.slot[nt];
+      L.sv[SV_SIGMA][sl] = softplus_f(hacc[0][nt][0]);                    // models.py:577
       if constexpr (G::PREDICT_NORM) {
         float n[3] = {hacc[0][nt][1], hacc[0][nt][2], hacc[0][nt][3]};
         {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) L.sv[SV_NORM + c][slot_of(nt)] = n[c];
+          for (int c = 0; c < 3; ++c) L.sv[SV_NORM + c][sl] = n[c];
         }
         normalize3(n);                                                      // models.py:1124
         if constexpr (G::HAS_WARP) {
-          const int sl = slot_of(nt);
           const float ax[3] = {L.sv[SV_AX][sl], L.sv[SV_AX + 1][sl], L.sv[SV_AX + 2][sl]};
           float Rm[9];
           rodrigues(Rm, ax, L.sv[SV_SN][sl], L.sv[SV_OMC][sl]);
@@ -1185,7 +1223,7 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
       } else {
         {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) L.sv[SV_NORM + c][slot_of(nt)] = 0.f;
+          for (int c = 0; c < 3; ++c) L.sv[SV_NORM + c][sl] = 0.f;
         }
       }
       build_chunks<PR, D::COND_KC>(cond[nt], h, [&](int f) {
@@ -1205,16 +1243,16 @@ DEVI void eval_batch(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, int
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       {
-        const int s = slot_of(nt);
+        const int s = sm.slot[nt];
         L.sv[SV_RGB + 0][s] = sigmoid_f(hacc[0][nt][0]);                       // models.py:576
         L.sv[SV_RGB + 1][s] = sigmoid_f(hacc[0][nt][1]);
         L.sv[SV_RGB + 2][s] = sigmoid_f(hacc[0][nt][2]);
       }
   }
-  pipe.finish_eval();
+  pipe.finish_segment(SEG_NERF);
+}
 #undef NERFDS_TRAIN_ROW
 #undef NERFDS_TRAIN_HEAD
-}
 
 // ------------------------------------------------------------------------------------------------
 // Compositing of one level (model_utils.py:95-159, 272-317; models.py:1346-1415) -> ray record.
@@ -1368,7 +1406,10 @@ template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int n
     zf[j] = b0 + t * (b1 - b0);
   }
   WAVE_SYNC();
-  // union into zn (unsorted), then rank-sort into zs
+  // union into zn (unsorted), then rank-sort into zs.  The level-independent per-sample state of the COARSE samples (eval_shared:
+  // predicted mask, warped point + ambient coordinates, rotation / translation fields, rotation) moves with them to their slots
+  // in the sorted union - the fine level evaluates the mask / warp / hyper networks only on the nf NEW samples, whose slots are
+  // left in L.cdf (as integers) and whose depths stay in zn[nc ..].
   const int n = nc + nf;
 #pragma unroll
   for (int j = 0; j < MAX_SAMPLES / 64; ++j) {
@@ -1377,8 +1418,13 @@ template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int n
     if (k < nf) L.zn[nc + k] = zf[j];
   }
   WAVE_SYNC();
-  for (int j = 0; j * 64 < n; ++j) {
-    int i = lane + 64 * j;
+  constexpr int NJ = MAX_SAMPLES / 64, NSTATE = 1 + (SV_COUNT - SV_WP);
+  int rk[NJ];
+  float st[NJ][NSTATE];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = lane + 64 * j;
+    rk[j] = 0;
     if (i < n) {
       const float v = L.zn[i];
       int rank = 0;
@@ -1386,7 +1432,24 @@ template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int n
         const float o = L.zn[q];
         rank += (o < v || (o == v && q < i)) ? 1 : 0;
       }
-      L.zs[rank] = v;
+      rk[j] = rank;
+    }
+    const int ic = i < nc ? i : nc - 1;
+    st[j][0] = L.sv[SV_MASK][ic];
+#pragma unroll
+    for (int a = 0; a < SV_COUNT - SV_WP; ++a) st[j][1 + a] = L.sv[SV_WP + a][ic];
+  }
+  WAVE_SYNC();
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = lane + 64 * j;
+    if (i < n) L.zs[rk[j]] = L.zn[i];
+    if (i < nc) {
+      L.sv[SV_MASK][rk[j]] = st[j][0];
+#pragma unroll
+      for (int a = 0; a < SV_COUNT - SV_WP; ++a) L.sv[SV_WP + a][rk[j]] = st[j][1 + a];
+    } else if (i < n) {
+      reinterpret_cast<int*>(L.cdf)[i - nc] = rk[j];
     }
   }
   WAVE_SYNC();
@@ -1417,22 +1480,22 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
     for (int i = threadIdx.x; i < total / 4; i += 64 * WAVES) reinterpret_cast<float*>(g_smem)[i] = 0.f;
     __syncthreads();
   }
+  using PP = Pipe<G, PL>;
   Pipe<G, PL> pipe;
-  const rsrc_t rs_nerf[2] = {make_rsrc(ka.wstream[1], Pipe<G, PL>::NERF_PAD * 1024),
-                             make_rsrc(ka.wstream[2], Pipe<G, PL>::NERF_PAD * 1024)};
-  pipe.ws = make_rsrc(ka.wstream[0], Pipe<G, PL>::SHARED_PAD * 1024);
-  pipe.wn = pipe.wn_next = rs_nerf[0];
+  const rsrc_t rs_nerf[2] = {make_rsrc(ka.wstream[1], PP::NERF_PAD * 1024), make_rsrc(ka.wstream[2], PP::NERF_PAD * 1024)};
+  const rsrc_t rs_shared = PP::HAS_SHARED ? make_rsrc(ka.wstream[0], PP::SHARED_PAD * 1024) : rs_nerf[0];
+  pipe.cur = pipe.next = PP::HAS_SHARED ? rs_shared : rs_nerf[0];
   pipe.lane16 = lane * 16;
   pipe.wave1k = wave * 1024;
-  pipe.prologue();     // the first NS - 1 stages of the first (coarse) evaluation
-  auto set_level = [&](int level, int next_level) {
-    pipe.wn = level ? rs_nerf[1] : rs_nerf[0];
-    pipe.wn_next = next_level ? rs_nerf[1] : rs_nerf[0];
-  };
+  pipe.prologue(PP::HAS_SHARED ? SEG_SHARED : SEG_NERF);     // the first NS - 1 stages of the first segment
   {  // padded biases ([tile][32 rows] from the packer) -> LDS in the bias_tile_off layout, once per workgroup
     constexpr int n0 = Dm::SHARED_BIAS_TILES * 32, n1 = Dm::NERF_BIAS_TILES * 32;     // float counts
     float* dst = reinterpret_cast<float*>(g_smem + BIAS_OFF);
-    for (int i = threadIdx.x; i < n0 + 2 * n1; i += 64 * WAVES) {
+    // Uniform trip count (the tail threads repeat the last element: same value to the same address): a divergent loop here is a
+    // region across which `lane` and friends are live, and this hipcc has placed a live-range-split copy of `lane` at the top of
+    // such a loop's join block, ahead of the exec restore (tools/isa_lint.py; seen as wild per-sample stores of the fp32 kernel).
+    for (int i0 = 0; i0 < n0 + 2 * n1; i0 += 64 * WAVES) {
+      const int ix = i0 + (int)threadIdx.x, i = ix < n0 + 2 * n1 ? ix : n0 + 2 * n1 - 1;
       const float v = i < n0 ? ka.bias[0][i] : (i < n0 + n1 ? ka.bias[1][i - n0] : ka.bias[2][i - n0 - n1]);
       const int t = i >> 5, m = i & 31;                      // row m = (r & 3) + 8 (r >> 2) + 4 h  ->  h = (m >> 2) & 1, r = (m & 3) + 4 (m >> 3)
       dst[bias_tile_off(t) / 4 + 128 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)] = v;
@@ -1497,10 +1560,26 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
     }
     ray_sync();
 
-    // ---- coarse level ----
+    const int ln = lane & 31;
+    auto samples_at = [&](int s0, int S) {       // slots s0 + 32 nt + (lane & 31) of a level with S sorted samples
+      Samples<NT> sm;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int sx = s0 + 32 * nt + ln;
+        sm.slot[nt] = sx < S ? sx : S - 1;
+        sm.z[nt] = L.zs[sm.slot[nt]];
+      }
+      return sm;
+    };
+    // ---- coarse level: every network on every sample ----
     for (int sb = 0; sb < nc; sb += BATCH) {
-      set_level(0, (sb + BATCH < nc) ? 0 : (nf > 0 ? 1 : 0));
-      eval_batch<G, PL, NT>(ka, rc, pipe, 0, lane, sb + 32 * NT * q, nc, L);
+      const Samples<NT> sm = samples_at(sb + 32 * NT * q, nc);
+      if constexpr (PP::HAS_SHARED) { pipe.cur = rs_shared; pipe.next = rs_nerf[0]; }
+      eval_shared<G, PL, NT>(ka, rc, pipe, lane, sm, L);
+      pipe.cur = rs_nerf[0];
+      if constexpr (PP::HAS_SHARED) pipe.next = rs_shared;      // another coarse batch, the fine level's new samples, or the next ray group
+      else pipe.next = (sb + BATCH < nc) ? rs_nerf[0] : (nf > 0 ? rs_nerf[1] : rs_nerf[0]);
+      eval_nerf<G, PL, NT>(ka, pipe, 0, lane, sm, L);
     }
     ray_sync();
     if (q == 0 && !(NERFDS_ABLATE & 16)) {
@@ -1514,12 +1593,28 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
     }
     ray_sync();
 
-    // ---- fine level ----
+    // ---- fine level: the level-independent networks on the nf NEW samples only (the coarse samples keep the values of the
+    // coarse pass: same networks, same inputs - the reference's second evaluation, models.py:1291-1300 under models.py:1528-1546,
+    // returns the same numbers), then the fine NerfMLP on the whole sorted union ----
     if (nf > 0) {
       const int n = nc + nf;
+      for (int sb = 0; sb < nf; sb += BATCH) {
+        Samples<NT> sm;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int kx = sb + 32 * NT * q + 32 * nt + ln, k = kx < nf ? kx : nf - 1;
+          sm.z[nt] = L.zn[nc + k];
+          sm.slot[nt] = reinterpret_cast<const int*>(L.cdf)[k];
+        }
+        if constexpr (PP::HAS_SHARED) { pipe.cur = rs_shared; pipe.next = (sb + BATCH < nf) ? rs_shared : rs_nerf[1]; }
+        eval_shared<G, PL, NT>(ka, rc, pipe, lane, sm, L);
+      }
+      ray_sync();              // a NerfMLP batch reads slots that other waves of the ray have written
       for (int sb = 0; sb < n; sb += BATCH) {
-        set_level(1, (sb + BATCH < n) ? 1 : 0);
-        eval_batch<G, PL, NT>(ka, rc, pipe, 1, lane, sb + 32 * NT * q, n, L);
+        const Samples<NT> sm = samples_at(sb + 32 * NT * q, n);
+        pipe.cur = rs_nerf[1];
+        pipe.next = (sb + BATCH < n) ? rs_nerf[1] : (PP::HAS_SHARED ? rs_shared : rs_nerf[0]);
+        eval_nerf<G, PL, NT>(ka, pipe, 1, lane, sm, L);
       }
       ray_sync();
       if (q == 0 && !(NERFDS_ABLATE & 16))
@@ -1550,16 +1645,19 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train
   const int slot = wave / SPLIT, q = wave % SPLIT;
   WaveLds& L = *reinterpret_cast<WaveLds*>(g_smem + BIAS_OFF + bias_bytes<G>() + slot * (int)sizeof(WaveLds));
   auto ray_sync = [&]() { if constexpr (SPLIT > 1) __syncthreads(); else WAVE_SYNC(); };
+  using PP = Pipe<G, PL>;
   Pipe<G, PL> pipe;
-  pipe.ws = make_rsrc(ka.wstream[0], Pipe<G, PL>::SHARED_PAD * 1024);
-  pipe.wn = pipe.wn_next = make_rsrc(ka.wstream[1], Pipe<G, PL>::NERF_PAD * 1024);
+  const rsrc_t rs_nerf = make_rsrc(ka.wstream[1], PP::NERF_PAD * 1024);
+  const rsrc_t rs_shared = PP::HAS_SHARED ? make_rsrc(ka.wstream[0], PP::SHARED_PAD * 1024) : rs_nerf;
+  pipe.cur = pipe.next = rs_shared;
   pipe.lane16 = lane * 16;
   pipe.wave1k = wave * 1024;
-  pipe.prologue();
+  pipe.prologue(PP::HAS_SHARED ? SEG_SHARED : SEG_NERF);
   {  // biases -> LDS (as render_rays_kernel; only the shared nets and slot 1 are used)
     constexpr int n0 = Dm::SHARED_BIAS_TILES * 32, n1 = Dm::NERF_BIAS_TILES * 32;
     float* dst = reinterpret_cast<float*>(g_smem + BIAS_OFF);
-    for (int i = threadIdx.x; i < n0 + n1; i += 64 * WAVES) {
+    for (int i0 = 0; i0 < n0 + n1; i0 += 64 * WAVES) {        // uniform trip count, as in render_rays_kernel
+      const int ix = i0 + (int)threadIdx.x, i = ix < n0 + n1 ? ix : n0 + n1 - 1;
       const float v = i < n0 ? ka.bias[0][i] : ka.bias[1][i - n0];
       const int t = i >> 5, m = i & 31;
       dst[bias_tile_off(t) / 4 + 128 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)] = v;
@@ -1596,8 +1694,21 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train
       for (int i = lane; i < S; i += 64) L.zs[i] = to.z[(size_t)ray * S + i];
     }
     ray_sync();
-    for (int sb = 0; sb < S; sb += BATCH)
-      eval_batch<G, PL, NT, WaveLds, TrainOut>(ka, rc, pipe, 0, lane, sb + 32 * NT * q, S, L, to, (long long)ray * S);
+    for (int sb = 0; sb < S; sb += BATCH) {
+      Samples<NT> sm;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int sx = sb + 32 * NT * q + 32 * nt + (lane & 31);
+        sm.slot[nt] = sx < S ? sx : S - 1;       // tail lanes repeat sample S - 1: same values, same rows
+        sm.z[nt] = L.zs[sm.slot[nt]];
+      }
+      const size_t row = (size_t)ray * S + (size_t)sm.slot[0];     // this lane's row of the [R * S][width] activation arrays
+      if constexpr (PP::HAS_SHARED) { pipe.cur = rs_shared; pipe.next = rs_nerf; }
+      eval_shared<G, PL, NT, WaveLds, TrainOut>(ka, rc, pipe, lane, sm, L, to, row);
+      pipe.cur = rs_nerf;
+      pipe.next = rs_shared;
+      eval_nerf<G, PL, NT, WaveLds, TrainOut>(ka, pipe, 0, lane, sm, L, to, row);
+    }
     ray_sync();
   }
 }

@@ -14,7 +14,7 @@ def main(path):
   while i < len(lines):
     if re.match(r'^\.LBB\d+_\d+:', lines[i]):
       j = i + 1; pre = []
-      while j < len(lines) and j < i + 12:
+      while j < len(lines) and j < i + 200:   # (SGPR-spill writelanes and scalar loads can put 20+ lines ahead of the restore)
         l = lines[j]
         if l.strip().startswith(';') or not l.strip():
           j += 1; continue
@@ -25,7 +25,7 @@ def main(path):
               bad += 1
               print(f'{path}:{k + 1}: {t.strip()}   (before exec restore at line {j + 1})')
           break
-        if re.match(r'^\S', l) or l.strip().startswith('s_cbranch') or l.strip().startswith('s_branch'):
+        if re.match(r'^\S', l) or l.strip().startswith('s_cbranch') or l.strip().startswith('s_branch') or 'saveexec' in l or re.match(r'\s+s_\w+_b64 exec,', l):   # a region opens: what follows is its body
           break
         pre.append((j, l)); j += 1
     i += 1

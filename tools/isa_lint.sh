@@ -1,11 +1,16 @@
 #!/bin/bash
-# Development: emit device asm for every (graph, precision) kernel and run tools/isa_lint.py on it.
+# Development / build check: emit device asm for every render kernel the library ships (3 graphs x 5 arithmetic modes + the training
+# forward), with the Makefile's flags, and run tools/isa_lint.py on it.  Exit status 1 when a suspect copy is found.
 cd "$(dirname "$0")/../nerf-ds_amd/csrc" || exit 1
 mkdir -p build/asm
-for g in nerfds:GraphNerfDS static:GraphStatic hyper:GraphHyperNeRF; do for p in bf16:P_BF16 bf16x3:P_BF16X3 f32:P_F32; do
+FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1 --cuda-device-only -S render_kernel.hip"
+jobs_n=0
+for g in nerfds:GraphNerfDS static:GraphStatic hyper:GraphHyperNeRF; do for p in bf16:P_BF16 bf16x3:P_BF16X3 f32:P_F32 f16:P_F16 "mixed:P_BF16 -DNERFDS_MIXED"; do
   n=${g%%:*}_${p%%:*}
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-value --cuda-device-only -S render_kernel.hip \
-     -DNERFDS_GRAPH=${g#*:} -DNERFDS_PREC=${p#*:} -DNERFDS_NAME=$n -o build/asm/$n.s 2>/dev/null &
+  /opt/rocm/bin/hipcc $FL $MIXFLAGS -DNERFDS_GRAPH=${g#*:} -DNERFDS_PREC=${p#*:} -DNERFDS_NAME=$n -o build/asm/$n.s 2>/dev/null &
+  jobs_n=$((jobs_n + 1)); if [ $jobs_n -ge 8 ]; then wait -n; jobs_n=$((jobs_n - 1)); fi
 done; done
+/opt/rocm/bin/hipcc $FL -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_TRAIN_FWD -DNERFDS_NAME=train_fwd_nerfds -o build/asm/train_fwd.s 2>/dev/null &
 wait
 python3 ../../tools/isa_lint.py build/asm/*.s | grep -v "^$"
+exit ${PIPESTATUS[0]}
