@@ -188,8 +188,29 @@ template <class G> constexpr int bias_tiles() { return Dims<G>::SHARED_BIAS_TILE
 #endif
 template <class G> constexpr int bias_bytes() { return cdiv(bias_tiles<G>(), 8) * 1024; }
 
+// 1: uniform split-bf16 plans issue the MFMAs of a tile pair interleaved (accum) and keep 8 units in the register ring.
+// Measured 41.6 -> 40.8 ms per 65 536 rays (same-accumulator MFMA pairs with instructions between them: 2305 -> 590 of 9384).
+#ifndef NERFDS_X3_INTERLEAVE
+#define NERFDS_X3_INTERLEAVE 1
+#endif
 #ifndef NERFDS_RING_UNITS
 #define NERFDS_RING_UNITS 4
+#endif
+#ifndef NERFDS_RING_UNITS_X3
+#define NERFDS_RING_UNITS_X3 8
+#endif
+// 1: the LDS-DMA pieces of a stage are issued one by one between the MFMAs of the stage NS - 1 earlier, with a counted vmcnt
+// at the boundaries (Pipe::boundary / spread_piece); 0: back to back behind the barrier.  Measured +0.9 % on the 8-wave
+// kernels, +-0 on the 4-wave ones.  The training forward keeps its own (measured) scheme.
+#ifndef NERFDS_SPREAD_DMA
+#ifdef NERFDS_TRAIN_FWD
+#define NERFDS_SPREAD_DMA 0
+#else
+#define NERFDS_SPREAD_DMA 1
+#endif
+#endif
+#ifndef NERFDS_SPREAD_AT
+#define NERFDS_SPREAD_AT 1
 #endif
 #ifndef NERFDS_TRAIN_VMCNT
 #define NERFDS_TRAIN_VMCNT 1      // 0: the training forward waits with vmcnt(0) at stage boundaries like the render kernels (A/B timing)
@@ -216,7 +237,7 @@ template <class G, class PL> struct Pipe {
   static constexpr int PIECES = SU / WAVES;                       // 1 KiB LDS-DMA pieces per wave per stage
   // LDS -> register prefetch distance in units: a ds_read_b128 takes ~100+ cycles to return under load, a bf16 unit is
   // consumed in 32-64 MFMA cycles, so the reads must run several units ahead of the MFMAs.
-  static constexpr int RD = NERFDS_RING_UNITS;
+  static constexpr int RD = (NERFDS_X3_INTERLEAVE && PL::UNIFORM && PL::TRUNK == P_BF16X3 && PL::NT == 1) ? NERFDS_RING_UNITS_X3 : NERFDS_RING_UNITS;
   static_assert(RD <= SU && RD >= 2, "prefetch reaches at most one stage ahead");
   u32x4 ring[RD];
   rsrc_t cur;       // stream of the segment being walked
@@ -227,14 +248,14 @@ template <class G, class PL> struct Pipe {
   // This wave's share of stage t of segment `seg` (t >= seg_stages: stage t - seg_stages of the next segment): LDS-DMA
   // (buffer_load ... lds), 1 KiB per instruction, no VGPRs.  Everything but "+ wave * 1024" (one s_add) and the descriptor is a
   // compile-time fact.
-  DEVI void issue_stage(int seg, int t) {
+  DEVI void issue_stage(int seg, int t, int k0 = 0, int k1 = PIECES) {
     if (NERFDS_ABLATE & 1) return;
     const bool wrap = t >= seg_stages(seg);
     const int tt = wrap ? t - seg_stages(seg) : t, slot = t % NS;
     if (!wrap && tt >= seg_used(seg)) return;                      // hole stage
     const int base = tt * STAGE_BYTES;
 #pragma unroll
-    for (int k = 0; k < PIECES; ++k) {
+    for (int k = k0; k < k1; ++k) {
       // readfirstlane makes the uniformity of the scalar operands provable: without it hipcc may keep them in
       // VGPRs under SGPR pressure and wrap every LDS-DMA in a waterfall loop (cdna guide T20).
       const int off = __builtin_amdgcn_readfirstlane(WAVES * k * 1024 + wave1k);
@@ -256,18 +277,20 @@ template <class G, class PL> struct Pipe {
     // (Waiting with vmcnt(0) only was 1.5 % faster and ran clean on the uniform kernels, but the mixed-precision kernel showed
     // run-to-run differences with it: kept safe.)
     static_assert(NS == 4, "protocol is written for a 4-stage ring");
-#if defined(NERFDS_TRAIN_FWD) && NERFDS_TRAIN_VMCNT
-    // Training forward: the activation stores share VM_CNT with the LDS-DMA, and with vmcnt(0) every boundary also waits for the
-    // wave's youngest stores to be acknowledged.  vmcnt(PIECES) is enough and safe: loads complete in order AMONG LOADS, so "at
-    // most PIECES operations outstanding" means every load older than the PIECES youngest loads has landed - and the PIECES youngest
-    // loads are (at least as young as) the pieces of stage s + 2 that the previous boundary issued, which this boundary does not
-    // need (stages s and s + 1 are older).  That argument needs the previous boundary to have issued a stage: after a hole (nothing
-    // issued) the wait is vmcnt(0).  Measured: -0.75 ms per training step against vmcnt(0).
+#if (defined(NERFDS_TRAIN_FWD) && NERFDS_TRAIN_VMCNT) || NERFDS_SPREAD_DMA
+    // Counted wait.  Training forward: the activation stores share VM_CNT with the LDS-DMA, and with vmcnt(0) every boundary also
+    // waits for the wave's youngest stores to be acknowledged.  Spread DMA: the pieces of stage s + 2 were issued DURING stage
+    // s - 1, the last of them a fraction of a stage ago.  vmcnt(PIECES) is enough and safe: loads complete in order AMONG LOADS, so
+    // "at most PIECES operations outstanding" means every load older than the PIECES youngest loads has landed - and the PIECES
+    // youngest loads are (at least as young as) the pieces of stage s + 2, which this boundary does not need (stages s and s + 1 are
+    // older); stores or later loads in flight only make the wait longer, never shorter.  That argument needs stage s + 2 to have been
+    // issued: when it is a hole (nothing issued) the wait is vmcnt(0).  Measured: -0.75 ms per training step against vmcnt(0).
     {
-      static_assert(PIECES == 4, "vmcnt(4) below");
-      const int tprev = s + NS - 2;              // the stage the previous boundary issued (s == 0: the previous segment's last boundary)
+      static_assert(PIECES == 4 || PIECES == 2, "vmcnt(PIECES) below");
+      const int tprev = s + NS - 2;              // the stage issued since the previous boundary (s == 0: by the previous segment's last stage)
       const bool prev_issued = tprev >= seg_stages(seg) || tprev < seg_used(seg);
-      if (prev_issued) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      if (prev_issued && PIECES == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else if (prev_issued) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
 #elif defined(NERFDS_BOUNDARY_NO_LGKM)
@@ -277,7 +300,16 @@ template <class G, class PL> struct Pipe {
 #endif
     if (!(NERFDS_ABLATE & 2)) __builtin_amdgcn_s_barrier();      // raw barrier (no compiler-added fences)
     if (NERFDS_DBG & 2) __builtin_amdgcn_s_sleep(4);
-    issue_stage(seg, s + NS - 1);
+    // NERFDS_SPREAD_DMA: the pieces of stage s + NS - 1 are issued one by one between the MFMAs of stage s (spread_piece) instead of
+    // back to back behind the barrier, where nothing covers their issue time (a hole stage has no MFMAs: issued here)
+    if (!NERFDS_SPREAD_DMA || s >= seg_used(seg)) issue_stage(seg, s + NS - 1);
+  }
+  // unit u of the segment has been consumed: with NERFDS_SPREAD_DMA, the k-th piece of the stage NS - 1 ahead goes out after the
+  // unit SPREAD_AT + k * (SU / PIECES) of the current stage (behind the barrier of this stage: its ring slot is free)
+  DEVI void spread_piece(int seg, int u) {
+    if (!NERFDS_SPREAD_DMA) return;
+    constexpr int EVERY = SU / PIECES;
+    if (u % EVERY == NERFDS_SPREAD_AT % EVERY) issue_stage(seg, u / SU + NS - 1, (u % SU) / EVERY, (u % SU) / EVERY + 1);
   }
   // the first NS - 1 stages of the first segment of the kernel
   DEVI void prologue(int seg) {
@@ -317,7 +349,15 @@ template <class G, class PL> struct Pipe {
     }
     return w;
   }
-  DEVI void finish_segment(int seg) {    // boundaries of the hole stages keep the barrier count and the ring in step
+  DEVI void finish_segment(int seg) {
+    if (NERFDS_SPREAD_DMA) {             // pieces whose trigger unit lies in the zero padding of the last stage
+      constexpr int EVERY = SU / PIECES;
+      const int last = (seg == SEG_SHARED ? SHARED_UNITS : NERF_UNITS) - 1, s = seg_used(seg) - 1;
+#pragma unroll
+      for (int k = 0; k < PIECES; ++k)
+        if (s * SU + k * EVERY + NERFDS_SPREAD_AT % EVERY > last) issue_stage(seg, s + NS - 1, k, k + 1);
+    }
+    // boundaries of the hole stages keep the barrier count and the ring in step
 #pragma unroll
     for (int s = seg_used(seg); s < seg_stages(seg); ++s) boundary(seg, s);
   }
@@ -386,6 +426,34 @@ template <class G, class PL, int NT, int TP, int P, int K, class SLOT>
 DEVI void accum(f32x16 (&acc)[TP][NT], Pipe<G, PL>& pipe, Cursor& cur, const Chunk<P> (&in)[NT][K], int& j, SLOT&& slot) {
   using PP = Pipe<G, PL>;
   constexpr int NP = frag_parts(P);
+  if constexpr (NERFDS_X3_INTERLEAVE && P == P_BF16X3 && TP == 2 && NT == 1 && PL::UNIFORM) {
+    // Split bf16, one wave per SIMD: the three MFMAs of a product go to the same accumulator, and whatever hipcc places
+    // between two MFMAs on the SAME accumulator (weight reads, waits, epilogue VALU) costs ~43 cycles instead of its issue
+    // slot.  Issued pairwise over the two tiles of the group - hl0 hl1 lh0 lh1 hh0 hh1 - consecutive MFMAs never share an
+    // accumulator; per accumulator the order of the terms (hi*lo, lo*hi, hi*hi, chunk by chunk) is unchanged, so the results
+    // are the same bits.  Needs the four units of the group in the register ring at once (RD >= 8 keeps the prefetch ahead).
+#pragma unroll
+    for (int kc = 0; kc < K; ++kc) {
+      const int u = cur.pos;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if ((u + q) % PP::SU == 0) pipe.begin_stage(cur.seg, u + q);
+      const WFrag<P> w0 = pipe.template frag<P>(u), w1 = pipe.template frag<P>(u + 2);
+      const Chunk<P>& c = in[0][kc];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, c.lo, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, c.lo, acc[1][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.lo, c.hi, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.lo, c.hi, acc[1][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, c.hi, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, c.hi, acc[1][0], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { pipe.refill(cur.seg, u + q); pipe.spread_piece(cur.seg, u + q); }
+      cur.pos += 4;
+      slot(j, 0); ++j;
+      slot(j, 1); ++j;
+    }
+    return;
+  }
 #pragma unroll
   for (int kc = 0; kc < K; ++kc) {
 #pragma unroll
@@ -399,7 +467,7 @@ DEVI void accum(f32x16 (&acc)[TP][NT], Pipe<G, PL>& pipe, Cursor& cur, const Chu
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) mma<P>(acc[tp][nt], w, in[nt][kc]);
 #pragma unroll
-      for (int q = 0; q < NP; ++q) pipe.refill(cur.seg, u + q);
+      for (int q = 0; q < NP; ++q) { pipe.refill(cur.seg, u + q); pipe.spread_piece(cur.seg, u + q); }
       cur.pos += NP;
       slot(j, tp);
       ++j;
@@ -1466,7 +1534,9 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
   using Dm = Dims<G>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int slot = wave / SPLIT, q = wave % SPLIT;        // ray slot in the workgroup, share of the ray's batch
+  // ray slot in the workgroup, share of the ray's batch.  The q == 0 waves (they run the per-ray phases alone) are waves
+  // 0 .. RAYS - 1, i.e. one per SIMD; with slot = wave / SPLIT they sat two by two on two of the four SIMDs (+0.7 %).
+  const int slot = wave % RAYS_PER_WG, q = wave / RAYS_PER_WG;
   WaveLds& L = *reinterpret_cast<WaveLds*>(g_smem + BIAS_OFF + bias_bytes<G>() + slot * (int)sizeof(WaveLds));
   // Waves that share a ray meet at workgroup barriers around the per-ray phases (every wave executes the same
   // barrier sequence, so these interleave consistently with the per-stage barriers of the weight pipe).

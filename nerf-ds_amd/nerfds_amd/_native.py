@@ -12,6 +12,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFDS_LIB', os.path.join(_HERE, '_lib', 'libnerfds_hip.so'))   # NERFDS_LIB: development builds
 
 ABI_VERSION = 3
+
+
+def resolve_device(device=None):
+  """A torch.device with an explicit index: 'cuda' / torch.device('cuda') mean the current device (tensors allocated on
+  'cuda' report cuda:<current>, and an unindexed device compares unequal to them)."""
+  import torch
+  d = torch.device(device) if device is not None else torch.device('cuda')
+  if d.type != 'cuda':
+    raise ValueError(f'the HIP path runs on a cuda (ROCm) device, got {d}')
+  return d if d.index is not None else torch.device('cuda', torch.cuda.current_device())
+
 MAX_DEPTH = 16
 RAY_REC = 26
 SAMPLE_REC = 18

@@ -12,6 +12,7 @@ contiguous block of the chunk with the fused HIP kernel, and the only exchange i
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from types import SimpleNamespace
 from typing import Any, Callable, Dict, Optional
@@ -245,7 +246,10 @@ def _render_image_device(state, rays_dict, model_fn, params, keys, num_rays, num
   rays_dict = tree_map(to_dev, rays_dict)
   frame = torch.empty((num_rays, N.RAY_REC), dtype=torch.float32, device=dev)
   compute = torch.cuda.current_stream(dev)
-  if world == 1:
+  # NERFDS_FORCE_COLLECTIVES=1 (tests): a one-rank process group takes the sharded path below - staging buffers, side stream and the
+  # all-gather itself - so that the RCCL branch of all_gather_into executes on a one-GPU box
+  forced = os.environ.get('NERFDS_FORCE_COLLECTIVES') == '1' and dist.is_available() and dist.is_initialized()
+  if world == 1 and not forced:
     for batch_idx in range(num_batches):
       ray_idx = batch_idx * chunk
       chunk_rays = tree_map(lambda x: x[ray_idx:ray_idx + chunk], rays_dict)

@@ -143,10 +143,10 @@ class NerfModel:
     self._lib = N.load()                      # raises if the HIP library is not built: no fallback
     if not torch.cuda.is_available():
       raise RuntimeError('NerfModel needs an MI355X (torch.cuda is not available); there is no CPU path')
-    self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    self.device = N.resolve_device(device)
     self._cstruct = _cfg_struct(cfg)
     ctx = C.c_void_p()
-    rc = self._lib.nerfds_ctx_create(C.byref(ctx), self.device.index or 0, C.byref(self._cstruct))
+    rc = self._lib.nerfds_ctx_create(C.byref(ctx), self.device.index, C.byref(self._cstruct))
     if rc != 0:
       msg = N.last_error(None)
       if rc == -95:
@@ -335,8 +335,12 @@ class NerfModel:
 
   def _target_norm(self, params, reloaded, origins, directions, viewdirs, warp_id, gt_mask, extra_params, mask_ratio, near, far,
                    t_rand, u_rand, seed, ray_offset):
+    # Cost: the first call allocates a trainer workspace of ~2.8 MB per ray of `sigma_gradient_block` (default 4096 rays: ~11 GB).
+    # The pass is local to this rank (data_parallel=False: no gradient all-reduce, whatever process group is initialised).  The
+    # trainer draws the fine depths from ITS coarse weights (split-bf16 / fp32 arithmetic): for render precisions other than
+    # f32 / bf16x3 target_norm is therefore taken at slightly different fine samples than the returned render.
     from .training import Trainer
-    block = getattr(self, 'sigma_gradient_block', 4096)      # rays per pass of the trainer (its workspace is ~2.8 MB per ray)
+    block = getattr(self, 'sigma_gradient_block', 4096)      # rays per pass of the trainer
     tr = getattr(self, '_sg_trainer', None)
     if tr is None:
       tr = self._sg_trainer = Trainer(self.cfg, params, max_rays=block, device=self.device)
@@ -352,7 +356,7 @@ class NerfModel:
                    mask=sl(gt_mask), rgb=torch.zeros((hi - lo, 3), device=self.device))
       # one gradient-only step at lr 0: the parameters do not move; ray_offset keeps the Philox counters of the block in step
       tr.step(batch, extra_params, 0.0, t_rand=sl(t_rand), u_rand=sl(u_rand), mask_ratio=mask_ratio, near=near, far=far,
-              grads_only=True, sigma_gradient=True, seed=int(seed), ray_offset=ray_offset + lo)
+              grads_only=True, sigma_gradient=True, seed=int(seed), ray_offset=ray_offset + lo, data_parallel=False)
       for level in out:
         out[level].append(torch.as_tensor(tr.target_norm(level), device=self.device))
     return {k: torch.cat(v, 0) for k, v in out.items()}

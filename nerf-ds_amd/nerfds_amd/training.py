@@ -30,10 +30,11 @@ class _DevVec:
     self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
 
 
-def allreduce_mean_(t: torch.Tensor) -> torch.Tensor:
-  """jax.lax.pmean(grad, 'batch') (training.py:502): in-place mean over the ranks of the default process group."""
+def allreduce_mean_(t: torch.Tensor, force: bool = False) -> torch.Tensor:
+  """jax.lax.pmean(grad, 'batch') (training.py:502): in-place mean over the ranks of the default process group.
+  ``force``: issue the collective also in a one-rank group (Trainer.step(data_parallel=True); a test executes RCCL that way)."""
   import torch.distributed as dist
-  if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+  if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     t /= dist.get_world_size()
   return t
@@ -76,10 +77,10 @@ class Trainer:
     self._lib = _bind(N.load())
     if not torch.cuda.is_available():
       raise RuntimeError('Trainer needs an MI355X (torch.cuda is not available); there is no CPU path')
-    self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    self.device = N.resolve_device(device)
     self._cstruct = _cfg_struct(cfg)
     h = C.c_void_p()
-    rc = self._lib.nerfds_trainer_create(C.byref(h), self.device.index or 0, C.byref(self._cstruct), max_rays)
+    rc = self._lib.nerfds_trainer_create(C.byref(h), self.device.index, C.byref(self._cstruct), max_rays)
     if rc != 0:
       msg = (self._lib.nerfds_trainer_last_error(None) or b'').decode()
       raise (NotImplementedError if rc == -95 else RuntimeError)(f'nerfds_trainer_create failed ({rc}): {msg}')
@@ -169,11 +170,15 @@ class Trainer:
   def step(self, batch: Dict[str, Any], extra_params: Dict[str, Any], learning_rate: float = 0.0, *, t_rand=None, u_rand=None,
            mask_ratio: float = 1.0, near: Optional[float] = None, far: Optional[float] = None, grads_only: bool = False,
            sigma_gradient: bool = False, objective: Optional[Dict[str, float]] = None, grad_max_val: float = 0.0,
-           grad_max_norm: float = 0.0, seed: Optional[int] = None, ray_offset: int = 0,
-           stream: Optional[torch.cuda.Stream] = None) -> Dict[str, float]:
+           grad_max_norm: float = 0.0, seed: Optional[int] = None, ray_offset: Optional[int] = None,
+           stream: Optional[torch.cuda.Stream] = None, data_parallel: Optional[bool] = None) -> Dict[str, float]:
     """One optimisation step.  Sampling jitter (cfg.use_stratified_sampling; the reference always draws it,
     model_utils.py:84,217): injected ``t_rand`` / ``u_rand``, else the on-chip Philox stream keyed by ``seed``; with
-    ``seed=None`` the trainer's own step counter is used, so that successive steps never sample the same depths."""
+    ``seed=None`` the trainer's own step counter is used, so that successive steps never sample the same depths.
+    ``data_parallel``: None = all-reduce the gradient vector when a process group with more than one rank is initialised
+    (training.py:502); False = never (a local pass such as NerfModel's target_norm); True = always (also at world size 1).
+    ``ray_offset``: Philox counter of the first ray; None = rank * max_rays, so that the ranks of a data-parallel step draw
+    independent jitter as the reference's per-device keys do (training.py:228 under pmap)."""
     dev = self.device
     f32 = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).to(dev, torch.float32).contiguous()
     origins = f32(batch['origins']).reshape(-1, 3)
@@ -194,6 +199,9 @@ class Trainer:
     if seed is None:
       self._auto_seed = getattr(self, '_auto_seed', 0) + 1
       seed = (0x5DEECE66D * self._auto_seed + 0xB) & 0xFFFFFFFFFFFFFFFF
+    if ray_offset is None:
+      import torch.distributed as dist
+      ray_offset = dist.get_rank() * self.max_rays if (dist.is_available() and dist.is_initialized()) else 0
     rnd = N.Rand(t_rand=None, u_rand=None, seed=int(seed) & 0xFFFFFFFFFFFFFFFF, first_ray=int(ray_offset))
     if t_rand is not None:
       t = f32(t_rand).reshape(R, self.cfg.num_coarse_samples); keep.append(t); rnd.t_rand = t.data_ptr()
@@ -208,7 +216,11 @@ class Trainer:
                      use_mask_sharp_weights=int(self.cfg.use_mask_sharp_weights), norm_loss_weight=objective.get('norm_loss_weight', 0.0))
     s = stream if stream is not None else torch.cuda.current_stream(dev)
     import torch.distributed as dist
-    data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    grouped = dist.is_available() and dist.is_initialized()
+    if data_parallel is None:
+      data_parallel = grouped and dist.get_world_size() > 1
+    elif data_parallel and not grouped:
+      raise RuntimeError('data_parallel=True needs an initialised torch.distributed process group')
     clip = grad_max_val > 0.0 or grad_max_norm > 0.0
     rc = self._lib.nerfds_trainer_step(self._h, C.byref(rays), target.data_ptr(), C.byref(ex), C.byref(rnd), C.byref(ob) if ob is not None else None,
                                        float(learning_rate),
@@ -219,7 +231,7 @@ class Trainer:
       raise RuntimeError(f'nerfds_trainer_step failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
     if data_parallel:       # one rank per GPU, each with its own rays: ONE all-reduce of the 6 MB gradient vector (training.py:502)
       with torch.cuda.stream(s):
-        allreduce_mean_(self.grads_tensor())
+        allreduce_mean_(self.grads_tensor(), force=True)
     if clip:                # utils.clip_gradients after the pmean (training.py:502-504)
       rc = self._lib.nerfds_trainer_clip_gradients(self._h, float(grad_max_val), float(grad_max_norm), C.c_void_p(s.cuda_stream))
       if rc != 0:

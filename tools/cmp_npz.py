@@ -3,6 +3,8 @@ import sys, numpy as np
 a, b = np.load(sys.argv[1]), np.load(sys.argv[2])
 bad = 0
 for k in a.files:
+  if k not in b.files:
+    continue
   x, y = a[k], b[k]
   same = x.shape == y.shape and np.array_equal(x.view(np.uint8) if x.dtype != object else x, y.view(np.uint8) if y.dtype != object else y)
   if not same:
