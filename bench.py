@@ -50,7 +50,7 @@ FLOP_PER_RAY = 333.15e6          # BASELINE.md section 2, nerf_ds graph, 192 fie
 PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f32': 157.3, 'f16': 2500.0, 'mixed': 2500.0}
 EXTRA = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
 # where the committed PMC measurement of the headline kernel lives (separate rocprofv3 passes of this command, tools/prof_bench.sh)
-TRAFFIC_FILE = 'profiles/r2_bf16_hbm_traffic.json'
+TRAFFIC_FILE = 'profiles/r3_bf16_hbm_traffic.json'
 TRAIN_TRAFFIC_FILE = 'profiles/r2_train_hbm_traffic.json'
 
 

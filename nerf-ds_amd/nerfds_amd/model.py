@@ -254,7 +254,7 @@ class NerfModel:
     if t_rand is not None:
       t_rand = f32(t_rand).reshape(R, nc)
     if u_rand is not None:
-      u_rand = f32(u_rand).reshape(R, max(nf, 1))
+      u_rand = f32(u_rand).reshape(R, nf) if nf > 0 else None      # a single-level model draws no fine samples
 
     ptr = lambda t: (t.data_ptr() if t is not None else None)
     rays = N.Rays(R, ptr(origins), ptr(directions), ptr(viewdirs), ptr(warp_id), ptr(gt_mask),
