@@ -274,6 +274,11 @@ int nerfds_trainer_upload(nerfds_trainer* t, int which, const float* host);
  * last step run with NERFDS_TRAIN_SIGMA_GRAD: HOST [num_rays][S][3], S = Nc (level 0) or Nc + Nf (level 1). */
 int nerfds_trainer_target_norm(nerfds_trainer* t, int level, int64_t num_rays, float* host);
 int nerfds_trainer_reset_optimizer(nerfds_trainer* t);   /* zero the Adam moments and the step count */
+/* Development / tests: HOST copy of an internal device buffer of the last step (the f16 activations, ReLU bits and per-layer
+ * gradients g_l of the fused backward, the head / input gradients): "<net>_h16_<l>", "<net>_bits_<l>", "<net>_g_<l>" with net = mask |
+ * warp | hyper | trunk, "rgb_h16", "rgb_bits", "rgb_g", "d_rgb_logit", "d_alpha", "d_trunk_in", "d_hyper_in", "d_warp_in",
+ * "d_mask_in", "dwamb", "dwv", "d_mask_logit".  Returns the bytes copied (= max_bytes) or a negative error code. */
+long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* host, long long max_bytes);
 int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* extra,
                         const nerfds_rand* rnd, const nerfds_train_objective* objective /* NULL = rgb loss only */, float learning_rate,
                         uint32_t flags, float* loss_host /* HOST float[10] or NULL */, void* hip_stream);

@@ -174,4 +174,22 @@ template <class G> constexpr int nerf_units(Plan pl) {
   return walk_seg(pos, G::RGB_W / 16, pl.rgb);                                                       // rgb head
 }
 
+// ---- Reversed networks of the fused training backward (render_kernel.hip train_backward_kernel, nerfds_train.cpp) ----
+// One stream per network: the TRANSPOSED layers in the order the data-gradient chain walks them, every fragment two units
+// (split bf16).  A plain MLP with head (mask, warp, hyper sheet):
+//   head^T (one linear chunk of head gradients -> width), layers depth-1 .. skip+1 transposed, the skip layer's [hidden rows]
+//   (-> width) and [raw-input rows] (-> 2 tiles of input gradient), layers skip-1 .. 1 transposed, layer 0 transposed (-> 2 tiles).
+// The NerfMLP: rgb head^T (-> rgb width), then [rgb hidden with the bottleneck folded in | alpha head]^T (-> trunk width), then the
+// trunk like a plain MLP without head.
+template <int W_, int DEPTH_, int NHEAD_, bool NERF_ = false, int RGB_W_ = 0> struct BwdNet {
+  static constexpr int W = W_, DEPTH = DEPTH_, NHEAD = NHEAD_, SKIP = 4, RGB_W = RGB_W_;
+  static constexpr bool IS_NERF = NERF_;
+  static constexpr int BWD_FRAGS = (NERF_ ? (RGB_W_ / 32) * 1 + (W_ / 32) * (RGB_W_ / 16 + 1) : (W_ / 32) * 1) +
+                                   (DEPTH_ - 1) * (W_ / 32) * (W_ / 16) + 2 * 2 * (W_ / 16);
+};
+template <class G> using BwdMask = BwdNet<G::MASK_W, G::MASK_DEPTH, 1>;
+template <class G> using BwdWarp = BwdNet<G::WARP_W, G::WARP_DEPTH, 6>;
+template <class G> using BwdHyper = BwdNet<G::HYP_W, G::HYP_DEPTH, G::HYP_DIMS>;
+template <class G> using BwdNerf = BwdNet<G::TRUNK_W, G::TRUNK_DEPTH, 3, true, G::RGB_W>;
+
 }  // namespace nerfds

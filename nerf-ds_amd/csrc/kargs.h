@@ -64,7 +64,37 @@ struct TrainOut {
   float* rgb_logit;    // [M][3]
   const float* z;      // [R][S]  sample depths of this level
   int level;
+  // half_out != 0 (the plain training step): every hidden layer is written as f16 (what the weight-gradient kernels read as X: 11
+  // significand bits in 2 bytes) into *_h16 plus one bit per feature "output > 0" into *_bits (what the fused backward reads as the
+  // ReLU mask), instead of the fp32 arrays above (which the tangent passes of the norm loss still need).
+  // Bit layout: u16 at [(row * 2 + half) * (width / 32) + tile], bit r <-> accumulator register r of the lane (half = lane >> 5).
+  int half_out;
+  uint16_t* mask_h16[8];  uint16_t* mask_bits[8];
+  uint16_t* warp_h16[6];  uint16_t* warp_bits[6];
+  uint16_t* hyper_h16[6]; uint16_t* hyper_bits[6];
+  uint16_t* trunk_h16[8]; uint16_t* trunk_bits[8];
+  uint16_t* rgb_h16;      uint16_t* rgb_bits;
 };
+
+// Fused backward of one network (render_kernel.hip built with -DNERFDS_TRAIN_BWD): the data-gradient chain of a reversed MLP.  Row
+// m = one sample; the kernel reads the gradient of the network's head outputs, walks the layers backwards with the transposed
+// weights streamed like the forward's (dX never leaves the registers between layers), masks with the forward's ReLU bits and
+// writes, for every hidden layer, g = d loss / d (pre-activation) as fp32 [M][width] - the dY the weight-gradient kernels read -
+// and the gradient of the network's raw input.
+struct TrainBwd {
+  long long M;
+  const void* wstream;          // transposed fragments in walk order (split bf16), zero padded to whole stages
+  const float* d_head;          // [M][ld_head] gradient of the head outputs (nerf: d rgb logit, 3 wide)
+  int ld_head;
+  const float* d_head2;         // nerf only: [M][4] gradient of the alpha head outputs (sigma_raw | raw normal)
+  const uint16_t* bits[9];      // ReLU bits of hidden layer l (nerf: 0..7 trunk, 8 rgb hidden)
+  float* g[9];                  // out: [M][width] per hidden layer (nerf: 0..7 trunk, 8 rgb hidden)
+  float* d_in;                  // out: [M][ld_in] gradient of the raw input (zero in the pad columns)
+  int ld_in;
+  float* sink;                  // >= 64 bytes of scratch: where lanes outside ld_in write
+};
+
+typedef void (*launch_bwd_fn)(const KArgs& ka, const TrainBwd& tb, int num_cus, void* stream);
 
 typedef void (*launch_fn)(const KArgs& ka, int num_cus, void* stream);
 

@@ -27,6 +27,8 @@
 
 // render_kernel.hip compiled with -DNERFDS_TRAIN_FWD: the fused forward of one level (TRAIN_PLAN arithmetic)
 extern "C" void nerfds_launch_train_fwd_nerfds(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream);
+// render_kernel.hip compiled with -DNERFDS_TRAIN_BWD: the data-gradient chain of one network (0 NerfMLP, 1 hyper sheet, 2 warp, 3 mask)
+extern "C" void nerfds_launch_train_bwd_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);
 
 using namespace nerfds_train;
 
@@ -104,6 +106,20 @@ struct nerfds_trainer {
   float* fbias[3] = {nullptr, nullptr, nullptr};
   float* fold = nullptr;    // [2 levels][(TW + 1) x RGB_W]: rgb hidden_0 with the bottleneck folded in, then its bias
   int fstream_frags[3] = {0, 0, 0}, fbias_n[3] = {0, 0, 0}, f32_lo = 0, f32_hi = 0;
+  // Fused backward (render_kernel.hip train_backward_kernel), the plain step's default when the fused forward is on: the forward
+  // writes every hidden layer as f16 + ReLU bits, ONE launch per network walks its data-gradient chain (dX stays in registers
+  // between layers) and leaves g_l = d loss / d pre-activation of every hidden layer in the fp32 arrays the forward did not use,
+  // and one weight-gradient launch per layer reads X (f16) and g_l.  Streams [NerfMLP coarse, NerfMLP fine, hyper, warp, mask] are
+  // re-packed from theta every step through index maps, like the forward's.  NERFDS_TRAIN_FUSED_BWD=0: layer-by-layer backward.
+  bool fused_bwd = false;
+  int* bmap[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* bstream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int bfrags[5] = {0, 0, 0, 0, 0};
+  uint16_t* hws = nullptr;   // f16 activations + ReLU bits
+  std::vector<uint16_t*> mask_h16, warp_h16, hyper_h16, trunk_h16, mask_bits, warp_bits, hyper_bits, trunk_bits;
+  uint16_t *rgb_h16 = nullptr, *rgb_bits = nullptr;
+  float* sink = nullptr;
+  bool half_step = false;    // this step's forward wrote f16 + bits (no tangent pass needs the fp32 activations)
   std::string err;
   // workspace views (set by carve())
   float *zc, *zf, *wc, *rs_scratch, *x, *mask_in, *mask_logit, *warp_in, *wv, *xw, *hyper_in, *wamb, *trunk_in, *bottv, *alphav, *sigma,
@@ -134,6 +150,12 @@ struct nerfds_trainer {
       if (fbias[i]) (void)hipFree(fbias[i]);
     }
     if (fold) (void)hipFree(fold);
+    for (int i = 0; i < 5; ++i) {
+      if (bmap[i]) (void)hipFree(bmap[i]);
+      if (bstream[i]) (void)hipFree(bstream[i]);
+    }
+    if (hws) (void)hipFree(hws);
+    if (sink) (void)hipFree(sink);
   }
 };
 
@@ -233,10 +255,33 @@ struct Run {
   // dy[M x N] (ldy) is d loss / d (post-activation output y); relu_y != nullptr -> mask with y > 0 first (needs ldy == N)
   // dW[K x N] += X[M x K]^T dY[M x N] (contraction over the sample axis): train_gemm.hip k_wgrad, one partial per workgroup
   // accumulated in registers and added to a gradient replica with float atomics.
-  void weight_grad(const float* X, int ldx, int K, const float* dy, int ldy, int N, float* dW, int64_t rows = -1) {
+  void weight_grad(const float* X, int ldx, int K, const float* dy, int ldy, int N, float* dW, int64_t rows = -1, bool x_half = false,
+                   float* bias_grad = nullptr) {
     const int64_t M = rows < 0 ? this->M : rows;
     WgradArgs A{X, ldx, K, dy, ldy, N, M, nullptr, rep(dW), static_cast<const char*>(t.wpack) + WPACK_BYTES, 0, 0, t.P, nrep()};
+    A.x_half = x_half ? 1 : 0;
+    A.colsum = rep(bias_grad);
     if (!(wgrad_supported(A) && wgrad(st, A, wgrad_grid(A, t.num_cus)))) unsupported("weight gradient", K, N, M);
+  }
+  // Weight and bias gradients of an MLP whose data-gradient chain has run (fused backward): g[l] = d loss / d pre-activation of
+  // layer l (fp32 [M x width]), h16[l] = its f16 output.  One launch per input segment; the bias gradient rides on the first.
+  void mlp_wgrads(const MlpP& m, const float* in0, const std::vector<uint16_t*>& h16, const std::vector<float*>& g) {
+    for (int l = 0; l < m.depth; ++l) {
+      const LayerP& L = m.hidden[l];
+      int k0 = 0;
+      bool first = true;
+      if (l > 0) {
+        weight_grad(reinterpret_cast<const float*>(h16[l - 1]), m.width, m.width, g[l], m.width, m.width, t.grad + L.w, -1, true, t.grad + L.b);
+        k0 = m.width;
+        first = false;
+      }
+      if (l == 0 || l == m.skip)
+        weight_grad(in0, m.in_ld, m.in_dim, g[l], m.width, m.width, t.grad + L.w + (int64_t)k0 * L.N, -1, false, first ? t.grad + L.b : nullptr);
+    }
+  }
+  // a head on the last hidden layer: dW = h^T d_head, db = column sums of d_head (N <= 6: the scalar-DMA shapes of k_wgrad)
+  void head_wgrads(const LayerP& L, const uint16_t* h16, int width, const float* d_head, int ld) {
+    weight_grad(reinterpret_cast<const float*>(h16), width, width, d_head, ld, L.N, t.grad + L.w, -1, true, t.grad + L.b);
   }
   // premasked: the kernel that produced dy already applied this layer's ReLU mask and added the bias gradient.
   // Returns true when the dx of the segment that asked for it (Seg::dx_relu_y) was masked / column-summed by the MFMA layer.
@@ -523,6 +568,113 @@ void pack_fused_forward(nerfds_trainer& t, hipStream_t st) {
   }
 }
 
+// ---- fused backward: index maps of the TRANSPOSED layers in chain order (graphs.h BwdNet), built once like the forward's ----
+// which: 0 / 1 NerfMLP coarse / fine, 2 hyper sheet, 3 warp field, 4 mask net.  Values are parameter indices + 1 (fold rows past P).
+bool build_fused_backward(nerfds_trainer& t) {
+  using G = nerfds::GraphNerfDS;
+  using Dm = nerfds::Dims<G>;
+  constexpr int TW = G::TRUNK_W, RW = G::RGB_W, FL = (TW + 1) * RW;
+  const int levels = t.cfg.num_fine_samples > 0 ? 2 : 1;
+  auto idx = [](int64_t i) { return (float)(i + 1); };
+  auto layer = [](std::function<float(int, int)> W, std::vector<nerfds::Seg> segs, int n_tiles, int n_out) {
+    nerfds::Layer L;
+    L.segs = std::move(segs); L.n_tiles = n_tiles; L.n_out = n_out; L.is_head = false; L.W = std::move(W); L.B = [](int) { return 0.f; };
+    return L;
+  };
+  auto tile_seg = [](int width) { std::vector<int> r; nerfds::rows_tile(r, width, 0); return nerfds::Seg{std::move(r), nerfds::P_F32}; };
+  auto lin_seg = [](int row0, int n) { std::vector<int> r; nerfds::rows_linear(r, 1, [&](int sl) { return sl < n ? row0 + sl : -1; }); return nerfds::Seg{std::move(r), nerfds::P_F32}; };
+  // hidden layers D-1 .. 0 of an MLP, transposed (the head or whatever produces g_{D-1} has been emitted by the caller)
+  auto emit_trunk = [&](nerfds::StreamWriter& sw, const MlpP& m) {
+    const int W = m.width;
+    for (int l = m.depth - 1; l >= 1; --l) {
+      const int64_t w = m.hidden[l].w;
+      sw.emit(layer([=](int n, int k) { return idx(w + (int64_t)k * W + n); }, {tile_seg(W)}, W / 32, W));                    // d h_{l-1} = W_l[:W] g_l
+      if (l == m.skip) sw.emit(layer([=](int n, int c) { return idx(w + (int64_t)(W + c) * W + n); }, {tile_seg(W)}, 2, m.in_dim));   // raw-input rows of the skip layer
+    }
+    const int64_t w0 = m.hidden[0].w;
+    sw.emit(layer([=](int n, int c) { return idx(w0 + (int64_t)c * W + n); }, {tile_seg(W)}, 2, m.in_dim));
+  };
+  for (int which = 0; which < 5; ++which) {
+    if (which == 1 && levels < 2) continue;
+    int frags = 0;
+    const MlpP* m = nullptr;
+    if (which <= 1) { frags = nerfds::BwdNerf<G>::BWD_FRAGS; m = &t.trunk[which]; }
+    else if (which == 2) { frags = nerfds::BwdHyper<G>::BWD_FRAGS; m = &t.hyper; }
+    else if (which == 3) { frags = nerfds::BwdWarp<G>::BWD_FRAGS; m = &t.warp; }
+    else { frags = nerfds::BwdMask<G>::BWD_FRAGS; m = &t.mask; }
+    if (m->skip != 4 || (m->depth != 8 && m->depth != 6) || m->in_dim > 64) return false;
+    const int64_t wb = (int64_t)nerfds::pad_units(2 * frags) * 1024;
+    std::vector<uint8_t> w((size_t)wb, 0);
+    nerfds::StreamWriter sw{w.data(), nullptr};
+    const int W = m->width;
+    if (which <= 1) {
+      const int lv = which;
+      const int64_t ro = t.rgb_out[lv].w, al = t.alpha[lv].w, fo = t.P + (int64_t)lv * FL;
+      sw.emit(layer([=](int j, int k) { return idx(ro + (int64_t)k * 3 + j); }, {lin_seg(0, 3)}, RW / 32, RW));                 // g_rgb <- W_rgb d rgb_logit
+      sw.emit(layer([=](int r, int k) { return r < RW ? idx(fo + (int64_t)k * RW + r) : idx(al + (int64_t)k * 4 + (r - RW)); },
+                    {tile_seg(RW), lin_seg(RW, 4)}, TW / 32, TW));                                                               // g_7 <- F^T g_rgb + W_alpha d alpha
+    } else if (which == 2) {
+      const int64_t ho = t.hyper_out.w;
+      sw.emit(layer([=](int j, int k) { return idx(ho + (int64_t)k * 2 + j); }, {lin_seg(0, 2)}, W / 32, W));
+    } else if (which == 3) {
+      const int64_t ww = t.warp_w.w, wv = t.warp_v.w;
+      sw.emit(layer([=](int j, int k) { return j < 3 ? idx(ww + (int64_t)k * 3 + j) : idx(wv + (int64_t)k * 3 + (j - 3)); }, {lin_seg(0, 6)}, W / 32, W));
+    } else {
+      const int64_t mo = t.mask_out.w;
+      sw.emit(layer([=](int j, int k) { return idx(mo + (int64_t)k + j); }, {lin_seg(0, 1)}, W / 32, W));
+    }
+    emit_trunk(sw, *m);
+    if ((int64_t)sw.wbytes != (int64_t)frags * 2048) return false;
+    std::vector<int> map((size_t)wb / 4);
+    const float* wf = reinterpret_cast<const float*>(w.data());
+    for (size_t i = 0; i < map.size(); ++i) map[i] = (int)wf[i];
+    if (hipMalloc(&t.bmap[which], map.size() * 4) != hipSuccess || hipMalloc(&t.bstream[which], (size_t)wb) != hipSuccess ||
+        hipMemcpy(t.bmap[which], map.data(), map.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return false;
+    t.bfrags[which] = (int)(wb / 2048);
+  }
+  // f16 activations + ReLU bits of every hidden layer (one allocation), the sink of the input-gradient stores
+  const int64_t M = t.max_rays * (t.cfg.num_coarse_samples + t.cfg.num_fine_samples);
+  size_t need = 0;
+  std::vector<std::pair<uint16_t**, size_t>> views;
+  auto take = [&](uint16_t** p, size_t n) { views.push_back({p, n}); need += (n + 127) & ~(size_t)127; };
+  auto take_net = [&](std::vector<uint16_t*>& h, std::vector<uint16_t*>& b, int depth, int width) {
+    h.assign(depth, nullptr); b.assign(depth, nullptr);
+    for (auto& p : h) take(&p, (size_t)M * width);
+    for (auto& p : b) take(&p, (size_t)M * width / 16);
+  };
+  take_net(t.mask_h16, t.mask_bits, t.mask.depth, t.mask.width);
+  take_net(t.warp_h16, t.warp_bits, t.warp.depth, t.warp.width);
+  take_net(t.hyper_h16, t.hyper_bits, t.hyper.depth, t.hyper.width);
+  take_net(t.trunk_h16, t.trunk_bits, t.trunk[0].depth, t.trunk[0].width);
+  take(&t.rgb_h16, (size_t)M * RW); take(&t.rgb_bits, (size_t)M * RW / 16);
+  if (hipMalloc(&t.hws, need * sizeof(uint16_t)) != hipSuccess || hipMalloc(&t.sink, 256) != hipSuccess) return false;
+  uint16_t* base = t.hws;
+  for (auto& v : views) { *v.first = base; base += (v.second + 127) & ~(size_t)127; }
+  (void)Dm::TRUNK_KC;
+  return true;
+}
+
+void pack_fused_backward(nerfds_trainer& t, hipStream_t st) {
+  for (int which = 0; which < 5; ++which)
+    if (t.bmap[which]) pack_stream(st, t.theta, t.fold, t.P, t.bmap[which], t.bstream[which], t.bfrags[which], 0, 0);
+}
+
+// the data-gradient chain of one network: net 0 NerfMLP of `level`, 1 hyper sheet, 2 warp field, 3 mask net
+void fused_backward(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M, const float* d_head, int ld_head, const float* d_head2,
+                    float* d_in, int ld_in) {
+  nerfds::TrainBwd tb{};
+  tb.M = M; tb.d_head = d_head; tb.ld_head = ld_head; tb.d_head2 = d_head2; tb.d_in = d_in; tb.ld_in = ld_in; tb.sink = t.sink;
+  const std::vector<uint16_t*>* bits = nullptr;
+  const std::vector<float*>* g = nullptr;
+  if (net == 0) { tb.wstream = t.bstream[level]; bits = &t.trunk_bits; g = &t.trunk_h; tb.bits[8] = t.rgb_bits; tb.g[8] = t.rgb_hv; }
+  else if (net == 1) { tb.wstream = t.bstream[2]; bits = &t.hyper_bits; g = &t.hyper_h; }
+  else if (net == 2) { tb.wstream = t.bstream[3]; bits = &t.warp_bits; g = &t.warp_h; }
+  else { tb.wstream = t.bstream[4]; bits = &t.mask_bits; g = &t.mask_h; }
+  for (size_t l = 0; l < bits->size(); ++l) { tb.bits[l] = (*bits)[l]; tb.g[l] = (*g)[l]; }
+  nerfds_launch_train_bwd_nerfds(tb, net, t.num_cus, st);
+}
+
 void fused_forward(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const float* z, const nerfds_rays* rays, const nerfds_extra* ex, const Windows& W) {
   nerfds::KArgs ka{};
   ka.origins = rays->origins; ka.directions = rays->directions; ka.viewdirs = rays->viewdirs;
@@ -539,6 +691,12 @@ void fused_forward(nerfds_trainer& t, hipStream_t st, int level, int R, int S, c
   for (int l = 0; l < 6; ++l) { to.warp_h[l] = t.warp_h[l]; to.hyper_h[l] = t.hyper_h[l]; }
   to.rgb_h = t.rgb_hv; to.mask_logit = t.mask_logit; to.wv = t.wv; to.wamb = t.wamb; to.alphav = t.alphav; to.rgb_logit = t.rgb_logit;
   to.z = z; to.level = level;
+  to.half_out = t.half_step ? 1 : 0;
+  if (t.half_step) {
+    for (int l = 0; l < 8; ++l) { to.mask_h16[l] = t.mask_h16[l]; to.mask_bits[l] = t.mask_bits[l]; to.trunk_h16[l] = t.trunk_h16[l]; to.trunk_bits[l] = t.trunk_bits[l]; }
+    for (int l = 0; l < 6; ++l) { to.warp_h16[l] = t.warp_h16[l]; to.warp_bits[l] = t.warp_bits[l]; to.hyper_h16[l] = t.hyper_h16[l]; to.hyper_bits[l] = t.hyper_bits[l]; }
+    to.rgb_h16 = t.rgb_h16; to.rgb_bits = t.rgb_bits;
+  }
   nerfds_launch_train_fwd_nerfds(ka, to, t.num_cus, st);
 }
 
@@ -562,7 +720,9 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
     mask_post(st, D, R, S, t.mask_logit, rays->gt_mask, ex->mask_ratio, t.warp_in, t.hyper_in);
     se3_fwd(st, M, t.wv, t.x, t.xw);
     trunk_in(st, D, M, t.xw, t.wamb, W, t.trunk_in);
-    r.dense_fwd(t.bott[level], {{tout, TW, TW, nullptr, 0, false}}, t.bottv, TW, false);          // the kernel folds it; dW of rgb hidden_0 reads it
+    // (layer-by-layer backward: dW of rgb hidden_0 reads the bottleneck output, which the kernel folds away; the fused backward gets
+    // the bottleneck's gradients from S = trunk_out^T g_rgb instead, bott_grads)
+    if (!t.half_step) r.dense_fwd(t.bott[level], {{tout, TW, TW, nullptr, 0, false}}, t.bottv, TW, false);
     alpha_post(st, D, R, S, t.alphav, t.wv, viewdirs, W, t.sigma, t.cond);
   } else {
   r.mlp_fwd(t.mask, t.mask_in, t.mask_h);
@@ -597,6 +757,37 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
                     t.du, t.ghat);
   // ---------------- backward ----------------
   const int RW = t.rgb_h[level].N;
+  if (t.half_step) {
+    // Fused backward: ONE launch per network walks its data-gradient chain and leaves g_l of every hidden layer (in the fp32
+    // activation arrays, unused in this mode) and the gradient of the raw input; one weight-gradient launch per layer segment then
+    // reads X (f16) and g_l once.  Between the chains: the element-wise backward of the encodings, exp_se3 and the mask blend.
+    fused_backward(t, st, 0, level, M, t.d_rgb_logit, 3, t.d_alpha, t.d_trunk_in, D.trunk_in);
+    trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, nullptr, t.dxw, t.dwamb);
+    fused_backward(t, st, 1, level, M, t.dwamb, 2, nullptr, t.d_hyper_in, D.hyper_ld);
+    se3_bwd(st, M, t.wv, t.x, t.dxw, nullptr, t.dwv);
+    fused_backward(t, st, 2, level, M, t.dwv, 6, nullptr, t.d_warp_in, D.warp_ld);
+    shared_in_bwd(st, D, R, S, t.d_warp_in, t.d_hyper_in, t.mask_logit, ex->mask_ratio, ob ? t.d_pm : nullptr, rays->warp_id, t.cfg.num_warp_embeds,
+                  t.grad + t.warp_tbl, t.d_mask_logit);
+    fused_backward(t, st, 3, level, M, t.d_mask_logit, 1, nullptr, t.d_mask_in, D.mask_in);
+    mask_in_bwd(st, D, R, S, t.d_mask_in, rays->warp_id, t.cfg.num_warp_embeds, t.grad + t.mask_tbl);
+    // weight gradients.  rgb branch: heads on rgb hidden / trunk_out, rgb hidden_0 = [bottleneck | viewdir | trunk_out | normal] rows
+    const LayerP& K = t.rgb_h[level];
+    r.head_wgrads(t.rgb_out[level], t.rgb_h16, RW, t.d_rgb_logit, 3);
+    r.head_wgrads(t.alpha[level], t.trunk_h16.back(), TW, t.d_alpha, 4);
+    r.weight_grad(reinterpret_cast<const float*>(t.trunk_h16.back()), TW, TW, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(TW + VD) * RW, -1, true, t.grad + K.b);   // S
+    r.weight_grad(t.cond, CW, VD, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)TW * RW);
+    r.weight_grad(t.cond + VD, CW, NM, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(2 * TW + VD) * RW);
+    r.mlp_wgrads(trunk, t.trunk_in, t.trunk_h16, t.trunk_h);
+    r.head_wgrads(t.hyper_out, t.hyper_h16.back(), t.hyper.width, t.dwamb, 2);
+    r.mlp_wgrads(t.hyper, t.hyper_in, t.hyper_h16, t.hyper_h);
+    r.head_wgrads(t.warp_w, t.warp_h16.back(), t.warp.width, t.dwv, 6);
+    r.head_wgrads(t.warp_v, t.warp_h16.back(), t.warp.width, t.dwv + 3, 6);
+    r.mlp_wgrads(t.warp, t.warp_in, t.warp_h16, t.warp_h);
+    r.head_wgrads(t.mask_out, t.mask_h16.back(), t.mask.width, t.d_mask_logit, 1);
+    r.mlp_wgrads(t.mask, t.mask_in, t.mask_h16, t.mask_h);
+    if (!r.ok) return t.fail(NERFDS_ENOTSUP, "%s", r.unsupported_what.c_str());
+    return NERFDS_OK;
+  }
   // (the last writer of a ReLU layer's output gradient masks it and adds its bias gradient: Seg::dx_relu_y / dx_bias_grad)
   bool pm = r.dense_bwd(t.rgb_out[level], {{t.rgb_hv, RW, RW, t.g0, RW, false, t.rgb_hv, t.grad + t.rgb_h[level].b}}, t.d_rgb_logit, 3, nullptr);
   r.dense_bwd(t.rgb_h[level], {{t.bottv, TW, TW, t.g1, TW, false}, {t.cond, CW, VD, nullptr, 0, false}, {tout, TW, TW, t.g2, TW, false},
@@ -702,6 +893,8 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
     t->fuse_bwd = !(fb && std::string(fb) == "0");
     const char* ff = getenv("NERFDS_TRAIN_FUSED_FWD");
     t->fused_fwd = !(ff && std::string(ff) == "0") && build_fused_forward(*t);
+    const char* fbw = getenv("NERFDS_TRAIN_FUSED_BWD");
+    t->fused_bwd = t->fused_fwd && !(fbw && std::string(fbw) == "0") && build_fused_backward(*t);
     if (hipMalloc(&t->arena, ARENA_BYTES) != hipSuccess) { g_train_error = "hipMalloc failed (fragment arena)"; return NERFDS_ENOMEM; }
     if (hipMalloc(&t->grad_rep, (size_t)GRAD_REPS * t->P * sizeof(float)) != hipSuccess) { g_train_error = "hipMalloc failed (gradient replicas)"; return NERFDS_ENOMEM; }
     if (hipMalloc(&t->wpack, WPACK_BYTES + 256) != hipSuccess || hipMemset(t->wpack, 0, WPACK_BYTES + 256) != hipSuccess) { g_train_error = "hipMalloc failed (weight fragments)"; return NERFDS_ENOMEM; }
@@ -757,6 +950,33 @@ int nerfds_trainer_target_norm(nerfds_trainer* t, int level, int64_t num_rays, f
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, t->tn[level], (size_t)num_rays * S * 3 * 4, hipMemcpyDeviceToHost) != hipSuccess)
     return t->fail(NERFDS_EDEVICE, "download failed");
   return NERFDS_OK;
+}
+
+// Development / tests: copies an internal buffer of the last step to the host.  name: "<net>_h16_<l>", "<net>_bits_<l>", "<net>_g_<l>"
+// (net = mask | warp | hyper | trunk, l = layer), "rgb_h16", "rgb_bits", "rgb_g", "d_rgb_logit", "d_alpha", "d_trunk_in", "d_hyper_in",
+// "d_warp_in", "d_mask_in", "dwamb", "dwv", "d_mask_logit".  Returns the number of bytes copied (<= max_bytes) or a negative error.
+long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* host, long long max_bytes) {
+  if (!t || !name || !host || max_bytes <= 0) return NERFDS_EINVAL;
+  const std::string n(name);
+  const void* p = nullptr;
+  auto layer_of = [&](const std::string& pre, const std::vector<uint16_t*>& h16, const std::vector<uint16_t*>& bits, const std::vector<float*>& g) {
+    for (size_t l = 0; l < g.size(); ++l) {
+      if (n == pre + "_h16_" + std::to_string(l) && l < h16.size()) p = h16[l];
+      if (n == pre + "_bits_" + std::to_string(l) && l < bits.size()) p = bits[l];
+      if (n == pre + "_g_" + std::to_string(l)) p = g[l];
+    }
+  };
+  layer_of("mask", t->mask_h16, t->mask_bits, t->mask_h); layer_of("warp", t->warp_h16, t->warp_bits, t->warp_h);
+  layer_of("hyper", t->hyper_h16, t->hyper_bits, t->hyper_h); layer_of("trunk", t->trunk_h16, t->trunk_bits, t->trunk_h);
+  if (n == "rgb_h16") p = t->rgb_h16; else if (n == "rgb_bits") p = t->rgb_bits; else if (n == "rgb_g") p = t->rgb_hv;
+  else if (n == "d_rgb_logit") p = t->d_rgb_logit; else if (n == "d_alpha") p = t->d_alpha; else if (n == "d_trunk_in") p = t->d_trunk_in;
+  else if (n == "d_hyper_in") p = t->d_hyper_in; else if (n == "d_warp_in") p = t->d_warp_in; else if (n == "d_mask_in") p = t->d_mask_in;
+  else if (n == "dwamb") p = t->dwamb; else if (n == "dwv") p = t->dwv; else if (n == "d_mask_logit") p = t->d_mask_logit;
+  if (!p) return t->fail(NERFDS_EINVAL, "debug_read: no buffer named %s", name);
+  (void)hipSetDevice(t->device);
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, p, (size_t)max_bytes, hipMemcpyDeviceToHost) != hipSuccess)
+    return t->fail(NERFDS_EDEVICE, "debug_read failed");
+  return max_bytes;
 }
 
 int nerfds_trainer_reset_optimizer(nerfds_trainer* t) {
@@ -844,6 +1064,9 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   (void)hipMemsetAsync(t->terms_dev, 0, 8 * sizeof(float), st);
   const float norm_weight = objective ? objective->norm_loss_weight : 0.f;
   const bool want_sg = (flags & NERFDS_TRAIN_SIGMA_GRAD) != 0 || norm_weight != 0.f;
+  // the tangent passes (sigma gradient, norm loss) read the fp32 activations: those steps keep the layer-by-layer backward
+  t->half_step = t->fused_fwd && t->fused_bwd && !want_sg;
+  if (t->half_step) pack_fused_backward(*t, st);
   t->keep_tangents = norm_weight != 0.f;
   if (norm_weight != 0.f && (!ensure_tangent_ws(*t) || !ensure_norm_ws(*t))) return t->fail(NERFDS_ENOMEM, "hipMalloc of the norm-loss workspace failed");
   if (want_sg && !ensure_tangent_ws(*t)) return t->fail(NERFDS_ENOMEM, "hipMalloc of the tangent workspace failed");
@@ -856,6 +1079,17 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     if (rc != NERFDS_OK) return rc;
   }
   if (t->grad_rep) sum_partials(st, t->grad_rep, GRAD_REPS, t->P, t->grad);      // grad += the replicas of the MFMA kernels
+  if (t->half_step) {
+    // Fused backward: the bottleneck Dense (no activation, modules.py:255) never ran as a layer.  With S = trunk_out^T g_rgb (the
+    // gradient of rgb hidden_0's trunk_out rows, just summed) and c = the bias gradient of rgb hidden_0:
+    //   d K[bottleneck rows] = Wb^T S + bb (x) c,   d Wb = S K_b^T,   d bb = K_b c      (exact: bott = trunk_out Wb + bb)
+    const int TW = t->trunk[0].width, VD = 6 * t->D.vd_bands;
+    for (int lv = 0; lv < (Nf > 0 ? 2 : 1); ++lv) {
+      const LayerP& K = t->rgb_h[lv];
+      bott_grads(st, TW, K.N, t->theta + t->bott[lv].w, t->theta + t->bott[lv].b, t->theta + K.w, t->grad + K.w + (int64_t)(TW + VD) * K.N, t->grad + K.b,
+                 t->grad + K.w, t->grad + t->bott[lv].w, t->grad + t->bott[lv].b);
+    }
+  }
   if (!(flags & NERFDS_TRAIN_GRADS_ONLY)) adam_update(t, learning_rate, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return t->fail(NERFDS_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));

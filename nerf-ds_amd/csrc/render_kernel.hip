@@ -203,7 +203,7 @@ template <class G> constexpr int bias_bytes() { return cdiv(bias_tiles<G>(), 8) 
 // at the boundaries (Pipe::boundary / spread_piece); 0: back to back behind the barrier.  Measured +0.9 % on the 8-wave
 // kernels, +-0 on the 4-wave ones.  The training forward keeps its own (measured) scheme.
 #ifndef NERFDS_SPREAD_DMA
-#ifdef NERFDS_TRAIN_FWD
+#if defined(NERFDS_TRAIN_FWD) || defined(NERFDS_TRAIN_BWD)
 #define NERFDS_SPREAD_DMA 0
 #else
 #define NERFDS_SPREAD_DMA 1
@@ -215,8 +215,16 @@ template <class G> constexpr int bias_bytes() { return cdiv(bias_tiles<G>(), 8) 
 #ifndef NERFDS_TRAIN_VMCNT
 #define NERFDS_TRAIN_VMCNT 1      // 0: the training forward waits with vmcnt(0) at stage boundaries like the render kernels (A/B timing)
 #endif
+// stream lengths of a graph (graphs.h) or of a reversed network of the training backward (one stream, walked as SEG_NERF)
+template <class G, class = void> struct StreamUnits {
+  static constexpr int shared(Plan p) { return shared_units<G>(p); }
+  static constexpr int nerf(Plan p) { return nerf_units<G>(p); }
+};
+template <class G> struct StreamUnits<G, std::void_t<decltype(G::BWD_FRAGS)>> {
+  static constexpr int shared(Plan) { return 0; }
+  static constexpr int nerf(Plan p) { return G::BWD_FRAGS * frag_parts(p.trunk); }
+};
 template <class G, class PL> struct Pipe {
-  using Dm = Dims<G>;
   static constexpr int SU = STAGE_UNITS;                          // units per stage
   static constexpr int NS = NUM_STAGES;
   // The fragments of the graph are TWO streams, each walked as a "segment": SEG_SHARED = [mask | warp | hyper] nets (the same
@@ -226,7 +234,7 @@ template <class G, class PL> struct Pipe {
   // shared, nerf(coarse) per coarse batch; then shared on the NEW fine samples only (the coarse samples' warp / hyper / mask
   // results are reused: same networks, same inputs - models.py:1291-1300 evaluates them again and gets the same values) and
   // nerf(fine) on every batch of the sorted union.
-  static constexpr int SHARED_UNITS = shared_units<G>(PL::value()), NERF_UNITS = nerf_units<G>(PL::value());
+  static constexpr int SHARED_UNITS = StreamUnits<G>::shared(PL::value()), NERF_UNITS = StreamUnits<G>::nerf(PL::value());
   static constexpr bool HAS_SHARED = SHARED_UNITS > 0;
   // stream positions count the zero padding at the end of each stream (graphs.h pad_units)
   static constexpr int SHARED_PAD = pad_units(SHARED_UNITS), NERF_PAD = pad_units(NERF_UNITS);
@@ -277,7 +285,7 @@ template <class G, class PL> struct Pipe {
     // (Waiting with vmcnt(0) only was 1.5 % faster and ran clean on the uniform kernels, but the mixed-precision kernel showed
     // run-to-run differences with it: kept safe.)
     static_assert(NS == 4, "protocol is written for a 4-stage ring");
-#if (defined(NERFDS_TRAIN_FWD) && NERFDS_TRAIN_VMCNT) || NERFDS_SPREAD_DMA
+#if ((defined(NERFDS_TRAIN_FWD) || defined(NERFDS_TRAIN_BWD)) && NERFDS_TRAIN_VMCNT) || NERFDS_SPREAD_DMA
     // Counted wait.  Training forward: the activation stores share VM_CNT with the LDS-DMA, and with vmcnt(0) every boundary also
     // waits for the wave's youngest stores to be acknowledged.  Spread DMA: the pieces of stage s + 2 were issued DURING stage
     // s - 1, the last of them a fraction of a stage ago.  vmcnt(PIECES) is enough and safe: loads complete in order AMONG LOADS, so
@@ -372,7 +380,27 @@ struct Cursor {
 // [sample][width], for the backward pass.  `row` = this lane's sample row of the layer being computed, + 4 * (lane >> 5) floats.
 struct TrainCursor : Cursor {
   float* row;
+  // TrainOut::half_out: the layer goes out as f16 [sample][width] (`row16` = this lane's row + 4 * (lane >> 5) halves) plus one
+  // "output > 0" bit per feature (`bits` = this lane's u16 run of the layer: one u16 per 32-feature tile, bit r = accumulator r)
+  uint16_t* row16;
+  uint16_t* bits;
+  int half;
 };
+// Fused backward (train_backward_kernel): the tiles of a hidden layer are masked with the forward's ReLU bits (`mask`: the lane's
+// u16 per tile, two tiles per register) and stored as fp32 g[sample][width]; the input-gradient tiles are stored (or added) into a
+// buffer whose row stride `ld_in` is not a multiple of 32 - lanes past it write to `sink`.
+struct BwdCursor : TrainCursor {
+  unsigned mask[8];
+  float* in_row;        // this lane's row of d_in + 4 * (lane >> 5)
+  float* sink;
+  int ld_in, in_h4;     // in_h4 = 4 * (lane >> 5)
+  int in_acc;           // add to what is there (the skip layer's contribution came first)
+  int live;             // 0: a tail lane that repeats the last row - its read-modify-write of d_in must not touch the row (it goes to the sink)
+};
+// the same cursor while the tiles being computed are the gradient of the raw input (a TYPE, so that dense() selects the epilogue at
+// compile time: a run-time test of the per-lane row pointer is a divergent branch to the compiler, and divergent regions in the
+// evaluation are where this hipcc misplaces live-range-split copies - see eval_shared)
+struct BwdInCursor : BwdCursor {};
 // Accumulator registers 4g .. 4g + 3 of a lane are output features 32 * tile + 8g + 4h + 0..3 of its sample: four 16-byte stores.
 // (Tried and measured, DESIGN 8.1: staging the tile through LDS so that every store instruction writes whole 128-byte lines,
 // non-temporal stores, a quarter of the bytes per line - none of them changes the cost of the stores, ~3.5 ms per step on top of
@@ -384,6 +412,49 @@ template <bool RELU> DEVI void store_tile(float* row_tile, const f32x16& acc) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = RELU ? relu_f(acc[4 * g + i]) : acc[4 * g + i];
     *reinterpret_cast<f32x4*>(row_tile + 8 * g) = v;
+  }
+}
+// The same tile as f16 (round to nearest even, clamped to the f16 range): four 8-byte stores; returns the tile's 16 ReLU bits.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+template <bool RELU> DEVI unsigned store_tile_half(uint16_t* row_tile, const f32x16& acc) {
+  unsigned bits = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = RELU ? relu_f(acc[4 * g + i]) : acc[4 * g + i];
+      const unsigned nz = __builtin_bit_cast(unsigned, v[i]) != 0u ? 1u : 0u;     // relu'd: non-zero <=> output > 0
+      bits |= nz << (4 * g + i);
+      v[i] = fminf(v[i], 65504.f);
+    }
+    const _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1], h2 = (_Float16)v[2], h3 = (_Float16)v[3];
+    u32x2 pk;
+    pk[0] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    pk[1] = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
+    *reinterpret_cast<u32x2*>(row_tile + 8 * g) = pk;
+  }
+  return bits;
+}
+// Fused backward: zero the accumulator registers whose ReLU bit is clear.  (Written as a select on purpose: the 2-VALU form
+// "x & sign-extended bit" through __builtin_amdgcn_sbfe on this (shifted, masked) operand is folded wrongly by hipcc 7.2 - every
+// register came out as register 0's value; found with tools/chain_diag.py.)
+DEVI void apply_mask(f32x16& acc, unsigned bits16) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = ((bits16 >> r) & 1u) ? acc[r] : 0.f;
+}
+// Input-gradient tile: features 32 t + 8 g + 4 h + 0..3 of the row, those below ld_in only (the others go to the sink: no
+// divergent store, see eval_shared).
+DEVI void store_tile_in(const BwdCursor& cur, int tile, const f32x16& acc) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n0 = 32 * tile + 8 * g + cur.in_h4;
+    float* dst = cur.in_row + (32 * tile + 8 * g);
+    const bool ok = (n0 < cur.ld_in) & (cur.live != 0);
+    dst = ok ? dst : cur.sink;
+    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    if (cur.in_acc) v += *reinterpret_cast<const f32x4*>(dst);
+    *reinterpret_cast<f32x4*>(dst) = v;
   }
 }
 
@@ -662,8 +733,10 @@ template <int P, int NT, int K> struct chunk_prec<Chunk<P>[NT][K]> { static cons
 template <class G, class PL, int NT, int OT, bool RELU, class CUR, int PO, class... Ins>
 DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Carry<NT>& carry, Chunk<PO> (&out)[NT][2 * OT], Ins&... ins) {
   constexpr int TP = TILE_PAIR;
-  constexpr bool TRAIN = std::is_same_v<CUR, TrainCursor>;
-  static_assert(!TRAIN || (NT == 1 && !PL::UNIFORM), "the training forward runs a mixed two-unit plan: one N-tile, C++ epilogue");
+  constexpr bool BWD_IN = std::is_same_v<CUR, BwdInCursor>;
+  constexpr bool BWD = std::is_same_v<CUR, BwdCursor> || BWD_IN;
+  constexpr bool TRAIN = std::is_same_v<CUR, TrainCursor> || BWD;
+  static_assert(!TRAIN || (NT == 1 && !is_single(PO)), "the training kernels run two-unit plans: one N-tile, C++ epilogue");
   static_assert(OT % TP == 0, "layers have an even number of 32-feature tiles");
   // (uniform one-unit plans only: in the mixed plan - f16 networks around a split-bf16 warp field - the asm epilogue build gave
   // run-to-run differences on ~1 % of the rays of the fine level; the C++ epilogue build of the same kernel is clean)
@@ -776,13 +849,26 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Carry<NT>& carry, Chunk<PO> (&out)[
       f32x16 acc[TP][NT];
 #pragma unroll
       for (int tp = 0; tp < TP; ++tp) {
-        const f32x16 bv = load_bias(cur.bt + ot + tp, hb);
+        f32x16 bv;
+        if constexpr (BWD) bv = f32x16{};                      // the transposed layers have no bias
+        else bv = load_bias(cur.bt + ot + tp, hb);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[tp][nt] = bv;
       }
       int j = 0;
       (accum<G, PL, NT, TP>(acc, pipe, cur, ins, j, no_slot), ...);
-      if constexpr (ASM_EPI) {
+      if constexpr (BWD_IN) {                                  // gradient of the raw input: no mask, no next layer
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) store_tile_in(cur, ot + tp, acc[tp][0]);
+      } else if constexpr (BWD) {
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+          apply_mask(acc[tp][0], (cur.mask[(ot + tp) >> 1] >> (16 * ((ot + tp) & 1))) & 0xffffu);
+          store_tile<false>(cur.row + 32 * (ot + tp), acc[tp][0]);
+        }
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) tile_epilogue<PO, NT, false>(out, ot + tp, acc[tp]);
+      } else if constexpr (ASM_EPI) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp)
@@ -798,8 +884,16 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Carry<NT>& carry, Chunk<PO> (&out)[
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) tile_epilogue<PO, NT, RELU>(out, ot + tp, acc[tp]);
         if constexpr (TRAIN) {
+          if (cur.half) {                                      // wave-uniform (a kernel argument)
+            unsigned two = 0;
 #pragma unroll
-          for (int tp = 0; tp < TP; ++tp) store_tile<RELU>(cur.row + 32 * (ot + tp), acc[tp][0]);
+            for (int tp = 0; tp < TP; ++tp) two |= store_tile_half<RELU>(cur.row16 + 32 * (ot + tp), acc[tp][0]) << (16 * tp);
+            static_assert(TP == 2, "one u32 of ReLU bits per tile pair");
+            *reinterpret_cast<unsigned*>(cur.bits + ot) = two;
+          } else {
+#pragma unroll
+            for (int tp = 0; tp < TP; ++tp) store_tile<RELU>(cur.row + 32 * (ot + tp), acc[tp][0]);
+          }
         }
       }
     }
@@ -985,8 +1079,8 @@ DEVI void rodrigues(float (&R)[9], const float (&w)[3], float st, float omc) {
 // so the 8x256 trunk runs with (almost) only MFMA operands in registers.
 // ------------------------------------------------------------------------------------------------
 struct NoTrain { static constexpr bool ON = false; };
-DEVI void set_row(Cursor&, float*) {}
-DEVI void set_row(TrainCursor& c, float* p) { c.row = p; }
+DEVI void set_row(Cursor&, float*, uint16_t*, uint16_t*, int) {}
+DEVI void set_row(TrainCursor& c, float* p, uint16_t* p16, uint16_t* bits, int half) { c.row = p; c.row16 = p16; c.bits = bits; c.half = half; }
 
 // Which samples the N-tiles of this lane evaluate: depth z and the slot of the ray's LDS block (SoA by sample) that receives /
 // holds the sample's per-sample state.  Tail lanes repeat the last sample (same values to the same slot).
@@ -995,7 +1089,8 @@ template <int NT> struct Samples {
   int slot[NT];
 };
 
-#define NERFDS_TRAIN_ROW(base, W) do { if constexpr (TO::ON) set_row(cur, (base) + row * (size_t)(W) + 4 * h); } while (0)
+#define NERFDS_TRAIN_ROW(base, base16, bits, W) do { if constexpr (TO::ON) set_row(cur, (base) + row * (size_t)(W) + 4 * h, \
+    (base16) + row * (size_t)(W) + 4 * h, (bits) + (row * 2 + h) * (size_t)((W) / 32), to.half_out); } while (0)
 #define NERFDS_TRAIN_HEAD(base, n) do { if constexpr (TO::ON) { _Pragma("unroll") for (int j_ = 0; j_ < (n); ++j_) (base)[row * (n) + j_] = hacc[0][0][j_]; } } while (0)
 
 // ---- The level-independent networks on one batch of 32 * NT samples: MaskMLP -> SE(3) field + exp_se3 -> hyper sheet.
@@ -1045,21 +1140,21 @@ DEVI void eval_shared(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, in
         return zero_feat();
       });
     static_assert(G::MASK_DEPTH == 8 || !G::HAS_MASK, "mask net is unrolled for depth 8, skip 4");
-    NERFDS_TRAIN_ROW(to.mask_h[0], G::MASK_W);
+    NERFDS_TRAIN_ROW(to.mask_h[0], to.mask_h16[0], to.mask_bits[0], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, in0);
-    NERFDS_TRAIN_ROW(to.mask_h[1], G::MASK_W);
+    NERFDS_TRAIN_ROW(to.mask_h[1], to.mask_h16[1], to.mask_bits[1], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
-    NERFDS_TRAIN_ROW(to.mask_h[2], G::MASK_W);
+    NERFDS_TRAIN_ROW(to.mask_h[2], to.mask_h16[2], to.mask_bits[2], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b);
-    NERFDS_TRAIN_ROW(to.mask_h[3], G::MASK_W);
+    NERFDS_TRAIN_ROW(to.mask_h[3], to.mask_h16[3], to.mask_bits[3], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
-    NERFDS_TRAIN_ROW(to.mask_h[4], G::MASK_W);
+    NERFDS_TRAIN_ROW(to.mask_h[4], to.mask_h16[4], to.mask_bits[4], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b, in0);      // skip: [x, inputs] (modules.py:66-67)
-    NERFDS_TRAIN_ROW(to.mask_h[5], G::MASK_W);
+    NERFDS_TRAIN_ROW(to.mask_h[5], to.mask_h16[5], to.mask_bits[5], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
-    NERFDS_TRAIN_ROW(to.mask_h[6], G::MASK_W);
+    NERFDS_TRAIN_ROW(to.mask_h[6], to.mask_h16[6], to.mask_bits[6], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b);
-    NERFDS_TRAIN_ROW(to.mask_h[7], G::MASK_W);
+    NERFDS_TRAIN_ROW(to.mask_h[7], to.mask_h16[7], to.mask_bits[7], G::MASK_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
     f32x16 hacc[1][NT];
     head<G, PL, NT>(pipe, cur, carry, hacc, b);
@@ -1090,17 +1185,17 @@ DEVI void eval_shared(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, in
         return zero_feat();
       });
     static_assert(G::WARP_DEPTH == 6 || !G::HAS_WARP, "warp trunk is unrolled for depth 6, skip 4");
-    NERFDS_TRAIN_ROW(to.warp_h[0], G::WARP_W);
+    NERFDS_TRAIN_ROW(to.warp_h[0], to.warp_h16[0], to.warp_bits[0], G::WARP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, in0);
-    NERFDS_TRAIN_ROW(to.warp_h[1], G::WARP_W);
+    NERFDS_TRAIN_ROW(to.warp_h[1], to.warp_h16[1], to.warp_bits[1], G::WARP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
-    NERFDS_TRAIN_ROW(to.warp_h[2], G::WARP_W);
+    NERFDS_TRAIN_ROW(to.warp_h[2], to.warp_h16[2], to.warp_bits[2], G::WARP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b);
-    NERFDS_TRAIN_ROW(to.warp_h[3], G::WARP_W);
+    NERFDS_TRAIN_ROW(to.warp_h[3], to.warp_h16[3], to.warp_bits[3], G::WARP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
-    NERFDS_TRAIN_ROW(to.warp_h[4], G::WARP_W);
+    NERFDS_TRAIN_ROW(to.warp_h[4], to.warp_h16[4], to.warp_bits[4], G::WARP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b, in0);
-    NERFDS_TRAIN_ROW(to.warp_h[5], G::WARP_W);
+    NERFDS_TRAIN_ROW(to.warp_h[5], to.warp_h16[5], to.warp_bits[5], G::WARP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
     f32x16 hacc[1][NT];
     head<G, PL, NT>(pipe, cur, carry, hacc, b);      // logical outputs: w = 0..2, v = 3..5
@@ -1181,17 +1276,17 @@ DEVI void eval_shared(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, in
         return zero_feat();
       });
     static_assert(G::HYP_DEPTH == 6 || !G::HAS_HYPER, "hyper sheet is unrolled for depth 6, skip 4");
-    NERFDS_TRAIN_ROW(to.hyper_h[0], G::HYP_W);
+    NERFDS_TRAIN_ROW(to.hyper_h[0], to.hyper_h16[0], to.hyper_bits[0], G::HYP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, in0);
-    NERFDS_TRAIN_ROW(to.hyper_h[1], G::HYP_W);
+    NERFDS_TRAIN_ROW(to.hyper_h[1], to.hyper_h16[1], to.hyper_bits[1], G::HYP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
-    NERFDS_TRAIN_ROW(to.hyper_h[2], G::HYP_W);
+    NERFDS_TRAIN_ROW(to.hyper_h[2], to.hyper_h16[2], to.hyper_bits[2], G::HYP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b);
-    NERFDS_TRAIN_ROW(to.hyper_h[3], G::HYP_W);
+    NERFDS_TRAIN_ROW(to.hyper_h[3], to.hyper_h16[3], to.hyper_bits[3], G::HYP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
-    NERFDS_TRAIN_ROW(to.hyper_h[4], G::HYP_W);
+    NERFDS_TRAIN_ROW(to.hyper_h[4], to.hyper_h16[4], to.hyper_bits[4], G::HYP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, a, b, in0);
-    NERFDS_TRAIN_ROW(to.hyper_h[5], G::HYP_W);
+    NERFDS_TRAIN_ROW(to.hyper_h[5], to.hyper_h16[5], to.hyper_bits[5], G::HYP_W);
     dense<G, PL, NT, W32, true>(pipe, cur, carry, b, a);
     f32x16 hacc[1][NT];
     head<G, PL, NT>(pipe, cur, carry, hacc, b);
@@ -1244,21 +1339,21 @@ DEVI void eval_nerf(const KArgs& ka, Pipe<G, PL>& pipe, int level, int lane, con
         return zero_feat();
       });
     static_assert(G::TRUNK_DEPTH == 8 && G::TRUNK_SKIP == 4, "trunk is unrolled for depth 8, skip 4");
-    NERFDS_TRAIN_ROW(to.trunk_h[0], G::TRUNK_W);
+    NERFDS_TRAIN_ROW(to.trunk_h[0], to.trunk_h16[0], to.trunk_bits[0], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, a, in0);
-    NERFDS_TRAIN_ROW(to.trunk_h[1], G::TRUNK_W);
+    NERFDS_TRAIN_ROW(to.trunk_h[1], to.trunk_h16[1], to.trunk_bits[1], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, b, a);
-    NERFDS_TRAIN_ROW(to.trunk_h[2], G::TRUNK_W);
+    NERFDS_TRAIN_ROW(to.trunk_h[2], to.trunk_h16[2], to.trunk_bits[2], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, a, b);
-    NERFDS_TRAIN_ROW(to.trunk_h[3], G::TRUNK_W);
+    NERFDS_TRAIN_ROW(to.trunk_h[3], to.trunk_h16[3], to.trunk_bits[3], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, b, a);
-    NERFDS_TRAIN_ROW(to.trunk_h[4], G::TRUNK_W);
+    NERFDS_TRAIN_ROW(to.trunk_h[4], to.trunk_h16[4], to.trunk_bits[4], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, a, b, in0);
-    NERFDS_TRAIN_ROW(to.trunk_h[5], G::TRUNK_W);
+    NERFDS_TRAIN_ROW(to.trunk_h[5], to.trunk_h16[5], to.trunk_bits[5], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, b, a);
-    NERFDS_TRAIN_ROW(to.trunk_h[6], G::TRUNK_W);
+    NERFDS_TRAIN_ROW(to.trunk_h[6], to.trunk_h16[6], to.trunk_bits[6], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, a, b);
-    NERFDS_TRAIN_ROW(to.trunk_h[7], G::TRUNK_W);
+    NERFDS_TRAIN_ROW(to.trunk_h[7], to.trunk_h16[7], to.trunk_bits[7], G::TRUNK_W);
     dense<G, PL, NT, TW32, true>(pipe, cur, carry, b, a);          // b = trunk_output
     // (the activation-free bottleneck Dense, modules.py:255, is folded into rgb hidden_0 by the packer)
     f32x16 hacc[1][NT];
@@ -1304,7 +1399,7 @@ DEVI void eval_nerf(const KArgs& ka, Pipe<G, PL>& pipe, int level, int lane, con
       });
     }
     Chunk<PR> c[NT][G::RGB_W / 16];
-    NERFDS_TRAIN_ROW(to.rgb_h, G::RGB_W);
+    NERFDS_TRAIN_ROW(to.rgb_h, to.rgb_h16, to.rgb_bits, G::RGB_W);
     dense<G, PL, NT, G::RGB_W / 32, true>(pipe, cur, carry, c, b, cond);       // K order [trunk_output | cond]
     head<G, PL, NT>(pipe, cur, carry, hacc, c);
     NERFDS_TRAIN_HEAD(to.rgb_logit, 3);
@@ -1784,6 +1879,107 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train
 }
 #endif  // NERFDS_TRAIN_FWD
 
+#ifdef NERFDS_TRAIN_BWD
+// ------------------------------------------------------------------------------------------------
+// Training backward of ONE network (training.py:494 differentiates the whole model.apply): the data-gradient chain of the reversed
+// MLP on the machinery of the forward - transposed weight fragments streamed through the LDS ring, every layer's gradient kept in
+// registers as the next (earlier) layer's B operand (the accumulator of a transposed tile IS g^T[feature][sample]), split-bf16
+// operands with fp32 accumulation.  Per 32-sample tile a wave reads the head gradients and the ReLU bits of every layer, and
+// writes g_l = d loss / d (pre-activation of layer l) for every hidden layer (the dY of the weight-gradient kernels) and the
+// gradient of the raw input.  dX of a hidden layer never goes to HBM as an operand of the next data-gradient kernel, nor do the
+// fp32 activations come back as masks: 1 array pass per layer where the layer-by-layer backward made 3.
+// ------------------------------------------------------------------------------------------------
+template <int W> DEVI void load_bits(unsigned (&m)[W / 64 > 0 ? W / 64 : 1], const uint16_t* bits, long long r, int h) {
+  const unsigned* p = reinterpret_cast<const unsigned*>(bits + ((size_t)r * 2 + h) * (W / 32));
+#pragma unroll
+  for (int j = 0; j < W / 64; ++j) m[j] = p[j];
+}
+template <class BG, class PL, int OT, class OUT, class... Ins>
+DEVI void bwd_hidden(Pipe<BG, PL>& pipe, BwdCursor& cur, Carry<1>& carry, const unsigned (&m)[OT / 2], float* g_row, OUT& out, Ins&... ins) {
+#pragma unroll
+  for (int j = 0; j < OT / 2; ++j) cur.mask[j] = m[j];
+  cur.row = g_row;
+  dense<BG, PL, 1, OT, false>(pipe, cur, carry, out, ins...);
+}
+template <class BG, class PL, int P, int K>
+DEVI void bwd_input(Pipe<BG, PL>& pipe, BwdCursor& cur, Carry<1>& carry, float* in_row, int acc, Chunk<P> (&in)[1][K]) {
+  Chunk<P> none[1][4];
+  BwdInCursor ic;
+  static_cast<BwdCursor&>(ic) = cur;
+  ic.in_row = in_row;
+  ic.in_acc = acc;
+  dense<BG, PL, 1, 2, false>(pipe, ic, carry, none, in);
+  cur.pos = ic.pos;
+  cur.bt = ic.bt;
+}
+
+template <class BG, class PL>
+DEVI void bwd_chain(const TrainBwd& tb, Pipe<BG, PL>& pipe, int lane, long long r, int live) {
+  constexpr int W = BG::W, D = BG::DEPTH, W16 = W / 16, W32 = W / 32, P = P_BF16X3, MW = W / 64;
+  static_assert(BG::SKIP == 4 && (D == 8 || D == 6) && W % 64 == 0, "chains are written out for depth 8 / 6, skip 4");
+  const int h = lane >> 5;
+  BwdCursor cur;
+  cur.seg = SEG_NERF; cur.pos = 0; cur.bt = 0;
+  cur.row = nullptr; cur.row16 = nullptr; cur.bits = nullptr; cur.half = 0;
+  cur.sink = tb.sink; cur.ld_in = tb.ld_in; cur.in_h4 = 4 * h; cur.in_row = nullptr; cur.in_acc = 0; cur.live = live;
+  Carry<1> carry;
+  // every load of the tile up front (one wait): ReLU bits of all layers, head gradients
+  unsigned mk[D][MW];
+#pragma unroll
+  for (int l = 0; l < D; ++l) load_bits<W>(mk[l], tb.bits[l], r, h);
+  auto g_row = [&](int l) { return tb.g[l] + (size_t)r * W + 4 * h; };
+  float* const in_row = tb.d_in + (size_t)r * tb.ld_in + 4 * h;
+  Chunk<P> a[1][W16], b[1][W16];
+  if constexpr (BG::IS_NERF) {
+    constexpr int RW = BG::RGB_W, R16 = RW / 16;
+    unsigned mr[RW / 64];
+    load_bits<RW>(mr, tb.bits[8], r, h);
+    Chunk<P> drgb[1][1], dalpha[1][1], c[1][R16];
+    build_chunks<P, 1>(drgb[0], h, [&](int f) { return f < 3 ? val_feat(tb.d_head[(size_t)r * tb.ld_head + f]) : zero_feat(); });
+    build_chunks<P, 1>(dalpha[0], h, [&](int f) { return f < 4 ? val_feat(tb.d_head2[(size_t)r * 4 + f]) : zero_feat(); });
+    bwd_hidden<BG, PL, RW / 32>(pipe, cur, carry, mr, tb.g[8] + (size_t)r * RW + 4 * h, c, drgb);     // g_rgb = mask(W_rgb d rgb_logit)
+    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[7], g_row(7), a, c, dalpha);                          // g_7 = mask(F^T g_rgb + W_alpha d alpha)
+  } else {
+    Chunk<P> dh[1][1];
+    build_chunks<P, 1>(dh[0], h, [&](int f) { return f < BG::NHEAD ? val_feat(tb.d_head[(size_t)r * tb.ld_head + f]) : zero_feat(); });
+    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[D - 1], g_row(D - 1), a, dh);                          // g_{D-1} = mask(W_head d head)
+  }
+  if constexpr (D == 8) {
+    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[6], g_row(6), b, a);
+    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[5], g_row(5), a, b);
+    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[4], g_row(4), b, a);
+  } else {
+    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[4], g_row(4), b, a);
+  }
+  // the skip layer [h_3 | raw input] (modules.py:66-67): its hidden rows give g_3, its raw-input rows the first part of d input
+  bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[3], g_row(3), a, b);
+  bwd_input<BG, PL>(pipe, cur, carry, in_row, 0, b);
+  bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[2], g_row(2), b, a);
+  bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[1], g_row(1), a, b);
+  bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[0], g_row(0), b, a);
+  bwd_input<BG, PL>(pipe, cur, carry, in_row, 1, b);
+  pipe.finish_segment(SEG_NERF);
+}
+
+template <class BG, class PL>
+__global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train_backward_kernel(const TrainBwd tb) {
+  using PP = Pipe<BG, PL>;
+  static_assert(wg_waves<PL>() == 4 && !PP::HAS_SHARED, "one 512-register wave per SIMD, one stream");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  Pipe<BG, PL> pipe;
+  pipe.cur = pipe.next = make_rsrc(tb.wstream, PP::NERF_PAD * 1024);
+  pipe.lane16 = lane * 16;
+  pipe.wave1k = wave * 1024;
+  pipe.prologue(SEG_NERF);
+  const long long groups = (tb.M + 127) / 128;
+  for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const long long rr = grp * 128 + wave * 32 + (lane & 31);
+    bwd_chain<BG, PL>(tb, pipe, lane, rr < tb.M ? rr : tb.M - 1, rr < tb.M ? 1 : 0);     // tail lanes redo the last row: same g values to the same places
+  }
+}
+#endif  // NERFDS_TRAIN_BWD
+
 }  // namespace nerfds
 
 // One translation unit per (graph, precision plan):
@@ -1795,7 +1991,9 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train
 #define NERFDS_CAT2(a, b) a##b
 #define NERFDS_CAT(a, b) NERFDS_CAT2(a, b)
 namespace nerfds {
-#if defined(NERFDS_TRAIN_FWD)
+#if defined(NERFDS_TRAIN_BWD)
+using KernelPlan = PlanT<P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3>;      // the data-gradient chains: split bf16 throughout
+#elif defined(NERFDS_TRAIN_FWD)
 // the trainer's arithmetic: 16-bit split operands everywhere, fp32 products in the warp field
 using KernelPlan = PlanT<TRAIN_PLAN.mask, TRAIN_PLAN.warp, TRAIN_PLAN.hyp, TRAIN_PLAN.trunk, TRAIN_PLAN.rgb>;
 #elif defined(NERFDS_MIXED)
@@ -1805,7 +2003,29 @@ using KernelPlan = PlanT<NERFDS_PREC, NERFDS_PREC, NERFDS_PREC, NERFDS_PREC, NER
 #endif
 }  // namespace nerfds
 
-#ifdef NERFDS_TRAIN_FWD
+#ifdef NERFDS_TRAIN_BWD
+template <class BG> static void launch_bwd(const nerfds::TrainBwd& tb, int num_cus, void* stream) {
+  using namespace nerfds;
+  using PLX = PlanT<P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3>;
+  static bool attr_set = false;
+  auto kern = train_backward_kernel<BG, PLX>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES);
+    attr_set = true;
+  }
+  const long long groups = (tb.M + 127) / 128;
+  const int grid = (int)(groups < num_cus ? groups : num_cus);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wg_waves<PLX>()), RING_BYTES, static_cast<hipStream_t>(stream), tb);
+}
+// net: 0 NerfMLP (trunk + rgb branch + alpha head), 1 hyper sheet, 2 warp field, 3 mask net
+extern "C" void nerfds_launch_train_bwd_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream) {
+  using G = nerfds::NERFDS_GRAPH;
+  if (net == 0) launch_bwd<nerfds::BwdNerf<G>>(tb, num_cus, stream);
+  else if (net == 1) launch_bwd<nerfds::BwdHyper<G>>(tb, num_cus, stream);
+  else if (net == 2) launch_bwd<nerfds::BwdWarp<G>>(tb, num_cus, stream);
+  else launch_bwd<nerfds::BwdMask<G>>(tb, num_cus, stream);
+}
+#elif defined(NERFDS_TRAIN_FWD)
 template <bool WIDE> static void launch_train(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream) {
   using namespace nerfds;
   using SH = Shape<KernelPlan, WIDE>;

@@ -40,6 +40,11 @@ struct WgradArgs {
   // their atomics on one small region queue up on a few L2 channels (40-60 us per kernel, whatever its size); spread over
   // nrep copies that tail goes away, and the caller sums the copies once per step.  nrep <= 1: no replicas.
   long long rep_stride; int nrep;
+  // x_half: x points to f16 [M x ldx] (what the fused forward stores for the plain training step; K, ldx multiples of 8, 16-byte
+  // aligned rows) - converted exactly into bf16 hi + lo on the way to the MFMAs.
+  int x_half;
+  // colsum != nullptr: += the column sums of dY (the bias gradient of the layer), a by-product of the tile conversion; replicas as dw.
+  float* colsum;
 };
 bool wgrad_supported(const WgradArgs& A);
 // Launches on `grid` workgroups chosen by wgrad_grid(); part must hold grid * K * N floats.  false = shape not covered.

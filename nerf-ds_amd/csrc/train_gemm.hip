@@ -508,7 +508,8 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
   // DMA descriptors.  The stage holds [16][K] floats of X, then [16][N] floats of dY; each part is fetched either in 16-byte
   // pieces (rows 16-byte aligned) or, for the odd shapes (K = 33, N = 1 .. 6), float by float - one kind per instruction,
   // so a part is rounded up to whole instructions.  Lanes past the end of a part / of M read the zero line.
-  const int NX = A.x_scalar ? (16 * K + 63) >> 6 : (16 * KQ + 63) >> 6;
+  const int XH = A.x_half;                                                   // X is f16: 8 elements per 16-byte piece, 2 bytes each
+  const int NX = A.x_scalar ? (16 * K + 63) >> 6 : (XH ? (2 * K + 63) >> 6 : (16 * KQ + 63) >> 6);
   const int NY = A.dy_scalar ? (16 * N + 63) >> 6 : (16 * NQ + 63) >> 6;
   const int XBYTES = NX * (A.x_scalar ? 256 : 1024);
   const char* src[IPW];
@@ -523,14 +524,15 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
     if (i < NX + NY) {
       const bool isx = i < NX;
       const int ii = isx ? i : i - NX, W = isx ? K : N, ld = isx ? A.ldx : A.ldy;
-      const float* base = isx ? A.x : A.dy;
+      const char* base = reinterpret_cast<const char*>(isx ? A.x : A.dy);
       sc = isx ? A.x_scalar != 0 : A.dy_scalar != 0;
-      const int e = (64 * ii + lane) * (sc ? 1 : 4);                        // first float of this lane's piece, in [16][W]
+      const int esz = (isx && XH) ? 2 : 4;                                  // bytes per element
+      const int e = (64 * ii + lane) * (sc ? 1 : 16 / esz);                 // first element of this lane's piece, in [16][W]
       off = (isx ? 0 : XBYTES) + ii * (sc ? 256 : 1024);
       if (e < 16 * W) {
         row = e / W;
-        p = reinterpret_cast<const char*>(base + ((size_t)blockIdx.x * 16 + row) * ld + (e - row * W));
-        st = grid * 16 * ld * 4;
+        p = base + (((size_t)blockIdx.x * 16 + row) * ld + (e - row * W)) * esz;
+        st = grid * 16 * ld * esz;
       }
     }
     src[u] = p; step[u] = st; rowu[u] = row; ldsoff[u] = __builtin_amdgcn_readfirstlane(off); scalar[u] = __builtin_amdgcn_readfirstlane(sc);
@@ -555,8 +557,8 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
     const int idx = threadIdx.x + 512 * j;
     c_src[j] = -1; c_dst[j] = 0; c_stride[j] = 0;
     if (idx < 2 * K) {
-      const int o = idx / K, f = idx - o * K;
-      c_src[j] = (8 * o * K + f) * 4; c_stride[j] = K * 4;
+      const int o = idx / K, f = idx - o * K, esz = XH ? 2 : 4;
+      c_src[j] = (8 * o * K + f) * esz; c_stride[j] = K * esz;
       c_dst[j] = (f >> 5) * 2048 + ((o << 5) | (f & 31)) * 16;
     } else if (idx < 2 * (K + N)) {
       const int i2 = idx - 2 * K, o = i2 / N, f = i2 - o * N;
@@ -568,6 +570,7 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
 #pragma unroll
   for (int j = 0; j < TPW; ++j) acc[j] = f32x16{};
   char* img = g_tile + S::NS * S::STAGE_BYTES;
+  float cs[2] = {0.f, 0.f};            // column sums of this thread's dY items (feature f, sample octet o) over the workgroup's tiles
 
   long long tile = blockIdx.x;
 #pragma unroll
@@ -584,8 +587,14 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
     for (int j = 0; j < 2; ++j) {
       if (c_src[j] >= 0) {
         float f[8];
+        if (XH && threadIdx.x + 512 * j < 2 * K) {       // f16 item of X (whole waves take one side: 2 K is a multiple of 64 on this path)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const float*>(stg + c_src[j] + i * c_stride[j]);
+          for (int i = 0; i < 8; ++i) f[i] = (float)*reinterpret_cast<const _Float16*>(stg + c_src[j] + i * c_stride[j]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const float*>(stg + c_src[j] + i * c_stride[j]);
+        }
+        if (threadIdx.x + 512 * j >= 2 * K) cs[j] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
         bf16x8 xh, xl;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -624,6 +633,14 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
     }
   }
   wait_vm_lgkm0<0>();
+  if (A.colsum != nullptr) {           // bias gradient: each dY item adds its 8-sample sums (two items per feature and workgroup)
+    float* cdst = A.colsum + (A.nrep > 1 ? (size_t)(blockIdx.x % A.nrep) * A.rep_stride : 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = threadIdx.x + 512 * j;
+      if (idx >= 2 * K && idx < 2 * (K + N)) unsafeAtomicAdd(cdst + (idx - 2 * K) % N, cs[j]);
+    }
+  }
   // this workgroup's partial: lane holds column n = 32 nt + (lane & 31), rows k = 32 kt + (r & 3) + 8 (r >> 2) + 4 h
   float* part = A.dw != nullptr ? A.dw + (A.nrep > 1 ? (size_t)(blockIdx.x % A.nrep) * A.rep_stride : 0) : A.part + (size_t)blockIdx.x * K * N;
   const bool atomic = A.dw != nullptr;
@@ -946,12 +963,13 @@ bool dense_ws(hipStream_t st, const DenseArgs& A, int num_cus) {
 }
 
 static void wgrad_kinds(const WgradArgs& A, int& xs, int& ys, int& ninstr) {
-  xs = (A.k % 4 || A.ldx % 4 || !aligned16(A.x)) ? 1 : 0;
+  xs = (!A.x_half && (A.k % 4 || A.ldx % 4 || !aligned16(A.x))) ? 1 : 0;
   ys = (A.n % 4 || A.ldy % 4 || !aligned16(A.dy)) ? 1 : 0;
-  ninstr = (xs ? (16 * A.k + 63) / 64 : (4 * A.k + 63) / 64) + (ys ? (16 * A.n + 63) / 64 : (4 * A.n + 63) / 64);
+  ninstr = (xs ? (16 * A.k + 63) / 64 : ((A.x_half ? 2 : 4) * A.k + 63) / 64) + (ys ? (16 * A.n + 63) / 64 : (4 * A.n + 63) / 64);
 }
 bool wgrad_supported(const WgradArgs& A) {
   if (A.k < 1 || A.n < 1 || A.k > 256 || A.n > 256 || A.M <= 0 || A.zeros == nullptr) return false;
+  if (A.x_half && (A.k % 32 || A.ldx % 8 || !aligned16(A.x))) return false;       // f16 rows: whole 16-byte pieces, whole waves of items
   int xs, ys, ninstr;
   wgrad_kinds(A, xs, ys, ninstr);
   return ninstr <= 32;                                              // at most 4 DMA instructions per wave and tile

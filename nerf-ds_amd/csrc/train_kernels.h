@@ -61,5 +61,9 @@ void adam(hipStream_t, float* p, const float* g, float* m1, float* m2, long long
 void pack_stream(hipStream_t, const float* theta, const float* fold, long long P, const int* map, void* stream, int nfrag, int f32_lo, int f32_hi);
 void pack_bias(hipStream_t, const float* theta, const float* fold, long long P, const int* map, float* out, int n);
 void fold_rgb(hipStream_t, const float* B, const float* Bb, const float* K, const float* Kb, int TW, int W, int row_x, float* fold);
+// gradients of the activation-free bottleneck Dense from S = trunk_out^T g_rgb [TW x W] and c = colsum(g_rgb) [W] (fused backward):
+//   dKb[TW x W] = Wb^T S + bb (x) c,  dWb[TW x TW] = S Kb^T,  dbb[TW] = Kb c;  Wb [TW x TW], Kb = the first TW rows of K [.. x W]
+void bott_grads(hipStream_t, int TW, int W, const float* Wb, const float* bb, const float* K, const float* S, const float* c, float* dKb,
+                float* dWb, float* dbb);
 
 }  // namespace nerfds_train

@@ -951,6 +951,34 @@ __global__ void k_fold_rgb(const float* __restrict__ B, const float* __restrict_
   for (int k = 0; k < TW; ++k) acc += (double)left[k] * (double)K[(size_t)k * W + c];
   fold[i] = (float)acc;
 }
+// fused backward: see train_kernels.h bott_grads.  One thread per output element, double accumulation like k_fold_rgb (3 x 65 k dot
+// products of length <= 256: a few microseconds).
+__global__ void k_bott_grads(int TW, int W, const float* __restrict__ Wb, const float* __restrict__ bb, const float* __restrict__ K,
+                             const float* __restrict__ S, const float* __restrict__ c, float* __restrict__ dKb, float* __restrict__ dWb,
+                             float* __restrict__ dbb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nK = TW * W, nW = TW * TW;
+  if (i < nK) {                                   // dKb[k][n] = sum_r Wb[r][k] S[r][n] + bb[k] c[n]
+    const int k = i / W, n = i % W;
+    double acc = (double)bb[k] * (double)c[n];
+    for (int r = 0; r < TW; ++r) acc += (double)Wb[(size_t)r * TW + k] * (double)S[(size_t)r * W + n];
+    dKb[i] = (float)acc;
+  } else if (i < nK + nW) {                       // dWb[r][k] = sum_n S[r][n] Kb[k][n]
+    const int j = i - nK, r = j / TW, k = j % TW;
+    double acc = 0.0;
+    for (int n = 0; n < W; ++n) acc += (double)S[(size_t)r * W + n] * (double)K[(size_t)k * W + n];
+    dWb[j] = (float)acc;
+  } else if (i < nK + nW + TW) {                  // dbb[k] = sum_n Kb[k][n] c[n]
+    const int k = i - nK - nW;
+    double acc = 0.0;
+    for (int n = 0; n < W; ++n) acc += (double)K[(size_t)k * W + n] * (double)c[n];
+    dbb[k] = (float)acc;
+  }
+}
+void bott_grads(hipStream_t st, int TW, int W, const float* Wb, const float* bb, const float* K, const float* S, const float* c, float* dKb,
+                float* dWb, float* dbb) {
+  LAUNCH(k_bott_grads, (long long)TW * W + (long long)TW * TW + TW, st, TW, W, Wb, bb, K, S, c, dKb, dWb, dbb);
+}
 void pack_stream(hipStream_t st, const float* theta, const float* fold, long long P, const int* map, void* stream, int nfrag, int f32_lo, int f32_hi) {
   LAUNCH(k_pack_stream, (long long)nfrag * 64, st, theta, fold, P, map, static_cast<unsigned char*>(stream), nfrag, f32_lo, f32_hi);
 }

@@ -62,6 +62,8 @@ def _bind(lib):
   lib.nerfds_trainer_clip_gradients.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
   lib.nerfds_trainer_target_norm.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
   lib.nerfds_trainer_last_error.argtypes = [C.c_void_p]
+  lib.nerfds_trainer_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_longlong]
+  lib.nerfds_trainer_debug_read.restype = C.c_longlong
   lib.nerfds_trainer_last_error.restype = C.c_char_p
   lib._trainer_bound = True
   return lib
@@ -158,6 +160,14 @@ class Trainer:
     rc = self._lib.nerfds_trainer_target_norm(self._h, lv, self._last_rays, out.ctypes.data)
     if rc != 0:
       raise RuntimeError(f'nerfds_trainer_target_norm failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
+    return out
+
+  def debug_read(self, name: str, shape, dtype=np.float32) -> np.ndarray:
+    """Development / tests: host copy of an internal buffer of the last step (include/nerfds.h nerfds_trainer_debug_read)."""
+    out = np.empty(shape, dtype)
+    rc = self._lib.nerfds_trainer_debug_read(self._h, name.encode(), out.ctypes.data, out.nbytes)
+    if rc < 0:
+      raise RuntimeError(f'nerfds_trainer_debug_read failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
     return out
 
   def get_params(self) -> Dict[str, Any]:

@@ -11,6 +11,7 @@ for g in nerfds:GraphNerfDS static:GraphStatic hyper:GraphHyperNeRF; do for p in
   jobs_n=$((jobs_n + 1)); if [ $jobs_n -ge 8 ]; then wait -n; jobs_n=$((jobs_n - 1)); fi
 done; done
 /opt/rocm/bin/hipcc $FL -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_TRAIN_FWD -DNERFDS_NAME=train_fwd_nerfds -o build/asm/train_fwd.s 2>/dev/null &
+/opt/rocm/bin/hipcc $FL -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_TRAIN_BWD -DNERFDS_NAME=train_bwd_nerfds -o build/asm/train_bwd.s 2>/dev/null &
 wait
 python3 ../../tools/isa_lint.py build/asm/*.s | grep -v "^$"
 exit ${PIPESTATUS[0]}
