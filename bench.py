@@ -51,7 +51,7 @@ PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f32': 157.3, 'f16': 2500.0, 'm
 EXTRA = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
 # where the committed PMC measurement of the headline kernel lives (separate rocprofv3 passes of this command, tools/prof_bench.sh)
 TRAFFIC_FILE = 'profiles/r3_bf16_hbm_traffic.json'
-TRAIN_TRAFFIC_FILE = 'profiles/r2_train_hbm_traffic.json'
+TRAIN_TRAFFIC_FILE = 'profiles/r3_train_hbm_traffic.json'
 
 
 def synth_rays(R, n_ids, seed, device):
@@ -175,32 +175,44 @@ def run_train(args, device):
   S = 3 * 64                                     # field evaluations per ray: 64 coarse + 128 fine
   M = R * S
   dims = layer_dims(cfg)
-  # traffic model of the step (fp32 activations in HBM): forward Y only (ONE fused launch per level keeps X on chip; layer by layer,
-  # NERFDS_TRAIN_FUSED_FWD=0, it is X + Y); weight gradient X + dY; data gradient dY + Y (ReLU mask) + dX
-  #   ->  N (+ K) + (K + N) + (K + 2N) floats per sample and layer, 4 bytes each
+  # Traffic model of the step, per sample and dense layer (K inputs, N outputs), bytes:
+  #   fused backward (default): forward writes Y as f16 + one ReLU bit per feature (2.125 N, hidden layers); the network's data-gradient
+  #     chain writes g = dL/d(pre-activation) once (4 N); the weight gradient reads X (2 K as f16 from a hidden layer, 4 K from a raw
+  #     input) and g (4 N).  dX never passes through HBM.
+  #   layer-by-layer backward (NERFDS_TRAIN_FUSED_BWD=0, round 2): forward Y (4 N), weight gradient X + dY (4 K + 4 N), data gradient
+  #     dY + Y + dX (8 N + 4 K); + X (4 K) in the forward when that is not fused either.
   fused_fwd = os.environ.get('NERFDS_TRAIN_FUSED_FWD', '1') != '0'
-  hbm_bytes = 4.0 * M * sum((2 if fused_fwd else 3) * K + 4 * N for K, N in dims)
+  fused_bwd = fused_fwd and os.environ.get('NERFDS_TRAIN_FUSED_BWD', '1') != '0'
+  if fused_bwd:
+    hbm_bytes = float(M) * sum((2.125 * N + 4 * N if N > 6 else 0) + 4 * N + (2 * K if K in (64, 128, 256) else 4 * K) for K, N in dims)
+  else:
+    hbm_bytes = 4.0 * M * sum((2 if fused_fwd else 3) * K + 4 * N for K, N in dims)
   traffic, traffic_source = None, None
   tpath = os.path.join(ROOT, TRAIN_TRAFFIC_FILE)
-  if os.path.exists(tpath) and R == 4096 and fused_fwd:
+  if os.path.exists(tpath) and R == 4096 and fused_bwd:
     tj = json.load(open(tpath))
     traffic, traffic_source = tj['hbm_bytes_per_step'], f"{TRAIN_TRAFFIC_FILE} ({tj['measured_on']})"
   flop = 3 * FLOP_PER_RAY * R                    # fwd + bwd ~ 3 x forward
   result = {
       'metric': 'training rays/sec (batch 4096, MSE of both levels + backward + Adam, full warp+NerfMLP)',
       'value': R / dt, 'unit': 'rays/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt * 1e3,
-      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16x2 (split bf16 operands, fp32 accumulate, fp32 activations)',
+      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16x2 (split bf16 operands, fp32 accumulate; activations stored as f16 + ReLU bits, gradients fp32)',
       'data': 'synthetic',
       'config': {'workload': f"BASELINE configs[3]: training step, {R} random rays of 64 synthetic frames, 64 coarse + 64 fine samples, nerf_ds graph, "
                              'loss = MSE(fine) + MSE(coarse), backward through every network, Adam; sampling jitter drawn on chip',
                  'rays_per_step': R, 'parallelism': 'single GPU', 'exchange': 'none (1 GPU)'},
       'roofline': {'bound': 'hbm', 'achieved': hbm_bytes / dt / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': hbm_bytes / dt / 8e12,
                    'traffic': traffic, 'traffic_source': traffic_source,
-                   'kernel': 'whole step (one fused forward launch per level + about 100 backward layer kernels; each is HBM-bound)' if fused_fwd
-                             else 'whole step (about 150 layer kernels; each is HBM-bound)',
+                   'kernel': ('whole step (per level: one fused forward launch, four fused data-gradient chains, one weight-gradient launch per layer segment)' if fused_bwd
+                              else 'whole step (one fused forward launch per level + about 100 backward layer kernels; each is HBM-bound)' if fused_fwd
+                              else 'whole step (about 150 layer kernels; each is HBM-bound)'),
                    'algorithmic_bytes_per_step': hbm_bytes,
-                   'traffic_model': 'fp32 activations: forward ' + ('Y (fused: X stays on chip)' if fused_fwd else 'X + Y') + ', weight gradient X + dY, data gradient dY + Y + dX',
-                   'algorithmic_tflops': flop / dt / 1e12, 'mfma_frac_of_2500': flop / dt / 2.5e15},
+                   'traffic_model': ('forward f16 Y + ReLU bits; chains write g once (fp32); weight gradient reads X (f16) + g' if fused_bwd else
+                                     'fp32 activations: forward ' + ('Y (fused: X stays on chip)' if fused_fwd else 'X + Y') + ', weight gradient X + dY, data gradient dY + Y + dX'),
+                   'algorithmic_tflops': flop / dt / 1e12, 'mfma_frac_of_2500': flop / dt / 2.5e15,
+                   # the matrix-pipe floor of the step: forward + data gradient + weight gradient (3 x the forward's FLOPs), three bf16 MFMAs
+                   # per product at the split-bf16 arithmetic the gradient tests need, at the 2.5 PFLOP/s dense peak
+                   'mfma_floor_ms': 3 * flop / 2.5e15 * 1e3, 'ms_over_mfma_floor': dt * 1e3 / (3 * flop / 2.5e15 * 1e3)},
       'loss_first': losses[0], 'loss_last': losses[-1],
   }
   if not args.no_cpu_baseline:

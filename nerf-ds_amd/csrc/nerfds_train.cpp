@@ -491,8 +491,9 @@ bool build_fused_forward(nerfds_trainer& t) {
                           c.num_coarse_samples + c.num_fine_samples <= nerfds::MAX_SAMPLES;
   if (!same_graph) return false;       // other widths: the layer-by-layer forward
   constexpr nerfds::Plan F32 = nerfds::uniform_plan(nerfds::P_F32);
-  static_assert(nerfds::shared_units<G>(F32) == nerfds::shared_units<G>(nerfds::TRAIN_PLAN) && nerfds::nerf_units<G>(F32) == nerfds::nerf_units<G>(nerfds::TRAIN_PLAN),
-                "index maps are packed in the fp32 layout: every network of TRAIN_PLAN must be two units per fragment");
+  static_assert(nerfds::nerf_units<G>(F32) == nerfds::nerf_units<G>(nerfds::TRAIN_PLAN) && nerfds::TRAIN_PLAN.mask == nerfds::P_BF16X3 &&
+                (nerfds::TRAIN_PLAN.warp == nerfds::P_BF16X6 || nerfds::TRAIN_PLAN.warp == nerfds::P_F32) && nerfds::TRAIN_PLAN.hyp == nerfds::P_BF16X3,
+                "index maps are packed in the two-unit fp32 layout; k_pack_stream keeps the warp field's fragments fp32 or widens them to three units");
   constexpr int TW = G::TRUNK_W, RW = G::RGB_W, VD = Dm::VD_FEATS, NM = Dm::NM_FEATS, FL = (TW + 1) * RW;
   const int levels = c.num_fine_samples > 0 ? 2 : 1;
   if (t.P + 2 * FL + 1 >= (1 << 24)) return false;     // indices travel through the packer as floats
@@ -542,12 +543,15 @@ bool build_fused_forward(nerfds_trainer& t) {
     const float* wf = reinterpret_cast<const float*>(w.data());
     for (size_t i = 0; i < map.size(); ++i) map[i] = (int)wf[i];
     for (size_t i = 0; i < bmap.size(); ++i) bmap[i] = (int)b[i];
+    // the stream itself is in TRAIN_PLAN's layout (the warp field's fragments take three units)
+    const int64_t sb = (int64_t)nerfds::pad_units(which == 0 ? nerfds::shared_units<G>(nerfds::TRAIN_PLAN) : nerfds::nerf_units<G>(nerfds::TRAIN_PLAN)) * 1024;
     if (hipMalloc(&t.fmap[which], map.size() * 4) != hipSuccess || hipMalloc(&t.fbmap[which], bmap.size() * 4) != hipSuccess ||
-        hipMalloc(&t.fstream[which], (size_t)wb) != hipSuccess || hipMalloc(&t.fbias[which], bmap.size() * 4) != hipSuccess ||
+        hipMalloc(&t.fstream[which], (size_t)sb) != hipSuccess || hipMemset(t.fstream[which], 0, (size_t)sb) != hipSuccess ||
+        hipMalloc(&t.fbias[which], bmap.size() * 4) != hipSuccess ||
         hipMemcpy(t.fmap[which], map.data(), map.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(t.fbmap[which], bmap.data(), bmap.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
       return false;
-    t.fstream_frags[which] = (int)(wb / 2048);
+    t.fstream_frags[which] = (which == 0 ? nerfds::shared_units<G>(F32) : nerfds::nerf_units<G>(F32)) / 2;      // real fragments (the padding of the stream stays zero)
     t.fbias_n[which] = (int)bf;
   }
   return true;
@@ -563,7 +567,8 @@ void pack_fused_forward(nerfds_trainer& t, hipStream_t st) {
     fold_rgb(st, t.theta + t.bott[lv].w, t.theta + t.bott[lv].b, t.theta + t.rgb_h[lv].w, t.theta + t.rgb_h[lv].b, TW, RW, TW + Dm::VD_FEATS,
              t.fold + (size_t)lv * FL);
   for (int which = 0; which < 1 + levels; ++which) {
-    pack_stream(st, t.theta, t.fold, t.P, t.fmap[which], t.fstream[which], t.fstream_frags[which], which == 0 ? t.f32_lo : 0, which == 0 ? t.f32_hi : 0);
+    pack_stream(st, t.theta, t.fold, t.P, t.fmap[which], t.fstream[which], t.fstream_frags[which], which == 0 ? t.f32_lo : 0, which == 0 ? t.f32_hi : 0,
+                nerfds::TRAIN_PLAN.warp == nerfds::P_F32 ? 1 : 0);
     pack_bias(st, t.theta, t.fold, t.P, t.fbmap[which], t.fbias[which], t.fbias_n[which]);
   }
 }

@@ -115,6 +115,16 @@ struct StreamWriter {
             dh[i] = f32_to_bf16_rne(v[i]);
             dl[i] = f32_to_bf16_rne(v[i] - bf16_to_f32(dh[i]));
           }
+        } else if (prec == P_BF16X6) {
+          uint16_t* dh = reinterpret_cast<uint16_t*>(frag + lane * 16);
+          uint16_t* dm = reinterpret_cast<uint16_t*>(frag + 1024 + lane * 16);
+          uint16_t* dl = reinterpret_cast<uint16_t*>(frag + 2048 + lane * 16);
+          for (int i = 0; i < 8; ++i) {
+            dh[i] = f32_to_bf16_rne(v[i]);
+            const float r = v[i] - bf16_to_f32(dh[i]);
+            dm[i] = f32_to_bf16_rne(r);
+            dl[i] = f32_to_bf16_rne(r - bf16_to_f32(dm[i]));
+          }
         } else {
           float* da = reinterpret_cast<float*>(frag + lane * 16);
           float* db = reinterpret_cast<float*>(frag + 1024 + lane * 16);

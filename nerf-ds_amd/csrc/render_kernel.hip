@@ -73,12 +73,14 @@ template <> struct Chunk<P_BF16> { bf16x8 v; };
 template <> struct Chunk<P_BF16X3> { bf16x8 hi, lo; };
 template <> struct Chunk<P_F32> { float v[8]; };
 template <> struct Chunk<P_F16> { f16x8 v; };
+template <> struct Chunk<P_BF16X6> { bf16x8 hi, mid, lo; };
 
 template <int P> struct WFrag;   // 32 out rows x 16 k-slots of weights (this lane: 8 slots of 1 row)
 template <> struct WFrag<P_BF16> { bf16x8 v; };
 template <> struct WFrag<P_BF16X3> { bf16x8 hi, lo; };
 template <> struct WFrag<P_F32> { f32x4 a, b; };
 template <> struct WFrag<P_F16> { f16x8 v; };
+template <> struct WFrag<P_BF16X6> { bf16x8 hi, mid, lo; };
 
 // relu on raw float bits: signed-integer max with 0 (one v_max_i32; fmaxf costs a canonicalising v_max on top).
 DEVI float relu_f(float x) {
@@ -106,6 +108,17 @@ template <> DEVI void make_chunk<P_BF16X3>(Chunk<P_BF16X3>& c, const float (&x)[
     c.lo[i] = (__bf16)(x[i] - (float)hi);
   }
 }
+template <> DEVI void make_chunk<P_BF16X6>(Chunk<P_BF16X6>& c, const float (&x)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 hi = (__bf16)x[i];
+    const float r = x[i] - (float)hi;
+    const __bf16 mid = (__bf16)r;
+    c.hi[i] = hi;
+    c.mid[i] = mid;
+    c.lo[i] = (__bf16)(r - (float)mid);
+  }
+}
 template <> DEVI void make_chunk<P_F32>(Chunk<P_F32>& c, const float (&x)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) c.v[i] = x[i];
@@ -129,6 +142,14 @@ template <int P> DEVI void mma(f32x16& acc, const WFrag<P>& w, const Chunk<P>& c
     // (w_hi + w_lo)(x_hi + x_lo) ~= w_hi x_lo + w_lo x_hi + w_hi x_hi ; small terms first.
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, c.lo, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, c.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, c.hi, acc, 0, 0, 0);
+  } else if constexpr (P == P_BF16X6) {
+    // every product of total order <= 2 of (hi + mid + lo)(hi + mid + lo), small terms first: fp32-grade (measured 1e-6 vs fp64)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, c.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, c.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, c.mid, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, c.mid, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, c.hi, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, c.hi, acc, 0, 0, 0);
   } else {
 #pragma unroll
@@ -351,6 +372,11 @@ template <class G, class PL> struct Pipe {
     } else if constexpr (P == P_BF16X3) {
       w.hi = __builtin_bit_cast(bf16x8, ring[u % RD]);
       w.lo = __builtin_bit_cast(bf16x8, ring[(u + 1) % RD]);
+    } else if constexpr (P == P_BF16X6) {
+      static_assert(RD >= 4 || P != P_BF16X6, "three units of one fragment and one of the next");
+      w.hi = __builtin_bit_cast(bf16x8, ring[u % RD]);
+      w.mid = __builtin_bit_cast(bf16x8, ring[(u + 1) % RD]);
+      w.lo = __builtin_bit_cast(bf16x8, ring[(u + 2) % RD]);
     } else {
       w.a = __builtin_bit_cast(f32x4, ring[u % RD]);
       w.b = __builtin_bit_cast(f32x4, ring[(u + 1) % RD]);
@@ -414,21 +440,23 @@ template <bool RELU> DEVI void store_tile(float* row_tile, const f32x16& acc) {
     *reinterpret_cast<f32x4*>(row_tile + 8 * g) = v;
   }
 }
-// The same tile as f16 (round to nearest even, clamped to the f16 range): four 8-byte stores; returns the tile's 16 ReLU bits.
+// The same tile as f16 (round to nearest even; an activation beyond 65504 becomes inf and shows up as an inf weight gradient): four
+// 8-byte stores; returns the tile's 16 ReLU bits, bit r <-> register r.  Two VALU per bit: the relu'd value has non-negative integer
+// bits, so 0 - bits is negative exactly when the output is > 0, and v_alignbit shifts that sign bit in (registers 15 .. 0).
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 template <bool RELU> DEVI unsigned store_tile_half(uint16_t* row_tile, const f32x16& acc) {
   unsigned bits = 0;
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = RELU ? relu_f(acc[r]) : acc[r];
+#pragma unroll
+  for (int r = 15; r >= 0; --r) {
+    const unsigned neg = 0u - __builtin_bit_cast(unsigned, v[r]);
+    bits = __builtin_amdgcn_alignbit(bits, neg, 31);                              // (bits << 1) | (neg >> 31)
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    float v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[i] = RELU ? relu_f(acc[4 * g + i]) : acc[4 * g + i];
-      const unsigned nz = __builtin_bit_cast(unsigned, v[i]) != 0u ? 1u : 0u;     // relu'd: non-zero <=> output > 0
-      bits |= nz << (4 * g + i);
-      v[i] = fminf(v[i], 65504.f);
-    }
-    const _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1], h2 = (_Float16)v[2], h3 = (_Float16)v[3];
+    const _Float16 h0 = (_Float16)v[4 * g], h1 = (_Float16)v[4 * g + 1], h2 = (_Float16)v[4 * g + 2], h3 = (_Float16)v[4 * g + 3];
     u32x2 pk;
     pk[0] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
     pk[1] = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
@@ -530,10 +558,11 @@ DEVI void accum(f32x16 (&acc)[TP][NT], Pipe<G, PL>& pipe, Cursor& cur, const Chu
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp) {
       const int u = cur.pos;
-      // First fragment that touches a new stage (a two-unit fragment may straddle: its first unit is in the register
+      // First fragment that touches a new stage (a multi-unit fragment may straddle: its first units are in the register
       // ring already, and so is every other unit of the stage that is being retired - the ring runs RD units ahead).
-      if (u % PP::SU == 0) pipe.begin_stage(cur.seg, u);
-      else if (NP == 2 && (u + 1) % PP::SU == 0) pipe.begin_stage(cur.seg, u + 1);
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+        if ((u + q) % PP::SU == 0) pipe.begin_stage(cur.seg, u + q);
       const WFrag<P> w = pipe.template frag<P>(u);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) mma<P>(acc[tp][nt], w, in[nt][kc]);
@@ -2014,7 +2043,10 @@ template <class BG> static void launch_bwd(const nerfds::TrainBwd& tb, int num_c
     attr_set = true;
   }
   const long long groups = (tb.M + 127) / 128;
-  const int grid = (int)(groups < num_cus ? groups : num_cus);
+  // the 64 / 128-wide chains need <= 256 registers: two workgroups per CU (two waves per SIMD cover each other's waits); the trunk's
+  // takes the whole register file
+  const long long want = (long long)num_cus * (BG::W <= 128 ? 2 : 1);
+  const int grid = (int)(groups < want ? groups : want);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wg_waves<PLX>()), RING_BYTES, static_cast<hipStream_t>(stream), tb);
 }
 // net: 0 NerfMLP (trunk + rgb branch + alpha head), 1 hyper sheet, 2 warp field, 3 mask net

@@ -58,7 +58,8 @@ void target_norm(hipStream_t, long long M, const float* t_alpha, const float* wv
 void clip_gradients(hipStream_t, float* g, long long n, float max_val, float max_norm, float* sumsq_scratch);
 void adam(hipStream_t, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2);
 // fused forward: weight streams / biases / folded rgb layer from the current parameters (see train_kernels.hip)
-void pack_stream(hipStream_t, const float* theta, const float* fold, long long P, const int* map, void* stream, int nfrag, int f32_lo, int f32_hi);
+// map: two units (2 KiB) per fragment; stream: split bf16 (two units), fragments [x6_lo, x6_hi) exact fp32 (wide_f32) or three units (hi | mid | lo)
+void pack_stream(hipStream_t, const float* theta, const float* fold, long long P, const int* map, void* stream, int nfrag, int x6_lo, int x6_hi, int wide_f32 = 0);
 void pack_bias(hipStream_t, const float* theta, const float* fold, long long P, const int* map, float* out, int n);
 void fold_rgb(hipStream_t, const float* B, const float* Bb, const float* K, const float* Kb, int TW, int W, int row_x, float* fold);
 // gradients of the activation-free bottleneck Dense from S = trunk_out^T g_rgb [TW x W] and c = colsum(g_rgb) [W] (fused backward):

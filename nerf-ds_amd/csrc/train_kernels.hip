@@ -905,10 +905,11 @@ __device__ __forceinline__ unsigned short bf16_rne(float f) {      // pack.h f32
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
-// One thread per (fragment, lane): 8 k-slots of one output row.  Fragments [f32_lo, f32_hi) keep fp32 (slots 0-3 in the first
-// 1-KiB unit, 4-7 in the second), the others become split bf16 (hi in the first unit, lo = bf16(v - hi) in the second): pack.h frag_out.
+// One thread per (fragment, lane): 8 k-slots of one output row.  The map is in the two-unit layout (2 KiB per fragment); the stream
+// holds split bf16 - hi | lo units - except the fragments [x6_lo, x6_hi) (the warp field's forward): exact fp32 (wide_f32), or split three
+// ways (hi | mid | lo units, graphs.h P_BF16X6) - then every fragment behind x6_lo starts one unit later per three-way fragment before it.
 __global__ void k_pack_stream(const float* __restrict__ theta, const float* __restrict__ fold, long long P, const int* __restrict__ map,
-                              unsigned char* __restrict__ stream, int nfrag, int f32_lo, int f32_hi) {
+                              unsigned char* __restrict__ stream, int nfrag, int x6_lo, int x6_hi, int wide_f32) {
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (long long)nfrag * 64) return;
   const int frag = (int)(tid >> 6), lane = (int)(tid & 63);
@@ -918,22 +919,34 @@ __global__ void k_pack_stream(const float* __restrict__ theta, const float* __re
   float v[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = map_value(theta, fold, P, mi[i]);
-  unsigned char* fa = stream + (size_t)frag * 2048 + lane * 16;
-  if (frag >= f32_lo && frag < f32_hi) {
-    *reinterpret_cast<float4*>(fa) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(fa + 1024) = make_float4(v[4], v[5], v[6], v[7]);
-  } else {
-    unsigned hi[4], lo[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned short h0 = bf16_rne(v[2 * i]), h1 = bf16_rne(v[2 * i + 1]);
-      const unsigned short l0 = bf16_rne(v[2 * i] - __uint_as_float((unsigned)h0 << 16)), l1 = bf16_rne(v[2 * i + 1] - __uint_as_float((unsigned)h1 << 16));
-      hi[i] = (unsigned)h0 | ((unsigned)h1 << 16);
-      lo[i] = (unsigned)l0 | ((unsigned)l1 << 16);
-    }
-    *reinterpret_cast<uint4*>(fa) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    *reinterpret_cast<uint4*>(fa + 1024) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  if (wide_f32 && frag >= x6_lo && frag < x6_hi) {        // the range keeps exact fp32: k-slots 0-3 | 4-7 (graphs.h P_F32), two units
+    unsigned char* ff = stream + (size_t)frag * 2048 + lane * 16;
+    *reinterpret_cast<float4*>(ff) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(ff + 1024) = make_float4(v[4], v[5], v[6], v[7]);
+    return;
   }
+  const int extra = wide_f32 ? 0 : (frag < x6_lo ? 0 : (frag < x6_hi ? frag - x6_lo : x6_hi - x6_lo));       // three-way fragments before this one
+  unsigned char* fa = stream + ((size_t)frag * 2 + extra) * 1024 + lane * 16;
+  const bool x6 = frag >= x6_lo && frag < x6_hi;
+  unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned short h[2], m[2], l[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float x = v[2 * i + e];
+      h[e] = bf16_rne(x);
+      const float r = x - __uint_as_float((unsigned)h[e] << 16);
+      m[e] = bf16_rne(r);
+      l[e] = bf16_rne(r - __uint_as_float((unsigned)m[e] << 16));
+    }
+    hi[i] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+    mid[i] = (unsigned)m[0] | ((unsigned)m[1] << 16);
+    lo[i] = (unsigned)l[0] | ((unsigned)l[1] << 16);
+  }
+  *reinterpret_cast<uint4*>(fa) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  *reinterpret_cast<uint4*>(fa + 1024) = make_uint4(mid[0], mid[1], mid[2], mid[3]);          // two-way: this is the "lo" unit
+  if (x6) *reinterpret_cast<uint4*>(fa + 2048) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 __global__ void k_pack_bias(const float* __restrict__ theta, const float* __restrict__ fold, long long P, const int* __restrict__ map, float* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -979,8 +992,8 @@ void bott_grads(hipStream_t st, int TW, int W, const float* Wb, const float* bb,
                 float* dWb, float* dbb) {
   LAUNCH(k_bott_grads, (long long)TW * W + (long long)TW * TW + TW, st, TW, W, Wb, bb, K, S, c, dKb, dWb, dbb);
 }
-void pack_stream(hipStream_t st, const float* theta, const float* fold, long long P, const int* map, void* stream, int nfrag, int f32_lo, int f32_hi) {
-  LAUNCH(k_pack_stream, (long long)nfrag * 64, st, theta, fold, P, map, static_cast<unsigned char*>(stream), nfrag, f32_lo, f32_hi);
+void pack_stream(hipStream_t st, const float* theta, const float* fold, long long P, const int* map, void* stream, int nfrag, int x6_lo, int x6_hi, int wide_f32) {
+  LAUNCH(k_pack_stream, (long long)nfrag * 64, st, theta, fold, P, map, static_cast<unsigned char*>(stream), nfrag, x6_lo, x6_hi, wide_f32);
 }
 void pack_bias(hipStream_t st, const float* theta, const float* fold, long long P, const int* map, float* out, int n) {
   LAUNCH(k_pack_bias, n, st, theta, fold, P, map, out, n);
