@@ -66,17 +66,18 @@ def test_train_oracle_reproduces_golden():
     assert abs(norm - float(z['norm/' + name])) <= 1e-10 * max(norm, 1e-30)
 
 
+MAX_TOL, NORM_TOL = 2e-3, 5e-4
+
+
 @pytest.mark.gpu
 def test_hip_training_step_matches_golden():
   """The HIP training step against COMMITTED gradient digests (the oracle is not run): per leaf a seeded subsample of
-  256 entries, the L2 norm and the max-abs value of the fp64 autograd gradient.  The trainer's layers are the hand-written
-  split-bf16 MFMA kernels (tests/test_training.py): bounds 1e-1 (max-abs: a ReLU whose pre-activation is ~0 can flip, which
-  moves single entries by one sample's contribution - 5e-2 of the leaf maximum on a trunk bias here) / 3e-2 (norm).  The wide
-  norm bound is not slack in the kernels: on this case (trained-regime weights) the gradient w.r.t. the warped points - which
-  every warp / hyper-sheet / mask leaf goes through - is a cancelling sum over the 2^0..2^7 posenc frequencies with condition
-  number ~300 (fp32 GEMMs land at 2e-5, not 6e-8, here), so the 2^-17 operand rounding of the split-bf16 GEMMs anywhere in the
-  trunk shows up as ~1e-2 on those leaves (measured 1.4e-2 worst, NerfMLP leaves 1e-4).  The reference's own matmuls (bf16 on
-  TPU, TF32 on NVIDIA GPUs at jnp's default precision) round coarser."""
+  256 entries, the L2 norm and the max-abs value of the fp64 autograd gradient.  The trainer's layers are hand-written
+  split-bf16 MFMA kernels (tests/test_training.py).  Measured in round 3 with the fused backward (activations as f16 + ReLU bits,
+  data gradient chained in registers): worst max-abs 3.3e-4 of the leaf maximum, worst norm 6.1e-5 - bounds MAX_TOL / NORM_TOL are
+  a few times that (the float atomics of the weight-gradient sums reorder from run to run).  Round 2's layer-by-layer backward
+  needed 1e-1 / 3e-2 here; what it lost is what a round trip of every dX through fp32 HBM arrays and a second rounding to split
+  bf16 costs on the ill-conditioned posenc backward of this trained-regime case."""
   from nerfds_amd.training import Trainer
   gemm = 'mfma'
   from nerfds_amd.params import tree_leaves
@@ -87,9 +88,15 @@ def test_hip_training_step_matches_golden():
   assert abs(stats['loss/fine'] - float(z['loss/fine'])) < 2e-5 and abs(stats['loss/coarse'] - float(z['loss/coarse'])) < 2e-5
   got = dict(tree_leaves(tr.get_grads()))
   gmax = max(float(z[k]) for k in z.files if k.startswith('max/'))
+  worst = {'max': (0.0, ''), 'norm': (0.0, '')}
   for name, g in got.items():
     idx, want, norm, amax = z['idx/' + name], z['val/' + name], float(z['norm/' + name]), float(z['max/' + name])
     flat = np.asarray(g, np.float64).ravel()
     scale = max(amax, 1e-3 * gmax)
-    assert np.abs(flat[idx] - want).max() / scale < (1e-1 if gemm == 'mfma' else 1e-2), name   # fp32 path vs fp64 fixture (yardstick: tests/test_training.py)
-    assert abs(np.linalg.norm(flat) - norm) <= (3e-2 if gemm == 'mfma' else 4e-3) * max(norm, 1e-3 * gmax * np.sqrt(flat.size)), name
+    e_max = float(np.abs(flat[idx] - want).max() / scale)
+    e_norm = float(abs(np.linalg.norm(flat) - norm) / max(norm, 1e-3 * gmax * np.sqrt(flat.size)))
+    worst['max'] = max(worst['max'], (e_max, name))
+    worst['norm'] = max(worst['norm'], (e_norm, name))
+  import sys
+  print(f"golden training digests: worst max-abs {worst['max'][0]:.2e} ({worst['max'][1]}), worst norm {worst['norm'][0]:.2e} ({worst['norm'][1]})", file=sys.stderr)
+  assert worst['max'][0] < MAX_TOL and worst['norm'][0] < NORM_TOL, worst

@@ -142,7 +142,7 @@ def test_nerf_ds_trained_regime_and_deterministic_sampling():
         assert e <= (1e-4 if k == 'rgb' else 1e-3), (prec, level, k, e)
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'f16'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'f16', 'bf16', 'mixed'])
 def test_windows_partially_open(prec):
   """warp_alpha / nerf_alpha mid-schedule: fractional Hann windows on the top bands (model_utils.py:420-436)."""
   cfg = nerf_ds_config(num_warp_embeds=2, num_coarse_samples=16, num_fine_samples=16)
@@ -192,7 +192,8 @@ def test_white_background_and_no_sample_at_infinity(graph, white, infinity):
       assert float(out[sorted(ref)[-1]]['rgb'].max()) <= 1.0 + 1e-5
 
 
-def test_mask_ratio_blends_gt_mask():
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
+def test_mask_ratio_blends_gt_mask(prec):
   cfg = nerf_ds_config(num_warp_embeds=2, num_coarse_samples=8, num_fine_samples=8)
   params = init_params(cfg, 6, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
   R = 6
@@ -202,7 +203,7 @@ def test_mask_ratio_blends_gt_mask():
   ref = O.NerfModel(cfg, params).apply(rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, mask_ratio=0.25,
                                        compute_sigma_gradient=False)
   out = _model(cfg).apply({'params': params}, rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True,
-                          mask_ratio=0.25, precision='f32')
+                          mask_ratio=0.25, precision=prec)
   for k in ('rgb', 'ray_delta_x', 'ray_hyper_points'):
     assert _relerr(out['fine'][k].cpu().numpy(), ref['fine'][k].numpy()) <= 1e-4, k
 

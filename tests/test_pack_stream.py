@@ -186,3 +186,18 @@ def test_weights_holder_rejects_tables_and_biases_of_the_wrong_shape():
   h.struct.embed_rows = 4
   assert lib.nerfds_pack_stream(C.byref(cs), C.byref(h.struct), 0, 0, 0, None, None) == -22
   assert 'num_warp_embeds' in N.last_error(None)
+
+
+def test_bench_fragment_counts_match_the_compiled_graphs():
+  """bench.py prices the executed MFMA work from its own walk of the graphs: it must agree with csrc/graphs.h (504 + 1060 fragments
+  per evaluation of the nerf_ds graph) and with the once-per-position evaluation of the level-independent nets."""
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('bench', os.path.join(os.path.dirname(__file__), '..', 'bench.py'))
+  bench = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(bench)
+  assert bench.stream_fragments('nerf_ds') == (504, 1060)
+  assert bench.stream_fragments('static')[0] == 0
+  shared, nerf = bench.stream_fragments('nerf_ds')
+  # 64 + 64 samples: 2 coarse tiles of everything, 2 tiles of the shared nets on the new samples, 4 tiles of the fine NerfMLP
+  assert bench.executed_flop_per_ray('nerf_ds', 64, 64) == 32768.0 * (2 * (shared + nerf) + 2 * shared + 4 * nerf)
+  assert bench.executed_flop_per_ray('nerf_ds', 64, 0) == 32768.0 * 2 * (shared + nerf)

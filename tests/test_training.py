@@ -61,7 +61,10 @@ def test_oracle_gradient_matches_finite_differences_where_no_stop_gradient_appli
 # field through the ill-conditioned posenc backward (tests/test_golden.py has the argument), the 16-bit trunk GEMMs leave ~9e-3
 # on warp-field leaves: bound 1.5e-2.
 L2_TOL = {'mfma': 4e-3}
-L2_TOL_2ND = {'mfma': 1.5e-2}
+# measured in round 3 (printed by the tests): rgb loss 2.9e-3 worst leaf at <= 64 rays and 4.0e-3 at 19 200 rows; first-order auxiliary
+# losses 2.5e-3; second-order norm loss 6.4e-3 (5.8e-3 at 19 200 rows).  Bounds are <= 2 x those.
+L2_TOL_2ND = {'mfma': 1.2e-2}
+L2_TOL_AUX = 5e-3        # first-order auxiliary losses (test_auxiliary_losses_match_the_oracle)
 
 
 @pytest.fixture(params=['mfma'])
@@ -91,6 +94,7 @@ def test_hip_gradients_match_autograd_oracle(R, Nc, Nf, ratio, gemm):
   _, G32, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u if Nf else None, mask_ratio=ratio, dtype=torch.float32)
   w32 = dict(tree_leaves(G32))
   gmax = max(np.abs(v).max() for v in want.values())
+  worst_l2, worst_max = (0.0, ''), (0.0, '')
   for name, w in want.items():
     g = got[name].reshape(w.shape)
     scale = max(np.abs(w).max(), 1e-3 * gmax)        # per-leaf scale, floored so all-zero leaves (stop-gradient) compare absolutely
@@ -98,9 +102,11 @@ def test_hip_gradients_match_autograd_oracle(R, Nc, Nf, ratio, gemm):
     noise = np.abs(w32[name] - w).max() / scale
     l2 = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
     # a ReLU whose pre-activation is ~0 can land on the other side with 16-bit operands; at 96 .. 2048 samples one flipped
-    # unit is visible in the max-abs error of a leaf (not in its L2 error), so the mfma mode bounds max-abs at 5e-2
-    max_tol = 5e-2
+    # unit is visible in the max-abs error of a leaf (not in its L2 error), so max-abs is bounded at 2.5e-2
+    max_tol = 2.5e-2          # measured 1.1e-2
+    worst_l2, worst_max = max(worst_l2, (float(l2), name)), max(worst_max, (float(err), name))
     assert l2 < L2_TOL[gemm] and err < max_tol, f'{name}: l2 {l2:.2e}, max {err:.2e} (oracle fp32 noise {noise:.2e})'
+  print(f'gradients vs oracle ({R} rays, {Nc}+{Nf}): worst l2 {worst_l2[0]:.2e} ({worst_l2[1]}), worst max-abs {worst_max[0]:.2e} ({worst_max[1]})', file=sys.stderr)
   # the normal channels of the alpha head receive no gradient (stop_gradient, models.py:1132-1133)
   for lv in (['coarse', 'fine'] if Nf else ['coarse']):
     assert np.abs(got[f'nerf_mlps_{lv}/alpha_mlp/logit/kernel'][:, 1:]).max() == 0.0
@@ -216,11 +222,13 @@ def test_fused_forward_equals_the_layer_by_layer_forward(monkeypatch, R, nc, nf)
     if k in sb:
       assert abs(sa[k] - sb[k]) <= 1e-5 * max(1.0, abs(sb[k])), (k, sa[k], sb[k])
   # per leaf, relative L2 with the denominator floored as in the oracle test above (near-zero leaves compare absolutely); each forward is
-  # within L2_TOL_2ND = 1.5e-2 of the fp64 oracle under this objective (the warp-field leaves, through the posenc backward), so two of
+  # within 1.5e-2 of the fp64 oracle under this objective (the warp-field leaves, through the posenc backward), so two of
   # them are within 3e-2 of each other; the median leaf agrees to 2e-3
   gmax = max(float(np.abs(v).max()) for v in gb.values())
   errs = sorted((float(np.linalg.norm(ga[k] - gb[k]) / max(np.linalg.norm(gb[k]), 1e-3 * gmax * np.sqrt(gb[k].size))), k) for k in gb)
-  assert errs[-1][0] <= 2 * L2_TOL_2ND['mfma'] and errs[len(errs) // 2][0] <= 2e-3, errs[-3:]
+  # (measured 2.5e-2 on warp_field/trunk/hidden_1/bias at 301 rays x 24 samples: the layer-by-layer path - every dX rounded to split
+  # bf16 again on its way back from HBM - is the looser of the two; against the oracle the fused path measures 2.5e-3 under this objective)
+  assert errs[-1][0] <= 3e-2 and errs[len(errs) // 2][0] <= 2e-3, errs[-3:]
 
 
 @pytest.mark.gpu
@@ -277,11 +285,11 @@ def test_sigma_gradient_target_norm_matches_oracle():
     np.testing.assert_allclose(np.linalg.norm(got, axis=-1), 1.0, atol=1e-5)
     cos = (got * want).sum(-1)
     # Normalising a gradient amplifies fp32 rounding where |d sigma / d x| is tiny.  Reported, not hidden: the fraction of samples
-    # off by more than 1e-4 (measured 0.7 % / 1.4 % on this case), bounded at 2.5 %; the median error is at fp32 level and no sample
-    # is off by more than 1 - cos = 0.2.
+    # off by more than 1e-4 (measured 0.0 % coarse / 0.35 % fine on this case), bounded at 1 %; the median error is at fp32 level and
+    # no sample is off by more than 1 - cos = 0.1 (measured worst 3.9e-2).
     frac = float((1 - cos > 1e-4).mean())
     print(f'target_norm {level}: {100 * frac:.2f} % of the samples have 1 - cos > 1e-4; median {np.median(1 - cos):.1e}, worst {1 - cos.min():.2e}', file=sys.stderr)
-    assert frac < 0.025 and np.median(1 - cos) < 1e-6 and cos.min() > 0.8, (level, frac, np.median(1 - cos), cos.min())
+    assert frac < 0.01 and np.median(1 - cos) < 1e-6 and cos.min() > 0.9, (level, frac, np.median(1 - cos), cos.min())
   with pytest.raises(RuntimeError):
     tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True)
     tr.target_norm('fine')                      # the last step did not evaluate it
@@ -312,10 +320,13 @@ def test_auxiliary_losses_match_the_oracle(sharp, gemm):
   assert abs(stats['loss/total'] - L['total']) < 1e-4 * L['total']
   got, want = dict(tree_leaves(tr.get_grads())), dict(tree_leaves(G))
   gmax = max(np.abs(v).max() for v in want.values())
+  worst = (0.0, '')
   for name, w in want.items():
     g = got[name].reshape(w.shape)
     l2 = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
-    assert l2 < L2_TOL_2ND[gemm], (name, l2)
+    worst = max(worst, (float(l2), name))
+    assert l2 < L2_TOL_AUX, (name, l2)
+  print(f'auxiliary losses (sharp={sharp}): worst leaf l2 {worst[0]:.2e} ({worst[1]})', file=sys.stderr)
   # the normal channels of the alpha head now DO receive gradient (back-facing regulariser), the mask net too
   assert np.abs(got['nerf_mlps_fine/alpha_mlp/logit/kernel'][:, 1:]).max() > 0
   assert np.abs(got['mask_mlp/MLP_0/hidden_0/kernel']).max() > 0
@@ -342,13 +353,16 @@ def test_norm_loss_second_order_matches_the_oracle(only_norm, gemm):
   got, want, base = dict(tree_leaves(tr.get_grads())), dict(tree_leaves(G)), dict(tree_leaves(G0))
   gmax = max(np.abs(v).max() for v in want.values())
   moved = 0
+  worst = (0.0, '')
   for name, w in want.items():
     g = got[name].reshape(w.shape)
     l2 = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
+    worst = max(worst, (float(l2), name))
     assert l2 < L2_TOL_2ND[gemm], (name, l2)
     # the norm loss must actually have contributed to this leaf's gradient for the check to mean something
     if np.linalg.norm(w - base[name]) > 0.05 * max(np.linalg.norm(w), 1e-12):
       moved += 1
+  print(f'norm loss (only_norm={only_norm}): worst leaf l2 {worst[0]:.2e} ({worst[1]})', file=sys.stderr)
   assert moved >= 20, moved      # trunk, warp and hyper leaves all move (second-order path), not only the alpha head
 
 
@@ -382,8 +396,7 @@ def test_gradients_match_the_oracle_at_multi_tile_size(full):
   tile.  Here 600 rays x (16 + 16) samples = 9 600 / 19 200 rows (300 / 600 tiles of 32 over 256 workgroups, a partial
   16-row tile for the weight gradient): several tiles per workgroup - and the SAME pin as above, the fp64 autograd oracle
   (5-8 s on the host), not another mode of the trainer.  What this guards against is an indexing error past the first
-  tile (O(1) differences).  Bounds: 6e-3 for the rgb loss (measured 4.1e-3 on warp_field/trunk/hidden_0/kernel, the leaf whose
-  gradient passes the ill-conditioned posenc backward; 4e-3 holds at the small sizes), 1.5e-2 with the full objective."""
+  tile (O(1) differences).  Bounds: 6e-3 for the rgb loss (4e-3 holds at the small sizes), L2_TOL_2ND with the full objective."""
   from nerfds_amd.training import Trainer
   from oracle import train_oracle as T
   R = 600
@@ -402,10 +415,56 @@ def test_gradients_match_the_oracle_at_multi_tile_size(full):
     errs[name] = float(np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size)))
   top = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
   print(f'multi-tile ({"full objective" if full else "rgb loss"}): worst leaves ' + ', '.join(f'{k} {v:.2e}' for k, v in top), file=sys.stderr)
-  # The leaves with thousands of entries (every hidden kernel: where a tile-indexing error would show as O(1)) meet the bounds of
-  # the small cases.  The SE(3) head leaves (branches_w / branches_v: all four are d loss / d (w, v) contracted with the same
-  # activations, and d loss / d (w, v) is the cancelling sum over the 2^0..2^7 posenc frequencies of tests/test_golden.py's
-  # argument) sit at 0.5 .. 1.6e-2 with 16-bit operands upstream: bounded at 2.5e-2.
+  # Every leaf - the SE(3) head leaves included, which round 2 had to bound at 2.5e-2 - meets one bound: 6e-3 for the rgb loss
+  # (measured 4.0e-3 worst, warp_field/trunk/hidden_5/bias), L2_TOL_2ND with the full objective (measured 5.8e-3).
   tol = L2_TOL_2ND['mfma'] if full else 6e-3
   for name, e in errs.items():
-    assert e < (2.5e-2 if name.startswith('warp_field/branches_') else tol), (name, e)
+    assert e < tol, (name, e)
+
+
+@pytest.mark.gpu
+def test_fused_backward_chain_against_numpy_on_the_step_buffers():
+  """Kernel-level pin of the fused backward (render_kernel.hip train_backward_kernel) on the buffers of one step, read back through
+  nerfds_trainer_debug_read: the forward's ReLU bits equal (f16 activation > 0) bit for bit; the first two links of the NerfMLP
+  chain - g_rgb = 1[h_rgb > 0] (d rgb_logit W_rgb^T) and g_7 = 1[h_7 > 0] (g_rgb F^T + d alpha W_alpha^T), F = the bottleneck folded
+  into rgb hidden_0 - and the input gradient d_trunk_in = g_0 W_0^T + g_4 W_4[raw-input rows]^T equal a float64 numpy evaluation of
+  the same expressions on the same inputs to split-bf16 accuracy."""
+  from nerfds_amd.training import Trainer
+  R, Nc = 37, 8                                          # 296 rows: three 128-row workgroup iterations, a ragged tail
+  cfg, params, batch, t, u = _problem(R, Nc, 0)
+  tr = Trainer(cfg, params, max_rays=R)
+  tr.step(batch, EX, 0.0, t_rand=t, mask_ratio=1.0, grads_only=True)
+  M = R * Nc
+
+  def bits_to_mask(bits, W):                             # u16 at [(row * 2 + half) * (W / 32) + tile], bit r <-> accumulator register r
+    b = bits.reshape(M, 2, W // 32)
+    m = np.zeros((M, W), bool)
+    for tl in range(W // 32):
+      for h in range(2):
+        for r in range(16):
+          m[:, 32 * tl + (r & 3) + 8 * (r >> 2) + 4 * h] = (b[:, h, tl] >> r) & 1
+    return m
+  P = params['nerf_mlps_coarse']
+  h_rgb = tr.debug_read('rgb_h16', (M, 128), np.float16).astype(np.float64)
+  assert np.array_equal(bits_to_mask(tr.debug_read('rgb_bits', (M * 2 * 4,), np.uint16), 128), h_rgb > 0)
+  h7 = tr.debug_read('trunk_h16_7', (M, 256), np.float16).astype(np.float64)
+  assert np.array_equal(bits_to_mask(tr.debug_read('trunk_bits_7', (M * 2 * 8,), np.uint16), 256), h7 > 0)
+  d_rgb = tr.debug_read('d_rgb_logit', (M, 3)).astype(np.float64)
+  d_alpha = tr.debug_read('d_alpha', (M, 4)).astype(np.float64)
+  Wr = np.asarray(P['rgb_mlp']['logit']['kernel'], np.float64)
+  want_rgb = (d_rgb @ Wr.T) * (h_rgb > 0)
+  got_rgb = tr.debug_read('rgb_g', (M, 128))
+  assert np.abs(got_rgb - want_rgb).max() <= 1e-4 * np.abs(want_rgb).max()
+  K = np.asarray(P['rgb_mlp']['hidden_0']['kernel'], np.float64)      # rows [bottleneck 256 | viewdir 24 | trunk_out 256 | normal 24]
+  F = np.asarray(P['bottleneck']['kernel'], np.float64) @ K[:256] + K[280:536]
+  Wa = np.asarray(P['alpha_mlp']['logit']['kernel'], np.float64)
+  want7 = (want_rgb @ F.T + d_alpha @ Wa.T) * (h7 > 0)
+  got7 = tr.debug_read('trunk_g_7', (M, 256))
+  assert np.abs(got7 - want7).max() <= 1e-4 * np.abs(want7).max()
+  # the input gradient of a chain: d_trunk_in = g_0 W_0^T + g_4 W_4[256:]^T
+  g0, g4 = tr.debug_read('trunk_g_0', (M, 256)).astype(np.float64), tr.debug_read('trunk_g_4', (M, 256)).astype(np.float64)
+  W0 = np.asarray(P['trunk_mlp']['hidden_0']['kernel'], np.float64)
+  W4 = np.asarray(P['trunk_mlp']['hidden_4']['kernel'], np.float64)
+  want_in = g0 @ W0.T + g4 @ W4[256:].T
+  got_in = tr.debug_read('d_trunk_in', (M, 52))
+  assert np.abs(got_in - want_in).max() <= 1e-4 * np.abs(want_in).max()
