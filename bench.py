@@ -348,7 +348,7 @@ def main():
     cfg = static_config(num_coarse_samples=nc)
   else:
     cfg = (nerf_ds_config if args.graph == 'nerf_ds' else hypernerf_config)(near=0.3, far=1.7, num_warp_embeds=256, num_coarse_samples=nc, num_fine_samples=nf)
-  flop_per_ray = (2 * nc + nf) * FLOP_PER_SAMPLE[args.graph]        # nc coarse + (nc + nf) fine field evaluations per ray
+  flop_per_ray = (nc + ((nc + nf) if nf else 0)) * FLOP_PER_SAMPLE[args.graph]        # nc coarse + (nc + nf) fine field evaluations per ray
   exec_per_ray = executed_flop_per_ray(args.graph, nc, nf)
   params = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)   # random-init weights
   model = NerfModel(cfg, device=device, precision=args.precision)
@@ -430,8 +430,8 @@ def main():
     return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (ach / peak) if ach else None,
             'traffic': None, 'traffic_source': None, 'kernel': kernel_name % prec, 'avg_launch_ms': launch_s * 1e3, 'launches': n_launch,
             'algorithmic_flop_per_launch': rays_per_launch * flop_per_ray,
-            'executed_mfma_flop_per_launch': (rays_per_launch * exec_per_ray * mult) if prec in ('bf16', 'f16', 'bf16x3') else None,
-            'executed_frac': (exe / 2500.0) if (exe and prec in ('bf16', 'f16', 'bf16x3')) else None}
+            'executed_mfma_flop_per_launch': (rays_per_launch * exec_per_ray * mult) if prec != 'mixed' else None,
+            'executed_frac': (exe / (157.3 if prec == 'f32' else 2500.0)) if (exe and prec != 'mixed') else None}
 
   if args.sweep:
     return run_sweep(args, world, rank, device, live, cfg, chunks, timed, flop_per_ray, exec_per_ray, kernel_name)

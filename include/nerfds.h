@@ -46,8 +46,10 @@ extern "C" {
 #define NERFDS_PREC_BF16X3  1u  /* split-bf16 (hi+lo) x3 MFMA: ~fp32 accuracy at 1/3 of the bf16 MFMA rate   */
 #define NERFDS_PREC_F32     2u  /* fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fp32 fma chains, parity gate    */
 #define NERFDS_PREC_F16     3u  /* f16 x f16 -> fp32 MFMA (v_mfma_f32_32x32x16_f16): bf16 rate, 3 more significand bits */
-#define NERFDS_PREC_MIXED   4u  /* per-network plan (csrc/graphs.h plan_of): error-amplifying networks in split bf16,
-                                   the bulk of the FLOPs in one f16 MFMA per product - the fast parity-grade path */
+#define NERFDS_PREC_MIXED   4u  /* per-network plan (csrc/graphs.h plan_of): the warp field in split bf16, the bulk of the
+                                   FLOPs in one f16 MFMA per product.  Does NOT meet the 1e-4 tolerance: measured 4.6e-4 on the
+                                   bench sample, bounded at 2e-3 in tests (profiles/r3_precision_budget.md: no plan with a
+                                   one-MFMA network meets it; only BF16X3 and F32 do) */
 #define NERFDS_PREC_COUNT   5u
 #define NERFDS_PREC_MASK    7u
 /* Other flags. */
