@@ -1000,22 +1000,54 @@ DEVI void normalize3(float (&v)[3]) {   // model_utils.py:438-442
   v[0] *= inv; v[1] *= inv; v[2] *= inv;
 }
 
-// wave-wide helpers (64 lanes)
+// wave-wide helpers (64 lanes) on DPP: no LDS round trip (the __shfl forms compile to ds_bpermute_b32, ~300 of them per kernel -
+// the per-ray phases run on one wave per SIMD while the matrix pipes idle, so their latency is all exposed).
+// update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes whose row is masked out or whose source lane does not exist keep `old`.
+template <int CTRL, int ROW_MASK = 0xf> DEVI float dpp_f(float old, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+#else
+  return old + 0.f * v;
+#endif
+}
+enum { DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140, DPP_ROW_BCAST15 = 0x142,
+       DPP_ROW_BCAST31 = 0x143, DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118, DPP_WAVE_SHR1 = 0x138 };
+DEVI float lane63(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#else
+  return v;
+#endif
+}
 DEVI float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += dpp_f<DPP_QUAD_1032>(0.f, v);
+  v += dpp_f<DPP_QUAD_2301>(0.f, v);
+  v += dpp_f<DPP_ROW_HALF_MIRROR>(0.f, v);
+  v += dpp_f<DPP_ROW_MIRROR>(0.f, v);                       // every lane: the sum of its row of 16
+  v += dpp_f<DPP_ROW_BCAST15, 0xA>(0.f, v);                 // rows 1, 3 += rows 0, 2
+  v += dpp_f<DPP_ROW_BCAST31, 0xC>(0.f, v);                 // rows 2, 3 += rows 0 + 1
+  return lane63(v);
+}
+DEVI float wave_scan_add(float v, int) {     // inclusive
+  v += dpp_f<DPP_ROW_SHR1>(0.f, v);
+  v += dpp_f<DPP_ROW_SHR2>(0.f, v);
+  v += dpp_f<DPP_ROW_SHR4>(0.f, v);
+  v += dpp_f<DPP_ROW_SHR8>(0.f, v);                         // inclusive within each row of 16
+  v += dpp_f<DPP_ROW_BCAST15, 0xA>(0.f, v);
+  v += dpp_f<DPP_ROW_BCAST31, 0xC>(0.f, v);
   return v;
 }
-DEVI float wave_scan_add(float v, int lane) {     // inclusive
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+DEVI float wave_scan_mul(float v, int) {     // inclusive
+  v *= dpp_f<DPP_ROW_SHR1>(1.f, v);
+  v *= dpp_f<DPP_ROW_SHR2>(1.f, v);
+  v *= dpp_f<DPP_ROW_SHR4>(1.f, v);
+  v *= dpp_f<DPP_ROW_SHR8>(1.f, v);
+  v *= dpp_f<DPP_ROW_BCAST15, 0xA>(1.f, v);
+  v *= dpp_f<DPP_ROW_BCAST31, 0xC>(1.f, v);
   return v;
 }
-DEVI float wave_scan_mul(float v, int lane) {     // inclusive
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(v, o, 64); if (lane >= o) v *= t; }
-  return v;
-}
+// value of the lane below (lane 0: `first`)
+DEVI float wave_shift_up1(float v, float first) { return dpp_f<DPP_WAVE_SHR1>(first, v); }
 
 // ------------------------------------------------------------------------------------------------
 // Input encodings -> B operands.  A feature descriptor says how to produce linear feature f for one sample.
@@ -1472,14 +1504,13 @@ DEVI void composite(const KArgs& ka, const RayConst& rc, int ray, int lane, int 
     float alpha = valid ? (1.0f - expf(-sigma * dist)) : 0.0f;             // model_utils.py:129
     float om = valid ? ((1.0f - alpha) + 1e-10f) : 1.0f;                   // model_utils.py:133
     float incl = wave_scan_mul(om, lane);
-    float excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 1.0f;
+    const float excl = wave_shift_up1(incl, 1.0f);
     const float T = carryT * excl;                                         // exclusive cumprod
-    carryT *= __shfl(incl, 63, 64);
+    carryT *= lane63(incl);
     const float w = alpha * T;                                             // model_utils.py:135
     if (valid) L.ws[s] = w;
     float cum = wave_scan_add(w, lane) + carryC;
-    carryC = __shfl(cum, 63, 64);
+    carryC = lane63(cum);
     unsigned long long hit = __ballot(valid && cum >= 0.5f);               // model_utils.py:285-291
     if (med_idx < 0 && hit) med_idx = 64 * j + __builtin_ctzll(hit);
     float xo[3];
@@ -1555,7 +1586,7 @@ template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int n
     int i = lane + 64 * j;
     float pdf = (i < nw) ? (L.ws[i + 1] + 1e-5f) / tot : 0.f;
     float c = wave_scan_add(pdf, lane) + carry;
-    carry = __shfl(c, 63, 64);
+    carry = lane63(c);
     if (i < nw) L.cdf[i + 1] = c;
   }
   for (int j = 0; j * 64 < nb; ++j) {
@@ -1613,19 +1644,32 @@ template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int n
   constexpr int NJ = MAX_SAMPLES / 64, NSTATE = 1 + (SV_COUNT - SV_WP);
   int rk[NJ];
   float st[NJ][NSTATE];
+  {
+    // rank of union element i = #{q : z_q < z_i or (z_q == z_i and q < i)}.  One pass over the union for ALL of the lane's elements,
+    // four values per (broadcast) LDS read and four reads in flight: as one dependent 4-byte read per comparison this loop was the
+    // largest single piece of the per-ray phases (~20 k of their ~34 k cycles per ray group).
+    float v[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int i = lane + 64 * j;
+      v[j] = L.zn[i < n ? i : n - 1];
+      rk[j] = 0;
+    }
+    auto count = [&](float o, int q) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) rk[j] += (o < v[j] || (o == v[j] && q < lane + 64 * j)) ? 1 : 0;
+    };
+    const int n4 = n & ~3;
+#pragma unroll 4
+    for (int q = 0; q < n4; q += 4) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(&L.zn[q]);
+      count(o[0], q); count(o[1], q + 1); count(o[2], q + 2); count(o[3], q + 3);
+    }
+    for (int q = n4; q < n; ++q) count(L.zn[q], q);
+  }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int i = lane + 64 * j;
-    rk[j] = 0;
-    if (i < n) {
-      const float v = L.zn[i];
-      int rank = 0;
-      for (int q = 0; q < n; ++q) {
-        const float o = L.zn[q];
-        rank += (o < v || (o == v && q < i)) ? 1 : 0;
-      }
-      rk[j] = rank;
-    }
     const int ic = i < nc ? i : nc - 1;
     st[j][0] = L.sv[SV_MASK][ic];
 #pragma unroll

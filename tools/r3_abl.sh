@@ -2,8 +2,8 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r3s1
 A=nerf-ds_amd/nerfds_amd/_lib/abl
 {
-python tools/dump_render.py /tmp/main.npz 2051 bf16x3 2>&1 | tail -1
-for v in xi8 xi4 xr8; do NERFDS_LIB=$A/libnerfds_hip_$v.so python tools/dump_render.py /tmp/$v.npz 2051 bf16x3 2>&1 | tail -1; echo "cmp $v"; python tools/cmp_npz.py /tmp/$v.npz /tmp/main.npz | tail -3; done
-python tools/ab.py bf16x3 3 main $A/libnerfds_hip_xi8.so $A/libnerfds_hip_xi4.so $A/libnerfds_hip_xr8.so
-} > gpurun_out/r3s1/ablate4.log 2>&1
-cat gpurun_out/r3s1/ablate4.log
+NERFDS_LIB=$PWD/$A/libnerfds_hip_rk.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_camera.py tests/test_render_image_gpu.py -q -m gpu -k "not rccl and not nccl and not two_ranks" 2>&1 | tail -3
+python tools/ab.py bf16 3 main $A/libnerfds_hip_dpp.so $A/libnerfds_hip_rk.so
+python tools/ab.py bf16x3 2 main $A/libnerfds_hip_rkx.so
+} > gpurun_out/r3s1/ablate6.log 2>&1
+cat gpurun_out/r3s1/ablate6.log
