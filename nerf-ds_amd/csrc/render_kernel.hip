@@ -1070,10 +1070,30 @@ DEVI FeatV zero_feat() { FeatV f; f.kind = 0; f.arg = 0.f; f.win = 0.f; f.val = 
 
 // sin for the network-input encodings.  One-unit operands (bf16 / f16) round every feature to 8 / 11 significand bits
 // anyway, so they use the hardware v_sin_f32 (argument in revolutions, abs error ~1e-6); the others use sin_cw.
+// Split-bf16 operands (16 significand bits, 7.6e-6) sit in between: the hardware sine is accurate enough IF the argument reaches it
+// reduced exactly - a * (1 / 2 pi) in two floats (product + fma residual + low word), fract of the exact high part, the residual
+// added after: 7 issue slots where the 3-term Cody-Waite sin_cw takes 22.  With one wave per SIMD (the 512-register kernels)
+// nothing hides the encodings: they were ~9 % of the split-bf16 kernel (80 MFMA-free blocks of 60+ instructions in its ISA).
+// NERFDS_X3_HW_SIN=0 keeps sin_cw (A/B).
+#ifndef NERFDS_X3_HW_SIN
+#if defined(NERFDS_TRAIN_FWD) || defined(NERFDS_TRAIN_BWD)
+#define NERFDS_X3_HW_SIN 0        // the trainer's forward stays on sin_cw (its gradient tests compare with the fp64 oracle at 1e-3-grade bounds)
+#else
+#define NERFDS_X3_HW_SIN 1
+#endif
+#endif
+DEVI float sin_hw_exact(float a) {
+  const float p = a * 0.15915494f;                                        // 1 / (2 pi) = 0.15915494 + 6.4206382e-09
+  float e = fmaf(a, 0.15915494f, -p);
+  e = fmaf(a, 6.4206382e-09f, e);
+  return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(p) + e);
+}
 template <int P> DEVI float sin_enc(float a) {
   if (NERFDS_ABLATE & 8) return a;
   if constexpr (is_single(P)) {
     return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(a * 0.159154943f));
+  } else if constexpr (NERFDS_X3_HW_SIN && P == P_BF16X3) {
+    return sin_hw_exact(a);
   } else {
     return sin_cw(a);
   }
