@@ -84,6 +84,12 @@ struct nerfds_trainer {
   // Gradient replicas: the MFMA kernels end with float atomics from every workgroup at once; on one copy of a small leaf they queue
   // up per address (40-60 us per kernel).  Workgroup b adds into replica b % GRAD_REPS; the replicas are summed into grad once per step.
   float* grad_rep = nullptr;
+  // Side streams of the fused backward: a weight-gradient launch ends with ~50 us of float atomics during which HBM idles (one workgroup
+  // per CU, 256 K adds each); the launches of a level are independent of each other, so they alternate over the caller's stream and
+  // these two - the tail of one runs under the streaming phase of the next.  Forked / joined with events inside every level.
+  static constexpr int SIDE = 2;
+  hipStream_t side[SIDE] = {nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr, join_ev[SIDE] = {nullptr, nullptr};
   // Fragment packs of the layers (train_gemm.h): the first step packs each (weight block, orientation, split) when it is first used and
   // records it; from then on ONE kernel at the start of a step packs them all into the arena (150 small launches less per step).
   std::vector<PackEntry> packs;
@@ -141,6 +147,8 @@ struct nerfds_trainer {
     for (float* p : {theta, grad, m1, m2, ws, loss_dev, tws, terms_dev, nws}) if (p) (void)hipFree(p);
     if (wpack) (void)hipFree(wpack);
     if (grad_rep) (void)hipFree(grad_rep);
+    for (int i = 0; i < SIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (join_ev[i]) (void)hipEventDestroy(join_ev[i]); }
+    if (fork_ev) (void)hipEventDestroy(fork_ev);
     if (arena) (void)hipFree(arena);
     if (packs_dev) (void)hipFree(packs_dev);
     for (int i = 0; i < 3; ++i) {
@@ -261,7 +269,28 @@ struct Run {
     WgradArgs A{X, ldx, K, dy, ldy, N, M, nullptr, rep(dW), static_cast<const char*>(t.wpack) + WPACK_BYTES, 0, 0, t.P, nrep()};
     A.x_half = x_half ? 1 : 0;
     A.colsum = rep(bias_grad);
-    if (!(wgrad_supported(A) && wgrad(st, A, wgrad_grid(A, t.num_cus)))) unsupported("weight gradient", K, N, M);
+    if (!(wgrad_supported(A) && wgrad(wgrad_stream(), A, wgrad_grid(A, t.num_cus)))) unsupported("weight gradient", K, N, M);
+  }
+  // fork(): the side streams wait for everything issued to st so far, and the weight-gradient launches that follow rotate over
+  // st and the side streams; join(): st waits for the side streams.  Without side streams both are no-ops.
+  int wg_turn = -1;
+  bool wg_main = true;     // the caller's stream takes a turn too (false while it still has chains to launch)
+  hipStream_t wgrad_stream() {
+    if (wg_turn < 0) return st;
+    const int k = wg_turn++ % (nerfds_trainer::SIDE + (wg_main ? 1 : 0));
+    return wg_main ? (k == 0 ? st : t.side[k - 1]) : t.side[k];
+  }
+  void fork(bool with_main = true) {
+    if (!t.side[0]) return;
+    (void)hipEventRecord(t.fork_ev, st);
+    for (int i = 0; i < nerfds_trainer::SIDE; ++i) (void)hipStreamWaitEvent(t.side[i], t.fork_ev, 0);
+    if (wg_turn < 0) wg_turn = 0;
+    wg_main = with_main;
+  }
+  void join() {
+    if (wg_turn < 0) return;
+    for (int i = 0; i < nerfds_trainer::SIDE; ++i) { (void)hipEventRecord(t.join_ev[i], t.side[i]); (void)hipStreamWaitEvent(st, t.join_ev[i], 0); }
+    wg_turn = -1;
   }
   // Weight and bias gradients of an MLP whose data-gradient chain has run (fused backward): g[l] = d loss / d pre-activation of
   // layer l (fp32 [M x width]), h16[l] = its f16 output.  One launch per input segment; the bias gradient rides on the first.
@@ -766,30 +795,46 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
     // Fused backward: ONE launch per network walks its data-gradient chain and leaves g_l of every hidden layer (in the fp32
     // activation arrays, unused in this mode) and the gradient of the raw input; one weight-gradient launch per layer segment then
     // reads X (f16) and g_l once.  Between the chains: the element-wise backward of the encodings, exp_se3 and the mask blend.
+    // Each network's weight gradients are forked off as soon as its chain has run (env NERFDS_TRAIN_EARLY_FORK=0: all after the last chain).
+    static const bool early = !(getenv("NERFDS_TRAIN_EARLY_FORK") && std::string(getenv("NERFDS_TRAIN_EARLY_FORK")) == "0");
+    const LayerP& K = t.rgb_h[level];
+    auto wg_nerf = [&] {   // rgb branch: heads on rgb hidden / trunk_out, rgb hidden_0 = [bottleneck | viewdir | trunk_out | normal] rows
+      r.head_wgrads(t.rgb_out[level], t.rgb_h16, RW, t.d_rgb_logit, 3);
+      r.head_wgrads(t.alpha[level], t.trunk_h16.back(), TW, t.d_alpha, 4);
+      r.weight_grad(reinterpret_cast<const float*>(t.trunk_h16.back()), TW, TW, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(TW + VD) * RW, -1, true, t.grad + K.b);   // S
+      r.weight_grad(t.cond, CW, VD, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)TW * RW);
+      r.weight_grad(t.cond + VD, CW, NM, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(2 * TW + VD) * RW);
+      r.mlp_wgrads(trunk, t.trunk_in, t.trunk_h16, t.trunk_h);
+    };
+    auto wg_hyper = [&] {
+      r.head_wgrads(t.hyper_out, t.hyper_h16.back(), t.hyper.width, t.dwamb, 2);
+      r.mlp_wgrads(t.hyper, t.hyper_in, t.hyper_h16, t.hyper_h);
+    };
+    auto wg_warp = [&] {
+      r.head_wgrads(t.warp_w, t.warp_h16.back(), t.warp.width, t.dwv, 6);
+      r.head_wgrads(t.warp_v, t.warp_h16.back(), t.warp.width, t.dwv + 3, 6);
+      r.mlp_wgrads(t.warp, t.warp_in, t.warp_h16, t.warp_h);
+    };
+    auto wg_mask = [&] {
+      r.head_wgrads(t.mask_out, t.mask_h16.back(), t.mask.width, t.d_mask_logit, 1);
+      r.mlp_wgrads(t.mask, t.mask_in, t.mask_h16, t.mask_h);
+    };
     fused_backward(t, st, 0, level, M, t.d_rgb_logit, 3, t.d_alpha, t.d_trunk_in, D.trunk_in);
+    if (early) { r.fork(false); wg_nerf(); }
     trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, nullptr, t.dxw, t.dwamb);
     fused_backward(t, st, 1, level, M, t.dwamb, 2, nullptr, t.d_hyper_in, D.hyper_ld);
+    if (early) { r.fork(false); wg_hyper(); }
     se3_bwd(st, M, t.wv, t.x, t.dxw, nullptr, t.dwv);
     fused_backward(t, st, 2, level, M, t.dwv, 6, nullptr, t.d_warp_in, D.warp_ld);
+    if (early) { r.fork(false); wg_warp(); }
     shared_in_bwd(st, D, R, S, t.d_warp_in, t.d_hyper_in, t.mask_logit, ex->mask_ratio, ob ? t.d_pm : nullptr, rays->warp_id, t.cfg.num_warp_embeds,
                   t.grad + t.warp_tbl, t.d_mask_logit);
     fused_backward(t, st, 3, level, M, t.d_mask_logit, 1, nullptr, t.d_mask_in, D.mask_in);
     mask_in_bwd(st, D, R, S, t.d_mask_in, rays->warp_id, t.cfg.num_warp_embeds, t.grad + t.mask_tbl);
-    // weight gradients.  rgb branch: heads on rgb hidden / trunk_out, rgb hidden_0 = [bottleneck | viewdir | trunk_out | normal] rows
-    const LayerP& K = t.rgb_h[level];
-    r.head_wgrads(t.rgb_out[level], t.rgb_h16, RW, t.d_rgb_logit, 3);
-    r.head_wgrads(t.alpha[level], t.trunk_h16.back(), TW, t.d_alpha, 4);
-    r.weight_grad(reinterpret_cast<const float*>(t.trunk_h16.back()), TW, TW, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(TW + VD) * RW, -1, true, t.grad + K.b);   // S
-    r.weight_grad(t.cond, CW, VD, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)TW * RW);
-    r.weight_grad(t.cond + VD, CW, NM, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(2 * TW + VD) * RW);
-    r.mlp_wgrads(trunk, t.trunk_in, t.trunk_h16, t.trunk_h);
-    r.head_wgrads(t.hyper_out, t.hyper_h16.back(), t.hyper.width, t.dwamb, 2);
-    r.mlp_wgrads(t.hyper, t.hyper_in, t.hyper_h16, t.hyper_h);
-    r.head_wgrads(t.warp_w, t.warp_h16.back(), t.warp.width, t.dwv, 6);
-    r.head_wgrads(t.warp_v, t.warp_h16.back(), t.warp.width, t.dwv + 3, 6);
-    r.mlp_wgrads(t.warp, t.warp_in, t.warp_h16, t.warp_h);
-    r.head_wgrads(t.mask_out, t.mask_h16.back(), t.mask.width, t.d_mask_logit, 1);
-    r.mlp_wgrads(t.mask, t.mask_in, t.mask_h16, t.mask_h);
+    r.fork(true);
+    if (!early) { wg_nerf(); wg_hyper(); wg_warp(); }
+    wg_mask();
+    r.join();
     if (!r.ok) return t.fail(NERFDS_ENOTSUP, "%s", r.unsupported_what.c_str());
     return NERFDS_OK;
   }
@@ -902,6 +947,13 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
     t->fused_bwd = t->fused_fwd && !(fbw && std::string(fbw) == "0") && build_fused_backward(*t);
     if (hipMalloc(&t->arena, ARENA_BYTES) != hipSuccess) { g_train_error = "hipMalloc failed (fragment arena)"; return NERFDS_ENOMEM; }
     if (hipMalloc(&t->grad_rep, (size_t)GRAD_REPS * t->P * sizeof(float)) != hipSuccess) { g_train_error = "hipMalloc failed (gradient replicas)"; return NERFDS_ENOMEM; }
+    const char* ss = getenv("NERFDS_TRAIN_SIDE_STREAMS");
+    if (t->fused_bwd && !(ss && std::string(ss) == "0")) {
+      bool ok = hipEventCreateWithFlags(&t->fork_ev, hipEventDisableTiming) == hipSuccess;
+      for (int i = 0; i < nerfds_trainer::SIDE && ok; ++i)
+        ok = hipStreamCreateWithFlags(&t->side[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&t->join_ev[i], hipEventDisableTiming) == hipSuccess;
+      if (!ok) { g_train_error = "hipStreamCreate failed (weight-gradient side streams)"; return NERFDS_EDEVICE; }
+    }
     if (hipMalloc(&t->wpack, WPACK_BYTES + 256) != hipSuccess || hipMemset(t->wpack, 0, WPACK_BYTES + 256) != hipSuccess) { g_train_error = "hipMalloc failed (weight fragments)"; return NERFDS_ENOMEM; }
   }
   *out = t.release();

@@ -485,20 +485,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_dma(const DenseArgs A) {
 // Each workgroup ends with a full K x N partial sum, written to part[blockIdx]; the caller adds the partials.
 // FULL: every one of the 8 IPW DMA instructions of a tile carries data (256 x 256: 32 instructions), so the stage needs no spare KiB for
 // idle ones - and then a fourth stage fits the 160 KiB next to the images (3 tiles = 96 KiB in flight per CU instead of 2).
-template <int IPW, bool FULL = false> struct WgShape {
+template <int TPW, int IPW, bool FULL = false> struct WgShape {
   static constexpr int STAGE_BYTES = IPW * 8 * 1024 + (FULL ? 0 : 1024);   // 8 waves x IPW DMA instructions x 1 KiB (+ a spare KiB for idle instructions)
-  static constexpr int IMG_BYTES = 16 * 2048;                 // up to 8 + 8 fragments of hi | lo
-  static constexpr int NS_FIT = (163840 - IMG_BYTES) / STAGE_BYTES;
+  // fragments of hi | lo in one image: KT + NT with KT NT <= 8 TPW and both <= 8
+  static constexpr int IMG_FRAGS = TPW == 1 ? 9 : TPW == 2 ? 10 : TPW == 4 ? 12 : 16;
+  static constexpr int IMG_BYTES = IMG_FRAGS * 2048;
+  static constexpr int NS_FIT = (163840 - 2 * IMG_BYTES) / STAGE_BYTES;    // two images: tile t + 1 is converted while tile t is multiplied
   static constexpr int NS = NS_FIT > 4 ? 4 : NS_FIT;
-  static_assert(NS >= 3 && (NS - 2) * IPW < 64, "ring depth");
-  static constexpr int LDS = NS * STAGE_BYTES + IMG_BYTES;
+  static_assert(NS >= 2 && (NS - 1) * IPW < 64, "ring depth");
+  static constexpr int LDS = NS * STAGE_BYTES + 2 * IMG_BYTES;
 };
 
 // ROW: the TPW output tiles of a wave lie in one row of tiles (N/32 is a multiple of TPW), so its X^T fragment is read once per
 // sample tile instead of once per output tile (a compile-time fact: as a run-time branch the two loop bodies cost 4x in spills).
 template <int TPW, int IPW, bool ROW, bool FULL>
 __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
-  typedef WgShape<IPW, FULL> S;
+  typedef WgShape<TPW, IPW, FULL> S;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int K = A.k, N = A.n, KQ = K >> 2, NQ = N >> 2;
   const int KT = (K + 31) >> 5, NT = (N + 31) >> 5, TT = KT * NT;
@@ -550,7 +552,9 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
       src[u] += step[u];
     }
   };
-  // conversion items of this thread: (feature f, sample octet o) of X (idx < 2 K) or dY; 2 (K + N) <= 1024 items
+  // conversion items of this thread: (feature f, sample octet o) of X (idx < 2 K) or dY; 2 (K + N) <= 1024 items.
+  // f16 X: the item's 8 samples come by two ds_read_b64_tr_b16 (a 16-lane group reads a [4 samples][16 features] block of the row-major
+  // stage, lane i supplies the 8-byte piece (row i / 4, features 4 (i % 4) ..) and receives column i) instead of 8 two-byte reads.
   int c_src[2], c_dst[2], c_stride[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -559,6 +563,7 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
     if (idx < 2 * K) {
       const int o = idx / K, f = idx - o * K, esz = XH ? 2 : 4;
       c_src[j] = (8 * o * K + f) * esz; c_stride[j] = K * esz;
+      if (XH) { const int i = lane & 15; c_src[j] = ((8 * o + (i >> 2)) * K + (f - i) + 4 * (i & 3)) * 2; }
       c_dst[j] = (f >> 5) * 2048 + ((o << 5) | (f & 31)) * 16;
     } else if (idx < 2 * (K + N)) {
       const int i2 = idx - 2 * K, o = i2 / N, f = i2 - o * N;
@@ -569,27 +574,23 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
   f32x16 acc[TPW];
 #pragma unroll
   for (int j = 0; j < TPW; ++j) acc[j] = f32x16{};
-  char* img = g_tile + S::NS * S::STAGE_BYTES;
+  char* img0 = g_tile + S::NS * S::STAGE_BYTES;
   float cs[2] = {0.f, 0.f};            // column sums of this thread's dY items (feature f, sample octet o) over the workgroup's tiles
 
-  long long tile = blockIdx.x;
-#pragma unroll
-  for (int s = 0; s < S::NS - 1; ++s) issue(tile + (long long)s * grid, s);
-  int it = 0;
-  for (; tile < tiles; tile += grid, ++it) {
-    wait_vm_lgkm0<(S::NS - 2) * IPW>();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    issue(tile + (long long)(S::NS - 1) * grid, (it + S::NS - 1) % S::NS);
-    __builtin_amdgcn_sched_barrier(0);
-    const char* stg = g_tile + (it % S::NS) * S::STAGE_BYTES;
+  // stage -> image: bf16 hi / lo fragment images of one 16-sample tile
+  auto convert = [&](const char* stg, char* img) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (c_src[j] >= 0) {
         float f[8];
         if (XH && threadIdx.x + 512 * j < 2 * K) {       // f16 item of X (whole waves take one side: 2 K is a multiple of 64 on this path)
+          // (inline asm: behind the builtin hipcc orders the read after EVERY outstanding LDS-DMA - s_waitcnt vmcnt(0) - and the ring is gone)
+          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+          h4 q0, q1;
+          const unsigned a0 = (unsigned)(size_t)(stg + c_src[j]), a1 = a0 + 4 * c_stride[j];
+          asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(q0), "=&v"(q1) : "v"(a0), "v"(a1) : "memory");
 #pragma unroll
-          for (int i = 0; i < 8; ++i) f[i] = (float)*reinterpret_cast<const _Float16*>(stg + c_src[j] + i * c_stride[j]);
+          for (int i = 0; i < 4; ++i) { f[i] = (float)q0[i]; f[4 + i] = (float)q1[i]; }
         } else {
 #pragma unroll
           for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const float*>(stg + c_src[j] + i * c_stride[j]);
@@ -606,29 +607,60 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
         *reinterpret_cast<u32x4*>(img + c_dst[j] + 1024) = __builtin_bit_cast(u32x4, xl);
       }
     }
-    wait_vm_lgkm0<63>();
+  };
+
+  // Software pipeline, ONE barrier per tile: iteration t converts tile t + 1 into the other image while it multiplies tile t, so the
+  // conversion (LDS reads, ~40 VALU, LDS writes per item) sits under the MFMAs of the same and of the SIMD's other wave instead of between
+  // two barriers of its own.  After the barrier of iteration t: every wave's DMA of tile t + 1 has landed, tile t is converted (its stage
+  // is free: tile t + NS goes there), and nobody reads the image of tile t - 1 any more.
+  long long tile = blockIdx.x;
+#pragma unroll
+  for (int s = 0; s < S::NS; ++s) issue(tile + (long long)s * grid, s);
+  wait_vm_lgkm0<(S::NS - 1) * IPW>();
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  convert(g_tile, img0);
+  int it = 0, st = 0;                  // st = it % NS
+  for (; tile < tiles; tile += grid, ++it) {
+    wait_vm_lgkm0<(S::NS - 2) * IPW>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 ah, al;
+    issue(tile + (long long)S::NS * grid, st);
+    __builtin_amdgcn_sched_barrier(0);
+    st = st + 1 == S::NS ? 0 : st + 1;
+    const char* img = img0 + (it & 1) * S::IMG_BYTES;
+    auto frag = [&](int f, int lo) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + f * 2048 + lo * 1024 + lane * 16)); };
     if constexpr (ROW) {
-      const int kt = (wave * TPW) / NT;
-      ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + kt * 2048 + lane * 16));
-      al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + kt * 2048 + 1024 + lane * 16));
-    }
+      // all TPW tiles of the wave share kt and exist together (NT is a multiple of TPW): one uniform test, then a branch-free body whose
+      // fragment reads the scheduler can batch ahead of the MFMAs (a test per tile left every read directly in front of its MFMA)
+      const int t0 = wave * TPW, kt = t0 / NT, nt0 = t0 - kt * NT;
+      bf16x8 ah, al, bh[TPW], bl[TPW];
+      if (t0 < TT) {
+        ah = frag(kt, 0); al = frag(kt, 1);
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-      const int t = wave * TPW + j;
-      if (t < TT) {
-        const int kt = t / NT, nt = t - kt * NT;
-        if constexpr (!ROW) {
-          ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + kt * 2048 + lane * 16));
-          al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + kt * 2048 + 1024 + lane * 16));
+        for (int j = 0; j < TPW; ++j) { bh[j] = frag(KT + nt0 + j, 0); bl[j] = frag(KT + nt0 + j, 1); }
+      }
+      convert(g_tile + st * S::STAGE_BYTES, img0 + ((it + 1) & 1) * S::IMG_BYTES);
+      if (t0 < TT) {
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
         }
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + (KT + nt) * 2048 + lane * 16));
-        const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + (KT + nt) * 2048 + 1024 + lane * 16));
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+      }
+    } else {
+      convert(g_tile + st * S::STAGE_BYTES, img0 + ((it + 1) & 1) * S::IMG_BYTES);
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int t = wave * TPW + j;
+        if (t < TT) {
+          const int kt = t / NT, nt = t - kt * NT;
+          const bf16x8 ah = frag(kt, 0), al = frag(kt, 1), bh = frag(KT + nt, 0), bl = frag(KT + nt, 1);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+        }
       }
     }
   }
@@ -982,7 +1014,7 @@ int wgrad_grid(const WgradArgs& A, int num_cus) {
 }
 template <int TPW, int IPW, bool ROW, bool FULL = false> static void launch_wgrad(hipStream_t st, const WgradArgs& A, int grid) {
   auto kern = k_wgrad<TPW, IPW, ROW, FULL>;
-  typedef WgShape<IPW, FULL> S;
+  typedef WgShape<TPW, IPW, FULL> S;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS); attr = true; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), S::LDS, st, A);
@@ -996,8 +1028,12 @@ bool wgrad(hipStream_t st, const WgradArgs& A0, int grid) {
   const int tpw = (TT + 7) / 8;                                     // 1 .. 8 output tiles per wave
   const int ipw = (ninstr + 7) / 8;                                 // DMA instructions per wave and 16-sample tile: 1 .. 4
   const int NT = (A.n + 31) / 32;
-  if (tpw == 8 && ipw == 4 && ninstr == 32) {                       // 256 x 256: no idle DMA instruction, four stages
+  if (tpw == 8 && ipw == 4 && ninstr == 32) {                       // 256 x 256, fp32 X: no idle DMA instruction
     if (NT % 8 == 0) launch_wgrad<8, 4, true, true>(st, A, grid); else launch_wgrad<8, 4, false, true>(st, A, grid);
+    return true;
+  }
+  if (tpw == 8 && ipw == 3 && ninstr == 24) {                       // 256 x 256, f16 X: no idle DMA instruction, four stages next to two images
+    if (NT % 8 == 0) launch_wgrad<8, 3, true, true>(st, A, grid); else launch_wgrad<8, 3, false, true>(st, A, grid);
     return true;
   }
 #define NERFDS_WG(T, I) if (tpw <= T && ipw <= I) { if (T > 1 && NT % T == 0) launch_wgrad<T, I, true>(st, A, grid); else launch_wgrad<T, I, false>(st, A, grid); return true; }
