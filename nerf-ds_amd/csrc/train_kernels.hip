@@ -24,6 +24,37 @@ template <int C> __device__ __forceinline__ float posenc_dval(int g, const float
   return win[band] * (float)(1 << band) * cosf(x[ch] * (float)(1 << band) + (sc ? 1.57079637f : 0.0f));
 }
 
+// ---- row tiles through LDS ---------------------------------------------------------------------------------------------
+// The per-sample kernels below own one ROW of a [samples][W] fp32 array per thread (W = 48 .. 60 floats): read or written straight from
+// the thread, every wave instruction touches 64 different cache lines.  Instead the block's rows go through an LDS tile with an odd row
+// stride (thread = row: conflict-free) and cross HBM as one contiguous run, consecutive threads = consecutive floats.
+constexpr int TILE_ROWS = 128;                                   // block size of the tiled kernels
+__device__ __forceinline__ int tile_stride(int W) { return W | 1; }
+static inline size_t tile_bytes(int W) { return (size_t)TILE_ROWS * (W | 1) * sizeof(float); }
+template <bool STORE> __device__ __forceinline__ void tile_io(float* __restrict__ g, int nrows, int W, float* __restrict__ tile, int stride) {
+  const int n = nrows * W;
+  int r = threadIdx.x / W, c = threadIdx.x - r * W;
+  const int dr = blockDim.x / W, dc = blockDim.x - dr * W;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    if (STORE) g[e] = tile[r * stride + c]; else tile[r * stride + c] = g[e];
+    r += dr; c += dc;
+    if (c >= W) { c -= W; ++r; }
+  }
+}
+// the calling block's rows [m0, m0 + blockDim.x) of g[M][W] <- tile (after every thread wrote its row) / -> tile (before it reads it)
+__device__ __forceinline__ void tile_store(float* g, long long m0, long long M, int W, float* tile) {
+  __syncthreads();
+  const long long left = M - m0;
+  tile_io<true>(g + m0 * W, (int)(left < (long long)blockDim.x ? left : (long long)blockDim.x), W, tile, tile_stride(W));
+  __syncthreads();
+}
+__device__ __forceinline__ void tile_load(const float* g, long long m0, long long M, int W, float* tile) {
+  const long long left = M - m0;
+  tile_io<false>(const_cast<float*>(g) + m0 * W, (int)(left < (long long)blockDim.x ? left : (long long)blockDim.x), W, tile, tile_stride(W));
+  __syncthreads();
+}
+extern __shared__ float g_rows[];
+
 // ---- sampling (model_utils.py:55-92) ---------------------------------------------------------------------------
 // t_rand == nullptr with stratified sampling: the on-chip Philox stream of philox.h (the reference always draws, model_utils.py:84)
 __global__ void k_coarse_z(int R, int Nc, float near_, float far_, int stratified, const float* __restrict__ t_rand, uint64_t seed, long long first_ray, float* __restrict__ z) {
@@ -128,24 +159,36 @@ __global__ void k_encode_inputs(Dims D, int R, int S, const float* __restrict__ 
                                 const uint32_t* __restrict__ warp_id, int n_embeds, const float* __restrict__ warp_tbl,
                                 const float* __restrict__ mask_tbl, Windows W, float* __restrict__ x, float* __restrict__ mask_in,
                                 float* __restrict__ warp_in, float* __restrict__ hyper_in) {
-  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (m >= (long long)R * S) return;
-  const int r = (int)(m / S);
-  float p[3];
-  for (int c = 0; c < 3; ++c) { p[c] = o[3 * r + c] + z[m] * d[3 * r + c]; x[3 * m + c] = p[c]; }
-  uint32_t id = warp_id ? warp_id[r] : 0u;
-  if (id >= (uint32_t)n_embeds) id = n_embeds - 1;      // jnp gathers clamp
-  float* mi = mask_in + m * D.mask_in;
-  for (int g = 0; g < 6 * D.mask_bands; ++g) mi[g] = posenc_val<3>(g, p, W.mask);
-  for (int g = 0; g < 8; ++g) mi[6 * D.mask_bands + g] = mask_tbl[id * 8 + g];
-  float* wi = warp_in + m * D.warp_ld;
-  for (int g = 0; g < 6 * D.warp_bands; ++g) wi[g] = posenc_val<3>(g, p, W.warp);
-  for (int g = 0; g < 8; ++g) wi[6 * D.warp_bands + g] = warp_tbl[id * 8 + g];
-  for (int g = D.warp_in; g < D.warp_ld; ++g) wi[g] = 0.f;            // pad columns (the mask column D.warp_in - 1 is written by k_mask_post)
-  float* hi = hyper_in + m * D.hyper_ld;
-  for (int g = 0; g < 6 * D.hyp_bands; ++g) hi[g] = posenc_val<3>(g, p, W.hyp);
-  for (int g = 0; g < 8; ++g) hi[6 * D.hyp_bands + g] = warp_tbl[id * 8 + g];
-  for (int g = D.hyper_in; g < D.hyper_ld; ++g) hi[g] = 0.f;
+  const long long M = (long long)R * S, m0 = blockIdx.x * (long long)blockDim.x, m = m0 + threadIdx.x;
+  const bool live = m < M;
+  float p[3] = {0.f, 0.f, 0.f};
+  uint32_t id = 0u;
+  if (live) {
+    const int r = (int)(m / S);
+    for (int c = 0; c < 3; ++c) { p[c] = o[3 * r + c] + z[m] * d[3 * r + c]; x[3 * m + c] = p[c]; }
+    id = warp_id ? warp_id[r] : 0u;
+    if (id >= (uint32_t)n_embeds) id = n_embeds - 1;      // jnp gathers clamp
+  }
+  {
+    float* mi = g_rows + threadIdx.x * tile_stride(D.mask_in);
+    for (int g = 0; g < 6 * D.mask_bands; ++g) mi[g] = posenc_val<3>(g, p, W.mask);
+    for (int g = 0; g < 8; ++g) mi[6 * D.mask_bands + g] = mask_tbl[id * 8 + g];
+    tile_store(mask_in, m0, M, D.mask_in, g_rows);
+  }
+  {
+    float* wi = g_rows + threadIdx.x * tile_stride(D.warp_ld);
+    for (int g = 0; g < 6 * D.warp_bands; ++g) wi[g] = posenc_val<3>(g, p, W.warp);
+    for (int g = 0; g < 8; ++g) wi[6 * D.warp_bands + g] = warp_tbl[id * 8 + g];
+    for (int g = D.warp_in - 1; g < D.warp_ld; ++g) wi[g] = 0.f;        // the mask column D.warp_in - 1 (k_mask_post fills it in) and the pad columns
+    tile_store(warp_in, m0, M, D.warp_ld, g_rows);
+  }
+  {
+    float* hi = g_rows + threadIdx.x * tile_stride(D.hyper_ld);
+    for (int g = 0; g < 6 * D.hyp_bands; ++g) hi[g] = posenc_val<3>(g, p, W.hyp);
+    for (int g = 0; g < 8; ++g) hi[6 * D.hyp_bands + g] = warp_tbl[id * 8 + g];
+    for (int g = D.hyper_in - 1; g < D.hyper_ld; ++g) hi[g] = 0.f;
+    tile_store(hyper_in, m0, M, D.hyper_ld, g_rows);
+  }
 }
 
 __global__ void k_bias_act(float* __restrict__ y, const float* __restrict__ b, long long M, int N, int ld, int relu) {
@@ -243,20 +286,21 @@ __global__ void k_se3_bwd(long long M, const float* __restrict__ wv, const float
 
 // ---- NerfMLP trunk input: posenc(x') | posenc(ambient coords) (models.py:493-523) and its backward -------------------
 __global__ void k_trunk_in(Dims D, long long M, const float* __restrict__ xw, const float* __restrict__ wamb, Windows W, float* __restrict__ tin) {
-  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (m >= M) return;
-  const float p[3] = {xw[3 * m], xw[3 * m + 1], xw[3 * m + 2]}, a[2] = {wamb[2 * m], wamb[2 * m + 1]};
-  float* t = tin + m * D.trunk_in;
+  const long long m0 = blockIdx.x * (long long)blockDim.x, m = m0 + threadIdx.x, mc = m < M ? m : M - 1;
+  const float p[3] = {xw[3 * mc], xw[3 * mc + 1], xw[3 * mc + 2]}, a[2] = {wamb[2 * mc], wamb[2 * mc + 1]};
+  float* t = g_rows + threadIdx.x * tile_stride(D.trunk_in);
   for (int g = 0; g < 6 * D.sp_bands; ++g) t[g] = posenc_val<3>(g, p, W.sp);
   for (int g = 0; g < 4 * D.hp_bands; ++g) t[6 * D.sp_bands + g] = posenc_val<2>(g, a, W.hp);
+  tile_store(tin, m0, M, D.trunk_in, g_rows);
 }
 __global__ void k_trunk_in_bwd(Dims D, long long M, const float* __restrict__ dtin, const float* __restrict__ xw, const float* __restrict__ wamb,
                                Windows W, const float* __restrict__ dxw_extra, const float* __restrict__ dwamb_extra, float* __restrict__ dxw,
                                float* __restrict__ dwamb) {
-  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long m0 = blockIdx.x * (long long)blockDim.x, m = m0 + threadIdx.x;
+  tile_load(dtin, m0, M, D.trunk_in, g_rows);
   if (m >= M) return;
   const float p[3] = {xw[3 * m], xw[3 * m + 1], xw[3 * m + 2]}, a[2] = {wamb[2 * m], wamb[2 * m + 1]};
-  const float* t = dtin + m * D.trunk_in;
+  const float* t = g_rows + threadIdx.x * tile_stride(D.trunk_in);
   for (int c = 0; c < 3; ++c) {
     float acc = 0.f;
     for (int bs = 0; bs < 2 * D.sp_bands; ++bs) acc += t[3 * bs + c] * posenc_dval<3>(3 * bs + c, p, W.sp);
@@ -273,10 +317,9 @@ __global__ void k_trunk_in_bwd(Dims D, long long M, const float* __restrict__ dt
 // (models.py:401-405, 1124-1150; the normal branch carries a stop_gradient, models.py:1132-1133 -> no backward)
 __global__ void k_alpha_post(Dims D, int R, int S, const float* __restrict__ alpha, const float* __restrict__ wv, const float* __restrict__ viewdirs,
                              Windows W, float* __restrict__ sigma, float* __restrict__ cond) {
-  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (m >= (long long)R * S) return;
+  const long long M = (long long)R * S, m0 = blockIdx.x * (long long)blockDim.x, ml = m0 + threadIdx.x, m = ml < M ? ml : M - 1;
   const int r = (int)(m / S);
-  sigma[m] = softplus_f(alpha[4 * m]);
+  if (ml < M) sigma[m] = softplus_f(alpha[4 * m]);
   float n[3] = {alpha[4 * m + 1], alpha[4 * m + 2], alpha[4 * m + 3]};
   auto normalize = [](float (&v)[3]) {
     const float inv = 1.0f / sqrtf(fmaxf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2], 1.1920929e-07f));
@@ -290,10 +333,12 @@ __global__ void k_alpha_post(Dims D, int R, int S, const float* __restrict__ alp
   for (int c = 0; c < 3; ++c) nin[c] = Rm[c] * n[0] + Rm[3 + c] * n[1] + Rm[6 + c] * n[2];       // R^T n (inverse warp of a vector)
   normalize(nin);
   const float vd[3] = {viewdirs[3 * r], viewdirs[3 * r + 1], viewdirs[3 * r + 2]};
-  float* c = cond + m * (6 * D.vd_bands + 6 * D.nm_bands);
+  const int CW = 6 * D.vd_bands + 6 * D.nm_bands;
+  float* c = g_rows + threadIdx.x * tile_stride(CW);
   const float ones[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   for (int g = 0; g < 6 * D.vd_bands; ++g) c[g] = posenc_val<3>(g, vd, ones);
   for (int g = 0; g < 6 * D.nm_bands; ++g) c[6 * D.vd_bands + g] = posenc_val<3>(g, nin, W.nm);
+  tile_store(cond, m0, M, CW, g_rows);
 }
 
 // ---- sigma gradient (models.py:1035-1077): forward-mode tangents of sigma_raw w.r.t. the observation-space
@@ -720,37 +765,69 @@ __global__ void k_relu_bwd_colsum(float* __restrict__ dy, const float* __restric
   }
 }
 
-// gradient of the shared-net inputs: the mask column (models.py:729-732) -> mask head, the GLO columns -> embedding rows
+// gradient of the shared-net inputs: the mask column (models.py:729-732) -> mask head, the GLO columns -> embedding rows.
+// One thread per SAMPLE (one per ray left 64 waves on the whole chip walking R x S rows); the 8 GLO sums of a ray's samples meet in
+// LDS (ds_add_f32), then one global atomic per (ray of the block, column).
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ float dpp_add(float v) {      // v + (v moved by the DPP control, 0 where no lane feeds)
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_total(float v) {      // sum of the 64 lanes, valid in lane 63
+  v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v); v = dpp_add<0x140>(v);       // quads, half rows, rows of 16
+  v = dpp_add<0x142, 0xA>(v); v = dpp_add<0x143, 0xC>(v);                                          // row_bcast:15, row_bcast:31
+  return v;
+}
+__device__ __forceinline__ void glo_sums(const float (&e)[8], int lr, int nrays, long long r0, const uint32_t* __restrict__ warp_id, int n_embeds,
+                                         float* __restrict__ d_tbl, float* acc) {
+  for (int i = threadIdx.x; i < nrays * 8; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  // a wave whose 64 samples belong to one ray (S a multiple of 64: every wave) adds its DPP sums once; a mixed wave adds lane by lane
+  const int lr0 = __builtin_amdgcn_readfirstlane(lr);
+  if (__builtin_amdgcn_ballot_w64(lr != lr0) == 0) {
+    for (int g = 0; g < 8; ++g) {
+      const float t = wave_total(e[g]);
+      if ((threadIdx.x & 63) == 63) unsafeAtomicAdd(acc + lr0 * 8 + g, t);
+    }
+  } else {
+    for (int g = 0; g < 8; ++g) unsafeAtomicAdd(acc + lr * 8 + g, e[g]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nrays * 8; i += blockDim.x) {
+    uint32_t id = warp_id ? warp_id[r0 + i / 8] : 0u;
+    if (id >= (uint32_t)n_embeds) id = n_embeds - 1;
+    unsafeAtomicAdd(d_tbl + id * 8 + (i & 7), acc[i]);
+  }
+}
 __global__ void k_shared_in_bwd(Dims D, int R, int S, const float* __restrict__ d_warp_in, const float* __restrict__ d_hyper_in,
                                 const float* __restrict__ mask_logit, float ratio, const float* __restrict__ d_pm_extra,
                                 const uint32_t* __restrict__ warp_id, int n_embeds, float* __restrict__ d_warp_tbl, float* __restrict__ d_mask_logit) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
-  uint32_t id = warp_id ? warp_id[r] : 0u;
-  if (id >= (uint32_t)n_embeds) id = n_embeds - 1;
+  const long long M = (long long)R * S, m0 = blockIdx.x * (long long)blockDim.x, m = m0 + threadIdx.x;
+  const long long last = (m0 + blockDim.x < M ? m0 + blockDim.x : M) - 1, r0 = m0 / S;
+  const int nrays = (int)(last / S - r0) + 1;
   float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < S; ++s) {
-    const size_t m = (size_t)r * S + s;
+  int lr = 0;
+  if (m < M) {
+    lr = (int)(m / S - r0);
     const float* dw = d_warp_in + m * D.warp_ld;
     const float* dh = d_hyper_in + m * D.hyper_ld;
-    for (int g = 0; g < 8; ++g) e[g] += dw[6 * D.warp_bands + g] + dh[6 * D.hyp_bands + g];
+    for (int g = 0; g < 8; ++g) e[g] = dw[6 * D.warp_bands + g] + dh[6 * D.hyp_bands + g];
     const float dmask = dw[D.warp_in - 1] + dh[D.hyper_in - 1];
     d_mask_logit[m] = (mask_logit[m] > 0.f) ? dmask * ratio + (d_pm_extra ? d_pm_extra[m] : 0.f) : 0.f;
   }
-  for (int g = 0; g < 8; ++g) atomicAdd(d_warp_tbl + id * 8 + g, e[g]);
+  glo_sums(e, lr, nrays, r0, warp_id, n_embeds, d_warp_tbl, g_rows);
 }
 __global__ void k_mask_in_bwd(Dims D, int R, int S, const float* __restrict__ d_mask_in, const uint32_t* __restrict__ warp_id, int n_embeds,
                               float* __restrict__ d_mask_tbl) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
-  uint32_t id = warp_id ? warp_id[r] : 0u;
-  if (id >= (uint32_t)n_embeds) id = n_embeds - 1;
+  const long long M = (long long)R * S, m0 = blockIdx.x * (long long)blockDim.x, m = m0 + threadIdx.x;
+  const long long last = (m0 + blockDim.x < M ? m0 + blockDim.x : M) - 1, r0 = m0 / S;
+  const int nrays = (int)(last / S - r0) + 1;
   float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < S; ++s) {
-    const float* dm = d_mask_in + ((size_t)r * S + s) * D.mask_in;
-    for (int g = 0; g < 8; ++g) e[g] += dm[6 * D.mask_bands + g];
+  int lr = 0;
+  if (m < M) {
+    lr = (int)(m / S - r0);
+    const float* dm = d_mask_in + m * D.mask_in;
+    for (int g = 0; g < 8; ++g) e[g] = dm[6 * D.mask_bands + g];
   }
-  for (int g = 0; g < 8; ++g) atomicAdd(d_mask_tbl + id * 8 + g, e[g]);
+  glo_sums(e, lr, nrays, r0, warp_id, n_embeds, d_mask_tbl, g_rows);
 }
 
 // flax.optim.Adam (flax 0.3.4): bias-corrected, no weight decay (training.py:508, train.py:297-301)
@@ -810,7 +887,9 @@ void resample(hipStream_t st, int R, int Nc, int Nf, const float* zc, const floa
 }
 void encode_inputs(hipStream_t st, const Dims& D, int R, int S, const float* o, const float* d, const float* z, const uint32_t* warp_id, int n_embeds,
                    const float* warp_tbl, const float* mask_tbl, const Windows& W, float* x, float* mask_in, float* warp_in, float* hyper_in) {
-  LAUNCH(k_encode_inputs, (long long)R * S, st, D, R, S, o, d, z, warp_id, n_embeds, warp_tbl, mask_tbl, W, x, mask_in, warp_in, hyper_in);
+  const int wmax = D.mask_in > D.warp_ld ? (D.mask_in > D.hyper_ld ? D.mask_in : D.hyper_ld) : (D.warp_ld > D.hyper_ld ? D.warp_ld : D.hyper_ld);
+  hipLaunchKernelGGL(k_encode_inputs, grid1((long long)R * S, TILE_ROWS), dim3(TILE_ROWS), tile_bytes(wmax), st, D, R, S, o, d, z, warp_id, n_embeds, warp_tbl, mask_tbl,
+                     W, x, mask_in, warp_in, hyper_in);
 }
 void bias_act(hipStream_t st, float* y, const float* b, long long M, int N, int ld, int relu) { LAUNCH(k_bias_act, M * N, st, y, b, M, N, ld, relu); }
 void mask_post(hipStream_t st, const Dims& D, int R, int S, const float* logit, const float* gt, float ratio, float* warp_in, float* hyper_in) {
@@ -821,11 +900,11 @@ void se3_bwd(hipStream_t st, long long M, const float* wv, const float* x, const
   LAUNCH(k_se3_bwd, M, st, M, wv, x, dxw, dwv_extra, dwv);
 }
 void trunk_in(hipStream_t st, const Dims& D, long long M, const float* xw, const float* wamb, const Windows& W, float* tin) {
-  LAUNCH(k_trunk_in, M, st, D, M, xw, wamb, W, tin);
+  hipLaunchKernelGGL(k_trunk_in, grid1(M, TILE_ROWS), dim3(TILE_ROWS), tile_bytes(D.trunk_in), st, D, M, xw, wamb, W, tin);
 }
 void trunk_in_bwd(hipStream_t st, const Dims& D, long long M, const float* dtin, const float* xw, const float* wamb, const Windows& W,
                   const float* dxw_extra, const float* dwamb_extra, float* dxw, float* dwamb) {
-  LAUNCH(k_trunk_in_bwd, M, st, D, M, dtin, xw, wamb, W, dxw_extra, dwamb_extra, dxw, dwamb);
+  hipLaunchKernelGGL(k_trunk_in_bwd, grid1(M, TILE_ROWS), dim3(TILE_ROWS), tile_bytes(D.trunk_in), st, D, M, dtin, xw, wamb, W, dxw_extra, dwamb_extra, dxw, dwamb);
 }
 void norm_loss(hipStream_t st, int R, int S, float weight, const float* weights, const float* alpha, const float* t_alpha, const float* wv,
                const float* target_norm, float* term, float* d_alpha, float* d_t_alpha, float* du, float* ghat) {
@@ -846,7 +925,8 @@ void aux_losses(hipStream_t st, int R, int S, const Objective& ob, const float* 
                      d_alpha, d_pm);
 }
 void alpha_post(hipStream_t st, const Dims& D, int R, int S, const float* alpha, const float* wv, const float* viewdirs, const Windows& W, float* sigma, float* cond) {
-  LAUNCH(k_alpha_post, (long long)R * S, st, D, R, S, alpha, wv, viewdirs, W, sigma, cond);
+  hipLaunchKernelGGL(k_alpha_post, grid1((long long)R * S, TILE_ROWS), dim3(TILE_ROWS), tile_bytes(6 * D.vd_bands + 6 * D.nm_bands), st, D, R, S, alpha, wv, viewdirs, W,
+                     sigma, cond);
 }
 void composite_loss(hipStream_t st, int R, int S, const float* z, const float* dirs, const float* sigma, const float* rgb_logit, const float* target,
                     int at_infinity, int white, float* rgb_ray, float* weights, float* loss, float* d_rgb_logit, float* d_alpha) {
@@ -862,11 +942,11 @@ void relu_bwd_colsum(hipStream_t st, float* dy, const float* y, long long M, int
 }
 void shared_in_bwd(hipStream_t st, const Dims& D, int R, int S, const float* d_warp_in, const float* d_hyper_in, const float* mask_logit, float ratio,
                    const float* d_pm_extra, const uint32_t* warp_id, int n_embeds, float* d_warp_tbl, float* d_mask_logit) {
-  hipLaunchKernelGGL(k_shared_in_bwd, grid1(R, 64), dim3(64), 0, st, D, R, S, d_warp_in, d_hyper_in, mask_logit, ratio, d_pm_extra, warp_id, n_embeds,
+  hipLaunchKernelGGL(k_shared_in_bwd, grid1((long long)R * S), dim3(256), 256 * 8 * sizeof(float), st, D, R, S, d_warp_in, d_hyper_in, mask_logit, ratio, d_pm_extra, warp_id, n_embeds,
                      d_warp_tbl, d_mask_logit);
 }
 void mask_in_bwd(hipStream_t st, const Dims& D, int R, int S, const float* d_mask_in, const uint32_t* warp_id, int n_embeds, float* d_mask_tbl) {
-  hipLaunchKernelGGL(k_mask_in_bwd, grid1(R, 64), dim3(64), 0, st, D, R, S, d_mask_in, warp_id, n_embeds, d_mask_tbl);
+  hipLaunchKernelGGL(k_mask_in_bwd, grid1((long long)R * S), dim3(256), 256 * 8 * sizeof(float), st, D, R, S, d_mask_in, warp_id, n_embeds, d_mask_tbl);
 }
 void sum_partials(hipStream_t st, const float* part, int slabs, long long n, float* out) { LAUNCH(k_sum_partials, n, st, part, slabs, n, out); }
 void fill(hipStream_t st, float* p, long long n, float v) { LAUNCH(k_fill, n, st, p, n, v); }
