@@ -1,8 +1,8 @@
 // Training step of BASELINE config 4: loss = MSE(rgb_fine, gt) + MSE(rgb_coarse, gt)
 // (training.py:265-274, 459-466, 481), gradients w.r.t. every parameter of the nerf_ds graph (training.py:494) and the
-// Adam update (training.py:508).  First correct version: fp32 throughout, activations of every layer resident in HBM
-// (needed for dW), dense layers as plain row-major GEMMs through rocBLAS (forward X W, backward dX = dZ W^T and
-// dW = X^T dZ), everything else in the hand-written kernels of train_kernels.hip.  The two levels are processed one
+// Adam update (training.py:508).  Activations of every layer stay resident in HBM (needed for dW); the dense layers
+// (forward X W, backward dX = dZ W^T and dW = X^T dZ) run on the hand-written MFMA kernels of train_gemm.hip and on the
+// fused forward / backward chains of render_kernel.hip (no BLAS library is linked), everything else in train_kernels.hip.  The two levels are processed one
 // after the other through the same workspace: their losses are independent sums and the fine z samples carry a
 // stop_gradient (model_utils.py:241), so no gradient crosses from the fine level into the coarse one.
 #include <hip/hip_runtime.h>

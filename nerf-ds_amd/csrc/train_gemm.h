@@ -73,7 +73,7 @@ size_t frag_bytes(int in_dim, int out_dim, int parts = 2);
 struct PackEntry { long long woff; long long dst; int ldw, row0, in_dim, out_dim, transpose, parts; };
 void pack_frags_all(hipStream_t st, const float* theta, const PackEntry* entries_dev, int n, int max_frag_lanes, void* arena);
 bool dense_ws_supported(const DenseArgs& A);
-// false = shape not covered (caller falls back to rocBLAS)
+// false = shape not covered (the step then returns NERFDS_ENOTSUP: there is no library fallback)
 bool dense_ws(hipStream_t st, const DenseArgs& A, int num_cus);
 
 }  // namespace nerfds_train

@@ -1,6 +1,6 @@
 // Element-wise / per-ray kernels of the training step (BASELINE config 4): everything of the
 // nerf_ds graph that is not a dense layer, forward AND backward, in fp32.  The dense layers themselves are plain
-// [samples x width] GEMMs over HBM-resident activations (rocBLAS, see nerfds_train.cpp): a training step has to keep
+// [samples x width] GEMMs over HBM-resident activations (hand-written MFMA kernels: train_gemm.hip, see nerfds_train.cpp): a training step has to keep
 // every layer's activations for dW anyway, so this path is HBM-resident by design, unlike the fused render kernel.
 // One thread per sample unless stated; sample m = ray * S + s.  Reference lines are cited per kernel.
 #include <hip/hip_runtime.h>
