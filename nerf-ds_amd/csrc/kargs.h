@@ -92,6 +92,10 @@ struct TrainBwd {
   float* d_in;                  // out: [M][ld_in] gradient of the raw input (zero in the pad columns)
   int ld_in;
   float* sink;                  // >= 64 bytes of scratch: where lanes outside ld_in write
+  // g_half != 0: g[l] is written as bf16 [M][width] (the same pointers, read as uint16_t*) - the weight-gradient kernels read it as a
+  // one-term operand (X hi * g + X lo * g: two MFMAs per product instead of three, half the bytes); the chain itself keeps every g in
+  // fp32 / split bf16 registers, so only the weight and bias gradients see the 8-bit rounding (unbiased, averaged over M samples)
+  int g_half;
 };
 
 typedef void (*launch_bwd_fn)(const KArgs& ka, const TrainBwd& tb, int num_cus, void* stream);

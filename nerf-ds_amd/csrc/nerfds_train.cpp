@@ -125,6 +125,9 @@ struct nerfds_trainer {
   std::vector<uint16_t*> mask_h16, warp_h16, hyper_h16, trunk_h16, mask_bits, warp_bits, hyper_bits, trunk_bits;
   uint16_t *rgb_h16 = nullptr, *rgb_bits = nullptr;
   float* sink = nullptr;
+  // the fused backward's chains leave g_l as bf16 (the weight-gradient kernels' dY operand: half the bytes, two MFMAs per product instead
+  // of three; the chains themselves keep g in registers at full precision).  NERFDS_TRAIN_G16=0: fp32 g arrays.
+  bool g16 = true;
   bool half_step = false;    // this step's forward wrote f16 + bits (no tangent pass needs the fp32 activations)
   std::string err;
   // workspace views (set by carve())
@@ -264,10 +267,11 @@ struct Run {
   // dW[K x N] += X[M x K]^T dY[M x N] (contraction over the sample axis): train_gemm.hip k_wgrad, one partial per workgroup
   // accumulated in registers and added to a gradient replica with float atomics.
   void weight_grad(const float* X, int ldx, int K, const float* dy, int ldy, int N, float* dW, int64_t rows = -1, bool x_half = false,
-                   float* bias_grad = nullptr) {
+                   float* bias_grad = nullptr, bool dy_half = false) {
     const int64_t M = rows < 0 ? this->M : rows;
     WgradArgs A{X, ldx, K, dy, ldy, N, M, nullptr, rep(dW), static_cast<const char*>(t.wpack) + WPACK_BYTES, 0, 0, t.P, nrep()};
     A.x_half = x_half ? 1 : 0;
+    A.dy_half = dy_half ? 1 : 0;
     A.colsum = rep(bias_grad);
     if (!(wgrad_supported(A) && wgrad(wgrad_stream(), A, wgrad_grid(A, t.num_cus)))) unsupported("weight gradient", K, N, M);
   }
@@ -300,12 +304,12 @@ struct Run {
       int k0 = 0;
       bool first = true;
       if (l > 0) {
-        weight_grad(reinterpret_cast<const float*>(h16[l - 1]), m.width, m.width, g[l], m.width, m.width, t.grad + L.w, -1, true, t.grad + L.b);
+        weight_grad(reinterpret_cast<const float*>(h16[l - 1]), m.width, m.width, g[l], m.width, m.width, t.grad + L.w, -1, true, t.grad + L.b, t.g16);
         k0 = m.width;
         first = false;
       }
       if (l == 0 || l == m.skip)
-        weight_grad(in0, m.in_ld, m.in_dim, g[l], m.width, m.width, t.grad + L.w + (int64_t)k0 * L.N, -1, false, first ? t.grad + L.b : nullptr);
+        weight_grad(in0, m.in_ld, m.in_dim, g[l], m.width, m.width, t.grad + L.w + (int64_t)k0 * L.N, -1, false, first ? t.grad + L.b : nullptr, t.g16);
     }
   }
   // a head on the last hidden layer: dW = h^T d_head, db = column sums of d_head (N <= 6: the scalar-DMA shapes of k_wgrad)
@@ -699,6 +703,7 @@ void fused_backward(nerfds_trainer& t, hipStream_t st, int net, int level, int64
                     float* d_in, int ld_in) {
   nerfds::TrainBwd tb{};
   tb.M = M; tb.d_head = d_head; tb.ld_head = ld_head; tb.d_head2 = d_head2; tb.d_in = d_in; tb.ld_in = ld_in; tb.sink = t.sink;
+  tb.g_half = t.g16 ? 1 : 0;
   const std::vector<uint16_t*>* bits = nullptr;
   const std::vector<float*>* g = nullptr;
   if (net == 0) { tb.wstream = t.bstream[level]; bits = &t.trunk_bits; g = &t.trunk_h; tb.bits[8] = t.rgb_bits; tb.g[8] = t.rgb_hv; }
@@ -801,9 +806,9 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
     auto wg_nerf = [&] {   // rgb branch: heads on rgb hidden / trunk_out, rgb hidden_0 = [bottleneck | viewdir | trunk_out | normal] rows
       r.head_wgrads(t.rgb_out[level], t.rgb_h16, RW, t.d_rgb_logit, 3);
       r.head_wgrads(t.alpha[level], t.trunk_h16.back(), TW, t.d_alpha, 4);
-      r.weight_grad(reinterpret_cast<const float*>(t.trunk_h16.back()), TW, TW, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(TW + VD) * RW, -1, true, t.grad + K.b);   // S
-      r.weight_grad(t.cond, CW, VD, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)TW * RW);
-      r.weight_grad(t.cond + VD, CW, NM, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(2 * TW + VD) * RW);
+      r.weight_grad(reinterpret_cast<const float*>(t.trunk_h16.back()), TW, TW, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(TW + VD) * RW, -1, true, t.grad + K.b, t.g16);   // S
+      r.weight_grad(t.cond, CW, VD, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)TW * RW, -1, false, nullptr, t.g16);
+      r.weight_grad(t.cond + VD, CW, NM, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(2 * TW + VD) * RW, -1, false, nullptr, t.g16);
       r.mlp_wgrads(trunk, t.trunk_in, t.trunk_h16, t.trunk_h);
     };
     auto wg_hyper = [&] {
@@ -945,6 +950,8 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
     t->fused_fwd = !(ff && std::string(ff) == "0") && build_fused_forward(*t);
     const char* fbw = getenv("NERFDS_TRAIN_FUSED_BWD");
     t->fused_bwd = t->fused_fwd && !(fbw && std::string(fbw) == "0") && build_fused_backward(*t);
+    const char* g16 = getenv("NERFDS_TRAIN_G16");
+    t->g16 = !(g16 && std::string(g16) == "0");
     if (hipMalloc(&t->arena, ARENA_BYTES) != hipSuccess) { g_train_error = "hipMalloc failed (fragment arena)"; return NERFDS_ENOMEM; }
     if (hipMalloc(&t->grad_rep, (size_t)GRAD_REPS * t->P * sizeof(float)) != hipSuccess) { g_train_error = "hipMalloc failed (gradient replicas)"; return NERFDS_ENOMEM; }
     const char* ss = getenv("NERFDS_TRAIN_SIDE_STREAMS");

@@ -318,6 +318,12 @@ template <class G, class PL> struct Pipe {
       static_assert(PIECES == 4 || PIECES == 2, "vmcnt(PIECES) below");
       const int tprev = s + NS - 2;              // the stage issued since the previous boundary (s == 0: by the previous segment's last stage)
       const bool prev_issued = tprev >= seg_stages(seg) || tprev < seg_used(seg);
+#ifdef NERFDS_UNSAFE_VMCNT      // timing experiment only (results may read stale weights): how much of the step is the wait for the stores?
+#define NERFDS_STR2(x) #x
+#define NERFDS_STR(x) NERFDS_STR2(x)
+      if (prev_issued) asm volatile("s_waitcnt vmcnt(" NERFDS_STR(NERFDS_UNSAFE_VMCNT) ") lgkmcnt(0)" ::: "memory");
+      else
+#endif
       if (prev_issued && PIECES == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       else if (prev_issued) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -463,6 +469,17 @@ template <bool RELU> DEVI unsigned store_tile_half(uint16_t* row_tile, const f32
     *reinterpret_cast<u32x2*>(row_tile + 8 * g) = pk;
   }
   return bits;
+}
+// The same tile as bf16 (round to nearest even, fp32 range): four 8-byte stores.  The g arrays of the fused backward (TrainBwd::g_half).
+DEVI void store_tile_bf16(uint16_t* row_tile, const f32x16& acc) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const __bf16 h0 = (__bf16)acc[4 * g], h1 = (__bf16)acc[4 * g + 1], h2 = (__bf16)acc[4 * g + 2], h3 = (__bf16)acc[4 * g + 3];
+    u32x2 pk;
+    pk[0] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    pk[1] = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
+    *reinterpret_cast<u32x2*>(row_tile + 8 * g) = pk;
+  }
 }
 // Fused backward: zero the accumulator registers whose ReLU bit is clear.  (Written as a select on purpose: the 2-VALU form
 // "x & sign-extended bit" through __builtin_amdgcn_sbfe on this (shifted, masked) operand is folded wrongly by hipcc 7.2 - every
@@ -893,7 +910,8 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Carry<NT>& carry, Chunk<PO> (&out)[
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) {
           apply_mask(acc[tp][0], (cur.mask[(ot + tp) >> 1] >> (16 * ((ot + tp) & 1))) & 0xffffu);
-          store_tile<false>(cur.row + 32 * (ot + tp), acc[tp][0]);
+          if (cur.half) store_tile_bf16(cur.row16 + 32 * (ot + tp), acc[tp][0]);      // wave-uniform (a kernel argument)
+          else store_tile<false>(cur.row + 32 * (ot + tp), acc[tp][0]);
         }
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) tile_epilogue<PO, NT, false>(out, ot + tp, acc[tp]);
@@ -1988,10 +2006,11 @@ template <int W> DEVI void load_bits(unsigned (&m)[W / 64 > 0 ? W / 64 : 1], con
   for (int j = 0; j < W / 64; ++j) m[j] = p[j];
 }
 template <class BG, class PL, int OT, class OUT, class... Ins>
-DEVI void bwd_hidden(Pipe<BG, PL>& pipe, BwdCursor& cur, Carry<1>& carry, const unsigned (&m)[OT / 2], float* g_row, OUT& out, Ins&... ins) {
+DEVI void bwd_hidden(Pipe<BG, PL>& pipe, BwdCursor& cur, Carry<1>& carry, const unsigned (&m)[OT / 2], float* g_base, size_t g_off, OUT& out, Ins&... ins) {
 #pragma unroll
   for (int j = 0; j < OT / 2; ++j) cur.mask[j] = m[j];
-  cur.row = g_row;
+  cur.row = g_base + g_off;                                        // fp32 [M][width] ...
+  cur.row16 = reinterpret_cast<uint16_t*>(g_base) + g_off;         // ... or bf16 [M][width] in the same buffer (cur.half)
   dense<BG, PL, 1, OT, false>(pipe, cur, carry, out, ins...);
 }
 template <class BG, class PL, int P, int K>
@@ -2013,14 +2032,14 @@ DEVI void bwd_chain(const TrainBwd& tb, Pipe<BG, PL>& pipe, int lane, long long 
   const int h = lane >> 5;
   BwdCursor cur;
   cur.seg = SEG_NERF; cur.pos = 0; cur.bt = 0;
-  cur.row = nullptr; cur.row16 = nullptr; cur.bits = nullptr; cur.half = 0;
+  cur.row = nullptr; cur.row16 = nullptr; cur.bits = nullptr; cur.half = tb.g_half;
   cur.sink = tb.sink; cur.ld_in = tb.ld_in; cur.in_h4 = 4 * h; cur.in_row = nullptr; cur.in_acc = 0; cur.live = live;
   Carry<1> carry;
   // every load of the tile up front (one wait): ReLU bits of all layers, head gradients
   unsigned mk[D][MW];
 #pragma unroll
   for (int l = 0; l < D; ++l) load_bits<W>(mk[l], tb.bits[l], r, h);
-  auto g_row = [&](int l) { return tb.g[l] + (size_t)r * W + 4 * h; };
+  const size_t g_off = (size_t)r * W + 4 * h;
   float* const in_row = tb.d_in + (size_t)r * tb.ld_in + 4 * h;
   Chunk<P> a[1][W16], b[1][W16];
   if constexpr (BG::IS_NERF) {
@@ -2030,26 +2049,26 @@ DEVI void bwd_chain(const TrainBwd& tb, Pipe<BG, PL>& pipe, int lane, long long 
     Chunk<P> drgb[1][1], dalpha[1][1], c[1][R16];
     build_chunks<P, 1>(drgb[0], h, [&](int f) { return f < 3 ? val_feat(tb.d_head[(size_t)r * tb.ld_head + f]) : zero_feat(); });
     build_chunks<P, 1>(dalpha[0], h, [&](int f) { return f < 4 ? val_feat(tb.d_head2[(size_t)r * 4 + f]) : zero_feat(); });
-    bwd_hidden<BG, PL, RW / 32>(pipe, cur, carry, mr, tb.g[8] + (size_t)r * RW + 4 * h, c, drgb);     // g_rgb = mask(W_rgb d rgb_logit)
-    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[7], g_row(7), a, c, dalpha);                          // g_7 = mask(F^T g_rgb + W_alpha d alpha)
+    bwd_hidden<BG, PL, RW / 32>(pipe, cur, carry, mr, tb.g[8], (size_t)r * RW + 4 * h, c, drgb);     // g_rgb = mask(W_rgb d rgb_logit)
+    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[7], tb.g[7], g_off, a, c, dalpha);                          // g_7 = mask(F^T g_rgb + W_alpha d alpha)
   } else {
     Chunk<P> dh[1][1];
     build_chunks<P, 1>(dh[0], h, [&](int f) { return f < BG::NHEAD ? val_feat(tb.d_head[(size_t)r * tb.ld_head + f]) : zero_feat(); });
-    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[D - 1], g_row(D - 1), a, dh);                          // g_{D-1} = mask(W_head d head)
+    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[D - 1], tb.g[D - 1], g_off, a, dh);                          // g_{D-1} = mask(W_head d head)
   }
   if constexpr (D == 8) {
-    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[6], g_row(6), b, a);
-    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[5], g_row(5), a, b);
-    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[4], g_row(4), b, a);
+    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[6], tb.g[6], g_off, b, a);
+    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[5], tb.g[5], g_off, a, b);
+    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[4], tb.g[4], g_off, b, a);
   } else {
-    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[4], g_row(4), b, a);
+    bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[4], tb.g[4], g_off, b, a);
   }
   // the skip layer [h_3 | raw input] (modules.py:66-67): its hidden rows give g_3, its raw-input rows the first part of d input
-  bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[3], g_row(3), a, b);
+  bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[3], tb.g[3], g_off, a, b);
   bwd_input<BG, PL>(pipe, cur, carry, in_row, 0, b);
-  bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[2], g_row(2), b, a);
-  bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[1], g_row(1), a, b);
-  bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[0], g_row(0), b, a);
+  bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[2], tb.g[2], g_off, b, a);
+  bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[1], tb.g[1], g_off, a, b);
+  bwd_hidden<BG, PL, W32>(pipe, cur, carry, mk[0], tb.g[0], g_off, b, a);
   bwd_input<BG, PL>(pipe, cur, carry, in_row, 1, b);
   pipe.finish_segment(SEG_NERF);
 }

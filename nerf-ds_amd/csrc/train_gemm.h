@@ -43,6 +43,9 @@ struct WgradArgs {
   // x_half: x points to f16 [M x ldx] (what the fused forward stores for the plain training step; K, ldx multiples of 8, 16-byte
   // aligned rows) - converted exactly into bf16 hi + lo on the way to the MFMAs.
   int x_half;
+  // dy_half: dy points to bf16 [M x ldy] (the g arrays of the fused backward; N a multiple of 32, ldy of 8, 16-byte aligned rows):
+  // a one-term operand, two MFMAs per product
+  int dy_half;
   // colsum != nullptr: += the column sums of dY (the bias gradient of the layer), a by-product of the tile conversion; replicas as dw.
   float* colsum;
 };

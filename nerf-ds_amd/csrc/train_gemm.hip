@@ -25,6 +25,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 extern __shared__ __attribute__((aligned(16))) char g_tile[];      // the one LDS object of every kernel here (a second one de-pipelines LDS-DMA code)
 
@@ -498,7 +499,9 @@ template <int TPW, int IPW, bool FULL = false> struct WgShape {
 
 // ROW: the TPW output tiles of a wave lie in one row of tiles (N/32 is a multiple of TPW), so its X^T fragment is read once per
 // sample tile instead of once per output tile (a compile-time fact: as a run-time branch the two loop bodies cost 4x in spills).
-template <int TPW, int IPW, bool ROW, bool FULL>
+// DYH: dY is bf16 [M x ldy] (the g arrays of the fused backward, WgradArgs::dy_half): half the bytes, its fragment image is the
+// transposed tile itself (no conversion, no lo part) and a product is two MFMAs (X hi * g, X lo * g) instead of three.
+template <int TPW, int IPW, bool ROW, bool FULL, bool DYH>
 __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
   typedef WgShape<TPW, IPW, FULL> S;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
   // so a part is rounded up to whole instructions.  Lanes past the end of a part / of M read the zero line.
   const int XH = A.x_half;                                                   // X is f16: 8 elements per 16-byte piece, 2 bytes each
   const int NX = A.x_scalar ? (16 * K + 63) >> 6 : (XH ? (2 * K + 63) >> 6 : (16 * KQ + 63) >> 6);
-  const int NY = A.dy_scalar ? (16 * N + 63) >> 6 : (16 * NQ + 63) >> 6;
+  const int NY = A.dy_scalar ? (16 * N + 63) >> 6 : (DYH ? (2 * N + 63) >> 6 : (16 * NQ + 63) >> 6);
   const int XBYTES = NX * (A.x_scalar ? 256 : 1024);
   const char* src[IPW];
   int step[IPW], rowu[IPW], ldsoff[IPW];
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
       const int ii = isx ? i : i - NX, W = isx ? K : N, ld = isx ? A.ldx : A.ldy;
       const char* base = reinterpret_cast<const char*>(isx ? A.x : A.dy);
       sc = isx ? A.x_scalar != 0 : A.dy_scalar != 0;
-      const int esz = (isx && XH) ? 2 : 4;                                  // bytes per element
+      const int esz = (isx ? XH != 0 : DYH) ? 2 : 4;                        // bytes per element
       const int e = (64 * ii + lane) * (sc ? 1 : 16 / esz);                 // first element of this lane's piece, in [16][W]
       off = (isx ? 0 : XBYTES) + ii * (sc ? 256 : 1024);
       if (e < 16 * W) {
@@ -555,6 +558,8 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
   // conversion items of this thread: (feature f, sample octet o) of X (idx < 2 K) or dY; 2 (K + N) <= 1024 items.
   // f16 X: the item's 8 samples come by two ds_read_b64_tr_b16 (a 16-lane group reads a [4 samples][16 features] block of the row-major
   // stage, lane i supplies the 8-byte piece (row i / 4, features 4 (i % 4) ..) and receives column i) instead of 8 two-byte reads.
+  // (bf16 dY: its items start at a multiple of 64, so that whole waves - and whole 16-lane transpose groups - lie on one side)
+  const int KI = DYH ? ((2 * K + 63) & ~63) : 2 * K;
   int c_src[2], c_dst[2], c_stride[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -565,9 +570,10 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
       c_src[j] = (8 * o * K + f) * esz; c_stride[j] = K * esz;
       if (XH) { const int i = lane & 15; c_src[j] = ((8 * o + (i >> 2)) * K + (f - i) + 4 * (i & 3)) * 2; }
       c_dst[j] = (f >> 5) * 2048 + ((o << 5) | (f & 31)) * 16;
-    } else if (idx < 2 * (K + N)) {
-      const int i2 = idx - 2 * K, o = i2 / N, f = i2 - o * N;
+    } else if (idx >= KI && idx < KI + 2 * N) {
+      const int i2 = idx - KI, o = i2 / N, f = i2 - o * N;
       c_src[j] = XBYTES + (8 * o * N + f) * 4; c_stride[j] = N * 4;
+      if (DYH) { const int i = lane & 15; c_src[j] = XBYTES + ((8 * o + (i >> 2)) * N + (f - i) + 4 * (i & 3)) * 2; c_stride[j] = N * 2; }
       c_dst[j] = (KT + (f >> 5)) * 2048 + ((o << 5) | (f & 31)) * 16;
     }
   }
@@ -583,6 +589,17 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
     for (int j = 0; j < 2; ++j) {
       if (c_src[j] >= 0) {
         float f[8];
+        if (DYH && threadIdx.x + 512 * j >= KI) {       // bf16 item of dY: the transposed 8 samples ARE the fragment piece
+          u32x2 q0, q1;
+          const unsigned a0 = (unsigned)(size_t)(stg + c_src[j]), a1 = a0 + 4 * c_stride[j];
+          asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(q0), "=&v"(q1) : "v"(a0), "v"(a1) : "memory");
+          const u32x4 pk = {q0[0], q0[1], q1[0], q1[1]};
+          auto lo16 = [](unsigned w) { return __builtin_bit_cast(float, w << 16); };
+          auto hi16 = [](unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); };
+          cs[j] += ((lo16(pk[0]) + hi16(pk[0])) + (lo16(pk[1]) + hi16(pk[1]))) + ((lo16(pk[2]) + hi16(pk[2])) + (lo16(pk[3]) + hi16(pk[3])));
+          *reinterpret_cast<u32x4*>(img + c_dst[j]) = pk;
+          continue;
+        }
         if (XH && threadIdx.x + 512 * j < 2 * K) {       // f16 item of X (whole waves take one side: 2 K is a multiple of 64 on this path)
           // (inline asm: behind the builtin hipcc orders the read after EVERY outstanding LDS-DMA - s_waitcnt vmcnt(0) - and the ring is gone)
           typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -595,7 +612,7 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const float*>(stg + c_src[j] + i * c_stride[j]);
         }
-        if (threadIdx.x + 512 * j >= 2 * K) cs[j] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+        if (threadIdx.x + 512 * j >= KI) cs[j] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
         bf16x8 xh, xl;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -638,13 +655,13 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
       if (t0 < TT) {
         ah = frag(kt, 0); al = frag(kt, 1);
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) { bh[j] = frag(KT + nt0 + j, 0); bl[j] = frag(KT + nt0 + j, 1); }
+        for (int j = 0; j < TPW; ++j) { bh[j] = frag(KT + nt0 + j, 0); if constexpr (!DYH) bl[j] = frag(KT + nt0 + j, 1); }
       }
       convert(g_tile + st * S::STAGE_BYTES, img0 + ((it + 1) & 1) * S::IMG_BYTES);
       if (t0 < TT) {
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
+          if constexpr (!DYH) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
         }
@@ -656,8 +673,8 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
         const int t = wave * TPW + j;
         if (t < TT) {
           const int kt = t / NT, nt = t - kt * NT;
-          const bf16x8 ah = frag(kt, 0), al = frag(kt, 1), bh = frag(KT + nt, 0), bl = frag(KT + nt, 1);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+          const bf16x8 ah = frag(kt, 0), al = frag(kt, 1), bh = frag(KT + nt, 0);
+          if constexpr (!DYH) { const bf16x8 bl = frag(KT + nt, 1); acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0); }
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
         }
@@ -670,7 +687,7 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int idx = threadIdx.x + 512 * j;
-      if (idx >= 2 * K && idx < 2 * (K + N)) unsafeAtomicAdd(cdst + (idx - 2 * K) % N, cs[j]);
+      if (idx >= KI && idx < KI + 2 * N) unsafeAtomicAdd(cdst + (idx - KI) % N, cs[j]);
     }
   }
   // this workgroup's partial: lane holds column n = 32 nt + (lane & 31), rows k = 32 kt + (r & 3) + 8 (r >> 2) + 4 h
@@ -996,12 +1013,13 @@ bool dense_ws(hipStream_t st, const DenseArgs& A, int num_cus) {
 
 static void wgrad_kinds(const WgradArgs& A, int& xs, int& ys, int& ninstr) {
   xs = (!A.x_half && (A.k % 4 || A.ldx % 4 || !aligned16(A.x))) ? 1 : 0;
-  ys = (A.n % 4 || A.ldy % 4 || !aligned16(A.dy)) ? 1 : 0;
-  ninstr = (xs ? (16 * A.k + 63) / 64 : ((A.x_half ? 2 : 4) * A.k + 63) / 64) + (ys ? (16 * A.n + 63) / 64 : (4 * A.n + 63) / 64);
+  ys = (!A.dy_half && (A.n % 4 || A.ldy % 4 || !aligned16(A.dy))) ? 1 : 0;
+  ninstr = (xs ? (16 * A.k + 63) / 64 : ((A.x_half ? 2 : 4) * A.k + 63) / 64) + (ys ? (16 * A.n + 63) / 64 : ((A.dy_half ? 2 : 4) * A.n + 63) / 64);
 }
 bool wgrad_supported(const WgradArgs& A) {
   if (A.k < 1 || A.n < 1 || A.k > 256 || A.n > 256 || A.M <= 0 || A.zeros == nullptr) return false;
   if (A.x_half && (A.k % 32 || A.ldx % 8 || !aligned16(A.x))) return false;       // f16 rows: whole 16-byte pieces, whole waves of items
+  if (A.dy_half && (A.n % 32 || A.ldy % 8 || !aligned16(A.dy) || ((2 * A.k + 63) & ~63) + 2 * A.n > 1024)) return false;   // bf16 rows likewise
   int xs, ys, ninstr;
   wgrad_kinds(A, xs, ys, ninstr);
   return ninstr <= 32;                                              // at most 4 DMA instructions per wave and tile
@@ -1012,12 +1030,16 @@ int wgrad_grid(const WgradArgs& A, int num_cus) {
   const long long want = num_cus;
   return (int)(tiles < want ? tiles : want);
 }
-template <int TPW, int IPW, bool ROW, bool FULL = false> static void launch_wgrad(hipStream_t st, const WgradArgs& A, int grid) {
-  auto kern = k_wgrad<TPW, IPW, ROW, FULL>;
+template <int TPW, int IPW, bool ROW, bool FULL, bool DYH> static void launch_wgrad_t(hipStream_t st, const WgradArgs& A, int grid) {
+  auto kern = k_wgrad<TPW, IPW, ROW, FULL, DYH>;
   typedef WgShape<TPW, IPW, FULL> S;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS); attr = true; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), S::LDS, st, A);
+}
+template <int TPW, int IPW, bool ROW, bool FULL = false> static void launch_wgrad(hipStream_t st, const WgradArgs& A, int grid) {
+  if (A.dy_half) launch_wgrad_t<TPW, IPW, ROW, FULL, true>(st, A, grid);
+  else launch_wgrad_t<TPW, IPW, ROW, FULL, false>(st, A, grid);
 }
 bool wgrad(hipStream_t st, const WgradArgs& A0, int grid) {
   if (!wgrad_supported(A0) || grid < 1) return false;
@@ -1032,6 +1054,10 @@ bool wgrad(hipStream_t st, const WgradArgs& A0, int grid) {
     if (NT % 8 == 0) launch_wgrad<8, 4, true, true>(st, A, grid); else launch_wgrad<8, 4, false, true>(st, A, grid);
     return true;
   }
+  if (tpw == 8 && ipw == 2 && ninstr == 16) {                       // 256 x 256, f16 X and bf16 dY: no idle DMA instruction
+    if (NT % 8 == 0) launch_wgrad<8, 2, true, true>(st, A, grid); else launch_wgrad<8, 2, false, true>(st, A, grid);
+    return true;
+  }
   if (tpw == 8 && ipw == 3 && ninstr == 24) {                       // 256 x 256, f16 X: no idle DMA instruction, four stages next to two images
     if (NT % 8 == 0) launch_wgrad<8, 3, true, true>(st, A, grid); else launch_wgrad<8, 3, false, true>(st, A, grid);
     return true;
@@ -1040,7 +1066,7 @@ bool wgrad(hipStream_t st, const WgradArgs& A0, int grid) {
   NERFDS_WG(1, 1) NERFDS_WG(1, 2) NERFDS_WG(1, 4)
   NERFDS_WG(2, 2) NERFDS_WG(2, 4)
   NERFDS_WG(4, 2) NERFDS_WG(4, 3) NERFDS_WG(4, 4)
-  NERFDS_WG(8, 3) NERFDS_WG(8, 4)
+  NERFDS_WG(8, 2) NERFDS_WG(8, 3) NERFDS_WG(8, 4)
 #undef NERFDS_WG
   return false;
 }

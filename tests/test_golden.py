@@ -66,19 +66,27 @@ def test_train_oracle_reproduces_golden():
     assert abs(norm - float(z['norm/' + name])) <= 1e-10 * max(norm, 1e-30)
 
 
-MAX_TOL, NORM_TOL = 2e-3, 5e-4
+# fp32 g arrays (NERFDS_TRAIN_G16=0) / bf16 g arrays (the default): measured 3.3e-4 / 6.1e-5 and 3.4e-3 / 7.5e-4
+TOLS = {False: (2e-3, 5e-4), True: (7e-3, 1.5e-3)}
 
 
 @pytest.mark.gpu
-def test_hip_training_step_matches_golden():
+@pytest.mark.parametrize('g16', [False, True])
+def test_hip_training_step_matches_golden(g16, monkeypatch):
   """The HIP training step against COMMITTED gradient digests (the oracle is not run): per leaf a seeded subsample of
   256 entries, the L2 norm and the max-abs value of the fp64 autograd gradient.  The trainer's layers are hand-written
   split-bf16 MFMA kernels (tests/test_training.py).  Measured in round 3 with the fused backward (activations as f16 + ReLU bits,
   data gradient chained in registers): worst max-abs 3.3e-4 of the leaf maximum, worst norm 6.1e-5 - bounds MAX_TOL / NORM_TOL are
   a few times that (the float atomics of the weight-gradient sums reorder from run to run).  Round 2's layer-by-layer backward
   needed 1e-1 / 3e-2 here; what it lost is what a round trip of every dX through fp32 HBM arrays and a second rounding to split
-  bf16 costs on the ill-conditioned posenc backward of this trained-regime case."""
+  bf16 costs on the ill-conditioned posenc backward of this trained-regime case.
+  g16=True is the shipped default: the chains hand g to the weight-gradient kernels as bf16 (half the bytes, two MFMAs per product).  On
+  this 16-ray case the 8-bit rounding shows in the cancelling column sums (bias gradients of the warp field: 3.4e-3 / 7.5e-4, ten times the
+  fp32-g figure, still 30x inside round 2's bounds); it averages down with the row count (the 19 200-row gradient test of
+  tests/test_training.py holds its fp32-era bounds in this mode).  g16=False keeps the chain arithmetic pinned at the tight bounds."""
   from nerfds_amd.training import Trainer
+  monkeypatch.setenv('NERFDS_TRAIN_G16', '1' if g16 else '0')
+  MAX_TOL, NORM_TOL = TOLS[g16]
   gemm = 'mfma'
   from nerfds_amd.params import tree_leaves
   z = np.load(os.path.join(HERE, 'golden', 'train_' + G.TRAIN_CASE + '.npz'))

@@ -423,16 +423,27 @@ def test_gradients_match_the_oracle_at_multi_tile_size(full):
 
 
 @pytest.mark.gpu
-def test_fused_backward_chain_against_numpy_on_the_step_buffers():
+@pytest.mark.parametrize('g16', [False, True])
+def test_fused_backward_chain_against_numpy_on_the_step_buffers(g16, monkeypatch):
   """Kernel-level pin of the fused backward (render_kernel.hip train_backward_kernel) on the buffers of one step, read back through
   nerfds_trainer_debug_read: the forward's ReLU bits equal (f16 activation > 0) bit for bit; the first two links of the NerfMLP
   chain - g_rgb = 1[h_rgb > 0] (d rgb_logit W_rgb^T) and g_7 = 1[h_7 > 0] (g_rgb F^T + d alpha W_alpha^T), F = the bottleneck folded
   into rgb hidden_0 - and the input gradient d_trunk_in = g_0 W_0^T + g_4 W_4[raw-input rows]^T equal a float64 numpy evaluation of
-  the same expressions on the same inputs to split-bf16 accuracy."""
+  the same expressions on the same inputs to split-bf16 accuracy.  g16=False (NERFDS_TRAIN_G16=0): the chains write g as fp32, which pins
+  the chain arithmetic at 1e-4; g16=True (the default): the g arrays are the bf16 copies the weight-gradient kernels read - every element
+  within half a bf16 ulp (2^-9) of the float64 value, while the input gradient (from the registers, never rounded) stays at 1e-4 of its own
+  float64 value when that is computed from fp32-grade g (here: from the float64 chain)."""
   from nerfds_amd.training import Trainer
+  monkeypatch.setenv('NERFDS_TRAIN_G16', '1' if g16 else '0')
   R, Nc = 37, 8                                          # 296 rows: three 128-row workgroup iterations, a ragged tail
   cfg, params, batch, t, u = _problem(R, Nc, 0)
   tr = Trainer(cfg, params, max_rays=R)
+
+  def read_g(name, shape):
+    if not g16:
+      return tr.debug_read(name, shape).astype(np.float64)
+    return (tr.debug_read(name, shape, np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+  gtol = 2.0 ** -8 if g16 else 1e-4
   tr.step(batch, EX, 0.0, t_rand=t, mask_ratio=1.0, grads_only=True)
   M = R * Nc
 
@@ -453,18 +464,19 @@ def test_fused_backward_chain_against_numpy_on_the_step_buffers():
   d_alpha = tr.debug_read('d_alpha', (M, 4)).astype(np.float64)
   Wr = np.asarray(P['rgb_mlp']['logit']['kernel'], np.float64)
   want_rgb = (d_rgb @ Wr.T) * (h_rgb > 0)
-  got_rgb = tr.debug_read('rgb_g', (M, 128))
-  assert np.abs(got_rgb - want_rgb).max() <= 1e-4 * np.abs(want_rgb).max()
+  got_rgb = read_g('rgb_g', (M, 128))
+  assert np.abs(got_rgb - want_rgb).max() <= gtol * np.abs(want_rgb).max()
   K = np.asarray(P['rgb_mlp']['hidden_0']['kernel'], np.float64)      # rows [bottleneck 256 | viewdir 24 | trunk_out 256 | normal 24]
   F = np.asarray(P['bottleneck']['kernel'], np.float64) @ K[:256] + K[280:536]
   Wa = np.asarray(P['alpha_mlp']['logit']['kernel'], np.float64)
   want7 = (want_rgb @ F.T + d_alpha @ Wa.T) * (h7 > 0)
-  got7 = tr.debug_read('trunk_g_7', (M, 256))
-  assert np.abs(got7 - want7).max() <= 1e-4 * np.abs(want7).max()
+  got7 = read_g('trunk_g_7', (M, 256))
+  assert np.abs(got7 - want7).max() <= gtol * np.abs(want7).max()
   # the input gradient of a chain: d_trunk_in = g_0 W_0^T + g_4 W_4[256:]^T
-  g0, g4 = tr.debug_read('trunk_g_0', (M, 256)).astype(np.float64), tr.debug_read('trunk_g_4', (M, 256)).astype(np.float64)
+  g0, g4 = read_g('trunk_g_0', (M, 256)), read_g('trunk_g_4', (M, 256))
   W0 = np.asarray(P['trunk_mlp']['hidden_0']['kernel'], np.float64)
   W4 = np.asarray(P['trunk_mlp']['hidden_4']['kernel'], np.float64)
   want_in = g0 @ W0.T + g4 @ W4[256:].T
   got_in = tr.debug_read('d_trunk_in', (M, 52))
-  assert np.abs(got_in - want_in).max() <= 1e-4 * np.abs(want_in).max()
+  # (g16: want_in is built from the ROUNDED copies of g_0 / g_4 while the kernel used its registers: 2^-9 per term, averaging down)
+  assert np.abs(got_in - want_in).max() <= (1e-4 if not g16 else 2e-3) * np.abs(want_in).max()
