@@ -410,6 +410,16 @@ struct Cursor {
 };
 // Training forward (train_forward_kernel below): every hidden layer also writes its fp32 post-activation output to HBM, row-major
 // [sample][width], for the backward pass.  `row` = this lane's sample row of the layer being computed, + 4 * (lane >> 5) floats.
+// TrainOut::half_out / TrainBwd::g_half stay RUN-TIME tests (a uniform branch per tile pair) on purpose.  -DNERFDS_TRAIN_HALF=0/1 makes them
+// compile-time facts: measured (two translation units, dispatch at launch) the forward got SLOWER, 3.39 -> 4.07 ms on the fine level - without
+// the branch a tile group is no longer its own scheduling region, hipcc interleaves the groups, register pressure goes from 12 to 46 spilled
+// VGPRs (176 B of scratch in the streaming loop) - and the step's loss came out different (not chased).  The branch is a scheduling fence
+// that this kernel needs, like the one after each 16-feature input chunk.
+#ifdef NERFDS_TRAIN_HALF
+#define NERFDS_HALF_TEST(c) (NERFDS_TRAIN_HALF != 0)
+#else
+#define NERFDS_HALF_TEST(c) ((c).half != 0)
+#endif
 struct TrainCursor : Cursor {
   float* row;
   // TrainOut::half_out: the layer goes out as f16 [sample][width] (`row16` = this lane's row + 4 * (lane >> 5) halves) plus one
@@ -450,6 +460,36 @@ template <bool RELU> DEVI void store_tile(float* row_tile, const f32x16& acc) {
 // 8-byte stores; returns the tile's 16 ReLU bits, bit r <-> register r.  Two VALU per bit: the relu'd value has non-negative integer
 // bits, so 0 - bits is negative exactly when the output is > 0, and v_alignbit shifts that sign bit in (registers 15 .. 0).
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+// A tile of 16-bit values (f16 activations, bf16 g): pk[2g], pk[2g + 1] = this lane's features 8g + 4h + 0..3 of its sample, as packed pairs.
+// NERFDS_STORE16_WIDE: the two lanes of a sample (l, l + 32) trade halves with v_permlane32_swap - afterwards lane half h owns features
+// 16h .. 16h + 15 of the tile - and each lane writes TWO 16-byte pieces instead of four 8-byte ones (`row16` then points at the lane's
+// feature 16h of tile 0, not 4h).  A training kernel runs one wave per SIMD and a global store occupies the wave for its whole issue
+// (address + data transfer of 64 lanes), MFMA pipe idle: what the stores cost is their NUMBER, not their bytes.
+#ifndef NERFDS_STORE16_WIDE
+#define NERFDS_STORE16_WIDE 1
+#endif
+constexpr int ROW16_H = NERFDS_STORE16_WIDE ? 16 : 4;      // offset of lane half 1 in a row of 16-bit features
+DEVI void store_tile_pk16(uint16_t* row_tile, const unsigned (&pk)[8]) {
+#if NERFDS_STORE16_WIDE && defined(__HIP_DEVICE_COMPILE__)
+  unsigned x[4], y[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // swaps pk[i] of lanes 32..63 with pk[4 + i] of lanes 0..31: half 0 ends with (own, partner's) features of groups 0 and 1, half 1 with
+    // (partner's, own) features of groups 2 and 3
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(pk[i], pk[4 + i], false, false);
+    x[i] = r[0]; y[i] = r[1];
+  }
+  const u32x4 s0 = {x[0], x[1], y[0], y[1]}, s1 = {x[2], x[3], y[2], y[3]};
+  *reinterpret_cast<u32x4*>(row_tile) = s0;
+  *reinterpret_cast<u32x4*>(row_tile + 8) = s1;
+#else
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const u32x2 v = {pk[2 * g], pk[2 * g + 1]};
+    *reinterpret_cast<u32x2*>(row_tile + 8 * g) = v;
+  }
+#endif
+}
 template <bool RELU> DEVI unsigned store_tile_half(uint16_t* row_tile, const f32x16& acc) {
   unsigned bits = 0;
   float v[16];
@@ -460,26 +500,26 @@ template <bool RELU> DEVI unsigned store_tile_half(uint16_t* row_tile, const f32
     const unsigned neg = 0u - __builtin_bit_cast(unsigned, v[r]);
     bits = __builtin_amdgcn_alignbit(bits, neg, 31);                              // (bits << 1) | (neg >> 31)
   }
+  unsigned pk[8];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const _Float16 h0 = (_Float16)v[4 * g], h1 = (_Float16)v[4 * g + 1], h2 = (_Float16)v[4 * g + 2], h3 = (_Float16)v[4 * g + 3];
-    u32x2 pk;
-    pk[0] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-    pk[1] = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
-    *reinterpret_cast<u32x2*>(row_tile + 8 * g) = pk;
+    pk[2 * g] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    pk[2 * g + 1] = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
   }
+  store_tile_pk16(row_tile, pk);
   return bits;
 }
 // The same tile as bf16 (round to nearest even, fp32 range): four 8-byte stores.  The g arrays of the fused backward (TrainBwd::g_half).
 DEVI void store_tile_bf16(uint16_t* row_tile, const f32x16& acc) {
+  unsigned pk[8];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const __bf16 h0 = (__bf16)acc[4 * g], h1 = (__bf16)acc[4 * g + 1], h2 = (__bf16)acc[4 * g + 2], h3 = (__bf16)acc[4 * g + 3];
-    u32x2 pk;
-    pk[0] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-    pk[1] = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
-    *reinterpret_cast<u32x2*>(row_tile + 8 * g) = pk;
+    pk[2 * g] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    pk[2 * g + 1] = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
   }
+  store_tile_pk16(row_tile, pk);
 }
 // Fused backward: zero the accumulator registers whose ReLU bit is clear.  (Written as a select on purpose: the 2-VALU form
 // "x & sign-extended bit" through __builtin_amdgcn_sbfe on this (shifted, masked) operand is folded wrongly by hipcc 7.2 - every
@@ -910,7 +950,7 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Carry<NT>& carry, Chunk<PO> (&out)[
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) {
           apply_mask(acc[tp][0], (cur.mask[(ot + tp) >> 1] >> (16 * ((ot + tp) & 1))) & 0xffffu);
-          if (cur.half) store_tile_bf16(cur.row16 + 32 * (ot + tp), acc[tp][0]);      // wave-uniform (a kernel argument)
+          if (NERFDS_HALF_TEST(cur)) store_tile_bf16(cur.row16 + 32 * (ot + tp), acc[tp][0]);
           else store_tile<false>(cur.row + 32 * (ot + tp), acc[tp][0]);
         }
 #pragma unroll
@@ -931,7 +971,7 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Carry<NT>& carry, Chunk<PO> (&out)[
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) tile_epilogue<PO, NT, RELU>(out, ot + tp, acc[tp]);
         if constexpr (TRAIN) {
-          if (cur.half) {                                      // wave-uniform (a kernel argument)
+          if (NERFDS_HALF_TEST(cur)) {
             unsigned two = 0;
 #pragma unroll
             for (int tp = 0; tp < TP; ++tp) two |= store_tile_half<RELU>(cur.row16 + 32 * (ot + tp), acc[tp][0]) << (16 * tp);
@@ -1189,7 +1229,7 @@ template <int NT> struct Samples {
 };
 
 #define NERFDS_TRAIN_ROW(base, base16, bits, W) do { if constexpr (TO::ON) set_row(cur, (base) + row * (size_t)(W) + 4 * h, \
-    (base16) + row * (size_t)(W) + 4 * h, (bits) + (row * 2 + h) * (size_t)((W) / 32), to.half_out); } while (0)
+    (base16) + row * (size_t)(W) + ROW16_H * h, (bits) + (row * 2 + h) * (size_t)((W) / 32), to.half_out); } while (0)
 #define NERFDS_TRAIN_HEAD(base, n) do { if constexpr (TO::ON) { _Pragma("unroll") for (int j_ = 0; j_ < (n); ++j_) (base)[row * (n) + j_] = hacc[0][0][j_]; } } while (0)
 
 // ---- The level-independent networks on one batch of 32 * NT samples: MaskMLP -> SE(3) field + exp_se3 -> hyper sheet.
@@ -2010,7 +2050,7 @@ DEVI void bwd_hidden(Pipe<BG, PL>& pipe, BwdCursor& cur, Carry<1>& carry, const 
 #pragma unroll
   for (int j = 0; j < OT / 2; ++j) cur.mask[j] = m[j];
   cur.row = g_base + g_off;                                        // fp32 [M][width] ...
-  cur.row16 = reinterpret_cast<uint16_t*>(g_base) + g_off;         // ... or bf16 [M][width] in the same buffer (cur.half)
+  cur.row16 = reinterpret_cast<uint16_t*>(g_base) + g_off + (ROW16_H / 4 - 1) * cur.in_h4;   // ... or bf16 [M][width] in the same buffer (cur.half)
   dense<BG, PL, 1, OT, false>(pipe, cur, carry, out, ins...);
 }
 template <class BG, class PL, int P, int K>
