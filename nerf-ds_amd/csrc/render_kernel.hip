@@ -500,30 +500,29 @@ template <bool RELU> DEVI unsigned store_tile_half(uint16_t* row_tile, const f32
     const unsigned neg = 0u - __builtin_bit_cast(unsigned, v[r]);
     bits = __builtin_amdgcn_alignbit(bits, neg, 31);                              // (bits << 1) | (neg >> 31)
   }
-  unsigned pk[8];
+  // (as vectors, like make_chunk<P_F16>: one v_cvt_pk_f16_f32 per pair; scalar converts + shift + or took three VALU per pair)
+  f16x8 a, b;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const _Float16 h0 = (_Float16)v[4 * g], h1 = (_Float16)v[4 * g + 1], h2 = (_Float16)v[4 * g + 2], h3 = (_Float16)v[4 * g + 3];
-    pk[2 * g] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-    pk[2 * g + 1] = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
-  }
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)v[i]; b[i] = (_Float16)v[8 + i]; }
+  const u32x4 pa = __builtin_bit_cast(u32x4, a), pb = __builtin_bit_cast(u32x4, b);
+  const unsigned pk[8] = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3]};
   store_tile_pk16(row_tile, pk);
   return bits;
 }
-// The same tile as bf16 (round to nearest even, fp32 range): four 8-byte stores.  The g arrays of the fused backward (TrainBwd::g_half).
-DEVI void store_tile_bf16(uint16_t* row_tile, const f32x16& acc) {
-  unsigned pk[8];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const __bf16 h0 = (__bf16)acc[4 * g], h1 = (__bf16)acc[4 * g + 1], h2 = (__bf16)acc[4 * g + 2], h3 = (__bf16)acc[4 * g + 3];
-    pk[2 * g] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-    pk[2 * g + 1] = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
-  }
+// The g arrays of the fused backward as bf16 (TrainBwd::g_half).
+// The tile's two chunks in split bf16 are what the next (earlier) layer multiplies; their hi parts - bf16(acc[0..7]), bf16(acc[8..15]),
+// round to nearest even - ARE the bf16 copy of g: no second conversion, no packing.
+DEVI void store_tile_bf16(uint16_t* row_tile, const Chunk<P_BF16X3>& c0, const Chunk<P_BF16X3>& c1) {
+  const u32x4 pa = __builtin_bit_cast(u32x4, c0.hi), pb = __builtin_bit_cast(u32x4, c1.hi);
+  const unsigned pk[8] = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3]};
   store_tile_pk16(row_tile, pk);
 }
 // Fused backward: zero the accumulator registers whose ReLU bit is clear.  (Written as a select on purpose: the 2-VALU form
 // "x & sign-extended bit" through __builtin_amdgcn_sbfe on this (shifted, masked) operand is folded wrongly by hipcc 7.2 - every
 // register came out as register 0's value; found with tools/chain_diag.py.)
+// (Round 3 tried the two-VALU form again with the bit field as an opaque asm - v_bfe_i32, then `bits(acc[r]) & m` in C++: the SAME misfold,
+// every register anded with register 0 - so the fold is in `extractelement + bitcast + and`, not in sbfe.  The chains are not VALU-bound
+// anyway: 35 % fewer VALU per MFMA in them changed their time by +-0.)
 DEVI void apply_mask(f32x16& acc, unsigned bits16) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = ((bits16 >> r) & 1u) ? acc[r] : 0.f;
@@ -950,11 +949,16 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Carry<NT>& carry, Chunk<PO> (&out)[
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) {
           apply_mask(acc[tp][0], (cur.mask[(ot + tp) >> 1] >> (16 * ((ot + tp) & 1))) & 0xffffu);
-          if (NERFDS_HALF_TEST(cur)) store_tile_bf16(cur.row16 + 32 * (ot + tp), acc[tp][0]);
-          else store_tile<false>(cur.row + 32 * (ot + tp), acc[tp][0]);
+          if (!NERFDS_HALF_TEST(cur)) store_tile<false>(cur.row + 32 * (ot + tp), acc[tp][0]);
         }
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) tile_epilogue<PO, NT, false>(out, ot + tp, acc[tp]);
+        if constexpr (PO == P_BF16X3) {
+          if (NERFDS_HALF_TEST(cur)) {
+#pragma unroll
+            for (int tp = 0; tp < TP; ++tp) store_tile_bf16(cur.row16 + 32 * (ot + tp), out[0][2 * (ot + tp)], out[0][2 * (ot + tp) + 1]);
+          }
+        }
       } else if constexpr (ASM_EPI) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -1228,8 +1232,16 @@ template <int NT> struct Samples {
   int slot[NT];
 };
 
+#ifdef NERFDS_EXP_PAGES
+// TIMING EXPERIMENT ONLY (wrong results): every 16-bit store of a wave lands in ONE 128-KiB region per wave instead of in ~70 arrays that lie
+// gigabytes apart - what a [32-sample block][layer] layout of the activations would do to the address translation of the stores.
+#define NERFDS_TRAIN_ROW(base, base16, bits, W) do { if constexpr (TO::ON) { uint16_t* c_ = to.trunk_h16[0] + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 65536; \
+    set_row(cur, (base) + row * (size_t)(W) + 4 * h, c_ + (((size_t)(base16) >> 21) & 7) * 8192 + (lane & 31) * (W) + ROW16_H * h, \
+            c_ + 61440 + ((lane & 31) * 2 + h) * 8, to.half_out); } } while (0)
+#else
 #define NERFDS_TRAIN_ROW(base, base16, bits, W) do { if constexpr (TO::ON) set_row(cur, (base) + row * (size_t)(W) + 4 * h, \
     (base16) + row * (size_t)(W) + ROW16_H * h, (bits) + (row * 2 + h) * (size_t)((W) / 32), to.half_out); } while (0)
+#endif
 #define NERFDS_TRAIN_HEAD(base, n) do { if constexpr (TO::ON) { _Pragma("unroll") for (int j_ = 0; j_ < (n); ++j_) (base)[row * (n) + j_] = hacc[0][0][j_]; } } while (0)
 
 // ---- The level-independent networks on one batch of 32 * NT samples: MaskMLP -> SE(3) field + exp_se3 -> hyper sheet.
