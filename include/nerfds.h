@@ -279,7 +279,8 @@ int nerfds_trainer_reset_optimizer(nerfds_trainer* t);   /* zero the Adam moment
 /* Development / tests: HOST copy of an internal device buffer of the last step (the f16 activations, ReLU bits and per-layer
  * gradients g_l of the fused backward, the head / input gradients): "<net>_h16_<l>", "<net>_bits_<l>", "<net>_g_<l>" with net = mask |
  * warp | hyper | trunk, "rgb_h16", "rgb_bits", "rgb_g", "d_rgb_logit", "d_alpha", "d_trunk_in", "d_hyper_in", "d_warp_in",
- * "d_mask_in", "dwamb", "dwv", "d_mask_logit".  Returns the bytes copied (= max_bytes) or a negative error code. */
+ * "d_mask_in", "dwamb", "dwv", "d_mask_logit".  The "<net>_g_<l>" / "rgb_g" arrays are bf16 [M][width] (2 bytes per element) unless the
+ * trainer was created under NERFDS_TRAIN_G16=0 (fp32).  Returns the bytes copied (= max_bytes) or a negative error code. */
 long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* host, long long max_bytes);
 int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* extra,
                         const nerfds_rand* rnd, const nerfds_train_objective* objective /* NULL = rgb loss only */, float learning_rate,

@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <cstdint>
 #include <vector>
 #include "train_gemm.h"
 using namespace nerfds_train;
@@ -113,6 +115,72 @@ int main(int argc, char** argv) {
     printf("wgrad M=%lld K=%d N=%d: %.3f ms  %.0f GB/s  max|err|=%.2e (max|dW|=%.1f)%s\n", M, w.k, w.n, ms, (double)M * (w.k + w.n) * 4 / ms / 1e6, worst, big,
            worst < 3e-5 * big ? "" : "  FAIL");
     (void)hipFree(x); (void)hipFree(dy); (void)hipFree(dw); (void)hipFree(zeros);
+  }
+  // ---- weight gradient with 16-bit operands: X as f16 (what the fused forward stores) and / or dY as bf16 (what the fused backward's chains
+  // store: a one-term operand, two MFMAs per product), and the bias gradient = column sums of dY as a by-product.  The reference is the fp64
+  // sum over the ROUNDED inputs, so the bound is the kernel's own arithmetic (split-bf16 products), not the storage format. ----
+  {
+    auto to_bf16 = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+    auto from_bf16 = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    struct HS { int k, n, xh; };
+    const HS hshapes[] = {{256, 256, 1}, {128, 128, 1}, {64, 64, 1}, {256, 128, 1}, {52, 256, 0}, {36, 128, 0}, {48, 64, 0}};
+    for (const HS& w : hshapes) {
+      void *x, *dy, *zeros; float *dw, *cs;
+      const int NREP = 16;
+      const size_t xe = w.xh ? 2 : 4;
+      (void)hipMalloc(&x, M * w.k * xe); (void)hipMalloc(&dy, M * w.n * 2); (void)hipMalloc(&dw, (size_t)NREP * (w.k * w.n + w.n) * 4); (void)hipMalloc(&zeros, 256);
+      cs = dw + (size_t)w.k * w.n;                              // replica layout [dW | colsum], stride k n + n
+      (void)hipMemset(zeros, 0, 256); (void)hipMemset(dw, 0, (size_t)NREP * (w.k * w.n + w.n) * 4);
+      (void)hipMemset(x, 0, M * w.k * xe); (void)hipMemset(dy, 0, M * w.n * 2);
+      const long long Mc = M < 4096 ? M : 4096;
+      std::vector<float> hx(Mc * w.k), hd(Mc * w.n);
+      std::vector<uint16_t> x16(w.k), d16(w.n);
+      for (long long j = 0; j < Mc; ++j) {
+        const long long r = j * M / Mc;
+        for (int k = 0; k < w.k; ++k) {
+          float v = frand();
+          if (w.xh) { const _Float16 h = (_Float16)v; memcpy(&x16[k], &h, 2); v = (float)h; }
+          hx[j * w.k + k] = v;
+        }
+        for (int n = 0; n < w.n; ++n) { d16[n] = to_bf16(frand()); hd[j * w.n + n] = from_bf16(d16[n]); }
+        if (w.xh) (void)hipMemcpy((char*)x + r * w.k * 2, x16.data(), w.k * 2, hipMemcpyHostToDevice);
+        else (void)hipMemcpy((char*)x + r * w.k * 4, hx.data() + j * w.k, w.k * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy((char*)dy + r * w.n * 2, d16.data(), w.n * 2, hipMemcpyHostToDevice);
+      }
+      WgradArgs A{(const float*)x, w.k, w.k, (const float*)dy, w.n, w.n, M, nullptr, dw, zeros, 0, 0, (long long)w.k * w.n + w.n, NREP};
+      A.x_half = w.xh; A.dy_half = 1; A.colsum = cs;
+      if (!wgrad_supported(A)) { printf("wgrad16 %d x %d not supported  FAIL\n", w.k, w.n); ++bad; continue; }
+      const int grid = wgrad_grid(A, prop.multiProcessorCount);
+      wgrad(nullptr, A, grid);
+      (void)hipDeviceSynchronize();
+      std::vector<float> hw(w.k * w.n + w.n, 0.f), hrep(w.k * w.n + w.n);
+      for (int rp = 0; rp < NREP; ++rp) {
+        (void)hipMemcpy(hrep.data(), dw + (size_t)rp * (w.k * w.n + w.n), hrep.size() * 4, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < hw.size(); ++i) hw[i] += hrep[i];
+      }
+      double worst = 0, big = 0, cworst = 0, cbig = 0;
+      for (int k = 0; k < w.k; ++k) for (int n = 0; n < w.n; ++n) {
+        double a = 0;
+        for (long long r = 0; r < Mc; ++r) a += (double)hx[r * w.k + k] * hd[r * w.n + n];
+        worst = std::fmax(worst, std::fabs(a - hw[k * w.n + n])); big = std::fmax(big, std::fabs(a));
+      }
+      for (int n = 0; n < w.n; ++n) {
+        double a = 0;
+        for (long long r = 0; r < Mc; ++r) a += hd[r * w.n + n];
+        cworst = std::fmax(cworst, std::fabs(a - hw[w.k * w.n + n])); cbig = std::fmax(cbig, std::fabs(a));
+      }
+      hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+      const int reps = 20;
+      (void)hipEventRecord(e0, nullptr);
+      for (int i = 0; i < reps; ++i) wgrad(nullptr, A, grid);
+      (void)hipEventRecord(e1, nullptr); (void)hipEventSynchronize(e1);
+      float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      const bool ok = worst < 3e-5 * big && cworst < 1e-5 * (cbig + Mc * 0.01);
+      if (!ok) ++bad;
+      printf("wgrad16 M=%lld K=%d (%s) N=%d (bf16): %.3f ms  %.0f GB/s  max|err|=%.2e (max|dW|=%.1f) colsum err %.2e%s\n", M, w.k, w.xh ? "f16" : "f32", w.n, ms,
+             (double)M * (w.k * xe + w.n * 2) / ms / 1e6, worst, big, cworst, ok ? "" : "  FAIL");
+      (void)hipFree(x); (void)hipFree(dy); (void)hipFree(dw); (void)hipFree(zeros);
+    }
   }
   // ---- fused backward of a narrow layer: dW += X^T dZ and dX = (dZ . W^T) . 1[X > 0] with its column sums ----
   struct FS { int k, n; };
