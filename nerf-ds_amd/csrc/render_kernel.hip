@@ -729,6 +729,10 @@ template <int P> DEVI void epilogue_piece_asm(unsigned& o0, unsigned& o1, float 
 #ifndef NERFDS_PIPE_EPI_X3
 #define NERFDS_PIPE_EPI_X3 0
 #endif
+// 1: the training kernels issue the epilogue of a tile group inside the next group's MFMA chain (dense(): TRAIN branch)
+#ifndef NERFDS_TRAIN_PIPE
+#define NERFDS_TRAIN_PIPE 0
+#endif
 #ifndef NERFDS_PIPE_J0
 #define NERFDS_PIPE_J0 2
 #endif
@@ -928,6 +932,73 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Carry<NT>& carry, Chunk<PO> (&out)[
     }
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp) tile_epilogue<PO, NT, RELU>(out, OT - TP + tp, prev[tp]);
+  } else if constexpr (TRAIN && !BWD_IN && NERFDS_TRAIN_PIPE && (OT > TP) && (BWD ? PO == P_BF16X3 : true)) {
+    // Training forward / backward chain, software-pipelined at the source level: the epilogue of tile group g - conversion into the next
+    // layer's operand, ReLU bits / mask, 16-bit stores - is cut into pieces that are issued between the MFMA steps of group g + 1 (the
+    // accumulators of group g rest in `prev`).  A training kernel runs ONE wave per SIMD: whatever is issued behind a group's last MFMA
+    // runs with the matrix pipe idle, whatever is issued between two MFMA steps of the next group runs under them.  The run-time
+    // `half` branch inside the store pieces keeps every piece in its own basic block, i.e. where it was put.
+    static_assert(TP == 2 && NT == 1, "pairs of tiles, one N-tile");
+    constexpr int SLOTS = TP * seg_total<Ins...>::value;       // MFMA steps per group
+    constexpr int NPIECE = 3 * TP + 1, J0 = 1;
+    constexpr int PPS = cdiv(NPIECE, SLOTS - J0 > 0 ? SLOTS - J0 : 1);
+    constexpr int IN_CHAIN = (SLOTS - J0) * PPS < NPIECE ? (SLOTS - J0 > 0 ? (SLOTS - J0) * PPS : 0) : NPIECE;
+    f32x16 prev[TP];
+    unsigned two = 0;
+    // piece q of the group whose first tile is `pot`: q = 3 tp + {0: chunk of registers 0-7, 1: chunk of registers 8-15, 2: store}, q = 3 TP: bits
+    auto piece = [&](int q, int pot) {
+      if (q < 3 * TP) {
+        const int tp = q / 3, sub = q % 3, t = pot + tp;
+        if (sub < 2) {
+          if constexpr (BWD) { if (sub == 0) apply_mask(prev[tp], (cur.mask[t >> 1] >> (16 * (t & 1))) & 0xffffu); }
+          float x[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) x[i] = prev[tp][8 * sub + i];
+          make_act_chunk<PO, RELU>(out[0][2 * t + sub], x);
+        } else if constexpr (BWD) {
+          if (NERFDS_HALF_TEST(cur)) store_tile_bf16(cur.row16 + 32 * t, out[0][2 * t], out[0][2 * t + 1]);
+          else store_tile<false>(cur.row + 32 * t, prev[tp]);
+        } else {
+          if (NERFDS_HALF_TEST(cur)) two |= store_tile_half<RELU>(cur.row16 + 32 * t, prev[tp]) << (16 * tp);
+          else store_tile<RELU>(cur.row + 32 * t, prev[tp]);
+        }
+      } else if constexpr (!BWD) {
+        if (NERFDS_HALF_TEST(cur)) { *reinterpret_cast<unsigned*>(cur.bits + pot) = two; two = 0; }
+      }
+    };
+#pragma unroll
+    for (int ot = 0; ot < OT; ot += TP) {
+      f32x16 acc[TP][NT];
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) {
+        if constexpr (BWD) acc[tp][0] = f32x16{};
+        else acc[tp][0] = load_bias(cur.bt + ot + tp, hb);
+      }
+      int j = 0;
+      auto slot = [&](int jj, int) {
+        if (ot == 0 || jj < J0) return;
+#pragma unroll
+        for (int q = (jj - J0) * PPS; q < (jj - J0 + 1) * PPS; ++q)
+          if (q < NPIECE) piece(q, ot - TP);
+      };
+      (accum<G, PL, NT, TP>(acc, pipe, cur, ins, j, slot), ...);
+      if (ot > 0) {
+#pragma unroll
+        for (int q = IN_CHAIN; q < NPIECE; ++q) piece(q, ot - TP);      // pieces the chain had no step for (short inputs)
+      }
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) prev[tp] = acc[tp][0];
+#if defined(NERFDS_TRAIN_HALF) && defined(__HIP_DEVICE_COMPILE__)
+      // with `half` a compile-time fact nothing else separates the groups: one scheduling region per group (its MFMAs + the previous
+      // group's epilogue), so that hipcc interleaves THOSE and does not pull later groups' work - and their registers - forward
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+#pragma unroll
+    for (int q = 0; q < NPIECE; ++q) piece(q, OT - TP);                 // the layer's last group: behind its own chain
+#if defined(NERFDS_TRAIN_HALF) && defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   } else {
 #pragma unroll
     for (int ot = 0; ot < OT; ot += TP) {
