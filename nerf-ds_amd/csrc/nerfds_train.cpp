@@ -26,9 +26,11 @@
 #include "pack.h"
 
 // render_kernel.hip compiled with -DNERFDS_TRAIN_FWD: the fused forward of one level (TRAIN_PLAN arithmetic)
-extern "C" void nerfds_launch_train_fwd_nerfds(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream);
+extern "C" void nerfds_launch_train_fwd_nerfds(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream);     // fp32 activations
+extern "C" void nerfds_launch_train_fwd16_nerfds(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream);   // f16 + ReLU bits
 // render_kernel.hip compiled with -DNERFDS_TRAIN_BWD: the data-gradient chain of one network (0 NerfMLP, 1 hyper sheet, 2 warp, 3 mask)
-extern "C" void nerfds_launch_train_bwd_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);
+extern "C" void nerfds_launch_train_bwd_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);      // g as fp32
+extern "C" void nerfds_launch_train_bwd16_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);    // g as bf16
 
 using namespace nerfds_train;
 
@@ -711,7 +713,8 @@ void fused_backward(nerfds_trainer& t, hipStream_t st, int net, int level, int64
   else if (net == 2) { tb.wstream = t.bstream[3]; bits = &t.warp_bits; g = &t.warp_h; }
   else { tb.wstream = t.bstream[4]; bits = &t.mask_bits; g = &t.mask_h; }
   for (size_t l = 0; l < bits->size(); ++l) { tb.bits[l] = (*bits)[l]; tb.g[l] = (*g)[l]; }
-  nerfds_launch_train_bwd_nerfds(tb, net, t.num_cus, st);
+  if (tb.g_half) nerfds_launch_train_bwd16_nerfds(tb, net, t.num_cus, st);
+  else nerfds_launch_train_bwd_nerfds(tb, net, t.num_cus, st);
 }
 
 void fused_forward(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const float* z, const nerfds_rays* rays, const nerfds_extra* ex, const Windows& W) {
@@ -736,7 +739,8 @@ void fused_forward(nerfds_trainer& t, hipStream_t st, int level, int R, int S, c
     for (int l = 0; l < 6; ++l) { to.warp_h16[l] = t.warp_h16[l]; to.warp_bits[l] = t.warp_bits[l]; to.hyper_h16[l] = t.hyper_h16[l]; to.hyper_bits[l] = t.hyper_bits[l]; }
     to.rgb_h16 = t.rgb_h16; to.rgb_bits = t.rgb_bits;
   }
-  nerfds_launch_train_fwd_nerfds(ka, to, t.num_cus, st);
+  if (to.half_out) nerfds_launch_train_fwd16_nerfds(ka, to, t.num_cus, st);
+  else nerfds_launch_train_fwd_nerfds(ka, to, t.num_cus, st);
 }
 
 int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const float* z, const nerfds_rays* rays, const float* target,

@@ -410,11 +410,21 @@ struct Cursor {
 };
 // Training forward (train_forward_kernel below): every hidden layer also writes its fp32 post-activation output to HBM, row-major
 // [sample][width], for the backward pass.  `row` = this lane's sample row of the layer being computed, + 4 * (lane >> 5) floats.
-// TrainOut::half_out / TrainBwd::g_half stay RUN-TIME tests (a uniform branch per tile pair) on purpose.  -DNERFDS_TRAIN_HALF=0/1 makes them
-// compile-time facts: measured (two translation units, dispatch at launch) the forward got SLOWER, 3.39 -> 4.07 ms on the fine level - without
-// the branch a tile group is no longer its own scheduling region, hipcc interleaves the groups, register pressure goes from 12 to 46 spilled
-// VGPRs (176 B of scratch in the streaming loop) - and the step's loss came out different (not chased).  The branch is a scheduling fence
-// that this kernel needs, like the one after each 16-feature input chunk.
+// TrainOut::half_out / TrainBwd::g_half: the Makefile builds every training kernel twice, -DNERFDS_TRAIN_HALF=0 (fp32 stores: the steps with a
+// tangent pass, NERFDS_TRAIN_G16=0) and =1 (f16 + ReLU bits / bf16 g: the plain step), and the host picks the launcher.  As a run-time test
+// (a uniform branch per tile pair) `half` cuts every tile group into its own basic blocks, and hipcc schedules within a block.  Compile-time
+// `half` alone is neutral (15.81 against 15.88 ms per step); together with the source-level pipeline of dense()'s TRAIN branch and one explicit
+// scheduling region per group (sched_barrier) it is 15.58 (profiles/r3_ab/ab_tph.txt).  Without the macro (development builds) the run-time
+// test remains.
+// NERFDS_TRAIN_TAG is a template argument of the training kernels: two translation units that build the SAME template with different
+// macros would otherwise emit one mangled kernel name with two bodies, and the runtime binds both launchers to ONE of them (this cost
+// round 3 a wrong conclusion: the first two-build attempt silently ran the fp32-store kernel for both modes - a step that barely
+// learns, loss 0.17302 instead of 0.1674 - and looked like "compile-time half is slower").
+#ifdef NERFDS_TRAIN_HALF
+#define NERFDS_TRAIN_TAG (1 + (NERFDS_TRAIN_HALF != 0) + 2 * (NERFDS_TRAIN_PIPE != 0))
+#else
+#define NERFDS_TRAIN_TAG 0
+#endif
 #ifdef NERFDS_TRAIN_HALF
 #define NERFDS_HALF_TEST(c) (NERFDS_TRAIN_HALF != 0)
 #else
@@ -2033,7 +2043,7 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
 // compositing here: the loss kernel composites from sigma / rgb (train_kernels.hip).  The host passes the level's NerfMLP
 // stream and biases in slot 1, so the kernel always evaluates "level 0".
 // ------------------------------------------------------------------------------------------------
-template <class G, class PL, bool WIDE>
+template <class G, class PL, bool WIDE, int TAG>
 __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train_forward_kernel(const KArgs ka, const TrainOut to) {
   using SH = Shape<PL, WIDE>;
   using WaveLds = WaveLdsT<SH::MAXS>;
@@ -2196,7 +2206,7 @@ DEVI void bwd_chain(const TrainBwd& tb, Pipe<BG, PL>& pipe, int lane, long long 
   pipe.finish_segment(SEG_NERF);
 }
 
-template <class BG, class PL>
+template <class BG, class PL, int TAG>
 __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train_backward_kernel(const TrainBwd tb) {
   using PP = Pipe<BG, PL>;
   static_assert(wg_waves<PL>() == 4 && !PP::HAS_SHARED, "one 512-register wave per SIMD, one stream");
@@ -2243,7 +2253,7 @@ template <class BG> static void launch_bwd(const nerfds::TrainBwd& tb, int num_c
   using namespace nerfds;
   using PLX = PlanT<P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3>;
   static bool attr_set = false;
-  auto kern = train_backward_kernel<BG, PLX>;
+  auto kern = train_backward_kernel<BG, PLX, NERFDS_TRAIN_TAG>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES);
     attr_set = true;
@@ -2256,7 +2266,7 @@ template <class BG> static void launch_bwd(const nerfds::TrainBwd& tb, int num_c
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wg_waves<PLX>()), RING_BYTES, static_cast<hipStream_t>(stream), tb);
 }
 // net: 0 NerfMLP (trunk + rgb branch + alpha head), 1 hyper sheet, 2 warp field, 3 mask net
-extern "C" void nerfds_launch_train_bwd_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream) {
+extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream) {
   using G = nerfds::NERFDS_GRAPH;
   if (net == 0) launch_bwd<nerfds::BwdNerf<G>>(tb, num_cus, stream);
   else if (net == 1) launch_bwd<nerfds::BwdHyper<G>>(tb, num_cus, stream);
@@ -2270,7 +2280,7 @@ template <bool WIDE> static void launch_train(const nerfds::KArgs& ka, const ner
   constexpr int lds = BIAS_OFF + bias_bytes<NERFDS_GRAPH>() + SH::RAYS * (int)sizeof(WaveLdsT<SH::MAXS>);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = train_forward_kernel<NERFDS_GRAPH, KernelPlan, WIDE>;
+  auto kern = train_forward_kernel<NERFDS_GRAPH, KernelPlan, WIDE, NERFDS_TRAIN_TAG>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;

@@ -11,8 +11,10 @@ for g in nerfds:GraphNerfDS static:GraphStatic hyper:GraphHyperNeRF; do for p in
   /opt/rocm/bin/hipcc $FL $XF $MIXFLAGS -DNERFDS_GRAPH=${g#*:} -DNERFDS_PREC=${p#*:} -DNERFDS_NAME=$n -o build/asm/$n.s 2>/dev/null &
   jobs_n=$((jobs_n + 1)); if [ $jobs_n -ge 8 ]; then wait -n; jobs_n=$((jobs_n - 1)); fi
 done; done
-/opt/rocm/bin/hipcc $FL -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_TRAIN_FWD -DNERFDS_NAME=train_fwd_nerfds -o build/asm/train_fwd.s 2>/dev/null &
-/opt/rocm/bin/hipcc $FL -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_TRAIN_BWD -DNERFDS_NAME=train_bwd_nerfds -o build/asm/train_bwd.s 2>/dev/null &
+for h in 0:"" 1:16; do hv=${h%%:*}; sfx=${h#*:}; TF="-DNERFDS_TRAIN_HALF=$hv"; [ $hv = 1 ] && TF="$TF -DNERFDS_TRAIN_PIPE=1"       # the Makefile's two builds of each
+  /opt/rocm/bin/hipcc $FL $TF -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_TRAIN_FWD -DNERFDS_NAME=train_fwd${sfx}_nerfds -o build/asm/train_fwd$sfx.s 2>/dev/null &
+  /opt/rocm/bin/hipcc $FL $TF -DNERFDS_GRAPH=GraphNerfDS -DNERFDS_TRAIN_BWD -DNERFDS_NAME=train_bwd${sfx}_nerfds -o build/asm/train_bwd$sfx.s 2>/dev/null &
+done
 wait
 python3 ../../tools/isa_lint.py build/asm/*.s | grep -v "^$"
 exit ${PIPESTATUS[0]}
