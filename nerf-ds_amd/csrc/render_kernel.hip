@@ -701,6 +701,10 @@ template <int P> DEVI void tile_epilogue_asm(Chunk<P>& c0, Chunk<P>& c1, const f
 #endif
 }
 
+constexpr int mfmas_per_step(int prec) { return prec == P_BF16X3 ? 3 : prec == P_BF16X6 ? 6 : prec == P_F32 ? 8 : 1; }
+template <class T> struct seg_mfmas;
+template <int P, int NT, int K> struct seg_mfmas<Chunk<P>[NT][K]> { static constexpr int value = K * NT * mfmas_per_step(P); };
+template <class... Ins> struct seg_mfma_total { static constexpr int value = (seg_mfmas<Ins>::value + ... + 0); };
 template <class T> struct seg_chunks;
 template <int P, int NT, int K> struct seg_chunks<Chunk<P>[NT][K]> { static constexpr int value = K; };
 template <class... Ins> struct seg_total { static constexpr int value = (seg_chunks<Ins>::value + ... + 0); };
@@ -742,6 +746,12 @@ template <int P> DEVI void epilogue_piece_asm(unsigned& o0, unsigned& o1, float 
 // 1: the training kernels issue the epilogue of a tile group inside the next group's MFMA chain (dense(): TRAIN branch)
 #ifndef NERFDS_TRAIN_PIPE
 #define NERFDS_TRAIN_PIPE 0
+#endif
+#ifndef NERFDS_TRAIN_SGB
+// > 0: VALU per MFMA asked of the scheduler in the pipelined training regions (llvm.amdgcn.sched.group.barrier).  Built and measured with 4 and 6:
+// 15.7 -> 21.6 ms per step - the forward spills 55 - 67 registers under the requested interleave (3.4 -> 6.8 ms on the fine level), the
+// chains lose 3 - 15 %, and the translation unit takes 8 minutes to compile.  Off.
+#define NERFDS_TRAIN_SGB 0
 #endif
 #ifndef NERFDS_PIPE_J0
 #define NERFDS_PIPE_J0 2
@@ -999,6 +1009,21 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Carry<NT>& carry, Chunk<PO> (&out)[
 #pragma unroll
       for (int tp = 0; tp < TP; ++tp) prev[tp] = acc[tp][0];
 #if defined(NERFDS_TRAIN_HALF) && defined(__HIP_DEVICE_COMPILE__)
+#if NERFDS_TRAIN_SGB
+      // ask for the interleave explicitly: after every MFMA of the region a few of the previous group's VALU (and a ring read every other
+      // MFMA): llvm.amdgcn.sched.group.barrier - masks 0x8 MFMA, 0x2 VALU, 0x100 DS read, 0x40 VMEM write
+      if (ot > 0) {
+        constexpr int NM = TP * seg_mfma_total<Ins...>::value;
+        constexpr int VPM = (280 + NM - 1) / NM < NERFDS_TRAIN_SGB ? (280 + NM - 1) / NM : NERFDS_TRAIN_SGB;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+          if (i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (i % (NM / 5 > 0 ? NM / 5 : 1) == 1) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+        }
+      }
+#endif
       // with `half` a compile-time fact nothing else separates the groups: one scheduling region per group (its MFMAs + the previous
       // group's epilogue), so that hipcc interleaves THOSE and does not pull later groups' work - and their registers - forward
       __builtin_amdgcn_sched_barrier(0);
