@@ -677,11 +677,18 @@ template <int P> DEVI void tile_epilogue_asm(Chunk<P>& c0, Chunk<P>& c1, const f
   static_assert(is_single(P), "packed-half epilogue");
 #if defined(__HIP_DEVICE_COMPILE__)
   unsigned o0, o1, o2, o3, o4, o5, o6, o7;
+#if NERFDS_ABLATE & 64      // timing experiment: conversions only, no ReLU (half the epilogue's VALU, same registers and copies; wrong results)
+#define NERFDS_EPI_RELU8 "s_nop 0"
+#define NERFDS_EPI_RELU2 "s_nop 0"
+#else
+#define NERFDS_EPI_RELU8 "v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0\n\tv_pk_max_i16 %2, %2, 0\n\tv_pk_max_i16 %3, %3, 0\n\t" \
+                         "v_pk_max_i16 %4, %4, 0\n\tv_pk_max_i16 %5, %5, 0\n\tv_pk_max_i16 %6, %6, 0\n\tv_pk_max_i16 %7, %7, 0"
+#define NERFDS_EPI_RELU2 "v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0"
+#endif
 #define NERFDS_EPI_BODY(CVT)                                                                                              \
   CVT " %0, %8, %9\n\t" CVT " %1, %10, %11\n\t" CVT " %2, %12, %13\n\t" CVT " %3, %14, %15\n\t"                            \
   CVT " %4, %16, %17\n\t" CVT " %5, %18, %19\n\t" CVT " %6, %20, %21\n\t" CVT " %7, %22, %23\n\t"                          \
-  "v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0\n\tv_pk_max_i16 %2, %2, 0\n\tv_pk_max_i16 %3, %3, 0\n\t"              \
-  "v_pk_max_i16 %4, %4, 0\n\tv_pk_max_i16 %5, %5, 0\n\tv_pk_max_i16 %6, %6, 0\n\tv_pk_max_i16 %7, %7, 0" NERFDS_EPI_TAIL
+  NERFDS_EPI_RELU8 NERFDS_EPI_TAIL
 #define NERFDS_EPI_OPS                                                                                                    \
   : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4), "=&v"(o5), "=&v"(o6), "=&v"(o7)                                \
   : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),          \
@@ -715,10 +722,10 @@ template <class... Ins> struct seg_total { static constexpr int value = (seg_chu
 template <int P> DEVI void epilogue_piece_asm(unsigned& o0, unsigned& o1, float a0, float a1, float a2, float a3, f32x16& order) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (P == P_BF16)
-    asm volatile("v_cvt_pk_bf16_f32 %0, %3, %4\n\tv_cvt_pk_bf16_f32 %1, %5, %6\n\tv_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0"
+    asm volatile("v_cvt_pk_bf16_f32 %0, %3, %4\n\tv_cvt_pk_bf16_f32 %1, %5, %6\n\t" NERFDS_EPI_RELU2
                  : "=&v"(o0), "=&v"(o1), "+v"(order) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
   else
-    asm volatile("v_cvt_pk_f16_f32 %0, %3, %4\n\tv_cvt_pk_f16_f32 %1, %5, %6\n\tv_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0"
+    asm volatile("v_cvt_pk_f16_f32 %0, %3, %4\n\tv_cvt_pk_f16_f32 %1, %5, %6\n\t" NERFDS_EPI_RELU2
                  : "=&v"(o0), "=&v"(o1), "+v"(order) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
 #endif
 }

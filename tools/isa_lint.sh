@@ -7,7 +7,7 @@ FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-value
 jobs_n=0
 for g in nerfds:GraphNerfDS static:GraphStatic hyper:GraphHyperNeRF; do for p in bf16:P_BF16 bf16x3:P_BF16X3 f32:P_F32 f16:P_F16 "mixed:P_BF16 -DNERFDS_MIXED"; do
   n=${g%%:*}_${p%%:*}
-  XF=""; case ${p%%:*} in bf16|f16) XF="-fno-slp-vectorize";; esac      # the Makefile's XFLAGS_bf16 / XFLAGS_f16
+  XF=""; case $n in static_bf16|static_f16) XF="-fno-slp-vectorize";; *_bf16|*_f16) XF="-fno-slp-vectorize -DNERFDS_NT=2 -DNERFDS_ASM_EPILOGUE=0";; esac      # the Makefile's XFLAGS_<kernel>
   /opt/rocm/bin/hipcc $FL $XF $MIXFLAGS -DNERFDS_GRAPH=${g#*:} -DNERFDS_PREC=${p#*:} -DNERFDS_NAME=$n -o build/asm/$n.s 2>/dev/null &
   jobs_n=$((jobs_n + 1)); if [ $jobs_n -ge 8 ]; then wait -n; jobs_n=$((jobs_n - 1)); fi
 done; done
