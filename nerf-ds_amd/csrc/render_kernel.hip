@@ -168,12 +168,14 @@ template <int P> DEVI void mma(f32x16& acc, const WFrag<P>& w, const Chunk<P>& c
 // to.  Every index is a compile-time constant after unrolling.
 // ------------------------------------------------------------------------------------------------
 // NERFDS_NT = 2 (plans of one-unit networks only): two N-tiles per wave, i.e. every weight fragment read from LDS feeds two
-// MFMAs; the activations of the 256-wide trunk then need 256 registers, so one 512-register wave per SIMD, and with one wave
-// per SIMD the tile epilogues have to be software-pipelined into the MFMA chains (NERFDS_PIPE_EPI).  Built, correct
-// (deterministic, parity green) and measured: 16.2 ms (no pipelining) / 16.6 ms (pipelined, with the ordering point that makes
-// the MFMA -> VALU hazard safe by construction) per 65 536 rays against 15.8 ms for the default below on the same box;
-// an earlier build whose first piece could be scheduled right behind the previous group's last MFMA ran 15.2 ms - and gave
-// 1-2 % of the rays different values from run to run.  Default: one N-tile, 8 waves.
+// MFMAs; the activations of the 256-wide trunk then need 256 registers, so one 512-register wave per SIMD.  The Makefile builds the
+// nerf_ds / HyperNeRF bf16 and f16 kernels this way (-DNERFDS_NT=2 -DNERFDS_ASM_EPILOGUE=0: the compiler-scheduled C++ epilogue).
+// History: round 2 measured the shape at 16.2 ms (no pipelining) / 16.6 ms (asm epilogue pieces pinned into the next chain, with the
+// ordering point that makes the MFMA -> VALU hazard safe by construction) per 65 536 rays against 15.8 ms for 8 waves x one N-tile; an
+// earlier build whose first piece could be scheduled right behind the previous group's last MFMA ran 15.2 ms - and gave 1-2 % of the
+// rays different values from run to run.  After round 3's changes (level-independent networks once per position, spread DMA, DPP phases)
+// the same shape with the plain C++ epilogue is level or ahead on every box tried (Makefile, profiles/r3_ab/ab_nt2_*.txt); with the asm
+// pieces it is 1 % behind.  The source default stays one N-tile (the static graph's kernels, every two-unit plan).
 #ifndef NERFDS_NT
 #define NERFDS_NT 1
 #endif
