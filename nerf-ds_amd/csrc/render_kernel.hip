@@ -88,9 +88,32 @@ DEVI float relu_f(float x) {
   return __builtin_bit_cast(float, i > 0 ? i : 0);
 }
 template <int P> DEVI void make_chunk(Chunk<P>& c, const float (&x)[8]);
+#ifndef NERFDS_PK_RELU
+#define NERFDS_PK_RELU 1
+#endif
 // Accumulator registers -> next layer's B operand, with optional ReLU.
 template <int P, bool RELU> DEVI void make_act_chunk(Chunk<P>& c, const float (&x)[8]) {
   // (a packed v_pk_max_i16 on the converted pairs would be cheaper still, but hipcc then un-pairs the v_cvt_pk_bf16_f32)
+#if NERFDS_PK_RELU
+  if constexpr (RELU && (P == P_BF16 || P == P_F16)) {
+    // pair form: v_cvt_pk of two values, then a signed 16-bit max with 0 on the packed halves (a negative half has its sign bit set)
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef std::remove_reference_t<decltype(c.v[0])> E;
+    typedef E ex2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    u32x4_ u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x2 f = {x[2 * k], x[2 * k + 1]};
+      const ex2 hh = __builtin_convertvector(f, ex2);
+      const s16x2 z = {0, 0};
+      u[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, hh), z));
+    }
+    c.v = __builtin_bit_cast(decltype(c.v), u);
+    return;
+  }
+#endif
   float y[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) y[i] = RELU ? relu_f(x[i]) : x[i];
