@@ -88,6 +88,12 @@ DEVI float relu_f(float x) {
   return __builtin_bit_cast(float, i > 0 ? i : 0);
 }
 template <int P> DEVI void make_chunk(Chunk<P>& c, const float (&x)[8]);
+#ifndef NERFDS_CPP_PIPE
+#define NERFDS_CPP_PIPE 0
+#endif
+#ifndef NERFDS_CPP_PIPE_J0
+#define NERFDS_CPP_PIPE_J0 1
+#endif
 #ifndef NERFDS_PK_RELU
 #define NERFDS_PK_RELU 1
 #endif
@@ -525,8 +531,32 @@ DEVI void store_tile_pk16(uint16_t* row_tile, const unsigned (&pk)[8]) {
   }
 #endif
 }
+// NERFDS_SIGN_BITS (ReLU tiles): the bit of an output is NOT its sign bit - one v_alignbit per register on the raw accumulator, one v_not per
+// tile - instead of the two VALU above, and the ReLU itself is applied to the converted pairs (v_pk_max_i16 with 0): 33 VALU per tile instead
+// of 56.  Differs from `output > 0` for an accumulator that is exactly +0 only (its bit is set; the stored activation is 0 either way).
+#ifndef NERFDS_SIGN_BITS
+#define NERFDS_SIGN_BITS 1
+#endif
 template <bool RELU> DEVI unsigned store_tile_half(uint16_t* row_tile, const f32x16& acc) {
   unsigned bits = 0;
+#if NERFDS_SIGN_BITS
+  if constexpr (RELU) {
+#pragma unroll
+    for (int r = 15; r >= 0; --r) bits = __builtin_amdgcn_alignbit(bits, __builtin_bit_cast(unsigned, acc[r]), 31);   // (bits << 1) | sign
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    unsigned pk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const f32x2 f = {acc[2 * k], acc[2 * k + 1]};
+      const s16x2 z = {0, 0};
+      pk[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(f, f16x2)), z));
+    }
+    store_tile_pk16(row_tile, pk);
+    return ~bits & 0xffffu;
+  }
+#endif
   float v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) v[r] = RELU ? relu_f(acc[r]) : acc[r];
@@ -984,6 +1014,56 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Carry<NT>& carry, Chunk<PO> (&out)[
     }
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp) tile_epilogue<PO, NT, RELU>(out, OT - TP + tp, prev[tp]);
+  } else if constexpr (NERFDS_CPP_PIPE && !TRAIN && is_single(PO) && RELU && (OT > TP)) {
+    // One-unit render kernels, two N-tiles (one wave per SIMD), software-pipelined at the source level like the training branch below: the
+    // accumulators of group g rest in `prev`; their conversion (one chunk = 4 v_cvt_pk + 4 v_pk_max_i16 per piece) is issued between the
+    // MFMA steps of group g + 1, one scheduling region per group.
+    constexpr int SLOTS = TP * seg_total<Ins...>::value;
+    constexpr int NPIECE = TP * NT * 2, J0 = NERFDS_CPP_PIPE_J0;
+    constexpr int PPS = cdiv(NPIECE, SLOTS - J0 > 0 ? SLOTS - J0 : 1);
+    constexpr int IN_CHAIN = (SLOTS - J0) * PPS < NPIECE ? (SLOTS - J0 > 0 ? (SLOTS - J0) * PPS : 0) : NPIECE;
+    f32x16 prev[TP][NT];
+    auto piece = [&](int q, int pot) {
+      const int tp = q / (2 * NT), nt = (q / 2) % NT, sub = q % 2, t = pot + tp;
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = prev[tp][nt][8 * sub + i];
+      make_act_chunk<PO, RELU>(out[nt][2 * t + sub], x);
+    };
+#pragma unroll
+    for (int ot = 0; ot < OT; ot += TP) {
+      f32x16 acc[TP][NT];
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) {
+        const f32x16 bv = load_bias(cur.bt + ot + tp, hb);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[tp][nt] = bv;
+      }
+      int j = 0;
+      auto slot = [&](int jj, int) {
+        if (ot == 0 || jj < J0) return;
+#pragma unroll
+        for (int q = (jj - J0) * PPS; q < (jj - J0 + 1) * PPS; ++q)
+          if (q < NPIECE) piece(q, ot - TP);
+      };
+      (accum<G, PL, NT, TP>(acc, pipe, cur, ins, j, slot), ...);
+      if (ot > 0) {
+#pragma unroll
+        for (int q = IN_CHAIN; q < NPIECE; ++q) piece(q, ot - TP);
+      }
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) prev[tp][nt] = acc[tp][nt];
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+#pragma unroll
+    for (int q = 0; q < NPIECE; ++q) piece(q, OT - TP);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   } else if constexpr (TRAIN && !BWD_IN && NERFDS_TRAIN_PIPE && (OT > TP) && (BWD ? PO == P_BF16X3 : true)) {
     // Training forward / backward chain, software-pipelined at the source level: the epilogue of tile group g - conversion into the next
     // layer's operand, ReLU bits / mask, 16-bit stores - is cut into pieces that are issued between the MFMA steps of group g + 1 (the
