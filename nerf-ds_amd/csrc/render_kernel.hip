@@ -531,18 +531,24 @@ DEVI void store_tile_pk16(uint16_t* row_tile, const unsigned (&pk)[8]) {
   }
 #endif
 }
-// NERFDS_SIGN_BITS (ReLU tiles): the bit of an output is NOT its sign bit - one v_alignbit per register on the raw accumulator, one v_not per
-// tile - instead of the two VALU above, and the ReLU itself is applied to the converted pairs (v_pk_max_i16 with 0): 33 VALU per tile instead
-// of 56.  Differs from `output > 0` for an accumulator that is exactly +0 only (its bit is set; the stored activation is 0 either way).
+// NERFDS_SIGN_BITS = 1 (EXPERIMENT, off): the bit of an output is NOT its sign bit - one v_alignbit per register on the raw accumulator, one v_not
+// per tile - and the ReLU itself on the converted pairs (v_pk_max_i16 with 0): 33 VALU per tile instead of 56.  Measured 15.72 - 15.78 against
+// 15.74 - 15.91 ms per step (within the noise: the forward is not VALU-bound), and NOT the reference's derivative: an accumulator that
+// is exactly +0 gets its bit set, and exact zeros are not rare here (a unit whose inputs are all zero - closed windows, zero-initialised
+// biases - sits exactly on its bias): the loss after 13 steps moved by 1.3e-4, three times the run-to-run spread.  Kept for the record.
 #ifndef NERFDS_SIGN_BITS
-#define NERFDS_SIGN_BITS 1
+#define NERFDS_SIGN_BITS 0
 #endif
 template <bool RELU> DEVI unsigned store_tile_half(uint16_t* row_tile, const f32x16& acc) {
   unsigned bits = 0;
 #if NERFDS_SIGN_BITS
   if constexpr (RELU) {
+    // (the accumulator's bits through ONE bit cast of the whole vector: `bit_cast<unsigned>(acc[r])` per register is folded wrongly by hipcc 7.2 -
+    //  every v_alignbit then read register 0, the misfold apply_mask documents; seen in the ISA and as a 100 % error of the embedding gradients)
+    typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+    const u32x16 ab = __builtin_bit_cast(u32x16, acc);
 #pragma unroll
-    for (int r = 15; r >= 0; --r) bits = __builtin_amdgcn_alignbit(bits, __builtin_bit_cast(unsigned, acc[r]), 31);   // (bits << 1) | sign
+    for (int r = 15; r >= 0; --r) bits = __builtin_amdgcn_alignbit(bits, ab[r], 31);   // (bits << 1) | sign
     typedef short s16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
