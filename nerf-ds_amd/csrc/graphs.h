@@ -37,6 +37,16 @@ constexpr int STAGE_BYTES = 16384;
 #define NERFDS_TILE_PAIR 2
 #endif
 constexpr int TILE_PAIR = NERFDS_TILE_PAIR;
+// EXPERIMENT (off: NERFDS_NT2_TILE_PAIR = 2): the two-N-tile render kernels (nerf_ds / HyperNeRF graph, bf16 / f16: Makefile NT2FLAGS) taking their tiles
+// ONE at a time - with two N-tiles one tile already gives a wave two independent accumulators, and the 32 registers the second tile takes could hold the
+// previous group's results while their conversion is issued inside the next chain (render_kernel.hip NERFDS_CPP_PIPE).  Needs the stream in that order
+// (the host packs it per kernel: StreamWriter::tile_pair) and -DNERFDS_TILE_PAIR=1 on those kernels (tools/variant_tp1.sh builds such a library).
+// Measured, parity green: bf16 13.65 (13.69 with the pipelined epilogue) against 13.54 ms per 65 536 rays, f16 14.01 (14.02) against 13.92
+// (profiles/r3_ab/ab_tp1.txt) - the exposed epilogue is not what these kernels wait for.
+#ifndef NERFDS_NT2_TILE_PAIR
+#define NERFDS_NT2_TILE_PAIR 2
+#endif
+constexpr int stream_tile_pair(bool two_n_tile_kernel) { return two_n_tile_kernel ? NERFDS_NT2_TILE_PAIR : 2; }
 constexpr int STAGE_UNITS = STAGE_BYTES / 1024;
 constexpr int pad_units(int n) { return cdiv(n, STAGE_UNITS) * STAGE_UNITS; }
 constexpr int chunks(int feats) { return cdiv(feats, 16); }   // k16 chunks needed for `feats` linear features

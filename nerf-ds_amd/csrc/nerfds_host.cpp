@@ -199,8 +199,13 @@ NerfNet nerf_views(const Weights::Nerf& s) {
 template <class G> void pack_which(StreamWriter& sw, const Weights& W, int which, int level, Plan pl) {
   if (which == 0) pack_shared<G>(sw, shared_views(W), pl); else pack_nerf<G>(sw, nerf_views(W.nerf[level]), pl);
 }
+// the kernels the Makefile builds in the two-N-tile shape (NT2FLAGS): nerf_ds / HyperNeRF graph, bf16 / f16
+static int tile_pair_of(int graph, int prec) {
+  return stream_tile_pair((graph == GraphNerfDS::ID || graph == GraphHyperNeRF::ID) && (prec == (int)NERFDS_PREC_BF16 || prec == (int)NERFDS_PREC_F16));
+}
 void pack_dispatch(int graph, StreamWriter& sw, const Weights& W, int which, int level, int prec) {
   const Plan pl = plan_of(prec);
+  sw.tile_pair = tile_pair_of(graph, prec);
   if (graph == GraphNerfDS::ID) pack_which<GraphNerfDS>(sw, W, which, level, pl);
   else if (graph == GraphStatic::ID) pack_which<GraphStatic>(sw, W, which, level, pl);
   else pack_which<GraphHyperNeRF>(sw, W, which, level, pl);

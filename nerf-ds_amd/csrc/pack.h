@@ -91,6 +91,7 @@ struct StreamWriter {
   uint8_t* w;       // may be nullptr: count only
   float* b;
   size_t wbytes = 0, bfloats = 0;
+  int tile_pair = TILE_PAIR;   // tiles per group in THIS stream (graphs.h stream_tile_pair: what the consuming kernel was built with)
 
   void frag_out(const Layer& L, const Seg& S, int ot, int kc) {
     const int prec = S.prec;
@@ -138,7 +139,7 @@ struct StreamWriter {
   // Stream order of a layer: tiles in groups of TILE_PAIR (heads: one tile); within a group, segment by segment and
   // chunk by chunk, one fragment per tile of the group - the order render_kernel.hip's accum consumes them in.
   void emit(const Layer& L) {
-    const int tp = (L.n_tiles % TILE_PAIR == 0) ? TILE_PAIR : 1;
+    const int tp = (L.n_tiles % tile_pair == 0) ? tile_pair : 1;
     for (int ot = 0; ot < L.n_tiles; ot += tp) {
       for (const Seg& S : L.segs) {
         const int kc_n = (int)S.rows.size() / 16;
