@@ -151,7 +151,7 @@ def layer_dims(cfg):
   return shared + nerf
 
 
-def run_train(args, device):
+def run_train(args, device, emit=True):
   """BASELINE configs[3]: forward + backward + Adam on a random-ray batch of 4096 (nerf_ds graph, 64 + 64 samples)."""
   from nerfds_amd import nerf_ds_config, init_params
   from nerfds_amd.training import Trainer
@@ -237,7 +237,9 @@ def run_train(args, device):
                               'sample': f'{done} rays (slices of {Rc}) x (64 + 128) samples, torch-CPU fp32 autograd through the oracle (loss + all gradients, no Adam), {dtc:.1f} s on {cores} threads'}
   else:
     result['cpu_baseline'] = None
-  print(json.dumps(result), flush=True)
+  if emit:
+    print(json.dumps(result), flush=True)
+  return result
 
 
 # ---- executed MFMA work (what the kernel issues) next to the algorithmic FLOPs (what the metric is defined on) ---------------
@@ -308,6 +310,7 @@ def main():
   ap.add_argument('--samples', type=int, default=64, help='coarse = fine sample count (64 = the headline config; 128 = BASELINE configs[4])')
   ap.add_argument('--strong', action='store_true', help='BASELINE configs[2]: one frame, every chunk split over the ranks (render_image)')
   ap.add_argument('--sweep', action='store_true', help='BASELINE configs[4]: seven synthetic scenes, base.gin graph, 128 + 128 samples, one 800x600 frame each')
+  ap.add_argument('--no-train-line', action='store_true', help='skip the train_step leg of the default run (N = 1 only)')
   ap.add_argument('--train', action='store_true', help='BASELINE configs[3]: the training step instead of the render')
   ap.add_argument('--train-rays', type=int, default=4096)
   args = ap.parse_args()
@@ -535,6 +538,15 @@ def main():
                       "north_star's 1e-4 on composited RGB (profiles/r3_precision_budget.md: no plan with a one-MFMA network does)")
         result['parity_path'] = pp
       result['other_paths'] = list(paths.values())
+      if not args.no_train_line:
+        # BASELINE configs[3] in the same run (the full line: --train): the 4096-ray training step, 10 timed steps after 3 warm-ups
+        targs = argparse.Namespace(**vars(args))
+        targs.steps, targs.warmup, targs.no_cpu_baseline = 10, 3, True
+        tr = run_train(targs, device, emit=False)
+        result['train_step'] = {k: tr[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'loss_first', 'loss_last')}
+        result['train_step']['workload'] = tr['config']['workload']
+        result['train_step']['roofline'] = {k: tr['roofline'][k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_step',
+                                                                         'algorithmic_tflops', 'mfma_floor_ms', 'ms_over_mfma_floor')}
     print(json.dumps(result), flush=True)
 
   if world > 1:
