@@ -129,6 +129,9 @@ template <> DEVI void make_chunk<P_BF16>(Chunk<P_BF16>& c, const float (&x)[8]) 
 #pragma unroll
   for (int i = 0; i < 8; ++i) c.v[i] = (__bf16)x[i];
 }
+#ifndef NERFDS_X3_DOT2
+#define NERFDS_X3_DOT2 0
+#endif
 #ifndef NERFDS_X3_PAIRWISE
 #define NERFDS_X3_PAIRWISE 1
 #endif
@@ -144,7 +147,16 @@ template <> DEVI void make_chunk<P_BF16X3>(Chunk<P_BF16X3>& c, const float (&x)[
   for (int k = 0; k < 4; ++k) {
     const f32x2 r = {x[2 * k], x[2 * k + 1]};
     const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+#if NERFDS_X3_DOT2 && defined(__HIP_DEVICE_COMPILE__)
+    // EXPERIMENT (off): r - float(hi) straight from the packed pair, v_dot2c_f32_bf16 d = hi.lo * (-1) + hi.hi * 0 + r0 (and the mirror image for r1): no
+    // unpacking of the pair, 2 VALU per pair instead of 4 (VALU per MFMA 2.89 -> 2.39).  Measured 39.34 against 38.75 ms per 65 536 rays (the dot
+    // instruction is not a full-rate VALU op) AND a parity test fails with it (its arithmetic is not the exact fp32 subtraction).  Kept for the record.
+    const bf16x2 hp = __builtin_bit_cast(bf16x2, hb);
+    const bf16x2 m0 = __builtin_bit_cast(bf16x2, 0x0000bf80u), m1 = __builtin_bit_cast(bf16x2, 0xbf800000u);
+    const f32x2 d = {__builtin_amdgcn_fdot2_f32_bf16(hp, m0, r[0], false), __builtin_amdgcn_fdot2_f32_bf16(hp, m1, r[1], false)};
+#else
     const f32x2 d = {r[0] - __builtin_bit_cast(float, hb << 16), r[1] - __builtin_bit_cast(float, hb & 0xffff0000u)};
+#endif
     uh[k] = hb;
     ul[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2));
   }
