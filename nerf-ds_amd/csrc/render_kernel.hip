@@ -129,6 +129,13 @@ template <> DEVI void make_chunk<P_BF16>(Chunk<P_BF16>& c, const float (&x)[8]) 
 #pragma unroll
   for (int i = 0; i < 8; ++i) c.v[i] = (__bf16)x[i];
 }
+#ifndef NERFDS_DMA_VOFF
+#if defined(NERFDS_TRAIN_FWD) || defined(NERFDS_TRAIN_BWD)
+#define NERFDS_DMA_VOFF 0     // the training kernels measured 1 % SLOWER with it (15.84 against 15.70 ms per step): they keep the scalar offsets
+#else
+#define NERFDS_DMA_VOFF 1     // render kernels: bf16 13.57 -> 13.47 ms per 65 536 rays, split bf16 39.95 -> 39.77 (profiles/r3_ab/ab_dma_voffset.txt)
+#endif
+#endif
 #ifndef NERFDS_X3_DOT2
 #define NERFDS_X3_DOT2 0
 #endif
@@ -354,7 +361,14 @@ template <class G, class PL> struct Pipe {
       // VGPRs under SGPR pressure and wrap every LDS-DMA in a waterfall loop (cdna guide T20).
       const int off = __builtin_amdgcn_readfirstlane(WAVES * k * 1024 + wave1k);
       auto dst = (__attribute__((address_space(3))) void*)(g_smem + slot * STAGE_BYTES + off);
+#if NERFDS_DMA_VOFF
+      // the wave's share of the stream offset rides in the VECTOR offset (lane * 16 + wave * 1024, one register for the whole kernel), so the scalar
+      // offset of every piece of every stage is a literal: as `constant + wave1k` each of the ~300 (stage, piece) offsets was a loop-invariant scalar
+      // that hipcc hoisted out of the persistent loop and then spilled to VGPR lanes (586 SGPR spill slots, 0.3 v_readlane / v_writelane per MFMA)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrap ? next : cur, dst, 16, lane16 + wave1k, base + WAVES * k * 1024, 0, 0);
+#else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrap ? next : cur, dst, 16, lane16, base + off, 0, 0);
+#endif
     }
   }
   // Entering stage s: stages s and s + 1 are complete in LDS (so the LDS->register prefetch can run ahead across the
