@@ -1,5 +1,5 @@
 // Compile-time descriptions of the render graphs that have HIP kernels, shared by the host-side
-// weight-stream packer (nerfds_host.cpp) and the device code (render_kernel.hip) so that both walk
+// weight-stream packer (nerfds_host.cpp) and the device code (field.h and its three kernel files) so that both walk
 // the layers in the same order.
 //
 // Dimensions follow SURVEY.md section 8 "Configuration resolved" (configs/nerf_ds.gin over
@@ -32,14 +32,14 @@ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 // whole number of stages so that a stage never straddles the shared -> NerfMLP seam.
 constexpr int STAGE_BYTES = 16384;
 // Output tiles of a hidden layer are computed TILE_PAIR at a time: within a pair the stream holds, chunk by chunk, one
-// fragment of each tile, so that consecutive MFMAs of a wave go to different accumulators (render_kernel.hip accum).
+// fragment of each tile, so that consecutive MFMAs of a wave go to different accumulators (field.h accum).
 #ifndef NERFDS_TILE_PAIR
 #define NERFDS_TILE_PAIR 2
 #endif
 constexpr int TILE_PAIR = NERFDS_TILE_PAIR;
 // EXPERIMENT (off: NERFDS_NT2_TILE_PAIR = 2): the two-N-tile render kernels (nerf_ds / HyperNeRF graph, bf16 / f16: Makefile NT2FLAGS) taking their tiles
 // ONE at a time - with two N-tiles one tile already gives a wave two independent accumulators, and the 32 registers the second tile takes could hold the
-// previous group's results while their conversion is issued inside the next chain (render_kernel.hip NERFDS_CPP_PIPE).  Needs the stream in that order
+// previous group's results while their conversion is issued inside the next chain (a source-level pipelined epilogue, since removed: profiles/r3_ab/README.md).  Needs the stream in that order
 // (the host packs it per kernel: StreamWriter::tile_pair) and -DNERFDS_TILE_PAIR=1 on those kernels (tools/variant_tp1.sh builds such a library).
 // Measured, parity green: bf16 13.65 (13.69 with the pipelined epilogue) against 13.54 ms per 65 536 rays, f16 14.01 (14.02) against 13.92
 // (profiles/r3_ab/ab_tp1.txt) - the exposed epilogue is not what these kernels wait for.
@@ -78,7 +78,7 @@ constexpr Plan plan_of(int prec_index) {
   return prec_index == 4 ? Plan{NERFDS_MIX_MASK, NERFDS_MIX_WARP, NERFDS_MIX_HYP, NERFDS_MIX_TRUNK, NERFDS_MIX_RGB}
                          : uniform_plan(prec_index);
 }
-// The plan of the fused training forward (render_kernel.hip train_forward_kernel): split bf16 operands as the trainer's layer
+// The plan of the fused training forward (train_fwd_kernel.hip): split bf16 operands as the trainer's layer
 // kernels (train_gemm.hip), exact fp32 products in the warp field (its 16-bit rounding is amplified to ~1 % on the warp-field
 // gradients by the 2^7-frequency encoding of the warped point).  Two units per fragment (three in a P_BF16X6 warp field).
 // (NERFDS_TRAIN_WARP_X6: the warp field in P_BF16X6 instead - 6 x 32 MFMA cycles per fragment where fp32 takes 8 x 64.  Measured 21.2 ->
@@ -174,7 +174,7 @@ template <class G> struct Dims {
 };
 
 // Lengths, in 1-KiB units, of the two weight streams under a precision plan.  The order of the walk is the order in
-// which pack.h emits and render_kernel.hip consumes the fragments.
+// which pack.h emits and field.h consumes the fragments.
 template <class G> constexpr int shared_units(Plan pl) {
   using D = Dims<G>;
   int pos = 0;
@@ -194,7 +194,7 @@ template <class G> constexpr int nerf_units(Plan pl) {
   return walk_seg(pos, G::RGB_W / 16, pl.rgb);                                                       // rgb head
 }
 
-// ---- Reversed networks of the fused training backward (render_kernel.hip train_backward_kernel, nerfds_train.cpp) ----
+// ---- Reversed networks of the fused training backward (train_bwd_kernel.hip, nerfds_train.cpp) ----
 // One stream per network: the TRANSPOSED layers in the order the data-gradient chain walks them, every fragment two units
 // (split bf16).  A plain MLP with head (mask, warp, hyper sheet):
 //   head^T (one linear chunk of head gradients -> width), layers depth-1 .. skip+1 transposed, the skip layer's [hidden rows]

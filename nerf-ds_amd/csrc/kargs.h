@@ -49,7 +49,7 @@ struct KArgs {
 };
 
 // Where the training forward writes what the backward pass reads (nerfds_train.cpp workspace, row-major [R * S][width] fp32).
-// Passed by value to train_forward_kernel (render_kernel.hip).
+// Passed by value to train_forward_kernel (train_fwd_kernel.hip).
 struct TrainOut {
   static constexpr bool ON = true;
   float* mask_h[8];
@@ -76,7 +76,7 @@ struct TrainOut {
   uint16_t* rgb_h16;      uint16_t* rgb_bits;
 };
 
-// Fused backward of one network (render_kernel.hip built with -DNERFDS_TRAIN_BWD): the data-gradient chain of a reversed MLP.  Row
+// Fused backward of one network (train_bwd_kernel.hip): the data-gradient chain of a reversed MLP.  Row
 // m = one sample; the kernel reads the gradient of the network's head outputs, walks the layers backwards with the transposed
 // weights streamed like the forward's (dX never leaves the registers between layers), masks with the forward's ReLU bits and
 // writes, for every hidden layer, g = d loss / d (pre-activation) as fp32 [M][width] - the dY the weight-gradient kernels read -
@@ -97,8 +97,6 @@ struct TrainBwd {
   // fp32 / split bf16 registers, so only the weight and bias gradients see the 8-bit rounding (unbiased, averaged over M samples)
   int g_half;
 };
-
-typedef void (*launch_bwd_fn)(const KArgs& ka, const TrainBwd& tb, int num_cus, void* stream);
 
 typedef void (*launch_fn)(const KArgs& ka, int num_cus, void* stream);
 

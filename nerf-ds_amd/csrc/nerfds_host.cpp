@@ -555,7 +555,7 @@ __global__ void mfma_probe(const float* __restrict__ A /*[32][16]*/, const float
   for (int i = 0; i < 8; ++i)            // fp32: one k-slot pair (h = 0, 1) per instruction
     accf = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m * 16 + 8 * h + i], B[(8 * h + i) * 32 + m], accf, 0, 0, 0);
   for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;   // the accumulator map render_kernel.hip relies on
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;   // the accumulator map field.h relies on
     Cb[row * 32 + m] = acc[r];
     Cf[row * 32 + m] = accf[r];
   }

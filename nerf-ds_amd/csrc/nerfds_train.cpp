@@ -2,7 +2,7 @@
 // (training.py:265-274, 459-466, 481), gradients w.r.t. every parameter of the nerf_ds graph (training.py:494) and the
 // Adam update (training.py:508).  Activations of every layer stay resident in HBM (needed for dW); the dense layers
 // (forward X W, backward dX = dZ W^T and dW = X^T dZ) run on the hand-written MFMA kernels of train_gemm.hip and on the
-// fused forward / backward chains of render_kernel.hip (no BLAS library is linked), everything else in train_kernels.hip.  The two levels are processed one
+// fused forward / backward chains of train_fwd_kernel.hip / train_bwd_kernel.hip (over field.h) (no BLAS library is linked), everything else in train_kernels.hip.  The two levels are processed one
 // after the other through the same workspace: their losses are independent sums and the fine z samples carry a
 // stop_gradient (model_utils.py:241), so no gradient crosses from the fine level into the coarse one.
 #include <hip/hip_runtime.h>
@@ -25,10 +25,10 @@
 #include "kargs.h"
 #include "pack.h"
 
-// render_kernel.hip compiled with -DNERFDS_TRAIN_FWD: the fused forward of one level (TRAIN_PLAN arithmetic)
+// train_fwd_kernel.hip: the fused forward of one level (TRAIN_PLAN arithmetic)
 extern "C" void nerfds_launch_train_fwd_nerfds(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream);     // fp32 activations
 extern "C" void nerfds_launch_train_fwd16_nerfds(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream);   // f16 + ReLU bits
-// render_kernel.hip compiled with -DNERFDS_TRAIN_BWD: the data-gradient chain of one network (0 NerfMLP, 1 hyper sheet, 2 warp, 3 mask)
+// train_bwd_kernel.hip: the data-gradient chain of one network (0 NerfMLP, 1 hyper sheet, 2 warp, 3 mask)
 extern "C" void nerfds_launch_train_bwd_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);      // g as fp32
 extern "C" void nerfds_launch_train_bwd16_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);    // g as bf16
 
@@ -104,7 +104,7 @@ struct nerfds_trainer {
   std::vector<uint64_t> pack_fresh;
   int num_cus = 256;
   bool fuse_bwd = true;     // NERFDS_TRAIN_FUSE_BWD=0: the narrow layers' backward as two kernels (A/B timing)
-  // Fused forward (render_kernel.hip train_forward_kernel): the whole field evaluation of a level in ONE launch, activations written once
+  // Fused forward (train_fwd_kernel.hip): the whole field evaluation of a level in ONE launch, activations written once
   // for the backward pass.  Its weight streams [shared, coarse, fine] are re-packed on the device from theta at the start of every step
   // through index maps built once (build_fused_forward).  NERFDS_TRAIN_FUSED_FWD=0 runs the forward layer by layer (A/B timing).
   bool fused_fwd = false;
@@ -114,7 +114,7 @@ struct nerfds_trainer {
   float* fbias[3] = {nullptr, nullptr, nullptr};
   float* fold = nullptr;    // [2 levels][(TW + 1) x RGB_W]: rgb hidden_0 with the bottleneck folded in, then its bias
   int fstream_frags[3] = {0, 0, 0}, fbias_n[3] = {0, 0, 0}, f32_lo = 0, f32_hi = 0;
-  // Fused backward (render_kernel.hip train_backward_kernel), the plain step's default when the fused forward is on: the forward
+  // Fused backward (train_bwd_kernel.hip), the plain step's default when the fused forward is on: the forward
   // writes every hidden layer as f16 + ReLU bits, ONE launch per network walks its data-gradient chain (dX stays in registers
   // between layers) and leaves g_l = d loss / d pre-activation of every hidden layer in the fp32 arrays the forward did not use,
   // and one weight-gradient launch per layer reads X (f16) and g_l.  Streams [NerfMLP coarse, NerfMLP fine, hyper, warp, mask] are
@@ -757,7 +757,7 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   const int TW = trunk.width, VD = 6 * D.vd_bands, NM = 6 * D.nm_bands, CW = VD + NM;
   float* tout = t.trunk_h.back();
   if (t.fused_fwd) {
-    // ONE launch evaluates the five networks on the level's samples and writes every hidden layer + head output (render_kernel.hip
+    // ONE launch evaluates the five networks on the level's samples and writes every hidden layer + head output (train_fwd_kernel.hip
     // train_forward_kernel); what follows only materialises the layer INPUTS the backward pass differentiates through.
     fused_forward(t, st, level, R, S, z, rays, ex, W);
     mask_post(st, D, R, S, t.mask_logit, rays->gt_mask, ex->mask_ratio, t.warp_in, t.hyper_in);

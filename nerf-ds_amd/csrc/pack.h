@@ -1,4 +1,4 @@
-// Host-side packer: Flax parameter tree -> MFMA fragment stream (see render_kernel.hip header).
+// Host-side packer: Flax parameter tree -> MFMA fragment stream (see field.h header).
 //
 // For every dense layer the stream holds, per output tile of 32 rows and per k16-chunk, one fragment
 // laid out lane-linearly: lane l = (h << 5) | m supplies, for output row m of the tile, the weights of
@@ -137,7 +137,7 @@ struct StreamWriter {
   }
 
   // Stream order of a layer: tiles in groups of TILE_PAIR (heads: one tile); within a group, segment by segment and
-  // chunk by chunk, one fragment per tile of the group - the order render_kernel.hip's accum consumes them in.
+  // chunk by chunk, one fragment per tile of the group - the order field.h accum consumes them in.
   void emit(const Layer& L) {
     const int tp = (L.n_tiles % tile_pair == 0) ? tile_pair : 1;
     for (int ot = 0; ot < L.n_tiles; ot += tp) {

@@ -1,0 +1,129 @@
+// Training backward of ONE network on the machinery of the fused field (field.h): see train_backward_kernel below.  Built twice by the
+// Makefile (-DNERFDS_TRAIN_HALF=0 -DNERFDS_TRAIN_PIPE=0: fp32 g; =1 / =1: bf16 g, pipelined tile epilogue).
+#define NERFDS_KERNEL_KIND 2
+#include "field.h"
+#include "launch.h"
+
+namespace nerfds {
+
+// ------------------------------------------------------------------------------------------------
+// Training backward of ONE network (training.py:494 differentiates the whole model.apply): the data-gradient chain of the reversed
+// MLP on the machinery of the forward - transposed weight fragments streamed through the LDS ring, every layer's gradient kept in
+// registers as the next (earlier) layer's B operand (the accumulator of a transposed tile IS g^T[feature][sample]), split-bf16
+// operands with fp32 accumulation.  Per 32-sample tile a wave reads the head gradients and the ReLU bits of every layer, and
+// writes g_l = d loss / d (pre-activation of layer l) for every hidden layer (the dY of the weight-gradient kernels) and the
+// gradient of the raw input.  dX of a hidden layer never goes to HBM as an operand of the next data-gradient kernel, nor do the
+// fp32 activations come back as masks: 1 array pass per layer where the layer-by-layer backward made 3.
+// ------------------------------------------------------------------------------------------------
+template <int W> DEVI void load_bits(unsigned (&m)[W / 64 > 0 ? W / 64 : 1], const uint16_t* bits, long long r, int h) {
+  const unsigned* p = reinterpret_cast<const unsigned*>(bits + ((size_t)r * 2 + h) * (W / 32));
+#pragma unroll
+  for (int j = 0; j < W / 64; ++j) m[j] = p[j];
+}
+template <class BG, class PL, int OT, class OUT, class... Ins>
+DEVI void bwd_hidden(Pipe<BG, PL>& pipe, BwdCursor& cur, const unsigned (&m)[OT / 2], float* g_base, size_t g_off, OUT& out, Ins&... ins) {
+#pragma unroll
+  for (int j = 0; j < OT / 2; ++j) cur.mask[j] = m[j];
+  cur.row = g_base + g_off;                                        // fp32 [M][width] ...
+  cur.row16 = reinterpret_cast<uint16_t*>(g_base) + g_off + (ROW16_H / 4 - 1) * cur.in_h4;   // ... or bf16 [M][width] in the same buffer (TRAIN_HALF)
+  dense<BG, PL, 1, OT, false>(pipe, cur, out, ins...);
+}
+template <class BG, class PL, int P, int K>
+DEVI void bwd_input(Pipe<BG, PL>& pipe, BwdCursor& cur, float* in_row, int acc, Chunk<P> (&in)[1][K]) {
+  Chunk<P> none[1][4];
+  BwdInCursor ic;
+  static_cast<BwdCursor&>(ic) = cur;
+  ic.in_row = in_row;
+  ic.in_acc = acc;
+  dense<BG, PL, 1, 2, false>(pipe, ic, none, in);
+  cur.pos = ic.pos;
+  cur.bt = ic.bt;
+}
+
+template <class BG, class PL>
+DEVI void bwd_chain(const TrainBwd& tb, Pipe<BG, PL>& pipe, int lane, long long r, int live) {
+  constexpr int W = BG::W, D = BG::DEPTH, W16 = W / 16, W32 = W / 32, P = P_BF16X3, MW = W / 64;
+  static_assert(BG::SKIP == 4 && (D == 8 || D == 6) && W % 64 == 0, "chains are written out for depth 8 / 6, skip 4");
+  const int h = lane >> 5;
+  BwdCursor cur;
+  cur.seg = SEG_NERF; cur.pos = 0; cur.bt = 0;
+  cur.row = nullptr; cur.row16 = nullptr; cur.bits = nullptr;
+  cur.sink = tb.sink; cur.ld_in = tb.ld_in; cur.in_h4 = 4 * h; cur.in_row = nullptr; cur.in_acc = 0; cur.live = live;
+  // every load of the tile up front (one wait): ReLU bits of all layers, head gradients
+  unsigned mk[D][MW];
+#pragma unroll
+  for (int l = 0; l < D; ++l) load_bits<W>(mk[l], tb.bits[l], r, h);
+  const size_t g_off = (size_t)r * W + 4 * h;
+  float* const in_row = tb.d_in + (size_t)r * tb.ld_in + 4 * h;
+  Chunk<P> a[1][W16], b[1][W16];
+  if constexpr (BG::IS_NERF) {
+    constexpr int RW = BG::RGB_W, R16 = RW / 16;
+    unsigned mr[RW / 64];
+    load_bits<RW>(mr, tb.bits[8], r, h);
+    Chunk<P> drgb[1][1], dalpha[1][1], c[1][R16];
+    build_chunks<P, 1>(drgb[0], h, [&](int f) { return f < 3 ? val_feat(tb.d_head[(size_t)r * tb.ld_head + f]) : zero_feat(); });
+    build_chunks<P, 1>(dalpha[0], h, [&](int f) { return f < 4 ? val_feat(tb.d_head2[(size_t)r * 4 + f]) : zero_feat(); });
+    bwd_hidden<BG, PL, RW / 32>(pipe, cur, mr, tb.g[8], (size_t)r * RW + 4 * h, c, drgb);     // g_rgb = mask(W_rgb d rgb_logit)
+    bwd_hidden<BG, PL, W32>(pipe, cur, mk[7], tb.g[7], g_off, a, c, dalpha);                          // g_7 = mask(F^T g_rgb + W_alpha d alpha)
+  } else {
+    Chunk<P> dh[1][1];
+    build_chunks<P, 1>(dh[0], h, [&](int f) { return f < BG::NHEAD ? val_feat(tb.d_head[(size_t)r * tb.ld_head + f]) : zero_feat(); });
+    bwd_hidden<BG, PL, W32>(pipe, cur, mk[D - 1], tb.g[D - 1], g_off, a, dh);                          // g_{D-1} = mask(W_head d head)
+  }
+  if constexpr (D == 8) {
+    bwd_hidden<BG, PL, W32>(pipe, cur, mk[6], tb.g[6], g_off, b, a);
+    bwd_hidden<BG, PL, W32>(pipe, cur, mk[5], tb.g[5], g_off, a, b);
+    bwd_hidden<BG, PL, W32>(pipe, cur, mk[4], tb.g[4], g_off, b, a);
+  } else {
+    bwd_hidden<BG, PL, W32>(pipe, cur, mk[4], tb.g[4], g_off, b, a);
+  }
+  // the skip layer [h_3 | raw input] (modules.py:66-67): its hidden rows give g_3, its raw-input rows the first part of d input
+  bwd_hidden<BG, PL, W32>(pipe, cur, mk[3], tb.g[3], g_off, a, b);
+  bwd_input<BG, PL>(pipe, cur, in_row, 0, b);
+  bwd_hidden<BG, PL, W32>(pipe, cur, mk[2], tb.g[2], g_off, b, a);
+  bwd_hidden<BG, PL, W32>(pipe, cur, mk[1], tb.g[1], g_off, a, b);
+  bwd_hidden<BG, PL, W32>(pipe, cur, mk[0], tb.g[0], g_off, b, a);
+  bwd_input<BG, PL>(pipe, cur, in_row, 1, b);
+  pipe.finish_segment(SEG_NERF);
+}
+
+template <class BG, class PL, int TAG>
+__global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train_backward_kernel(const TrainBwd tb) {
+  using PP = Pipe<BG, PL>;
+  static_assert(wg_waves<PL>() == 4 && !PP::HAS_SHARED, "one 512-register wave per SIMD, one stream");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  Pipe<BG, PL> pipe;
+  pipe.cur = pipe.next = make_rsrc(tb.wstream, PP::NERF_PAD * 1024);
+  pipe.lane16 = lane * 16;
+  pipe.wave1k = wave * 1024;
+  pipe.prologue(SEG_NERF);
+  const long long groups = (tb.M + 127) / 128;
+  for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const long long rr = grp * 128 + wave * 32 + (lane & 31);
+    bwd_chain<BG, PL>(tb, pipe, lane, rr < tb.M ? rr : tb.M - 1, rr < tb.M ? 1 : 0);     // tail lanes redo the last row: same g values to the same places
+  }
+}
+
+}  // namespace nerfds
+
+template <class BG> static void launch_bwd(const nerfds::TrainBwd& tb, int num_cus, void* stream) {
+  using namespace nerfds;
+  using PLX = PlanT<P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3>;      // the data-gradient chains: split bf16 throughout
+  auto kern = train_backward_kernel<BG, PLX, TRAIN_TAG>;
+  allow_dynamic_lds(reinterpret_cast<const void*>(kern), RING_BYTES);
+  const long long groups = (tb.M + 127) / 128;
+  // the 64 / 128-wide chains need <= 256 registers: two workgroups per CU (two waves per SIMD cover each other's waits); the trunk's
+  // takes the whole register file
+  const long long want = (long long)num_cus * (BG::W <= 128 ? 2 : 1);
+  const int grid = (int)(groups < want ? groups : want);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wg_waves<PLX>()), RING_BYTES, static_cast<hipStream_t>(stream), tb);
+}
+// net: 0 NerfMLP (trunk + rgb branch + alpha head), 1 hyper sheet, 2 warp field, 3 mask net
+extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream) {
+  using G = nerfds::NERFDS_GRAPH;
+  if (net == 0) launch_bwd<nerfds::BwdNerf<G>>(tb, num_cus, stream);
+  else if (net == 1) launch_bwd<nerfds::BwdHyper<G>>(tb, num_cus, stream);
+  else if (net == 2) launch_bwd<nerfds::BwdWarp<G>>(tb, num_cus, stream);
+  else launch_bwd<nerfds::BwdMask<G>>(tb, num_cus, stream);
+}

@@ -1,0 +1,114 @@
+// Training forward of ONE level on the fused field (field.h): see train_forward_kernel below.  Built twice by the Makefile
+// (-DNERFDS_TRAIN_HALF=0 -DNERFDS_TRAIN_PIPE=0: fp32 activation stores; =1 / =1: f16 + ReLU bits, pipelined tile epilogue).
+#define NERFDS_KERNEL_KIND 1
+#include "field.h"
+#include "launch.h"
+
+namespace nerfds {
+
+// ------------------------------------------------------------------------------------------------
+// Training forward of ONE level (training.py:198-511 -> models.py:867-1417 on the level's samples): the same field evaluation as
+// render_rays_kernel - same weight pipe, same register-chained layers - on depths the trainer has already drawn (to.z), with every
+// hidden layer's fp32 output and every head's raw output written to the trainer's workspace for the backward pass.  No
+// compositing here: the loss kernel composites from sigma / rgb (train_kernels.hip).  The host passes the level's NerfMLP
+// stream and biases in slot 1, so the kernel always evaluates "level 0".
+// ------------------------------------------------------------------------------------------------
+template <class G, class PL, bool WIDE, int TAG>
+__global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train_forward_kernel(const KArgs ka, const TrainOut to) {
+  using SH = Shape<PL, WIDE>;
+  using WaveLds = WaveLdsT<SH::MAXS>;
+  constexpr int NT = SH::NT, SPLIT = SH::SPLIT, RAYS_PER_WG = SH::RAYS, WAVES = wg_waves<PL>(), BATCH = 32 * NT * SPLIT;
+  using Dm = Dims<G>;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int slot = wave / SPLIT, q = wave % SPLIT;
+  WaveLds& L = *reinterpret_cast<WaveLds*>(g_smem + BIAS_OFF + bias_bytes<G>() + slot * (int)sizeof(WaveLds));
+  auto ray_sync = [&]() { if constexpr (SPLIT > 1) __syncthreads(); else WAVE_SYNC(); };
+  using PP = Pipe<G, PL>;
+  Pipe<G, PL> pipe;
+  const rsrc_t rs_nerf = make_rsrc(ka.wstream[1], PP::NERF_PAD * 1024);
+  const rsrc_t rs_shared = PP::HAS_SHARED ? make_rsrc(ka.wstream[0], PP::SHARED_PAD * 1024) : rs_nerf;
+  pipe.cur = pipe.next = rs_shared;
+  pipe.lane16 = lane * 16;
+  pipe.wave1k = wave * 1024;
+  pipe.prologue(PP::HAS_SHARED ? SEG_SHARED : SEG_NERF);
+  {  // biases -> LDS (as render_rays_kernel; only the shared nets and slot 1 are used)
+    constexpr int n0 = Dm::SHARED_BIAS_TILES * 32, n1 = Dm::NERF_BIAS_TILES * 32;
+    float* dst = reinterpret_cast<float*>(g_smem + BIAS_OFF);
+    for (int i0 = 0; i0 < n0 + n1; i0 += 64 * WAVES) {        // uniform trip count, as in render_rays_kernel
+      const int ix = i0 + (int)threadIdx.x, i = ix < n0 + n1 ? ix : n0 + n1 - 1;
+      const float v = i < n0 ? ka.bias[0][i] : ka.bias[1][i - n0];
+      const int t = i >> 5, m = i & 31;
+      dst[bias_tile_off(t) / 4 + 128 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)] = v;
+    }
+    __syncthreads();
+  }
+  const int S = ka.nc;
+  const int groups = (ka.num_rays + RAYS_PER_WG - 1) / RAYS_PER_WG;
+  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const int ray_raw = grp * RAYS_PER_WG + slot;
+    const int ray = (ray_raw < ka.num_rays) ? ray_raw : ka.num_rays - 1;     // tail slots redo the last ray: same values to the same rows
+    RayConst rc;
+    float vdir[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      rc.o[c] = ka.origins[3 * (size_t)ray + c];
+      rc.d[c] = ka.directions[3 * (size_t)ray + c];
+      vdir[c] = (ka.viewdirs ? ka.viewdirs : ka.directions)[3 * (size_t)ray + c];
+    }
+    rc.gt_mask = (ka.gt_mask != nullptr) ? ka.gt_mask[ray] : 0.f;
+    if (q == 0) {
+      uint32_t wid = (G::HAS_WARP && ka.warp_id != nullptr) ? ka.warp_id[ray] : 0u;
+      wid = wid < (uint32_t)ka.num_embeds ? wid : (uint32_t)(ka.num_embeds - 1);
+      if (lane < 8) {
+        L.rayc[RC_WEMB + lane] = G::HAS_WARP ? ka.warp_embed[(size_t)wid * 8 + lane] : 0.f;
+        L.rayc[RC_MEMB + lane] = G::HAS_MASK ? ka.mask_embed[(size_t)wid * 8 + lane] : 0.f;
+      }
+      if (lane < 24) {
+        const int band = lane / 6, sc = (lane % 6) / 3, ch = lane % 3;
+        const float vdc = ch == 0 ? vdir[0] : (ch == 1 ? vdir[1] : vdir[2]);
+        L.rayc[RC_VDENC + lane] = sin_cw(fmaf(vdc, (float)(1 << band), sc ? 1.57079637f : 0.0f));
+      }
+      if (lane < 3) L.rayc[RC_VD + lane] = lane == 0 ? vdir[0] : (lane == 1 ? vdir[1] : vdir[2]);
+      for (int i = lane; i < S; i += 64) L.zs[i] = to.z[(size_t)ray * S + i];
+    }
+    ray_sync();
+    for (int sb = 0; sb < S; sb += BATCH) {
+      Samples<NT> sm;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int sx = sb + 32 * NT * q + 32 * nt + (lane & 31);
+        sm.slot[nt] = sx < S ? sx : S - 1;       // tail lanes repeat sample S - 1: same values, same rows
+        sm.z[nt] = L.zs[sm.slot[nt]];
+      }
+      const size_t row = (size_t)ray * S + (size_t)sm.slot[0];     // this lane's row of the [R * S][width] activation arrays
+      if constexpr (PP::HAS_SHARED) { pipe.cur = rs_shared; pipe.next = rs_nerf; }
+      eval_shared<G, PL, NT, WaveLds, TrainOut>(ka, rc, pipe, lane, sm, L, to, row);
+      pipe.cur = rs_nerf;
+      pipe.next = rs_shared;
+      eval_nerf<G, PL, NT, WaveLds, TrainOut>(ka, pipe, 0, lane, sm, L, to, row);
+    }
+    ray_sync();
+  }
+}
+
+// the trainer's arithmetic: 16-bit split operands everywhere, fp32 products in the warp field
+using KernelPlan = PlanT<TRAIN_PLAN.mask, TRAIN_PLAN.warp, TRAIN_PLAN.hyp, TRAIN_PLAN.trunk, TRAIN_PLAN.rgb>;
+}  // namespace nerfds
+
+template <bool WIDE> static void launch_train(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream) {
+  using namespace nerfds;
+  using SH = Shape<KernelPlan, WIDE>;
+  constexpr int lds = BIAS_OFF + bias_bytes<NERFDS_GRAPH>() + SH::RAYS * (int)sizeof(WaveLdsT<SH::MAXS>);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = train_forward_kernel<NERFDS_GRAPH, KernelPlan, WIDE, TRAIN_TAG>;
+  allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+  const long long groups = ((long long)ka.num_rays + SH::RAYS - 1) / SH::RAYS;
+  const int grid = (int)(groups < num_cus ? groups : num_cus);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wg_waves<KernelPlan>()), lds, static_cast<hipStream_t>(stream), ka, to);
+}
+// ka.nc = samples of the level (ka.nf unused); ka.wstream[1] / ka.bias[1] = the level's NerfMLP
+extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream) {
+  if (ka.nc > nerfds::Shape<nerfds::KernelPlan, false>::MAXS) launch_train<true>(ka, to, num_cus, stream);
+  else launch_train<false>(ka, to, num_cus, stream);
+}

@@ -970,7 +970,7 @@ void adam(hipStream_t st, float* p, const float* g, float* m1, float* m2, long l
 }
 
 // ------------------------------------------------------------------------------------------------
-// Weight streams of the fused forward (render_kernel.hip train_forward_kernel) from the CURRENT parameters, every step.
+// Weight streams of the fused forward (train_fwd_kernel.hip) from the CURRENT parameters, every step.
 // The host packs the streams once with the parameters replaced by their own indices (nerfds_train.cpp build_fused_forward):
 // map[i] = 1 + index into theta (or, past P, into `fold`) of the value at float slot i of the fp32-layout stream, 0 = padding.
 // ------------------------------------------------------------------------------------------------

@@ -10,7 +10,9 @@ Deviations, all deliberate (DESIGN.md "Out of scope"):
   * per-sample tensors (sigma, alpha, weights, ...) are produced only when asked for
     (``return_weights`` / ``return_points`` / ``return_samples``): the reference always returns ~15
     per-sample arrays that render.py then throws away (render.py:192-193);
-  * ``target_norm`` (needs d sigma / d x, models.py:1065-1077) is not produced by the HIP path yet;
+  * ``target_norm`` (d sigma / d x, models.py:1065-1077) is produced on request only (``use_sigma_gradient=True``: the rays go
+    through the trainer's tangent pass in blocks, ``_target_norm`` below); the render kernel itself does not compute it because
+    render.py discards it;
   * sampling randomness: JAX threefry streams cannot be reproduced, so either inject ``t_rand`` / ``u_rand``
     or an on-chip Philox4x32 stream keyed by the integer seed derived from ``rngs`` is used.
 """

@@ -4,8 +4,12 @@ colourisation of hypernerf/visualization.py:178-235 (scale_values, interpolate_c
 conversion of hypernerf/image_utils.py:124-131 (image_to_uint8).  Only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline may import this file.
 
-PARITY UNPINNED: the reference ships no test or fixture for this path; cv2 / mediapy / matplotlib are not importable here.
-The oracle restates the numpy arithmetic of those lines INCLUDING its dtypes, because the outputs are bytes and must
+PARITY: the depth colourisation (get_colormap, scale_values, interpolate_colormap, colorize) is PINNED BY REFERENCE-RUN VECTORS:
+hypernerf/visualization.py needs only numpy + matplotlib and runs in the build container; tests/golden/make_frame_golden.py
+executes it from /root/reference and tests/golden/frame_colorize_ref.npz holds its outputs for the real 'magma' table that
+render.py:263 uses (tests/test_frames.py::test_oracle_matches_reference_run_colorize, bit for bit).  The rest of the frame
+assembly (render.py:231-268, image_utils.image_to_uint8) imports cv2 / mediapy / jax and cannot run here: those lines stay
+restated and unpinned.  The oracle restates the numpy arithmetic INCLUDING its dtypes, because the outputs are bytes and must
 match bit for bit:
   * the tiles that come from the model are float32; matplotlib colormaps are float64 [256, 3], so ``depth_viz`` is
     float64 and np.concatenate promotes the whole debug frame to float64 before ``* 255`` (render.py:265-268), while the
@@ -26,13 +30,19 @@ def sinebow(h):                                                       # visualiz
   return np.stack([f(3 / 6 - h), f(5 / 6 - h), f(7 / 6 - h)], -1)
 
 
-def get_colormap(name, num_bins=256):                                  # visualization.py:173-183 (analytic maps only)
+def get_colormap(name, num_bins=256):                                  # visualization.py:158-164, 173-183
   if name == 'sinebow':
     return np.array([sinebow(i) for i in np.linspace(0, 1, num_bins)])
-  if name == 'gray':
+  if name == 'gray':                                                   # (not a reference map: an analytic table for known answers)
     g = np.linspace(0, 1, num_bins)
     return np.stack([g, g, g], -1)
-  raise KeyError(name)
+  # _build_colormap: the matplotlib map sampled at num_bins points, rebuilt as a LinearSegmentedColormap and sampled again
+  from matplotlib import cm
+  from matplotlib.colors import LinearSegmentedColormap
+  base = cm.get_cmap(name)
+  color_list = base(np.linspace(0, 1, num_bins))
+  colormap = LinearSegmentedColormap.from_list(base.name + str(num_bins), color_list, num_bins)
+  return colormap(np.linspace(0, 1, num_bins))[:, :3]
 
 
 def scale_values(values, vmin, vmax, eps=1e-6):                        # visualization.py:195-196
@@ -49,9 +59,17 @@ def interpolate_colormap(values, colormap):                            # visuali
   return colormap[a] + (colormap[b] - colormap[a]) * f[..., np.newaxis]
 
 
-def colorize(array, cmin, cmax, colormap, eps=1e-6, invert=False):     # visualization.py:199-235 with clip=False
+def colorize(array, cmin=None, cmax=None, colormap='magma', eps=1e-6, invert=False, clip=False):     # visualization.py:199-235
   array = np.asarray(array, np.float32)
+  if cmin is None:
+    cmin = array.min()
+  if cmax is None:
+    cmax = array.max()
+  if isinstance(colormap, str):
+    colormap = get_colormap(colormap)
   x = scale_values(array, cmin, cmax, eps)
+  if clip:
+    x = np.clip(x, 0.0, 1.0)
   colorized = interpolate_colormap(np.float32(1.0) - x if invert else x, np.asarray(colormap, np.float64))
   colorized[x > 1.0] = 0.0 if invert else 1.0
   colorized[x < 0.0] = 1.0 if invert else 0.0

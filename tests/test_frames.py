@@ -61,6 +61,57 @@ def test_oracle_mosaic_layout():
   np.testing.assert_array_equal(dbg[H, 2 * W], [255, 0, 127])         # (p + 1.5) / 3
 
 
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'frame_colorize_ref.npz')
+
+
+def test_oracle_matches_reference_run_colorize():
+  """The oracle's colourisation against outputs of the REFERENCE's own visualization.py, run in the build container by
+  tests/golden/make_frame_golden.py (real 'magma' / 'turbo' tables, render.py:263's arguments and the function's other modes):
+  bit for bit, float64."""
+  g = np.load(GOLD)
+  import matplotlib
+  if matplotlib.__version__ == str(g['matplotlib_version']):       # the tables come out of matplotlib: same version, same bits
+    for name in ('magma', 'sinebow'):
+      np.testing.assert_array_equal(FO.get_colormap(name), g[f'table_{name}'])
+  magma, turbo = g['table_magma'], g['table_turbo']
+  got = FO.interpolate_colormap(g['interp_values'], magma)
+  np.testing.assert_array_equal(got, g['interp_magma'])
+  for ci in g['cases']:
+    d = g[f'c{ci}_depth']
+    near, far = (float(x) for x in g[f'c{ci}_near_far'])
+    assert d.dtype == np.float32
+    np.testing.assert_array_equal(FO.scale_values(d, near, far), g[f'c{ci}_scaled'])
+    with np.errstate(invalid='ignore'):
+      np.testing.assert_array_equal(FO.colorize(d, near, far, magma, invert=True), g[f'c{ci}_magma_inv'])
+      np.testing.assert_array_equal(FO.colorize(d, near, far, magma), g[f'c{ci}_magma'])
+      np.testing.assert_array_equal(FO.colorize(d, near, far, turbo, invert=True), g[f'c{ci}_turbo_inv'])
+      np.testing.assert_array_equal(FO.colorize(d, near, far, magma, invert=True, clip=True), g[f'c{ci}_magma_inv_clip'])
+      np.testing.assert_array_equal(FO.colorize(d, colormap=magma), g[f'c{ci}_magma_auto'])
+    assert g[f'c{ci}_magma_inv'].dtype == np.float64
+
+
+@pytest.mark.gpu
+def test_hip_depth_tile_matches_reference_run_colorize():
+  """nerfds_frame_images on the fixture's depth maps with the real magma table: the depth tile of the debug mosaic equals
+  image_to_uint8 of the REFERENCE-run colorize output byte for byte (render.py:263-268)."""
+  import torch
+  from nerfds_amd.frames import frame_images, get_colormap
+  g = np.load(GOLD)
+  np.testing.assert_array_equal(get_colormap('magma'), g['table_magma'])      # the product's own table lookup (same matplotlib in the image)
+  for ci in g['cases']:
+    d = g[f'c{ci}_depth']
+    H, W = d.shape
+    near, far = (float(x) for x in g[f'c{ci}_near_far'])
+    r = _records(H, W, 11 + int(ci), near, far)
+    r[:, FO.F_MED_DEPTH] = d.reshape(-1)
+    want = FO.image_to_uint8(g[f'c{ci}_magma_inv'])
+    for table in ('magma', g['table_magma']):
+      _, dbg = frame_images(torch.from_numpy(r).cuda(), H, W, near, far, colormap=table)
+      got = dbg.cpu().numpy()[:H, W:2 * W]
+      diff = got != want
+      assert int(diff.sum()) == 0, f'case {ci}: {int(diff.sum())} differing bytes, first at {np.argwhere(diff)[0]}'
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('H,W,cmap', [(5, 7, 'sinebow'), (64, 48, 'gray'), (600, 800, 'random')])
 def test_hip_frame_images_are_byte_exact(H, W, cmap):

@@ -192,7 +192,7 @@ def test_training_step_at_config4_size():
 @pytest.mark.gpu
 @pytest.mark.parametrize('R,nc,nf', [(1001, 48, 16), (70, 128, 128), (301, 24, 0)])
 def test_fused_forward_equals_the_layer_by_layer_forward(monkeypatch, R, nc, nf):
-  """The step's forward is ONE launch per level (render_kernel.hip train_forward_kernel: the render kernel's field evaluation writing
+  """The step's forward is ONE launch per level (train_fwd_kernel.hip: the render kernel's field evaluation writing
   every activation); NERFDS_TRAIN_FUSED_FWD=0 runs the same forward as ~50 layer kernels.  Same parameters, rays and jitter: the two
   losses agree to 1e-5, every gradient leaf to 2.5e-2 of its largest entry and the median leaf to 2e-3 (both forwards round operands
   to split bf16 in a different order, and a ReLU unit within that rounding of zero switches its whole gradient path: the same
@@ -425,7 +425,7 @@ def test_gradients_match_the_oracle_at_multi_tile_size(full):
 @pytest.mark.gpu
 @pytest.mark.parametrize('g16', [False, True])
 def test_fused_backward_chain_against_numpy_on_the_step_buffers(g16, monkeypatch):
-  """Kernel-level pin of the fused backward (render_kernel.hip train_backward_kernel) on the buffers of one step, read back through
+  """Kernel-level pin of the fused backward (train_bwd_kernel.hip) on the buffers of one step, read back through
   nerfds_trainer_debug_read: the forward's ReLU bits equal (f16 activation > 0) bit for bit; the first two links of the NerfMLP
   chain - g_rgb = 1[h_rgb > 0] (d rgb_logit W_rgb^T) and g_7 = 1[h_7 > 0] (g_rgb F^T + d alpha W_alpha^T), F = the bottleneck folded
   into rgb hidden_0 - and the input gradient d_trunk_in = g_0 W_0^T + g_4 W_4[raw-input rows]^T equal a float64 numpy evaluation of

@@ -1,4 +1,4 @@
-"""Numpy emulation of how render_kernel.hip consumes the packed MFMA weight stream.
+"""Numpy emulation of how field.h (the fused kernels) consumes the packed MFMA weight stream.
 
 It restates, independently of the C++ packer, the conventions of the device code:
   * fragment = [32 rows m] x [16 k-slots (h, i)], lane = (h << 5) | m; the stream is a sequence of 1-KiB units: a bf16 / f16

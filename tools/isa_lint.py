@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development lint for the hipcc issue described at eval_batch (render_kernel.hip): reports vector copies/spills that
+"""Development lint for the hipcc issue described at eval_shared (field.h): reports vector copies/spills that
 sit at the top of a basic block BEFORE the instruction that restores exec (s_or_b64 exec, exec, ...), i.e. copies that
 run under the partial EXEC of the region being closed.   usage: hipcc ... --cuda-device-only -S -o k.s ; isa_lint.py k.s"""
 import re, sys
