@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NERFDS_ABI_VERSION 3
+#define NERFDS_ABI_VERSION 4
 
 /* error codes */
 #define NERFDS_OK         0
@@ -168,6 +168,14 @@ typedef struct nerfds_rays {
    * (origin = camera position, viewdir = direction). */
   const nerfds_camera* camera;
   int64_t first_pixel;
+  /* metadata_encoded=True (models.py:898-899, 908-909): per-ray GLO vectors instead of ids - what evaluation.encode_metadata
+   * (evaluation.py:29-50) produced with NerfModel._encode_embed (models.py:271-294; nerfds_encode_embed below), e.g. the interpolation of
+   * two rows for 3-channel metadata (left id, right id, progression).  encoded_warp [R][glo_num_dims] replaces the warp_embed row of warp_id
+   * (and is the hyper-sheet embedding too: every built graph has hyper_use_warp_embed); NULL = ids.  The mask network's embedding is
+   * looked up from warp_id in the reference even then (models.py:924-926); encoded_mask [R][glo_num_dims], if given, replaces that row
+   * (no reference counterpart: 3-channel metadata has no integer id to look up).  DEVICE pointers. */
+  const float* encoded_warp;
+  const float* encoded_mask;
 } nerfds_rays;
 
 /* Runtime scalars: state.extra_params (model_utils.py:41-52) + the kwargs of NerfModel.__call__ that the
@@ -177,7 +185,15 @@ typedef struct nerfds_extra {
   float mask_ratio;           /* render.py:152: always 1 at inference */
   float near, far;
   int32_t use_stratified_sampling;   /* NerfModel.use_stratified_sampling */
+  /* render_opts of NerfModel.__call__ (filter_sigma, models.py:38-66): densities below dust_threshold, and of samples whose
+   * observation-space point lies outside the box [xmin, xmax, ymin, ymax, zmin, zmax], are zeroed before compositing (models.py:1288);
+   * the per-sample 'sigma' output stays unfiltered (models.py:1271).  render_opt_flags = 0: render_opts is None. */
+  uint32_t render_opt_flags;         /* NERFDS_OPT_* */
+  float dust_threshold;
+  float bounding_box[6];
 } nerfds_extra;
+#define NERFDS_OPT_DUST_THRESHOLD 1u
+#define NERFDS_OPT_BOUNDING_BOX   2u
 
 /* Sampling uniforms.  The reference draws them from JAX threefry streams (model_utils.py:84,217) which
  * cannot be reproduced outside JAX; for parity they are injected.  Either pointer NULL -> on-chip
@@ -210,6 +226,12 @@ int nerfds_ctx_create(nerfds_ctx** out, int device, const nerfds_model_cfg* cfg)
 int nerfds_ctx_load_weights(nerfds_ctx* ctx, const nerfds_weights* w);
 int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_extra* extra,
                        const nerfds_rand* rnd, const nerfds_out* out, uint32_t flags, void* hip_stream);
+/* NerfModel._encode_embed (models.py:271-294) on the device, the body of evaluation.encode_metadata (evaluation.py:29-50):
+ * metadata [R][channels] (float: ids are small integers) -> out [R][glo_num_dims].  channels 1: the GLO row of the id; channels 3:
+ * (1 - progression) * row(left) + progression * row(right).  table: 0 = warp_embed (encode_warp_embed / encode_hyper_embed of the
+ * built graphs), 1 = mask_embed.  Ids are cast like astype(uint32) and clamped like a jnp gather.  DEVICE pointers. */
+int nerfds_encode_embed(nerfds_ctx* ctx, int32_t table, const float* metadata, int32_t channels, int64_t num_rays, float* out,
+                        void* hip_stream);
 int nerfds_ctx_destroy(nerfds_ctx* ctx);
 /* Message of the last failure on this ctx (or of the last failed nerfds_ctx_create when ctx == NULL). */
 const char* nerfds_last_error(const nerfds_ctx* ctx);

@@ -332,6 +332,8 @@ template <class G, class PL> struct Pipe {
     static_assert(PIECES == 4 || PIECES == 2, "vmcnt(PIECES) below");
     const int tprev = s + NS - 2;              // the stage issued since the previous boundary (s == 0: by the previous segment's last stage)
     const bool prev_issued = tprev >= seg_stages(seg) || tprev < seg_used(seg);
+    // (A counted lgkmcnt in the pinned chains - the 8 youngest ring reads left in flight, safe there because program order is source order -
+    // measured +-0 against the full drain: 38.25 against 38.26 ms per 65 536 rays, profiles/r4_ab/ab_x3_pin_variants.txt; not kept.)
     if (prev_issued && PIECES == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else if (prev_issued) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -574,10 +576,50 @@ DEVI f32x16 load_bias(int t, int hb) {
 // constants).  The B operand (activation chunk) is shared by the TP MFMAs.
 // `slot(j, tp)` runs after the MFMAs of the j-th (chunk, tile) step of the tile group - the place where the previous group's
 // epilogue is issued when it is software-pipelined (dense()).
-template <class G, class PL, int NT, int TP, int P, int K, class SLOT>
-DEVI void accum(f32x16 (&acc)[TP][NT], Pipe<G, PL>& pipe, Cursor& cur, const Chunk<P> (&in)[NT][K], int& j, SLOT&& slot) {
+// The split-bf16 render kernel's tile epilogue inside the next group's MFMA chain, in pinned program order (dense(): first branch)
+#ifndef NERFDS_X3_PIN
+#define NERFDS_X3_PIN 1
+#endif
+constexpr bool X3_PIN = !IS_TRAIN && NERFDS_X3_PIN != 0;
+// `win(w)` (pinned form, interleaved split-bf16 chains only): runs after MFMA w of the tile group; every MFMA is followed by an ordering point -
+// an empty volatile asm that "rewrites" both accumulators - so each MFMA sits between two of them in the instruction stream, and what `win`
+// issues (volatile asm too) stays in its window: program order is source order, instruction by instruction.  The ring reads of a chunk
+// step go out behind its first four MFMAs (loads do not cross volatile asm either).
+struct NoWin { static constexpr bool ON = false; DEVI void operator()(int) const {} };
+template <class F> struct Win { static constexpr bool ON = true; F& f; DEVI void operator()(int w) const { f(w); } };
+template <class G, class PL, int NT, int TP, int P, int K, class SLOT, class WIN = NoWin>
+DEVI void accum(f32x16 (&acc)[TP][NT], Pipe<G, PL>& pipe, Cursor& cur, const Chunk<P> (&in)[NT][K], int& j, SLOT&& slot, const WIN& win = WIN()) {
   using PP = Pipe<G, PL>;
   constexpr int NP = frag_parts(P);
+  if constexpr (WIN::ON) {
+    static_assert(PP::X3_INTERLEAVE && P == P_BF16X3 && TP == 2 && NT == 1, "pinned windows: interleaved split-bf16 tile pairs");
+#pragma unroll
+    for (int kc = 0; kc < K; ++kc) {
+      const int u = cur.pos;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if ((u + q) % PP::SU == 0) pipe.begin_stage(cur.seg, u + q);
+      const WFrag<P> w0 = pipe.template frag<P>(u), w1 = pipe.template frag<P>(u + 2);
+      const Chunk<P>& c = in[0][kc];
+      // (always_inline: as an ordinary call its argument is a run-time value, the unrolled indices stop being constants and the ring lands in scratch)
+      auto after = [&](int m) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]));
+#endif
+        if (m < 4) { pipe.refill(cur.seg, u + m); pipe.spread_piece(cur.seg, u + m); }
+        win(3 * j + m);
+      };
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, c.lo, acc[0][0], 0, 0, 0); after(0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, c.lo, acc[1][0], 0, 0, 0); after(1);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.lo, c.hi, acc[0][0], 0, 0, 0); after(2);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.lo, c.hi, acc[1][0], 0, 0, 0); after(3);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, c.hi, acc[0][0], 0, 0, 0); after(4);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, c.hi, acc[1][0], 0, 0, 0); after(5);
+      cur.pos += 4;
+      j += 2;
+    }
+    return;
+  }
   if constexpr (PP::X3_INTERLEAVE && P == P_BF16X3 && TP == 2) {
     // Split bf16, one wave per SIMD: the three MFMAs of a product go to the same accumulator, and whatever hipcc places
     // between two MFMAs on the SAME accumulator (weight reads, waits, epilogue VALU) costs ~43 cycles instead of its issue
@@ -676,6 +718,39 @@ template <int P> DEVI void tile_epilogue_asm(Chunk<P>& c0, Chunk<P>& c1, const f
 #endif
 }
 
+// One group's conversion (2 tiles x 16 accumulator registers -> 4 split-bf16 chunks) as 128 single VALU instructions: per value pair
+// ReLU, ReLU, hi = cvt_pk, unpack, unpack, subtract, subtract, lo = cvt_pk - make_chunk<P_BF16X3>'s arithmetic on relu_f'd values.  Two pairs
+// are in flight at a time (op i: block i / 16 of two pairs, step (i % 16) / 2, pair i % 2), so neighbouring instructions are independent.
+struct X3Epi {
+  static constexpr int OPS = 128;
+  float t0[2], t1[2];
+  unsigned hi[2], lo[2], h0[2], h1[2];
+  unsigned uh[2][8], ul[2][8];
+};
+template <int W> DEVI void x3_epi_op(int i, const f32x16 (&prev)[2], X3Epi& e, Chunk<P_BF16X3> (&out)[1][W], int pot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int w = i % 2, s = (i % 16) / 2, pair = 2 * (i / 16) + w, tp = pair / 8, k = pair % 8;
+  if (s == 0) asm volatile("v_max_i32 %0, 0, %1" : "=v"(e.t0[w]) : "v"(prev[tp][2 * k]));
+  else if (s == 1) asm volatile("v_max_i32 %0, 0, %1" : "=v"(e.t1[w]) : "v"(prev[tp][2 * k + 1]));
+  else if (s == 2) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(e.hi[w]) : "v"(e.t0[w]), "v"(e.t1[w]));
+  else if (s == 3) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(e.h0[w]) : "v"(e.hi[w]));
+  else if (s == 4) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(e.h1[w]) : "v"(e.hi[w]));
+  else if (s == 5) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(e.t0[w]) : "v"(e.t0[w]), "v"(e.h0[w]));
+  else if (s == 6) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(e.t1[w]) : "v"(e.t1[w]), "v"(e.h1[w]));
+  else {
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(e.lo[w]) : "v"(e.t0[w]), "v"(e.t1[w]));
+    e.uh[tp][k] = e.hi[w];
+    e.ul[tp][k] = e.lo[w];
+    if (k % 4 == 3) {                                              // a chunk (8 values) of the pending group is complete
+      const int sub = k / 4, t = pot + tp;
+      const u32x4 rh = {e.uh[tp][4 * sub], e.uh[tp][4 * sub + 1], e.uh[tp][4 * sub + 2], e.uh[tp][4 * sub + 3]};
+      const u32x4 rl = {e.ul[tp][4 * sub], e.ul[tp][4 * sub + 1], e.ul[tp][4 * sub + 2], e.ul[tp][4 * sub + 3]};
+      out[0][2 * t + sub].hi = __builtin_bit_cast(bf16x8, rh);
+      out[0][2 * t + sub].lo = __builtin_bit_cast(bf16x8, rl);
+    }
+  }
+#endif
+}
 template <class T> struct seg_chunks;
 template <int P, int NT, int K> struct seg_chunks<Chunk<P>[NT][K]> { static constexpr int value = K; };
 template <class... Ins> struct seg_total { static constexpr int value = (seg_chunks<Ins>::value + ... + 0); };
@@ -698,7 +773,46 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Chunk<PO> (&out)[NT][2 * OT], Ins&.
   constexpr bool ASM_EPI = PL::NT == 1 && is_single(PO) && RELU && PL::UNIFORM;
   const int hb = bias_base(pipe.lane16);
   auto no_slot = [](int, int) {};
-  if constexpr (TRAIN && !BWD_IN && TRAIN_PIPE && (OT > TP) && (BWD ? PO == P_BF16X3 : true)) {
+  if constexpr (!TRAIN && X3_PIN && PO == P_BF16X3 && RELU && Pipe<G, PL>::X3_INTERLEAVE && (OT > TP)) {
+    // Split bf16 render kernel: one 512-register wave per SIMD, so nothing covers a tile group's epilogue - 128 VALU (ReLU + hi / lo split of 32
+    // values) behind 24 - 96 MFMAs.  As hipcc schedules it, every group's conversion is ONE uninterrupted run behind the group's last MFMA
+    // (the stage boundaries cut a group into scheduling regions, and nothing moves across them): 15 % of the kernel's time, measured by issuing the
+    // conversion twice (38.7 -> 44.8 ms per 65 536 rays, profiles/r4_ab/ab_epi2.txt).  Here the accumulators of group g rest in `prev` and their
+    // conversion is issued as single-instruction volatile asm statements in the MFMA windows of group g + 1 (accum: PIN) - program order is the
+    // source order, PER VALU per window from window J0 on (the MFMA -> VALU hazard of `prev` is then >= J0 MFMAs old: hipcc does not pad it for
+    // asm).  Same arithmetic, same order per accumulator: bit-identical results.
+    static_assert(TP == 2 && NT == 1, "pairs of tiles, one N-tile");
+    constexpr int KC = seg_total<Ins...>::value, NW = 6 * KC, J0 = 2;       // MFMA windows per group
+    constexpr int PER = cdiv(X3Epi::OPS, NW - J0), IN_CHAIN = (NW - J0) * PER < X3Epi::OPS ? (NW - J0) * PER : X3Epi::OPS;
+    f32x16 prev[TP];
+    X3Epi e;
+#pragma unroll
+    for (int ot = 0; ot < OT; ot += TP) {
+      f32x16 acc[TP][NT];
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) acc[tp][0] = load_bias(cur.bt + ot + tp, hb);
+      int j = 0;
+      auto fill = [&](int w) __attribute__((always_inline)) {
+        if (ot == 0 || w < J0) return;
+#pragma unroll
+        for (int q = (w - J0) * PER; q < (w - J0 + 1) * PER; ++q)
+          if (q < X3Epi::OPS) x3_epi_op(q, prev, e, out, ot - TP);
+      };
+      Win<decltype(fill)> win{fill};
+      (accum<G, PL, NT, TP>(acc, pipe, cur, ins, j, no_slot, win), ...);
+      if (ot > 0) {
+#pragma unroll
+        for (int q = IN_CHAIN; q < X3Epi::OPS; ++q) x3_epi_op(q, prev, e, out, ot - TP);      // what the chain had no window for (short inputs)
+      }
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) prev[tp] = acc[tp][0];
+    }
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) {                                     // the layer's last group: behind its own chain (builtin MFMAs: hipcc pads the hazard)
+      const f32x16 (&pa)[1] = reinterpret_cast<const f32x16 (&)[1]>(prev[tp]);
+      tile_epilogue<PO, NT, RELU>(out, OT - TP + tp, pa);
+    }
+  } else if constexpr (TRAIN && !BWD_IN && TRAIN_PIPE && (OT > TP) && (BWD ? PO == P_BF16X3 : true)) {
     // Training forward / backward chain, software-pipelined at the source level: the epilogue of tile group g - conversion into the next
     // layer's operand, ReLU bits / mask, 16-bit stores - is cut into pieces that are issued between the MFMA steps of group g + 1 (the
     // accumulators of group g rest in `prev`).  A training kernel runs ONE wave per SIMD: whatever is issued behind a group's last MFMA

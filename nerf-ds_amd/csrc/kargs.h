@@ -16,6 +16,8 @@ struct KArgs {
   const float* viewdirs;
   const uint32_t* warp_id;
   const float* gt_mask;
+  const float* enc_warp;     // [R][8] per-ray GLO vectors instead of the warp_embed row of warp_id (metadata_encoded), or null
+  const float* enc_mask;     // [R][8] the same for the mask network's embedding, or null
   // sampling uniforms (nullable -> Philox)
   const float* t_rand;
   const float* u_rand;
@@ -39,6 +41,10 @@ struct KArgs {
   int white_bkgd;
   float near_, far_;
   float mask_ratio;
+  // render_opts (filter_sigma, models.py:38-66): opt_flags bit 0 dust threshold, bit 1 bounding box (xmin, xmax, ymin, ymax, zmin, zmax)
+  int opt_flags;
+  float dust_threshold;
+  float bbox[6];
   // posenc windows per band (model_utils.py:420-436), evaluated on the host from the extra_params alphas
   float win_mask[MAX_BANDS];   // alpha = warp_alpha        (models.py:967)
   float win_warp[MAX_BANDS];   // alpha = warp_alpha        (warping.py:213)

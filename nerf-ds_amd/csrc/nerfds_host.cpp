@@ -35,6 +35,7 @@ void nerfds_launch_nerfds_mixed(const KArgs&, int, void*);
 void nerfds_launch_static_mixed(const KArgs&, int, void*);
 void nerfds_launch_hyper_mixed(const KArgs&, int, void*);
 void nerfds_launch_camera_rays(const nerfds::CameraParams&, long long, long long, const float*, float*, float*, float*, void*);
+void nerfds_launch_encode_embed(const float* table, int rows, const float* meta, int channels, long long n, float* out, void* stream);
 void nerfds_launch_frame_images(const float*, int, int, float, float, const double*, uint8_t*, uint8_t*, void*);
 }
 static_assert(sizeof(nerfds_camera) == sizeof(nerfds::CameraParams), "nerfds_camera and CameraParams must have the same layout");
@@ -378,7 +379,11 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   if (rays->camera && (rays->first_pixel < 0 || rays->camera->image_width <= 0 ||
                        rays->first_pixel + rays->num_rays > (int64_t)rays->camera->image_width * rays->camera->image_height))
     return ctx->fail(NERFDS_EINVAL, "camera pixel range [first_pixel, first_pixel + num_rays) is outside the image");
-  if (ctx->cfg.use_warp && !rays->warp_id) return ctx->fail(NERFDS_EINVAL, "metadata['warp'] ids are required by this graph");
+  if (ctx->cfg.use_warp && !rays->warp_id && !rays->encoded_warp)
+    return ctx->fail(NERFDS_EINVAL, "metadata['warp'] ids (or encoded_warp vectors) are required by this graph");
+  if (ctx->cfg.use_predicted_mask && !rays->warp_id && !rays->encoded_mask)
+    return ctx->fail(NERFDS_EINVAL, "the mask network looks its embedding up from metadata['warp'] ids (models.py:924-926): pass warp_id or encoded_mask");
+  if (extra->render_opt_flags & ~(NERFDS_OPT_DUST_THRESHOLD | NERFDS_OPT_BOUNDING_BOX)) return ctx->fail(NERFDS_EINVAL, "unknown render_opt_flags");
   if (extra->mask_ratio != 1.0f && ctx->cfg.use_predicted_mask && !rays->gt_mask)
     return ctx->fail(NERFDS_EINVAL, "rays_dict['mask'] is required when mask_ratio != 1");
   if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(NERFDS_EDEVICE, "hipSetDevice failed");
@@ -388,6 +393,11 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   KArgs ka{};
   ka.origins = rays->origins; ka.directions = rays->directions; ka.viewdirs = rays->viewdirs;
   ka.warp_id = rays->warp_id; ka.gt_mask = rays->gt_mask;
+  ka.enc_warp = ctx->cfg.use_warp ? rays->encoded_warp : nullptr;
+  ka.enc_mask = ctx->cfg.use_predicted_mask ? rays->encoded_mask : nullptr;
+  ka.opt_flags = (int)extra->render_opt_flags;
+  ka.dust_threshold = extra->dust_threshold;
+  for (int i = 0; i < 6; ++i) ka.bbox[i] = extra->bounding_box[i];
   ka.t_rand = rnd ? rnd->t_rand : nullptr;
   ka.u_rand = rnd ? rnd->u_rand : nullptr;
   ka.seed = rnd ? rnd->seed : 0;
@@ -448,6 +458,21 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
     (void)hipEventRecord(ev.second, stream);
     ctx->events.push_back(ev);
   }
+  if (e != hipSuccess) return ctx->fail(NERFDS_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+  return NERFDS_OK;
+}
+
+int nerfds_encode_embed(nerfds_ctx* ctx, int32_t table, const float* metadata, int32_t channels, int64_t num_rays, float* out, void* hip_stream) {
+  if (!ctx) return NERFDS_EINVAL;
+  if (!ctx->W.loaded) return ctx->fail(NERFDS_EINVAL, "nerfds_ctx_load_weights has not been called");
+  if ((table != 0 && table != 1) || (channels != 1 && channels != 3) || num_rays < 0 || (num_rays > 0 && (!metadata || !out)))
+    return ctx->fail(NERFDS_EINVAL, "nerfds_encode_embed: table 0 | 1, channels 1 | 3, non-null pointers");
+  const float* tab = static_cast<const float*>(table == 0 ? ctx->warp_embed.p : ctx->mask_embed.p);
+  if (!tab) return ctx->fail(NERFDS_EINVAL, "this graph has no %s table", table == 0 ? "warp_embed" : "mask_embed");
+  if (num_rays == 0) return NERFDS_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(NERFDS_EDEVICE, "hipSetDevice failed");
+  nerfds_launch_encode_embed(tab, ctx->cfg.num_warp_embeds > 0 ? ctx->cfg.num_warp_embeds : 1, metadata, channels, num_rays, out, hip_stream);
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ctx->fail(NERFDS_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));
   return NERFDS_OK;
 }

@@ -42,7 +42,19 @@ DEVI void composite(const KArgs& ka, const RayConst& rc, int ray, int lane, int 
     float dist = (sc == S - 1) ? last : (zn - z);
     dist *= dnorm;                                                         // model_utils.py:124-128
     const float sigma = L.sv[SV_SIGMA][sc];
-    float alpha = valid ? (1.0f - expf(-sigma * dist)) : 0.0f;             // model_utils.py:129
+    float xo[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xo[c] = __fadd_rn(rc.o[c], __fmul_rn(z, rc.d[c]));
+    // render_opts (filter_sigma, models.py:38-66, applied at models.py:1288 to the ACTIVATED density; the per-sample 'sigma' output below is
+    // the unfiltered one, models.py:1271): (sigma >= dust_threshold) * sigma, then (point inside the box) * sigma.  Uniform flags, selects.
+    float sig_f = sigma;
+    if (ka.opt_flags & 1) sig_f = (sig_f >= ka.dust_threshold) ? sig_f : 0.f * sig_f;
+    if (ka.opt_flags & 2) {
+      const bool in = (xo[0] >= ka.bbox[0]) & (xo[0] <= ka.bbox[1]) & (xo[1] >= ka.bbox[2]) & (xo[1] <= ka.bbox[3]) &
+                      (xo[2] >= ka.bbox[4]) & (xo[2] <= ka.bbox[5]);
+      sig_f = in ? sig_f : 0.f * sig_f;
+    }
+    float alpha = valid ? (1.0f - expf(-sig_f * dist)) : 0.0f;             // model_utils.py:129
     float om = valid ? ((1.0f - alpha) + 1e-10f) : 1.0f;                   // model_utils.py:133
     float incl = wave_scan_mul(om, lane);
     const float excl = wave_shift_up1(incl, 1.0f);
@@ -54,9 +66,6 @@ DEVI void composite(const KArgs& ka, const RayConst& rc, int ray, int lane, int 
     carryC = lane63(cum);
     unsigned long long hit = __ballot(valid && cum >= 0.5f);               // model_utils.py:285-291
     if (med_idx < 0 && hit) med_idx = 64 * j + __builtin_ctzll(hit);
-    float xo[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) xo[c] = __fadd_rn(rc.o[c], __fmul_rn(z, rc.d[c]));
     acc_v[0] += w * L.sv[SV_RGB + 0][sc];
     acc_v[1] += w * L.sv[SV_RGB + 1][sc];
     acc_v[2] += w * L.sv[SV_RGB + 2][sc];
@@ -294,8 +303,11 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
       uint32_t wid = (G::HAS_WARP && ka.warp_id != nullptr) ? ka.warp_id[ray] : 0u;
       wid = wid < (uint32_t)ka.num_embeds ? wid : (uint32_t)(ka.num_embeds - 1);     // jnp gathers clamp out-of-range ids
       if (lane < 8) {
-        L.rayc[RC_WEMB + lane] = G::HAS_WARP ? ka.warp_embed[(size_t)wid * 8 + lane] : 0.f;
-        L.rayc[RC_MEMB + lane] = G::HAS_MASK ? ka.mask_embed[(size_t)wid * 8 + lane] : 0.f;
+        // metadata_encoded (models.py:898-899): the ray's pre-encoded GLO vector instead of the table row of its id (uniform selects)
+        const float* wrow = ka.enc_warp != nullptr ? ka.enc_warp + (size_t)ray * 8 : ka.warp_embed + (size_t)wid * 8;
+        const float* mrow = ka.enc_mask != nullptr ? ka.enc_mask + (size_t)ray * 8 : ka.mask_embed + (size_t)wid * 8;
+        L.rayc[RC_WEMB + lane] = G::HAS_WARP ? wrow[lane] : 0.f;
+        L.rayc[RC_MEMB + lane] = G::HAS_MASK ? mrow[lane] : 0.f;
       }
       if (lane < 24) {
         const int band = lane / 6, sc = (lane % 6) / 3, ch = lane % 3;

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFDS_LIB', os.path.join(_HERE, '_lib', 'libnerfds_hip.so'))   # NERFDS_LIB: development builds
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def resolve_device(device=None):
@@ -82,13 +82,36 @@ class CameraStruct(C.Structure):
 class Rays(C.Structure):
   _fields_ = [('num_rays', C.c_int64), ('origins', C.c_void_p), ('directions', C.c_void_p),
               ('viewdirs', C.c_void_p), ('warp_id', C.c_void_p), ('gt_mask', C.c_void_p),
-              ('camera', C.POINTER(CameraStruct)), ('first_pixel', C.c_int64)]
+              ('camera', C.POINTER(CameraStruct)), ('first_pixel', C.c_int64),
+              ('encoded_warp', C.c_void_p), ('encoded_mask', C.c_void_p)]
 
 
 class Extra(C.Structure):
   _fields_ = [('nerf_alpha', C.c_float), ('warp_alpha', C.c_float), ('hyper_alpha', C.c_float),
               ('hyper_sheet_alpha', C.c_float), ('norm_input_alpha', C.c_float), ('mask_ratio', C.c_float),
-              ('near', C.c_float), ('far', C.c_float), ('use_stratified_sampling', C.c_int32)]
+              ('near', C.c_float), ('far', C.c_float), ('use_stratified_sampling', C.c_int32),
+              ('render_opt_flags', C.c_uint32), ('dust_threshold', C.c_float), ('bounding_box', C.c_float * 6)]
+
+
+OPT_DUST_THRESHOLD, OPT_BOUNDING_BOX = 1, 2
+
+
+def set_render_opts(extra: 'Extra', render_opts) -> None:
+  """render_opts dict of NerfModel.__call__ (filter_sigma, models.py:38-66) -> the nerfds_extra fields."""
+  if render_opts is None:
+    return
+  unknown = set(render_opts) - {'dust_threshold', 'bounding_box'}
+  if unknown:
+    raise ValueError(f'unknown render_opts keys {sorted(unknown)} (filter_sigma knows dust_threshold and bounding_box)')
+  if 'dust_threshold' in render_opts:
+    extra.render_opt_flags |= OPT_DUST_THRESHOLD
+    extra.dust_threshold = float(render_opts['dust_threshold'])
+  if 'bounding_box' in render_opts:
+    box = [float(v) for v in render_opts['bounding_box']]
+    if len(box) != 6:
+      raise ValueError('bounding_box = (xmin, xmax, ymin, ymax, zmin, zmax)')
+    extra.render_opt_flags |= OPT_BOUNDING_BOX
+    extra.bounding_box = (C.c_float * 6)(*box)
 
 
 class Rand(C.Structure):
@@ -102,7 +125,7 @@ class Out(C.Structure):
 
 # every symbol include/nerfds.h declares
 SYMBOLS = ('nerfds_abi_version', 'nerfds_precision_plan', 'nerfds_ctx_create', 'nerfds_ctx_load_weights', 'nerfds_render_rays',
-           'nerfds_ctx_destroy', 'nerfds_last_error', 'nerfds_kernel_time_ms', 'nerfds_pack_stream_bytes',
+           'nerfds_encode_embed', 'nerfds_ctx_destroy', 'nerfds_last_error', 'nerfds_kernel_time_ms', 'nerfds_pack_stream_bytes',
            'nerfds_pack_bias_floats', 'nerfds_pack_stream', 'nerfds_debug_mfma', 'nerfds_camera_to_rays',
            'nerfds_frame_images', 'nerfds_trainer_create', 'nerfds_trainer_destroy', 'nerfds_trainer_param_count',
            'nerfds_trainer_num_leaves', 'nerfds_trainer_leaf', 'nerfds_trainer_params', 'nerfds_trainer_grads',
@@ -126,6 +149,7 @@ def load():
   lib.nerfds_ctx_load_weights.argtypes = [C.c_void_p, C.POINTER(Weights)]
   lib.nerfds_render_rays.argtypes = [C.c_void_p, C.POINTER(Rays), C.POINTER(Extra), C.POINTER(Rand), C.POINTER(Out),
                                      C.c_uint32, C.c_void_p]
+  lib.nerfds_encode_embed.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
   lib.nerfds_ctx_destroy.argtypes = [C.c_void_p]
   lib.nerfds_last_error.argtypes = [C.c_void_p]
   lib.nerfds_last_error.restype = C.c_char_p

@@ -49,6 +49,23 @@ class TrainState:
     return cls(optimizer=SimpleNamespace(target={'model': params}), **alphas)
 
 
+def encode_metadata(model, params, metadata) -> Dict[str, torch.Tensor]:
+  """evaluation.encode_metadata (evaluation.py:29-50): metadata ids - ``[..., 1]``, or ``[..., 3]`` = (left id, right id,
+  progression), NerfModel._encode_embed models.py:271-294 - to per-ray GLO vectors, on the GPU (csrc/embed_kernel.hip).  The result goes
+  back into ``rays_dict['metadata']`` for ``model.apply(..., metadata_encoded=True)``.  Of the reference's three entries the built graphs
+  have ``encoded_warp`` and ``encoded_hyper`` (hyper_use_warp_embed: the same table and the same metadata, models.py:296-319);
+  ``use_nerf_embed`` graphs are not built."""
+  params = params['params'] if 'params' in params else params
+  if params is not getattr(model, '_params_ref', None):
+    model.load_params(params)
+  enc = {}
+  if model.cfg.use_warp:
+    enc['encoded_warp'] = model.encode_embed(metadata['warp'], 'warp')
+    if model.cfg.has_hyper:
+      enc['encoded_hyper'] = enc['encoded_warp']
+  return enc
+
+
 def _world():
   if dist.is_available() and dist.is_initialized():
     return dist.get_rank(), dist.get_world_size()

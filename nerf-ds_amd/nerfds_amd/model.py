@@ -198,10 +198,10 @@ class NerfModel:
     reloaded = reload_params or params is not self._params_ref
     if reloaded:
       self.load_params(params)
-    if metadata_encoded:
-      raise NotImplementedError('metadata_encoded=True (pre-encoded GLO vectors) is not built')
-    if render_opts is not None:
-      raise NotImplementedError('render_opts (dust_threshold / bounding_box, models.py:38-66) is not built')
+    if render_opts is not None and cfg.use_mask_sharp_weights and (return_weights or return_samples or return_points):
+      # filter_sigma runs on the RAW density on that path (models.py:1236-1237) and on the activated one for compositing (models.py:1288);
+      # sharp_weights is rebuilt on the host from the composited weights, which is the same thing only without render_opts
+      raise NotImplementedError('render_opts together with per-sample outputs of a use_mask_sharp_weights model (sharp_weights)')
     if use_sigma_gradient and not (cfg.use_warp and cfg.use_predicted_mask and cfg.has_hyper and nf > 0):
       raise NotImplementedError('use_sigma_gradient=True (target_norm, models.py:1065-1077) is built for the nerf_ds graph: '
                                 'the tangent pass lives in the trainer, which covers only that graph')
@@ -230,9 +230,21 @@ class NerfModel:
       origins, directions = origins.reshape(-1, 3), directions.reshape(-1, 3)
       R = origins.shape[0]
       viewdirs = f32(rays_dict['viewdirs']).reshape(-1, 3) if 'viewdirs' in rays_dict else None
-    warp_id = None
-    if cfg.use_warp:
-      ids = rays_dict['metadata']['warp']
+    warp_id = enc_warp = enc_mask = None
+    metadata = rays_dict.get('metadata', {})
+    if metadata_encoded:
+      # models.py:898-899, 908-909: per-ray GLO vectors from evaluation.encode_metadata instead of ids
+      if cfg.use_warp:
+        enc_warp = f32(metadata['encoded_warp']).reshape(-1, 8)
+        if cfg.has_hyper and 'encoded_hyper' in metadata and metadata['encoded_hyper'] is not metadata['encoded_warp']:
+          if not torch.equal(f32(metadata['encoded_hyper']).reshape(enc_warp.shape), enc_warp):
+            raise NotImplementedError('encoded_hyper != encoded_warp: every built graph has hyper_use_warp_embed (models.py:296-319)')
+        if enc_warp.shape[0] != R:
+          raise ValueError(f'encoded_warp has {enc_warp.shape[0]} rows for {R} rays')
+      if cfg.use_predicted_mask and metadata.get('encoded_mask') is not None:
+        enc_mask = f32(metadata['encoded_mask']).reshape(-1, 8)
+    if cfg.use_warp and (not metadata_encoded or (cfg.use_predicted_mask and enc_mask is None)):
+      ids = metadata['warp']          # (the mask network looks its embedding up from the ids even when metadata_encoded: models.py:924-926)
       ids = ids if isinstance(ids, torch.Tensor) else torch.as_tensor(np.asarray(ids).astype(np.int64))
       # out-of-range ids are clamped in the kernel, as a jnp gather does (nn.Embed, modules.py:331-348)
       warp_id = ids.to(dev).reshape(-1).to(torch.int32).contiguous()   # uint32 bit pattern for ids < 2^31
@@ -260,11 +272,12 @@ class NerfModel:
 
     ptr = lambda t: (t.data_ptr() if t is not None else None)
     rays = N.Rays(R, ptr(origins), ptr(directions), ptr(viewdirs), ptr(warp_id), ptr(gt_mask),
-                  C.pointer(cam_struct) if cam_struct is not None else None, int(first_pixel))
+                  C.pointer(cam_struct) if cam_struct is not None else None, int(first_pixel), ptr(enc_warp), ptr(enc_mask))
     g = lambda k, d=0.0: float(extra_params[k]) if extra_params.get(k) is not None else d
     extra = N.Extra(g('nerf_alpha'), g('warp_alpha'), g('hyper_alpha'), g('hyper_sheet_alpha'), g('norm_input_alpha'),
                     float(mask_ratio), float(cfg.near if near is None else near), float(cfg.far if far is None else far),
                     int(cfg.use_stratified_sampling))
+    N.set_render_opts(extra, render_opts)
     rnd = N.Rand(ptr(t_rand), ptr(u_rand), _seed_from_rngs(rngs), int(ray_offset))
     out = N.Out(ptr(rec_fine), ptr(rec_coarse), ptr(smp_fine), ptr(smp_coarse))
     flags = N.PREC[precision or self.precision]
@@ -291,6 +304,8 @@ class NerfModel:
       # depths: injected uniforms are passed on, and the on-chip Philox stream is keyed identically in both (csrc/philox.h).
       if camera is not None:
         raise NotImplementedError('use_sigma_gradient with fused camera rays: pass origins / directions')
+      if metadata_encoded or render_opts is not None:
+        raise NotImplementedError('use_sigma_gradient with metadata_encoded / render_opts (the tangent pass is the trainer\'s: ids, no render_opts)')
       tn = self._target_norm(params, reloaded, origins, directions, viewdirs, warp_id, gt_mask, extra_params, float(mask_ratio),
                              near, far, t_rand, u_rand, rnd.seed, int(ray_offset))
       for level in ret:
@@ -362,6 +377,21 @@ class NerfModel:
       for level in out:
         out[level].append(torch.as_tensor(tr.target_norm(level), device=self.device))
     return {k: torch.cat(v, 0) for k, v in out.items()}
+
+  def encode_embed(self, metadata, table: str = 'warp', stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+    """NerfModel._encode_embed (models.py:271-294) on the GPU (csrc/embed_kernel.hip): metadata [..., 1] ids or [..., 3] (left id, right id,
+    progression) -> [..., 8] GLO vectors of the loaded parameters' ``warp_embed`` / ``mask_embed`` table."""
+    m = metadata if isinstance(metadata, torch.Tensor) else torch.as_tensor(np.asarray(metadata))
+    if m.shape[-1] not in (1, 3):
+      raise ValueError('metadata must have 1 (id) or 3 (left id, right id, progression) channels')
+    lead, ch = m.shape[:-1], m.shape[-1]
+    m = m.to(self.device, torch.float32).reshape(-1, ch).contiguous()
+    out = torch.empty((m.shape[0], 8), device=self.device, dtype=torch.float32)
+    s = stream if stream is not None else torch.cuda.current_stream(self.device)
+    rc = self._lib.nerfds_encode_embed(self._ctx, {'warp': 0, 'mask': 1}[table], m.data_ptr(), ch, m.shape[0], out.data_ptr(), C.c_void_p(s.cuda_stream))
+    if rc != 0:
+      raise RuntimeError(f'nerfds_encode_embed failed ({rc}): {N.last_error(self._ctx)}')
+    return out.reshape(*lead, 8)
 
   # timing hooks for bench.py -------------------------------------------------------------------------
   def kernel_time_ms(self, reset: bool = False):

@@ -263,6 +263,44 @@ def glo_embed(p, ids):
   return p['embed']['embedding'][ids.long()]
 
 
+def encode_embed(embed, p):
+  """NerfModel._encode_embed (models.py:271-294): one id channel -> the GLO row; three channels (left id, right id, progression)
+  -> (1 - progression) * row(left) + progression * row(right).  Ids are cast like ``astype(jnp.uint32)`` and clamped like a jnp gather."""
+  table = p['embed']['embedding']
+  rows = table.shape[0]
+  row = lambda ids: table[ids.to(torch.int64).clamp(0, rows - 1)]
+  if embed.shape[-1] == 3:
+    left, right, progression = embed[..., 0], embed[..., 1], embed[..., 2:3].to(table.dtype)
+    return (1.0 - progression) * row(left) + progression * row(right)
+  return row(embed[..., 0])
+
+
+def encode_metadata(cfg, params, metadata):
+  """evaluation.encode_metadata (evaluation.py:29-50) for the built graphs: encode_warp_embed (models.py:321-322) and
+  encode_hyper_embed (models.py:296-319: hyper_use_warp_embed -> the warp table and the warp metadata)."""
+  enc = {}
+  if cfg.use_warp:
+    enc['encoded_warp'] = encode_embed(torch.as_tensor(np.asarray(metadata['warp'])), params['warp_embed'])
+  if cfg.has_hyper:
+    enc['encoded_hyper'] = encode_embed(torch.as_tensor(np.asarray(metadata['warp'])), params['warp_embed'])
+  return enc
+
+
+def filter_sigma(points, sigma, render_opts):
+  """models.py:38-66."""
+  if render_opts is None:
+    return sigma
+  if 'dust_threshold' in render_opts:
+    dust_thres = render_opts.get('dust_threshold', 0.0)
+    sigma = (sigma >= dust_thres).to(sigma.dtype) * sigma
+  if 'bounding_box' in render_opts:
+    xmin, xmax, ymin, ymax, zmin, zmax = render_opts['bounding_box']
+    render_mask = ((points[..., 0] >= xmin) & (points[..., 0] <= xmax) & (points[..., 1] >= ymin) & (points[..., 1] <= ymax)
+                   & (points[..., 2] >= zmin) & (points[..., 2] <= zmax))
+    sigma = render_mask.to(sigma.dtype) * sigma
+  return sigma
+
+
 def hyper_sheet_mlp(cfg, p, points, embed, alpha):
   """modules.py:367-392."""
   feat = posenc(points, cfg.hyper_sheet_min_deg, cfg.hyper_sheet_max_deg, alpha=alpha)
@@ -399,7 +437,7 @@ class NerfModel:
   # -- models.py:867-1417 -----------------------------------------------------------------------
   def render_samples(self, level, points, z_vals, directions, viewdirs, metadata, extra_params,
                      gt_mask, use_warp=True, use_sample_at_infinity=False, use_predicted_norm=False,
-                     mask_ratio=1, sharp_weights_std=1.0, compute_sigma_gradient=True):
+                     mask_ratio=1, sharp_weights_std=1.0, compute_sigma_gradient=True, metadata_encoded=False, render_opts=None):
     cfg, P = self.cfg, self.params
     out = {'points': points}
     R, S = points.shape[:2]
@@ -407,11 +445,13 @@ class NerfModel:
 
     warp_embed = hyper_embed = mask_embed = None
     if use_warp and cfg.use_warp:                                    # models.py:897-904
-      warp_embed = glo_embed(P['warp_embed'], metadata['warp'])
+      warp_embed = metadata['encoded_warp'].to(self.dtype) if metadata_encoded else glo_embed(P['warp_embed'], metadata['warp'])
     if cfg.has_hyper:                                                # models.py:907-916
-      hyper_embed = warp_embed
-    if cfg.use_predicted_mask:                                       # models.py:924-928
-      mask_embed = glo_embed(P['mask_embed'], metadata['warp'])
+      hyper_embed = metadata['encoded_hyper'].to(self.dtype) if metadata_encoded else warp_embed
+    if cfg.use_predicted_mask:                                       # models.py:924-928 (ids even when metadata_encoded)
+      # 'encoded_mask' has no reference counterpart: 3-channel metadata has no integer id for the mask table (include/nerfds.h)
+      mask_embed = metadata['encoded_mask'].to(self.dtype) if (metadata_encoded and 'encoded_mask' in metadata) \
+          else glo_embed(P['mask_embed'], metadata['warp'])
 
     def bcast(e):
       return None if e is None else e[:, None, :].expand(*batch_shape, e.shape[-1])
@@ -473,7 +513,7 @@ class NerfModel:
 
     # sharp weights (models.py:1236-1246)
     sigma_raw = sigma.reshape(R, S)
-    sigmoid_sigma = torch.nn.functional.softplus(sigma_raw)
+    sigmoid_sigma = torch.nn.functional.softplus(filter_sigma(points, sigma_raw, render_opts))   # the filter on the RAW density here (models.py:1236-1237)
     weights_sg = cal_weights(sigmoid_sigma, z_vals, directions)
     if cfg.use_mask_sharp_weights:
       out['sharp_weights'] = sharpen_weights(weights_sg, z_vals, std=sharp_weights_std)
@@ -507,6 +547,7 @@ class NerfModel:
 
     warped_points = warped_points.reshape(R, S, warped_points.shape[-1])
     out['warped_points'] = warped_points
+    sigma = filter_sigma(points, sigma, render_opts)                 # models.py:1288 (out['sigma'] above stays unfiltered)
     out.update(volumetric_rendering(rgb, sigma, z_vals, directions,
                                     use_white_background=cfg.use_white_background,
                                     sample_at_infinity=use_sample_at_infinity))
@@ -545,12 +586,13 @@ class NerfModel:
   def apply(self, rays_dict: Dict[str, Any], extra_params: Dict[str, Any], *, t_rand=None, u_rand=None,
             use_warp=True, return_points=False, return_weights=False, near=None, far=None,
             use_sample_at_infinity=None, use_predicted_norm=False, mask_ratio=1, sharp_weights_std=1.0,
-            compute_sigma_gradient=True):
+            compute_sigma_gradient=True, metadata_encoded=False, render_opts=None):
     cfg, dt = self.cfg, self.dtype
     as_t = lambda a: torch.as_tensor(np.asarray(a)).to(dt)
     origins, directions = as_t(rays_dict['origins']), as_t(rays_dict['directions'])
     viewdirs = as_t(rays_dict['viewdirs']) if 'viewdirs' in rays_dict else directions
-    metadata = {k: torch.as_tensor(np.asarray(v).astype(np.int64)) for k, v in rays_dict.get('metadata', {}).items()}
+    metadata = {k: (torch.as_tensor(np.asarray(v)).to(dt) if k.startswith('encoded_') else torch.as_tensor(np.asarray(v).astype(np.int64)))
+                for k, v in rays_dict.get('metadata', {}).items()}
     mask = as_t(rays_dict['mask']) if rays_dict.get('mask') is not None else None
     use_warp = cfg.use_warp and use_warp
     near = cfg.near if near is None else near
@@ -562,7 +604,8 @@ class NerfModel:
     if u_rand is not None:
       u_rand = as_t(u_rand)
     common = dict(use_warp=use_warp, use_predicted_norm=use_predicted_norm, mask_ratio=mask_ratio,
-                  sharp_weights_std=sharp_weights_std, compute_sigma_gradient=compute_sigma_gradient)
+                  sharp_weights_std=sharp_weights_std, compute_sigma_gradient=compute_sigma_gradient,
+                  metadata_encoded=metadata_encoded, render_opts=render_opts)
 
     z_vals, points = sample_along_rays(t_rand, origins, directions, cfg.num_coarse_samples, near, far,
                                        cfg.use_stratified_sampling, cfg.use_linear_disparity)

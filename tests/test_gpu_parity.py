@@ -384,3 +384,92 @@ def test_kernels_are_deterministic_and_ray_order_independent(prec):
   c = m.apply({'params': params}, rp, EXTRA, t_rand=t[perm], u_rand=u[perm], use_predicted_norm=True, precision=prec)
   for lv in a:
     assert torch.equal(a[lv][perm], c[lv]['rgb']), (prec, lv)
+
+
+# ---- rows B and Q of SURVEY 8a: pre-encoded / interpolated GLO metadata, render_opts ---------------------------------------------------------
+def _tiny_case(seed=7, R=24, ns=16):
+  cfg = nerf_ds_config(num_warp_embeds=6, num_coarse_samples=ns, num_fine_samples=ns)
+  params = init_params(cfg, seed, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  rng = np.random.default_rng(seed)
+  d = rng.normal(size=(R, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+  rays = dict(origins=rng.normal(size=(R, 3)) * 0.1, directions=d, viewdirs=d,
+              metadata={'warp': rng.integers(0, 6, (R, 1))}, mask=np.zeros((R, 1)))
+  return cfg, params, rng, rays, rng.random((R, ns)), rng.random((R, ns))
+
+
+@pytest.mark.gpu
+def test_encode_metadata_matches_the_oracle():
+  """evaluation.encode_metadata / NerfModel._encode_embed (evaluation.py:29-50, models.py:271-294): one id channel and the 3-channel
+  (left, right, progression) interpolation, out-of-range ids clamped like a jnp gather - bit for bit in fp32."""
+  from nerfds_amd.evaluation import encode_metadata
+  cfg, params, rng, rays, _, _ = _tiny_case()
+  model = _model(cfg)
+  om = O.NerfModel(cfg, params, dtype=torch.float32)
+  ids1 = rng.integers(0, 9, (5, 7, 1))                      # some ids >= 6: clamped
+  meta3 = np.concatenate([rng.integers(0, 6, (40, 1)), rng.integers(0, 8, (40, 1)), rng.random((40, 1))], -1).astype(np.float32)
+  meta3[:3, 2] = [0.0, 1.0, 0.5]
+  for meta in (ids1, meta3):
+    got = encode_metadata(model, {'params': params}, {'warp': meta})
+    want = O.encode_metadata(cfg, om.params, {'warp': meta})
+    assert set(got) == {'encoded_warp', 'encoded_hyper'}
+    for k in got:
+      assert got[k].shape == tuple(meta.shape[:-1]) + (8,)
+      np.testing.assert_array_equal(got[k].cpu().numpy(), want[k].numpy())
+  m = model.encode_embed(ids1, 'mask').cpu().numpy()
+  np.testing.assert_array_equal(m, O.encode_embed(torch.as_tensor(ids1), om.params['mask_embed']).numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
+def test_metadata_encoded_interpolated_embeddings(prec):
+  """model.apply(metadata_encoded=True) on vectors interpolated between two GLO rows (the 3-channel metadata of models.py:271-294)
+  against the oracle run the same way; with integer progression it reproduces the id path exactly."""
+  from nerfds_amd.evaluation import encode_metadata
+  cfg, params, rng, rays, t, u = _tiny_case(seed=8)
+  R = t.shape[0]
+  model = _model(cfg)
+  meta3 = np.concatenate([rng.integers(0, 6, (R, 1)), rng.integers(0, 6, (R, 1)), rng.random((R, 1))], -1).astype(np.float32)
+  enc = encode_metadata(model, {'params': params}, {'warp': meta3})
+  enc_mask = model.encode_embed(meta3, 'mask')
+  kw = dict(t_rand=t, u_rand=u, use_predicted_norm=True)
+  rays_e = dict(rays, metadata=dict(enc, encoded_mask=enc_mask))
+  got = model.apply({'params': params}, rays_e, EXTRA, metadata_encoded=True, precision=prec, **kw)
+  om = O.NerfModel(cfg, params)
+  oenc = O.encode_metadata(cfg, om.params, {'warp': meta3})
+  oenc['encoded_mask'] = O.encode_embed(torch.as_tensor(meta3), om.params['mask_embed'])
+  ref = O.to_numpy(om.apply(dict(rays, metadata=oenc), EXTRA, metadata_encoded=True, compute_sigma_gradient=False, **kw))
+  for level in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'acc', 'ray_predicted_mask', 'ray_delta_x'):
+      assert _relerr(got[level][k].cpu().numpy(), ref[level][k]) < 1e-4, (level, k)
+  # the reference's own form: encoded warp vectors, the mask embedding still looked up from the ids (models.py:924-926)
+  ids = rays['metadata']['warp']
+  enc1 = encode_metadata(model, {'params': params}, {'warp': ids})
+  a = model.apply({'params': params}, dict(rays, metadata=dict(enc1, warp=ids)), EXTRA, metadata_encoded=True, precision=prec, **kw)
+  b = model.apply({'params': params}, rays, EXTRA, precision=prec, **kw)
+  assert torch.equal(a['fine']['rgb'], b['fine']['rgb']) and torch.equal(a['coarse']['ray_delta_x'], b['coarse']['ray_delta_x'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
+def test_render_opts_filter_sigma(prec):
+  """render_opts (filter_sigma, models.py:38-66, 1288): dust threshold and bounding box against the oracle; the per-sample 'sigma' stays
+  unfiltered (models.py:1271) while alpha / weights see the filter."""
+  cfg, params, rng, rays, t, u = _tiny_case(seed=9)
+  cfg = cfg.replace(use_mask_sharp_weights=False)
+  model = _model(cfg)
+  om = O.NerfModel(cfg, params)
+  kw = dict(t_rand=t, u_rand=u, use_predicted_norm=True)
+  plain = O.to_numpy(om.apply(rays, EXTRA, compute_sigma_gradient=False, return_weights=True, **kw))
+  thr = float(np.median(plain['fine']['sigma']))
+  for opts in ({'dust_threshold': thr}, {'bounding_box': (-0.3, 0.4, -0.5, 0.5, -0.2, 0.6)},
+               {'dust_threshold': thr * 0.5, 'bounding_box': (-0.6, 0.6, -0.6, 0.6, -0.6, 0.6)}):
+    ref = O.to_numpy(om.apply(rays, EXTRA, compute_sigma_gradient=False, return_weights=True, render_opts=opts, **kw))
+    got = model.apply({'params': params}, rays, EXTRA, precision=prec, render_opts=opts, return_weights=True, **kw)
+    assert _relerr(ref['fine']['rgb'], plain['fine']['rgb']) > 1e-3          # the options do something on this case
+    for level in ('coarse', 'fine'):
+      for k in ('rgb', 'depth', 'acc', 'ray_norm'):
+        assert _relerr(got[level][k].cpu().numpy(), ref[level][k]) < 1e-4, (opts, level, k)
+      assert _relerr(got[level]['sigma'].cpu().numpy(), ref[level]['sigma']) < 2e-4
+      assert _relerr(got[level]['weights'].cpu().numpy(), ref[level]['weights']) < 2e-4
+  with pytest.raises(ValueError):
+    model.apply({'params': params}, rays, EXTRA, precision=prec, render_opts={'nonsense': 1}, **kw)

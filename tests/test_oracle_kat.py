@@ -257,3 +257,20 @@ def test_static_graph_runs_and_is_identity_warp():
   assert np.allclose(c['warped_points'].numpy(), c['points'].numpy())
   assert 'ray_rotation_field' not in c and c['ray_hyper_points'].shape == (5, 0)
   assert np.all((c['rgb'].numpy() >= 0) & (c['rgb'].numpy() <= 1))
+
+
+def test_encode_embed_and_filter_sigma_known_answers():
+  """NerfModel._encode_embed (models.py:271-294) and filter_sigma (models.py:38-66) restatements."""
+  table = {'embed': {'embedding': torch.arange(24, dtype=torch.float64).reshape(3, 8)}}
+  ids = torch.tensor([[0], [2], [7]])                                   # 7: clamped to the last row like a jnp gather
+  np.testing.assert_array_equal(O.encode_embed(ids, table).numpy(), table['embed']['embedding'][[0, 2, 2]].numpy())
+  m3 = torch.tensor([[0., 2., 0.25], [1., 1., 0.7], [2., 0., 1.0]])
+  e = O.encode_embed(m3, table).numpy()
+  T = table['embed']['embedding'].numpy()
+  np.testing.assert_allclose(e, [0.75 * T[0] + 0.25 * T[2], T[1], T[0]], rtol=1e-15)
+  pts = torch.tensor([[[0., 0., 0.], [2., 0., 0.], [0.5, 0.5, -0.5]]], dtype=torch.float64)
+  sig = torch.tensor([[1.0, 3.0, 0.2]], dtype=torch.float64)
+  assert O.filter_sigma(pts, sig, None) is sig
+  np.testing.assert_array_equal(O.filter_sigma(pts, sig, {'dust_threshold': 0.5}).numpy(), [[1.0, 3.0, 0.0]])
+  np.testing.assert_array_equal(O.filter_sigma(pts, sig, {'bounding_box': (-1, 1, -1, 1, -1, 1)}).numpy(), [[1.0, 0.0, 0.2]])
+  np.testing.assert_array_equal(O.filter_sigma(pts, sig, {'dust_threshold': 0.5, 'bounding_box': (-1, 1, -1, 1, 0, 1)}).numpy(), [[1.0, 0.0, 0.0]])
