@@ -591,7 +591,31 @@ template <class G, class PL, int NT, int TP, int P, int K, class SLOT, class WIN
 DEVI void accum(f32x16 (&acc)[TP][NT], Pipe<G, PL>& pipe, Cursor& cur, const Chunk<P> (&in)[NT][K], int& j, SLOT&& slot, const WIN& win = WIN()) {
   using PP = Pipe<G, PL>;
   constexpr int NP = frag_parts(P);
-  if constexpr (WIN::ON) {
+  if constexpr (WIN::ON && is_single(P)) {
+    // one-unit operands, two N-tiles, tiles one at a time: a fragment feeds the two MFMAs of its tile (one per N-tile, two accumulators)
+    static_assert(TP == 1 && NT == 2, "pinned windows: one tile x two N-tiles");
+#pragma unroll
+    for (int kc = 0; kc < K; ++kc) {
+      const int u = cur.pos;
+      if (u % PP::SU == 0) pipe.begin_stage(cur.seg, u);
+      const WFrag<P> w = pipe.template frag<P>(u);
+      mma<P>(acc[0][0], w, in[0][kc]);
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]));
+#endif
+      pipe.refill(cur.seg, u); pipe.spread_piece(cur.seg, u);
+      win(2 * j);
+      mma<P>(acc[0][1], w, in[1][kc]);
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]));
+#endif
+      win(2 * j + 1);
+      cur.pos += 1;
+      j += 1;
+    }
+    return;
+  }
+  if constexpr (WIN::ON && !is_single(P)) {
     static_assert(PP::X3_INTERLEAVE && P == P_BF16X3 && TP == 2 && NT == 1, "pinned windows: interleaved split-bf16 tile pairs");
 #pragma unroll
     for (int kc = 0; kc < K; ++kc) {
@@ -718,6 +742,37 @@ template <int P> DEVI void tile_epilogue_asm(Chunk<P>& c0, Chunk<P>& c1, const f
 #endif
 }
 
+// The same for the one-unit two-N-tile kernels (bf16 / f16 on the nerf_ds / HyperNeRF graphs, built with NERFDS_TILE_PAIR = 1): one tile =
+// 2 accumulators = 16 value pairs, per pair v_cvt_pk + v_pk_max_i16 with 0 (make_act_chunk's arithmetic) = 32 instructions.
+#ifndef NERFDS_X1_PIN
+#define NERFDS_X1_PIN 1
+#endif
+constexpr bool X1_PIN = !IS_TRAIN && NERFDS_X1_PIN != 0 && TILE_PAIR == 1;
+#ifndef NERFDS_X1_J0
+#define NERFDS_X1_J0 0
+#endif
+struct X1Epi {
+  static constexpr int OPS = 32;
+  unsigned u[2][8];
+};
+template <int P, int W> DEVI void x1_epi_op(int i, const f32x16 (&prev)[2], X1Epi& e, Chunk<P> (&out)[2][W], int t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // op order: cvt p, cvt p + 1, max p, max p + 1 (p even): a conversion and its ReLU are never neighbours
+  const int blk = i / 4, r = i % 4, pair = 2 * blk + (r & 1), nt = pair / 8, k = pair % 8;
+  if (r < 2) {
+    if constexpr (P == P_BF16) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(e.u[nt][k]) : "v"(prev[nt][2 * k]), "v"(prev[nt][2 * k + 1]));
+    else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(e.u[nt][k]) : "v"(prev[nt][2 * k]), "v"(prev[nt][2 * k + 1]));
+  } else {
+    asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(e.u[nt][k]));
+    if (k % 4 == 3) {
+      const int sub = k / 4;
+      const u32x4 rr = {e.u[nt][4 * sub], e.u[nt][4 * sub + 1], e.u[nt][4 * sub + 2], e.u[nt][4 * sub + 3]};
+      out[nt][2 * t + sub].v = __builtin_bit_cast(decltype(out[nt][2 * t + sub].v), rr);
+    }
+  }
+#endif
+}
+
 // One group's conversion (2 tiles x 16 accumulator registers -> 4 split-bf16 chunks) as 128 single VALU instructions: per value pair
 // ReLU, ReLU, hi = cvt_pk, unpack, unpack, subtract, subtract, lo = cvt_pk - make_chunk<P_BF16X3>'s arithmetic on relu_f'd values.  Two pairs
 // are in flight at a time (op i: block i / 16 of two pairs, step (i % 16) / 2, pair i % 2), so neighbouring instructions are independent.
@@ -773,7 +828,43 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Chunk<PO> (&out)[NT][2 * OT], Ins&.
   constexpr bool ASM_EPI = PL::NT == 1 && is_single(PO) && RELU && PL::UNIFORM;
   const int hb = bias_base(pipe.lane16);
   auto no_slot = [](int, int) {};
-  if constexpr (!TRAIN && X3_PIN && PO == P_BF16X3 && RELU && Pipe<G, PL>::X3_INTERLEAVE && (OT > TP)) {
+  if constexpr (!TRAIN && X1_PIN && is_single(PO) && RELU && NT == 2 && TP == 1 && (OT > 1) && PL::UNIFORM) {
+    // One-unit two-N-tile render kernels, tiles one at a time: the conversion of tile t (its two accumulators rest in `prev`) is issued as
+    // single-instruction volatile asm statements in the MFMA windows of tile t + 1 - the scheme of the split-bf16 branch below, which has the
+    // measurements.  As hipcc scheduled the C++ epilogue of these kernels, a group's 64 - 70 VALU sat in one run behind its last MFMA.
+    // J0 = 0: the first 16 instructions read prev[0], whose last MFMA is TWO MFMAs above window 0 (prev[1]'s chain ended in between, the new
+    // tile's first MFMA opens the window): the hazard distance holds by construction; prev[1] is first read at instruction 16.
+    constexpr int KC = seg_total<Ins...>::value, NW = 2 * KC, J0 = NERFDS_X1_J0;
+    static_assert(J0 == 0 || J0 == 2, "window of the first conversion instruction");
+    constexpr int PER = cdiv(X1Epi::OPS, NW - J0), IN_CHAIN = (NW - J0) * PER < X1Epi::OPS ? (NW - J0) * PER : X1Epi::OPS;
+    f32x16 prev[NT];
+    X1Epi e;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      f32x16 acc[TP][NT];
+      {
+        const f32x16 bv = load_bias(cur.bt + ot, hb);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[0][nt] = bv;
+      }
+      int j = 0;
+      auto fill = [&](int w) __attribute__((always_inline)) {
+        if (ot == 0 || w < J0) return;
+#pragma unroll
+        for (int q = (w - J0) * PER; q < (w - J0 + 1) * PER; ++q)
+          if (q < X1Epi::OPS) x1_epi_op<PO>(q, prev, e, out, ot - 1);
+      };
+      Win<decltype(fill)> win{fill};
+      (accum<G, PL, NT, TP>(acc, pipe, cur, ins, j, no_slot, win), ...);
+      if (ot > 0) {
+#pragma unroll
+        for (int q = IN_CHAIN; q < X1Epi::OPS; ++q) x1_epi_op<PO>(q, prev, e, out, ot - 1);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) prev[nt] = acc[0][nt];
+    }
+    tile_epilogue<PO, NT, RELU>(out, OT - 1, prev);                         // the layer's last tile: behind its own chain (builtin MFMAs: hipcc pads the hazard)
+  } else if constexpr (!TRAIN && X3_PIN && PO == P_BF16X3 && RELU && Pipe<G, PL>::X3_INTERLEAVE && (OT > TP)) {
     // Split bf16 render kernel: one 512-register wave per SIMD, so nothing covers a tile group's epilogue - 128 VALU (ReLU + hi / lo split of 32
     // values) behind 24 - 96 MFMAs.  As hipcc schedules it, every group's conversion is ONE uninterrupted run behind the group's last MFMA
     // (the stage boundaries cut a group into scheduling regions, and nothing moves across them): 15 % of the kernel's time, measured by issuing the
