@@ -126,16 +126,22 @@ def cpu_baseline(cfg, params, budget_s=25.0, rays_full=None):
   return obj, keep
 
 
+PIXEL_FLOOR = 1e-2      # per-pixel relative error: |d rgb| / max(|rgb|, PIXEL_FLOOR) - dark pixels are not excused by the brightest one
+
+
 def rgb_error(model, cfg, params, sample, precision):
-  """Max over rays and channels of |rgb_gpu - rgb_oracle| / max |rgb_oracle| (the statistic of tests/test_gpu_parity.py),
-  worst of the two levels, on the cpu_baseline sample: same rays, same injected sampling uniforms."""
+  """Two statistics of the composited RGB against the oracle on the cpu_baseline sample (same rays, same injected sampling uniforms), worst of
+  the two levels: (global) max |d rgb| / max |rgb| over rays and channels - the statistic of tests/test_gpu_parity.py - and (per pixel)
+  max over rays and channels of |d rgb| / max(|rgb|, 1e-2)."""
   out = model.apply({'params': params}, sample['rays'], EXTRA, t_rand=sample['t'], u_rand=sample['u'],
                     use_predicted_norm=cfg.predict_norm, precision=precision)
-  err = 0.0
+  err = pix = 0.0
   for lv, ref in sample['rgb'].items():
     got = out[lv]['rgb'].cpu().numpy()
-    err = max(err, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6)))
-  return err
+    d = np.abs(got - ref)
+    err = max(err, float(d.max() / max(np.abs(ref).max(), 1e-6)))
+    pix = max(pix, float((d / np.maximum(np.abs(ref), PIXEL_FLOOR)).max()))
+  return err, pix
 
 
 def layer_dims(cfg):
@@ -494,9 +500,9 @@ def main():
     else:
       result['cpu_baseline'] = None
     if sample:
-      result['rgb_max_rel_err'] = rgb_error(model, cfg, params, sample, args.precision)
-      result['err_reference'] = ('CPU oracle (torch fp32) on the cpu_baseline sample: same rays, same injected uniforms; statistic = max |d rgb| / max |rgb|, '
-                                 'worst of the levels')
+      result['rgb_max_rel_err'], result['rgb_max_pixel_rel_err'] = rgb_error(model, cfg, params, sample, args.precision)
+      result['err_reference'] = ('CPU oracle (torch fp32) on the cpu_baseline sample: same rays, same injected uniforms; rgb_max_rel_err = max |d rgb| / max |rgb|, '
+                                 'rgb_max_pixel_rel_err = max |d rgb| / max(|rgb|, 1e-2) per pixel and channel; worst of the levels')
     if world == 1 and not args.no_other_paths and not args.strong and not static:
       # The same frame in the other arithmetic modes, timed in this run.  The parity path - the arithmetic that meets north_star's
       # 1e-4 - gets the same treatment as the headline: >= 10 timed steps, its own roofline object, and its error measured twice:
@@ -508,10 +514,12 @@ def main():
         step_weak(7, 'f32', ref_f, ref_c)
         step_weak(7, prec, got_f, got_c)
         torch.cuda.synchronize()
-        err = 0.0
+        err = pix = 0.0
         for g, r in ((got_f, ref_f), (got_c, ref_c)):
-          err = max(err, float((g[:, :3] - r[:, :3]).abs().max() / r[:, :3].abs().max()))
-        return err
+          d = (g[:, :3] - r[:, :3]).abs()
+          err = max(err, float(d.max() / r[:, :3].abs().max()))
+          pix = max(pix, float((d / r[:, :3].abs().clamp_min(PIXEL_FLOOR)).max()))
+        return err, pix
       paths = {}
       for prec in ('bf16x3', 'f16', 'mixed'):
         if prec == args.precision:
@@ -519,9 +527,10 @@ def main():
         steps = max(10, args.steps) if prec == 'bf16x3' else 3
         el, nl, kms = timed(steps, 2 if prec == 'bf16x3' else 1, prec)
         r = roofline_of(prec, nl, kms)
+        e_glob, e_pix = rgb_error(model, cfg, params, sample, prec) if sample else (None, None)
         paths[prec] = {'precision': prec, 'value': args.rays / (el / steps), 'unit': 'rays/s', 'ms_per_step': el * 1e3 / steps, 'steps': steps,
                        'warmup': 2 if prec == 'bf16x3' else 1, 'roofline': r, 'roofline_frac': r['frac'], 'avg_launch_ms': r['avg_launch_ms'],
-                       'rgb_max_rel_err': rgb_error(model, cfg, params, sample, prec) if sample else None}
+                       'rgb_max_rel_err': e_glob, 'rgb_max_pixel_rel_err': e_pix}
       if 'mixed' in paths:
         plan = (C_int32 * 5)()
         N.load().nerfds_precision_plan(N.PREC['mixed'], plan)
@@ -529,11 +538,13 @@ def main():
         paths['mixed']['plan'] = dict(zip(('mask', 'warp', 'hyper', 'trunk', 'rgb'), (names[v] for v in plan)))
       pp = paths.pop('bf16x3', None)
       if pp is not None:
-        pp['full_frame_rgb_max_rel_err'] = full_frame_error('bf16x3')
-        pp['full_frame_reference'] = (f'the fp32-MFMA kernel (v_mfma_f32_32x32x2_f32, exact fp32 fma chains) on all {args.rays} rays of the frame, both levels, '
-                                      'same Philox sampling stream')
+        pp['full_frame_rgb_max_rel_err'], pp['full_frame_rgb_max_pixel_rel_err'] = full_frame_error('bf16x3')
+        pp['full_frame_reference'] = (f'the fp32-MFMA kernel (v_mfma_f32_32x32x2_f32, exact fp32 fma chains; itself within ~4e-6 of the fp64 oracle on the sample) on all '
+                                      f'{args.rays} rays of the frame, both levels, same Philox sampling stream - NOT the CPU oracle, which sees the cpu_baseline sample only')
         errs = [e for e in (pp['rgb_max_rel_err'], pp['full_frame_rgb_max_rel_err']) if e is not None]
         pp['meets_1e-4'] = bool(errs) and max(errs) <= 1e-4
+        pix = [e for e in (pp['rgb_max_pixel_rel_err'], pp['full_frame_rgb_max_pixel_rel_err']) if e is not None]
+        pp['meets_1e-4_per_pixel'] = bool(pix) and max(pix) <= 1e-4
         pp['note'] = ('split bf16 (hi + lo) operands, three MFMAs per product, fp32 accumulate: the fastest arithmetic that meets '
                       "north_star's 1e-4 on composited RGB (profiles/r3_precision_budget.md: no plan with a one-MFMA network does)")
         result['parity_path'] = pp

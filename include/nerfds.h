@@ -39,6 +39,7 @@ extern "C" {
 #define NERFDS_ENOMEM   (-12)
 #define NERFDS_ENOTSUP  (-95)   /* graph / option not built as a HIP kernel */
 #define NERFDS_EDEVICE  (-5)    /* HIP runtime error (no device, launch failure, ...) */
+#define NERFDS_ENONFINITE (-34) /* trainer: the gradient vector held an inf / NaN; the Adam update of that step was skipped as a whole */
 
 /* Arithmetic of the per-sample dense layers (flags bits 0-2 of nerfds_render_rays).  The reference's layers are
  * fp32 nn.Dense (hypernerf/modules.py:61-65,74-78); every mode accumulates in fp32. */
@@ -310,6 +311,12 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
 /* One Adam update with the gradient vector as it stands (after a NERFDS_TRAIN_GRADS_ONLY step and, on N GPUs, after the
  * all-reduce of nerfds_trainer_grads that replaces jax.lax.pmean(grad), training.py:502). */
 int nerfds_trainer_apply(nerfds_trainer* t, float learning_rate, void* hip_stream);
+/* The plain step keeps activations as f16 and the weight-gradient operand g as bf16 (a documented deviation from the reference's fp32
+ * arrays; NERFDS_TRAIN_G16=0 in the environment keeps g in fp32): a value beyond 65504 turns into an inf / NaN gradient.  Every Adam update
+ * first checks the whole gradient vector on the device and is SKIPPED when an element is not finite; nerfds_trainer_step reports
+ * NERFDS_ENONFINITE when it reads the loss back (loss_host != NULL), and this call (it synchronises the device) returns 1 if the last update
+ * was skipped, 0 if not. */
+int nerfds_trainer_nonfinite(nerfds_trainer* t);
 /* utils.clip_gradients (utils.py:32-47, training.py:503-504) on the gradient vector: clip by value (if > 0), then scale so that the global
  * L2 norm is at most grad_max_norm (if > 0).  Call between a NERFDS_TRAIN_GRADS_ONLY step (and the all-reduce) and nerfds_trainer_apply. */
 int nerfds_trainer_clip_gradients(nerfds_trainer* t, float grad_max_val, float grad_max_norm, void* hip_stream);
@@ -324,6 +331,9 @@ int nerfds_kernel_time_ms(nerfds_ctx* ctx, int reset, double* total_ms);
  * nets, 1 = NerfMLP) at precision `prec`; negative on error. */
 int64_t nerfds_pack_stream_bytes(const nerfds_model_cfg* cfg, int which, uint32_t prec);
 int64_t nerfds_pack_bias_floats(const nerfds_model_cfg* cfg, int which);
+/* Output tiles per group in the stream of that (graph, precision) kernel: within a group the stream holds, chunk by chunk, one fragment
+ * of each tile.  2, except 1 for the kernels that carry two N-tiles per wave (nerf_ds / HyperNeRF graph in bf16 / f16); negative on error. */
+int nerfds_pack_tile_pair(const nerfds_model_cfg* cfg, uint32_t prec);
 /* Packs into caller-provided host buffers.  level: 0 coarse, 1 fine (ignored for which == 0). */
 int nerfds_pack_stream(const nerfds_model_cfg* cfg, const nerfds_weights* w, int which, int level, uint32_t prec,
                        void* stream_out, float* bias_out);

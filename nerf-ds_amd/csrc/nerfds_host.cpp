@@ -537,6 +537,12 @@ int64_t nerfds_pack_stream_bytes(const nerfds_model_cfg* cfg, int which, uint32_
   stream_dims_dispatch(g, which, (int)prec, &wb, &bf);
   return wb;
 }
+int nerfds_pack_tile_pair(const nerfds_model_cfg* cfg, uint32_t prec) {
+  if (!cfg || prec >= NERFDS_PREC_COUNT) return NERFDS_EINVAL;
+  const int g = graph_of(*cfg);
+  if (g < 0) return NERFDS_ENOTSUP;
+  return tile_pair_of(g, (int)prec);
+}
 int64_t nerfds_pack_bias_floats(const nerfds_model_cfg* cfg, int which) {
   if (!cfg || which < 0 || which > 1) return NERFDS_EINVAL;
   const int g = graph_of(*cfg);

@@ -938,11 +938,12 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
   carve(*t);      // sizes only
   const size_t pbytes = (size_t)t->P * sizeof(float);
   if (hipMalloc(&t->theta, pbytes) != hipSuccess || hipMalloc(&t->grad, pbytes) != hipSuccess || hipMalloc(&t->m1, pbytes) != hipSuccess ||
-      hipMalloc(&t->m2, pbytes) != hipSuccess || hipMalloc(&t->loss_dev, 2 * sizeof(float)) != hipSuccess || hipMalloc(&t->terms_dev, 8 * sizeof(float)) != hipSuccess ||
+      hipMalloc(&t->m2, pbytes) != hipSuccess || hipMalloc(&t->loss_dev, 2 * sizeof(float)) != hipSuccess || hipMalloc(&t->terms_dev, 12 * sizeof(float)) != hipSuccess ||
       hipMalloc(&t->ws, t->ws_floats * sizeof(float)) != hipSuccess) {
     g_train_error = "hipMalloc failed (workspace of " + std::to_string(t->ws_floats * 4 >> 20) + " MiB)";
     return NERFDS_ENOMEM;
   }
+  (void)hipMemset(t->terms_dev, 0, 12 * sizeof(float));      // [8]: the non-finite-gradient flag (adam_update)
   (void)hipMemset(t->theta, 0, pbytes); (void)hipMemset(t->m1, 0, pbytes); (void)hipMemset(t->m2, 0, pbytes); (void)hipMemset(t->grad, 0, pbytes);
   carve(*t);
   {
@@ -1027,24 +1028,50 @@ long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* h
   if (!t || !name || !host || max_bytes <= 0) return NERFDS_EINVAL;
   const std::string n(name);
   const void* p = nullptr;
-  auto layer_of = [&](const std::string& pre, const std::vector<uint16_t*>& h16, const std::vector<uint16_t*>& bits, const std::vector<float*>& g) {
+  long long cap = 0;                     // bytes the named view holds for the largest level (rows = max_rays * (Nc + Nf))
+  bool half_only = false;                // views only a half step (f16 activations + ReLU bits, fused backward) fills
+  const long long M = (long long)t->max_rays * (t->cfg.num_coarse_samples + t->cfg.num_fine_samples);
+  const long long gsz = t->g16 ? 2 : 4;  // the g arrays are bf16 in the default mode, fp32 under NERFDS_TRAIN_G16=0
+  auto layer_of = [&](const std::string& pre, int width, const std::vector<uint16_t*>& h16, const std::vector<uint16_t*>& bits, const std::vector<float*>& g) {
     for (size_t l = 0; l < g.size(); ++l) {
-      if (n == pre + "_h16_" + std::to_string(l) && l < h16.size()) p = h16[l];
-      if (n == pre + "_bits_" + std::to_string(l) && l < bits.size()) p = bits[l];
-      if (n == pre + "_g_" + std::to_string(l)) p = g[l];
+      if (n == pre + "_h16_" + std::to_string(l) && l < h16.size()) { p = h16[l]; cap = M * width * 2; half_only = true; }
+      if (n == pre + "_bits_" + std::to_string(l) && l < bits.size()) { p = bits[l]; cap = M * 2 * (width / 32) * 2; half_only = true; }
+      if (n == pre + "_g_" + std::to_string(l)) { p = g[l]; cap = M * width * gsz; half_only = true; }
     }
   };
-  layer_of("mask", t->mask_h16, t->mask_bits, t->mask_h); layer_of("warp", t->warp_h16, t->warp_bits, t->warp_h);
-  layer_of("hyper", t->hyper_h16, t->hyper_bits, t->hyper_h); layer_of("trunk", t->trunk_h16, t->trunk_bits, t->trunk_h);
-  if (n == "rgb_h16") p = t->rgb_h16; else if (n == "rgb_bits") p = t->rgb_bits; else if (n == "rgb_g") p = t->rgb_hv;
-  else if (n == "d_rgb_logit") p = t->d_rgb_logit; else if (n == "d_alpha") p = t->d_alpha; else if (n == "d_trunk_in") p = t->d_trunk_in;
-  else if (n == "d_hyper_in") p = t->d_hyper_in; else if (n == "d_warp_in") p = t->d_warp_in; else if (n == "d_mask_in") p = t->d_mask_in;
-  else if (n == "dwamb") p = t->dwamb; else if (n == "dwv") p = t->dwv; else if (n == "d_mask_logit") p = t->d_mask_logit;
+  layer_of("mask", t->mask.width, t->mask_h16, t->mask_bits, t->mask_h); layer_of("warp", t->warp.width, t->warp_h16, t->warp_bits, t->warp_h);
+  layer_of("hyper", t->hyper.width, t->hyper_h16, t->hyper_bits, t->hyper_h); layer_of("trunk", t->trunk[0].width, t->trunk_h16, t->trunk_bits, t->trunk_h);
+  const int RW = t->rgb_h[0].N;
+  if (n == "rgb_h16") { p = t->rgb_h16; cap = M * RW * 2; half_only = true; }
+  else if (n == "rgb_bits") { p = t->rgb_bits; cap = M * 2 * (RW / 32) * 2; half_only = true; }
+  else if (n == "rgb_g") { p = t->rgb_hv; cap = M * RW * gsz; half_only = true; }
+  else if (n == "d_rgb_logit") { p = t->d_rgb_logit; cap = M * 3 * 4; }
+  else if (n == "d_alpha") { p = t->d_alpha; cap = M * 4 * 4; }
+  else if (n == "d_trunk_in") { p = t->d_trunk_in; cap = M * t->D.trunk_in * 4; }
+  else if (n == "d_hyper_in") { p = t->d_hyper_in; cap = M * t->D.hyper_ld * 4; }
+  else if (n == "d_warp_in") { p = t->d_warp_in; cap = M * t->D.warp_ld * 4; }
+  else if (n == "d_mask_in") { p = t->d_mask_in; cap = M * t->D.mask_in * 4; }
+  else if (n == "dwamb") { p = t->dwamb; cap = M * 2 * 4; }
+  else if (n == "dwv") { p = t->dwv; cap = M * 6 * 4; }
+  else if (n == "d_mask_logit") { p = t->d_mask_logit; cap = M * 4; }
   if (!p) return t->fail(NERFDS_EINVAL, "debug_read: no buffer named %s", name);
+  if (half_only && !t->half_step)
+    return t->fail(NERFDS_EINVAL, "debug_read: %s is written by a half step only (the last step kept fp32 activations: tangent pass or NERFDS_TRAIN_FUSED_*=0)", name);
+  if (max_bytes > cap) return t->fail(NERFDS_EINVAL, "debug_read: %s holds %lld bytes (%s elements), %lld asked for", name, cap,
+                                      half_only && n.find("_g") != std::string::npos ? (t->g16 ? "bf16" : "fp32") : "its own", max_bytes);
   (void)hipSetDevice(t->device);
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, p, (size_t)max_bytes, hipMemcpyDeviceToHost) != hipSuccess)
     return t->fail(NERFDS_EDEVICE, "debug_read failed");
   return max_bytes;
+}
+
+int nerfds_trainer_nonfinite(nerfds_trainer* t) {
+  if (!t) return NERFDS_EINVAL;
+  (void)hipSetDevice(t->device);
+  unsigned f = 0;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&f, t->terms_dev + 8, sizeof f, hipMemcpyDeviceToHost) != hipSuccess)
+    return t->fail(NERFDS_EDEVICE, "flag read-back failed");
+  return f != 0 ? 1 : 0;
 }
 
 int nerfds_trainer_reset_optimizer(nerfds_trainer* t) {
@@ -1058,9 +1085,11 @@ int nerfds_trainer_reset_optimizer(nerfds_trainer* t) {
 static void adam_update(nerfds_trainer* t, float learning_rate, hipStream_t st) {
   const double b1 = 0.9, b2 = 0.999;
   const double tt = (double)(t->adam_t + 1);
+  unsigned* flag = reinterpret_cast<unsigned*>(t->terms_dev + 8);
+  (void)hipMemsetAsync(flag, 0, sizeof(unsigned), st);
   adam(st, t->theta, t->grad, t->m1, t->m2, t->P, learning_rate, (float)b1, (float)b2, 1e-8f, (float)(1.0 - std::pow(b1, tt)),
-       (float)(1.0 - std::pow(b2, tt)));
-  t->adam_t += 1;
+       (float)(1.0 - std::pow(b2, tt)), flag);
+  t->adam_t += 1;       // (a skipped update still counts as a step: the host learns of it at its next read-back)
 }
 
 int nerfds_trainer_clip_gradients(nerfds_trainer* t, float grad_max_val, float grad_max_norm, void* hip_stream) {
@@ -1165,12 +1194,17 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     float l[2];
     if (hipMemcpyAsync(l, t->loss_dev, sizeof l, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       return t->fail(NERFDS_EDEVICE, "loss read-back failed");
-    float tm[8];
+    float tm[9];
     if (hipMemcpy(tm, t->terms_dev, sizeof tm, hipMemcpyDeviceToHost) != hipSuccess) return t->fail(NERFDS_EDEVICE, "loss read-back failed");
+    unsigned nonfinite = 0;
+    std::memcpy(&nonfinite, &tm[8], sizeof nonfinite);
     const int fl = Nf > 0 ? 1 : 0;
     loss_host[0] = l[fl];     // rgb loss of the fine level (the level render_image returns; coarse if there is none), of the coarse level
     loss_host[1] = l[0];
     for (int k = 0; k < 4; ++k) { loss_host[2 + k] = tm[4 * fl + k]; loss_host[6 + k] = tm[k]; }   // weighted warp_reg / back_facing / mask / norm terms: fine, coarse
+    if (nonfinite && !(flags & NERFDS_TRAIN_GRADS_ONLY))
+      return t->fail(NERFDS_ENONFINITE, "non-finite gradient: the Adam update of this step was skipped (f16 activations / bf16 g overflowed? NERFDS_TRAIN_G16=0 "
+                                        "keeps g in fp32; a step with the sigma-gradient flag keeps fp32 activations)");
   }
   return NERFDS_OK;
 }

@@ -831,10 +831,17 @@ __global__ void k_mask_in_bwd(Dims D, int R, int S, const float* __restrict__ d_
 }
 
 // flax.optim.Adam (flax 0.3.4): bias-corrected, no weight decay (training.py:508, train.py:297-301)
-__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, long long n,
-                       float lr, float b1, float b2, float eps, float c1, float c2) {
+// The plain step stores activations as f16 and g as bf16: an activation beyond 65504 becomes inf there and arrives as an
+// inf / NaN weight gradient.  k_nonfinite raises a flag if ANY gradient element is not finite; k_adam then leaves parameters and moments
+// untouched (the whole update is skipped, not element by element), and the host reports NERFDS_ENONFINITE at its next read-back.
+__global__ void k_nonfinite(const float* __restrict__ g, long long n, unsigned* __restrict__ flag) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i < n && !isfinite(g[i])) atomicOr(flag, 1u);
+}
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, long long n,
+                       float lr, float b1, float b2, float eps, float c1, float c2, const unsigned* __restrict__ skip) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n || *skip != 0u) return;
   const float gi = g[i];
   const float a = (1.0f - b1) * gi + b1 * m1[i];
   const float b = (1.0f - b2) * gi * gi + b2 * m2[i];
@@ -965,8 +972,10 @@ void clip_gradients(hipStream_t st, float* g, long long n, float max_val, float 
   LAUNCH(k_clip_val_sumsq, n, st, g, n, max_val, sumsq_scratch);
   if (max_norm > 0.f) LAUNCH(k_clip_norm, n, st, g, n, max_norm, 1e-7f, sumsq_scratch);
 }
-void adam(hipStream_t st, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2) {
-  LAUNCH(k_adam, n, st, p, g, m1, m2, n, lr, b1, b2, eps, c1, c2);
+void adam(hipStream_t st, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2,
+          unsigned* nonfinite_flag) {
+  LAUNCH(k_nonfinite, n, st, g, n, nonfinite_flag);
+  LAUNCH(k_adam, n, st, p, g, m1, m2, n, lr, b1, b2, eps, c1, c2, nonfinite_flag);
 }
 
 // ------------------------------------------------------------------------------------------------

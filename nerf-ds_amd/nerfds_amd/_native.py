@@ -126,11 +126,11 @@ class Out(C.Structure):
 # every symbol include/nerfds.h declares
 SYMBOLS = ('nerfds_abi_version', 'nerfds_precision_plan', 'nerfds_ctx_create', 'nerfds_ctx_load_weights', 'nerfds_render_rays',
            'nerfds_encode_embed', 'nerfds_ctx_destroy', 'nerfds_last_error', 'nerfds_kernel_time_ms', 'nerfds_pack_stream_bytes',
-           'nerfds_pack_bias_floats', 'nerfds_pack_stream', 'nerfds_debug_mfma', 'nerfds_camera_to_rays',
+           'nerfds_pack_bias_floats', 'nerfds_pack_tile_pair', 'nerfds_pack_stream', 'nerfds_debug_mfma', 'nerfds_camera_to_rays',
            'nerfds_frame_images', 'nerfds_trainer_create', 'nerfds_trainer_destroy', 'nerfds_trainer_param_count',
            'nerfds_trainer_num_leaves', 'nerfds_trainer_leaf', 'nerfds_trainer_params', 'nerfds_trainer_grads',
            'nerfds_trainer_download', 'nerfds_trainer_upload', 'nerfds_trainer_reset_optimizer', 'nerfds_trainer_step', 'nerfds_trainer_apply', 'nerfds_trainer_clip_gradients', 'nerfds_trainer_target_norm',
-           'nerfds_trainer_last_error', 'nerfds_trainer_debug_read')
+           'nerfds_trainer_last_error', 'nerfds_trainer_debug_read', 'nerfds_trainer_nonfinite')
 
 _lib = None
 
@@ -156,6 +156,7 @@ def load():
   lib.nerfds_kernel_time_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
   lib.nerfds_pack_stream_bytes.argtypes = [C.POINTER(ModelCfg), C.c_int, C.c_uint32]
   lib.nerfds_pack_stream_bytes.restype = C.c_int64
+  lib.nerfds_pack_tile_pair.argtypes = [C.POINTER(ModelCfg), C.c_uint32]
   lib.nerfds_pack_bias_floats.argtypes = [C.POINTER(ModelCfg), C.c_int]
   lib.nerfds_pack_bias_floats.restype = C.c_int64
   lib.nerfds_pack_stream.argtypes = [C.POINTER(ModelCfg), C.POINTER(Weights), C.c_int, C.c_int, C.c_uint32,

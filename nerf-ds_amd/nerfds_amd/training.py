@@ -170,6 +170,13 @@ class Trainer:
       raise RuntimeError(f'nerfds_trainer_debug_read failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
     return out
 
+  def nonfinite(self) -> bool:
+    """True if the last Adam update was skipped because the gradient vector held an inf / NaN (nerfds_trainer_nonfinite; synchronises)."""
+    rc = self._lib.nerfds_trainer_nonfinite(self._h)
+    if rc < 0:
+      raise RuntimeError(f'nerfds_trainer_nonfinite failed ({rc})')
+    return bool(rc)
+
   def get_params(self) -> Dict[str, Any]:
     return self._tree(self._download(0))
 
@@ -237,6 +244,8 @@ class Trainer:
                                        (GRADS_ONLY if (grads_only or data_parallel or clip) else 0) | (SIGMA_GRAD if sigma_gradient else 0), loss,
                                        C.c_void_p(s.cuda_stream))
     self._last_rays = R
+    if rc == -34:      # NERFDS_ENONFINITE: the gradient held an inf / NaN, the update was skipped as a whole (include/nerfds.h)
+      raise FloatingPointError((self._lib.nerfds_trainer_last_error(self._h) or b'').decode())
     if rc != 0:
       raise RuntimeError(f'nerfds_trainer_step failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
     if data_parallel:       # one rank per GPU, each with its own rays: ONE all-reduce of the 6 MB gradient vector (training.py:502)

@@ -52,6 +52,8 @@ def _pack(cfg, params, which, level, prec):
   b = np.zeros(max(nf, 1), np.float32)
   rc = lib.nerfds_pack_stream(C.byref(cs), C.byref(holder.struct), which, level, N.PREC[prec], w.ctypes.data, b.ctypes.data)
   assert rc == 0, N.last_error(None)
+  E.TILE_PAIR = lib.nerfds_pack_tile_pair(C.byref(cs), N.PREC[prec])     # tiles per group in THIS kernel's stream (1 for the two-N-tile kernels)
+  assert E.TILE_PAIR in (1, 2)
   return E.Stream(w[:nb], b[:nf], prec)
 
 

@@ -68,7 +68,7 @@ def _free_port():
   return p
 
 
-def _rank_worker(rank, world, port, q, backend):
+def _rank_worker(rank, world, port, q, backend, shape=(23, 41), chunk=300):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
   import torch.distributed as dist
   gpu = rank if backend == 'nccl' else 0
@@ -81,36 +81,36 @@ def _rank_worker(rank, world, port, q, backend):
     from nerfds_amd.evaluation import TrainState, make_model_fn, render_image
     from nerfds_amd.model import NerfModel
     cfg, params = _setup(False)
-    rays = _frame_rays(23, 41, 4, 1)                     # 943 rays: chunk 300 -> odd chunk sizes, padding on the last chunk
+    rays = _frame_rays(shape[0], shape[1], 4, 1)         # default 943 rays: chunk 300 -> odd chunk sizes, padding on the last chunk
     model = NerfModel(cfg, device=torch.device('cuda', gpu), precision='f32')
     out = render_image(TrainState.create(params, **EXTRA), rays, make_model_fn(model, precision='f32'), device_count=world,
-                       rng=np.array([0, 1]), chunk=300, cfg=cfg)
+                       rng=np.array([0, 1]), chunk=chunk, cfg=cfg)
     q.put((rank, out['rgb'].numpy(), out['depth'].numpy()))
   finally:
     dist.destroy_process_group()
 
 
-def _two_rank_frame(backend):
+def _two_rank_frame(backend, world=2, shape=(23, 41), chunk=300):
   import torch.multiprocessing as mp
   from nerfds_amd.model import NerfModel
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
   port = _free_port()
-  procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q, backend)) for r in range(2)]
+  procs = [ctx.Process(target=_rank_worker, args=(r, world, port, q, backend, shape, chunk)) for r in range(world)]
   for p in procs:
     p.start()
   try:
-    got = dict((r, (a, b)) for r, a, b in (q.get(timeout=300) for _ in range(2)))
+    got = dict((r, (a, b)) for r, a, b in (q.get(timeout=600) for _ in range(world)))
   finally:
     for p in procs:
       p.join(60)
       if p.is_alive():
         p.kill()
   cfg, params = _setup(False)
-  rays = _frame_rays(23, 41, 4, 1)
+  rays = _frame_rays(shape[0], shape[1], 4, 1)
   whole = NerfModel(cfg, device=torch.device('cuda', 0), precision='f32').apply({'params': params}, rays, EXTRA, use_predicted_norm=True,
                                                                                  precision='f32')['fine']
-  for r in range(2):     # every rank holds the whole frame, identical to the unsharded render
+  for r in range(world):     # every rank holds the whole frame, identical to the unsharded render
     assert np.array_equal(got[r][0], whole['rgb'].cpu().numpy()) and np.array_equal(got[r][1], whole['depth'].cpu().numpy())
 
 
@@ -123,6 +123,30 @@ def test_render_image_two_ranks_sharing_one_gpu():
   """The N > 1 code path of render_image on a one-GPU box: two processes on cuda:0, chunk shards, staging buffers, side-stream
   exchange, padding of the ragged chunk - everything but RCCL itself (the exchange goes through gloo on host copies)."""
   _two_rank_frame('gloo')
+
+
+def test_config3_eight_ranks_sharing_one_gpu():
+  """BASELINE configs[2] at its own numbers without an 8-GPU node: chunk_size = 65 536 rays split over EIGHT ranks in contiguous blocks of
+  8 192 (evaluation.py:97-129, render.py:155), two chunks (131 072 rays), every rank a process on cuda:0 with the exchange staged through
+  gloo - the frame every rank ends up with equals the 1-rank render bit for bit (fp32 kernel)."""
+  _two_rank_frame('gloo', world=8, shape=(256, 512), chunk=65536)
+
+
+def test_bench_config3_eight_ranks_sharing_one_gpu():
+  """`bench.py --gpus 8 --strong --rays 131072 --chunk 65536` as the driver launches it, eight ranks on cuda:0 over gloo: one JSON line."""
+  import json
+  import subprocess
+  env = dict(os.environ, NERFDS_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+         '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1',
+         '--rays', '131072', '--chunk', '65536', '--no-cpu-baseline', '--strong']
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+  assert len(lines) == 1, r.stdout
+  rec = json.loads(lines[0])
+  assert rec['n_gpus'] == 8 and rec['scaling'] == 'strong' and rec['value'] > 0
+  assert abs(rec['value'] - 131072 / (rec['ms_per_step'] * 1e-3)) <= 1e-3 * rec['value']
 
 
 @pytest.mark.parametrize('mode', ['weak', 'strong'])

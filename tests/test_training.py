@@ -457,9 +457,14 @@ def test_fused_backward_chain_against_numpy_on_the_step_buffers(g16, monkeypatch
     return m
   P = params['nerf_mlps_coarse']
   h_rgb = tr.debug_read('rgb_h16', (M, 128), np.float16).astype(np.float64)
-  assert np.array_equal(bits_to_mask(tr.debug_read('rgb_bits', (M * 2 * 4,), np.uint16), 128), h_rgb > 0)
+  def check_bits(mask, h16):        # bit = (fp32 activation > 0); the stored f16 may have underflowed to 0 for a tiny positive value
+    assert np.all(mask[h16 > 0]), 'a positive stored activation without its ReLU bit'
+    assert np.count_nonzero(mask & (h16 == 0)) <= 1e-4 * mask.size, 'set bits on zero activations beyond f16 underflow'
+  check_bits(bits_to_mask(tr.debug_read('rgb_bits', (M * 2 * 4,), np.uint16), 128), h_rgb)
   h7 = tr.debug_read('trunk_h16_7', (M, 256), np.float16).astype(np.float64)
-  assert np.array_equal(bits_to_mask(tr.debug_read('trunk_bits_7', (M * 2 * 8,), np.uint16), 256), h7 > 0)
+  check_bits(bits_to_mask(tr.debug_read('trunk_bits_7', (M * 2 * 8,), np.uint16), 256), h7)
+  with pytest.raises(RuntimeError):                      # a view holds M * width elements: an oversized read is refused, not performed
+    tr.debug_read('trunk_h16_7', (tr.max_rays * (Nc + Nf) + 1, 256), np.float16)
   d_rgb = tr.debug_read('d_rgb_logit', (M, 3)).astype(np.float64)
   d_alpha = tr.debug_read('d_alpha', (M, 4)).astype(np.float64)
   Wr = np.asarray(P['rgb_mlp']['logit']['kernel'], np.float64)
@@ -480,3 +485,25 @@ def test_fused_backward_chain_against_numpy_on_the_step_buffers(g16, monkeypatch
   got_in = tr.debug_read('d_trunk_in', (M, 52))
   # (g16: want_in is built from the ROUNDED copies of g_0 / g_4 while the kernel used its registers: 2^-9 per term, averaging down)
   assert np.abs(got_in - want_in).max() <= (1e-4 if not g16 else 2e-3) * np.abs(want_in).max()
+
+
+@pytest.mark.gpu
+def test_nonfinite_gradient_skips_the_update_and_is_reported():
+  """The plain step stores activations as f16: weights that push an activation beyond 65504 give an inf / NaN gradient.  The update is then
+  skipped as a whole (parameters and Adam moments untouched) and the step reports it (NERFDS_ENONFINITE -> FloatingPointError)."""
+  import copy
+  from nerfds_amd.training import Trainer
+  cfg, params, batch, t, u = _problem(16, 8, 8, seed=4)
+  big = copy.deepcopy(params)
+  big['nerf_mlps_coarse']['trunk_mlp']['hidden_1']['kernel'] = np.asarray(big['nerf_mlps_coarse']['trunk_mlp']['hidden_1']['kernel']) * 3e5
+  tr = Trainer(cfg, big, max_rays=16)
+  before = tr.get_params()
+  with pytest.raises(FloatingPointError):
+    tr.step(batch, EX, 1e-3, t_rand=t, u_rand=u, mask_ratio=1.0)
+  assert tr.nonfinite()
+  after = tr.get_params()
+  for (ka, a), (kb, b) in zip(tree_leaves(before), tree_leaves(after)):
+    assert ka == kb and np.array_equal(np.asarray(a), np.asarray(b)), ka
+  tr.set_params(params)                                   # a healthy step afterwards clears the flag
+  tr.step(batch, EX, 1e-3, t_rand=t, u_rand=u, mask_ratio=1.0)
+  assert not tr.nonfinite()
