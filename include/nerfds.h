@@ -192,6 +192,7 @@ typedef struct nerfds_extra {
   uint32_t render_opt_flags;         /* NERFDS_OPT_* */
   float dust_threshold;
   float bounding_box[6];
+  int32_t use_linear_disparity;      /* NerfModel.use_linear_disparity: coarse depths linear in 1 / z (model_utils.py:73-76) */
 } nerfds_extra;
 #define NERFDS_OPT_DUST_THRESHOLD 1u
 #define NERFDS_OPT_BOUNDING_BOX   2u
@@ -299,6 +300,7 @@ int nerfds_trainer_upload(nerfds_trainer* t, int which, const float* host);
  * last step run with NERFDS_TRAIN_SIGMA_GRAD: HOST [num_rays][S][3], S = Nc (level 0) or Nc + Nf (level 1). */
 int nerfds_trainer_target_norm(nerfds_trainer* t, int level, int64_t num_rays, float* host);
 int nerfds_trainer_reset_optimizer(nerfds_trainer* t);   /* zero the Adam moments and the step count */
+int nerfds_trainer_set_step(nerfds_trainer* t, int64_t step);   /* the optimizer's step count (resuming from a checkpoint: OptimizerState.step) */
 /* Development / tests: HOST copy of an internal device buffer of the last step (the f16 activations, ReLU bits and per-layer
  * gradients g_l of the fused backward, the head / input gradients): "<net>_h16_<l>", "<net>_bits_<l>", "<net>_g_<l>" with net = mask |
  * warp | hyper | trunk, "rgb_h16", "rgb_bits", "rgb_g", "d_rgb_logit", "d_alpha", "d_trunk_in", "d_hyper_in", "d_warp_in",

@@ -37,6 +37,7 @@ struct KArgs {
   int num_embeds;            // rows of the GLO tables (ids are clamped like a jnp gather)
   int nc, nf;
   int stratified;
+  int lindisp;               // use_linear_disparity (model_utils.py:73-76)
   int sample_at_infinity;
   int white_bkgd;
   float near_, far_;

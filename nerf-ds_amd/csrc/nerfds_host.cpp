@@ -429,6 +429,7 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   ka.num_embeds = ctx->cfg.num_warp_embeds > 0 ? ctx->cfg.num_warp_embeds : 1;
   ka.nc = ctx->cfg.num_coarse_samples; ka.nf = ctx->cfg.num_fine_samples;
   ka.stratified = extra->use_stratified_sampling;
+  ka.lindisp = extra->use_linear_disparity;
   ka.sample_at_infinity = ctx->cfg.use_sample_at_infinity;
   ka.white_bkgd = ctx->cfg.use_white_background;
   ka.near_ = extra->near; ka.far_ = extra->far;

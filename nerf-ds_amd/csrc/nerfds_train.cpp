@@ -1065,6 +1065,12 @@ long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* h
   return max_bytes;
 }
 
+int nerfds_trainer_set_step(nerfds_trainer* t, int64_t step) {
+  if (!t || step < 0) return NERFDS_EINVAL;
+  t->adam_t = step;
+  return NERFDS_OK;
+}
+
 int nerfds_trainer_nonfinite(nerfds_trainer* t) {
   if (!t) return NERFDS_EINVAL;
   (void)hipSetDevice(t->device);
@@ -1147,7 +1153,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   if (t->fused_fwd) pack_fused_forward(*t, st);
   (void)hipMemsetAsync(t->loss_dev, 0, 2 * sizeof(float), st);
   const int strat = ex->use_stratified_sampling;
-  coarse_z(st, R, Nc, ex->near, ex->far, strat, rnd ? rnd->t_rand : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->first_ray : 0, t->zc);
+  coarse_z(st, R, Nc, ex->near, ex->far, strat, ex->use_linear_disparity, rnd ? rnd->t_rand : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->first_ray : 0, t->zc);
   Objective ob{};
   const Objective* obp = nullptr;
   if (objective) {

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
       if (i < nc && q == 0) {
         auto zlin = [&](int q) {
           const float t = (nc > 1) ? (float)q / (float)(nc - 1) : 0.f;
+          if (ka.lindisp) return 1.0f / (1.0f / ka.near_ * (1.0f - t) + 1.0f / ka.far_ * t);      // model_utils.py:75-76
           return ka.near_ * (1.0f - t) + ka.far_ * t;
         };
         float z = zlin(i);

@@ -20,7 +20,7 @@ struct Objective {   // weights of the auxiliary losses (0 = off); mirrors nerfd
   int use_sharp_weights;
 };
 
-void coarse_z(hipStream_t, int R, int Nc, float near_, float far_, int stratified, const float* t_rand, uint64_t seed, long long first_ray, float* z);
+void coarse_z(hipStream_t, int R, int Nc, float near_, float far_, int stratified, int lindisp, const float* t_rand, uint64_t seed, long long first_ray, float* z);
 void resample(hipStream_t, int R, int Nc, int Nf, const float* zc, const float* wc, int stratified, const float* u_rand, uint64_t seed, long long first_ray, float* zf, float* scratch);
 void encode_inputs(hipStream_t, const Dims&, int R, int S, const float* o, const float* d, const float* z, const uint32_t* warp_id, int n_embeds,
                    const float* warp_tbl, const float* mask_tbl, const Windows&, float* x, float* mask_in, float* warp_in, float* hyper_in);

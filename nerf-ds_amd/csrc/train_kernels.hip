@@ -57,12 +57,13 @@ extern __shared__ float g_rows[];
 
 // ---- sampling (model_utils.py:55-92) ---------------------------------------------------------------------------
 // t_rand == nullptr with stratified sampling: the on-chip Philox stream of philox.h (the reference always draws, model_utils.py:84)
-__global__ void k_coarse_z(int R, int Nc, float near_, float far_, int stratified, const float* __restrict__ t_rand, uint64_t seed, long long first_ray, float* __restrict__ z) {
+__global__ void k_coarse_z(int R, int Nc, float near_, float far_, int stratified, int lindisp, const float* __restrict__ t_rand, uint64_t seed, long long first_ray, float* __restrict__ z) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= (long long)R * Nc) return;
   const int s = (int)(i % Nc);
   auto zlin = [&](int q) {
     const float t = (Nc > 1) ? (float)q / (float)(Nc - 1) : 0.f;
+    if (lindisp) return 1.0f / (1.0f / near_ * (1.0f - t) + 1.0f / far_ * t);
     return near_ * (1.0f - t) + far_ * t;
   };
   float v = zlin(s);
@@ -885,8 +886,8 @@ __global__ void k_clip_norm(float* __restrict__ g, long long n, float max_norm, 
 static inline dim3 grid1(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 #define LAUNCH(kern, n, stream, ...) hipLaunchKernelGGL(kern, grid1(n), dim3(256), 0, stream, __VA_ARGS__)
 
-void coarse_z(hipStream_t st, int R, int Nc, float near_, float far_, int stratified, const float* t_rand, uint64_t seed, long long first_ray, float* z) {
-  LAUNCH(k_coarse_z, (long long)R * Nc, st, R, Nc, near_, far_, stratified, t_rand, seed, first_ray, z);
+void coarse_z(hipStream_t st, int R, int Nc, float near_, float far_, int stratified, int lindisp, const float* t_rand, uint64_t seed, long long first_ray, float* z) {
+  LAUNCH(k_coarse_z, (long long)R * Nc, st, R, Nc, near_, far_, stratified, lindisp, t_rand, seed, first_ray, z);
 }
 void resample(hipStream_t st, int R, int Nc, int Nf, const float* zc, const float* wc, int stratified, const float* u_rand, uint64_t seed, long long first_ray, float* zf, float* scratch) {
   if (Nc <= 256 && Nf <= 256) hipLaunchKernelGGL(k_resample_wave, dim3(R), dim3(64), 0, st, R, Nc, Nf, zc, wc, stratified, u_rand, seed, first_ray, zf);

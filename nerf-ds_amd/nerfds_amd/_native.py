@@ -90,7 +90,8 @@ class Extra(C.Structure):
   _fields_ = [('nerf_alpha', C.c_float), ('warp_alpha', C.c_float), ('hyper_alpha', C.c_float),
               ('hyper_sheet_alpha', C.c_float), ('norm_input_alpha', C.c_float), ('mask_ratio', C.c_float),
               ('near', C.c_float), ('far', C.c_float), ('use_stratified_sampling', C.c_int32),
-              ('render_opt_flags', C.c_uint32), ('dust_threshold', C.c_float), ('bounding_box', C.c_float * 6)]
+              ('render_opt_flags', C.c_uint32), ('dust_threshold', C.c_float), ('bounding_box', C.c_float * 6),
+              ('use_linear_disparity', C.c_int32)]
 
 
 OPT_DUST_THRESHOLD, OPT_BOUNDING_BOX = 1, 2
@@ -130,7 +131,7 @@ SYMBOLS = ('nerfds_abi_version', 'nerfds_precision_plan', 'nerfds_ctx_create', '
            'nerfds_frame_images', 'nerfds_trainer_create', 'nerfds_trainer_destroy', 'nerfds_trainer_param_count',
            'nerfds_trainer_num_leaves', 'nerfds_trainer_leaf', 'nerfds_trainer_params', 'nerfds_trainer_grads',
            'nerfds_trainer_download', 'nerfds_trainer_upload', 'nerfds_trainer_reset_optimizer', 'nerfds_trainer_step', 'nerfds_trainer_apply', 'nerfds_trainer_clip_gradients', 'nerfds_trainer_target_norm',
-           'nerfds_trainer_last_error', 'nerfds_trainer_debug_read', 'nerfds_trainer_nonfinite')
+           'nerfds_trainer_last_error', 'nerfds_trainer_debug_read', 'nerfds_trainer_nonfinite', 'nerfds_trainer_set_step')
 
 _lib = None
 

@@ -12,9 +12,14 @@ The file format belongs to a third-party dependency that is not under /root/refe
 
 The state dict of ``model_utils.TrainState`` (model_utils.py:24-52) is
 ``{'optimizer': {'target': {'model': <params>}, 'state': {'step': ..., 'param_states': ...}}, 'nerf_alpha': ..., ...}``.
+The optimizer is ``flax.optim.Adam`` (train.py:297-301): ``state`` = ``OptimizerState(step, param_states)`` with one
+``_AdamParamState(grad_ema, grad_sq_ema)`` per parameter leaf (flax/optim/adam.py of 0.3.4), i.e. ``param_states`` mirrors ``target``
+with ``{'grad_ema': ..., 'grad_sq_ema': ...}`` at every leaf.  ``save_checkpoint`` writes the COMPLETE state dict - every TrainState field,
+``None`` schedule scalars as nil, the Adam moments (zeros when none are given) - which is what ``from_state_dict`` needs to restore into a
+``TrainState`` target (training.py:59-66 / train.py:335-338 resume).
 PARITY UNPINNED for the byte format: no checkpoint file ships with the reference and flax cannot be imported here, so
-the reader is pinned only by the published format above (hand-assembled byte vectors in tests/test_checkpoint.py) and by
-round trips through the writer below (which exists for the tests and for this package's own save / restore; the reference cannot load its files, see save_checkpoint).
+reader and writer are pinned only by the published format above (hand-assembled byte vectors in tests/test_checkpoint.py) and by
+round trips.
 """
 from __future__ import annotations
 
@@ -156,16 +161,46 @@ def restore_checkpoint(path: str) -> Tuple[Dict[str, Any], Dict[str, float], int
   return _to_float_tree(params), extra, step
 
 
-def save_checkpoint(ckpt_dir: str, params_model: Dict[str, Any], extra_params: Dict[str, float], step: int) -> str:
-  """Writes ``checkpoint_<step>`` in the same msgpack layout (parameters + schedule scalars) for THIS package's
-  ``restore_checkpoint``.  It is not a file the reference's train.py / eval.py / render.py can restore: flax 0.3.4's
-  ``restore_checkpoint(target=TrainState)`` goes through ``from_state_dict``, which wants every dataclass field and the Adam
-  ``param_states`` (mu / nu per leaf), and those are not written."""
+def restore_optimizer_state(path: str) -> Optional[Tuple[Dict[str, Any], Dict[str, Any], int]]:
+  """(grad_ema tree, grad_sq_ema tree, step) of the Adam state in the newest checkpoint under ``path`` (trees shaped like
+  params['model']), or None if the file carries no ``param_states`` (a parameters-only file)."""
+  f = latest_checkpoint(path)
+  if f is None:
+    raise FileNotFoundError(f'no checkpoint_* file under {path!r}')
+  with open(f, 'rb') as fh:
+    state = msgpack_restore(fh.read())
+  st = state.get('optimizer', {}).get('state', {})
+  ps = st.get('param_states')
+  if ps is None:
+    return None
+  ps = ps['model'] if 'model' in ps else ps
+
+  def pick(tree, key):
+    if isinstance(tree, dict) and set(tree) == {'grad_ema', 'grad_sq_ema'} and not isinstance(tree['grad_ema'], dict):
+      return np.ascontiguousarray(np.asarray(tree[key]), dtype=np.float32)
+    return {k: pick(v, key) for k, v in tree.items()}
+  return pick(ps, 'grad_ema'), pick(ps, 'grad_sq_ema'), int(np.asarray(st.get('step', 0)))
+
+
+def _param_states(params, grad_ema, grad_sq_ema):
+  if isinstance(params, dict):
+    return {k: _param_states(v, None if grad_ema is None else grad_ema[k], None if grad_sq_ema is None else grad_sq_ema[k]) for k, v in params.items()}
+  p = np.asarray(params)
+  z = lambda a: np.zeros(p.shape, np.float32) if a is None else np.ascontiguousarray(np.asarray(a, np.float32).reshape(p.shape))
+  return {'grad_ema': z(grad_ema), 'grad_sq_ema': z(grad_sq_ema)}
+
+
+def save_checkpoint(ckpt_dir: str, params_model: Dict[str, Any], extra_params: Dict[str, float], step: int,
+                    opt_state: Optional[Tuple[Dict[str, Any], Dict[str, Any]]] = None) -> str:
+  """``training.save_checkpoint`` (training.py:59-66): writes ``checkpoint_<step>`` holding the complete TrainState state dict of flax
+  0.3.4 - parameters, Adam ``step`` and ``param_states`` (``opt_state`` = (grad_ema tree, grad_sq_ema tree), e.g. ``Trainer.get_opt_state()``;
+  zeros, a freshly created optimizer, when None), and all eight schedule scalars (nil when unset)."""
   os.makedirs(ckpt_dir, exist_ok=True)
-  state = {'optimizer': {'target': {'model': params_model}, 'state': {'step': np.int32(step)}}}
+  ema, sq = opt_state if opt_state is not None else (None, None)
+  state = {'optimizer': {'target': {'model': params_model},
+                         'state': {'step': np.asarray(step, np.int32), 'param_states': {'model': _param_states(params_model, ema, sq)}}}}
   for k in EXTRA_PARAM_KEYS:
-    if k in extra_params and extra_params[k] is not None:
-      state[k] = np.float32(extra_params[k])
+    state[k] = np.float32(extra_params[k]) if extra_params.get(k) is not None else None
   path = os.path.join(ckpt_dir, f'checkpoint_{int(step)}')
   tmp = path + 'tmp'
   with open(tmp, 'wb') as fh:

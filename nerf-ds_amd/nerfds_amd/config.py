@@ -173,8 +173,6 @@ class NerfModelConfig:
       raise NotImplementedError('use_mask_in_rgb=True is not configured by any shipped gin file')
     if self.window_x_in_rgb_condition:
       raise NotImplementedError('window_x_in_rgb_condition=True is not configured by any shipped gin file')
-    if self.use_linear_disparity:
-      raise NotImplementedError('use_linear_disparity=True is not configured by any shipped gin file')
     if self.use_predicted_mask and not self.use_warp:
       raise ValueError('use_predicted_mask needs the warp GLO ids (models.py:335-336,925)')
     if self.has_hyper and not self.hyper_use_warp_embed:

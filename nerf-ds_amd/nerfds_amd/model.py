@@ -278,6 +278,7 @@ class NerfModel:
                     float(mask_ratio), float(cfg.near if near is None else near), float(cfg.far if far is None else far),
                     int(cfg.use_stratified_sampling))
     N.set_render_opts(extra, render_opts)
+    extra.use_linear_disparity = int(cfg.use_linear_disparity)
     rnd = N.Rand(ptr(t_rand), ptr(u_rand), _seed_from_rngs(rngs), int(ray_offset))
     out = N.Out(ptr(rec_fine), ptr(rec_coarse), ptr(smp_fine), ptr(smp_coarse))
     flags = N.PREC[precision or self.precision]

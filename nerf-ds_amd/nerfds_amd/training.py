@@ -54,6 +54,8 @@ def _bind(lib):
   lib.nerfds_trainer_grads.argtypes = [C.c_void_p]
   lib.nerfds_trainer_grads.restype = C.c_void_p
   lib.nerfds_trainer_reset_optimizer.argtypes = [C.c_void_p]
+  lib.nerfds_trainer_set_step.argtypes = [C.c_void_p, C.c_int64]
+  lib.nerfds_trainer_nonfinite.argtypes = [C.c_void_p]
   lib.nerfds_trainer_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
   lib.nerfds_trainer_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
   lib.nerfds_trainer_step.argtypes = [C.c_void_p, C.POINTER(N.Rays), C.c_void_p, C.POINTER(N.Extra), C.POINTER(N.Rand), C.POINTER(Objective),
@@ -183,6 +185,27 @@ class Trainer:
   def get_grads(self) -> Dict[str, Any]:
     return self._tree(self._download(1))
 
+  def get_opt_state(self):
+    """(grad_ema tree, grad_sq_ema tree): the Adam moments, shaped like the parameter tree (flax 0.3.4 _AdamParamState per leaf) - what
+    checkpoint.save_checkpoint(..., opt_state=) writes so that a run can be resumed (training.py:59-66)."""
+    return self._tree(self._download(2)), self._tree(self._download(3))
+
+  def set_opt_state(self, grad_ema: Dict[str, Any], grad_sq_ema: Dict[str, Any], step: int) -> None:
+    """Restores the Adam moments and the optimizer step count (checkpoint.restore_optimizer_state)."""
+    for which, tree in ((2, grad_ema), (3, grad_sq_ema)):
+      flat = np.empty(self.num_params, np.float32)
+      for name, off, rows, cols in self.leaves:
+        node = tree
+        for part in name.split('/'):
+          node = node[part]
+        flat[off:off + rows * cols] = np.asarray(node, np.float32).reshape(-1)
+      rc = self._lib.nerfds_trainer_upload(self._h, which, flat.ctypes.data)
+      if rc != 0:
+        raise RuntimeError(f'nerfds_trainer_upload failed ({rc})')
+    rc = self._lib.nerfds_trainer_set_step(self._h, int(step))
+    if rc != 0:
+      raise RuntimeError(f'nerfds_trainer_set_step failed ({rc})')
+
   # -- one step ------------------------------------------------------------------------------------------
   def step(self, batch: Dict[str, Any], extra_params: Dict[str, Any], learning_rate: float = 0.0, *, t_rand=None, u_rand=None,
            mask_ratio: float = 1.0, near: Optional[float] = None, far: Optional[float] = None, grads_only: bool = False,
@@ -212,7 +235,8 @@ class Trainer:
     g = lambda k, d=0.0: float(extra_params[k]) if extra_params.get(k) is not None else d
     ex = N.Extra(nerf_alpha=g('nerf_alpha'), warp_alpha=g('warp_alpha'), hyper_alpha=g('hyper_alpha'), hyper_sheet_alpha=g('hyper_sheet_alpha'),
                  norm_input_alpha=g('norm_input_alpha'), mask_ratio=float(mask_ratio), near=float(self.cfg.near if near is None else near),
-                 far=float(self.cfg.far if far is None else far), use_stratified_sampling=int(self.cfg.use_stratified_sampling))
+                 far=float(self.cfg.far if far is None else far), use_stratified_sampling=int(self.cfg.use_stratified_sampling),
+                 use_linear_disparity=int(self.cfg.use_linear_disparity))
     if seed is None:
       self._auto_seed = getattr(self, '_auto_seed', 0) + 1
       seed = (0x5DEECE66D * self._auto_seed + 0xB) & 0xFFFFFFFFFFFFFFFF

@@ -68,3 +68,33 @@ def test_errors(tmp_path):
   p.write_bytes(ck.msgpack_serialize({'not': {'a': np.zeros(1, np.float32)}}))
   with pytest.raises(ValueError):
     ck.restore_checkpoint(str(p))
+
+
+def test_complete_train_state_with_adam_moments(tmp_path):
+  """The writer emits every field flax 0.3.4's from_state_dict(TrainState) needs (training.py:59-66): target, OptimizerState.step,
+  one {grad_ema, grad_sq_ema} per parameter leaf, all eight schedule scalars (nil when unset)."""
+  cfg = nerf_ds_config(num_warp_embeds=3)
+  params = init_params(cfg, 5, bias_scale=0.1)
+  rng = np.random.default_rng(0)
+  ema = {k: v for k, v in params.items()}
+  def rand_like(tree):
+    return {k: rand_like(v) for k, v in tree.items()} if isinstance(tree, dict) else rng.normal(size=np.asarray(tree).shape).astype(np.float32)
+  ema, sq = rand_like(params), rand_like(params)
+  path = ck.save_checkpoint(str(tmp_path), params, dict(nerf_alpha=8.0, warp_alpha=4.0), 77, opt_state=(ema, sq))
+  raw = ck.msgpack_restore(open(path, 'rb').read())
+  assert set(raw) == {'optimizer'} | set(ck.EXTRA_PARAM_KEYS) and raw['hyper_alpha'] is None and float(raw['nerf_alpha']) == 8.0
+  assert set(raw['optimizer']) == {'target', 'state'} and set(raw['optimizer']['state']) == {'step', 'param_states'}
+  assert raw['optimizer']['state']['step'].shape == () and raw['optimizer']['state']['step'].dtype == np.int32
+  ps = raw['optimizer']['state']['param_states']['model']
+  names = [n for n, _ in tree_leaves(params)]
+  assert [n for n, _ in tree_leaves(ps)] == [f'{n}/{m}' for n in names for m in ('grad_ema', 'grad_sq_ema')]
+  got_ema, got_sq, step = ck.restore_optimizer_state(str(tmp_path))
+  assert step == 77
+  for (n, a), (_, b) in zip(tree_leaves(ema), tree_leaves(got_ema)):
+    np.testing.assert_array_equal(a, b, err_msg=n)
+  for (n, a), (_, b) in zip(tree_leaves(sq), tree_leaves(got_sq)):
+    np.testing.assert_array_equal(a, b, err_msg=n)
+  # a fresh optimizer: zeros of every leaf's shape
+  ck.save_checkpoint(str(tmp_path), params, {}, 78)
+  z, _, _ = ck.restore_optimizer_state(str(tmp_path))
+  assert all(not np.any(v) and v.shape == np.asarray(p).shape for (_, v), (_, p) in zip(tree_leaves(z), tree_leaves(params)))

@@ -473,3 +473,25 @@ def test_render_opts_filter_sigma(prec):
       assert _relerr(got[level]['weights'].cpu().numpy(), ref[level]['weights']) < 2e-4
   with pytest.raises(ValueError):
     model.apply({'params': params}, rays, EXTRA, precision=prec, render_opts={'nonsense': 1}, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('stratified', [False, True])
+def test_linear_disparity_sampling(stratified):
+  """NerfModel.use_linear_disparity (model_utils.py:73-76): coarse depths linear in 1 / z, in the render kernel and in the trainer's forward."""
+  cfg, params, rng, rays, t, u = _tiny_case(seed=10)
+  cfg = cfg.replace(use_linear_disparity=True, near=0.3, far=1.7, use_stratified_sampling=stratified)
+  kw = dict(t_rand=t, u_rand=u, use_predicted_norm=True)
+  ref = O.to_numpy(O.NerfModel(cfg, params).apply(rays, EXTRA, compute_sigma_gradient=False, return_weights=True, **kw))
+  got = _model(cfg).apply({'params': params}, rays, EXTRA, precision='f32', return_weights=True, **kw)
+  lin = O.to_numpy(O.NerfModel(cfg.replace(use_linear_disparity=False), params).apply(rays, EXTRA, compute_sigma_gradient=False, **kw))
+  assert _relerr(ref['fine']['rgb'], lin['fine']['rgb']) > 1e-3             # the option changes the picture
+  for level in ('coarse', 'fine'):
+    assert np.allclose(got[level]['z_vals'].cpu().numpy(), ref[level]['z_vals'], rtol=3e-6, atol=1e-6), level
+    assert _relerr(got[level]['rgb'].cpu().numpy(), ref[level]['rgb']) < 1e-4
+  from nerfds_amd.training import Trainer
+  batch = dict(rays, rgb=rng.random((t.shape[0], 3)))
+  tr = Trainer(cfg, params, max_rays=t.shape[0])
+  stats = tr.step(batch, EXTRA, 0.0, t_rand=t, u_rand=u, mask_ratio=1.0, grads_only=True)
+  want = float(((ref['fine']['rgb'] - batch['rgb']) ** 2).mean())
+  assert abs(stats['loss/fine'] - want) < 2e-5 * max(want, 1e-3), (stats, want)
