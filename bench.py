@@ -50,7 +50,7 @@ FLOP_PER_RAY = 333.15e6          # BASELINE.md section 2, nerf_ds graph, 192 fie
 PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f32': 157.3, 'f16': 2500.0, 'mixed': 2500.0}
 EXTRA = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
 # where the committed PMC measurement of the headline kernel lives (separate rocprofv3 passes of this command, tools/prof_bench.sh)
-TRAFFIC_FILE = 'profiles/r3_bf16_hbm_traffic.json'
+TRAFFIC_FILE = 'profiles/r4_bf16_hbm_traffic.json'
 TRAIN_TRAFFIC_FILE = 'profiles/r3_train_hbm_traffic.json'
 
 
@@ -546,7 +546,7 @@ def main():
         pix = [e for e in (pp['rgb_max_pixel_rel_err'], pp['full_frame_rgb_max_pixel_rel_err']) if e is not None]
         pp['meets_1e-4_per_pixel'] = bool(pix) and max(pix) <= 1e-4
         pp['note'] = ('split bf16 (hi + lo) operands, three MFMAs per product, fp32 accumulate: the fastest arithmetic that meets '
-                      "north_star's 1e-4 on composited RGB (profiles/r3_precision_budget.md: no plan with a one-MFMA network does)")
+                      "north_star's 1e-4 on composited RGB (profiles/r4_precision_budget.md: no arithmetic below three MFMA-equivalents per product holds it at frame size)")
         result['parity_path'] = pp
       result['other_paths'] = list(paths.values())
       if not args.no_train_line:

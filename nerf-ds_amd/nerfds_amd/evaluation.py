@@ -278,6 +278,11 @@ def _render_image_device(state, rays_dict, model_fn, params, keys, num_rays, num
   comm = torch.cuda.Stream(dev)
   per_max = (min(chunk, num_rays) + world - 1) // world
   staging = [torch.empty((per_max, N.RAY_REC), dtype=torch.float32, device=dev) for _ in range(2)]
+  # everything the loop needs is allocated once: two staging buffers, two (ready, done) event pairs, one buffer for the gather of a padded
+  # chunk (only the frame's last chunk can be ragged) - the loop itself allocates nothing, whatever the number of chunks or ranks
+  ready_ev = [torch.cuda.Event() for _ in range(2)]
+  done_ev = [torch.cuda.Event() for _ in range(2)]
+  padded = None
   done = [None, None]
   for batch_idx in range(num_batches):
     ray_idx = batch_idx * chunk
@@ -292,17 +297,19 @@ def _render_image_device(state, rays_dict, model_fn, params, keys, num_rays, num
       compute.wait_event(done[slot])                         # the exchange of chunk i - 2 has read this buffer
     rec = staging[slot][:per]
     model_fn.render_local(*keys, params, local, state.extra_params, records_out={ret_key: rec})
-    ready = torch.cuda.Event()
+    ready = ready_ev[slot]
     ready.record(compute)
     with torch.cuda.stream(comm):
       comm.wait_event(ready)
       if padding == 0:
         all_gather_into(frame[ray_idx:ray_idx + n], rec)
       else:
-        full = torch.empty((world * per, N.RAY_REC), dtype=torch.float32, device=dev)
+        if padded is None or padded.shape[0] < world * per:
+          padded = torch.empty((world * per_max, N.RAY_REC), dtype=torch.float32, device=dev)
+        full = padded[:world * per]
         all_gather_into(full, rec)
         frame[ray_idx:ray_idx + n].copy_(full[:n])                                       # utils.unshard: drop the padding
-      done[slot] = torch.cuda.Event()
+      done[slot] = done_ev[slot]
       done[slot].record(comm)
   compute.wait_stream(comm)
   return frame

@@ -4,8 +4,10 @@ on identical rays, weights and injected sampling uniforms.
 Tolerance (BASELINE.json north_star): composited RGB within 1e-4 relative of the reference semantics.  The
 fp32-MFMA kernel (exact fp32 fma chains) and the split-bf16 kernel are held to that bar.  The one-MFMA-per-product
 kernels cannot meet it (profiles/r2_precision_budget.md: >= 16 significand bits are needed on both operands of every
-layer); their measured error is printed and bounded just above what was measured: bf16 3e-2 (8 significand bits: 2.0e-2 is
-the worst of these cases, 3.9e-2 the worst ray of 4096), f16 3e-3 (11 bits), mixed (f16 with the warp field in split bf16) 2e-3.
+layer; profiles/r4_precision_budget.md: nor can any arithmetic below three MFMA-equivalents per product); their measured error is printed and
+bounded at <= 2 x the worst value these tests measure: bf16 3e-2 (8 significand bits: 2.05e-2 measured), f16 2.4e-3 (1.24e-3), mixed (f16 with
+the warp field in split bf16) 1.4e-3 (7.3e-4).  Statistics: global = max |d| / max |ref| over rays and channels; for the composited rgb of the
+parity-grade modes also per pixel = max |d| / max(|ref|, 1e-2), bounded at 2e-4.
 """
 import ctypes as C
 import sys
@@ -20,7 +22,9 @@ from oracle import nerfds_oracle as O
 pytestmark = pytest.mark.gpu
 
 EXTRA = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
-RTOL = {'f32': 1e-4, 'bf16x3': 1e-4, 'bf16': 3e-2, 'f16': 3e-3, 'mixed': 2e-3}
+# parity grade: north_star's 1e-4.  Throughput modes: <= 2 x the worst value these tests measure (round 4: bf16 2.05e-2, f16 1.24e-3, mixed 7.3e-4)
+RTOL = {'f32': 1e-4, 'bf16x3': 1e-4, 'bf16': 3e-2, 'f16': 2.4e-3, 'mixed': 1.4e-3}
+PIXEL_FLOOR = 1e-2
 FAST = ('bf16', 'f16', 'mixed')      # throughput arithmetic: composited maps only, bounded by RTOL
 
 
@@ -35,6 +39,11 @@ def _rays(R, n_ids, seed, spread=0.1):
 
 def _relerr(a, b):
   return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-6))
+
+
+def _pixerr(a, b):
+  """per-pixel relative error: max |a - b| / max(|b|, 1e-2) - a dark pixel is not excused by the brightest one (bench.py reports the same)"""
+  return float((np.abs(a - b) / np.maximum(np.abs(b), PIXEL_FLOOR)).max())
 
 
 def _model(cfg):
@@ -88,6 +97,10 @@ def test_nerf_ds_graph_tiny(prec):
       print(f'{prec} {level} {k}: {e:.2e}', file=sys.stderr)
       lim = tol if k == 'rgb' else 10 * tol
       assert e <= lim, (level, k, e)
+      if k == 'rgb':                 # the per-pixel form of the same bar
+        ep = _pixerr(g[k], r[k].numpy())
+        print(f'{prec} {level} rgb per-pixel: {ep:.2e}', file=sys.stderr)
+        assert ep <= 2 * tol, (level, 'rgb per pixel', ep)
 
 
 @pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])

@@ -263,7 +263,8 @@ def test_target_norm_on_the_render_surface():
     got = out[level]['target_norm'].cpu().numpy()
     assert got.shape == (5, 6, S, 3)
     cos = (got.reshape(30, S, 3) * ref[level]['target_norm'].numpy()).sum(-1)
-    assert float((1 - cos > 1e-4).mean()) < 0.03 and np.median(1 - cos) < 1e-6, level
+    # quantile bound (measured: q99 = 6e-8, worst sample 1.3e-2 - a sample whose gradient is tiny, where normalisation amplifies fp32 rounding)
+    assert np.quantile(1 - cos, 0.99) < 1e-6 and float((1 - cos > 1e-4).mean()) <= 0.01 and float((1 - cos).max()) < 5e-2, level
     assert float((out[level]['rgb'].cpu() - ref[level]['rgb'].reshape(5, 6, 3).float()).abs().max()) <= 1e-4
 
 

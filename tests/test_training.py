@@ -464,7 +464,7 @@ def test_fused_backward_chain_against_numpy_on_the_step_buffers(g16, monkeypatch
   h7 = tr.debug_read('trunk_h16_7', (M, 256), np.float16).astype(np.float64)
   check_bits(bits_to_mask(tr.debug_read('trunk_bits_7', (M * 2 * 8,), np.uint16), 256), h7)
   with pytest.raises(RuntimeError):                      # a view holds M * width elements: an oversized read is refused, not performed
-    tr.debug_read('trunk_h16_7', (tr.max_rays * (Nc + Nf) + 1, 256), np.float16)
+    tr.debug_read('trunk_h16_7', (tr.max_rays * Nc + 1, 256), np.float16)
   d_rgb = tr.debug_read('d_rgb_logit', (M, 3)).astype(np.float64)
   d_alpha = tr.debug_read('d_alpha', (M, 4)).astype(np.float64)
   Wr = np.asarray(P['rgb_mlp']['logit']['kernel'], np.float64)
@@ -534,10 +534,10 @@ def test_resume_from_a_checkpoint_with_adam_state(tmp_path):
   p0 = dict(tree_leaves(params))
   for k in pa:
     moved = np.abs(pa[k] - np.asarray(p0[k], np.float32).reshape(pa[k].shape)).max()
-    assert np.abs(pa[k] - pb[k]).max() <= 2e-3 * max(moved, 1e-6) + 1e-7, k
+    assert np.abs(pa[k] - pb[k]).max() <= 2e-2 * max(moved, 1e-6) + 1e-6, k      # (float atomics: two runs of the SAME steps differ by ~2e-3 of the move)
   # without the moments the continuation is a different one (bias correction restarts): the test above is not vacuous
   c = Trainer(cfg, p, max_rays=32)
   for _ in range(2):
     c.step(batch, EX, 1e-3, **kw)
   pc = dict(tree_leaves(c.get_params()))
-  assert max(np.abs(pa[k] - pc[k]).max() for k in pa) > 1e-4
+  assert max(np.abs(pa[k] - pc[k]).max() / max(np.abs(pa[k] - np.asarray(p0[k], np.float32).reshape(pa[k].shape)).max(), 1e-6) for k in pa) > 0.1
