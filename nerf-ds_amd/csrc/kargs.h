@@ -71,6 +71,12 @@ struct TrainOut {
   float* rgb_logit;    // [M][3]
   const float* z;      // [R][S]  sample depths of this level
   int level;
+  // train_fwd_kernel.hip MODE: 0 shared networks + NerfMLP, 1 shared networks only, 2 NerfMLP only with the shared networks' per-sample results
+  // read from in_xw [M][3] (warped point), in_wamb [M][2] (ambient coordinates), in_wv [M][6] (screw axis head) in the level's row order
+  int mode;
+  const float* in_xw;
+  const float* in_wamb;
+  const float* in_wv;
   // half_out != 0 (the plain training step): every hidden layer is written as f16 (what the weight-gradient kernels read as X: 11
   // significand bits in 2 bytes) into *_h16 plus one bit per feature "output > 0" into *_bits (what the fused backward reads as the
   // ReLU mask), instead of the fp32 arrays above (which the tangent passes of the norm loss still need).

@@ -12,8 +12,16 @@ namespace nerfds {
 // hidden layer's fp32 output and every head's raw output written to the trainer's workspace for the backward pass.  No
 // compositing here: the loss kernel composites from sigma / rgb (train_kernels.hip).  The host passes the level's NerfMLP
 // stream and biases in slot 1, so the kernel always evaluates "level 0".
+// MODE (round 4, the merged step of nerfds_train.cpp run_merged): the mask / warp / hyper-sheet networks see only the observation-space point,
+// and the fine level's sorted union repeats the coarse positions - the reference evaluates (and differentiates) them there a second time and
+// gets the same numbers (models.py:1528-1546 over 1291-1300).  The trainer runs them ONCE per position:
+//   MODE 0  shared networks + NerfMLP on the level's samples (the coarse level; every step that is not a merged one)
+//   MODE 1  shared networks only, on the fine level's NEW samples
+//   MODE 2  NerfMLP only, on the sorted union: the per-sample state the shared networks produced (warped point, ambient coordinates, screw
+//           axis) comes from arrays gathered in union order (to.in_xw / in_wamb / in_wv) and is parked in the ray's LDS block here
 // ------------------------------------------------------------------------------------------------
-template <class G, class PL, bool WIDE, int TAG>
+enum { FWD_FULL = 0, FWD_SHARED_ONLY = 1, FWD_NERF_ONLY = 2 };
+template <class G, class PL, bool WIDE, int TAG, int MODE>
 __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train_forward_kernel(const KArgs ka, const TrainOut to) {
   using SH = Shape<PL, WIDE>;
   using WaveLds = WaveLdsT<SH::MAXS>;
@@ -28,10 +36,10 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train
   Pipe<G, PL> pipe;
   const rsrc_t rs_nerf = make_rsrc(ka.wstream[1], PP::NERF_PAD * 1024);
   const rsrc_t rs_shared = PP::HAS_SHARED ? make_rsrc(ka.wstream[0], PP::SHARED_PAD * 1024) : rs_nerf;
-  pipe.cur = pipe.next = rs_shared;
+  pipe.cur = pipe.next = (MODE == FWD_NERF_ONLY) ? rs_nerf : rs_shared;
   pipe.lane16 = lane * 16;
   pipe.wave1k = wave * 1024;
-  pipe.prologue(PP::HAS_SHARED ? SEG_SHARED : SEG_NERF);
+  pipe.prologue((PP::HAS_SHARED && MODE != FWD_NERF_ONLY) ? SEG_SHARED : SEG_NERF);
   {  // biases -> LDS (as render_rays_kernel; only the shared nets and slot 1 are used)
     constexpr int n0 = Dm::SHARED_BIAS_TILES * 32, n1 = Dm::NERF_BIAS_TILES * 32;
     float* dst = reinterpret_cast<float*>(g_smem + BIAS_OFF);
@@ -82,11 +90,33 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train
         sm.z[nt] = L.zs[sm.slot[nt]];
       }
       const size_t row = (size_t)ray * S + (size_t)sm.slot[0];     // this lane's row of the [R * S][width] activation arrays
-      if constexpr (PP::HAS_SHARED) { pipe.cur = rs_shared; pipe.next = rs_nerf; }
-      eval_shared<G, PL, NT, WaveLds, TrainOut>(ka, rc, pipe, lane, sm, L, to, row);
-      pipe.cur = rs_nerf;
-      pipe.next = rs_shared;
-      eval_nerf<G, PL, NT, WaveLds, TrainOut>(ka, pipe, 0, lane, sm, L, to, row);
+      if constexpr (MODE != FWD_NERF_ONLY) {
+        if constexpr (PP::HAS_SHARED) { pipe.cur = rs_shared; pipe.next = (MODE == FWD_SHARED_ONLY) ? rs_shared : rs_nerf; }
+        eval_shared<G, PL, NT, WaveLds, TrainOut>(ka, rc, pipe, lane, sm, L, to, row);
+      } else {
+        // what eval_shared would have parked for this sample, from the gathered arrays (every lane, unconditionally: the two lane halves and
+        // the clamped tail lanes hold the same values); the screw axis exactly as eval_shared derives it from the head outputs
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int s = sm.slot[nt];
+          const size_t r = (size_t)ray * S + (size_t)s;
+          float w[3] = {to.in_wv[6 * r], to.in_wv[6 * r + 1], to.in_wv[6 * r + 2]};
+          const float theta = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+          w[0] /= theta; w[1] /= theta; w[2] /= theta;
+          float st, ct;
+          sincos_cw(theta, st, ct);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { L.sv[SV_WP + c][s] = to.in_xw[3 * r + c]; L.sv[SV_AX + c][s] = w[c]; }
+          L.sv[SV_WP + 3][s] = to.in_wamb[2 * r]; L.sv[SV_WP + 4][s] = to.in_wamb[2 * r + 1];
+          L.sv[SV_SN][s] = st;
+          L.sv[SV_OMC][s] = 1.0f - ct;
+        }
+      }
+      if constexpr (MODE != FWD_SHARED_ONLY) {
+        pipe.cur = rs_nerf;
+        pipe.next = (MODE == FWD_NERF_ONLY) ? rs_nerf : rs_shared;
+        eval_nerf<G, PL, NT, WaveLds, TrainOut>(ka, pipe, 0, lane, sm, L, to, row);
+      }
     }
     ray_sync();
   }
@@ -96,19 +126,25 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train
 using KernelPlan = PlanT<TRAIN_PLAN.mask, TRAIN_PLAN.warp, TRAIN_PLAN.hyp, TRAIN_PLAN.trunk, TRAIN_PLAN.rgb>;
 }  // namespace nerfds
 
-template <bool WIDE> static void launch_train(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream) {
+template <bool WIDE, int MODE> static void launch_train(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream) {
   using namespace nerfds;
   using SH = Shape<KernelPlan, WIDE>;
   constexpr int lds = BIAS_OFF + bias_bytes<NERFDS_GRAPH>() + SH::RAYS * (int)sizeof(WaveLdsT<SH::MAXS>);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = train_forward_kernel<NERFDS_GRAPH, KernelPlan, WIDE, TRAIN_TAG>;
+  auto kern = train_forward_kernel<NERFDS_GRAPH, KernelPlan, WIDE, TRAIN_TAG, MODE>;
   allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
   const long long groups = ((long long)ka.num_rays + SH::RAYS - 1) / SH::RAYS;
   const int grid = (int)(groups < num_cus ? groups : num_cus);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wg_waves<KernelPlan>()), lds, static_cast<hipStream_t>(stream), ka, to);
 }
-// ka.nc = samples of the level (ka.nf unused); ka.wstream[1] / ka.bias[1] = the level's NerfMLP
+// ka.nc = samples of the level (ka.nf unused); ka.wstream[1] / ka.bias[1] = the level's NerfMLP; to.mode = FWD_* (the partial modes exist in the
+// f16-store build only: the merged step is a plain step)
 extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream) {
-  if (ka.nc > nerfds::Shape<nerfds::KernelPlan, false>::MAXS) launch_train<true>(ka, to, num_cus, stream);
-  else launch_train<false>(ka, to, num_cus, stream);
+  const bool wide = ka.nc > nerfds::Shape<nerfds::KernelPlan, false>::MAXS;
+  if constexpr (nerfds::TRAIN_HALF) {
+    if (to.mode == nerfds::FWD_SHARED_ONLY) { if (wide) launch_train<true, nerfds::FWD_SHARED_ONLY>(ka, to, num_cus, stream); else launch_train<false, nerfds::FWD_SHARED_ONLY>(ka, to, num_cus, stream); return; }
+    if (to.mode == nerfds::FWD_NERF_ONLY) { if (wide) launch_train<true, nerfds::FWD_NERF_ONLY>(ka, to, num_cus, stream); else launch_train<false, nerfds::FWD_NERF_ONLY>(ka, to, num_cus, stream); return; }
+  }
+  if (wide) launch_train<true, nerfds::FWD_FULL>(ka, to, num_cus, stream);
+  else launch_train<false, nerfds::FWD_FULL>(ka, to, num_cus, stream);
 }

@@ -532,12 +532,16 @@ def test_resume_from_a_checkpoint_with_adam_state(tmp_path):
     b.step(batch, EX, 1e-3, **kw)
   pa, pb = dict(tree_leaves(a.get_params())), dict(tree_leaves(b.get_params()))
   p0 = dict(tree_leaves(params))
-  for k in pa:
-    moved = np.abs(pa[k] - np.asarray(p0[k], np.float32).reshape(pa[k].shape)).max()
-    assert np.abs(pa[k] - pb[k]).max() <= 2e-2 * max(moved, 1e-6) + 1e-6, k      # (float atomics: two runs of the SAME steps differ by ~2e-3 of the move)
-  # without the moments the continuation is a different one (bias correction restarts): the test above is not vacuous
+  flat = lambda d: np.concatenate([np.asarray(d[k], np.float32).ravel() for k in pa])
+  va, vb, v0 = flat(pa), flat(pb), flat(p0)
+  moved = np.linalg.norm(va - v0)
+  # Adam normalises every element's step to ~lr: an element whose gradient is at the noise level of the float atomics can take a different sign
+  # in two runs of the SAME steps, so the comparison is on the whole vector
+  same = np.linalg.norm(va - vb) / moved
+  assert same < 0.05, same
+  # without the moments the continuation is a different one (moments and bias correction restart): the check above is not vacuous
   c = Trainer(cfg, p, max_rays=32)
   for _ in range(2):
     c.step(batch, EX, 1e-3, **kw)
-  pc = dict(tree_leaves(c.get_params()))
-  assert max(np.abs(pa[k] - pc[k]).max() / max(np.abs(pa[k] - np.asarray(p0[k], np.float32).reshape(pa[k].shape)).max(), 1e-6) for k in pa) > 0.1
+  other = np.linalg.norm(va - flat(dict(tree_leaves(c.get_params())))) / moved
+  assert other > 4 * same and other > 0.1, (same, other)
