@@ -717,7 +717,10 @@ void fused_backward(nerfds_trainer& t, hipStream_t st, int net, int level, int64
   else nerfds_launch_train_bwd_nerfds(tb, net, t.num_cus, st);
 }
 
-void fused_forward(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const float* z, const nerfds_rays* rays, const nerfds_extra* ex, const Windows& W) {
+// mode / row_off / in_*: the merged step (run_merged) - mode 1 runs the shared networks only and writes their arrays `row_off` rows further down
+// (the block of the fine level's new samples); mode 2 runs the NerfMLP only on shared-network results gathered into the level's row order
+void fused_forward(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const float* z, const nerfds_rays* rays, const nerfds_extra* ex, const Windows& W,
+                   int mode = 0, int64_t row_off = 0, const float* in_xw = nullptr, const float* in_wamb = nullptr, const float* in_wv = nullptr) {
   nerfds::KArgs ka{};
   ka.origins = rays->origins; ka.directions = rays->directions; ka.viewdirs = rays->viewdirs;
   ka.warp_id = rays->warp_id; ka.gt_mask = rays->gt_mask;
@@ -733,14 +736,116 @@ void fused_forward(nerfds_trainer& t, hipStream_t st, int level, int R, int S, c
   for (int l = 0; l < 6; ++l) { to.warp_h[l] = t.warp_h[l]; to.hyper_h[l] = t.hyper_h[l]; }
   to.rgb_h = t.rgb_hv; to.mask_logit = t.mask_logit; to.wv = t.wv; to.wamb = t.wamb; to.alphav = t.alphav; to.rgb_logit = t.rgb_logit;
   to.z = z; to.level = level;
+  to.mode = mode; to.in_xw = in_xw; to.in_wamb = in_wamb; to.in_wv = in_wv;
   to.half_out = t.half_step ? 1 : 0;
   if (t.half_step) {
     for (int l = 0; l < 8; ++l) { to.mask_h16[l] = t.mask_h16[l]; to.mask_bits[l] = t.mask_bits[l]; to.trunk_h16[l] = t.trunk_h16[l]; to.trunk_bits[l] = t.trunk_bits[l]; }
     for (int l = 0; l < 6; ++l) { to.warp_h16[l] = t.warp_h16[l]; to.warp_bits[l] = t.warp_bits[l]; to.hyper_h16[l] = t.hyper_h16[l]; to.hyper_bits[l] = t.hyper_bits[l]; }
     to.rgb_h16 = t.rgb_h16; to.rgb_bits = t.rgb_bits;
   }
+  if (row_off) {        // the shared networks' arrays, `row_off` rows down ([M][width] each; ReLU bits: one u16 per row, lane half and 32-feature tile)
+    const int MW = t.mask.width, WW = t.warp.width, HW = t.hyper.width;
+    for (int l = 0; l < 8; ++l) { to.mask_h[l] += row_off * MW; if (to.mask_h16[l]) { to.mask_h16[l] += row_off * MW; to.mask_bits[l] += row_off * 2 * (MW / 32); } }
+    for (int l = 0; l < 6; ++l) {
+      to.warp_h[l] += row_off * WW; to.hyper_h[l] += row_off * HW;
+      if (to.warp_h16[l]) { to.warp_h16[l] += row_off * WW; to.warp_bits[l] += row_off * 2 * (WW / 32); to.hyper_h16[l] += row_off * HW; to.hyper_bits[l] += row_off * 2 * (HW / 32); }
+    }
+    to.mask_logit += row_off; to.wv += row_off * 6; to.wamb += row_off * 2;
+  }
   if (to.half_out) nerfds_launch_train_fwd16_nerfds(ka, to, t.num_cus, st);
   else nerfds_launch_train_fwd_nerfds(ka, to, t.num_cus, st);
+}
+
+// The plain two-level step with the level-independent networks evaluated - and differentiated - ONCE per sample position (round 4).
+// The mask network, the SE(3) field and the hyper sheet see only the observation-space point, the GLO rows and the mask; the fine level's
+// sorted union repeats the Nc coarse positions, and the reference runs the three networks there a second time (models.py:1528-1546 over
+// 1291-1300) on identical inputs.  The gradient of a loss through two identical evaluations is the gradient through one evaluation with the two
+// upstream gradients added.  So: position rows = [R x Nc coarse samples | R x Nf new samples]; the shared networks run forward once on each
+// block; the fine NerfMLP runs on the union with their results gathered into its row order; its gradient w.r.t. the warped points / ambient
+// coordinates is scattered back to the position rows (added, for the coarse block, to what the coarse NerfMLP left there); and ONE backward
+// pass of the three networks (chains + weight gradients) covers all R x (Nc + Nf) positions instead of R x Nc + R x (Nc + Nf) rows: a third
+// less shared-network work per step.  Same loss, same gradients up to the order of the sums (tests/test_training.py compares with the oracle).
+int run_merged(nerfds_trainer& t, hipStream_t st, int R, const float* zc, const nerfds_rays* rays, const float* target, const nerfds_extra* ex,
+               const Windows& W, const nerfds_rand* rnd) {
+  const Dims& D = t.D;
+  const int Nc = t.cfg.num_coarse_samples, Nf = t.cfg.num_fine_samples, S = Nc + Nf, strat = ex->use_stratified_sampling;
+  const int64_t Mc = (int64_t)R * Nc, Mn = (int64_t)R * Nf, Mf = Mc + Mn, Ms = Mc + Mn;
+  const float* viewdirs = rays->viewdirs ? rays->viewdirs : rays->directions;
+  const int VD = 6 * D.vd_bands, NM = 6 * D.nm_bands, CW = VD + NM;
+  // scratch in buffers only the layer-by-layer backward uses (g0 / g1 / g2: M x 256 floats each)
+  float* xw_f = t.g0; float* wamb_f = xw_f + 3 * Mf; float* wv_f = wamb_f + 2 * Mf;
+  float* dxw_f = t.g1; float* dwamb_f = dxw_f + 3 * Mf;
+  float* z_new = t.g2; int* src = reinterpret_cast<int*>(z_new + Mn);
+  auto wg_nerf = [&](Run& r, int level) {
+    const MlpP& trunk = t.trunk[level];
+    const LayerP& K = t.rgb_h[level];
+    const int TW = trunk.width, RW = K.N;
+    r.head_wgrads(t.rgb_out[level], t.rgb_h16, RW, t.d_rgb_logit, 3);
+    r.head_wgrads(t.alpha[level], t.trunk_h16.back(), TW, t.d_alpha, 4);
+    r.weight_grad(reinterpret_cast<const float*>(t.trunk_h16.back()), TW, TW, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(TW + VD) * RW, -1, true, t.grad + K.b, t.g16);
+    r.weight_grad(t.cond, CW, VD, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)TW * RW, -1, false, nullptr, t.g16);
+    r.weight_grad(t.cond + VD, CW, NM, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(2 * TW + VD) * RW, -1, false, nullptr, t.g16);
+    r.mlp_wgrads(trunk, t.trunk_in, t.trunk_h16, t.trunk_h);
+  };
+  // ---------------- coarse level: shared networks (block A) + coarse NerfMLP, its loss and its NerfMLP backward ----------------
+  Run rc{t, st, Mc};
+  encode_inputs(st, D, R, Nc, rays->origins, rays->directions, zc, rays->warp_id, t.cfg.num_warp_embeds, t.theta + t.warp_tbl, t.theta + t.mask_tbl, W,
+                t.x, t.mask_in, t.warp_in, t.hyper_in);
+  fused_forward(t, st, 0, R, Nc, zc, rays, ex, W);
+  mask_post(st, D, R, Nc, t.mask_logit, rays->gt_mask, ex->mask_ratio, t.warp_in, t.hyper_in);
+  se3_fwd(st, Mc, t.wv, t.x, t.xw);
+  trunk_in(st, D, Mc, t.xw, t.wamb, W, t.trunk_in);
+  alpha_post(st, D, R, Nc, t.alphav, t.wv, viewdirs, W, t.sigma, t.cond);
+  composite_loss(st, R, Nc, zc, rays->directions, t.sigma, t.rgb_logit, target, t.cfg.use_sample_at_infinity, t.cfg.use_white_background, t.rgb_ray, t.wc,
+                 t.loss_dev + 0, t.d_rgb_logit, t.d_alpha);
+  fused_backward(t, st, 0, 0, Mc, t.d_rgb_logit, 3, t.d_alpha, t.d_trunk_in, D.trunk_in);
+  rc.fork(false); wg_nerf(rc, 0);
+  trunk_in_bwd(st, D, Mc, t.d_trunk_in, t.xw, t.wamb, W, nullptr, nullptr, t.dxw, t.dwamb);          // position rows of block A
+  // ---------------- the fine level's new samples: shared networks only (block B), under the coarse weight gradients ----------------
+  resample(st, R, Nc, Nf, zc, t.wc, strat, rnd ? rnd->u_rand : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->first_ray : 0, t.zf, t.rs_scratch, z_new, src);
+  encode_inputs(st, D, R, Nf, rays->origins, rays->directions, z_new, rays->warp_id, t.cfg.num_warp_embeds, t.theta + t.warp_tbl, t.theta + t.mask_tbl, W,
+                t.x + 3 * Mc, t.mask_in + Mc * D.mask_in, t.warp_in + Mc * D.warp_ld, t.hyper_in + Mc * D.hyper_ld);
+  fused_forward(t, st, 1, R, Nf, z_new, rays, ex, W, 1, Mc);
+  mask_post(st, D, R, Nf, t.mask_logit + Mc, rays->gt_mask, ex->mask_ratio, t.warp_in + Mc * D.warp_ld, t.hyper_in + Mc * D.hyper_ld);
+  se3_fwd(st, Mn, t.wv + 6 * Mc, t.x + 3 * Mc, t.xw + 3 * Mc);
+  gather_rows(st, Mf, src, t.xw, t.wamb, t.wv, xw_f, wamb_f, wv_f);
+  // ---------------- fine level: NerfMLP on the sorted union (the coarse NerfMLP's activations are free once its weight gradients ran) ----------------
+  rc.join();
+  if (!rc.ok) return t.fail(NERFDS_ENOTSUP, "%s", rc.unsupported_what.c_str());
+  Run rf{t, st, Mf};
+  fused_forward(t, st, 1, R, S, t.zf, rays, ex, W, 2, 0, xw_f, wamb_f, wv_f);
+  trunk_in(st, D, Mf, xw_f, wamb_f, W, t.trunk_in);
+  alpha_post(st, D, R, S, t.alphav, wv_f, viewdirs, W, t.sigma, t.cond);
+  composite_loss(st, R, S, t.zf, rays->directions, t.sigma, t.rgb_logit, target, t.cfg.use_sample_at_infinity, t.cfg.use_white_background, t.rgb_ray, t.weights,
+                 t.loss_dev + 1, t.d_rgb_logit, t.d_alpha);
+  fused_backward(t, st, 0, 1, Mf, t.d_rgb_logit, 3, t.d_alpha, t.d_trunk_in, D.trunk_in);
+  rf.fork(false); wg_nerf(rf, 1);
+  trunk_in_bwd(st, D, Mf, t.d_trunk_in, xw_f, wamb_f, W, nullptr, nullptr, dxw_f, dwamb_f);
+  scatter_rows(st, Mf, src, Mc, dxw_f, dwamb_f, t.dxw, t.dwamb);
+  // ---------------- the shared networks' backward, once over every position row ----------------
+  rf.M = Ms;
+  fused_backward(t, st, 1, 1, Ms, t.dwamb, 2, nullptr, t.d_hyper_in, D.hyper_ld);
+  rf.fork(false);
+  rf.head_wgrads(t.hyper_out, t.hyper_h16.back(), t.hyper.width, t.dwamb, 2);
+  rf.mlp_wgrads(t.hyper, t.hyper_in, t.hyper_h16, t.hyper_h);
+  se3_bwd(st, Ms, t.wv, t.x, t.dxw, nullptr, t.dwv);
+  fused_backward(t, st, 2, 1, Ms, t.dwv, 6, nullptr, t.d_warp_in, D.warp_ld);
+  rf.fork(false);
+  rf.head_wgrads(t.warp_w, t.warp_h16.back(), t.warp.width, t.dwv, 6);
+  rf.head_wgrads(t.warp_v, t.warp_h16.back(), t.warp.width, t.dwv + 3, 6);
+  rf.mlp_wgrads(t.warp, t.warp_in, t.warp_h16, t.warp_h);
+  shared_in_bwd(st, D, R, Nc, t.d_warp_in, t.d_hyper_in, t.mask_logit, ex->mask_ratio, nullptr, rays->warp_id, t.cfg.num_warp_embeds, t.grad + t.warp_tbl, t.d_mask_logit);
+  shared_in_bwd(st, D, R, Nf, t.d_warp_in + Mc * D.warp_ld, t.d_hyper_in + Mc * D.hyper_ld, t.mask_logit + Mc, ex->mask_ratio, nullptr, rays->warp_id,
+                t.cfg.num_warp_embeds, t.grad + t.warp_tbl, t.d_mask_logit + Mc);
+  fused_backward(t, st, 3, 1, Ms, t.d_mask_logit, 1, nullptr, t.d_mask_in, D.mask_in);
+  mask_in_bwd(st, D, R, Nc, t.d_mask_in, rays->warp_id, t.cfg.num_warp_embeds, t.grad + t.mask_tbl);
+  mask_in_bwd(st, D, R, Nf, t.d_mask_in + Mc * D.mask_in, rays->warp_id, t.cfg.num_warp_embeds, t.grad + t.mask_tbl);
+  rf.fork(true);
+  rf.head_wgrads(t.mask_out, t.mask_h16.back(), t.mask.width, t.d_mask_logit, 1);
+  rf.mlp_wgrads(t.mask, t.mask_in, t.mask_h16, t.mask_h);
+  rf.join();
+  if (!rf.ok) return t.fail(NERFDS_ENOTSUP, "%s", rf.unsupported_what.c_str());
+  return NERFDS_OK;
 }
 
 int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const float* z, const nerfds_rays* rays, const float* target,
@@ -1174,12 +1279,21 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   if (norm_weight != 0.f && (!ensure_tangent_ws(*t) || !ensure_norm_ws(*t))) return t->fail(NERFDS_ENOMEM, "hipMalloc of the norm-loss workspace failed");
   if (want_sg && !ensure_tangent_ws(*t)) return t->fail(NERFDS_ENOMEM, "hipMalloc of the tangent workspace failed");
   t->tn_valid = want_sg;
-  int rc = run_level(*t, st, 0, R, Nc, t->zc, rays, target_rgb, ex, W, t->wc, want_sg, obp, norm_weight);
+  // NERFDS_TRAIN_MERGED=0: the two levels one after the other, each with its own pass over the shared networks (A/B, and every step the merged
+  // flow does not cover: auxiliary losses, tangent passes, one level, the layer-by-layer kernels)
+  static const bool merged_on = !(getenv("NERFDS_TRAIN_MERGED") && std::string(getenv("NERFDS_TRAIN_MERGED")) == "0");
+  int rc;
+  if (merged_on && t->half_step && Nf > 0 && !obp && resample_has_sources(Nc, Nf) && t->g0 && 11 * (int64_t)R * (Nc + Nf) <= (int64_t)t->max_rays * (Nc + Nf) * t->trunk[0].width) {
+    rc = run_merged(*t, st, R, t->zc, rays, target_rgb, ex, W, rnd);
+    if (rc != NERFDS_OK) return rc;
+  } else {
+  rc = run_level(*t, st, 0, R, Nc, t->zc, rays, target_rgb, ex, W, t->wc, want_sg, obp, norm_weight);
   if (rc != NERFDS_OK) return rc;
   if (Nf > 0) {
     resample(st, R, Nc, Nf, t->zc, t->wc, strat, rnd ? rnd->u_rand : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->first_ray : 0, t->zf, t->rs_scratch);
     rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights, want_sg, obp, norm_weight);
     if (rc != NERFDS_OK) return rc;
+  }
   }
   if (t->grad_rep) sum_partials(st, t->grad_rep, GRAD_REPS, t->P, t->grad);      // grad += the replicas of the MFMA kernels
   if (t->half_step) {

@@ -21,7 +21,11 @@ struct Objective {   // weights of the auxiliary losses (0 = off); mirrors nerfd
 };
 
 void coarse_z(hipStream_t, int R, int Nc, float near_, float far_, int stratified, int lindisp, const float* t_rand, uint64_t seed, long long first_ray, float* z);
-void resample(hipStream_t, int R, int Nc, int Nf, const float* zc, const float* wc, int stratified, const float* u_rand, uint64_t seed, long long first_ray, float* zf, float* scratch);
+void resample(hipStream_t, int R, int Nc, int Nf, const float* zc, const float* wc, int stratified, const float* u_rand, uint64_t seed, long long first_ray, float* zf, float* scratch,
+              float* z_new = nullptr, int* src = nullptr);      // z_new / src: the merged step (resample_has_sources sizes only)
+bool resample_has_sources(int Nc, int Nf);
+void gather_rows(hipStream_t, long long M, const int* src, const float* xw, const float* wamb, const float* wv, float* xw_f, float* wamb_f, float* wv_f);
+void scatter_rows(hipStream_t, long long M, const int* src, long long add_below, const float* dxw_f, const float* dwamb_f, float* dxw, float* dwamb);
 void encode_inputs(hipStream_t, const Dims&, int R, int S, const float* o, const float* d, const float* z, const uint32_t* warp_id, int n_embeds,
                    const float* warp_tbl, const float* mask_tbl, const Windows&, float* x, float* mask_in, float* warp_in, float* hyper_in);
 void bias_act(hipStream_t, float* y, const float* b, long long M, int N, int ld, int relu);

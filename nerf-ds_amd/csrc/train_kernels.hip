@@ -116,8 +116,11 @@ __global__ void k_resample(int R, int Nc, int Nf, const float* __restrict__ zc, 
 
 // The same, one wavefront per ray (Nc, Nf <= 256): the running sums stay serial (lane 0: the cdf must round exactly as the
 // sequential cumsum does), the Nf inverse-cdf look-ups and the rank sort of the Nc + Nf depths are spread over the lanes.
+// z_new / src (optional, the merged step): the Nf NEW depths of the ray in draw order, and for every slot of the sorted union the POSITION ROW its
+// sample lives in - coarse sample i of ray r: r * Nc + i; new sample k: R * Nc + r * Nf + k (the shared networks run once per position row)
 __global__ __launch_bounds__(64) void k_resample_wave(int R, int Nc, int Nf, const float* __restrict__ zc, const float* __restrict__ wc, int stratified,
-                                                      const float* __restrict__ u_rand, uint64_t seed, long long first_ray, float* __restrict__ zf) {
+                                                      const float* __restrict__ u_rand, uint64_t seed, long long first_ray, float* __restrict__ zf,
+                                                      float* __restrict__ z_new, int* __restrict__ src) {
   __shared__ float cdf[256], bins[256], zall[512];
   const int r = blockIdx.x, lane = threadIdx.x;
   const float* z = zc + (size_t)r * Nc;
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(64) void k_resample_wave(int R, int Nc, int Nf, con
     const float c0 = fminf(cdf[k0], cdf[nb - 2]), c1 = fmaxf(cdf[k1], cdf[1]);
     float denom = c1 - c0; if (denom < 1e-5f) denom = 1.0f;
     zall[Nc + k] = b0 + (u - c0) / denom * (b1 - b0);
+    if (z_new) z_new[(size_t)r * Nf + k] = zall[Nc + k];
   }
   __syncthreads();
   float* out = zf + (size_t)r * n;
@@ -152,7 +156,30 @@ __global__ __launch_bounds__(64) void k_resample_wave(int R, int Nc, int Nf, con
     int rank = 0;
     for (int q = 0; q < n; ++q) { const float o = zall[q]; rank += (o < v || (o == v && q < i)) ? 1 : 0; }
     out[rank] = v;
+    if (src) src[(size_t)r * n + rank] = i < Nc ? r * Nc + i : R * Nc + r * Nf + (i - Nc);
   }
+}
+
+// merged step: the shared networks' per-sample results in the fine level's (sorted-union) row order, and the way back for their gradients
+__global__ void k_gather_rows(long long M, const int* __restrict__ src, const float* __restrict__ xw, const float* __restrict__ wamb, const float* __restrict__ wv,
+                              float* __restrict__ xw_f, float* __restrict__ wamb_f, float* __restrict__ wv_f) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const long long s = src[i];
+  for (int c = 0; c < 3; ++c) xw_f[3 * i + c] = xw[3 * s + c];
+  for (int c = 0; c < 2; ++c) wamb_f[2 * i + c] = wamb[2 * s + c];
+  for (int c = 0; c < 6; ++c) wv_f[6 * i + c] = wv[6 * s + c];
+}
+// every position row appears exactly once in the union: rows below `add_below` (the coarse positions, which already hold the coarse level's
+// gradient) are added to, the others written
+__global__ void k_scatter_rows(long long M, const int* __restrict__ src, long long add_below, const float* __restrict__ dxw_f, const float* __restrict__ dwamb_f,
+                               float* __restrict__ dxw, float* __restrict__ dwamb) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const long long s = src[i];
+  const bool add = s < add_below;
+  for (int c = 0; c < 3; ++c) dxw[3 * s + c] = (add ? dxw[3 * s + c] : 0.f) + dxw_f[3 * i + c];
+  for (int c = 0; c < 2; ++c) dwamb[2 * s + c] = (add ? dwamb[2 * s + c] : 0.f) + dwamb_f[2 * i + c];
 }
 
 // ---- inputs of the three shared nets (models.py:931-975, 729-732; modules.py:367-434; warping.py:200-237) --------
@@ -889,8 +916,16 @@ static inline dim3 grid1(long long n, int block = 256) { return dim3((unsigned)(
 void coarse_z(hipStream_t st, int R, int Nc, float near_, float far_, int stratified, int lindisp, const float* t_rand, uint64_t seed, long long first_ray, float* z) {
   LAUNCH(k_coarse_z, (long long)R * Nc, st, R, Nc, near_, far_, stratified, lindisp, t_rand, seed, first_ray, z);
 }
-void resample(hipStream_t st, int R, int Nc, int Nf, const float* zc, const float* wc, int stratified, const float* u_rand, uint64_t seed, long long first_ray, float* zf, float* scratch) {
-  if (Nc <= 256 && Nf <= 256) hipLaunchKernelGGL(k_resample_wave, dim3(R), dim3(64), 0, st, R, Nc, Nf, zc, wc, stratified, u_rand, seed, first_ray, zf);
+void gather_rows(hipStream_t st, long long M, const int* src, const float* xw, const float* wamb, const float* wv, float* xw_f, float* wamb_f, float* wv_f) {
+  LAUNCH(k_gather_rows, M, st, M, src, xw, wamb, wv, xw_f, wamb_f, wv_f);
+}
+void scatter_rows(hipStream_t st, long long M, const int* src, long long add_below, const float* dxw_f, const float* dwamb_f, float* dxw, float* dwamb) {
+  LAUNCH(k_scatter_rows, M, st, M, src, add_below, dxw_f, dwamb_f, dxw, dwamb);
+}
+bool resample_has_sources(int Nc, int Nf) { return Nc <= 256 && Nf <= 256; }
+void resample(hipStream_t st, int R, int Nc, int Nf, const float* zc, const float* wc, int stratified, const float* u_rand, uint64_t seed, long long first_ray, float* zf, float* scratch,
+              float* z_new, int* src) {
+  if (Nc <= 256 && Nf <= 256) hipLaunchKernelGGL(k_resample_wave, dim3(R), dim3(64), 0, st, R, Nc, Nf, zc, wc, stratified, u_rand, seed, first_ray, zf, z_new, src);
   else hipLaunchKernelGGL(k_resample, grid1(R, 64), dim3(64), 0, st, R, Nc, Nf, zc, wc, stratified, u_rand, seed, first_ray, zf, scratch);
 }
 void encode_inputs(hipStream_t st, const Dims& D, int R, int S, const float* o, const float* d, const float* z, const uint32_t* warp_id, int n_embeds,
