@@ -51,7 +51,7 @@ PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f32': 157.3, 'f16': 2500.0, 'm
 EXTRA = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
 # where the committed PMC measurement of the headline kernel lives (separate rocprofv3 passes of this command, tools/prof_bench.sh)
 TRAFFIC_FILE = 'profiles/r4_bf16_hbm_traffic.json'
-TRAIN_TRAFFIC_FILE = 'profiles/r3_train_hbm_traffic.json'
+TRAIN_TRAFFIC_FILE = 'profiles/r4_train_hbm_traffic.json'
 
 
 def synth_rays(R, n_ids, seed, device):
@@ -154,7 +154,7 @@ def layer_dims(cfg):
     return L + [(width, h) for h in heads]
   shared = mlp(8, 128, 44, 4, [1]) + mlp(6, 128, 33, 4, [3, 3]) + mlp(6, 64, 45, 4, [2])
   nerf = mlp(8, 256, 52, 4, [256, 4]) + [(256 + 24 + 256 + 24, 128), (128, 3)]
-  return shared + nerf
+  return shared, nerf
 
 
 def run_train(args, device, emit=True):
@@ -178,9 +178,14 @@ def run_train(args, device, emit=True):
     losses.append(tr.step(batch, EXTRA, 1e-3)['loss/total'])
   torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / args.steps
-  S = 3 * 64                                     # field evaluations per ray: 64 coarse + 128 fine
+  # Rows per ray.  NerfMLP: 64 coarse + 128 fine field evaluations.  Level-independent networks (mask / warp / hyper sheet): the reference
+  # evaluates them 64 + 128 times too; since round 4 the plain step runs them - forwards and backwards - once per sample POSITION, 64 + 64
+  # (nerfds_train.cpp run_merged; NERFDS_TRAIN_MERGED=0 restores one pass per level)
+  merged = os.environ.get('NERFDS_TRAIN_MERGED', '1') != '0' and os.environ.get('NERFDS_TRAIN_FUSED_FWD', '1') != '0' and os.environ.get('NERFDS_TRAIN_FUSED_BWD', '1') != '0'
+  S = 3 * 64
   M = R * S
-  dims = layer_dims(cfg)
+  M_shared = R * (2 * 64 if merged else S)
+  dims_shared, dims_nerf = layer_dims(cfg)
   # Traffic model of the step, per sample and dense layer (K inputs, N outputs), bytes:
   #   fused backward (default): forward writes Y as f16 + one ReLU bit per feature (2.125 N, hidden layers); the network's data-gradient
   #     chain writes g = dL/d(pre-activation) once (4 N); the weight gradient reads X (2 K as f16 from a hidden layer, 4 K from a raw
@@ -192,9 +197,10 @@ def run_train(args, device, emit=True):
   g16 = fused_bwd and os.environ.get('NERFDS_TRAIN_G16', '1') != '0'      # the chains hand g to the weight gradients as bf16 (2 N) instead of fp32 (4 N)
   gb = 2 if g16 else 4
   if fused_bwd:
-    hbm_bytes = float(M) * sum((2.125 * N + gb * N if N > 6 else 0) + (gb if N > 6 else 4) * N + (2 * K if K in (64, 128, 256) else 4 * K) for K, N in dims)
+    per_row = lambda dims: sum((2.125 * N + gb * N if N > 6 else 0) + (gb if N > 6 else 4) * N + (2 * K if K in (64, 128, 256) else 4 * K) for K, N in dims)
+    hbm_bytes = float(M) * per_row(dims_nerf) + float(M_shared) * per_row(dims_shared)
   else:
-    hbm_bytes = 4.0 * M * sum((2 if fused_fwd else 3) * K + 4 * N for K, N in dims)
+    hbm_bytes = 4.0 * M * sum((2 if fused_fwd else 3) * K + 4 * N for K, N in dims_shared + dims_nerf)
   traffic, traffic_source = None, None
   tpath = os.path.join(ROOT, TRAIN_TRAFFIC_FILE)
   if os.path.exists(tpath) and R == 4096 and fused_bwd:
@@ -211,7 +217,9 @@ def run_train(args, device, emit=True):
                  'rays_per_step': R, 'parallelism': 'single GPU', 'exchange': 'none (1 GPU)'},
       'roofline': {'bound': 'hbm', 'achieved': hbm_bytes / dt / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': hbm_bytes / dt / 8e12,
                    'traffic': traffic, 'traffic_source': traffic_source,
-                   'kernel': ('whole step (per level: one fused forward launch, four fused data-gradient chains, one weight-gradient launch per layer segment)' if fused_bwd
+                   'kernel': ('whole step, level-independent networks once per sample position (three fused forward launches: coarse, new samples, fine NerfMLP; two NerfMLP '
+                              'data-gradient chains + one chain per shared network over all positions; one weight-gradient launch per layer segment)' if (fused_bwd and merged)
+                              else 'whole step (per level: one fused forward launch, four fused data-gradient chains, one weight-gradient launch per layer segment)' if fused_bwd
                               else 'whole step (one fused forward launch per level + about 100 backward layer kernels; each is HBM-bound)' if fused_fwd
                               else 'whole step (about 150 layer kernels; each is HBM-bound)'),
                    'algorithmic_bytes_per_step': hbm_bytes,

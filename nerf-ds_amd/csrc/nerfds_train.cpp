@@ -89,9 +89,10 @@ struct nerfds_trainer {
   // Side streams of the fused backward: a weight-gradient launch ends with ~50 us of float atomics during which HBM idles (one workgroup
   // per CU, 256 K adds each); the launches of a level are independent of each other, so they alternate over the caller's stream and
   // these two - the tail of one runs under the streaming phase of the next.  Forked / joined with events inside every level.
-  static constexpr int SIDE = 2;
-  hipStream_t side[SIDE] = {nullptr, nullptr};
-  hipEvent_t fork_ev = nullptr, join_ev[SIDE] = {nullptr, nullptr};
+  static constexpr int SIDE = 6;     // at most; nside = the streams in use (NERFDS_TRAIN_SIDE_STREAMS, default 3; 0 = none)
+  int nside = 0;
+  hipStream_t side[SIDE] = {};
+  hipEvent_t fork_ev = nullptr, join_ev[SIDE] = {};
   // Fragment packs of the layers (train_gemm.h): the first step packs each (weight block, orientation, split) when it is first used and
   // records it; from then on ONE kernel at the start of a step packs them all into the arena (150 small launches less per step).
   std::vector<PackEntry> packs;
@@ -283,19 +284,19 @@ struct Run {
   bool wg_main = true;     // the caller's stream takes a turn too (false while it still has chains to launch)
   hipStream_t wgrad_stream() {
     if (wg_turn < 0) return st;
-    const int k = wg_turn++ % (nerfds_trainer::SIDE + (wg_main ? 1 : 0));
+    const int k = wg_turn++ % (t.nside + (wg_main ? 1 : 0));
     return wg_main ? (k == 0 ? st : t.side[k - 1]) : t.side[k];
   }
   void fork(bool with_main = true) {
     if (!t.side[0]) return;
     (void)hipEventRecord(t.fork_ev, st);
-    for (int i = 0; i < nerfds_trainer::SIDE; ++i) (void)hipStreamWaitEvent(t.side[i], t.fork_ev, 0);
+    for (int i = 0; i < t.nside; ++i) (void)hipStreamWaitEvent(t.side[i], t.fork_ev, 0);
     if (wg_turn < 0) wg_turn = 0;
     wg_main = with_main;
   }
   void join() {
     if (wg_turn < 0) return;
-    for (int i = 0; i < nerfds_trainer::SIDE; ++i) { (void)hipEventRecord(t.join_ev[i], t.side[i]); (void)hipStreamWaitEvent(st, t.join_ev[i], 0); }
+    for (int i = 0; i < t.nside; ++i) { (void)hipEventRecord(t.join_ev[i], t.side[i]); (void)hipStreamWaitEvent(st, t.join_ev[i], 0); }
     wg_turn = -1;
   }
   // Weight and bias gradients of an MLP whose data-gradient chain has run (fused backward): g[l] = d loss / d pre-activation of
@@ -1065,9 +1066,12 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
     if (hipMalloc(&t->arena, ARENA_BYTES) != hipSuccess) { g_train_error = "hipMalloc failed (fragment arena)"; return NERFDS_ENOMEM; }
     if (hipMalloc(&t->grad_rep, (size_t)GRAD_REPS * t->P * sizeof(float)) != hipSuccess) { g_train_error = "hipMalloc failed (gradient replicas)"; return NERFDS_ENOMEM; }
     const char* ss = getenv("NERFDS_TRAIN_SIDE_STREAMS");
-    if (t->fused_bwd && !(ss && std::string(ss) == "0")) {
+    int want_side = ss ? atoi(ss) : 3;      // (2 / 3 / 4 / 6 side streams: 13.3 / 13.0 / 13.3 / 13.2 ms per step - the weight gradients are bound by their CU time, not by how many run at once)
+    want_side = want_side < 0 ? 0 : (want_side > nerfds_trainer::SIDE ? nerfds_trainer::SIDE : want_side);
+    if (t->fused_bwd && want_side > 0) {
       bool ok = hipEventCreateWithFlags(&t->fork_ev, hipEventDisableTiming) == hipSuccess;
-      for (int i = 0; i < nerfds_trainer::SIDE && ok; ++i)
+      t->nside = want_side;
+      for (int i = 0; i < t->nside && ok; ++i)
         ok = hipStreamCreateWithFlags(&t->side[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&t->join_ev[i], hipEventDisableTiming) == hipSuccess;
       if (!ok) { g_train_error = "hipStreamCreate failed (weight-gradient side streams)"; return NERFDS_EDEVICE; }
     }
