@@ -446,6 +446,7 @@ struct BwdCursor : TrainCursor {
   float* sink;
   int ld_in, in_h4;     // in_h4 = 4 * (lane >> 5)
   int in_acc;           // add to what is there (the skip layer's contribution came first)
+  float in_scale;       // TrainBwd::g_inv_scale: the chain's values are g_scale * g, the raw-input gradient leaves unscaled
   int live;             // 0: a tail lane that repeats the last row - its read-modify-write of d_in must not touch the row (it goes to the sink)
 };
 // the same cursor while the tiles being computed are the gradient of the raw input (a TYPE, so that dense() selects the epilogue at
@@ -510,11 +511,16 @@ template <bool RELU> DEVI unsigned store_tile_half(uint16_t* row_tile, const f32
   store_tile_pk16(row_tile, pk);
   return bits;
 }
-// The g arrays of the fused backward as bf16 (TRAIN_HALF).
-// The tile's two chunks in split bf16 are what the next (earlier) layer multiplies; their hi parts - bf16(acc[0..7]), bf16(acc[8..15]),
-// round to nearest even - ARE the bf16 copy of g: no second conversion, no packing.
-DEVI void store_tile_bf16(uint16_t* row_tile, const Chunk<P_BF16X3>& c0, const Chunk<P_BF16X3>& c1) {
-  const u32x4 pa = __builtin_bit_cast(u32x4, c0.hi), pb = __builtin_bit_cast(u32x4, c1.hi);
+// The g arrays of the fused backward as f16 (TRAIN_HALF): the masked accumulators - g_scale * g, see TrainBwd - rounded to nearest even, one
+// v_cvt_pk_f16_f32 per pair.  (Through round 3 the stored copy was the hi part of the tile's split-bf16 chunks - free, but bf16: the
+// weight-gradient kernels then had to turn the f16 activations into bf16 hi + lo for every tile and spend two MFMAs per product; with both
+// operands f16 they read them from the DMA'd stage as they are.)  A value beyond 65504 becomes inf and is reported like an overflowing
+// activation (store_tile_half).
+DEVI void store_tile_g16(uint16_t* row_tile, const f32x16& acc) {
+  f16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)acc[i]; b[i] = (_Float16)acc[8 + i]; }
+  const u32x4 pa = __builtin_bit_cast(u32x4, a), pb = __builtin_bit_cast(u32x4, b);
   const unsigned pk[8] = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3]};
   store_tile_pk16(row_tile, pk);
 }
@@ -535,7 +541,7 @@ DEVI void store_tile_in(const BwdCursor& cur, int tile, const f32x16& acc) {
     float* dst = cur.in_row + (32 * tile + 8 * g);
     const bool ok = (n0 < cur.ld_in) & (cur.live != 0);
     dst = ok ? dst : cur.sink;
-    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    f32x4 v = {acc[4 * g] * cur.in_scale, acc[4 * g + 1] * cur.in_scale, acc[4 * g + 2] * cur.in_scale, acc[4 * g + 3] * cur.in_scale};
     if (cur.in_acc) v += *reinterpret_cast<const f32x4*>(dst);
     *reinterpret_cast<f32x4*>(dst) = v;
   }
@@ -926,7 +932,7 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Chunk<PO> (&out)[NT][2 * OT], Ins&.
           for (int i = 0; i < 8; ++i) x[i] = prev[tp][8 * sub + i];
           make_act_chunk<PO, RELU>(out[0][2 * t + sub], x);
         } else if constexpr (BWD) {
-          if (TRAIN_HALF) store_tile_bf16(cur.row16 + 32 * t, out[0][2 * t], out[0][2 * t + 1]);
+          if (TRAIN_HALF) store_tile_g16(cur.row16 + 32 * t, prev[tp]);
           else store_tile<false>(cur.row + 32 * t, prev[tp]);
         } else {
           if (TRAIN_HALF) two |= store_tile_half<RELU>(cur.row16 + 32 * t, prev[tp]) << (16 * tp);
@@ -998,7 +1004,7 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Chunk<PO> (&out)[NT][2 * OT], Ins&.
         if constexpr (PO == P_BF16X3) {
           if (TRAIN_HALF) {
 #pragma unroll
-            for (int tp = 0; tp < TP; ++tp) store_tile_bf16(cur.row16 + 32 * (ot + tp), out[0][2 * (ot + tp)], out[0][2 * (ot + tp) + 1]);
+            for (int tp = 0; tp < TP; ++tp) store_tile_g16(cur.row16 + 32 * (ot + tp), acc[tp][0]);
           }
         }
       } else if constexpr (ASM_EPI) {

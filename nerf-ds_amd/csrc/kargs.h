@@ -105,10 +105,14 @@ struct TrainBwd {
   float* d_in;                  // out: [M][ld_in] gradient of the raw input (zero in the pad columns)
   int ld_in;
   float* sink;                  // >= 64 bytes of scratch: where lanes outside ld_in write
-  // g_half != 0: g[l] is written as bf16 [M][width] (the same pointers, read as uint16_t*) - the weight-gradient kernels read it as a
-  // one-term operand (X hi * g + X lo * g: two MFMAs per product instead of three, half the bytes); the chain itself keeps every g in
-  // fp32 / split bf16 registers, so only the weight and bias gradients see the 8-bit rounding (unbiased, averaged over M samples)
+  // g_half != 0: g[l] is written as f16 [M][width] (the same pointers, read as uint16_t*) - the weight-gradient kernels multiply it with the
+  // forward's f16 activations as stored (one MFMA per product); the chain itself keeps every g in fp32 / split bf16 registers, so only the
+  // weight and bias gradients see the 11-bit rounding (unbiased, averaged over M samples)
   int g_half;
+  // The whole chain runs on g_scale * g (a power of two: exact in fp32 and bf16, applied to the head gradients on their way in) so that the
+  // stored g sits in f16's range (loss scaling); the raw-input gradient is multiplied by g_inv_scale on its way out and the weight-gradient
+  // kernels by the same factor (WgradArgs::out_scale).  1 / 1 for fp32 g.
+  float g_scale, g_inv_scale;
 };
 
 typedef void (*launch_fn)(const KArgs& ka, int num_cus, void* stream);

@@ -128,9 +128,15 @@ struct nerfds_trainer {
   std::vector<uint16_t*> mask_h16, warp_h16, hyper_h16, trunk_h16, mask_bits, warp_bits, hyper_bits, trunk_bits;
   uint16_t *rgb_h16 = nullptr, *rgb_bits = nullptr;
   float* sink = nullptr;
-  // the fused backward's chains leave g_l as bf16 (the weight-gradient kernels' dY operand: half the bytes, two MFMAs per product instead
-  // of three; the chains themselves keep g in registers at full precision).  NERFDS_TRAIN_G16=0: fp32 g arrays.
+  // the fused backward's chains leave g_l as f16, scaled by g_scale (the weight-gradient kernels' dY operand: with the forward's f16
+  // activations one MFMA per product and no conversion pass; the chains themselves keep g in registers at full precision).
+  // NERFDS_TRAIN_G16=0: fp32 g arrays.
   bool g16 = true;
+  // Loss scaling of the stored g: a power of two, 64 x the ray count rounded up to a power of two, so that a head gradient of the mean squared
+  // error - at most 2 / (3 R) per unit of colour error - lands near 2^5 with 2^11 of headroom below f16's largest value for what the layers
+  // amplify and 2^-19 .. 2^-29 of it (f16's normal .. denormal range) still represented; a g beyond the range gives an inf weight gradient
+  // and the step reports NERFDS_ENONFINITE.  NERFDS_TRAIN_G_SCALE_LOG2 overrides the exponent.
+  float g_scale = 1.f;
   bool half_step = false;    // this step's forward wrote f16 + bits (no tangent pass needs the fp32 activations)
   std::string err;
   // workspace views (set by carve())
@@ -275,6 +281,7 @@ struct Run {
     WgradArgs A{X, ldx, K, dy, ldy, N, M, nullptr, rep(dW), static_cast<const char*>(t.wpack) + WPACK_BYTES, 0, 0, t.P, nrep()};
     A.x_half = x_half ? 1 : 0;
     A.dy_half = dy_half ? 1 : 0;
+    A.out_scale = dy_half ? 1.f / t.g_scale : 1.f;
     A.colsum = rep(bias_grad);
     if (!(wgrad_supported(A) && wgrad(wgrad_stream(), A, wgrad_grid(A, t.num_cus)))) unsupported("weight gradient", K, N, M);
   }
@@ -707,6 +714,7 @@ void fused_backward(nerfds_trainer& t, hipStream_t st, int net, int level, int64
   nerfds::TrainBwd tb{};
   tb.M = M; tb.d_head = d_head; tb.ld_head = ld_head; tb.d_head2 = d_head2; tb.d_in = d_in; tb.ld_in = ld_in; tb.sink = t.sink;
   tb.g_half = t.g16 ? 1 : 0;
+  tb.g_scale = t.g16 ? t.g_scale : 1.f; tb.g_inv_scale = 1.f / tb.g_scale;
   const std::vector<uint16_t*>* bits = nullptr;
   const std::vector<float*>* g = nullptr;
   if (net == 0) { tb.wstream = t.bstream[level]; bits = &t.trunk_bits; g = &t.trunk_h; tb.bits[8] = t.rgb_bits; tb.g[8] = t.rgb_hv; }
@@ -1136,11 +1144,16 @@ int nerfds_trainer_target_norm(nerfds_trainer* t, int level, int64_t num_rays, f
 long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* host, long long max_bytes) {
   if (!t || !name || !host || max_bytes <= 0) return NERFDS_EINVAL;
   const std::string n(name);
+  if (n == "g_scale") {                  // the power of two the last step's stored g carries (host value)
+    if (max_bytes < 4) return NERFDS_EINVAL;
+    std::memcpy(host, &t->g_scale, 4);
+    return 4;
+  }
   const void* p = nullptr;
   long long cap = 0;                     // bytes the named view holds for the largest level (rows = max_rays * (Nc + Nf))
   bool half_only = false;                // views only a half step (f16 activations + ReLU bits, fused backward) fills
   const long long M = (long long)t->max_rays * (t->cfg.num_coarse_samples + t->cfg.num_fine_samples);
-  const long long gsz = t->g16 ? 2 : 4;  // the g arrays are bf16 in the default mode, fp32 under NERFDS_TRAIN_G16=0
+  const long long gsz = t->g16 ? 2 : 4;  // the g arrays are (scaled) f16 in the default mode, fp32 under NERFDS_TRAIN_G16=0
   auto layer_of = [&](const std::string& pre, int width, const std::vector<uint16_t*>& h16, const std::vector<uint16_t*>& bits, const std::vector<float*>& g) {
     for (size_t l = 0; l < g.size(); ++l) {
       if (n == pre + "_h16_" + std::to_string(l) && l < h16.size()) { p = h16[l]; cap = M * width * 2; half_only = true; }
@@ -1167,7 +1180,7 @@ long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* h
   if (half_only && !t->half_step)
     return t->fail(NERFDS_EINVAL, "debug_read: %s is written by a half step only (the last step kept fp32 activations: tangent pass or NERFDS_TRAIN_FUSED_*=0)", name);
   if (max_bytes > cap) return t->fail(NERFDS_EINVAL, "debug_read: %s holds %lld bytes (%s elements), %lld asked for", name, cap,
-                                      half_only && n.find("_g") != std::string::npos ? (t->g16 ? "bf16" : "fp32") : "its own", max_bytes);
+                                      half_only && n.find("_g") != std::string::npos ? (t->g16 ? "f16" : "fp32") : "its own", max_bytes);
   (void)hipSetDevice(t->device);
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, p, (size_t)max_bytes, hipMemcpyDeviceToHost) != hipSuccess)
     return t->fail(NERFDS_EDEVICE, "debug_read failed");
@@ -1279,6 +1292,12 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   // the tangent passes (sigma gradient, norm loss) read the fp32 activations: those steps keep the layer-by-layer backward
   t->half_step = t->fused_fwd && t->fused_bwd && !want_sg;
   if (t->half_step) pack_fused_backward(*t, st);
+  {
+    int e = 6;
+    while ((1 << (e - 6)) < R && e < 40) ++e;
+    if (const char* s = getenv("NERFDS_TRAIN_G_SCALE_LOG2")) e = atoi(s);
+    t->g_scale = (t->half_step && t->g16) ? std::ldexp(1.f, e) : 1.f;
+  }
   t->keep_tangents = norm_weight != 0.f;
   if (norm_weight != 0.f && (!ensure_tangent_ws(*t) || !ensure_norm_ws(*t))) return t->fail(NERFDS_ENOMEM, "hipMalloc of the norm-loss workspace failed");
   if (want_sg && !ensure_tangent_ws(*t)) return t->fail(NERFDS_ENOMEM, "hipMalloc of the tangent workspace failed");

@@ -1,5 +1,5 @@
 // Training backward of ONE network on the machinery of the fused field (field.h): see train_backward_kernel below.  Built twice by the
-// Makefile (-DNERFDS_TRAIN_HALF=0 -DNERFDS_TRAIN_PIPE=0: fp32 g; =1 / =1: bf16 g, pipelined tile epilogue).
+// Makefile (-DNERFDS_TRAIN_HALF=0 -DNERFDS_TRAIN_PIPE=0: fp32 g; =1 / =1: scaled f16 g, pipelined tile epilogue).
 #define NERFDS_KERNEL_KIND 2
 #include "field.h"
 #include "launch.h"
@@ -49,6 +49,8 @@ DEVI void bwd_chain(const TrainBwd& tb, Pipe<BG, PL>& pipe, int lane, long long 
   cur.seg = SEG_NERF; cur.pos = 0; cur.bt = 0;
   cur.row = nullptr; cur.row16 = nullptr; cur.bits = nullptr;
   cur.sink = tb.sink; cur.ld_in = tb.ld_in; cur.in_h4 = 4 * h; cur.in_row = nullptr; cur.in_acc = 0; cur.live = live;
+  cur.in_scale = tb.g_inv_scale;
+  const float gs = tb.g_scale;                    // the chain runs on g_scale * g (TrainBwd)
   // every load of the tile up front (one wait): ReLU bits of all layers, head gradients
   unsigned mk[D][MW];
 #pragma unroll
@@ -61,13 +63,13 @@ DEVI void bwd_chain(const TrainBwd& tb, Pipe<BG, PL>& pipe, int lane, long long 
     unsigned mr[RW / 64];
     load_bits<RW>(mr, tb.bits[8], r, h);
     Chunk<P> drgb[1][1], dalpha[1][1], c[1][R16];
-    build_chunks<P, 1>(drgb[0], h, [&](int f) { return f < 3 ? val_feat(tb.d_head[(size_t)r * tb.ld_head + f]) : zero_feat(); });
-    build_chunks<P, 1>(dalpha[0], h, [&](int f) { return f < 4 ? val_feat(tb.d_head2[(size_t)r * 4 + f]) : zero_feat(); });
+    build_chunks<P, 1>(drgb[0], h, [&](int f) { return f < 3 ? val_feat(gs * tb.d_head[(size_t)r * tb.ld_head + f]) : zero_feat(); });
+    build_chunks<P, 1>(dalpha[0], h, [&](int f) { return f < 4 ? val_feat(gs * tb.d_head2[(size_t)r * 4 + f]) : zero_feat(); });
     bwd_hidden<BG, PL, RW / 32>(pipe, cur, mr, tb.g[8], (size_t)r * RW + 4 * h, c, drgb);     // g_rgb = mask(W_rgb d rgb_logit)
     bwd_hidden<BG, PL, W32>(pipe, cur, mk[7], tb.g[7], g_off, a, c, dalpha);                          // g_7 = mask(F^T g_rgb + W_alpha d alpha)
   } else {
     Chunk<P> dh[1][1];
-    build_chunks<P, 1>(dh[0], h, [&](int f) { return f < BG::NHEAD ? val_feat(tb.d_head[(size_t)r * tb.ld_head + f]) : zero_feat(); });
+    build_chunks<P, 1>(dh[0], h, [&](int f) { return f < BG::NHEAD ? val_feat(gs * tb.d_head[(size_t)r * tb.ld_head + f]) : zero_feat(); });
     bwd_hidden<BG, PL, W32>(pipe, cur, mk[D - 1], tb.g[D - 1], g_off, a, dh);                          // g_{D-1} = mask(W_head d head)
   }
   if constexpr (D == 8) {

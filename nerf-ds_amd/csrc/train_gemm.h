@@ -43,11 +43,14 @@ struct WgradArgs {
   // x_half: x points to f16 [M x ldx] (what the fused forward stores for the plain training step; K, ldx multiples of 8, 16-byte
   // aligned rows) - converted exactly into bf16 hi + lo on the way to the MFMAs.
   int x_half;
-  // dy_half: dy points to bf16 [M x ldy] (the g arrays of the fused backward; N a multiple of 32, ldy of 8, 16-byte aligned rows):
-  // a one-term operand, two MFMAs per product
+  // dy_half: dy points to f16 [M x ldy] (the g arrays of the fused backward, scaled - see out_scale; N a multiple of 32, ldy of 8, 16-byte
+  // aligned rows): a one-term operand.  With an f16 X both operands go to the MFMAs as they are (k_wgrad_tr: one MFMA per product); an fp32 X
+  // is split into f16 hi + lo (two MFMAs per product).
   int dy_half;
   // colsum != nullptr: += the column sums of dY (the bias gradient of the layer), a by-product of the tile conversion; replicas as dw.
   float* colsum;
+  // dy_half: what reaches dw / colsum is multiplied by out_scale (0 = 1): the chains write g times a power of two so that it fits f16.
+  float out_scale;
 };
 bool wgrad_supported(const WgradArgs& A);
 // Launches on `grid` workgroups chosen by wgrad_grid(); part must hold grid * K * N floats.  false = shape not covered.

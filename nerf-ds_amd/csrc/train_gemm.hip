@@ -22,6 +22,8 @@
 namespace nerfds_train {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -589,13 +591,13 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
     for (int j = 0; j < 2; ++j) {
       if (c_src[j] >= 0) {
         float f[8];
-        if (DYH && threadIdx.x + 512 * j >= KI) {       // bf16 item of dY: the transposed 8 samples ARE the fragment piece
+        if (DYH && threadIdx.x + 512 * j >= KI) {       // f16 item of dY: the transposed 8 samples ARE the fragment piece
           u32x2 q0, q1;
           const unsigned a0 = (unsigned)(size_t)(stg + c_src[j]), a1 = a0 + 4 * c_stride[j];
           asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(q0), "=&v"(q1) : "v"(a0), "v"(a1) : "memory");
           const u32x4 pk = {q0[0], q0[1], q1[0], q1[1]};
-          auto lo16 = [](unsigned w) { return __builtin_bit_cast(float, w << 16); };
-          auto hi16 = [](unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); };
+          auto lo16 = [](unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); };
+          auto hi16 = [](unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); };
           cs[j] += ((lo16(pk[0]) + hi16(pk[0])) + (lo16(pk[1]) + hi16(pk[1]))) + ((lo16(pk[2]) + hi16(pk[2])) + (lo16(pk[3]) + hi16(pk[3])));
           *reinterpret_cast<u32x4*>(img + c_dst[j]) = pk;
           continue;
@@ -613,15 +615,27 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
           for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const float*>(stg + c_src[j] + i * c_stride[j]);
         }
         if (threadIdx.x + 512 * j >= KI) cs[j] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-        bf16x8 xh, xl;
+        if constexpr (DYH) {                              // f16 dY: X as f16 hi + lo (an f16 X: lo = 0)
+          f16x8 xh, xl;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const __bf16 a = (__bf16)f[i];
-          xh[i] = a;
-          xl[i] = (__bf16)(f[i] - (float)a);
+          for (int i = 0; i < 8; ++i) {
+            const _Float16 a = (_Float16)f[i];
+            xh[i] = a;
+            xl[i] = (_Float16)(f[i] - (float)a);
+          }
+          *reinterpret_cast<u32x4*>(img + c_dst[j]) = __builtin_bit_cast(u32x4, xh);
+          *reinterpret_cast<u32x4*>(img + c_dst[j] + 1024) = __builtin_bit_cast(u32x4, xl);
+        } else {
+          bf16x8 xh, xl;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const __bf16 a = (__bf16)f[i];
+            xh[i] = a;
+            xl[i] = (__bf16)(f[i] - (float)a);
+          }
+          *reinterpret_cast<u32x4*>(img + c_dst[j]) = __builtin_bit_cast(u32x4, xh);
+          *reinterpret_cast<u32x4*>(img + c_dst[j] + 1024) = __builtin_bit_cast(u32x4, xl);
         }
-        *reinterpret_cast<u32x4*>(img + c_dst[j]) = __builtin_bit_cast(u32x4, xh);
-        *reinterpret_cast<u32x4*>(img + c_dst[j] + 1024) = __builtin_bit_cast(u32x4, xl);
       }
     }
   };
@@ -647,6 +661,10 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
     st = st + 1 == S::NS ? 0 : st + 1;
     const char* img = img0 + (it & 1) * S::IMG_BYTES;
     auto frag = [&](int f, int lo) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + f * 2048 + lo * 1024 + lane * 16)); };
+    auto mm = [](const bf16x8& a, const bf16x8& b, const f32x16& c) {     // the images hold f16 bits when dY is f16
+      if constexpr (DYH) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+      else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    };
     if constexpr (ROW) {
       // all TPW tiles of the wave share kt and exist together (NT is a multiple of TPW): one uniform test, then a branch-free body whose
       // fragment reads the scheduler can batch ahead of the MFMAs (a test per tile left every read directly in front of its MFMA)
@@ -661,9 +679,9 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
       if (t0 < TT) {
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
-          if constexpr (!DYH) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
+          if constexpr (!DYH) acc[j] = mm(ah, bl[j], acc[j]);
+          acc[j] = mm(al, bh[j], acc[j]);
+          acc[j] = mm(ah, bh[j], acc[j]);
         }
       }
     } else {
@@ -674,20 +692,21 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
         if (t < TT) {
           const int kt = t / NT, nt = t - kt * NT;
           const bf16x8 ah = frag(kt, 0), al = frag(kt, 1), bh = frag(KT + nt, 0);
-          if constexpr (!DYH) { const bf16x8 bl = frag(KT + nt, 1); acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0); }
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+          if constexpr (!DYH) { const bf16x8 bl = frag(KT + nt, 1); acc[j] = mm(ah, bl, acc[j]); }
+          acc[j] = mm(al, bh, acc[j]);
+          acc[j] = mm(ah, bh, acc[j]);
         }
       }
     }
   }
   wait_vm_lgkm0<0>();
+  const float osc = (DYH && A.out_scale != 0.f) ? A.out_scale : 1.f;       // f16 dY carries the chains' power-of-two scale
   if (A.colsum != nullptr) {           // bias gradient: each dY item adds its 8-sample sums (two items per feature and workgroup)
     float* cdst = A.colsum + (A.nrep > 1 ? (size_t)(blockIdx.x % A.nrep) * A.rep_stride : 0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int idx = threadIdx.x + 512 * j;
-      if (idx >= KI && idx < KI + 2 * N) unsafeAtomicAdd(cdst + (idx - KI) % N, cs[j]);
+      if (idx >= KI && idx < KI + 2 * N) unsafeAtomicAdd(cdst + (idx - KI) % N, cs[j] * osc);
     }
   }
   // this workgroup's partial: lane holds column n = 32 nt + (lane & 31), rows k = 32 kt + (r & 3) + 8 (r >> 2) + 4 h
@@ -703,12 +722,185 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
       for (int r = 0; r < 16; ++r) {
         const int k = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (k < K && n < N) {
-          if (atomic) unsafeAtomicAdd(part + (size_t)k * N + n, acc[j][r]);
-          else part[(size_t)k * N + n] = acc[j][r];
+          if (atomic) unsafeAtomicAdd(part + (size_t)k * N + n, acc[j][r] * osc);
+          else part[(size_t)k * N + n] = acc[j][r] * osc;
         }
       }
     }
   }
+}
+
+// ---- weight gradient of the fused training step: both operands 16-bit, read TRANSPOSED straight from the stage (round 4) ----
+// X is f16 [M x K] (the forward's stored activations), dY is f16 [M x N] (the chains' g, scaled by a power of two - WgradArgs::out_scale
+// undoes it), K and N multiples of 32.  Both MFMA operands of dW = X^T dY want "lane = feature, 8 consecutive samples": exactly what
+// ds_read_b64_tr_b16 delivers from a row-major [sample][feature] block.  So the DMA'd stage IS the operand store: no conversion pass, no
+// fragment images, one v_mfma_f32_32x32x16_f16 per product (k_wgrad: an LDS -> VALU -> LDS transpose + hi / lo split of every tile between two
+// barriers and two bf16 MFMAs per product; its 16-sample tile cost ~2700 cycles of latency against 1024 of MFMA work).
+// Stage = SPS samples x (K + N) f16 = 24 - 32 KiB, NS = 4 stages (2 - 3 in flight per CU), one barrier per stage.  The 16-byte granules of a row
+// are swizzled (granule p of sample s sits at p ^ sw(s)) by the DMA's per-lane source addresses - the LDS side of an LDS-DMA is always
+// 1 KiB contiguous per instruction - so that the 8 rows x 64 B of a transposed read cover every bank group exactly twice.
+// Waves: 8, as a GK x GN grid over the KT x NT output tiles (x SS sample halves when there are fewer than 8 tiles), WK x WN tiles each.
+template <int KT_, int NT_> struct WtShape {
+  static constexpr int KT = KT_, NT = NT_, K = 32 * KT, N = 32 * NT;
+  static constexpr int PRX = K / 8, PRN = N / 8;                     // 16-byte granules per row
+  static constexpr int ROWB = (K + N) * 2;
+  static constexpr int SPS = (32768 / ROWB) / 16 * 16;               // samples per stage
+  static constexpr int XBYTES = SPS * K * 2, STAGE = SPS * ROWB;
+  static constexpr int NS = 4, LDS = NS * STAGE;
+  static constexpr int NI = STAGE / 1024, IPW = NI / 8;
+  static_assert(STAGE % 8192 == 0 && XBYTES % 1024 == 0, "whole DMA instructions per wave and per operand");
+  static constexpr int TT = KT * NT, SS = TT >= 8 ? 1 : 8 / TT;
+  static constexpr int GK = KT >= 4 ? 4 : KT, GN = 8 / SS / GK, WK = KT / GK, WN = NT / GN;
+  static_assert(GK * GN * SS == 8 && WK * GK == KT && WN * GN == NT && WK >= 1 && WN >= 1, "wave grid");
+  static constexpr int SUB = SPS / 16;                                // 16-sample MFMA steps per stage
+  static_assert(SUB % SS == 0, "sample halves");
+  static constexpr int swz(int s, int pr) { return pr >= 16 ? (s & 3) << 2 : ((s >> 1) & 1) << 2; }
+};
+
+template <int KT, int NT>
+__global__ __launch_bounds__(512) void k_wgrad_tr(const WgradArgs A) {
+  typedef WtShape<KT, NT> S;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long tiles = (A.M + S::SPS - 1) / S::SPS;
+  const int grid = gridDim.x;
+  // DMA: instruction c = wave + 8 u fills granules 64 c .. 64 c + 63 of the stage ([SPS][K] of X, then [SPS][N] of dY, rows swizzled)
+  const char* src[S::IPW];
+  long long step[S::IPW];
+  int rowu[S::IPW];
+#pragma unroll
+  for (int u = 0; u < S::IPW; ++u) {
+    int slot = (wave + 8 * u) * 64 + lane;
+    const bool isx = slot < S::SPS * S::PRX;
+    if (!isx) slot -= S::SPS * S::PRX;
+    const int pr = isx ? S::PRX : S::PRN, s = slot / pr, p = (slot - s * pr) ^ S::swz(s, pr);
+    const int ld = isx ? A.ldx : A.ldy;
+    const char* base = reinterpret_cast<const char*>(isx ? A.x : A.dy);
+    src[u] = base + (((size_t)blockIdx.x * S::SPS + s) * ld + 8 * p) * 2;
+    step[u] = (long long)grid * S::SPS * ld * 2;
+    rowu[u] = s;
+  }
+  auto issue = [&](long long tile, int stage) {
+#pragma unroll
+    for (int u = 0; u < S::IPW; ++u) {
+      const bool ok = tile * S::SPS + rowu[u] < A.M;
+      const char* g = ok ? src[u] : reinterpret_cast<const char*>(A.zeros);
+      const int off = __builtin_amdgcn_readfirstlane(stage * S::STAGE + (wave + 8 * u) * 1024);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(g_tile + off), 16, 0, 0);
+      src[u] += step[u];
+    }
+  };
+  // operand addresses: a 16-lane group reads a [4 samples][16 features] block, lane i supplies the 8-byte piece (row i / 4, features 4 (i % 4) ..)
+  // and receives feature i of the block at those 4 samples; lanes 16-31 the tile's second 16 features, lanes 32-63 samples 8 .. 15
+  const int i16 = lane & 15, fh = (lane >> 4) & 1, o8 = 8 * (lane >> 5);
+  const int ws = wave / (S::GK * S::GN), wr = wave - ws * (S::GK * S::GN), wa = wr / S::GN, wb = wr - wa * S::GN;
+  const int piece = (2 * fh + ((i16 & 3) >> 1)) * 16 + (i16 & 1) * 8;
+  const int xk = S::PRX >= 16 ? (i16 >> 2) : (i16 >> 3) & 1, xn = S::PRN >= 16 ? (i16 >> 2) : (i16 >> 3) & 1;
+  const unsigned lds0 = (unsigned)(size_t)g_tile;
+  unsigned adA[S::WK], adB[S::WN];
+#pragma unroll
+  for (int j = 0; j < S::WK; ++j) adA[j] = lds0 + (16 * ws + o8 + (i16 >> 2)) * (S::PRX * 16) + 64 * ((wa * S::WK + j) ^ xk) + piece;
+#pragma unroll
+  for (int j = 0; j < S::WN; ++j) adB[j] = lds0 + S::XBYTES + (16 * ws + o8 + (i16 >> 2)) * (S::PRN * 16) + 64 * ((wb * S::WN + j) ^ xn) + piece;
+  f32x16 acc[S::WK][S::WN];
+#pragma unroll
+  for (int j = 0; j < S::WK; ++j)
+#pragma unroll
+    for (int n = 0; n < S::WN; ++n) acc[j][n] = f32x16{};
+  float cs[S::WN];
+#pragma unroll
+  for (int n = 0; n < S::WN; ++n) cs[n] = 0.f;
+  const bool sums = A.colsum != nullptr && wa == 0;                 // the waves of tile row 0 see every dY fragment of their sample half once
+
+  long long tile = blockIdx.x;
+#pragma unroll
+  for (int s = 0; s < S::NS - 1; ++s) issue(tile + (long long)s * grid, s);
+  int st = 0;
+  for (; tile < tiles; tile += grid) {
+    wait_vm_lgkm0<(S::NS - 2) * S::IPW>();                          // this wave's pieces of the stage have landed ...
+    __builtin_amdgcn_s_barrier();                                    // ... everybody's have, and nobody reads the previous stage any more
+    __builtin_amdgcn_sched_barrier(0);
+    issue(tile + (long long)(S::NS - 1) * grid, st == 0 ? S::NS - 1 : st - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned so = st * S::STAGE;
+    // software pipeline over the stage's 16-sample steps: the reads of step s + 1 are issued before the MFMAs of step s; the wait in front of
+    // a step's MFMAs lets exactly those newer reads stay outstanding (LDS returns in order), and the step's registers pass THROUGH the wait
+    // statement, so nothing of theirs is touched before it
+    constexpr int NSUB = S::SUB / S::SS, NRD = 2 * (S::WK + S::WN);
+    u32x2 qa[2][S::WK][2], qb[2][S::WN][2];
+    auto reads = [&](int sub, int b) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < S::WK; ++j)
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                     : "=&v"(qa[b][j][0]), "=&v"(qa[b][j][1]) : "v"(adA[j] + (so + sub * S::SS * 16 * S::PRX * 16)), "n"(4 * S::PRX * 16) : "memory");
+#pragma unroll
+      for (int n = 0; n < S::WN; ++n)
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                     : "=&v"(qb[b][n][0]), "=&v"(qb[b][n][1]) : "v"(adB[n] + (so + sub * S::SS * 16 * S::PRN * 16)), "n"(4 * S::PRN * 16) : "memory");
+    };
+#define NERFDS_WT_WAIT(CNT)                                                                                                                            \
+    do {                                                                                                                                               \
+      if constexpr (S::WK == 2 && S::WN == 4)                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(qa[b][0][0]), "+v"(qa[b][0][1]), "+v"(qa[b][1][0]), "+v"(qa[b][1][1]), "+v"(qb[b][0][0]), "+v"(qb[b][0][1]), \
+                     "+v"(qb[b][1][0]), "+v"(qb[b][1][1]), "+v"(qb[b][2][0]), "+v"(qb[b][2][1]), "+v"(qb[b][3][0]), "+v"(qb[b][3][1]) : "n"(CNT));  \
+      else if constexpr (S::WK == 2 && S::WN == 2)                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(qa[b][0][0]), "+v"(qa[b][0][1]), "+v"(qa[b][1][0]), "+v"(qa[b][1][1]), "+v"(qb[b][0][0]), "+v"(qb[b][0][1]), \
+                     "+v"(qb[b][1][0]), "+v"(qb[b][1][1]) : "n"(CNT));                                                                               \
+      else if constexpr (S::WK == 1 && S::WN == 2)                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(qa[b][0][0]), "+v"(qa[b][0][1]), "+v"(qb[b][0][0]), "+v"(qb[b][0][1]), "+v"(qb[b][1][0]), "+v"(qb[b][1][1]) : "n"(CNT)); \
+      else {                                                                                                                                           \
+        static_assert((S::WK == 2 || S::WK == 1) && (S::WN == 4 || S::WN == 2 || S::WN == 1), "wave block shapes with a written-out wait");            \
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(qa[b][0][0]), "+v"(qa[b][0][1]), "+v"(qb[b][0][0]), "+v"(qb[b][0][1]) : "n"(CNT));              \
+      }                                                                                                                                                \
+    } while (0)
+    reads(0, 0);
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+      const int b = sub & 1;
+      if (sub + 1 < NSUB) { reads(sub + 1, b ^ 1); NERFDS_WT_WAIT(NRD); }
+      else NERFDS_WT_WAIT(0);
+      f16x8 fa[S::WK], fb[S::WN];
+#pragma unroll
+      for (int j = 0; j < S::WK; ++j) fa[j] = __builtin_bit_cast(f16x8, u32x4{qa[b][j][0][0], qa[b][j][0][1], qa[b][j][1][0], qa[b][j][1][1]});
+#pragma unroll
+      for (int n = 0; n < S::WN; ++n) fb[n] = __builtin_bit_cast(f16x8, u32x4{qb[b][n][0][0], qb[b][n][0][1], qb[b][n][1][0], qb[b][n][1][1]});
+#pragma unroll
+      for (int j = 0; j < S::WK; ++j)
+#pragma unroll
+        for (int n = 0; n < S::WN; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j], fb[n], acc[j][n], 0, 0, 0);
+      if (sums) {
+        const f16x2 one = {(_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+        for (int n = 0; n < S::WN; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cs[n] = __builtin_amdgcn_fdot2(f16x2{fb[n][2 * q], fb[n][2 * q + 1]}, one, cs[n], false);
+      }
+    }
+#undef NERFDS_WT_WAIT
+    __builtin_amdgcn_sched_barrier(0);
+    st = st + 1 == S::NS ? 0 : st + 1;
+  }
+  wait_vm_lgkm0<0>();
+  const float osc = A.out_scale != 0.f ? A.out_scale : 1.f;
+  const size_t rep = A.nrep > 1 ? (size_t)(blockIdx.x % A.nrep) * A.rep_stride : 0;
+  const int m = lane & 31, h = lane >> 5;
+  if (sums) {
+#pragma unroll
+    for (int n = 0; n < S::WN; ++n) unsafeAtomicAdd(A.colsum + rep + 32 * (wb * S::WN + n) + m, cs[n] * osc);
+  }
+  float* part = A.dw != nullptr ? A.dw + rep : A.part + (size_t)blockIdx.x * S::K * S::N;
+  const bool atomic = A.dw != nullptr || S::SS > 1;
+#pragma unroll
+  for (int j = 0; j < S::WK; ++j)
+#pragma unroll
+    for (int n = 0; n < S::WN; ++n) {
+      const int kt = wa * S::WK + j, nn = 32 * (wb * S::WN + n) + m;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (atomic) unsafeAtomicAdd(part + (size_t)k * S::N + nn, acc[j][n][r] * osc);
+        else part[(size_t)k * S::N + nn] = acc[j][n][r] * osc;
+      }
+    }
 }
 
 // ---- backward of a narrow hidden layer in one pass ---------------------------------------------------------------------
@@ -1041,9 +1233,23 @@ template <int TPW, int IPW, bool ROW, bool FULL = false> static void launch_wgra
   if (A.dy_half) launch_wgrad_t<TPW, IPW, ROW, FULL, true>(st, A, grid);
   else launch_wgrad_t<TPW, IPW, ROW, FULL, false>(st, A, grid);
 }
+template <int KT, int NT> static void launch_wgrad_tr(hipStream_t st, const WgradArgs& A, int grid) {
+  typedef WtShape<KT, NT> S;
+  auto kern = k_wgrad_tr<KT, NT>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS); attr = true; }
+  const long long tiles = (A.M + S::SPS - 1) / S::SPS;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < grid ? tiles : grid)), dim3(512), S::LDS, st, A);
+}
 bool wgrad(hipStream_t st, const WgradArgs& A0, int grid) {
   if (!wgrad_supported(A0) || grid < 1) return false;
   WgradArgs A = A0;
+  if (A.x_half && A.dy_half && A.dw != nullptr && !getenv("NERFDS_WGRAD_TR_OFF")) {        // both operands 16-bit: transposed reads straight from the stage
+    const int kt = A.k / 32, nt = A.n / 32;
+#define NERFDS_WT(KT, NT) if (kt == KT && nt == NT) { launch_wgrad_tr<KT, NT>(st, A, grid); return true; }
+    NERFDS_WT(8, 8) NERFDS_WT(8, 4) NERFDS_WT(4, 4) NERFDS_WT(2, 2)
+#undef NERFDS_WT
+  }
   int ninstr;
   wgrad_kinds(A, A.x_scalar, A.dy_scalar, ninstr);
   const int TT = ((A.k + 31) / 32) * ((A.n + 31) / 32);

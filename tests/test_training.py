@@ -432,8 +432,8 @@ def test_fused_backward_chain_against_numpy_on_the_step_buffers(g16, monkeypatch
   chain - g_rgb = 1[h_rgb > 0] (d rgb_logit W_rgb^T) and g_7 = 1[h_7 > 0] (g_rgb F^T + d alpha W_alpha^T), F = the bottleneck folded
   into rgb hidden_0 - and the input gradient d_trunk_in = g_0 W_0^T + g_4 W_4[raw-input rows]^T equal a float64 numpy evaluation of
   the same expressions on the same inputs to split-bf16 accuracy.  g16=False (NERFDS_TRAIN_G16=0): the chains write g as fp32, which pins
-  the chain arithmetic at 1e-4; g16=True (the default): the g arrays are the bf16 copies the weight-gradient kernels read - every element
-  within half a bf16 ulp (2^-9) of the float64 value, while the input gradient (from the registers, never rounded) stays at 1e-4 of its own
+  the chain arithmetic at 1e-4; g16=True (the default): the g arrays are the scaled f16 copies the weight-gradient kernels read - every element
+  within an f16 ulp (2^-10) of the float64 value, while the input gradient (from the registers, never rounded) stays at 1e-4 of its own
   float64 value when that is computed from fp32-grade g (here: from the float64 chain)."""
   from nerfds_amd.training import Trainer
   monkeypatch.setenv('NERFDS_TRAIN_G16', '1' if g16 else '0')
@@ -444,8 +444,10 @@ def test_fused_backward_chain_against_numpy_on_the_step_buffers(g16, monkeypatch
   def read_g(name, shape):
     if not g16:
       return tr.debug_read(name, shape).astype(np.float64)
-    return (tr.debug_read(name, shape, np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64)
-  gtol = 2.0 ** -8 if g16 else 1e-4
+    scale = float(tr.debug_read('g_scale', (1,))[0])     # the chains store g_scale * g as f16 (loss scaling, a power of two)
+    assert scale >= 64.0 and np.log2(scale) == int(np.log2(scale))
+    return tr.debug_read(name, shape, np.float16).astype(np.float64) / scale
+  gtol = 2.0 ** -10 if g16 else 1e-4
   tr.step(batch, EX, 0.0, t_rand=t, mask_ratio=1.0, grads_only=True)
   M = R * Nc
 
@@ -485,8 +487,8 @@ def test_fused_backward_chain_against_numpy_on_the_step_buffers(g16, monkeypatch
   W4 = np.asarray(P['trunk_mlp']['hidden_4']['kernel'], np.float64)
   want_in = g0 @ W0.T + g4 @ W4[256:].T
   got_in = tr.debug_read('d_trunk_in', (M, 52))
-  # (g16: want_in is built from the ROUNDED copies of g_0 / g_4 while the kernel used its registers: 2^-9 per term, averaging down)
-  assert np.abs(got_in - want_in).max() <= (1e-4 if not g16 else 2e-3) * np.abs(want_in).max()
+  # (g16: want_in is built from the ROUNDED copies of g_0 / g_4 while the kernel used its registers: 2^-12 per term, averaging down)
+  assert np.abs(got_in - want_in).max() <= (1e-4 if not g16 else 5e-4) * np.abs(want_in).max()
 
 
 @pytest.mark.gpu

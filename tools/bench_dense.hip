@@ -116,12 +116,12 @@ int main(int argc, char** argv) {
            worst < 3e-5 * big ? "" : "  FAIL");
     (void)hipFree(x); (void)hipFree(dy); (void)hipFree(dw); (void)hipFree(zeros);
   }
-  // ---- weight gradient with 16-bit operands: X as f16 (what the fused forward stores) and / or dY as bf16 (what the fused backward's chains
-  // store: a one-term operand, two MFMAs per product), and the bias gradient = column sums of dY as a by-product.  The reference is the fp64
-  // sum over the ROUNDED inputs, so the bound is the kernel's own arithmetic (split-bf16 products), not the storage format. ----
+  // ---- weight gradient with 16-bit operands: X as f16 (what the fused forward stores) and / or dY as scaled f16 (what the fused backward's chains
+  // store), and the bias gradient = column sums of dY as a by-product.  f16 X: both operands go to the MFMAs as stored (k_wgrad_tr, one MFMA
+  // per product, exact products); fp32 X: f16 hi + lo, two MFMAs.  The reference is the fp64 sum over the ROUNDED inputs, so the bound is the
+  // kernel's own arithmetic, not the storage format. ----
   {
-    auto to_bf16 = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
-    auto from_bf16 = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    const float GS = 64.f;
     struct HS { int k, n, xh; };
     const HS hshapes[] = {{256, 256, 1}, {128, 128, 1}, {64, 64, 1}, {256, 128, 1}, {52, 256, 0}, {36, 128, 0}, {48, 64, 0}};
     for (const HS& w : hshapes) {
@@ -142,13 +142,14 @@ int main(int argc, char** argv) {
           if (w.xh) { const _Float16 h = (_Float16)v; memcpy(&x16[k], &h, 2); v = (float)h; }
           hx[j * w.k + k] = v;
         }
-        for (int n = 0; n < w.n; ++n) { d16[n] = to_bf16(frand()); hd[j * w.n + n] = from_bf16(d16[n]); }
+        // dY as the chains store it: f16 of (g times a power of two); the kernel multiplies its sums by out_scale = 1 / that power
+        for (int n = 0; n < w.n; ++n) { const _Float16 h = (_Float16)(frand() * GS); memcpy(&d16[n], &h, 2); hd[j * w.n + n] = (float)h / GS; }
         if (w.xh) (void)hipMemcpy((char*)x + r * w.k * 2, x16.data(), w.k * 2, hipMemcpyHostToDevice);
         else (void)hipMemcpy((char*)x + r * w.k * 4, hx.data() + j * w.k, w.k * 4, hipMemcpyHostToDevice);
         (void)hipMemcpy((char*)dy + r * w.n * 2, d16.data(), w.n * 2, hipMemcpyHostToDevice);
       }
       WgradArgs A{(const float*)x, w.k, w.k, (const float*)dy, w.n, w.n, M, nullptr, dw, zeros, 0, 0, (long long)w.k * w.n + w.n, NREP};
-      A.x_half = w.xh; A.dy_half = 1; A.colsum = cs;
+      A.x_half = w.xh; A.dy_half = 1; A.colsum = cs; A.out_scale = 1.f / GS;
       if (!wgrad_supported(A)) { printf("wgrad16 %d x %d not supported  FAIL\n", w.k, w.n); ++bad; continue; }
       const int grid = wgrad_grid(A, prop.multiProcessorCount);
       wgrad(nullptr, A, grid);
@@ -177,7 +178,7 @@ int main(int argc, char** argv) {
       float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
       const bool ok = worst < 3e-5 * big && cworst < 1e-5 * (cbig + Mc * 0.01);
       if (!ok) ++bad;
-      printf("wgrad16 M=%lld K=%d (%s) N=%d (bf16): %.3f ms  %.0f GB/s  max|err|=%.2e (max|dW|=%.1f) colsum err %.2e%s\n", M, w.k, w.xh ? "f16" : "f32", w.n, ms,
+      printf("wgrad16 M=%lld K=%d (%s) N=%d (f16): %.3f ms  %.0f GB/s  max|err|=%.2e (max|dW|=%.1f) colsum err %.2e%s\n", M, w.k, w.xh ? "f16" : "f32", w.n, ms,
              (double)M * (w.k * xe + w.n * 2) / ms / 1e6, worst, big, cworst, ok ? "" : "  FAIL");
       (void)hipFree(x); (void)hipFree(dy); (void)hipFree(dw); (void)hipFree(zeros);
     }
