@@ -247,6 +247,9 @@ template <class G> struct StreamUnits<G, std::void_t<decltype(G::BWD_FRAGS)>> {
   static constexpr int shared(Plan) { return 0; }
   static constexpr int nerf(Plan p) { return G::BWD_FRAGS * frag_parts(p.trunk); }
 };
+// waves that share the ring: the render / forward shapes (wg_waves), or what a chain graph of the training backward asks for (graphs.h BwdNet)
+template <class G, class PL, class = void> struct PipeWaves { static constexpr int value = wg_waves<PL>(); };
+template <class G, class PL> struct PipeWaves<G, PL, std::void_t<decltype(G::WG_WAVES)>> { static constexpr int value = G::WG_WAVES; };
 template <class G, class PL> struct Pipe {
   static constexpr int SU = STAGE_UNITS;                          // units per stage
   static constexpr int NS = NUM_STAGES;
@@ -264,7 +267,7 @@ template <class G, class PL> struct Pipe {
   static constexpr int seg_used(int seg) { return (seg == SEG_SHARED ? SHARED_PAD : NERF_PAD) / SU; }       // stages that hold data
   static constexpr int seg_stages(int seg) { return cdiv(seg_used(seg), NS) * NS; }                          // incl. hole stages
   static_assert((!HAS_SHARED || seg_used(SEG_SHARED) >= NS - 1) && seg_used(SEG_NERF) >= NS - 1, "the wrap prefetch needs NS - 1 stages in every segment");
-  static constexpr int WAVES = wg_waves<PL>();
+  static constexpr int WAVES = PipeWaves<G, PL>::value;
   static constexpr int PIECES = SU / WAVES;                       // 1 KiB LDS-DMA pieces per wave per stage
   // LDS -> register prefetch distance in units: a ds_read_b128 takes ~100+ cycles to return under load, a bf16 unit is
   // consumed in 32-64 MFMA cycles, so the reads must run several units ahead of the MFMAs.

@@ -204,6 +204,13 @@ template <class G> constexpr int nerf_units(Plan pl) {
 template <int W_, int DEPTH_, int NHEAD_, bool NERF_ = false, int RGB_W_ = 0> struct BwdNet {
   static constexpr int W = W_, DEPTH = DEPTH_, NHEAD = NHEAD_, SKIP = 4, RGB_W = RGB_W_;
   static constexpr bool IS_NERF = NERF_;
+  // Waves per workgroup of the chain kernel.  The 64 / 128-wide chains need <= 256 registers per wave: EIGHT waves (two per SIMD) share one
+  // weight ring, so the transposed weight set is streamed L2 -> LDS once per 256 rows (through round 3: two 4-wave workgroups per CU, each
+  // with its own ring - the same occupancy, twice the stream per row; the chains run at the rate of that stream).  -DNERFDS_BWD_WAVES8=0: 4.
+#ifndef NERFDS_BWD_WAVES8
+#define NERFDS_BWD_WAVES8 1
+#endif
+  static constexpr int WG_WAVES = (NERFDS_BWD_WAVES8 && W_ <= 128) ? 8 : 4;
   static constexpr int BWD_FRAGS = (NERF_ ? (RGB_W_ / 32) * 1 + (W_ / 32) * (RGB_W_ / 16 + 1) : (W_ / 32) * 1) +
                                    (DEPTH_ - 1) * (W_ / 32) * (W_ / 16) + 2 * 2 * (W_ / 16);
 };

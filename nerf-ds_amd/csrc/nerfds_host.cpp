@@ -404,6 +404,11 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   ka.first_ray = rnd ? rnd->first_ray : 0;
   for (int i = 0; i < 3; ++i) { ka.wstream[i] = ctx->wstream[prec][i].p; ka.bias[i] = static_cast<const float*>(ctx->wbias[i].p); }
   if (ctx->cfg.num_fine_samples == 0) { ka.wstream[2] = ka.wstream[1]; ka.bias[2] = ka.bias[1]; }
+#ifdef NERFDS_EXP_ONE_NERF_STREAM
+  // MEASUREMENT BUILD ONLY (tools/variant.sh, results wrong by construction): the fine level walks the coarse level's weight stream, i.e. the
+  // weight set every XCD's L2 has to hold shrinks from shared + 2 NerfMLPs to shared + 1 - what "L2 overflow" costs the kernel
+  ka.wstream[2] = ka.wstream[1];
+#endif
   ka.warp_embed = static_cast<const float*>(ctx->warp_embed.p);
   ka.mask_embed = static_cast<const float*>(ctx->mask_embed.p);
   ka.ray_fine = out->ray_fine; ka.ray_coarse = out->ray_coarse; ka.smp_fine = out->sample_fine; ka.smp_coarse = out->sample_coarse;

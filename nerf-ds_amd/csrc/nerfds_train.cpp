@@ -309,12 +309,30 @@ struct Run {
   // Weight and bias gradients of an MLP whose data-gradient chain has run (fused backward): g[l] = d loss / d pre-activation of
   // layer l (fp32 [M x width]), h16[l] = its f16 output.  One launch per input segment; the bias gradient rides on the first.
   void mlp_wgrads(const MlpP& m, const float* in0, const std::vector<uint16_t*>& h16, const std::vector<float*>& g) {
+    // the width x width parts of hidden layers 1 .. depth - 1 in ONE launch (WgradArgs::nl): their operands all exist once the chain has run, and
+    // seven 128 x 128 products over 524 288 rows are 0.05 ms each - a launch apiece spends more on filling and draining the machine than on the rows
+    static const bool multi_on = !(getenv("NERFDS_WGRAD_MULTI") && std::string(getenv("NERFDS_WGRAD_MULTI")) == "0");
+    bool batched = false;
+    if (multi_on && t.g16 && m.depth >= 3 && m.depth <= 9) {
+      WgradArgs A{reinterpret_cast<const float*>(h16[0]), m.width, m.width, g[1], m.width, m.width, M, nullptr, rep(t.grad + m.hidden[1].w),
+                  static_cast<const char*>(t.wpack) + WPACK_BYTES, 0, 0, t.P, nrep()};
+      A.x_half = 1; A.dy_half = 1; A.out_scale = 1.f / t.g_scale; A.colsum = rep(t.grad + m.hidden[1].b);
+      A.nl = m.depth - 1;
+      for (int l = 1; l < m.depth; ++l) {
+        A.mx[l - 1] = h16[l - 1]; A.mdy[l - 1] = g[l]; A.mdw[l - 1] = rep(t.grad + m.hidden[l].w); A.mcs[l - 1] = rep(t.grad + m.hidden[l].b);
+      }
+      if (wgrad_supported(A) && wgrad_multi_supported(A)) {
+        if (!wgrad(wgrad_stream(), A, wgrad_grid(A, t.num_cus))) unsupported("weight gradient (layers batched)", m.width, m.width, M);
+        batched = true;
+      }
+    }
     for (int l = 0; l < m.depth; ++l) {
       const LayerP& L = m.hidden[l];
       int k0 = 0;
       bool first = true;
       if (l > 0) {
-        weight_grad(reinterpret_cast<const float*>(h16[l - 1]), m.width, m.width, g[l], m.width, m.width, t.grad + L.w, -1, true, t.grad + L.b, t.g16);
+        if (!batched)
+          weight_grad(reinterpret_cast<const float*>(h16[l - 1]), m.width, m.width, g[l], m.width, m.width, t.grad + L.w, -1, true, t.grad + L.b, t.g16);
         k0 = m.width;
         first = false;
       }

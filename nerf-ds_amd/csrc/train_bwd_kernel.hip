@@ -90,9 +90,9 @@ DEVI void bwd_chain(const TrainBwd& tb, Pipe<BG, PL>& pipe, int lane, long long 
 }
 
 template <class BG, class PL, int TAG>
-__global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train_backward_kernel(const TrainBwd tb) {
+__global__ __launch_bounds__(64 * BG::WG_WAVES) void train_backward_kernel(const TrainBwd tb) {
   using PP = Pipe<BG, PL>;
-  static_assert(wg_waves<PL>() == 4 && !PP::HAS_SHARED, "one 512-register wave per SIMD, one stream");
+  static_assert((PP::WAVES == 4 || PP::WAVES == 8) && !PP::HAS_SHARED, "one 512-register wave or two 256-register waves per SIMD, one stream");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   Pipe<BG, PL> pipe;
@@ -100,9 +100,10 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train
   pipe.lane16 = lane * 16;
   pipe.wave1k = wave * 1024;
   pipe.prologue(SEG_NERF);
-  const long long groups = (tb.M + 127) / 128;
+  constexpr int ROWS = 32 * PP::WAVES;
+  const long long groups = (tb.M + ROWS - 1) / ROWS;
   for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-    const long long rr = grp * 128 + wave * 32 + (lane & 31);
+    const long long rr = grp * ROWS + wave * 32 + (lane & 31);
     bwd_chain<BG, PL>(tb, pipe, lane, rr < tb.M ? rr : tb.M - 1, rr < tb.M ? 1 : 0);     // tail lanes redo the last row: same g values to the same places
   }
 }
@@ -114,12 +115,13 @@ template <class BG> static void launch_bwd(const nerfds::TrainBwd& tb, int num_c
   using PLX = PlanT<P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3>;      // the data-gradient chains: split bf16 throughout
   auto kern = train_backward_kernel<BG, PLX, TRAIN_TAG>;
   allow_dynamic_lds(reinterpret_cast<const void*>(kern), RING_BYTES);
-  const long long groups = (tb.M + 127) / 128;
-  // the 64 / 128-wide chains need <= 256 registers: two workgroups per CU (two waves per SIMD cover each other's waits); the trunk's
-  // takes the whole register file
-  const long long want = (long long)num_cus * (BG::W <= 128 ? 2 : 1);
+  constexpr int WAVES = BG::WG_WAVES, ROWS = 32 * WAVES;
+  const long long groups = (tb.M + ROWS - 1) / ROWS;
+  // two waves per SIMD for the 64 / 128-wide chains (<= 256 registers; they cover each other's waits): one 8-wave workgroup per CU on one
+  // ring, or (NERFDS_BWD_WAVES8=0) two 4-wave workgroups; the trunk's chain takes the whole register file with four waves
+  const long long want = (long long)num_cus * (BG::W <= 128 && WAVES == 4 ? 2 : 1);
   const int grid = (int)(groups < want ? groups : want);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wg_waves<PLX>()), RING_BYTES, static_cast<hipStream_t>(stream), tb);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), RING_BYTES, static_cast<hipStream_t>(stream), tb);
 }
 // net: 0 NerfMLP (trunk + rgb branch + alpha head), 1 hyper sheet, 2 warp field, 3 mask net
 extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream) {

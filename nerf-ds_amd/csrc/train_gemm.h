@@ -51,8 +51,14 @@ struct WgradArgs {
   float* colsum;
   // dy_half: what reaches dw / colsum is multiplied by out_scale (0 = 1): the chains write g times a power of two so that it fits f16.
   float out_scale;
+  // nl > 1 (x_half and dy_half only): ONE launch computes nl weight gradients of the same shape and row count - the hidden layers of one MLP,
+  // whose chain leaves all their g at once: workgroup b works on layer b % nl, as workgroup b / nl of gridDim / nl.  Layer i: X = mx[i],
+  // dY = mdy[i] (ldx / ldy as above), destination mdw[i] / mcs[i] (replicas as above); x, dy, dw, colsum must equal entry 0.
+  int nl;
+  const void* mx[8]; const void* mdy[8]; float* mdw[8]; float* mcs[8];
 };
 bool wgrad_supported(const WgradArgs& A);
+bool wgrad_multi_supported(const WgradArgs& A);     // nl layers in one launch (same shape, 16-bit operands)
 // Launches on `grid` workgroups chosen by wgrad_grid(); part must hold grid * K * N floats.  false = shape not covered.
 int wgrad_grid(const WgradArgs& A, int num_cus);
 bool wgrad(hipStream_t st, const WgradArgs& A, int grid);

@@ -762,7 +762,12 @@ __global__ __launch_bounds__(512) void k_wgrad_tr(const WgradArgs A) {
   typedef WtShape<KT, NT> S;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long tiles = (A.M + S::SPS - 1) / S::SPS;
-  const int grid = gridDim.x;
+  // several layers in one launch (WgradArgs::nl): this workgroup is number `wg` of `grid` on layer `layer`
+  const int nl = A.nl > 1 ? A.nl : 1, layer = blockIdx.x % nl, wg = blockIdx.x / nl, grid = gridDim.x / nl;
+  const char* const xbase = reinterpret_cast<const char*>(A.nl > 1 ? A.mx[layer] : A.x);
+  const char* const ybase = reinterpret_cast<const char*>(A.nl > 1 ? A.mdy[layer] : A.dy);
+  float* const dwbase = A.nl > 1 ? A.mdw[layer] : A.dw;
+  float* const csbase = A.nl > 1 ? A.mcs[layer] : A.colsum;
   // DMA: instruction c = wave + 8 u fills granules 64 c .. 64 c + 63 of the stage ([SPS][K] of X, then [SPS][N] of dY, rows swizzled)
   const char* src[S::IPW];
   long long step[S::IPW];
@@ -774,8 +779,8 @@ __global__ __launch_bounds__(512) void k_wgrad_tr(const WgradArgs A) {
     if (!isx) slot -= S::SPS * S::PRX;
     const int pr = isx ? S::PRX : S::PRN, s = slot / pr, p = (slot - s * pr) ^ S::swz(s, pr);
     const int ld = isx ? A.ldx : A.ldy;
-    const char* base = reinterpret_cast<const char*>(isx ? A.x : A.dy);
-    src[u] = base + (((size_t)blockIdx.x * S::SPS + s) * ld + 8 * p) * 2;
+    const char* base = isx ? xbase : ybase;
+    src[u] = base + (((size_t)wg * S::SPS + s) * ld + 8 * p) * 2;
     step[u] = (long long)grid * S::SPS * ld * 2;
     rowu[u] = s;
   }
@@ -809,9 +814,9 @@ __global__ __launch_bounds__(512) void k_wgrad_tr(const WgradArgs A) {
   float cs[S::WN];
 #pragma unroll
   for (int n = 0; n < S::WN; ++n) cs[n] = 0.f;
-  const bool sums = A.colsum != nullptr && wa == 0;                 // the waves of tile row 0 see every dY fragment of their sample half once
+  const bool sums = csbase != nullptr && wa == 0;                   // the waves of tile row 0 see every dY fragment of their sample half once
 
-  long long tile = blockIdx.x;
+  long long tile = wg;
 #pragma unroll
   for (int s = 0; s < S::NS - 1; ++s) issue(tile + (long long)s * grid, s);
   int st = 0;
@@ -881,14 +886,14 @@ __global__ __launch_bounds__(512) void k_wgrad_tr(const WgradArgs A) {
   }
   wait_vm_lgkm0<0>();
   const float osc = A.out_scale != 0.f ? A.out_scale : 1.f;
-  const size_t rep = A.nrep > 1 ? (size_t)(blockIdx.x % A.nrep) * A.rep_stride : 0;
+  const size_t rep = A.nrep > 1 ? (size_t)(wg % A.nrep) * A.rep_stride : 0;
   const int m = lane & 31, h = lane >> 5;
   if (sums) {
 #pragma unroll
-    for (int n = 0; n < S::WN; ++n) unsafeAtomicAdd(A.colsum + rep + 32 * (wb * S::WN + n) + m, cs[n] * osc);
+    for (int n = 0; n < S::WN; ++n) unsafeAtomicAdd(csbase + rep + 32 * (wb * S::WN + n) + m, cs[n] * osc);
   }
-  float* part = A.dw != nullptr ? A.dw + rep : A.part + (size_t)blockIdx.x * S::K * S::N;
-  const bool atomic = A.dw != nullptr || S::SS > 1;
+  float* part = dwbase + rep;                                        // (the launcher requires dw: every workgroup adds with float atomics)
+  const bool atomic = true;
 #pragma unroll
   for (int j = 0; j < S::WK; ++j)
 #pragma unroll
@@ -1208,6 +1213,15 @@ static void wgrad_kinds(const WgradArgs& A, int& xs, int& ys, int& ninstr) {
   ys = (!A.dy_half && (A.n % 4 || A.ldy % 4 || !aligned16(A.dy))) ? 1 : 0;
   ninstr = (xs ? (16 * A.k + 63) / 64 : ((A.x_half ? 2 : 4) * A.k + 63) / 64) + (ys ? (16 * A.n + 63) / 64 : ((A.dy_half ? 2 : 4) * A.n + 63) / 64);
 }
+// the shapes k_wgrad_tr is built for; several layers per launch exist on that kernel only
+bool wgrad_multi_supported(const WgradArgs& A) {
+  if (!(A.x_half && A.dy_half && A.dw != nullptr) || A.nl > 8 || getenv("NERFDS_WGRAD_TR_OFF")) return false;
+  const int kt = A.k / 32, nt = A.n / 32;
+  if (!((kt == 8 && nt == 8) || (kt == 8 && nt == 4) || (kt == 4 && nt == 4) || (kt == 2 && nt == 2))) return false;
+  for (int i = 0; i < A.nl; ++i)
+    if (!aligned16(A.mx[i]) || !aligned16(A.mdy[i]) || A.mdw[i] == nullptr) return false;
+  return A.nl < 2 || (A.mx[0] == A.x && A.mdy[0] == A.dy && A.mdw[0] == A.dw && A.mcs[0] == A.colsum);
+}
 bool wgrad_supported(const WgradArgs& A) {
   if (A.k < 1 || A.n < 1 || A.k > 256 || A.n > 256 || A.M <= 0 || A.zeros == nullptr) return false;
   if (A.x_half && (A.k % 32 || A.ldx % 8 || !aligned16(A.x))) return false;       // f16 rows: whole 16-byte pieces, whole waves of items
@@ -1239,11 +1253,16 @@ template <int KT, int NT> static void launch_wgrad_tr(hipStream_t st, const Wgra
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS); attr = true; }
   const long long tiles = (A.M + S::SPS - 1) / S::SPS;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < grid ? tiles : grid)), dim3(512), S::LDS, st, A);
+  const int nl = A.nl > 1 ? A.nl : 1;
+  long long per = grid / nl;                                          // workgroups per layer
+  if (per < 1) per = 1;
+  if (per > tiles) per = tiles;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(per * nl)), dim3(512), S::LDS, st, A);
 }
 bool wgrad(hipStream_t st, const WgradArgs& A0, int grid) {
   if (!wgrad_supported(A0) || grid < 1) return false;
   WgradArgs A = A0;
+  if (A.nl > 1 && !wgrad_multi_supported(A)) return false;
   if (A.x_half && A.dy_half && A.dw != nullptr && !getenv("NERFDS_WGRAD_TR_OFF")) {        // both operands 16-bit: transposed reads straight from the stage
     const int kt = A.k / 32, nt = A.n / 32;
 #define NERFDS_WT(KT, NT) if (kt == KT && nt == NT) { launch_wgrad_tr<KT, NT>(st, A, grid); return true; }
