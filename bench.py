@@ -194,7 +194,7 @@ def run_train(args, device, emit=True):
   #     dY + Y + dX (8 N + 4 K); + X (4 K) in the forward when that is not fused either.
   fused_fwd = os.environ.get('NERFDS_TRAIN_FUSED_FWD', '1') != '0'
   fused_bwd = fused_fwd and os.environ.get('NERFDS_TRAIN_FUSED_BWD', '1') != '0'
-  g16 = fused_bwd and os.environ.get('NERFDS_TRAIN_G16', '1') != '0'      # the chains hand g to the weight gradients as bf16 (2 N) instead of fp32 (4 N)
+  g16 = fused_bwd and os.environ.get('NERFDS_TRAIN_G16', '1') != '0'      # the chains hand g to the weight gradients as loss-scaled f16 (2 N) instead of fp32 (4 N)
   gb = 2 if g16 else 4
   if fused_bwd:
     per_row = lambda dims: sum((2.125 * N + gb * N if N > 6 else 0) + (gb if N > 6 else 4) * N + (2 * K if K in (64, 128, 256) else 4 * K) for K, N in dims)
@@ -210,7 +210,7 @@ def run_train(args, device, emit=True):
   result = {
       'metric': 'training rays/sec (batch 4096, MSE of both levels + backward + Adam, full warp+NerfMLP)',
       'value': R / dt, 'unit': 'rays/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt * 1e3,
-      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16x2 (split bf16 operands, fp32 accumulate; activations stored as f16 + ReLU bits; the weight-gradient operand g as bf16; data gradients and sums fp32)',
+      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16x2 (forward and data-gradient chains: split bf16 operands, fp32 accumulate; activations stored as f16 + ReLU bits, the weight-gradient operand g as loss-scaled f16: weight gradients one f16 MFMA per product; data gradients and sums fp32)',
       'data': 'synthetic',
       'config': {'workload': f"BASELINE configs[3]: training step, {R} random rays of 64 synthetic frames, 64 coarse + 64 fine samples, nerf_ds graph, "
                              'loss = MSE(fine) + MSE(coarse), backward through every network, Adam; sampling jitter drawn on chip',
@@ -218,19 +218,19 @@ def run_train(args, device, emit=True):
       'roofline': {'bound': 'hbm', 'achieved': hbm_bytes / dt / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': hbm_bytes / dt / 8e12,
                    'traffic': traffic, 'traffic_source': traffic_source,
                    'kernel': ('whole step, level-independent networks once per sample position (three fused forward launches: coarse, new samples, fine NerfMLP; two NerfMLP '
-                              'data-gradient chains + one chain per shared network over all positions; one weight-gradient launch per layer segment)' if (fused_bwd and merged)
+                              'data-gradient chains + one chain per shared network over all positions; the hidden-layer weight gradients of an MLP in one launch)' if (fused_bwd and merged)
                               else 'whole step (per level: one fused forward launch, four fused data-gradient chains, one weight-gradient launch per layer segment)' if fused_bwd
                               else 'whole step (one fused forward launch per level + about 100 backward layer kernels; each is HBM-bound)' if fused_fwd
                               else 'whole step (about 150 layer kernels; each is HBM-bound)'),
                    'algorithmic_bytes_per_step': hbm_bytes,
-                   'traffic_model': (f"forward f16 Y + ReLU bits; chains write g once ({'bf16' if g16 else 'fp32'}); weight gradient reads X (f16) + g" if fused_bwd else
+                   'traffic_model': (f"forward f16 Y + ReLU bits; chains write g once ({'f16' if g16 else 'fp32'}); weight gradient reads X (f16) + g" if fused_bwd else
                                      'fp32 activations: forward ' + ('Y (fused: X stays on chip)' if fused_fwd else 'X + Y') + ', weight gradient X + dY, data gradient dY + Y + dX'),
                    'algorithmic_tflops': flop / dt / 1e12, 'mfma_frac_of_2500': flop / dt / 2.5e15,
                    # the matrix-pipe floor of the step: forward + data gradient + weight gradient (3 x the forward's FLOPs), three bf16 MFMAs
                    # per product at the split-bf16 arithmetic the gradient tests need, at the 2.5 PFLOP/s dense peak
-                   # (bf16 g: the weight gradient is two MFMAs per product, X hi * g + X lo * g: 3 + 3 + 2 of 9)
-                   'mfma_floor_ms': (8 / 9 if g16 else 1) * 3 * flop / 2.5e15 * 1e3,
-                   'ms_over_mfma_floor': dt * 1e3 / ((8 / 9 if g16 else 1) * 3 * flop / 2.5e15 * 1e3)},
+                   # (f16 g: the weight gradient is ONE f16 MFMA per product on the stored operands: 3 + 3 + 1 of 9; round 3 / early round 4: bf16 g, two)
+                   'mfma_floor_ms': (7 / 9 if g16 else 1) * 3 * flop / 2.5e15 * 1e3,
+                   'ms_over_mfma_floor': dt * 1e3 / ((7 / 9 if g16 else 1) * 3 * flop / 2.5e15 * 1e3)},
       'loss_first': losses[0], 'loss_last': losses[-1],
   }
   if not args.no_cpu_baseline:

@@ -211,7 +211,14 @@ template <int PM, int PW, int PH, int PT, int PR> struct PlanT {
   static constexpr bool EIGHT_WAVES = is_single(PT) && NT == 1;
 };
 // STAGE_BYTES (graphs.h): one ring stage = 16 units
-constexpr int NUM_STAGES = 4;          // ring depth
+// Ring depth: 4 stages.  The training backward's chain kernels own the whole LDS and could go deeper (-DNERFDS_BWD_STAGES=8 builds it; the
+// counted wait of boundary() is written for 4 .. 8 stages): measured SLOWER, 11.85 - 11.95 against 11.63 - 11.66 ms per training step
+// (profiles/r4_ab/ab_bwd_ring_depth.txt: the 128-wide chains spill 33 - 41 registers with the longer unrolled walk, and a segment padded to a
+// multiple of 8 stages has more barrier-only hole stages) - the chains are not waiting for the ring.
+#ifndef NERFDS_BWD_STAGES
+#define NERFDS_BWD_STAGES 4
+#endif
+constexpr int NUM_STAGES = NERFDS_KERNEL_KIND == 2 ? NERFDS_BWD_STAGES : 4;
 enum { SEG_SHARED = 0, SEG_NERF = 1 };  // the two weight streams (Pipe)
 constexpr int RING_BYTES = NUM_STAGES * STAGE_BYTES;
 // Work shape.  NT = N-tiles (32 samples) per wave and evaluation; SPLIT = waves that share one ray's batch of
@@ -331,15 +338,25 @@ template <class G, class PL> struct Pipe {
     // s_waitcnt of its operand read - BELOW the asm and the barrier; another wave's DMA into that slot would then race the read.
     // (Waiting on vmcnt only was 1.5 % faster and ran clean on the uniform kernels, but the mixed-precision kernel showed
     // run-to-run differences with it: kept safe.)
-    static_assert(NS == 4, "protocol is written for a 4-stage ring");
-    static_assert(PIECES == 4 || PIECES == 2, "vmcnt(PIECES) below");
-    const int tprev = s + NS - 2;              // the stage issued since the previous boundary (s == 0: by the previous segment's last stage)
-    const bool prev_issued = tprev >= seg_stages(seg) || tprev < seg_used(seg);
+    // With a ring of NS stages the stages s + 2 .. s + NS - 2 may be in flight (NS = 4: the one stage issued since the previous boundary); those of
+    // them that are holes issued nothing and do not count.
+    static_assert(NS >= 4 && NS <= 8 && (PIECES == 4 || PIECES == 2), "counted wait: at most 5 stages of PIECES loads in flight");
+    int young = 0;
+#pragma unroll
+    for (int t = s + 2; t <= s + NS - 2; ++t)
+      if (t >= seg_stages(seg) || t < seg_used(seg)) young += PIECES;
     // (A counted lgkmcnt in the pinned chains - the 8 youngest ring reads left in flight, safe there because program order is source order -
     // measured +-0 against the full drain: 38.25 against 38.26 ms per 65 536 rays, profiles/r4_ab/ab_x3_pin_variants.txt; not kept.)
-    if (prev_issued && PIECES == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else if (prev_issued) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (young == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (young == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if (young == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if (young == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if (young == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (young == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+    else if (young == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else if (young == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    else if (young == 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+    else __builtin_trap();                       // (a count this list does not spell out)
     __builtin_amdgcn_s_barrier();      // raw barrier (no compiler-added fences)
     // SPREAD_DMA: the pieces of stage s + NS - 1 are issued one by one between the MFMAs of stage s (spread_piece) instead of
     // back to back behind the barrier, where nothing covers their issue time (a hole stage has no MFMAs: issued here)

@@ -595,59 +595,101 @@ __global__ void k_se3_jvp_bwd(long long M, const float* __restrict__ wv, const f
   for (int i = 0; i < 6; ++i) dwv_extra[6 * m + i] = extra[i];
 }
 
-// ---- compositing (model_utils.py:95-159), MSE loss (training.py:265-274) and the backward of both; one thread per ray ----
-__global__ void k_composite_loss(int R, int S, const float* __restrict__ z, const float* __restrict__ dirs, const float* __restrict__ sigma,
+// ---- compositing (model_utils.py:95-159), MSE loss (training.py:265-274) and the backward of both; one WAVE per ray ----
+// Lanes = samples (64 at a time): the transmittance is a wave-level exclusive product scan with a carry between chunks, the backward's
+// sum over the later samples a reverse exclusive sum scan.  (Through round 4's first half: one THREAD per ray walking its S samples - 16
+// workgroups for 4096 rays, every load strided by S, 76 + 149 us per step for 10 MB of data.)
+__device__ __forceinline__ float wave_scan_prod(float x, int lane) {      // inclusive, lanes 0 .. 63
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const float v = __shfl_up(x, d, 64); if (lane >= d) x *= v; }
+  return x;
+}
+__device__ __forceinline__ float wave_rscan_sum(float x, int lane) {      // inclusive from the top: lane l = sum of lanes l .. 63
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const float v = __shfl_down(x, d, 64); if (lane + d < 64) x += v; }
+  return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+  return x;
+}
+__global__ __launch_bounds__(256) void k_composite_loss(int R, int S, const float* __restrict__ z, const float* __restrict__ dirs, const float* __restrict__ sigma,
                                  const float* __restrict__ rgb_logit, const float* __restrict__ target, int at_infinity, int white,
                                  float* __restrict__ rgb_ray, float* __restrict__ weights, float* __restrict__ loss,
                                  float* __restrict__ d_rgb_logit, float* __restrict__ d_alpha) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= R) return;                                     // whole waves
   const float* zr = z + (size_t)r * S;
   const float dn = sqrtf(dirs[3 * r] * dirs[3 * r] + dirs[3 * r + 1] * dirs[3 * r + 1] + dirs[3 * r + 2] * dirs[3 * r + 2]);
   const float last = at_infinity ? 1e10f : 1e-19f;
-  float T = 1.0f, acc[3] = {0.f, 0.f, 0.f}, wsum = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const size_t m = (size_t)r * S + s;
-    const float dist = ((s == S - 1) ? last : (zr[s + 1] - zr[s])) * dn;
-    const float a = 1.0f - expf(-sigma[m] * dist);
-    const float w = a * T;
-    weights[m] = w;
-    wsum += w;
-    for (int c = 0; c < 3; ++c) acc[c] += w / (1.0f + expf(-rgb_logit[3 * m + c]));
-    T *= (1.0f - a) + 1e-10f;
+  float carryT = 1.0f, acc[3] = {0.f, 0.f, 0.f}, wsum = 0.f;
+  for (int c0 = 0; c0 < S; c0 += 64) {
+    const int s = c0 + lane;
+    const bool valid = s < S;
+    const size_t m = (size_t)r * S + (valid ? s : S - 1);
+    const float dist = ((s >= S - 1) ? last : (zr[s + 1] - zr[s])) * dn;
+    const float a = valid ? 1.0f - expf(-sigma[m] * dist) : 0.f;
+    const float om = valid ? (1.0f - a) + 1e-10f : 1.0f;
+    const float incl = wave_scan_prod(om, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.0f;
+    const float w = a * (carryT * excl);
+    carryT *= __shfl(incl, 63, 64);
+    if (valid) {
+      weights[m] = w;
+      wsum += w;
+      for (int c = 0; c < 3; ++c) acc[c] += w / (1.0f + expf(-rgb_logit[3 * m + c]));
+    }
   }
+  wsum = wave_sum(wsum);
   float g[3], gsum = 0.f, l = 0.f;
   for (int c = 0; c < 3; ++c) {
+    acc[c] = wave_sum(acc[c]);
     if (white) acc[c] += 1.0f - wsum;
-    rgb_ray[3 * r + c] = acc[c];
     const float e = acc[c] - target[3 * r + c];
     l += e * e;
     g[c] = 2.0f * e / (3.0f * (float)R);
     gsum += g[c];
   }
-  atomicAdd(loss, l / (3.0f * (float)R));
+  if (lane == 0) {
+    for (int c = 0; c < 3; ++c) rgb_ray[3 * r + c] = acc[c];
+    atomicAdd(loss, l / (3.0f * (float)R));
+  }
   // backward: w_i = a_i T_i, T_i = prod_{j<i} (1 - a_j + eps);  dL/da_i = G_i T_i - (sum_{k>i} G_k w_k) / (1 - a_i + eps)
-  float suffix = 0.f;
-  for (int s = S - 1; s >= 0; --s) {
-    const size_t m = (size_t)r * S + s;
-    const float dist = ((s == S - 1) ? last : (zr[s + 1] - zr[s])) * dn;
+  float carryS = 0.f;
+  for (int c0 = ((S - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
+    const int s = c0 + lane;
+    const bool valid = s < S;
+    const size_t m = (size_t)r * S + (valid ? s : S - 1);
+    const float dist = ((s >= S - 1) ? last : (zr[s + 1] - zr[s])) * dn;
     const float sg = sigma[m];
     const float ex = expf(-sg * dist);
     const float a = 1.0f - ex;
-    const float w = weights[m];
+    const float w = valid ? weights[m] : 0.f;
     const float om = (1.0f - a) + 1e-10f;
     const float Ti = (a > 0.f) ? w / a : 0.f;     // T_i (only its product with d a / d sigma matters; a == 0 only if sigma == 0)
     float G = white ? -gsum : 0.f;
+    float dl[3];
     for (int c = 0; c < 3; ++c) {
       const float col = 1.0f / (1.0f + expf(-rgb_logit[3 * m + c]));
       G += g[c] * col;
-      d_rgb_logit[3 * m + c] = g[c] * w * col * (1.0f - col);
+      dl[c] = g[c] * w * col * (1.0f - col);
     }
-    const float dLda = G * Ti - suffix / om;
-    const float dads = dist * ex;                                   // d a / d sigma
-    d_alpha[4 * m] = dLda * dads * (1.0f - expf(-sg));              // d sigma / d sigma_raw = sigmoid(sigma_raw) = 1 - exp(-sigma)
-    d_alpha[4 * m + 1] = 0.f; d_alpha[4 * m + 2] = 0.f; d_alpha[4 * m + 3] = 0.f;      // normal channels: stop_gradient
-    suffix += G * w;
+    const float Gw = valid ? G * w : 0.f;
+    const float incl = wave_rscan_sum(Gw, lane);
+    float excl = __shfl_down(incl, 1, 64);
+    if (lane == 63) excl = 0.f;
+    const float suffix = carryS + excl;
+    carryS += __shfl(incl, 0, 64);
+    if (valid) {
+      for (int c = 0; c < 3; ++c) d_rgb_logit[3 * m + c] = dl[c];
+      const float dLda = G * Ti - suffix / om;
+      const float dads = dist * ex;                                   // d a / d sigma
+      // d sigma / d sigma_raw = sigmoid(sigma_raw) = 1 - exp(-sigma); normal channels: stop_gradient
+      *reinterpret_cast<float4*>(d_alpha + 4 * m) = make_float4(dLda * dads * (1.0f - expf(-sg)), 0.f, 0.f, 0.f);
+    }
   }
 }
 
@@ -973,7 +1015,7 @@ void alpha_post(hipStream_t st, const Dims& D, int R, int S, const float* alpha,
 }
 void composite_loss(hipStream_t st, int R, int S, const float* z, const float* dirs, const float* sigma, const float* rgb_logit, const float* target,
                     int at_infinity, int white, float* rgb_ray, float* weights, float* loss, float* d_rgb_logit, float* d_alpha) {
-  hipLaunchKernelGGL(k_composite_loss, grid1(R, 64), dim3(64), 0, st, R, S, z, dirs, sigma, rgb_logit, target, at_infinity, white, rgb_ray, weights,
+  hipLaunchKernelGGL(k_composite_loss, dim3((R + 3) / 4), dim3(256), 0, st, R, S, z, dirs, sigma, rgb_logit, target, at_infinity, white, rgb_ray, weights,
                      loss, d_rgb_logit, d_alpha);
 }
 void relu_bwd(hipStream_t st, float* dy, const float* y, long long n) { LAUNCH(k_relu_bwd, n, st, dy, y, n); }
@@ -1089,33 +1131,54 @@ __global__ void k_fold_rgb(const float* __restrict__ B, const float* __restrict_
   for (int k = 0; k < TW; ++k) acc += (double)left[k] * (double)K[(size_t)k * W + c];
   fold[i] = (float)acc;
 }
-// fused backward: see train_kernels.h bott_grads.  One thread per output element, double accumulation like k_fold_rgb (3 x 65 k dot
-// products of length <= 256: a few microseconds).
-__global__ void k_bott_grads(int TW, int W, const float* __restrict__ Wb, const float* __restrict__ bb, const float* __restrict__ K,
-                             const float* __restrict__ S, const float* __restrict__ c, float* __restrict__ dKb, float* __restrict__ dWb,
-                             float* __restrict__ dbb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int nK = TW * W, nW = TW * TW;
-  if (i < nK) {                                   // dKb[k][n] = sum_r Wb[r][k] S[r][n] + bb[k] c[n]
-    const int k = i / W, n = i % W;
-    double acc = (double)bb[k] * (double)c[n];
-    for (int r = 0; r < TW; ++r) acc += (double)Wb[(size_t)r * TW + k] * (double)S[(size_t)r * W + n];
-    dKb[i] = (float)acc;
-  } else if (i < nK + nW) {                       // dWb[r][k] = sum_n S[r][n] Kb[k][n]
-    const int j = i - nK, r = j / TW, k = j % TW;
-    double acc = 0.0;
-    for (int n = 0; n < W; ++n) acc += (double)S[(size_t)r * W + n] * (double)K[(size_t)k * W + n];
-    dWb[j] = (float)acc;
-  } else if (i < nK + nW + TW) {                  // dbb[k] = sum_n Kb[k][n] c[n]
-    const int k = i - nK - nW;
-    double acc = 0.0;
-    for (int n = 0; n < W; ++n) acc += (double)K[(size_t)k * W + n] * (double)c[n];
-    dbb[k] = (float)acc;
+// fused backward: see train_kernels.h bott_grads.  Three small products with double accumulation like k_fold_rgb:
+//   dKb[k][n] = sum_r Wb[r][k] S[r][n] + bb[k] c[n],   dWb[r][k] = sum_n S[r][n] Kb[k][n],   dbb[k] = sum_n Kb[k][n] c[n].
+// k_small_gemm: C[i][j] = sum_r A(r, i) B(r, j) (+ u[i] v[j]) for any strides, 32 x 32 output tiles, the operands staged through LDS 32
+// reduction steps at a time (as one thread per output element walking 256 operand pairs from L2 the launch took 90 us).
+__global__ __launch_bounds__(256) void k_small_gemm(int I, int J, int Rn, const float* __restrict__ A, long long sa_r, long long sa_i,
+                                                    const float* __restrict__ B, long long sb_r, long long sb_j, const float* __restrict__ u,
+                                                    const float* __restrict__ v, float* __restrict__ C) {
+  __shared__ float As[32][33], Bs[32][33];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  for (int r0 = 0; r0 < Rn; r0 += 32) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+      // the faster-moving index of the load follows the smaller stride of each operand
+      const int p = e & 31, q = e >> 5;
+      const int ra = sa_i <= sa_r ? q : p, ia = sa_i <= sa_r ? p : q;
+      As[ra][ia] = (r0 + ra < Rn && i0 + ia < I) ? A[(r0 + ra) * sa_r + (i0 + ia) * sa_i] : 0.f;
+      const int rb = sb_j <= sb_r ? q : p, jb = sb_j <= sb_r ? p : q;
+      Bs[rb][jb] = (r0 + rb < Rn && j0 + jb < J) ? B[(r0 + rb) * sb_r + (j0 + jb) * sb_j] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      const double a0 = As[r][ty], a1 = As[r][ty + 16], b0 = Bs[r][tx], b1 = Bs[r][tx + 16];
+      acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+    }
   }
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * b;
+      if (i < I && j < J) C[(size_t)i * J + j] = (float)(acc[a][b] + (u ? (double)u[i] * (double)v[j] : 0.0));
+    }
+}
+__global__ void k_bott_dbb(int TW, int W, const float* __restrict__ K, const float* __restrict__ c, float* __restrict__ dbb) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= TW) return;
+  double acc = 0.0;
+  for (int n = 0; n < W; ++n) acc += (double)K[(size_t)k * W + n] * (double)c[n];
+  dbb[k] = (float)acc;
 }
 void bott_grads(hipStream_t st, int TW, int W, const float* Wb, const float* bb, const float* K, const float* S, const float* c, float* dKb,
                 float* dWb, float* dbb) {
-  LAUNCH(k_bott_grads, (long long)TW * W + (long long)TW * TW + TW, st, TW, W, Wb, bb, K, S, c, dKb, dWb, dbb);
+  // dKb: i = k, j = n, reduction r: A(r, k) = Wb[r * TW + k], B(r, n) = S[r * W + n]
+  hipLaunchKernelGGL(k_small_gemm, dim3((W + 31) / 32, (TW + 31) / 32), dim3(256), 0, st, TW, W, TW, Wb, (long long)TW, 1LL, S, (long long)W, 1LL, bb, c, dKb);
+  // dWb: i = r, j = k, reduction n: A(n, r) = S[r * W + n], B(n, k) = K[k * W + n]
+  hipLaunchKernelGGL(k_small_gemm, dim3((TW + 31) / 32, (TW + 31) / 32), dim3(256), 0, st, TW, TW, W, S, 1LL, (long long)W, K, 1LL, (long long)W,
+                     static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), dWb);
+  LAUNCH(k_bott_dbb, TW, st, TW, W, K, c, dbb);
 }
 void pack_stream(hipStream_t st, const float* theta, const float* fold, long long P, const int* map, void* stream, int nfrag, int x6_lo, int x6_hi, int wide_f32) {
   LAUNCH(k_pack_stream, (long long)nfrag * 64, st, theta, fold, P, map, static_cast<unsigned char*>(stream), nfrag, x6_lo, x6_hi, wide_f32);
