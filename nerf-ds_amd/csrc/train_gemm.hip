@@ -908,6 +908,67 @@ __global__ __launch_bounds__(512) void k_wgrad_tr(const WgradArgs A) {
     }
 }
 
+// ---- weight gradient of a HEAD: X f16 [M x K] (the last hidden layer, K = 64 / 128 / 256), dY fp32 [M x N], N <= 6 -------------------------
+// 768 FMAs per row at most: VALU work, the kernel is the read of X.  A thread owns 8 features (one 16-byte load per row) x N outputs in registers,
+// K / 8 threads share a row, the rows of a block iteration are reduced by shuffles and through LDS, one float atomic per output and block.
+// (k_wgrad ran these shapes with scalar-DMA dY tiles and MFMAs on 32-padded N: 60 - 110 us per launch for 134 - 268 MB, eight launches per step.)
+template <int K, int N>
+__global__ __launch_bounds__(256) void k_wgrad_head(const WgradArgs A) {
+  constexpr int TPR = K / 8, RPI = 256 / TPR;                            // threads per row; rows per block iteration
+  const int f = threadIdx.x % TPR, rr = threadIdx.x / TPR, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const _Float16* X = reinterpret_cast<const _Float16*>(A.x);
+  float acc[8][N], cs[N];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[i][n] = 0.f;
+#pragma unroll
+  for (int n = 0; n < N; ++n) cs[n] = 0.f;
+#pragma unroll 4
+  for (long long row = (long long)blockIdx.x * RPI + rr; row < A.M; row += (long long)gridDim.x * RPI) {
+    const f16x8 x = *reinterpret_cast<const f16x8*>(X + (size_t)row * A.ldx + 8 * f);
+    float d[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) d[n] = A.dy[(size_t)row * A.ldy + n];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float xi = (float)x[i];
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc[i][n] += xi * d[n];
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) cs[n] += d[n];
+  }
+  // rows of one wave: lanes f, f + TPR, ... hold the same features
+#pragma unroll
+  for (int sft = TPR; sft < 64; sft <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc[i][n] += __shfl_xor(acc[i][n], sft, 64);
+#pragma unroll
+    for (int n = 0; n < N; ++n) cs[n] += __shfl_xor(cs[n], sft, 64);
+  }
+  float* sm = reinterpret_cast<float*>(g_tile);                         // [4 waves][K x N + N]
+  if (lane < TPR) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int n = 0; n < N; ++n) sm[wave * (K * N + N) + (8 * f + i) * N + n] = acc[i][n];
+    if (f == 0) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) sm[wave * (K * N + N) + K * N + n] = cs[n];
+    }
+  }
+  __syncthreads();
+  const size_t rep = A.nrep > 1 ? (size_t)(blockIdx.x % A.nrep) * A.rep_stride : 0;
+  for (int e = threadIdx.x; e < K * N + N; e += 256) {
+    const float v = (sm[e] + sm[(K * N + N) + e]) + (sm[2 * (K * N + N) + e] + sm[3 * (K * N + N) + e]);
+    if (e < K * N) unsafeAtomicAdd(A.dw + rep + e, v);
+    else if (A.colsum != nullptr) unsafeAtomicAdd(A.colsum + rep + (e - K * N), v);
+  }
+}
+
 // ---- backward of a narrow hidden layer in one pass ---------------------------------------------------------------------
 // k_wgrad and the data-gradient kernel of a layer both read dZ, and the latter reads X again as its ReLU mask: 5 array passes per
 // layer.  For the 64 / 128-wide networks (mask MLP, warp field, hyper sheet: 34 layers per step) everything fits one 4-wave
@@ -1268,6 +1329,17 @@ bool wgrad(hipStream_t st, const WgradArgs& A0, int grid) {
 #define NERFDS_WT(KT, NT) if (kt == KT && nt == NT) { launch_wgrad_tr<KT, NT>(st, A, grid); return true; }
     NERFDS_WT(8, 8) NERFDS_WT(8, 4) NERFDS_WT(4, 4) NERFDS_WT(2, 2)
 #undef NERFDS_WT
+  }
+  if (A.x_half && !A.dy_half && A.dw != nullptr && A.n <= 6 && (A.k == 64 || A.k == 128 || A.k == 256) && !getenv("NERFDS_WGRAD_HEAD_OFF")) {
+    // a head on an f16 hidden layer: VALU kernel, the read of X is the cost
+    const long long want = 4LL * grid, rows = (A.M + 255 / (A.k / 8)) / (256 / (A.k / 8));
+    const dim3 g((unsigned)(rows < want ? (rows < 1 ? 1 : rows) : want));
+    const size_t lds = 4 * (size_t)(A.k * A.n + A.n) * sizeof(float);
+#define NERFDS_WH(KK, NN) if (A.k == KK && A.n == NN) { hipLaunchKernelGGL((k_wgrad_head<KK, NN>), g, dim3(256), lds, st, A); return true; }
+#define NERFDS_WHK(KK) NERFDS_WH(KK, 1) NERFDS_WH(KK, 2) NERFDS_WH(KK, 3) NERFDS_WH(KK, 4) NERFDS_WH(KK, 6)
+    NERFDS_WHK(64) NERFDS_WHK(128) NERFDS_WHK(256)
+#undef NERFDS_WHK
+#undef NERFDS_WH
   }
   int ninstr;
   wgrad_kinds(A, A.x_scalar, A.dy_scalar, ninstr);

@@ -116,6 +116,61 @@ int main(int argc, char** argv) {
            worst < 3e-5 * big ? "" : "  FAIL");
     (void)hipFree(x); (void)hipFree(dy); (void)hipFree(dw); (void)hipFree(zeros);
   }
+  // ---- weight gradient of a head: X f16 (the last hidden layer), dY fp32 with N <= 6 columns in rows of `ld` floats (k_wgrad_head), bias gradient = column sums ----
+  {
+    struct HD { int k, n, ld, off; };
+    const HD heads[] = {{256, 4, 4, 0}, {256, 3, 3, 0}, {128, 3, 6, 3}, {128, 1, 1, 0}, {64, 2, 2, 0}, {128, 6, 6, 0}};
+    for (const HD& w : heads) {
+      void *x, *zeros; float *dy, *dw;
+      const int NREP = 16;
+      const long long RS = (long long)w.k * w.n + w.n;
+      (void)hipMalloc(&x, M * w.k * 2); (void)hipMalloc(&dy, M * w.ld * 4); (void)hipMalloc(&dw, (size_t)NREP * RS * 4); (void)hipMalloc(&zeros, 256);
+      (void)hipMemset(zeros, 0, 256); (void)hipMemset(dw, 0, (size_t)NREP * RS * 4); (void)hipMemset(x, 0, M * w.k * 2); (void)hipMemset(dy, 0, M * w.ld * 4);
+      const long long Mc = M < 4096 ? M : 4096;
+      std::vector<float> hx(Mc * w.k), hd(Mc * w.ld);
+      std::vector<uint16_t> x16(w.k);
+      for (long long j = 0; j < Mc; ++j) {
+        const long long r = j * M / Mc;
+        for (int k = 0; k < w.k; ++k) { const _Float16 h = (_Float16)frand(); memcpy(&x16[k], &h, 2); hx[j * w.k + k] = (float)h; }
+        for (int n = 0; n < w.ld; ++n) hd[j * w.ld + n] = frand();
+        (void)hipMemcpy((char*)x + r * w.k * 2, x16.data(), w.k * 2, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dy + r * w.ld, hd.data() + j * w.ld, w.ld * 4, hipMemcpyHostToDevice);
+      }
+      WgradArgs A{(const float*)x, w.k, w.k, dy + w.off, w.ld, w.n, M, nullptr, dw, zeros, 0, 0, RS, NREP};
+      A.x_half = 1; A.colsum = dw + (size_t)w.k * w.n;
+      if (!wgrad_supported(A)) { printf("wgrad head %d x %d not supported  FAIL\n", w.k, w.n); ++bad; continue; }
+      const int grid = wgrad_grid(A, prop.multiProcessorCount);
+      wgrad(nullptr, A, grid);
+      (void)hipDeviceSynchronize();
+      std::vector<float> hw(RS, 0.f), hrep(RS);
+      for (int rp = 0; rp < NREP; ++rp) {
+        (void)hipMemcpy(hrep.data(), dw + (size_t)rp * RS, RS * 4, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < hw.size(); ++i) hw[i] += hrep[i];
+      }
+      double worst = 0, big = 0, cworst = 0, cbig = 0;
+      for (int k = 0; k < w.k; ++k) for (int n = 0; n < w.n; ++n) {
+        double a = 0;
+        for (long long r = 0; r < Mc; ++r) a += (double)hx[r * w.k + k] * hd[r * w.ld + w.off + n];
+        worst = std::fmax(worst, std::fabs(a - hw[k * w.n + n])); big = std::fmax(big, std::fabs(a));
+      }
+      for (int n = 0; n < w.n; ++n) {
+        double a = 0;
+        for (long long r = 0; r < Mc; ++r) a += hd[r * w.ld + w.off + n];
+        cworst = std::fmax(cworst, std::fabs(a - hw[w.k * w.n + n])); cbig = std::fmax(cbig, std::fabs(a));
+      }
+      hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+      const int reps = 20;
+      (void)hipEventRecord(e0, nullptr);
+      for (int i = 0; i < reps; ++i) wgrad(nullptr, A, grid);
+      (void)hipEventRecord(e1, nullptr); (void)hipEventSynchronize(e1);
+      float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      const bool ok = worst < 3e-5 * big && cworst < 1e-5 * (cbig + Mc * 0.01);
+      if (!ok) ++bad;
+      printf("wgrad head M=%lld K=%d (f16) N=%d (fp32, ld %d): %.3f ms  %.0f GB/s  max|err|=%.2e (max|dW|=%.1f) colsum err %.2e%s\n", M, w.k, w.n, w.ld, ms,
+             (double)M * (w.k * 2 + w.ld * 4) / ms / 1e6, worst, big, cworst, ok ? "" : "  FAIL");
+      (void)hipFree(x); (void)hipFree(dy); (void)hipFree(dw); (void)hipFree(zeros);
+    }
+  }
   // ---- weight gradient with 16-bit operands: X as f16 (what the fused forward stores) and / or dY as scaled f16 (what the fused backward's chains
   // store), and the bias gradient = column sums of dY as a by-product.  f16 X: both operands go to the MFMAs as stored (k_wgrad_tr, one MFMA
   // per product, exact products); fp32 X: f16 hi + lo, two MFMAs.  The reference is the fp64 sum over the ROUNDED inputs, so the bound is the
