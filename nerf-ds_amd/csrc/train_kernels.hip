@@ -614,6 +614,23 @@ __device__ __forceinline__ float wave_sum(float x) {
   for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
   return x;
 }
+// loss += mean over rays and channels of (rgb_ray - target)^2 (training.py:265-274): one block, every thread a fixed set of rays, a tree in LDS
+__global__ __launch_bounds__(256) void k_mse_sum(int R, const float* __restrict__ rgb_ray, const float* __restrict__ target, float* __restrict__ loss) {
+  __shared__ float part[256];
+  float l = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    float e2 = 0.f;
+    for (int c = 0; c < 3; ++c) { const float e = rgb_ray[3 * r + c] - target[3 * r + c]; e2 += e * e; }
+    l += e2 / (3.0f * (float)R);
+  }
+  part[threadIdx.x] = l;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss += part[0];
+}
 __global__ __launch_bounds__(256) void k_composite_loss(int R, int S, const float* __restrict__ z, const float* __restrict__ dirs, const float* __restrict__ sigma,
                                  const float* __restrict__ rgb_logit, const float* __restrict__ target, int at_infinity, int white,
                                  float* __restrict__ rgb_ray, float* __restrict__ weights, float* __restrict__ loss,
@@ -654,9 +671,8 @@ __global__ __launch_bounds__(256) void k_composite_loss(int R, int S, const floa
     gsum += g[c];
   }
   if (lane == 0) {
-    for (int c = 0; c < 3; ++c) rgb_ray[3 * r + c] = acc[c];
-    atomicAdd(loss, l / (3.0f * (float)R));
-  }
+    for (int c = 0; c < 3; ++c) rgb_ray[3 * r + c] = acc[c];      // the loss is summed from these in a fixed order (k_mse_sum): a float atomic per ray
+  }                                                                // from waves on different CUs would make the reported loss depend on their timing
   // backward: w_i = a_i T_i, T_i = prod_{j<i} (1 - a_j + eps);  dL/da_i = G_i T_i - (sum_{k>i} G_k w_k) / (1 - a_i + eps)
   float carryS = 0.f;
   for (int c0 = ((S - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
@@ -1017,6 +1033,7 @@ void composite_loss(hipStream_t st, int R, int S, const float* z, const float* d
                     int at_infinity, int white, float* rgb_ray, float* weights, float* loss, float* d_rgb_logit, float* d_alpha) {
   hipLaunchKernelGGL(k_composite_loss, dim3((R + 3) / 4), dim3(256), 0, st, R, S, z, dirs, sigma, rgb_logit, target, at_infinity, white, rgb_ray, weights,
                      loss, d_rgb_logit, d_alpha);
+  hipLaunchKernelGGL(k_mse_sum, dim3(1), dim3(256), 0, st, R, rgb_ray, target, loss);
 }
 void relu_bwd(hipStream_t st, float* dy, const float* y, long long n) { LAUNCH(k_relu_bwd, n, st, dy, y, n); }
 void colsum_add(hipStream_t st, const float* dz, long long M, int N, int ld, float* db) {      // N <= 256
