@@ -1274,9 +1274,12 @@ static void wgrad_kinds(const WgradArgs& A, int& xs, int& ys, int& ninstr) {
   ys = (!A.dy_half && (A.n % 4 || A.ldy % 4 || !aligned16(A.dy))) ? 1 : 0;
   ninstr = (xs ? (16 * A.k + 63) / 64 : ((A.x_half ? 2 : 4) * A.k + 63) / 64) + (ys ? (16 * A.n + 63) / 64 : ((A.dy_half ? 2 : 4) * A.n + 63) / 64);
 }
+// development switches (A/B), read once: NERFDS_WGRAD_TR_OFF=1 sends every shape to k_wgrad, NERFDS_WGRAD_HEAD_OFF=1 the heads too
+static bool wgrad_tr_off() { static const bool v = getenv("NERFDS_WGRAD_TR_OFF") != nullptr; return v; }
+static bool wgrad_head_off() { static const bool v = getenv("NERFDS_WGRAD_HEAD_OFF") != nullptr; return v; }
 // the shapes k_wgrad_tr is built for; several layers per launch exist on that kernel only
 bool wgrad_multi_supported(const WgradArgs& A) {
-  if (!(A.x_half && A.dy_half && A.dw != nullptr) || A.nl > 8 || getenv("NERFDS_WGRAD_TR_OFF")) return false;
+  if (!(A.x_half && A.dy_half && A.dw != nullptr) || A.nl > 8 || wgrad_tr_off()) return false;
   const int kt = A.k / 32, nt = A.n / 32;
   if (!((kt == 8 && nt == 8) || (kt == 8 && nt == 4) || (kt == 4 && nt == 4) || (kt == 2 && nt == 2))) return false;
   for (int i = 0; i < A.nl; ++i)
@@ -1324,13 +1327,13 @@ bool wgrad(hipStream_t st, const WgradArgs& A0, int grid) {
   if (!wgrad_supported(A0) || grid < 1) return false;
   WgradArgs A = A0;
   if (A.nl > 1 && !wgrad_multi_supported(A)) return false;
-  if (A.x_half && A.dy_half && A.dw != nullptr && !getenv("NERFDS_WGRAD_TR_OFF")) {        // both operands 16-bit: transposed reads straight from the stage
+  if (A.x_half && A.dy_half && A.dw != nullptr && !wgrad_tr_off()) {        // both operands 16-bit: transposed reads straight from the stage
     const int kt = A.k / 32, nt = A.n / 32;
 #define NERFDS_WT(KT, NT) if (kt == KT && nt == NT) { launch_wgrad_tr<KT, NT>(st, A, grid); return true; }
     NERFDS_WT(8, 8) NERFDS_WT(8, 4) NERFDS_WT(4, 4) NERFDS_WT(2, 2)
 #undef NERFDS_WT
   }
-  if (A.x_half && !A.dy_half && A.dw != nullptr && A.n <= 6 && (A.k == 64 || A.k == 128 || A.k == 256) && !getenv("NERFDS_WGRAD_HEAD_OFF")) {
+  if (A.x_half && !A.dy_half && A.dw != nullptr && A.n <= 6 && (A.k == 64 || A.k == 128 || A.k == 256) && !wgrad_head_off()) {
     // a head on an f16 hidden layer: VALU kernel, the read of X is the cost
     const long long want = 4LL * grid, rows = (A.M + 255 / (A.k / 8)) / (256 / (A.k / 8));
     const dim3 g((unsigned)(rows < want ? (rows < 1 ? 1 : rows) : want));

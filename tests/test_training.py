@@ -514,6 +514,41 @@ def test_nonfinite_gradient_skips_the_update_and_is_reported():
 
 
 @pytest.mark.gpu
+def test_gradient_scale_of_the_f16_g_arrays(monkeypatch):
+  """The chains store g_scale * g as f16 (loss scaling) and the weight-gradient kernels undo the power of two: the gradients do not depend on
+  it while g stays in range (2^8 .. 2^22 here: every leaf within 2e-3 of the default scale's, the differences being f16 roundings of g at another
+  exponent and - at the small end - g values that drop below f16's denormals), and a scale that pushes g beyond 65504 is REPORTED: the weight gradients
+  become inf, the update is skipped and the step raises (NERFDS_ENONFINITE) instead of training on garbage."""
+  from nerfds_amd.training import Trainer
+  cfg, params, batch, t, u = _problem(32, 8, 8, seed=7)
+  kw = dict(t_rand=t, u_rand=u, mask_ratio=1.0, grads_only=True)
+
+  def grads(log2):
+    if log2 is None:
+      monkeypatch.delenv('NERFDS_TRAIN_G_SCALE_LOG2', raising=False)
+    else:
+      monkeypatch.setenv('NERFDS_TRAIN_G_SCALE_LOG2', str(log2))
+    tr = Trainer(cfg, params, max_rays=32)
+    tr.step(batch, EX, 0.0, **kw)
+    scale = float(tr.debug_read('g_scale', (1,))[0])
+    return dict(tree_leaves(tr.get_grads())), scale
+  ref, s0 = grads(None)
+  assert s0 == 2.0 ** 11                                 # 64 x 32 rays
+  gmax = max(np.abs(v).max() for v in ref.values())
+  for log2 in (8, 16, 22):
+    got, sc = grads(log2)
+    assert sc == 2.0 ** log2
+    for name, w in ref.items():
+      l2 = np.linalg.norm(got[name] - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
+      assert l2 < 2e-3, (log2, name, l2)
+  monkeypatch.setenv('NERFDS_TRAIN_G_SCALE_LOG2', '40')  # 2^40 x a head gradient of ~1e-3: far beyond f16
+  tr = Trainer(cfg, params, max_rays=32)
+  with pytest.raises(FloatingPointError):
+    tr.step(batch, EX, 1e-3, t_rand=t, u_rand=u, mask_ratio=1.0)
+  assert tr.nonfinite()
+
+
+@pytest.mark.gpu
 def test_resume_from_a_checkpoint_with_adam_state(tmp_path):
   """training.save_checkpoint / restore (training.py:59-66, train.py:335-338): parameters + Adam moments + step count through the flax-msgpack file;
   a run resumed from it continues like the uninterrupted one (up to the order of the float atomics in the gradient sums)."""
