@@ -304,8 +304,8 @@ int nerfds_trainer_set_step(nerfds_trainer* t, int64_t step);   /* the optimizer
 /* Development / tests: HOST copy of an internal device buffer of the last step (the f16 activations, ReLU bits and per-layer
  * gradients g_l of the fused backward, the head / input gradients): "<net>_h16_<l>", "<net>_bits_<l>", "<net>_g_<l>" with net = mask |
  * warp | hyper | trunk, "rgb_h16", "rgb_bits", "rgb_g", "d_rgb_logit", "d_alpha", "d_trunk_in", "d_hyper_in", "d_warp_in",
- * "d_mask_in", "dwamb", "dwv", "d_mask_logit".  The "<net>_g_<l>" / "rgb_g" arrays are bf16 [M][width] (2 bytes per element) unless the
- * trainer was created under NERFDS_TRAIN_G16=0 (fp32).  Returns the bytes copied (= max_bytes) or a negative error code. */
+ * "d_mask_in", "dwamb", "dwv", "d_mask_logit".  The "<net>_g_<l>" / "rgb_g" arrays are f16 [M][width] (2 bytes per element) holding
+ * g_scale * g - "g_scale" reads that power of two as one float - unless the trainer was created under NERFDS_TRAIN_G16=0 (fp32, unscaled).  Returns the bytes copied (= max_bytes) or a negative error code. */
 long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* host, long long max_bytes);
 int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* extra,
                         const nerfds_rand* rnd, const nerfds_train_objective* objective /* NULL = rgb loss only */, float learning_rate,
@@ -313,8 +313,9 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
 /* One Adam update with the gradient vector as it stands (after a NERFDS_TRAIN_GRADS_ONLY step and, on N GPUs, after the
  * all-reduce of nerfds_trainer_grads that replaces jax.lax.pmean(grad), training.py:502). */
 int nerfds_trainer_apply(nerfds_trainer* t, float learning_rate, void* hip_stream);
-/* The plain step keeps activations as f16 and the weight-gradient operand g as bf16 (a documented deviation from the reference's fp32
- * arrays; NERFDS_TRAIN_G16=0 in the environment keeps g in fp32): a value beyond 65504 turns into an inf / NaN gradient.  Every Adam update
+/* The plain step keeps activations as f16 and the weight-gradient operand g as loss-scaled f16 (a documented deviation from the reference's
+ * fp32 arrays; g times 64 x the ray count rounded up to a power of two, NERFDS_TRAIN_G_SCALE_LOG2 overrides the exponent; NERFDS_TRAIN_G16=0 in the
+ * environment keeps g in fp32): a value beyond 65504 turns into an inf / NaN gradient.  Every Adam update
  * first checks the whole gradient vector on the device and is SKIPPED when an element is not finite; nerfds_trainer_step reports
  * NERFDS_ENONFINITE when it reads the loss back (loss_host != NULL), and this call (it synchronises the device) returns 1 if the last update
  * was skipped, 0 if not. */

@@ -430,7 +430,7 @@ struct Cursor {
 };
 // Training kernels (train_fwd_kernel.hip, train_bwd_kernel.hip).  The Makefile builds each of them twice; what they store is a compile-time fact:
 //   -DNERFDS_TRAIN_HALF=0                        fp32 activations / fp32 g (the steps with a tangent pass; NERFDS_TRAIN_G16=0)
-//   -DNERFDS_TRAIN_HALF=1 -DNERFDS_TRAIN_PIPE=1  f16 activations + ReLU bits / bf16 g, a tile group's epilogue issued inside the next group's
+//   -DNERFDS_TRAIN_HALF=1 -DNERFDS_TRAIN_PIPE=1  f16 activations + ReLU bits / scaled f16 g, a tile group's epilogue issued inside the next group's
 //                                                MFMA chain (dense(): TRAIN_PIPE branch) - the plain training step
 // and the host picks the launcher (TrainOut::half_out / TrainBwd::g_half).  As a run-time test (a uniform branch per tile pair) the mode cut
 // every tile group into its own basic blocks, and hipcc schedules within a block; compile-time alone is neutral (15.81 against 15.88 ms per
@@ -487,7 +487,7 @@ template <bool RELU> DEVI void store_tile(float* row_tile, const f32x16& acc) {
   }
 }
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-// A tile of 16-bit values (f16 activations, bf16 g): pk[2g], pk[2g + 1] = this lane's features 8g + 4h + 0..3 of its sample, as packed pairs.
+// A tile of 16-bit values (f16 activations, f16 g): pk[2g], pk[2g + 1] = this lane's features 8g + 4h + 0..3 of its sample, as packed pairs.
 // The two lanes of a sample (l, l + 32) trade halves with v_permlane32_swap - afterwards lane half h owns features 16h .. 16h + 15 of the
 // tile - and each lane writes TWO 16-byte pieces instead of four 8-byte ones (`row16` points at the lane's feature 16h of tile 0).  A training
 // kernel runs one wave per SIMD and a global store occupies the wave for its whole issue (address + data transfer of 64 lanes), MFMA pipe

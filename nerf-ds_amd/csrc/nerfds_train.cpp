@@ -30,7 +30,7 @@ extern "C" void nerfds_launch_train_fwd_nerfds(const nerfds::KArgs& ka, const ne
 extern "C" void nerfds_launch_train_fwd16_nerfds(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream);   // f16 + ReLU bits
 // train_bwd_kernel.hip: the data-gradient chain of one network (0 NerfMLP, 1 hyper sheet, 2 warp, 3 mask)
 extern "C" void nerfds_launch_train_bwd_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);      // g as fp32
-extern "C" void nerfds_launch_train_bwd16_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);    // g as bf16
+extern "C" void nerfds_launch_train_bwd16_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);    // g as scaled f16
 
 using namespace nerfds_train;
 
@@ -1364,7 +1364,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     loss_host[1] = l[0];
     for (int k = 0; k < 4; ++k) { loss_host[2 + k] = tm[4 * fl + k]; loss_host[6 + k] = tm[k]; }   // weighted warp_reg / back_facing / mask / norm terms: fine, coarse
     if (nonfinite && !(flags & NERFDS_TRAIN_GRADS_ONLY))
-      return t->fail(NERFDS_ENONFINITE, "non-finite gradient: the Adam update of this step was skipped (f16 activations / bf16 g overflowed? NERFDS_TRAIN_G16=0 "
+      return t->fail(NERFDS_ENONFINITE, "non-finite gradient: the Adam update of this step was skipped (f16 activations / scaled f16 g overflowed? NERFDS_TRAIN_G16=0 "
                                         "keeps g in fp32; a step with the sigma-gradient flag keeps fp32 activations)");
   }
   return NERFDS_OK;

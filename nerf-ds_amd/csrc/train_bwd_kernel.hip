@@ -25,7 +25,7 @@ DEVI void bwd_hidden(Pipe<BG, PL>& pipe, BwdCursor& cur, const unsigned (&m)[OT 
 #pragma unroll
   for (int j = 0; j < OT / 2; ++j) cur.mask[j] = m[j];
   cur.row = g_base + g_off;                                        // fp32 [M][width] ...
-  cur.row16 = reinterpret_cast<uint16_t*>(g_base) + g_off + (ROW16_H / 4 - 1) * cur.in_h4;   // ... or bf16 [M][width] in the same buffer (TRAIN_HALF)
+  cur.row16 = reinterpret_cast<uint16_t*>(g_base) + g_off + (ROW16_H / 4 - 1) * cur.in_h4;   // ... or f16 [M][width] in the same buffer (TRAIN_HALF)
   dense<BG, PL, 1, OT, false>(pipe, cur, out, ins...);
 }
 template <class BG, class PL, int P, int K>

@@ -10,6 +10,9 @@
 //   k_dense_ws    the same layer with the X tile staged through registers (rows that are not 16-byte aligned: 33 / 45-wide inputs).
 //   k_wgrad       dW[K x N] += X^T dZ: 16-sample tiles of both operands by LDS-DMA, transposed + split once per workgroup into
 //                 fragment images, output tiles accumulated in registers for the whole kernel, float atomics at the end.
+//   k_wgrad_tr    the same product with BOTH operands 16-bit (f16 activations, loss-scaled f16 g - the fused training step): the DMA'd stage is the
+//                 operand store, transposed reads (ds_read_b64_tr_b16), one MFMA per product; several layers of an MLP per launch.
+//   k_wgrad_head  heads (f16 X, fp32 dZ of <= 6 columns): VALU, bound by the read of X.
 //
 // Epilogue of the first two: bias, ReLU | accumulate, the consumer's ReLU mask (dX . 1[y_prev > 0]), column sums (bias gradient).
 // Every layer is HBM bound (X read once, Y written once); DESIGN.md section 8.1 has the measurements and what was tried.
@@ -501,8 +504,9 @@ template <int TPW, int IPW, bool FULL = false> struct WgShape {
 
 // ROW: the TPW output tiles of a wave lie in one row of tiles (N/32 is a multiple of TPW), so its X^T fragment is read once per
 // sample tile instead of once per output tile (a compile-time fact: as a run-time branch the two loop bodies cost 4x in spills).
-// DYH: dY is bf16 [M x ldy] (the g arrays of the fused backward, WgradArgs::dy_half): half the bytes, its fragment image is the
-// transposed tile itself (no conversion, no lo part) and a product is two MFMAs (X hi * g, X lo * g) instead of three.
+// DYH: dY is f16 [M x ldy] (the scaled g arrays of the fused backward, WgradArgs::dy_half): half the bytes, its fragment image is the
+// transposed tile itself (no conversion, no lo part), X goes into f16 hi + lo and a product is two f16 MFMAs (X hi * g, X lo * g) instead of three
+// bf16 ones.  (With an f16 X as well the launch goes to k_wgrad_tr below; this path then serves the fp32 inputs of the first / skip layers.)
 template <int TPW, int IPW, bool ROW, bool FULL, bool DYH>
 __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
   typedef WgShape<TPW, IPW, FULL> S;
@@ -917,13 +921,14 @@ __global__ __launch_bounds__(256) void k_wgrad_head(const WgradArgs A) {
   constexpr int TPR = K / 8, RPI = 256 / TPR;                            // threads per row; rows per block iteration
   const int f = threadIdx.x % TPR, rr = threadIdx.x / TPR, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const _Float16* X = reinterpret_cast<const _Float16*>(A.x);
-  float acc[8][N], cs[N];
+  float acc[8][N];
+  double cs[N];                    // the bias gradient is a sum of CANCELLING rows (|sum| << sum of |terms|): summed in double per block
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int n = 0; n < N; ++n) acc[i][n] = 0.f;
 #pragma unroll
-  for (int n = 0; n < N; ++n) cs[n] = 0.f;
+  for (int n = 0; n < N; ++n) cs[n] = 0.0;
 #pragma unroll 4
   for (long long row = (long long)blockIdx.x * RPI + rr; row < A.M; row += (long long)gridDim.x * RPI) {
     const f16x8 x = *reinterpret_cast<const f16x8*>(X + (size_t)row * A.ldx + 8 * f);
@@ -936,8 +941,10 @@ __global__ __launch_bounds__(256) void k_wgrad_head(const WgradArgs A) {
 #pragma unroll
       for (int n = 0; n < N; ++n) acc[i][n] += xi * d[n];
     }
+    if (f == 0) {
 #pragma unroll
-    for (int n = 0; n < N; ++n) cs[n] += d[n];
+      for (int n = 0; n < N; ++n) cs[n] += (double)d[n];
+    }
   }
   // rows of one wave: lanes f, f + TPR, ... hold the same features
 #pragma unroll
@@ -949,6 +956,7 @@ __global__ __launch_bounds__(256) void k_wgrad_head(const WgradArgs A) {
 #pragma unroll
     for (int n = 0; n < N; ++n) cs[n] += __shfl_xor(cs[n], sft, 64);
   }
+  __shared__ double scs[4][8];
   float* sm = reinterpret_cast<float*>(g_tile);                         // [4 waves][K x N + N]
   if (lane < TPR) {
 #pragma unroll
@@ -957,16 +965,15 @@ __global__ __launch_bounds__(256) void k_wgrad_head(const WgradArgs A) {
       for (int n = 0; n < N; ++n) sm[wave * (K * N + N) + (8 * f + i) * N + n] = acc[i][n];
     if (f == 0) {
 #pragma unroll
-      for (int n = 0; n < N; ++n) sm[wave * (K * N + N) + K * N + n] = cs[n];
+      for (int n = 0; n < N; ++n) scs[wave][n] = cs[n];
     }
   }
   __syncthreads();
   const size_t rep = A.nrep > 1 ? (size_t)(blockIdx.x % A.nrep) * A.rep_stride : 0;
-  for (int e = threadIdx.x; e < K * N + N; e += 256) {
-    const float v = (sm[e] + sm[(K * N + N) + e]) + (sm[2 * (K * N + N) + e] + sm[3 * (K * N + N) + e]);
-    if (e < K * N) unsafeAtomicAdd(A.dw + rep + e, v);
-    else if (A.colsum != nullptr) unsafeAtomicAdd(A.colsum + rep + (e - K * N), v);
-  }
+  for (int e = threadIdx.x; e < K * N; e += 256)
+    unsafeAtomicAdd(A.dw + rep + e, (sm[e] + sm[(K * N + N) + e]) + (sm[2 * (K * N + N) + e] + sm[3 * (K * N + N) + e]));
+  if (A.colsum != nullptr && threadIdx.x < N)
+    unsafeAtomicAdd(A.colsum + rep + threadIdx.x, (float)((scs[0][threadIdx.x] + scs[1][threadIdx.x]) + (scs[2][threadIdx.x] + scs[3][threadIdx.x])));
 }
 
 // ---- backward of a narrow hidden layer in one pass ---------------------------------------------------------------------

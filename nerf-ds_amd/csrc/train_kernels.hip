@@ -917,7 +917,7 @@ __global__ void k_mask_in_bwd(Dims D, int R, int S, const float* __restrict__ d_
 }
 
 // flax.optim.Adam (flax 0.3.4): bias-corrected, no weight decay (training.py:508, train.py:297-301)
-// The plain step stores activations as f16 and g as bf16: an activation beyond 65504 becomes inf there and arrives as an
+// The plain step stores activations as f16 and g as loss-scaled f16: an activation beyond 65504 becomes inf there and arrives as an
 // inf / NaN weight gradient.  k_nonfinite raises a flag if ANY gradient element is not finite; k_adam then leaves parameters and moments
 // untouched (the whole update is skipped, not element by element), and the host reports NERFDS_ENONFINITE at its next read-back.
 __global__ void k_nonfinite(const float* __restrict__ g, long long n, unsigned* __restrict__ flag) {

@@ -66,7 +66,7 @@ def test_train_oracle_reproduces_golden():
     assert abs(norm - float(z['norm/' + name])) <= 1e-10 * max(norm, 1e-30)
 
 
-# fp32 g arrays (NERFDS_TRAIN_G16=0) / bf16 g arrays (the default): measured 3.3e-4 / 6.1e-5 and 3.4e-3 / 7.5e-4
+# fp32 g arrays (NERFDS_TRAIN_G16=0) / 16-bit g arrays (the default): measured 3.3e-4 / 6.1e-5 and - with round 3's bf16 g - 3.4e-3 / 7.5e-4
 TOLS = {False: (2e-3, 5e-4), True: (7e-3, 1.5e-3)}
 
 
@@ -80,8 +80,8 @@ def test_hip_training_step_matches_golden(g16, monkeypatch):
   a few times that (the float atomics of the weight-gradient sums reorder from run to run).  Round 2's layer-by-layer backward
   needed 1e-1 / 3e-2 here; what it lost is what a round trip of every dX through fp32 HBM arrays and a second rounding to split
   bf16 costs on the ill-conditioned posenc backward of this trained-regime case.
-  g16=True is the shipped default: the chains hand g to the weight-gradient kernels as bf16 (half the bytes, two MFMAs per product).  On
-  this 16-ray case the 8-bit rounding shows in the cancelling column sums (bias gradients of the warp field: 3.4e-3 / 7.5e-4, ten times the
+  g16=True is the shipped default: the chains hand g to the weight-gradient kernels in 16 bits (round 3: bf16; round 4: loss-scaled f16, which
+  only tightens what follows).  On this 16-ray case the 8-bit rounding of bf16 showed in the cancelling column sums (bias gradients of the warp field: 3.4e-3 / 7.5e-4, ten times the
   fp32-g figure, still 30x inside round 2's bounds); it averages down with the row count (the 19 200-row gradient test of
   tests/test_training.py holds its fp32-era bounds in this mode).  g16=False keeps the chain arithmetic pinned at the tight bounds."""
   from nerfds_amd.training import Trainer

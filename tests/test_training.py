@@ -396,7 +396,8 @@ def test_gradients_match_the_oracle_at_multi_tile_size(full):
   tile.  Here 600 rays x (16 + 16) samples = 9 600 / 19 200 rows (300 / 600 tiles of 32 over 256 workgroups, a partial
   16-row tile for the weight gradient): several tiles per workgroup - and the SAME pin as above, the fp64 autograd oracle
   (5-8 s on the host), not another mode of the trainer.  What this guards against is an indexing error past the first
-  tile (O(1) differences).  Bounds: 8e-3 for the rgb loss (4e-3 holds at the small sizes), L2_TOL_2ND with the full objective."""
+  tile (O(1) differences).  Bounds, rgb loss: 6e-3 per leaf, or twice the oracle's OWN fp32-against-fp64 difference on that leaf where that
+  is larger (the yardstick of the small-size test, measured here too); L2_TOL_2ND with the full objective."""
   from nerfds_amd.training import Trainer
   from oracle import train_oracle as T
   R = 600
@@ -415,13 +416,23 @@ def test_gradients_match_the_oracle_at_multi_tile_size(full):
     errs[name] = float(np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size)))
   top = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
   print(f'multi-tile ({"full objective" if full else "rgb loss"}): worst leaves ' + ', '.join(f'{k} {v:.2e}' for k, v in top), file=sys.stderr)
-  # Every leaf - the SE(3) head leaves included, which round 2 had to bound at 2.5e-2 - meets one bound: 6e-3 for the rgb loss
-  # (measured 4.0e-3 worst, warp_field/trunk/hidden_5/bias, with one shared-network pass per level; 6.0e-3 on the same leaf in round 4's merged
-  # step, where the coarse positions' upstream gradients of both levels are summed BEFORE g is rounded to bf16 - a bias gradient is a sum of
-  # cancelling rows, so its relative error moves with the order of the sums), L2_TOL_2ND with the full objective (measured 5.8e-3).
-  tol = L2_TOL_2ND['mfma'] if full else 8e-3
+  # rgb loss: every leaf but the SE(3) field's cancelling sums sits below 4.3e-3.  The warp field's bias gradients are sums of 19 200 rows that
+  # cancel to ~1e-4 of their terms: there ANY fp32 evaluation is several 1e-3 off the fp64 one - the oracle itself, run in fp32, differs from its fp64
+  # run by 7.3e-3 on warp_field/branches_v/logit/bias and 4.6e-3 on trunk/hidden_5/bias at this size - and which side of that noise a given build lands
+  # on moves with one-ulp changes upstream (measured on these two leaves: 3.3e-3 / 3.9e-3 with one shared-network pass per level, 7.9e-3 / 5.1e-3 in
+  # the merged step - deterministic, the same with fp32 or f16 g arrays and with every weight-gradient kernel).  So: 6e-3, or 2 x the fp32 oracle's own
+  # difference on the leaf.  Full objective: L2_TOL_2ND (measured 6.0e-3).
+  if full:
+    for name, e in errs.items():
+      assert e < L2_TOL_2ND['mfma'], (name, e)
+    return
+  import torch
+  _, G32, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, dtype=torch.float32)
+  w32 = dict(tree_leaves(G32))
   for name, e in errs.items():
-    assert e < tol, (name, e)
+    w = want[name]
+    noise = float(np.linalg.norm(w32[name].reshape(w.shape) - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size)))
+    assert e < max(6e-3, 2.0 * noise), (name, e, noise)
 
 
 @pytest.mark.gpu
