@@ -67,7 +67,8 @@ def test_train_oracle_reproduces_golden():
 
 
 # fp32 g arrays (NERFDS_TRAIN_G16=0) / 16-bit g arrays (the default): measured 3.3e-4 / 6.1e-5 and - with round 3's bf16 g - 3.4e-3 / 7.5e-4
-TOLS = {False: (2e-3, 5e-4), True: (7e-3, 1.5e-3)}
+# round 4 (f16 g, merged step): 3.6e-4 / 1.1e-4 and 6.9e-4 / 1.1e-4; the bounds are 2 x those (the float atomics of the sums reorder from run to run)
+TOLS = {False: (8e-4, 2.5e-4), True: (1.4e-3, 2.5e-4)}
 
 
 @pytest.mark.gpu
