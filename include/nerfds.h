@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NERFDS_ABI_VERSION 4
+#define NERFDS_ABI_VERSION 5
 
 /* error codes */
 #define NERFDS_OK         0
@@ -269,8 +269,8 @@ int nerfds_frame_images(int device, const float* ray_records, int32_t height, in
  * ONE launch of the fused field kernel (the render kernel's evaluation, writing every activation the backward reads; its weight streams
  * are re-packed on the device from the parameter vector at the start of every step); other widths, and the whole backward, run layer by
  * layer on the library's own MFMA kernels: a layer shape they do not cover is NERFDS_ENOTSUP (there is no library-GEMM detour).  The auxiliary losses of
- * configs/nerf_ds.gin are selected by nerfds_train_objective; elastic / background / hyper-reg losses (off in every shipped gin)
- * are not built. */
+ * configs/nerf_ds.gin and the hyper-point regulariser are selected by nerfds_train_objective; the elastic and background losses (off in
+ * every shipped gin) are not built. */
 typedef struct nerfds_trainer nerfds_trainer;
 /* Weights of the auxiliary first-order losses added to the rgb loss of EACH level (0 = off): warp regulariser at the median-depth
  * sample (training.py:297-310, utils.general_loss_with_squared_residual), back-facing regulariser on the raw predicted normal
@@ -283,6 +283,9 @@ typedef struct nerfds_train_objective {
   float predicted_mask_loss_weight, sharp_weights_std;
   int32_t use_mask_sharp_weights;
   float norm_loss_weight;
+  /* hyper-point regulariser (training.py:312-321): mean over rays of sum_s w_s * general_loss(|ambient coordinates|^2, alpha 0, scale 0.05),
+   * the weights as constants; reported in loss_host[10] (fine) / [11] (coarse) */
+  float hyper_reg_loss_weight;
 } nerfds_train_objective;
 #define NERFDS_TRAIN_GRADS_ONLY 1u
 #define NERFDS_TRAIN_SIGMA_GRAD 2u   /* also evaluate the sigma gradient (models.py:1035-1077) -> nerfds_trainer_target_norm */
@@ -309,7 +312,7 @@ int nerfds_trainer_set_step(nerfds_trainer* t, int64_t step);   /* the optimizer
 long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* host, long long max_bytes);
 int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* extra,
                         const nerfds_rand* rnd, const nerfds_train_objective* objective /* NULL = rgb loss only */, float learning_rate,
-                        uint32_t flags, float* loss_host /* HOST float[10] or NULL */, void* hip_stream);
+                        uint32_t flags, float* loss_host /* HOST float[12] or NULL */, void* hip_stream);
 /* One Adam update with the gradient vector as it stands (after a NERFDS_TRAIN_GRADS_ONLY step and, on N GPUs, after the
  * all-reduce of nerfds_trainer_grads that replaces jax.lax.pmean(grad), training.py:502). */
 int nerfds_trainer_apply(nerfds_trainer* t, float learning_rate, void* hip_stream);

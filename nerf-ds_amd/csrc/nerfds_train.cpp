@@ -142,7 +142,7 @@ struct nerfds_trainer {
   // workspace views (set by carve())
   float *zc, *zf, *wc, *rs_scratch, *x, *mask_in, *mask_logit, *warp_in, *wv, *xw, *hyper_in, *wamb, *trunk_in, *bottv, *alphav, *sigma,
       *cond, *rgb_hv, *rgb_logit, *weights, *rgb_ray, *g0, *g1, *g2, *d_trunk_in, *d_rgb_logit, *d_alpha, *dxw, *dwamb, *dwv, *d_warp_in,
-      *d_hyper_in, *d_mask_in, *d_mask_logit, *dxw_reg, *d_pm;
+      *d_hyper_in, *d_mask_in, *d_mask_logit, *dxw_reg, *d_pm, *dwamb_reg;
   float* terms_dev = nullptr;   // [2 levels][4]: weighted warp_reg, back_facing, mask terms of the last step
   std::vector<float*> mask_h, warp_h, hyper_h, trunk_h;
 
@@ -468,7 +468,7 @@ void carve(nerfds_trainer& t) {
   take(&t.g0, M * t.trunk[0].width); take(&t.g1, M * t.trunk[0].width); take(&t.g2, M * t.trunk[0].width);
   take(&t.d_trunk_in, M * D.trunk_in); take(&t.d_rgb_logit, M * 3); take(&t.d_alpha, M * 4); take(&t.dxw, M * 3); take(&t.dwamb, M * 2);
   take(&t.dwv, M * 6); take(&t.d_warp_in, M * D.warp_ld); take(&t.d_hyper_in, M * D.hyper_ld); take(&t.d_mask_in, M * D.mask_in);
-  take(&t.d_mask_logit, M); take(&t.dxw_reg, M * 3); take(&t.d_pm, M);
+  take(&t.d_mask_logit, M); take(&t.dxw_reg, M * 3); take(&t.d_pm, M); take(&t.dwamb_reg, M * 2);
   t.ws_floats = need;
   // (pointers into vectors: the vectors are not resized after this point)
   float* base = t.ws;
@@ -926,8 +926,9 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   if (want_sigma_gradient) sigma_gradient(t, r, level, W);
   if (ob)     // auxiliary first-order losses: extra upstream gradients for x', the raw normal and the predicted mask
     aux_losses(st, R, S, *ob, z, weights_out, t.x, t.xw, t.alphav, viewdirs, t.mask_logit, rays->gt_mask, t.terms_dev + 4 * level, t.dxw_reg,
-               t.d_alpha, t.d_pm);
+               t.d_alpha, t.d_pm, t.wamb, t.terms_dev + 9 + level, t.dwamb_reg);
   const bool nl = norm_weight != 0.f;
+  const bool hreg = ob && ob->hyper_reg_weight != 0.f;      // hyper-point regulariser: one more upstream gradient of the ambient coordinates
   if (nl) norm_loss(st, R, S, norm_weight, weights_out, t.alphav, t.t_alpha, t.wv, t.tn[level], t.terms_dev + 4 * level + 3, t.d_alpha, t.d_t_alpha,
                     t.du, t.ghat);
   // ---------------- backward ----------------
@@ -962,7 +963,7 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
     };
     fused_backward(t, st, 0, level, M, t.d_rgb_logit, 3, t.d_alpha, t.d_trunk_in, D.trunk_in);
     if (early) { r.fork(false); wg_nerf(); }
-    trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, nullptr, t.dxw, t.dwamb);
+    trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, hreg ? t.dwamb_reg : nullptr, t.dxw, t.dwamb);
     fused_backward(t, st, 1, level, M, t.dwamb, 2, nullptr, t.d_hyper_in, D.hyper_ld);
     if (early) { r.fork(false); wg_hyper(); }
     se3_bwd(st, M, t.wv, t.x, t.dxw, nullptr, t.dwv);
@@ -990,8 +991,9 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
     pm = r.dense_jvp_bwd(t.alpha[level], {{t.tt_h.back(), TW, TW, t.tA, TW, false, tout, nullptr}}, t.d_t_alpha, 4, nullptr);
     r.mlp_jvp_bwd(trunk, t.t_tin, t.tt_h, t.trunk_h, t.tA, t.tB, t.d_t_tin, pm);
     trunk_in_jvp_bwd(st, D, M, t.d_t_tin, t.xw, t.wamb, t.t_xw, t.t_wamb, W, t.d_t_xw, t.d_t_wamb, t.dxw_reg, t.dwamb_extra);
+    if (hreg) add_inplace(st, t.dwamb_extra, t.dwamb_reg, 2 * M);      // both extra gradients of the ambient coordinates in one array
   }
-  trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, nl ? t.dwamb_extra : nullptr, t.dxw, t.dwamb);
+  trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, nl ? t.dwamb_extra : (hreg ? t.dwamb_reg : nullptr), t.dxw, t.dwamb);
   if (nl) {   // part 2: hyper sheet tangents
     pm = r.dense_jvp_bwd(t.hyper_out, {{t.th_h.back(), t.hyper.width, t.hyper.width, t.tA, t.hyper.width, false, t.hyper_h.back(), nullptr}}, t.d_t_wamb, 2, nullptr);
     r.mlp_jvp_bwd(t.hyper, t.t_hyper_in, t.th_h, t.hyper_h, t.tA, t.tB, nullptr, pm);
@@ -1300,11 +1302,13 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     ob.warp_reg_weight = objective->warp_reg_loss_weight; ob.warp_reg_alpha = objective->warp_reg_loss_alpha; ob.warp_reg_scale = objective->warp_reg_loss_scale;
     ob.back_facing_weight = objective->back_facing_reg_weight; ob.mask_loss_weight = objective->predicted_mask_loss_weight;
     ob.sharp_weights_std = objective->sharp_weights_std; ob.use_sharp_weights = objective->use_mask_sharp_weights;
+    ob.hyper_reg_weight = objective->hyper_reg_loss_weight;
     if (ob.mask_loss_weight != 0.f && !rays->gt_mask) return t->fail(NERFDS_EINVAL, "the mask loss needs rays_dict['mask']");
     if (ob.use_sharp_weights && !(ob.sharp_weights_std > 0.f)) return t->fail(NERFDS_EINVAL, "sharp_weights_std must be > 0");
     obp = &ob;
   }
   (void)hipMemsetAsync(t->terms_dev, 0, 8 * sizeof(float), st);
+  (void)hipMemsetAsync(t->terms_dev + 9, 0, 2 * sizeof(float), st);          // [9], [10]: hyper-point regulariser of the coarse / fine level ([8]: non-finite flag)
   const float norm_weight = objective ? objective->norm_loss_weight : 0.f;
   const bool want_sg = (flags & NERFDS_TRAIN_SIGMA_GRAD) != 0 || norm_weight != 0.f;
   // the tangent passes (sigma gradient, norm loss) read the fp32 activations: those steps keep the layer-by-layer backward
@@ -1355,7 +1359,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     float l[2];
     if (hipMemcpyAsync(l, t->loss_dev, sizeof l, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       return t->fail(NERFDS_EDEVICE, "loss read-back failed");
-    float tm[9];
+    float tm[11];
     if (hipMemcpy(tm, t->terms_dev, sizeof tm, hipMemcpyDeviceToHost) != hipSuccess) return t->fail(NERFDS_EDEVICE, "loss read-back failed");
     unsigned nonfinite = 0;
     std::memcpy(&nonfinite, &tm[8], sizeof nonfinite);
@@ -1363,6 +1367,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     loss_host[0] = l[fl];     // rgb loss of the fine level (the level render_image returns; coarse if there is none), of the coarse level
     loss_host[1] = l[0];
     for (int k = 0; k < 4; ++k) { loss_host[2 + k] = tm[4 * fl + k]; loss_host[6 + k] = tm[k]; }   // weighted warp_reg / back_facing / mask / norm terms: fine, coarse
+    loss_host[10] = tm[9 + fl]; loss_host[11] = tm[9];                                                // weighted hyper-point regulariser: fine, coarse
     if (nonfinite && !(flags & NERFDS_TRAIN_GRADS_ONLY))
       return t->fail(NERFDS_ENONFINITE, "non-finite gradient: the Adam update of this step was skipped (f16 activations / scaled f16 g overflowed? NERFDS_TRAIN_G16=0 "
                                         "keeps g in fp32; a step with the sigma-gradient flag keeps fp32 activations)");

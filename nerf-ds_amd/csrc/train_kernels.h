@@ -18,6 +18,7 @@ struct Windows {   // posenc windows (model_utils.py:420-436), one weight per ba
 struct Objective {   // weights of the auxiliary losses (0 = off); mirrors nerfds_train_objective
   float warp_reg_weight, warp_reg_alpha, warp_reg_scale, back_facing_weight, mask_loss_weight, sharp_weights_std;
   int use_sharp_weights;
+  float hyper_reg_weight;
 };
 
 void coarse_z(hipStream_t, int R, int Nc, float near_, float far_, int stratified, int lindisp, const float* t_rand, uint64_t seed, long long first_ray, float* z);
@@ -42,7 +43,9 @@ void trunk_in_jvp_bwd(hipStream_t, const Dims&, long long M, const float* d_t_ti
 void se3_jvp_bwd(hipStream_t, long long M, const float* wv, const float* x, const float* t_wv, const float* d_t_xw, const float* du,
                  const float* ghat, float* d_t_wv, float* dwv_extra);
 void aux_losses(hipStream_t, int R, int S, const Objective&, const float* z, const float* weights, const float* x, const float* xw, const float* alpha,
-                const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg, float* d_alpha, float* d_pm);
+                const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg, float* d_alpha, float* d_pm,
+                const float* wamb = nullptr, float* term_hyper = nullptr, float* dwamb_reg = nullptr);   // hyper-point regulariser: ambient coordinates in, its term and d / d wamb out
+void add_inplace(hipStream_t, float* dst, const float* src, long long n);
 void alpha_post(hipStream_t, const Dims&, int R, int S, const float* alpha, const float* wv, const float* viewdirs, const Windows&, float* sigma, float* cond);
 void composite_loss(hipStream_t, int R, int S, const float* z, const float* dirs, const float* sigma, const float* rgb_logit, const float* target,
                     int at_infinity, int white, float* rgb_ray, float* weights, float* loss, float* d_rgb_logit, float* d_alpha);

@@ -734,10 +734,25 @@ __device__ __forceinline__ float general_loss_sq(float x_sq, float alpha, float 
 __global__ void k_aux_losses(int R, int S, Objective ob, const float* __restrict__ z, const float* __restrict__ weights, const float* __restrict__ x,
                              const float* __restrict__ xw, const float* __restrict__ alpha, const float* __restrict__ viewdirs,
                              const float* __restrict__ mask_logit, const float* __restrict__ gt_mask, float* __restrict__ terms,
-                             float* __restrict__ dxw_reg, float* __restrict__ d_alpha, float* __restrict__ d_pm) {
+                             float* __restrict__ dxw_reg, float* __restrict__ d_alpha, float* __restrict__ d_pm, const float* __restrict__ wamb,
+                             float* __restrict__ term_hyper, float* __restrict__ dwamb_reg) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const float* w = weights + (size_t)r * S;
+  // hyper-point regulariser (training.py:312-321): (w * general_loss(|ambient|^2, alpha 0, scale 0.05)).sum(1).mean(), w constant
+  if (ob.hyper_reg_weight != 0.f && wamb != nullptr) {
+    const float k = ob.hyper_reg_weight / (float)R;
+    float l = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const size_t m = (size_t)r * S + s;
+      const float a0 = wamb[2 * m], a1 = wamb[2 * m + 1];
+      float dl;
+      l += w[s] * general_loss_sq(a0 * a0 + a1 * a1, 0.0f, 0.05f, dl);
+      dwamb_reg[2 * m] = k * w[s] * dl * 2.0f * a0;
+      dwamb_reg[2 * m + 1] = k * w[s] * dl * 2.0f * a1;
+    }
+    atomicAdd(term_hyper, k * l);
+  }
   // median-depth index (model_utils.py:272-299): first s with cumsum(w) >= 0.5, else 0; arg-max of the weights
   int med = 0, amax = 0;
   {
@@ -1021,10 +1036,15 @@ void se3_jvp_bwd(hipStream_t st, long long M, const float* wv, const float* x, c
 }
 void aux_losses(hipStream_t st, int R, int S, const Objective& ob, const float* z, const float* weights, const float* x, const float* xw,
                 const float* alpha, const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg,
-                float* d_alpha, float* d_pm) {
+                float* d_alpha, float* d_pm, const float* wamb, float* term_hyper, float* dwamb_reg) {
   hipLaunchKernelGGL(k_aux_losses, grid1(R, 64), dim3(64), 0, st, R, S, ob, z, weights, x, xw, alpha, viewdirs, mask_logit, gt_mask, terms, dxw_reg,
-                     d_alpha, d_pm);
+                     d_alpha, d_pm, wamb, term_hyper, dwamb_reg);
 }
+__global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, long long n) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+void add_inplace(hipStream_t st, float* dst, const float* src, long long n) { LAUNCH(k_add_inplace, n, st, dst, src, n); }
 void alpha_post(hipStream_t st, const Dims& D, int R, int S, const float* alpha, const float* wv, const float* viewdirs, const Windows& W, float* sigma, float* cond) {
   hipLaunchKernelGGL(k_alpha_post, grid1((long long)R * S, TILE_ROWS), dim3(TILE_ROWS), tile_bytes(6 * D.vd_bands + 6 * D.nm_bands), st, D, R, S, alpha, wv, viewdirs, W,
                      sigma, cond);

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFDS_LIB', os.path.join(_HERE, '_lib', 'libnerfds_hip.so'))   # NERFDS_LIB: development builds
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def resolve_device(device=None):

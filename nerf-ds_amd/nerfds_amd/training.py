@@ -20,7 +20,7 @@ SIGMA_GRAD = 2
 class Objective(C.Structure):
   _fields_ = [('warp_reg_loss_weight', C.c_float), ('warp_reg_loss_alpha', C.c_float), ('warp_reg_loss_scale', C.c_float),
               ('back_facing_reg_weight', C.c_float), ('predicted_mask_loss_weight', C.c_float), ('sharp_weights_std', C.c_float),
-              ('use_mask_sharp_weights', C.c_int32), ('norm_loss_weight', C.c_float)]
+              ('use_mask_sharp_weights', C.c_int32), ('norm_loss_weight', C.c_float), ('hyper_reg_loss_weight', C.c_float)]
 
 
 class _DevVec:
@@ -248,13 +248,14 @@ class Trainer:
       t = f32(t_rand).reshape(R, self.cfg.num_coarse_samples); keep.append(t); rnd.t_rand = t.data_ptr()
     if u_rand is not None and self.cfg.num_fine_samples > 0:
       u = f32(u_rand).reshape(R, self.cfg.num_fine_samples); keep.append(u); rnd.u_rand = u.data_ptr()
-    loss = (C.c_float * 10)()
+    loss = (C.c_float * 12)()
     ob = None
     if objective:       # scalar_params / SpecularConfig names (training.py:36-56)
       ob = Objective(warp_reg_loss_weight=objective.get('warp_reg_loss_weight', 0.0), warp_reg_loss_alpha=objective.get('warp_reg_loss_alpha', -2.0),
                      warp_reg_loss_scale=objective.get('warp_reg_loss_scale', 0.001), back_facing_reg_weight=objective.get('back_facing_reg_weight', 0.0),
                      predicted_mask_loss_weight=objective.get('predicted_mask_loss_weight', 0.0), sharp_weights_std=objective.get('sharp_weights_std', 1.0),
-                     use_mask_sharp_weights=int(self.cfg.use_mask_sharp_weights), norm_loss_weight=objective.get('norm_loss_weight', 0.0))
+                     use_mask_sharp_weights=int(self.cfg.use_mask_sharp_weights), norm_loss_weight=objective.get('norm_loss_weight', 0.0),
+                     hyper_reg_loss_weight=objective.get('hyper_reg_loss_weight', 0.0))
     s = stream if stream is not None else torch.cuda.current_stream(dev)
     import torch.distributed as dist
     grouped = dist.is_available() and dist.is_initialized()
@@ -289,6 +290,8 @@ class Trainer:
     for k, name in enumerate(('warp_reg', 'back_facing', 'predicted_mask', 'norm')):
       stats[f'loss/{name}/fine'], stats[f'loss/{name}/coarse'] = float(loss[2 + k]), float(loss[6 + k])
       aux += (float(loss[2 + k]) if two else 0.0) + float(loss[6 + k])
+    stats['loss/hyper_reg/fine'], stats['loss/hyper_reg/coarse'] = float(loss[10]), float(loss[11])      # training.py:312-321
+    aux += (float(loss[10]) if two else 0.0) + float(loss[11])
     stats['loss/total'] = (fine + coarse if two else coarse) + aux
     return stats
 

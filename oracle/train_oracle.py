@@ -53,6 +53,9 @@ def auxiliary_losses(cfg, out, rays_dict, objective, dtype):
     gt = torch.as_tensor(np.asarray(rays_dict['mask'])).to(dtype).reshape(-1)
     w = out['sharp_weights'].detach() if cfg.use_mask_sharp_weights else weights
     terms['predicted_mask'] = objective['predicted_mask_loss_weight'] * ((gt - (w * pm).sum(-1)) ** 2).mean()
+  if objective.get('hyper_reg_loss_weight', 0.0):                              # training.py:312-321
+    resid = (out['warped_points'][..., 3:] ** 2).sum(-1)
+    terms['hyper_reg'] = objective['hyper_reg_loss_weight'] * (weights * general_loss_with_squared_residual(resid, 0.0, 0.05)).sum(1).mean()
   if objective.get('norm_loss_weight', 0.0):                                   # training.py:323-332 (second order: target_norm is NOT detached)
     diff = out['predicted_norm'] - out['target_norm']
     terms['norm'] = objective['norm_loss_weight'] * (weights * torch.sqrt((diff ** 2).sum(-1))).mean()

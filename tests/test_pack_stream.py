@@ -25,7 +25,7 @@ def test_library_loads_and_exports_header_symbols():
   assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
   for s in declared:
     assert hasattr(lib, s), s
-  assert lib.nerfds_abi_version() == N.ABI_VERSION == 4
+  assert lib.nerfds_abi_version() == N.ABI_VERSION == 5
 
 
 def test_ctx_create_errors_without_touching_a_gpu():

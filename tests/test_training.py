@@ -302,19 +302,23 @@ OBJECTIVE = dict(warp_reg_loss_weight=0.001, warp_reg_loss_alpha=-2.0, warp_reg_
 @pytest.mark.gpu
 @pytest.mark.parametrize('sharp', [True, False])
 def test_auxiliary_losses_match_the_oracle(sharp, gemm):
-  """warp regulariser, back-facing regulariser and 3-D mask supervision of the reference objective (everything but the
-  second-order norm loss): loss terms and the full gradient vs autograd."""
+  """warp regulariser, back-facing regulariser, 3-D mask supervision and hyper-point regulariser of the reference objective (everything
+  but the second-order norm loss): loss terms and the full gradient vs autograd."""
   from nerfds_amd.training import Trainer
   from oracle import train_oracle as T
   cfg, params, batch, t, u = _problem(40, 12, 12)
   cfg = cfg.replace(use_mask_sharp_weights=sharp)
   # give the mask / normal heads something to supervise (the init regime has relu(mask logit) == 0 everywhere)
   params['mask_mlp']['MLP_0']['logit']['bias'] = np.asarray(params['mask_mlp']['MLP_0']['logit']['bias']) + 0.7      # logits span [-1.0, -0.35] at init: make relu(logit) a mix of zeros and positives
-  L, G, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=OBJECTIVE)
+  ob = dict(OBJECTIVE, hyper_reg_loss_weight=0.01)      # + the hyper-point regulariser (training.py:312-321; off in nerf_ds.gin, on in HyperNeRF's own configs)
+  L, G, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=ob)
+  L0, G0, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=OBJECTIVE)
   tr = Trainer(cfg, params, max_rays=40)
-  stats = tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=OBJECTIVE)
+  stats = tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=ob)
+  hs = np.linalg.norm(dict(tree_leaves(G))['hyper_sheet_mlp/MLP_0/logit/kernel'] - dict(tree_leaves(G0))['hyper_sheet_mlp/MLP_0/logit/kernel'])
+  assert hs > 0.05 * np.linalg.norm(dict(tree_leaves(G0))['hyper_sheet_mlp/MLP_0/logit/kernel'])      # the regulariser moves the hyper sheet's gradient visibly
   for level in ('fine', 'coarse'):
-    for k in ('warp_reg', 'back_facing', 'predicted_mask'):
+    for k in ('warp_reg', 'back_facing', 'predicted_mask', 'hyper_reg'):
       want = L[f'{k}/{level}']
       assert abs(stats[f'loss/{k}/{level}'] - want) <= 2e-4 * max(abs(want), 1e-4), (k, level, stats[f'loss/{k}/{level}'], want)
   assert abs(stats['loss/total'] - L['total']) < 1e-4 * L['total']
@@ -342,7 +346,7 @@ def test_norm_loss_second_order_matches_the_oracle(only_norm, gemm):
   # (16 + 16 samples: at 8 + 8 one sample of this seed sits on a ReLU boundary of the fp32 primal pass, which flips its mask
   # w.r.t. the fp64 oracle and moves a few leaves by 1 % - inherent to comparing fp32 with fp64 at a kink, not a bug)
   cfg, params, batch, t, u = _problem(24, 16, 16)
-  ob = dict(norm_loss_weight=0.05) if only_norm else dict(OBJECTIVE, norm_loss_weight=0.05)
+  ob = dict(norm_loss_weight=0.05) if only_norm else dict(OBJECTIVE, norm_loss_weight=0.05, hyper_reg_loss_weight=0.01)
   L, G, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=ob)
   L0, G0, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective={k: v for k, v in ob.items() if k != 'norm_loss_weight'} or None)
   tr = Trainer(cfg, params, max_rays=24)
