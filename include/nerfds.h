@@ -269,8 +269,8 @@ int nerfds_frame_images(int device, const float* ray_records, int32_t height, in
  * ONE launch of the fused field kernel (the render kernel's evaluation, writing every activation the backward reads; its weight streams
  * are re-packed on the device from the parameter vector at the start of every step); other widths, and the whole backward, run layer by
  * layer on the library's own MFMA kernels: a layer shape they do not cover is NERFDS_ENOTSUP (there is no library-GEMM detour).  The auxiliary losses of
- * configs/nerf_ds.gin and the hyper-point regulariser are selected by nerfds_train_objective; the elastic and background losses (off in
- * every shipped gin) are not built. */
+ * configs/nerf_ds.gin, the hyper-point regulariser and the background regulariser are selected by nerfds_train_objective; the elastic loss
+ * (off in every shipped gin) is not built. */
 typedef struct nerfds_trainer nerfds_trainer;
 /* Weights of the auxiliary first-order losses added to the rgb loss of EACH level (0 = off): warp regulariser at the median-depth
  * sample (training.py:297-310, utils.general_loss_with_squared_residual), back-facing regulariser on the raw predicted normal
@@ -286,6 +286,15 @@ typedef struct nerfds_train_objective {
   /* hyper-point regulariser (training.py:312-321): mean over rays of sum_s w_s * general_loss(|ambient coordinates|^2, alpha 0, scale 0.05),
    * the weights as constants; reported in loss_host[10] (fine) / [11] (coarse) */
   float hyper_reg_loss_weight;
+  /* background regulariser (training.py:159-183, 468-479): background_loss_weight * mean over the points of
+   * general_loss(|warp(x) - x|^2, background_loss_alpha, background_loss_scale), warp = NerfModel.apply_warp (the SE(3) field with the GLO row
+   * of background_ids and mask 0, models.py:766-773).  background_points: DEVICE [num_background_points][3] - the caller has added its noise
+   * (training.py:163-165) -, background_ids: DEVICE uint32 [num_background_points] (the reference draws them at random among the warp ids);
+   * at most max_rays * (Nc + Nf) points.  Reported in loss_host[12]. */
+  float background_loss_weight, background_loss_alpha, background_loss_scale;
+  const float* background_points;
+  const uint32_t* background_ids;
+  int64_t num_background_points;
 } nerfds_train_objective;
 #define NERFDS_TRAIN_GRADS_ONLY 1u
 #define NERFDS_TRAIN_SIGMA_GRAD 2u   /* also evaluate the sigma gradient (models.py:1035-1077) -> nerfds_trainer_target_norm */
@@ -312,7 +321,7 @@ int nerfds_trainer_set_step(nerfds_trainer* t, int64_t step);   /* the optimizer
 long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* host, long long max_bytes);
 int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* extra,
                         const nerfds_rand* rnd, const nerfds_train_objective* objective /* NULL = rgb loss only */, float learning_rate,
-                        uint32_t flags, float* loss_host /* HOST float[12] or NULL */, void* hip_stream);
+                        uint32_t flags, float* loss_host /* HOST float[16] or NULL: [0..12] used, the rest 0 */, void* hip_stream);
 /* One Adam update with the gradient vector as it stands (after a NERFDS_TRAIN_GRADS_ONLY step and, on N GPUs, after the
  * all-reduce of nerfds_trainer_grads that replaces jax.lax.pmean(grad), training.py:502). */
 int nerfds_trainer_apply(nerfds_trainer* t, float learning_rate, void* hip_stream);

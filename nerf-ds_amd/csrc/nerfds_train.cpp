@@ -875,6 +875,36 @@ int run_merged(nerfds_trainer& t, hipStream_t st, int R, const float* zc, const 
   return NERFDS_OK;
 }
 
+// Background regulariser (training.py:159-183, 468-479): the SE(3) field alone on a batch of points that should not move, each with the GLO row of
+// its id and mask 0 (models.py:766-773 apply_warp), loss = weight * mean general_loss(|warp(x) - x|^2).  Runs after the levels on their (now free)
+// buffers, layer by layer on the MFMA layer kernels (the three-way split forward of the warp field, as every step's): points as "rays" of one
+// sample at depth 0, so the encodings, the GLO gather and the GLO table's gradient are the step's own kernels.
+int run_background(nerfds_trainer& t, hipStream_t st, const nerfds_train_objective& o, const Windows& W) {
+  const Dims& D = t.D;
+  const int64_t B = o.num_background_points;
+  const int WW = t.warp.width;
+  Run r{t, st, B};
+  (void)hipMemsetAsync(t.sigma, 0, (size_t)B * sizeof(float), st);                    // depth 0 and mask logit 0 for every point
+  (void)hipMemsetAsync(t.d_hyper_in, 0, (size_t)B * D.hyper_ld * sizeof(float), st);  // the hyper sheet is not part of apply_warp
+  encode_inputs(st, D, (int)B, 1, o.background_points, o.background_points, t.sigma, o.background_ids, t.cfg.num_warp_embeds, t.theta + t.warp_tbl,
+                t.theta + t.mask_tbl, W, t.x, t.mask_in, t.warp_in, t.hyper_in);
+  mask_post(st, D, (int)B, 1, t.sigma, nullptr, 1.0f, t.warp_in, t.hyper_in);         // "assume background has 0 mask"
+  r.precise_layers = true;
+  r.mlp_fwd(t.warp, t.warp_in, t.warp_h);
+  r.dense_fwd(t.warp_w, {{t.warp_h.back(), WW, WW, nullptr, 0, false}}, t.wv, 6, false);
+  r.dense_fwd(t.warp_v, {{t.warp_h.back(), WW, WW, nullptr, 0, false}}, t.wv + 3, 6, false);
+  r.precise_layers = false;
+  se3_fwd(st, B, t.wv, t.x, t.xw);
+  background_loss(st, B, t.x, t.xw, o.background_loss_weight, o.background_loss_alpha, o.background_loss_scale, t.terms_dev + 11, t.dxw);
+  se3_bwd(st, B, t.wv, t.x, t.dxw, nullptr, t.dwv);
+  r.dense_bwd(t.warp_w, {{t.warp_h.back(), WW, WW, t.g0, WW, false}}, t.dwv, 6, nullptr);
+  const bool pm = r.dense_bwd(t.warp_v, {{t.warp_h.back(), WW, WW, t.g0, WW, true, t.warp_h.back(), t.grad + t.warp.hidden.back().b}}, t.dwv + 3, 6, nullptr);
+  r.mlp_bwd(t.warp, t.warp_in, t.warp_h, t.g0, t.g1, t.d_warp_in, pm);
+  shared_in_bwd(st, D, (int)B, 1, t.d_warp_in, t.d_hyper_in, t.sigma, 1.0f, nullptr, o.background_ids, t.cfg.num_warp_embeds, t.grad + t.warp_tbl, t.d_mask_logit);
+  if (!r.ok) return t.fail(NERFDS_ENOTSUP, "%s", r.unsupported_what.c_str());
+  return NERFDS_OK;
+}
+
 int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const float* z, const nerfds_rays* rays, const float* target,
               const nerfds_extra* ex, const Windows& W, float* weights_out, bool want_sigma_gradient, const Objective* ob,
               float norm_weight) {
@@ -1305,10 +1335,18 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     ob.hyper_reg_weight = objective->hyper_reg_loss_weight;
     if (ob.mask_loss_weight != 0.f && !rays->gt_mask) return t->fail(NERFDS_EINVAL, "the mask loss needs rays_dict['mask']");
     if (ob.use_sharp_weights && !(ob.sharp_weights_std > 0.f)) return t->fail(NERFDS_EINVAL, "sharp_weights_std must be > 0");
-    obp = &ob;
+    // (a background-only objective keeps the plain - merged - flow of the levels: the per-ray auxiliary kernel has nothing to do)
+    if (ob.warp_reg_weight != 0.f || ob.back_facing_weight != 0.f || ob.mask_loss_weight != 0.f || ob.hyper_reg_weight != 0.f || objective->norm_loss_weight != 0.f)
+      obp = &ob;
+    if (objective->background_loss_weight != 0.f) {
+      if (!objective->background_points || !objective->background_ids || objective->num_background_points < 1)
+        return t->fail(NERFDS_EINVAL, "the background loss needs background_points and background_ids");
+      if (objective->num_background_points > (int64_t)t->max_rays * (Nc + Nf))
+        return t->fail(NERFDS_EINVAL, "at most max_rays * (Nc + Nf) = %lld background points per step", (long long)t->max_rays * (Nc + Nf));
+    }
   }
   (void)hipMemsetAsync(t->terms_dev, 0, 8 * sizeof(float), st);
-  (void)hipMemsetAsync(t->terms_dev + 9, 0, 2 * sizeof(float), st);          // [9], [10]: hyper-point regulariser of the coarse / fine level ([8]: non-finite flag)
+  (void)hipMemsetAsync(t->terms_dev + 9, 0, 3 * sizeof(float), st);          // [9], [10]: hyper-point regulariser of the coarse / fine level, [11]: background loss ([8]: non-finite flag)
   const float norm_weight = objective ? objective->norm_loss_weight : 0.f;
   const bool want_sg = (flags & NERFDS_TRAIN_SIGMA_GRAD) != 0 || norm_weight != 0.f;
   // the tangent passes (sigma gradient, norm loss) read the fp32 activations: those steps keep the layer-by-layer backward
@@ -1340,6 +1378,10 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     if (rc != NERFDS_OK) return rc;
   }
   }
+  if (objective && objective->background_loss_weight != 0.f) {
+    rc = run_background(*t, st, *objective, W);
+    if (rc != NERFDS_OK) return rc;
+  }
   if (t->grad_rep) sum_partials(st, t->grad_rep, GRAD_REPS, t->P, t->grad);      // grad += the replicas of the MFMA kernels
   if (t->half_step) {
     // Fused backward: the bottleneck Dense (no activation, modules.py:255) never ran as a layer.  With S = trunk_out^T g_rgb (the
@@ -1359,7 +1401,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     float l[2];
     if (hipMemcpyAsync(l, t->loss_dev, sizeof l, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       return t->fail(NERFDS_EDEVICE, "loss read-back failed");
-    float tm[11];
+    float tm[12];
     if (hipMemcpy(tm, t->terms_dev, sizeof tm, hipMemcpyDeviceToHost) != hipSuccess) return t->fail(NERFDS_EDEVICE, "loss read-back failed");
     unsigned nonfinite = 0;
     std::memcpy(&nonfinite, &tm[8], sizeof nonfinite);
@@ -1368,6 +1410,8 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     loss_host[1] = l[0];
     for (int k = 0; k < 4; ++k) { loss_host[2 + k] = tm[4 * fl + k]; loss_host[6 + k] = tm[k]; }   // weighted warp_reg / back_facing / mask / norm terms: fine, coarse
     loss_host[10] = tm[9 + fl]; loss_host[11] = tm[9];                                                // weighted hyper-point regulariser: fine, coarse
+    loss_host[12] = tm[11];                                                                            // weighted background regulariser
+    loss_host[13] = loss_host[14] = loss_host[15] = 0.f;
     if (nonfinite && !(flags & NERFDS_TRAIN_GRADS_ONLY))
       return t->fail(NERFDS_ENONFINITE, "non-finite gradient: the Adam update of this step was skipped (f16 activations / scaled f16 g overflowed? NERFDS_TRAIN_G16=0 "
                                         "keeps g in fp32; a step with the sigma-gradient flag keeps fp32 activations)");

@@ -46,6 +46,8 @@ void aux_losses(hipStream_t, int R, int S, const Objective&, const float* z, con
                 const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg, float* d_alpha, float* d_pm,
                 const float* wamb = nullptr, float* term_hyper = nullptr, float* dwamb_reg = nullptr);   // hyper-point regulariser: ambient coordinates in, its term and d / d wamb out
 void add_inplace(hipStream_t, float* dst, const float* src, long long n);
+// background regulariser (training.py:159-183): term += weight * mean_i general_loss(|xw_i - x_i|^2, alpha, scale); dxw = its gradient w.r.t. xw
+void background_loss(hipStream_t, long long B, const float* x, const float* xw, float weight, float alpha, float scale, float* term, float* dxw);
 void alpha_post(hipStream_t, const Dims&, int R, int S, const float* alpha, const float* wv, const float* viewdirs, const Windows&, float* sigma, float* cond);
 void composite_loss(hipStream_t, int R, int S, const float* z, const float* dirs, const float* sigma, const float* rgb_logit, const float* target,
                     int at_infinity, int white, float* rgb_ray, float* weights, float* loss, float* d_rgb_logit, float* d_alpha);

@@ -1045,6 +1045,24 @@ __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__
   if (i < n) dst[i] += src[i];
 }
 void add_inplace(hipStream_t st, float* dst, const float* src, long long n) { LAUNCH(k_add_inplace, n, st, dst, src, n); }
+__global__ void k_background_loss(long long B, const float* __restrict__ x, const float* __restrict__ xw, float weight, float alpha, float scale,
+                                  float* __restrict__ term, float* __restrict__ dxw) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  float l = 0.f;
+  if (i < B) {
+    float dv[3], sq = 0.f;
+    for (int c = 0; c < 3; ++c) { dv[c] = xw[3 * i + c] - x[3 * i + c]; sq += dv[c] * dv[c]; }
+    float dl;
+    l = general_loss_sq(sq, alpha, scale, dl) * weight / (float)B;
+    for (int c = 0; c < 3; ++c) dxw[3 * i + c] = weight / (float)B * dl * 2.0f * dv[c];
+  }
+  // one atomic per wave
+  for (int d = 32; d >= 1; d >>= 1) l += __shfl_xor(l, d, 64);
+  if ((threadIdx.x & 63) == 0 && l != 0.f) atomicAdd(term, l);
+}
+void background_loss(hipStream_t st, long long B, const float* x, const float* xw, float weight, float alpha, float scale, float* term, float* dxw) {
+  LAUNCH(k_background_loss, B, st, B, x, xw, weight, alpha, scale, term, dxw);
+}
 void alpha_post(hipStream_t st, const Dims& D, int R, int S, const float* alpha, const float* wv, const float* viewdirs, const Windows& W, float* sigma, float* cond) {
   hipLaunchKernelGGL(k_alpha_post, grid1((long long)R * S, TILE_ROWS), dim3(TILE_ROWS), tile_bytes(6 * D.vd_bands + 6 * D.nm_bands), st, D, R, S, alpha, wv, viewdirs, W,
                      sigma, cond);

@@ -20,7 +20,9 @@ SIGMA_GRAD = 2
 class Objective(C.Structure):
   _fields_ = [('warp_reg_loss_weight', C.c_float), ('warp_reg_loss_alpha', C.c_float), ('warp_reg_loss_scale', C.c_float),
               ('back_facing_reg_weight', C.c_float), ('predicted_mask_loss_weight', C.c_float), ('sharp_weights_std', C.c_float),
-              ('use_mask_sharp_weights', C.c_int32), ('norm_loss_weight', C.c_float), ('hyper_reg_loss_weight', C.c_float)]
+              ('use_mask_sharp_weights', C.c_int32), ('norm_loss_weight', C.c_float), ('hyper_reg_loss_weight', C.c_float),
+              ('background_loss_weight', C.c_float), ('background_loss_alpha', C.c_float), ('background_loss_scale', C.c_float),
+              ('background_points', C.c_void_p), ('background_ids', C.c_void_p), ('num_background_points', C.c_int64)]
 
 
 class _DevVec:
@@ -248,7 +250,7 @@ class Trainer:
       t = f32(t_rand).reshape(R, self.cfg.num_coarse_samples); keep.append(t); rnd.t_rand = t.data_ptr()
     if u_rand is not None and self.cfg.num_fine_samples > 0:
       u = f32(u_rand).reshape(R, self.cfg.num_fine_samples); keep.append(u); rnd.u_rand = u.data_ptr()
-    loss = (C.c_float * 12)()
+    loss = (C.c_float * 16)()
     ob = None
     if objective:       # scalar_params / SpecularConfig names (training.py:36-56)
       ob = Objective(warp_reg_loss_weight=objective.get('warp_reg_loss_weight', 0.0), warp_reg_loss_alpha=objective.get('warp_reg_loss_alpha', -2.0),
@@ -256,6 +258,24 @@ class Trainer:
                      predicted_mask_loss_weight=objective.get('predicted_mask_loss_weight', 0.0), sharp_weights_std=objective.get('sharp_weights_std', 1.0),
                      use_mask_sharp_weights=int(self.cfg.use_mask_sharp_weights), norm_loss_weight=objective.get('norm_loss_weight', 0.0),
                      hyper_reg_loss_weight=objective.get('hyper_reg_loss_weight', 0.0))
+      if objective.get('background_loss_weight', 0.0):      # training.py:159-183, 468-479: batch['background_points'] (+ noise, random warp ids)
+        if batch.get('background_points') is None:
+          raise ValueError("the background loss needs batch['background_points']")
+        bp = f32(batch['background_points']).reshape(-1, 3)
+        gen = torch.Generator(device='cpu').manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+        bid = batch.get('background_ids')        # the reference draws them: random.choice(key, model.warp_embeds, ...); injectable for tests
+        if bid is None:
+          bid = torch.randint(0, self.cfg.num_warp_embeds, (bp.shape[0],), generator=gen)
+        bid = (bid if isinstance(bid, torch.Tensor) else torch.as_tensor(np.asarray(bid).astype(np.int64))).to(dev).reshape(-1).to(torch.int32).contiguous()
+        std = float(objective.get('background_noise_std', 0.0))
+        if std != 0.0:
+          bp = bp + std * torch.randn(bp.shape, generator=gen).to(dev)
+        bp = bp.contiguous()
+        keep += [bp, bid]
+        ob.background_loss_weight = float(objective['background_loss_weight'])
+        ob.background_loss_alpha = float(objective.get('background_loss_alpha', -2.0))
+        ob.background_loss_scale = float(objective.get('background_loss_scale', 0.001))
+        ob.background_points, ob.background_ids, ob.num_background_points = bp.data_ptr(), bid.data_ptr(), int(bp.shape[0])
     s = stream if stream is not None else torch.cuda.current_stream(dev)
     import torch.distributed as dist
     grouped = dist.is_available() and dist.is_initialized()
@@ -292,6 +312,8 @@ class Trainer:
       aux += (float(loss[2 + k]) if two else 0.0) + float(loss[6 + k])
     stats['loss/hyper_reg/fine'], stats['loss/hyper_reg/coarse'] = float(loss[10]), float(loss[11])      # training.py:312-321
     aux += (float(loss[10]) if two else 0.0) + float(loss[11])
+    stats['loss/background'] = float(loss[12])                                                           # training.py:468-479
+    aux += float(loss[12])
     stats['loss/total'] = (fine + coarse if two else coarse) + aux
     return stats
 

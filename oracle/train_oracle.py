@@ -76,7 +76,17 @@ def loss_and_grads(cfg, params, rays_dict, target_rgb, extra_params, t_rand, u_r
   gt = torch.as_tensor(np.asarray(target_rgb)).to(dtype)
   losses = {level: ((out[level]['rgb'][..., :3] - gt) ** 2).mean() for level in out}      # training.py:265-274
   aux = {level: auxiliary_losses(cfg, out[level], rays_dict, objective, dtype) for level in out} if objective else {}
-  total = sum(losses.values()) + sum(v for a in aux.values() for v in a.values())           # training.py:481
+  bg = None
+  if objective and objective.get('background_loss_weight', 0.0):                             # training.py:159-183, 468-479 (ids / noise injected)
+    pts = torch.as_tensor(np.asarray(rays_dict['background_points'])).to(dtype).reshape(-1, 3)
+    ids = torch.as_tensor(np.asarray(rays_dict['background_ids']).astype(np.int64)).reshape(-1)
+    embed = model.params['warp_embed']['embed']['embedding'][ids]                             # models.py:767
+    if cfg.use_mask_in_warp:
+      embed = torch.cat([embed, torch.zeros_like(embed[..., :1])], dim=-1)                    # "assume background has 0 mask"
+    warped, _ = O.se3_field_warp(cfg, model.params['warp_field'], pts, embed, extra_params['warp_alpha'])
+    bg = objective['background_loss_weight'] * general_loss_with_squared_residual(
+        ((warped[..., :3] - pts) ** 2).sum(-1), objective.get('background_loss_alpha', -2.0), objective.get('background_loss_scale', 0.001)).mean()
+  total = sum(losses.values()) + sum(v for a in aux.values() for v in a.values()) + (bg if bg is not None else 0.0)      # training.py:481
   grads = torch.autograd.grad(total, [v for _, v in leaves], allow_unused=True)
   flat = {n: (g if g is not None else torch.zeros_like(v)).detach().cpu().numpy() for (n, v), g in zip(leaves, grads)}
   tree = {}
@@ -90,6 +100,8 @@ def loss_and_grads(cfg, params, rays_dict, target_rgb, extra_params, t_rand, u_r
   for level, a in aux.items():
     for k, v in a.items():
       losses[f'{k}/{level}'] = float(v)
+  if bg is not None:
+    losses['background'] = float(bg)
   losses['total'] = float(total)
   return losses, tree, {lvl: {k: v.detach() for k, v in o.items() if torch.is_tensor(v)} for lvl, o in out.items()}
 

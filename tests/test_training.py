@@ -337,6 +337,44 @@ def test_auxiliary_losses_match_the_oracle(sharp, gemm):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('with_aux', [False, True])
+def test_background_loss_matches_the_oracle(with_aux):
+  """training.py:159-183, 468-479: background_loss_weight * mean general_loss(|apply_warp(x) - x|^2, -2, 0.001) over a batch of points that should not move
+  (ids and noise injected - the reference draws them), added to the levels' losses: its term, the total and every gradient leaf against autograd, alone
+  (the levels then keep the merged flow) and together with the per-ray auxiliary terms; a ragged point count (3 workgroup tiles + 5 rows)."""
+  from nerfds_amd.training import Trainer
+  from oracle import train_oracle as T
+  cfg, params, batch, t, u = _problem(64, 16, 16)      # (the size of the rgb-loss test: at 24 rays x 8 + 8 a ReLU flip already costs 1e-2 on a leaf)
+  rng = np.random.default_rng(11)
+  B = 101
+  batch['background_points'] = rng.uniform(-1.0, 1.0, (B, 3)).astype(np.float32)
+  batch['background_ids'] = rng.integers(0, cfg.num_warp_embeds, (B,))
+  # scale 0.3 instead of the reference's default 0.001: the init-regime warp moves points by ~0.05, where the alpha = -2 loss at scale 0.001 is
+  # saturated and its gradient vanishes - the check would see nothing
+  ob = dict(OBJECTIVE if with_aux else {}, background_loss_weight=1.0, background_loss_scale=0.3)
+  L, G, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=ob)
+  L0, G0, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=(OBJECTIVE if with_aux else None))
+  tr = Trainer(cfg, params, max_rays=64)
+  stats = tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=ob)
+  assert L['background'] > 1e-3 * L['total']                       # the term is a visible part of this objective
+  assert abs(stats['loss/background'] - L['background']) <= 2e-4 * L['background'], (stats['loss/background'], L['background'])
+  assert abs(stats['loss/total'] - L['total']) < 1e-4 * L['total']
+  got, want, base = dict(tree_leaves(tr.get_grads())), dict(tree_leaves(G)), dict(tree_leaves(G0))
+  gmax = max(np.abs(v).max() for v in want.values())
+  worst = (0.0, '')
+  for name, w in want.items():
+    g = got[name].reshape(w.shape)
+    l2 = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
+    worst = max(worst, (float(l2), name))
+    assert l2 < L2_TOL_AUX, (name, l2)
+  print(f'background loss (with_aux={with_aux}): worst leaf l2 {worst[0]:.2e} ({worst[1]})', file=sys.stderr)
+  for name in ('warp_field/trunk/hidden_0/kernel', 'warp_field/branches_v/logit/bias', 'warp_embed/embed/embedding'):
+    assert np.linalg.norm(want[name] - base[name]) > 0.05 * np.linalg.norm(base[name]), name      # ... and of these gradients
+  with pytest.raises(ValueError):
+    tr.step({k: v for k, v in batch.items() if k != 'background_points'}, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=ob)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('only_norm', [True, False])
 def test_norm_loss_second_order_matches_the_oracle(only_norm, gemm):
   """training.py:323-332: mean(w |n - target_norm|) with NO stop_gradient on target_norm = d sigma / d x, i.e. second order in
