@@ -284,7 +284,8 @@ typedef struct nerfds_train_objective {
   int32_t use_mask_sharp_weights;
   float norm_loss_weight;
   /* hyper-point regulariser (training.py:312-321): mean over rays of sum_s w_s * general_loss(|ambient coordinates|^2, alpha 0, scale 0.05),
-   * the weights as constants; reported in loss_host[10] (fine) / [11] (coarse) */
+   * the weights as constants - on the COARSE level only, as the reference (training.py:461-466); reported in loss_host[11] ([10], the fine
+   * level's slot, stays 0) */
   float hyper_reg_loss_weight;
   /* background regulariser (training.py:159-183, 468-479): background_loss_weight * mean over the points of
    * general_loss(|warp(x) - x|^2, background_loss_alpha, background_loss_scale), warp = NerfModel.apply_warp (the SE(3) field with the GLO row

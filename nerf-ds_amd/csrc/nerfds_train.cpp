@@ -954,11 +954,15 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   composite_loss(st, R, S, z, rays->directions, t.sigma, t.rgb_logit, target, t.cfg.use_sample_at_infinity, t.cfg.use_white_background, t.rgb_ray,
                  weights_out, t.loss_dev + level, t.d_rgb_logit, t.d_alpha);
   if (want_sigma_gradient) sigma_gradient(t, r, level, W);
+  Objective ob_level;
+  if (ob) { ob_level = *ob; if (level != 0) ob_level.hyper_reg_weight = 0.f; ob = &ob_level; }
   if (ob)     // auxiliary first-order losses: extra upstream gradients for x', the raw normal and the predicted mask
     aux_losses(st, R, S, *ob, z, weights_out, t.x, t.xw, t.alphav, viewdirs, t.mask_logit, rays->gt_mask, t.terms_dev + 4 * level, t.dxw_reg,
                t.d_alpha, t.d_pm, t.wamb, t.terms_dev + 9 + level, t.dwamb_reg);
   const bool nl = norm_weight != 0.f;
-  const bool hreg = ob && ob->hyper_reg_weight != 0.f;      // hyper-point regulariser: one more upstream gradient of the ambient coordinates
+  // hyper-point regulariser: one more upstream gradient of the ambient coordinates - of the COARSE level only (training.py:461-466 passes
+  // use_hyper_reg_loss to the coarse level's _compute_loss_and_stats; the fine level runs with its default, False)
+  const bool hreg = ob && ob->hyper_reg_weight != 0.f && level == 0;
   if (nl) norm_loss(st, R, S, norm_weight, weights_out, t.alphav, t.t_alpha, t.wv, t.tn[level], t.terms_dev + 4 * level + 3, t.d_alpha, t.d_t_alpha,
                     t.du, t.ghat);
   // ---------------- backward ----------------

@@ -36,7 +36,7 @@ def general_loss_with_squared_residual(x_sq, alpha, scale):
   return scale * (b / a) * ((loss_two / (0.5 * b) + 1) ** (0.5 * alpha) - 1)
 
 
-def auxiliary_losses(cfg, out, rays_dict, objective, dtype):
+def auxiliary_losses(cfg, out, rays_dict, objective, dtype, level='coarse'):
   """The first-order auxiliary terms of _compute_loss_and_stats for one level (training.py:297-310, 334-339, 386-408)."""
   terms = {}
   weights = out['weights'].detach()                                            # lax.stop_gradient(model_out['weights'])
@@ -53,7 +53,8 @@ def auxiliary_losses(cfg, out, rays_dict, objective, dtype):
     gt = torch.as_tensor(np.asarray(rays_dict['mask'])).to(dtype).reshape(-1)
     w = out['sharp_weights'].detach() if cfg.use_mask_sharp_weights else weights
     terms['predicted_mask'] = objective['predicted_mask_loss_weight'] * ((gt - (w * pm).sum(-1)) ** 2).mean()
-  if objective.get('hyper_reg_loss_weight', 0.0):                              # training.py:312-321
+  if objective.get('hyper_reg_loss_weight', 0.0) and level == 'coarse':        # training.py:312-321; the COARSE level only (training.py:461-466: the fine
+    #                                                                             level is evaluated with use_hyper_reg_loss at its default, False)
     resid = (out['warped_points'][..., 3:] ** 2).sum(-1)
     terms['hyper_reg'] = objective['hyper_reg_loss_weight'] * (weights * general_loss_with_squared_residual(resid, 0.0, 0.05)).sum(1).mean()
   if objective.get('norm_loss_weight', 0.0):                                   # training.py:323-332 (second order: target_norm is NOT detached)
@@ -75,7 +76,7 @@ def loss_and_grads(cfg, params, rays_dict, target_rgb, extra_params, t_rand, u_r
                     sharp_weights_std=(objective or {}).get('sharp_weights_std', 1.0))
   gt = torch.as_tensor(np.asarray(target_rgb)).to(dtype)
   losses = {level: ((out[level]['rgb'][..., :3] - gt) ** 2).mean() for level in out}      # training.py:265-274
-  aux = {level: auxiliary_losses(cfg, out[level], rays_dict, objective, dtype) for level in out} if objective else {}
+  aux = {level: auxiliary_losses(cfg, out[level], rays_dict, objective, dtype, level) for level in out} if objective else {}
   bg = None
   if objective and objective.get('background_loss_weight', 0.0):                             # training.py:159-183, 468-479 (ids / noise injected)
     pts = torch.as_tensor(np.asarray(rays_dict['background_points'])).to(dtype).reshape(-1, 3)

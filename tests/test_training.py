@@ -317,8 +317,9 @@ def test_auxiliary_losses_match_the_oracle(sharp, gemm):
   stats = tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=ob)
   hs = np.linalg.norm(dict(tree_leaves(G))['hyper_sheet_mlp/MLP_0/logit/kernel'] - dict(tree_leaves(G0))['hyper_sheet_mlp/MLP_0/logit/kernel'])
   assert hs > 0.05 * np.linalg.norm(dict(tree_leaves(G0))['hyper_sheet_mlp/MLP_0/logit/kernel'])      # the regulariser moves the hyper sheet's gradient visibly
+  assert stats['loss/hyper_reg/fine'] == 0.0 and 'hyper_reg/fine' not in L      # coarse level only (training.py:461-466)
   for level in ('fine', 'coarse'):
-    for k in ('warp_reg', 'back_facing', 'predicted_mask', 'hyper_reg'):
+    for k in ('warp_reg', 'back_facing', 'predicted_mask') + (('hyper_reg',) if level == 'coarse' else ()):
       want = L[f'{k}/{level}']
       assert abs(stats[f'loss/{k}/{level}'] - want) <= 2e-4 * max(abs(want), 1e-4), (k, level, stats[f'loss/{k}/{level}'], want)
   assert abs(stats['loss/total'] - L['total']) < 1e-4 * L['total']
