@@ -269,8 +269,7 @@ int nerfds_frame_images(int device, const float* ray_records, int32_t height, in
  * ONE launch of the fused field kernel (the render kernel's evaluation, writing every activation the backward reads; its weight streams
  * are re-packed on the device from the parameter vector at the start of every step); other widths, and the whole backward, run layer by
  * layer on the library's own MFMA kernels: a layer shape they do not cover is NERFDS_ENOTSUP (there is no library-GEMM detour).  The auxiliary losses of
- * configs/nerf_ds.gin, the hyper-point regulariser and the background regulariser are selected by nerfds_train_objective; the elastic loss
- * (off in every shipped gin) is not built. */
+ * configs/nerf_ds.gin, the hyper-point, background and elastic ('log_svals') regularisers are selected by nerfds_train_objective. */
 typedef struct nerfds_trainer nerfds_trainer;
 /* Weights of the auxiliary first-order losses added to the rgb loss of EACH level (0 = off): warp regulariser at the median-depth
  * sample (training.py:297-310, utils.general_loss_with_squared_residual), back-facing regulariser on the raw predicted normal
@@ -296,6 +295,12 @@ typedef struct nerfds_train_objective {
   const float* background_points;
   const uint32_t* background_ids;
   int64_t num_background_points;
+  /* elastic regulariser (training.py:112-156, 274-295; 'log_svals'): elastic_loss_weight * mean over rays of general_loss(sum log^2 of the
+   * singular values of the warp field's Jacobian d x' / d x, alpha -2, scale 0.03) at the median-depth sample of the COARSE level
+   * (elastic_reduce_by_weight = 0, 'median') or summed over its samples with the compositing weights as constant factors (1, 'weight').
+   * Second order in the warp field's weights: it runs the tangent pass like norm_loss_weight (and costs as much).  Reported in loss_host[13]. */
+  float elastic_loss_weight;
+  int32_t elastic_reduce_by_weight;
 } nerfds_train_objective;
 #define NERFDS_TRAIN_GRADS_ONLY 1u
 #define NERFDS_TRAIN_SIGMA_GRAD 2u   /* also evaluate the sigma gradient (models.py:1035-1077) -> nerfds_trainer_target_norm */
@@ -322,7 +327,7 @@ int nerfds_trainer_set_step(nerfds_trainer* t, int64_t step);   /* the optimizer
 long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* host, long long max_bytes);
 int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* extra,
                         const nerfds_rand* rnd, const nerfds_train_objective* objective /* NULL = rgb loss only */, float learning_rate,
-                        uint32_t flags, float* loss_host /* HOST float[16] or NULL: [0..12] used, the rest 0 */, void* hip_stream);
+                        uint32_t flags, float* loss_host /* HOST float[16] or NULL: [0..13] used, the rest 0 */, void* hip_stream);
 /* One Adam update with the gradient vector as it stands (after a NERFDS_TRAIN_GRADS_ONLY step and, on N GPUs, after the
  * all-reduce of nerfds_trainer_grads that replaces jax.lax.pmean(grad), training.py:502). */
 int nerfds_trainer_apply(nerfds_trainer* t, float learning_rate, void* hip_stream);

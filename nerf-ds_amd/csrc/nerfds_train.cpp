@@ -955,7 +955,7 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
                  weights_out, t.loss_dev + level, t.d_rgb_logit, t.d_alpha);
   if (want_sigma_gradient) sigma_gradient(t, r, level, W);
   Objective ob_level;
-  if (ob) { ob_level = *ob; if (level != 0) ob_level.hyper_reg_weight = 0.f; ob = &ob_level; }
+  if (ob) { ob_level = *ob; if (level != 0) { ob_level.hyper_reg_weight = 0.f; ob_level.elastic_weight = 0.f; } ob = &ob_level; }
   if (ob)     // auxiliary first-order losses: extra upstream gradients for x', the raw normal and the predicted mask
     aux_losses(st, R, S, *ob, z, weights_out, t.x, t.xw, t.alphav, viewdirs, t.mask_logit, rays->gt_mask, t.terms_dev + 4 * level, t.dxw_reg,
                t.d_alpha, t.d_pm, t.wamb, t.terms_dev + 9 + level, t.dwamb_reg);
@@ -965,6 +965,15 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   const bool hreg = ob && ob->hyper_reg_weight != 0.f && level == 0;
   if (nl) norm_loss(st, R, S, norm_weight, weights_out, t.alphav, t.t_alpha, t.wv, t.tn[level], t.terms_dev + 4 * level + 3, t.d_alpha, t.d_t_alpha,
                     t.du, t.ghat);
+  // elastic regulariser on the warp Jacobian (the tangent pass's t_xw), coarse level only; like the norm loss it is second order in the warp
+  // field: its gradient enters the backward of the tangent pass at d_t_xw (part 3 below)
+  const bool el = ob && ob->elastic_weight != 0.f && level == 0;
+  const bool so = nl || el;
+  if (el && !nl) {            // no norm loss: nothing else writes the tangent gradients of x' or exp_se3's direct terms
+    (void)hipMemsetAsync(t.d_t_xw, 0, (size_t)9 * M * sizeof(float), st);
+    (void)hipMemsetAsync(t.du, 0, (size_t)3 * M * sizeof(float), st);
+    (void)hipMemsetAsync(t.ghat, 0, (size_t)3 * M * sizeof(float), st);
+  }
   // ---------------- backward ----------------
   const int RW = t.rgb_h[level].N;
   if (t.half_step) {
@@ -1027,6 +1036,7 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
     trunk_in_jvp_bwd(st, D, M, t.d_t_tin, t.xw, t.wamb, t.t_xw, t.t_wamb, W, t.d_t_xw, t.d_t_wamb, t.dxw_reg, t.dwamb_extra);
     if (hreg) add_inplace(st, t.dwamb_extra, t.dwamb_reg, 2 * M);      // both extra gradients of the ambient coordinates in one array
   }
+  if (el) elastic_loss(st, R, S, ob->elastic_weight, ob->elastic_by_weight, weights_out, t.t_xw, t.terms_dev + 12, t.d_t_xw);   // (+= : behind trunk_in_jvp_bwd's write)
   trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, nl ? t.dwamb_extra : (hreg ? t.dwamb_reg : nullptr), t.dxw, t.dwamb);
   if (nl) {   // part 2: hyper sheet tangents
     pm = r.dense_jvp_bwd(t.hyper_out, {{t.th_h.back(), t.hyper.width, t.hyper.width, t.tA, t.hyper.width, false, t.hyper_h.back(), nullptr}}, t.d_t_wamb, 2, nullptr);
@@ -1034,13 +1044,13 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   }
   pm = r.dense_bwd(t.hyper_out, {{t.hyper_h.back(), t.hyper.width, t.hyper.width, t.g0, t.hyper.width, false, t.hyper_h.back(), t.grad + t.hyper.hidden.back().b}}, t.dwamb, 2, nullptr);
   r.mlp_bwd(t.hyper, t.hyper_in, t.hyper_h, t.g0, t.g1, t.d_hyper_in, pm);
-  if (nl) {   // part 3: exp_se3 tangents (second derivatives) and the warp net's tangents
+  if (so) {   // part 3: exp_se3 tangents (second derivatives) and the warp net's tangents
     se3_jvp_bwd(st, M, t.wv, t.x, t.t_wv, t.d_t_xw, t.du, t.ghat, t.d_t_wv, t.dwv_extra);
     r.dense_jvp_bwd(t.warp_w, {{t.tw_h.back(), t.warp.width, t.warp.width, t.tA, t.warp.width, false}}, t.d_t_wv, 6, nullptr);
     pm = r.dense_jvp_bwd(t.warp_v, {{t.tw_h.back(), t.warp.width, t.warp.width, t.tA, t.warp.width, true, t.warp_h.back(), nullptr}}, t.d_t_wv + 3, 6, nullptr);
     r.mlp_jvp_bwd(t.warp, t.t_warp_in, t.tw_h, t.warp_h, t.tA, t.tB, nullptr, pm);
   }
-  se3_bwd(st, M, t.wv, t.x, t.dxw, nl ? t.dwv_extra : nullptr, t.dwv);
+  se3_bwd(st, M, t.wv, t.x, t.dxw, so ? t.dwv_extra : nullptr, t.dwv);
   r.dense_bwd(t.warp_w, {{t.warp_h.back(), t.warp.width, t.warp.width, t.g0, t.warp.width, false}}, t.dwv, 6, nullptr);
   pm = r.dense_bwd(t.warp_v, {{t.warp_h.back(), t.warp.width, t.warp.width, t.g0, t.warp.width, true, t.warp_h.back(), t.grad + t.warp.hidden.back().b}}, t.dwv + 3, 6, nullptr);
   r.mlp_bwd(t.warp, t.warp_in, t.warp_h, t.g0, t.g1, t.d_warp_in, pm);
@@ -1106,12 +1116,12 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
   carve(*t);      // sizes only
   const size_t pbytes = (size_t)t->P * sizeof(float);
   if (hipMalloc(&t->theta, pbytes) != hipSuccess || hipMalloc(&t->grad, pbytes) != hipSuccess || hipMalloc(&t->m1, pbytes) != hipSuccess ||
-      hipMalloc(&t->m2, pbytes) != hipSuccess || hipMalloc(&t->loss_dev, 2 * sizeof(float)) != hipSuccess || hipMalloc(&t->terms_dev, 12 * sizeof(float)) != hipSuccess ||
+      hipMalloc(&t->m2, pbytes) != hipSuccess || hipMalloc(&t->loss_dev, 2 * sizeof(float)) != hipSuccess || hipMalloc(&t->terms_dev, 16 * sizeof(float)) != hipSuccess ||
       hipMalloc(&t->ws, t->ws_floats * sizeof(float)) != hipSuccess) {
     g_train_error = "hipMalloc failed (workspace of " + std::to_string(t->ws_floats * 4 >> 20) + " MiB)";
     return NERFDS_ENOMEM;
   }
-  (void)hipMemset(t->terms_dev, 0, 12 * sizeof(float));      // [8]: the non-finite-gradient flag (adam_update)
+  (void)hipMemset(t->terms_dev, 0, 16 * sizeof(float));      // [8]: the non-finite-gradient flag (adam_update)
   (void)hipMemset(t->theta, 0, pbytes); (void)hipMemset(t->m1, 0, pbytes); (void)hipMemset(t->m2, 0, pbytes); (void)hipMemset(t->grad, 0, pbytes);
   carve(*t);
   {
@@ -1337,10 +1347,11 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     ob.back_facing_weight = objective->back_facing_reg_weight; ob.mask_loss_weight = objective->predicted_mask_loss_weight;
     ob.sharp_weights_std = objective->sharp_weights_std; ob.use_sharp_weights = objective->use_mask_sharp_weights;
     ob.hyper_reg_weight = objective->hyper_reg_loss_weight;
+    ob.elastic_weight = objective->elastic_loss_weight; ob.elastic_by_weight = objective->elastic_reduce_by_weight;
     if (ob.mask_loss_weight != 0.f && !rays->gt_mask) return t->fail(NERFDS_EINVAL, "the mask loss needs rays_dict['mask']");
     if (ob.use_sharp_weights && !(ob.sharp_weights_std > 0.f)) return t->fail(NERFDS_EINVAL, "sharp_weights_std must be > 0");
     // (a background-only objective keeps the plain - merged - flow of the levels: the per-ray auxiliary kernel has nothing to do)
-    if (ob.warp_reg_weight != 0.f || ob.back_facing_weight != 0.f || ob.mask_loss_weight != 0.f || ob.hyper_reg_weight != 0.f || objective->norm_loss_weight != 0.f)
+    if (ob.warp_reg_weight != 0.f || ob.back_facing_weight != 0.f || ob.mask_loss_weight != 0.f || ob.hyper_reg_weight != 0.f || ob.elastic_weight != 0.f || objective->norm_loss_weight != 0.f)
       obp = &ob;
     if (objective->background_loss_weight != 0.f) {
       if (!objective->background_points || !objective->background_ids || objective->num_background_points < 1)
@@ -1350,9 +1361,11 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     }
   }
   (void)hipMemsetAsync(t->terms_dev, 0, 8 * sizeof(float), st);
-  (void)hipMemsetAsync(t->terms_dev + 9, 0, 3 * sizeof(float), st);          // [9], [10]: hyper-point regulariser of the coarse / fine level, [11]: background loss ([8]: non-finite flag)
+  (void)hipMemsetAsync(t->terms_dev + 9, 0, 4 * sizeof(float), st);          // ... [12]: elastic regulariser
+  // [9], [10]: hyper-point regulariser of the coarse / fine level, [11]: background loss ([8]: non-finite flag)
   const float norm_weight = objective ? objective->norm_loss_weight : 0.f;
-  const bool want_sg = (flags & NERFDS_TRAIN_SIGMA_GRAD) != 0 || norm_weight != 0.f;
+  const bool elastic = objective && objective->elastic_loss_weight != 0.f;      // second order like the norm loss: needs the tangent pass and its backward
+  const bool want_sg = (flags & NERFDS_TRAIN_SIGMA_GRAD) != 0 || norm_weight != 0.f || elastic;
   // the tangent passes (sigma gradient, norm loss) read the fp32 activations: those steps keep the layer-by-layer backward
   t->half_step = t->fused_fwd && t->fused_bwd && !want_sg;
   if (t->half_step) pack_fused_backward(*t, st);
@@ -1362,8 +1375,8 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     if (const char* s = getenv("NERFDS_TRAIN_G_SCALE_LOG2")) e = atoi(s);
     t->g_scale = (t->half_step && t->g16) ? std::ldexp(1.f, e) : 1.f;
   }
-  t->keep_tangents = norm_weight != 0.f;
-  if (norm_weight != 0.f && (!ensure_tangent_ws(*t) || !ensure_norm_ws(*t))) return t->fail(NERFDS_ENOMEM, "hipMalloc of the norm-loss workspace failed");
+  t->keep_tangents = norm_weight != 0.f || elastic;
+  if ((norm_weight != 0.f || elastic) && (!ensure_tangent_ws(*t) || !ensure_norm_ws(*t))) return t->fail(NERFDS_ENOMEM, "hipMalloc of the norm-loss workspace failed");
   if (want_sg && !ensure_tangent_ws(*t)) return t->fail(NERFDS_ENOMEM, "hipMalloc of the tangent workspace failed");
   t->tn_valid = want_sg;
   // NERFDS_TRAIN_MERGED=0: the two levels one after the other, each with its own pass over the shared networks (A/B, and every step the merged
@@ -1405,7 +1418,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     float l[2];
     if (hipMemcpyAsync(l, t->loss_dev, sizeof l, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       return t->fail(NERFDS_EDEVICE, "loss read-back failed");
-    float tm[12];
+    float tm[13];
     if (hipMemcpy(tm, t->terms_dev, sizeof tm, hipMemcpyDeviceToHost) != hipSuccess) return t->fail(NERFDS_EDEVICE, "loss read-back failed");
     unsigned nonfinite = 0;
     std::memcpy(&nonfinite, &tm[8], sizeof nonfinite);
@@ -1415,7 +1428,8 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     for (int k = 0; k < 4; ++k) { loss_host[2 + k] = tm[4 * fl + k]; loss_host[6 + k] = tm[k]; }   // weighted warp_reg / back_facing / mask / norm terms: fine, coarse
     loss_host[10] = tm[9 + fl]; loss_host[11] = tm[9];                                                // weighted hyper-point regulariser: fine, coarse
     loss_host[12] = tm[11];                                                                            // weighted background regulariser
-    loss_host[13] = loss_host[14] = loss_host[15] = 0.f;
+    loss_host[13] = tm[12];                                                                            // weighted elastic regulariser (coarse level)
+    loss_host[14] = loss_host[15] = 0.f;
     if (nonfinite && !(flags & NERFDS_TRAIN_GRADS_ONLY))
       return t->fail(NERFDS_ENONFINITE, "non-finite gradient: the Adam update of this step was skipped (f16 activations / scaled f16 g overflowed? NERFDS_TRAIN_G16=0 "
                                         "keeps g in fp32; a step with the sigma-gradient flag keeps fp32 activations)");

@@ -19,6 +19,8 @@ struct Objective {   // weights of the auxiliary losses (0 = off); mirrors nerfd
   float warp_reg_weight, warp_reg_alpha, warp_reg_scale, back_facing_weight, mask_loss_weight, sharp_weights_std;
   int use_sharp_weights;
   float hyper_reg_weight;
+  float elastic_weight;       // elastic regulariser on the warp Jacobian (coarse level), elastic_by_weight: 'weight' reduction instead of 'median'
+  int elastic_by_weight;
 };
 
 void coarse_z(hipStream_t, int R, int Nc, float near_, float far_, int stratified, int lindisp, const float* t_rand, uint64_t seed, long long first_ray, float* z);
@@ -47,6 +49,9 @@ void aux_losses(hipStream_t, int R, int S, const Objective&, const float* z, con
                 const float* wamb = nullptr, float* term_hyper = nullptr, float* dwamb_reg = nullptr);   // hyper-point regulariser: ambient coordinates in, its term and d / d wamb out
 void add_inplace(hipStream_t, float* dst, const float* src, long long n);
 // background regulariser (training.py:159-183): term += weight * mean_i general_loss(|xw_i - x_i|^2, alpha, scale); dxw = its gradient w.r.t. xw
+// elastic regulariser (training.py:112-156 'log_svals', 274-295): t_xw = the tangents of the warped point, row 3 m + j = d x' / d x_j (the Jacobian's
+// column j); term += weight * mean_rays sum_selected f * general_loss(sum_i log^2 max(s_i, 1e-6), -2, 0.03); d_t_xw += its gradient
+void elastic_loss(hipStream_t, int R, int S, float weight, int by_weight, const float* weights, const float* t_xw, float* term, float* d_t_xw);
 void background_loss(hipStream_t, long long B, const float* x, const float* xw, float weight, float alpha, float scale, float* term, float* dxw);
 void alpha_post(hipStream_t, const Dims&, int R, int S, const float* alpha, const float* wv, const float* viewdirs, const Windows&, float* sigma, float* cond);
 void composite_loss(hipStream_t, int R, int S, const float* z, const float* dirs, const float* sigma, const float* rgb_logit, const float* target,

@@ -1045,6 +1045,61 @@ __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__
   if (i < n) dst[i] += src[i];
 }
 void add_inplace(hipStream_t st, float* dst, const float* src, long long n) { LAUNCH(k_add_inplace, n, st, dst, src, n); }
+// Singular values / vectors of a 3 x 3 matrix through the eigen-decomposition of J^T J (cyclic Jacobi in double: the warp Jacobian is close to a
+// rotation, its singular values close to each other - any basis of a (near-)degenerate eigenspace gives the same sum over i of f'(s_i) u_i v_i^T).
+__global__ void k_elastic_loss(int R, int S, float weight, int by_weight, const float* __restrict__ weights, const float* __restrict__ t_xw,
+                               float* __restrict__ term, float* __restrict__ d_t_xw) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* w = weights + (size_t)r * S;
+  int med = 0;
+  {
+    float cum = 0.f;
+    for (int s = 0; s < S; ++s) { cum += w[s]; if (cum >= 0.5f) { med = s; break; } }      // model_utils.py:272-299 (no sample reaches 0.5: index 0)
+  }
+  float total = 0.f;
+  const float k = weight / (float)R;
+  for (int s = by_weight ? 0 : med; s < (by_weight ? S : med + 1); ++s) {
+    const size_t m = (size_t)r * S + s;
+    double J[3][3], A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int j = 0; j < 3; ++j)
+      for (int c = 0; c < 3; ++c) J[c][j] = (double)t_xw[(3 * m + j) * 3 + c];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) A[a][b] = J[0][a] * J[0][b] + J[1][a] * J[1][b] + J[2][a] * J[2][b];
+    for (int sweep = 0; sweep < 12; ++sweep)
+      for (int p = 0; p < 2; ++p)
+        for (int q = p + 1; q < 3; ++q) {
+          if (fabs(A[p][q]) < 1e-300) continue;
+          const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+          const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0)), cc = 1.0 / sqrt(tt * tt + 1.0), ss = tt * cc;
+          for (int i = 0; i < 3; ++i) { const double x = A[i][p], y = A[i][q]; A[i][p] = cc * x - ss * y; A[i][q] = ss * x + cc * y; }
+          for (int i = 0; i < 3; ++i) { const double x = A[p][i], y = A[q][i]; A[p][i] = cc * x - ss * y; A[q][i] = ss * x + cc * y; }
+          for (int i = 0; i < 3; ++i) { const double x = V[i][p], y = V[i][q]; V[i][p] = cc * x - ss * y; V[i][q] = ss * x + cc * y; }
+        }
+    double sq = 0.0, coef[3];
+    for (int i = 0; i < 3; ++i) {
+      const double sv = sqrt(fmax(A[i][i], 0.0));
+      const double ls = log(fmax(sv, 1e-6));
+      sq += ls * ls;
+      coef[i] = sv > 1e-6 ? 2.0 * ls / (sv * sv) : 0.0;            // f'(s_i) / s_i with u_i = J v_i / s_i; the clamped branch is constant
+    }
+    float dl;
+    const float l = general_loss_sq((float)sq, -2.0f, 0.03f, dl);
+    const float f = by_weight ? w[s] : 1.0f;
+    total += f * l;
+    // d sq / d J = sum_i coef_i (J v_i) v_i^T
+    for (int c = 0; c < 3; ++c)
+      for (int j = 0; j < 3; ++j) {
+        double g = 0.0;
+        for (int i = 0; i < 3; ++i) g += coef[i] * (J[c][0] * V[0][i] + J[c][1] * V[1][i] + J[c][2] * V[2][i]) * V[j][i];
+        d_t_xw[(3 * m + j) * 3 + c] += k * f * dl * (float)g;
+      }
+  }
+  atomicAdd(term, k * total);
+}
+void elastic_loss(hipStream_t st, int R, int S, float weight, int by_weight, const float* weights, const float* t_xw, float* term, float* d_t_xw) {
+  hipLaunchKernelGGL(k_elastic_loss, grid1(R, 64), dim3(64), 0, st, R, S, weight, by_weight, weights, t_xw, term, d_t_xw);
+}
 __global__ void k_background_loss(long long B, const float* __restrict__ x, const float* __restrict__ xw, float weight, float alpha, float scale,
                                   float* __restrict__ term, float* __restrict__ dxw) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;

@@ -22,7 +22,8 @@ class Objective(C.Structure):
               ('back_facing_reg_weight', C.c_float), ('predicted_mask_loss_weight', C.c_float), ('sharp_weights_std', C.c_float),
               ('use_mask_sharp_weights', C.c_int32), ('norm_loss_weight', C.c_float), ('hyper_reg_loss_weight', C.c_float),
               ('background_loss_weight', C.c_float), ('background_loss_alpha', C.c_float), ('background_loss_scale', C.c_float),
-              ('background_points', C.c_void_p), ('background_ids', C.c_void_p), ('num_background_points', C.c_int64)]
+              ('background_points', C.c_void_p), ('background_ids', C.c_void_p), ('num_background_points', C.c_int64),
+              ('elastic_loss_weight', C.c_float), ('elastic_reduce_by_weight', C.c_int32)]
 
 
 class _DevVec:
@@ -258,6 +259,13 @@ class Trainer:
                      predicted_mask_loss_weight=objective.get('predicted_mask_loss_weight', 0.0), sharp_weights_std=objective.get('sharp_weights_std', 1.0),
                      use_mask_sharp_weights=int(self.cfg.use_mask_sharp_weights), norm_loss_weight=objective.get('norm_loss_weight', 0.0),
                      hyper_reg_loss_weight=objective.get('hyper_reg_loss_weight', 0.0))
+      if objective.get('elastic_loss_weight', 0.0):         # training.py:112-156, 274-295
+        if objective.get('elastic_loss_type', 'log_svals') != 'log_svals':
+          raise NotImplementedError("elastic_loss_type: only 'log_svals' (the reference's default) is built")
+        method = objective.get('elastic_reduce_method', 'median')
+        if method not in ('median', 'weight'):
+          raise ValueError(f'elastic_reduce_method {method!r}')
+        ob.elastic_loss_weight, ob.elastic_reduce_by_weight = float(objective['elastic_loss_weight']), int(method == 'weight')
       if objective.get('background_loss_weight', 0.0):      # training.py:159-183, 468-479: batch['background_points'] (+ noise, random warp ids)
         if batch.get('background_points') is None:
           raise ValueError("the background loss needs batch['background_points']")
@@ -313,7 +321,8 @@ class Trainer:
     stats['loss/hyper_reg/fine'], stats['loss/hyper_reg/coarse'] = float(loss[10]), float(loss[11])      # training.py:312-321
     aux += (float(loss[10]) if two else 0.0) + float(loss[11])
     stats['loss/background'] = float(loss[12])                                                           # training.py:468-479
-    aux += float(loss[12])
+    stats['loss/elastic'] = float(loss[13])                                                              # training.py:274-295 (coarse level)
+    aux += float(loss[12]) + float(loss[13])
     stats['loss/total'] = (fine + coarse if two else coarse) + aux
     return stats
 

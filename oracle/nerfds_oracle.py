@@ -465,6 +465,8 @@ class NerfModel:
     else:
       predicted_mask = None
       mask = gt_mask_b
+    if warp_embed is not None:      # what the warp field sees next to the point (map_points): test infrastructure for the warp Jacobian (training.py:279)
+      out['warp_metadata'] = torch.cat([warp_embed, mask], dim=-1) if cfg.use_mask_in_warp else warp_embed
 
     # value_and_grad(cal_single_pt_sigma) (models.py:1065-1077); mask enters as a constant input.
     if compute_sigma_gradient == 'differentiable':

@@ -77,6 +77,22 @@ def loss_and_grads(cfg, params, rays_dict, target_rgb, extra_params, t_rand, u_r
   gt = torch.as_tensor(np.asarray(target_rgb)).to(dtype)
   losses = {level: ((out[level]['rgb'][..., :3] - gt) ** 2).mean() for level in out}      # training.py:265-274
   aux = {level: auxiliary_losses(cfg, out[level], rays_dict, objective, dtype, level) for level in out} if objective else {}
+  el = None
+  if objective and objective.get('elastic_loss_weight', 0.0):                                # training.py:112-156, 274-295: coarse level only (461-466)
+    o = out['coarse']
+    pts = o['points'].detach().clone().requires_grad_(True)
+    warped, _ = O.se3_field_warp(cfg, model.params['warp_field'], pts, o['warp_metadata'], extra_params['warp_alpha'])
+    # samples are independent: row c of every sample's Jacobian d warp / d point (warping.py:276-278: metadata - mask included - held fixed)
+    J = torch.stack([torch.autograd.grad(warped[..., c].sum(), pts, create_graph=True)[0] for c in range(3)], dim=-2)      # [R, S, 3 (out), 3 (in)]
+    w = o['weights'].detach()
+    by_weight = objective.get('elastic_reduce_method', 'median') == 'weight'
+    if not by_weight:
+      J = torch.take_along_dim(J, O.compute_depth_index(w)[..., None, None, None], dim=-3)    # the median-depth sample's Jacobian
+    sq = (torch.log(torch.clamp(torch.linalg.svdvals(J), min=1e-6)) ** 2).sum(-1)            # 'log_svals'
+    l = general_loss_with_squared_residual(sq, -2.0, 0.03)
+    if by_weight:
+      l = w * l
+    el = objective['elastic_loss_weight'] * l.sum(-1).mean()
   bg = None
   if objective and objective.get('background_loss_weight', 0.0):                             # training.py:159-183, 468-479 (ids / noise injected)
     pts = torch.as_tensor(np.asarray(rays_dict['background_points'])).to(dtype).reshape(-1, 3)
@@ -87,7 +103,7 @@ def loss_and_grads(cfg, params, rays_dict, target_rgb, extra_params, t_rand, u_r
     warped, _ = O.se3_field_warp(cfg, model.params['warp_field'], pts, embed, extra_params['warp_alpha'])
     bg = objective['background_loss_weight'] * general_loss_with_squared_residual(
         ((warped[..., :3] - pts) ** 2).sum(-1), objective.get('background_loss_alpha', -2.0), objective.get('background_loss_scale', 0.001)).mean()
-  total = sum(losses.values()) + sum(v for a in aux.values() for v in a.values()) + (bg if bg is not None else 0.0)      # training.py:481
+  total = sum(losses.values()) + sum(v for a in aux.values() for v in a.values()) + (bg if bg is not None else 0.0) + (el if el is not None else 0.0)      # training.py:481
   grads = torch.autograd.grad(total, [v for _, v in leaves], allow_unused=True)
   flat = {n: (g if g is not None else torch.zeros_like(v)).detach().cpu().numpy() for (n, v), g in zip(leaves, grads)}
   tree = {}
@@ -103,6 +119,8 @@ def loss_and_grads(cfg, params, rays_dict, target_rgb, extra_params, t_rand, u_r
       losses[f'{k}/{level}'] = float(v)
   if bg is not None:
     losses['background'] = float(bg)
+  if el is not None:
+    losses['elastic'] = float(el)
   losses['total'] = float(total)
   return losses, tree, {lvl: {k: v.detach() for k, v in o.items() if torch.is_tensor(v)} for lvl, o in out.items()}
 

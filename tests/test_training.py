@@ -376,6 +376,40 @@ def test_background_loss_matches_the_oracle(with_aux):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('method,with_rest', [('median', False), ('weight', False), ('median', True)])
+def test_elastic_loss_second_order_matches_the_oracle(method, with_rest):
+  """training.py:112-156 ('log_svals'), 274-295: general_loss(sum log^2 of the singular values of the warp field's Jacobian) at the median-depth sample
+  (or over all samples, weighted) of the COARSE level.  Second order in the warp field's weights: forward-mode Jacobian + its backward in the trainer,
+  autograd-of-autograd in the oracle; alone, and together with the first-order auxiliary terms and the second-order norm loss."""
+  from nerfds_amd.training import Trainer
+  from oracle import train_oracle as T
+  cfg, params, batch, t, u = _problem(24, 16, 16)
+  rest = dict(OBJECTIVE, norm_loss_weight=0.05, hyper_reg_loss_weight=0.01) if with_rest else {}
+  # (weight 1: at the init regime's warp the alpha = -2 loss sits in its flat part - 0.059 of at most 0.06 - and a typical 0.01 would move no gradient visibly)
+  ob = dict(rest, elastic_loss_weight=1.0, elastic_reduce_method=method)
+  L, G, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=ob)
+  L0, G0, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=rest or None)
+  tr = Trainer(cfg, params, max_rays=24)
+  stats = tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=ob)
+  assert L['elastic'] > 1e-4 * L['total']
+  assert abs(stats['loss/elastic'] - L['elastic']) <= 1e-3 * L['elastic'], (stats['loss/elastic'], L['elastic'])
+  assert abs(stats['loss/total'] - L['total']) < 2e-4 * L['total']
+  got, want, base = dict(tree_leaves(tr.get_grads())), dict(tree_leaves(G)), dict(tree_leaves(G0))
+  gmax = max(np.abs(v).max() for v in want.values())
+  worst = (0.0, '')
+  for name, w in want.items():
+    g = got[name].reshape(w.shape)
+    l2 = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
+    worst = max(worst, (float(l2), name))
+    assert l2 < L2_TOL_2ND['mfma'], (name, l2)
+  print(f'elastic loss ({method}, with_rest={with_rest}): worst leaf l2 {worst[0]:.2e} ({worst[1]})', file=sys.stderr)
+  for name in ('warp_field/trunk/hidden_2/kernel', 'warp_field/branches_w/logit/kernel'):
+    assert np.linalg.norm(want[name] - base[name]) > 0.05 * np.linalg.norm(base[name]), name      # the term is a visible part of these gradients
+  with pytest.raises(NotImplementedError):
+    tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=dict(ob, elastic_loss_type='svals'))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('only_norm', [True, False])
 def test_norm_loss_second_order_matches_the_oracle(only_norm, gemm):
   """training.py:323-332: mean(w |n - target_norm|) with NO stop_gradient on target_norm = d sigma / d x, i.e. second order in
