@@ -175,3 +175,34 @@ def extra_params_from_gin(path: str) -> Dict[str, float]:
     if key in b:
       out[name] = _schedule_final(b[key])
   return out
+
+
+def objective_from_gin(path: str, step: int = 0) -> Dict[str, Any]:
+  """The ``objective`` dict of ``Trainer.step`` at training step ``step``, from the loss switches and weights train.py reads out of
+  ``TrainConfig`` / ``SpecularConfig`` (train.py:313-355: ``scalar_params``, the static flags of ``training.train_step``, ``state.norm_loss_weight``;
+  defaults as configs.py:40-110, 222-252 and training.py:36-56).  A switched-off loss contributes no key, so ``{}`` (falsy) selects the plain rgb step."""
+  from . import sched
+  b = resolve(path)
+  g = lambda k, d: b.get(k, d)
+  at = lambda key, default: sched.build(b[key] if key in b else default)(step)
+  ob: Dict[str, Any] = {}
+  if g('TrainConfig.use_warp_reg_loss', False):
+    ob.update(warp_reg_loss_weight=float(g('TrainConfig.warp_reg_loss_weight', 0.0)), warp_reg_loss_alpha=float(g('TrainConfig.warp_reg_loss_alpha', -2.0)),
+              warp_reg_loss_scale=float(g('TrainConfig.warp_reg_loss_scale', 0.001)))
+  if g('TrainConfig.use_hyper_reg_loss', False):
+    ob['hyper_reg_loss_weight'] = float(g('TrainConfig.hyper_reg_loss_weight', 0.0))
+  if g('TrainConfig.use_background_loss', False):      # batch['background_points'] comes from the data source (train.py; batch size
+    ob.update(background_loss_weight=float(g('TrainConfig.background_loss_weight', 0.0)),              # TrainConfig.background_points_batch_size)
+              background_noise_std=float(g('TrainConfig.background_noise_std', 0.001)))
+  if g('TrainConfig.use_elastic_loss', False):
+    ob.update(elastic_loss_weight=float(at('TrainConfig.elastic_loss_weight_schedule', None) or 0.0),
+              elastic_reduce_method=g('TrainConfig.elastic_reduce_method', 'weight'), elastic_loss_type=g('TrainConfig.elastic_loss_type', 'log_svals'))
+  if g('SpecularConfig.use_back_facing_reg', False):
+    ob['back_facing_reg_weight'] = float(g('SpecularConfig.back_facing_reg_weight', 0.0))
+  if g('SpecularConfig.use_predicted_norm', False):    # training.py:323-332 with state.norm_loss_weight (train.py:401-427)
+    ob['norm_loss_weight'] = float(at('SpecularConfig.norm_loss_weight_schedule', {'type': 'constant', 'value': 0.001}))
+  if g('NerfModel.use_predicted_mask', False) and float(g('SpecularConfig.predicted_mask_loss_weight', 0.0)) != 0.0:
+    ob['predicted_mask_loss_weight'] = float(g('SpecularConfig.predicted_mask_loss_weight', 0.0))
+    ob['sharp_weights_std'] = float(at('SpecularConfig.sharp_mask_std_schedule', {'type': 'constant', 'value': 1.0}))
+  return ob if any(k.endswith('_weight') and v != 0.0 for k, v in ob.items()) else {}
+

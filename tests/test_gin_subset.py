@@ -58,3 +58,19 @@ def test_reference_base_gin_resolves_to_the_hypernerf_graph():
   cfg = config_from_gin('/root/reference/configs/base.gin', near=0.3, far=1.7, num_warp_embeds=256)
   assert cfg == hypernerf_config(near=0.3, far=1.7, num_warp_embeds=256)
   assert (cfg.warp_in_dim, cfg.hyper_in_dim, cfg.trunk_in_dim, cfg.rgb_in_dim) == (47, 44, 55, 283)
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/configs/nerf_ds.gin'), reason='reference configs not present')
+def test_training_objectives_of_the_reference_gin_files():
+  """The loss switches / weights train.py hands to training.train_step (train.py:313-355), as Trainer.step's objective dict."""
+  from nerfds_amd.gin_subset import objective_from_gin
+  nds = objective_from_gin('/root/reference/configs/nerf_ds.gin', 0)          # nerf_ds.gin:58-65, 82-87, 108, 120-126
+  assert nds == dict(warp_reg_loss_weight=0.001, warp_reg_loss_alpha=-2.0, warp_reg_loss_scale=0.001, back_facing_reg_weight=0.1, norm_loss_weight=0.001,
+                     predicted_mask_loss_weight=0.1, sharp_weights_std=1.0)
+  late = objective_from_gin('/root/reference/configs/nerf_ds.gin', 100000)
+  assert late['sharp_weights_std'] == pytest.approx(0.1) and {k: v for k, v in late.items() if k != 'sharp_weights_std'} == {k: v for k, v in nds.items() if k != 'sharp_weights_std'}
+  mid = objective_from_gin('/root/reference/configs/nerf_ds.gin', 15000)['sharp_weights_std']       # exponential 1 -> 0.1 over 30 000 steps
+  assert mid == pytest.approx(1.0 * 0.1 ** (15000 / 29999), rel=1e-12)
+  # base.gin (HyperNeRF): the background regulariser is ON (base.gin:65-66), the elastic loss off, no specular terms
+  assert objective_from_gin('/root/reference/configs/base.gin', 0) == dict(background_loss_weight=1.0, background_noise_std=0.001)
+
