@@ -262,9 +262,10 @@ int nerfds_frame_images(int device, const float* ray_records, int32_t height, in
  * sized for max_rays.  nerfds_trainer_step: forward + backward of both levels into the gradient vector, then (unless
  * NERFDS_TRAIN_GRADS_ONLY) one Adam update with `learning_rate`.  rays / target_rgb ([R][3]) / rnd->t_rand,u_rand are DEVICE
  * pointers; NULL uniforms with extra->use_stratified_sampling = the on-chip Philox stream described at struct nerfds_rand - the reference always
- * draws the jitter, model_utils.py:84,217 - so pass a new seed every step.  loss_host (optional, HOST float[10]) receives
- * {rgb loss fine (coarse if there is no fine level), rgb loss coarse, weighted warp_reg / back_facing / mask / norm terms of the fine level,
- * the same four of the coarse level} and synchronises the stream.
+ * draws the jitter, model_utils.py:84,217 - so pass a new seed every step.  loss_host (optional, HOST float[16]) receives
+ * {[0] rgb loss fine (coarse if there is no fine level), [1] rgb loss coarse, [2..5] weighted warp_reg / back_facing / mask / norm terms of the fine
+ * level, [6..9] the same four of the coarse level, [10] 0, [11] hyper-point regulariser (coarse level), [12] background regulariser, [13] elastic
+ * regulariser (coarse level), [14..15] 0} and synchronises the stream.
  * Only the configs/nerf_ds.gin graph is built (NERFDS_ENOTSUP otherwise).  With the widths of that gin file the forward of a level is
  * ONE launch of the fused field kernel (the render kernel's evaluation, writing every activation the backward reads; its weight streams
  * are re-packed on the device from the parameter vector at the start of every step); other widths, and the whole backward, run layer by
