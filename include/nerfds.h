@@ -265,7 +265,7 @@ int nerfds_frame_images(int device, const float* ray_records, int32_t height, in
  * draws the jitter, model_utils.py:84,217 - so pass a new seed every step.  loss_host (optional, HOST float[16]) receives
  * {[0] rgb loss fine (coarse if there is no fine level), [1] rgb loss coarse, [2..5] weighted warp_reg / back_facing / mask / norm terms of the fine
  * level, [6..9] the same four of the coarse level, [10] 0, [11] hyper-point regulariser (coarse level), [12] background regulariser, [13] elastic
- * regulariser (coarse level), [14..15] 0} and synchronises the stream.
+ * regulariser (coarse level), [14] / [15] mask occlusion regulariser of the fine / coarse level} and synchronises the stream.
  * Only the configs/nerf_ds.gin graph is built (NERFDS_ENOTSUP otherwise).  With the widths of that gin file the forward of a level is
  * ONE launch of the fused field kernel (the render kernel's evaluation, writing every activation the backward reads; its weight streams
  * are re-packed on the device from the parameter vector at the start of every step); other widths, and the whole backward, run layer by
@@ -302,6 +302,9 @@ typedef struct nerfds_train_objective {
    * Second order in the warp field's weights: it runs the tangent pass like norm_loss_weight (and costs as much).  Reported in loss_host[13]. */
   float elastic_loss_weight;
   int32_t elastic_reduce_by_weight;
+  /* mask occlusion regulariser (training.py:409-417, with the 3-D mask supervision): mean over rays of sum_s max(0.01 - w_s, 0) |predicted mask_s|,
+   * the weights as constants, both levels; reported in loss_host[14] (fine) / [15] (coarse) */
+  float mask_occlusion_reg_loss_weight;
 } nerfds_train_objective;
 #define NERFDS_TRAIN_GRADS_ONLY 1u
 #define NERFDS_TRAIN_SIGMA_GRAD 2u   /* also evaluate the sigma gradient (models.py:1035-1077) -> nerfds_trainer_target_norm */
@@ -328,7 +331,7 @@ int nerfds_trainer_set_step(nerfds_trainer* t, int64_t step);   /* the optimizer
 long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* host, long long max_bytes);
 int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* extra,
                         const nerfds_rand* rnd, const nerfds_train_objective* objective /* NULL = rgb loss only */, float learning_rate,
-                        uint32_t flags, float* loss_host /* HOST float[16] or NULL: [0..13] used, the rest 0 */, void* hip_stream);
+                        uint32_t flags, float* loss_host /* HOST float[16] or NULL: all 16 used */, void* hip_stream);
 /* One Adam update with the gradient vector as it stands (after a NERFDS_TRAIN_GRADS_ONLY step and, on N GPUs, after the
  * all-reduce of nerfds_trainer_grads that replaces jax.lax.pmean(grad), training.py:502). */
 int nerfds_trainer_apply(nerfds_trainer* t, float learning_rate, void* hip_stream);

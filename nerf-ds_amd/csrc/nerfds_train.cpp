@@ -958,7 +958,7 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   if (ob) { ob_level = *ob; if (level != 0) { ob_level.hyper_reg_weight = 0.f; ob_level.elastic_weight = 0.f; } ob = &ob_level; }
   if (ob)     // auxiliary first-order losses: extra upstream gradients for x', the raw normal and the predicted mask
     aux_losses(st, R, S, *ob, z, weights_out, t.x, t.xw, t.alphav, viewdirs, t.mask_logit, rays->gt_mask, t.terms_dev + 4 * level, t.dxw_reg,
-               t.d_alpha, t.d_pm, t.wamb, t.terms_dev + 9 + level, t.dwamb_reg);
+               t.d_alpha, t.d_pm, t.wamb, t.terms_dev + 9 + level, t.dwamb_reg, t.terms_dev + 13 + level);
   const bool nl = norm_weight != 0.f;
   // hyper-point regulariser: one more upstream gradient of the ambient coordinates - of the COARSE level only (training.py:461-466 passes
   // use_hyper_reg_loss to the coarse level's _compute_loss_and_stats; the fine level runs with its default, False)
@@ -1348,10 +1348,11 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     ob.sharp_weights_std = objective->sharp_weights_std; ob.use_sharp_weights = objective->use_mask_sharp_weights;
     ob.hyper_reg_weight = objective->hyper_reg_loss_weight;
     ob.elastic_weight = objective->elastic_loss_weight; ob.elastic_by_weight = objective->elastic_reduce_by_weight;
+    ob.mask_occlusion_weight = objective->mask_occlusion_reg_loss_weight;
     if (ob.mask_loss_weight != 0.f && !rays->gt_mask) return t->fail(NERFDS_EINVAL, "the mask loss needs rays_dict['mask']");
     if (ob.use_sharp_weights && !(ob.sharp_weights_std > 0.f)) return t->fail(NERFDS_EINVAL, "sharp_weights_std must be > 0");
     // (a background-only objective keeps the plain - merged - flow of the levels: the per-ray auxiliary kernel has nothing to do)
-    if (ob.warp_reg_weight != 0.f || ob.back_facing_weight != 0.f || ob.mask_loss_weight != 0.f || ob.hyper_reg_weight != 0.f || ob.elastic_weight != 0.f || objective->norm_loss_weight != 0.f)
+    if (ob.warp_reg_weight != 0.f || ob.back_facing_weight != 0.f || ob.mask_loss_weight != 0.f || ob.hyper_reg_weight != 0.f || ob.elastic_weight != 0.f || ob.mask_occlusion_weight != 0.f || objective->norm_loss_weight != 0.f)
       obp = &ob;
     if (objective->background_loss_weight != 0.f) {
       if (!objective->background_points || !objective->background_ids || objective->num_background_points < 1)
@@ -1361,7 +1362,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     }
   }
   (void)hipMemsetAsync(t->terms_dev, 0, 8 * sizeof(float), st);
-  (void)hipMemsetAsync(t->terms_dev + 9, 0, 4 * sizeof(float), st);          // ... [12]: elastic regulariser
+  (void)hipMemsetAsync(t->terms_dev + 9, 0, 6 * sizeof(float), st);          // ... [12]: elastic regulariser, [13], [14]: mask occlusion regulariser (coarse / fine)
   // [9], [10]: hyper-point regulariser of the coarse / fine level, [11]: background loss ([8]: non-finite flag)
   const float norm_weight = objective ? objective->norm_loss_weight : 0.f;
   const bool elastic = objective && objective->elastic_loss_weight != 0.f;      // second order like the norm loss: needs the tangent pass and its backward
@@ -1418,7 +1419,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     float l[2];
     if (hipMemcpyAsync(l, t->loss_dev, sizeof l, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       return t->fail(NERFDS_EDEVICE, "loss read-back failed");
-    float tm[13];
+    float tm[15];
     if (hipMemcpy(tm, t->terms_dev, sizeof tm, hipMemcpyDeviceToHost) != hipSuccess) return t->fail(NERFDS_EDEVICE, "loss read-back failed");
     unsigned nonfinite = 0;
     std::memcpy(&nonfinite, &tm[8], sizeof nonfinite);
@@ -1429,7 +1430,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     loss_host[10] = tm[9 + fl]; loss_host[11] = tm[9];                                                // weighted hyper-point regulariser: fine, coarse
     loss_host[12] = tm[11];                                                                            // weighted background regulariser
     loss_host[13] = tm[12];                                                                            // weighted elastic regulariser (coarse level)
-    loss_host[14] = loss_host[15] = 0.f;
+    loss_host[14] = tm[13 + fl]; loss_host[15] = tm[13];                                              // weighted mask occlusion regulariser: fine, coarse
     if (nonfinite && !(flags & NERFDS_TRAIN_GRADS_ONLY))
       return t->fail(NERFDS_ENONFINITE, "non-finite gradient: the Adam update of this step was skipped (f16 activations / scaled f16 g overflowed? NERFDS_TRAIN_G16=0 "
                                         "keeps g in fp32; a step with the sigma-gradient flag keeps fp32 activations)");

@@ -21,6 +21,7 @@ struct Objective {   // weights of the auxiliary losses (0 = off); mirrors nerfd
   float hyper_reg_weight;
   float elastic_weight;       // elastic regulariser on the warp Jacobian (coarse level), elastic_by_weight: 'weight' reduction instead of 'median'
   int elastic_by_weight;
+  float mask_occlusion_weight;   // training.py:409-417
 };
 
 void coarse_z(hipStream_t, int R, int Nc, float near_, float far_, int stratified, int lindisp, const float* t_rand, uint64_t seed, long long first_ray, float* z);
@@ -46,7 +47,7 @@ void se3_jvp_bwd(hipStream_t, long long M, const float* wv, const float* x, cons
                  const float* ghat, float* d_t_wv, float* dwv_extra);
 void aux_losses(hipStream_t, int R, int S, const Objective&, const float* z, const float* weights, const float* x, const float* xw, const float* alpha,
                 const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg, float* d_alpha, float* d_pm,
-                const float* wamb = nullptr, float* term_hyper = nullptr, float* dwamb_reg = nullptr);   // hyper-point regulariser: ambient coordinates in, its term and d / d wamb out
+                const float* wamb = nullptr, float* term_hyper = nullptr, float* dwamb_reg = nullptr, float* term_occlusion = nullptr);   // hyper-point regulariser: ambient coordinates in, its term and d / d wamb out
 void add_inplace(hipStream_t, float* dst, const float* src, long long n);
 // background regulariser (training.py:159-183): term += weight * mean_i general_loss(|xw_i - x_i|^2, alpha, scale); dxw = its gradient w.r.t. xw
 // elastic regulariser (training.py:112-156 'log_svals', 274-295): t_xw = the tangents of the warped point, row 3 m + j = d x' / d x_j (the Jacobian's

@@ -735,7 +735,7 @@ __global__ void k_aux_losses(int R, int S, Objective ob, const float* __restrict
                              const float* __restrict__ xw, const float* __restrict__ alpha, const float* __restrict__ viewdirs,
                              const float* __restrict__ mask_logit, const float* __restrict__ gt_mask, float* __restrict__ terms,
                              float* __restrict__ dxw_reg, float* __restrict__ d_alpha, float* __restrict__ d_pm, const float* __restrict__ wamb,
-                             float* __restrict__ term_hyper, float* __restrict__ dwamb_reg) {
+                             float* __restrict__ term_hyper, float* __restrict__ dwamb_reg, float* __restrict__ term_occlusion) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const float* w = weights + (size_t)r * S;
@@ -815,6 +815,17 @@ __global__ void k_aux_losses(int R, int S, Objective ob, const float* __restrict
       atomicAdd(terms + 2, ob.mask_loss_weight * e * e / (float)R);
       for (int s = 0; s < S; ++s) d_pm[(size_t)r * S + s] = ob.mask_loss_weight * 2.0f * e / (float)R * w[s];
     }
+  }
+  // mask occlusion regulariser (training.py:409-417): where hardly any weight lands, the predicted mask should be 0
+  if (ob.mask_occlusion_weight != 0.f && term_occlusion != nullptr) {
+    const float k = ob.mask_occlusion_weight / (float)R;
+    float l = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float low = fmaxf(0.01f - w[s], 0.f);
+      l += low * fmaxf(mask_logit[(size_t)r * S + s], 0.f);        // |relu(logit)|
+      d_pm[(size_t)r * S + s] += k * low;                          // (the ReLU's own mask is applied with d_pm in shared_in_bwd)
+    }
+    atomicAdd(term_occlusion, k * l);
   }
 }
 
@@ -1036,9 +1047,9 @@ void se3_jvp_bwd(hipStream_t st, long long M, const float* wv, const float* x, c
 }
 void aux_losses(hipStream_t st, int R, int S, const Objective& ob, const float* z, const float* weights, const float* x, const float* xw,
                 const float* alpha, const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg,
-                float* d_alpha, float* d_pm, const float* wamb, float* term_hyper, float* dwamb_reg) {
+                float* d_alpha, float* d_pm, const float* wamb, float* term_hyper, float* dwamb_reg, float* term_occlusion) {
   hipLaunchKernelGGL(k_aux_losses, grid1(R, 64), dim3(64), 0, st, R, S, ob, z, weights, x, xw, alpha, viewdirs, mask_logit, gt_mask, terms, dxw_reg,
-                     d_alpha, d_pm, wamb, term_hyper, dwamb_reg);
+                     d_alpha, d_pm, wamb, term_hyper, dwamb_reg, term_occlusion);
 }
 __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, long long n) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;

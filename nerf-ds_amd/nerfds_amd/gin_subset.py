@@ -204,5 +204,7 @@ def objective_from_gin(path: str, step: int = 0) -> Dict[str, Any]:
   if g('NerfModel.use_predicted_mask', False) and float(g('SpecularConfig.predicted_mask_loss_weight', 0.0)) != 0.0:
     ob['predicted_mask_loss_weight'] = float(g('SpecularConfig.predicted_mask_loss_weight', 0.0))
     ob['sharp_weights_std'] = float(at('SpecularConfig.sharp_mask_std_schedule', {'type': 'constant', 'value': 1.0}))
+    if g('SpecularConfig.use_mask_occlusion_reg_loss', False):      # training.py:409-417 (inside the 3-D mask branch)
+      ob['mask_occlusion_reg_loss_weight'] = float(g('SpecularConfig.mask_occlusion_reg_loss_weight', 1.0))
   return ob if any(k.endswith('_weight') and v != 0.0 for k, v in ob.items()) else {}
 

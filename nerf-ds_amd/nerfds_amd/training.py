@@ -23,7 +23,7 @@ class Objective(C.Structure):
               ('use_mask_sharp_weights', C.c_int32), ('norm_loss_weight', C.c_float), ('hyper_reg_loss_weight', C.c_float),
               ('background_loss_weight', C.c_float), ('background_loss_alpha', C.c_float), ('background_loss_scale', C.c_float),
               ('background_points', C.c_void_p), ('background_ids', C.c_void_p), ('num_background_points', C.c_int64),
-              ('elastic_loss_weight', C.c_float), ('elastic_reduce_by_weight', C.c_int32)]
+              ('elastic_loss_weight', C.c_float), ('elastic_reduce_by_weight', C.c_int32), ('mask_occlusion_reg_loss_weight', C.c_float)]
 
 
 class _DevVec:
@@ -259,6 +259,7 @@ class Trainer:
                      predicted_mask_loss_weight=objective.get('predicted_mask_loss_weight', 0.0), sharp_weights_std=objective.get('sharp_weights_std', 1.0),
                      use_mask_sharp_weights=int(self.cfg.use_mask_sharp_weights), norm_loss_weight=objective.get('norm_loss_weight', 0.0),
                      hyper_reg_loss_weight=objective.get('hyper_reg_loss_weight', 0.0))
+      ob.mask_occlusion_reg_loss_weight = float(objective.get('mask_occlusion_reg_loss_weight', 0.0))      # training.py:409-417
       if objective.get('elastic_loss_weight', 0.0):         # training.py:112-156, 274-295
         if objective.get('elastic_loss_type', 'log_svals') != 'log_svals':
           raise NotImplementedError("elastic_loss_type: only 'log_svals' (the reference's default) is built")
@@ -323,6 +324,8 @@ class Trainer:
     stats['loss/background'] = float(loss[12])                                                           # training.py:468-479
     stats['loss/elastic'] = float(loss[13])                                                              # training.py:274-295 (coarse level)
     aux += float(loss[12]) + float(loss[13])
+    stats['loss/mask_occlusion_reg/fine'], stats['loss/mask_occlusion_reg/coarse'] = float(loss[14]), float(loss[15])      # training.py:409-417
+    aux += (float(loss[14]) if two else 0.0) + float(loss[15])
     stats['loss/total'] = (fine + coarse if two else coarse) + aux
     return stats
 

@@ -53,6 +53,9 @@ def auxiliary_losses(cfg, out, rays_dict, objective, dtype, level='coarse'):
     gt = torch.as_tensor(np.asarray(rays_dict['mask'])).to(dtype).reshape(-1)
     w = out['sharp_weights'].detach() if cfg.use_mask_sharp_weights else weights
     terms['predicted_mask'] = objective['predicted_mask_loss_weight'] * ((gt - (w * pm).sum(-1)) ** 2).mean()
+  if objective.get('mask_occlusion_reg_loss_weight', 0.0):                     # training.py:409-417
+    low = torch.clamp(0.01 - weights, min=0.0)
+    terms['mask_occlusion_reg'] = objective['mask_occlusion_reg_loss_weight'] * (low * out['predicted_mask'].squeeze(-1).abs()).sum(-1).mean()
   if objective.get('hyper_reg_loss_weight', 0.0) and level == 'coarse':        # training.py:312-321; the COARSE level only (training.py:461-466: the fine
     #                                                                             level is evaluated with use_hyper_reg_loss at its default, False)
     resid = (out['warped_points'][..., 3:] ** 2).sum(-1)

@@ -310,7 +310,7 @@ def test_auxiliary_losses_match_the_oracle(sharp, gemm):
   cfg = cfg.replace(use_mask_sharp_weights=sharp)
   # give the mask / normal heads something to supervise (the init regime has relu(mask logit) == 0 everywhere)
   params['mask_mlp']['MLP_0']['logit']['bias'] = np.asarray(params['mask_mlp']['MLP_0']['logit']['bias']) + 0.7      # logits span [-1.0, -0.35] at init: make relu(logit) a mix of zeros and positives
-  ob = dict(OBJECTIVE, hyper_reg_loss_weight=0.01)      # + the hyper-point regulariser (training.py:312-321; off in nerf_ds.gin, on in HyperNeRF's own configs)
+  ob = dict(OBJECTIVE, hyper_reg_loss_weight=0.01, mask_occlusion_reg_loss_weight=1.0)      # + the mask occlusion regulariser (training.py:409-417) and the hyper-point regulariser (training.py:312-321; off in nerf_ds.gin, on in HyperNeRF's own configs)
   L, G, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=ob)
   L0, G0, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=OBJECTIVE)
   tr = Trainer(cfg, params, max_rays=40)
@@ -319,7 +319,7 @@ def test_auxiliary_losses_match_the_oracle(sharp, gemm):
   assert hs > 0.05 * np.linalg.norm(dict(tree_leaves(G0))['hyper_sheet_mlp/MLP_0/logit/kernel'])      # the regulariser moves the hyper sheet's gradient visibly
   assert stats['loss/hyper_reg/fine'] == 0.0 and 'hyper_reg/fine' not in L      # coarse level only (training.py:461-466)
   for level in ('fine', 'coarse'):
-    for k in ('warp_reg', 'back_facing', 'predicted_mask') + (('hyper_reg',) if level == 'coarse' else ()):
+    for k in ('warp_reg', 'back_facing', 'predicted_mask', 'mask_occlusion_reg') + (('hyper_reg',) if level == 'coarse' else ()):
       want = L[f'{k}/{level}']
       assert abs(stats[f'loss/{k}/{level}'] - want) <= 2e-4 * max(abs(want), 1e-4), (k, level, stats[f'loss/{k}/{level}'], want)
   assert abs(stats['loss/total'] - L['total']) < 1e-4 * L['total']
