@@ -273,6 +273,19 @@ static launch_fn launcher(int graph, uint32_t prec) {
 extern "C" {
 
 int nerfds_abi_version(void) { return NERFDS_ABI_VERSION; }
+int64_t nerfds_struct_size(int which) {
+  switch (which) {
+    case 0: return sizeof(nerfds_model_cfg);
+    case 1: return sizeof(nerfds_weights);
+    case 2: return sizeof(nerfds_camera);
+    case 3: return sizeof(nerfds_rays);
+    case 4: return sizeof(nerfds_extra);
+    case 5: return sizeof(nerfds_rand);
+    case 6: return sizeof(nerfds_out);
+    case 7: return sizeof(nerfds_train_objective);
+    default: return -1;
+  }
+}
 
 int nerfds_precision_plan(uint32_t prec, int32_t plan_out[5]) {
   if (prec >= NERFDS_PREC_COUNT || !plan_out) return NERFDS_EINVAL;

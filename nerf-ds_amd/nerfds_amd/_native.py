@@ -125,7 +125,7 @@ class Out(C.Structure):
 
 
 # every symbol include/nerfds.h declares
-SYMBOLS = ('nerfds_abi_version', 'nerfds_precision_plan', 'nerfds_ctx_create', 'nerfds_ctx_load_weights', 'nerfds_render_rays',
+SYMBOLS = ('nerfds_abi_version', 'nerfds_struct_size', 'nerfds_precision_plan', 'nerfds_ctx_create', 'nerfds_ctx_load_weights', 'nerfds_render_rays',
            'nerfds_encode_embed', 'nerfds_ctx_destroy', 'nerfds_last_error', 'nerfds_kernel_time_ms', 'nerfds_pack_stream_bytes',
            'nerfds_pack_bias_floats', 'nerfds_pack_tile_pair', 'nerfds_pack_stream', 'nerfds_debug_mfma', 'nerfds_camera_to_rays',
            'nerfds_frame_images', 'nerfds_trainer_create', 'nerfds_trainer_destroy', 'nerfds_trainer_param_count',
@@ -169,6 +169,11 @@ def load():
                                       C.c_void_p, C.c_void_p]
   if lib.nerfds_abi_version() != ABI_VERSION:
     raise RuntimeError('libnerfds_hip.so ABI version mismatch: rebuild')
+  lib.nerfds_struct_size.argtypes = [C.c_int]
+  lib.nerfds_struct_size.restype = C.c_int64
+  for which, st in enumerate((ModelCfg, Weights, CameraStruct, Rays, Extra, Rand, Out)):      # the ctypes mirrors against the library's own sizeof
+    if lib.nerfds_struct_size(which) != C.sizeof(st):
+      raise RuntimeError(f'{st.__name__}: ctypes declares {C.sizeof(st)} bytes, libnerfds_hip.so has {lib.nerfds_struct_size(which)} (include/nerfds.h changed?)')
   _lib = lib
   return lib
 
