@@ -81,6 +81,7 @@ struct nerfds_trainer {
   std::vector<float*> tw_h, th_h, tt_h;
   float *d_t_alpha, *d_t_tin, *d_t_xw, *d_t_wamb, *d_t_wv, *du, *ghat, *dwamb_extra, *dwv_extra;
   bool tn_valid = false;
+  bool tangents_warp_only = false;   // this step's tangent pass stops at the warped point (elastic regulariser without norm loss / sigma-gradient flag)
   bool keep_tangents = false;
   void* wpack = nullptr;    // MFMA fragments of the layer being run (train_gemm.hip)
   // Gradient replicas: the MFMA kernels end with float atomics from every workgroup at once; on one copy of a small leaf they queue
@@ -526,6 +527,7 @@ void sigma_gradient(nerfds_trainer& t, Run& r, int level, const Windows& W) {
   r.dense_jvp(t.warp_v, {{tw, t.warp.width, t.warp.width, nullptr, 0, false}}, t.t_wv + 3, 6);
   r.precise_layers = false;
   se3_jvp(st, M, t.wv, t.x, t.t_wv, t.t_xw);
+  if (t.tangents_warp_only) return;        // the elastic regulariser reads d x' / d x and nothing behind it
   float* th = r.mlp_jvp(t.hyper, t.t_hyper_in, t.hyper_h, t.tA, t.tB, keep ? &t.th_h : nullptr);
   r.dense_jvp(t.hyper_out, {{th, t.hyper.width, t.hyper.width, nullptr, 0, false}}, t.t_wamb, 2);
   trunk_in_jvp(st, D, M, t.xw, t.wamb, t.t_xw, t.t_wamb, W, t.t_tin);
@@ -1379,7 +1381,10 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   t->keep_tangents = norm_weight != 0.f || elastic;
   if ((norm_weight != 0.f || elastic) && (!ensure_tangent_ws(*t) || !ensure_norm_ws(*t))) return t->fail(NERFDS_ENOMEM, "hipMalloc of the norm-loss workspace failed");
   if (want_sg && !ensure_tangent_ws(*t)) return t->fail(NERFDS_ENOMEM, "hipMalloc of the tangent workspace failed");
-  t->tn_valid = want_sg;
+  // the elastic regulariser reads the tangents of the COARSE level only: without the norm loss (or the caller's flag) the fine level runs no tangent pass
+  const bool want_sg_fine = (flags & NERFDS_TRAIN_SIGMA_GRAD) != 0 || norm_weight != 0.f;
+  t->tn_valid = want_sg_fine;
+  t->tangents_warp_only = elastic && !want_sg_fine;
   // NERFDS_TRAIN_MERGED=0: the two levels one after the other, each with its own pass over the shared networks (A/B, and every step the merged
   // flow does not cover: auxiliary losses, tangent passes, one level, the layer-by-layer kernels)
   static const bool merged_on = !(getenv("NERFDS_TRAIN_MERGED") && std::string(getenv("NERFDS_TRAIN_MERGED")) == "0");
@@ -1392,7 +1397,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   if (rc != NERFDS_OK) return rc;
   if (Nf > 0) {
     resample(st, R, Nc, Nf, t->zc, t->wc, strat, rnd ? rnd->u_rand : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->first_ray : 0, t->zf, t->rs_scratch);
-    rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights, want_sg, obp, norm_weight);
+    rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights, want_sg_fine, obp, norm_weight);
     if (rc != NERFDS_OK) return rc;
   }
   }
