@@ -138,7 +138,7 @@ struct nerfds_trainer {
   // amplify and 2^-19 .. 2^-29 of it (f16's normal .. denormal range) still represented; a g beyond the range gives an inf weight gradient
   // and the step reports NERFDS_ENONFINITE.  NERFDS_TRAIN_G_SCALE_LOG2 overrides the exponent.
   float g_scale = 1.f;
-  bool half_step = false;    // this step's forward wrote f16 + bits (no tangent pass needs the fp32 activations)
+  bool half_step = false;    // this step's forward wrote f16 + bits
   std::string err;
   // workspace views (set by carve())
   float *zc, *zf, *wc, *rs_scratch, *x, *mask_in, *mask_logit, *warp_in, *wv, *xw, *hyper_in, *wamb, *trunk_in, *bottv, *alphav, *sigma,
@@ -955,7 +955,16 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   }
   composite_loss(st, R, S, z, rays->directions, t.sigma, t.rgb_logit, target, t.cfg.use_sample_at_infinity, t.cfg.use_white_background, t.rgb_ray,
                  weights_out, t.loss_dev + level, t.d_rgb_logit, t.d_alpha);
-  if (want_sigma_gradient) sigma_gradient(t, r, level, W);
+  if (want_sigma_gradient) {
+    if (t.half_step) {      // the tangent pass reads the primal layers' ReLU masks as fp32 arrays: the f16 activations, widened (their sign is all it uses)
+      for (int l = 0; l < t.warp.depth; ++l) expand_half(st, t.warp_h16[l], t.warp_h[l], M * t.warp.width);
+      if (!t.tangents_warp_only) {
+        for (int l = 0; l < t.hyper.depth; ++l) expand_half(st, t.hyper_h16[l], t.hyper_h[l], M * t.hyper.width);
+        for (int l = 0; l < trunk.depth; ++l) expand_half(st, t.trunk_h16[l], t.trunk_h[l], M * trunk.width);
+      }
+    }
+    sigma_gradient(t, r, level, W);
+  }
   Objective ob_level;
   if (ob) { ob_level = *ob; if (level != 0) { ob_level.hyper_reg_weight = 0.f; ob_level.elastic_weight = 0.f; } ob = &ob_level; }
   if (ob)     // auxiliary first-order losses: extra upstream gradients for x', the raw normal and the predicted mask
@@ -975,6 +984,29 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
     (void)hipMemsetAsync(t.d_t_xw, 0, (size_t)9 * M * sizeof(float), st);
     (void)hipMemsetAsync(t.du, 0, (size_t)3 * M * sizeof(float), st);
     (void)hipMemsetAsync(t.ghat, 0, (size_t)3 * M * sizeof(float), st);
+  }
+  // Backward of the tangent pass (second order: norm loss, elastic regulariser), BEFORE the primal backward: it reads the primal layers' ReLU masks in
+  // the fp32 activation arrays - which the half step's chains are about to overwrite with g - and leaves what the primal backward adds to its
+  // own upstream gradients: dxw_reg / dwamb_extra (second-derivative terms of the encodings) and dwv_extra (of exp_se3).
+  if (so) {
+    const float* tout_m = t.trunk_h.back();
+    bool pm2;
+    if (nl) {   // part 1: alpha head, trunk, trunk input (adds second-derivative terms to d x', d w)
+      pm2 = r.dense_jvp_bwd(t.alpha[level], {{t.tt_h.back(), trunk.width, trunk.width, t.tA, trunk.width, false, tout_m, nullptr}}, t.d_t_alpha, 4, nullptr);
+      r.mlp_jvp_bwd(trunk, t.t_tin, t.tt_h, t.trunk_h, t.tA, t.tB, t.d_t_tin, pm2);
+      trunk_in_jvp_bwd(st, D, M, t.d_t_tin, t.xw, t.wamb, t.t_xw, t.t_wamb, W, t.d_t_xw, t.d_t_wamb, t.dxw_reg, t.dwamb_extra);
+      if (hreg) add_inplace(st, t.dwamb_extra, t.dwamb_reg, 2 * M);      // both extra gradients of the ambient coordinates in one array
+    }
+    if (el) elastic_loss(st, R, S, ob->elastic_weight, ob->elastic_by_weight, weights_out, t.t_xw, t.terms_dev + 12, t.d_t_xw);   // (+= : behind trunk_in_jvp_bwd's write)
+    if (nl) {   // part 2: hyper sheet tangents
+      pm2 = r.dense_jvp_bwd(t.hyper_out, {{t.th_h.back(), t.hyper.width, t.hyper.width, t.tA, t.hyper.width, false, t.hyper_h.back(), nullptr}}, t.d_t_wamb, 2, nullptr);
+      r.mlp_jvp_bwd(t.hyper, t.t_hyper_in, t.th_h, t.hyper_h, t.tA, t.tB, nullptr, pm2);
+    }
+    // part 3: exp_se3 tangents (second derivatives) and the warp net's tangents
+    se3_jvp_bwd(st, M, t.wv, t.x, t.t_wv, t.d_t_xw, t.du, t.ghat, t.d_t_wv, t.dwv_extra);
+    r.dense_jvp_bwd(t.warp_w, {{t.tw_h.back(), t.warp.width, t.warp.width, t.tA, t.warp.width, false}}, t.d_t_wv, 6, nullptr);
+    pm2 = r.dense_jvp_bwd(t.warp_v, {{t.tw_h.back(), t.warp.width, t.warp.width, t.tA, t.warp.width, true, t.warp_h.back(), nullptr}}, t.d_t_wv + 3, 6, nullptr);
+    r.mlp_jvp_bwd(t.warp, t.t_warp_in, t.tw_h, t.warp_h, t.tA, t.tB, nullptr, pm2);
   }
   // ---------------- backward ----------------
   const int RW = t.rgb_h[level].N;
@@ -1008,10 +1040,10 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
     };
     fused_backward(t, st, 0, level, M, t.d_rgb_logit, 3, t.d_alpha, t.d_trunk_in, D.trunk_in);
     if (early) { r.fork(false); wg_nerf(); }
-    trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, hreg ? t.dwamb_reg : nullptr, t.dxw, t.dwamb);
+    trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, nl ? t.dwamb_extra : (hreg ? t.dwamb_reg : nullptr), t.dxw, t.dwamb);
     fused_backward(t, st, 1, level, M, t.dwamb, 2, nullptr, t.d_hyper_in, D.hyper_ld);
     if (early) { r.fork(false); wg_hyper(); }
-    se3_bwd(st, M, t.wv, t.x, t.dxw, nullptr, t.dwv);
+    se3_bwd(st, M, t.wv, t.x, t.dxw, so ? t.dwv_extra : nullptr, t.dwv);
     fused_backward(t, st, 2, level, M, t.dwv, 6, nullptr, t.d_warp_in, D.warp_ld);
     if (early) { r.fork(false); wg_warp(); }
     shared_in_bwd(st, D, R, S, t.d_warp_in, t.d_hyper_in, t.mask_logit, ex->mask_ratio, ob ? t.d_pm : nullptr, rays->warp_id, t.cfg.num_warp_embeds,
@@ -1032,26 +1064,9 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   r.dense_bwd(t.bott[level], {{tout, TW, TW, t.g2, TW, true}}, t.g1, TW, nullptr);
   pm = r.dense_bwd(t.alpha[level], {{tout, TW, TW, t.g2, TW, true, tout, t.grad + trunk.hidden.back().b}}, t.d_alpha, 4, nullptr);
   r.mlp_bwd(trunk, t.trunk_in, t.trunk_h, t.g2, t.g0, t.d_trunk_in, pm);
-  if (nl) {   // backward of the tangent pass, part 1: alpha head, trunk, trunk input (adds second-derivative terms to d x', d w)
-    pm = r.dense_jvp_bwd(t.alpha[level], {{t.tt_h.back(), TW, TW, t.tA, TW, false, tout, nullptr}}, t.d_t_alpha, 4, nullptr);
-    r.mlp_jvp_bwd(trunk, t.t_tin, t.tt_h, t.trunk_h, t.tA, t.tB, t.d_t_tin, pm);
-    trunk_in_jvp_bwd(st, D, M, t.d_t_tin, t.xw, t.wamb, t.t_xw, t.t_wamb, W, t.d_t_xw, t.d_t_wamb, t.dxw_reg, t.dwamb_extra);
-    if (hreg) add_inplace(st, t.dwamb_extra, t.dwamb_reg, 2 * M);      // both extra gradients of the ambient coordinates in one array
-  }
-  if (el) elastic_loss(st, R, S, ob->elastic_weight, ob->elastic_by_weight, weights_out, t.t_xw, t.terms_dev + 12, t.d_t_xw);   // (+= : behind trunk_in_jvp_bwd's write)
   trunk_in_bwd(st, D, M, t.d_trunk_in, t.xw, t.wamb, W, ob ? t.dxw_reg : nullptr, nl ? t.dwamb_extra : (hreg ? t.dwamb_reg : nullptr), t.dxw, t.dwamb);
-  if (nl) {   // part 2: hyper sheet tangents
-    pm = r.dense_jvp_bwd(t.hyper_out, {{t.th_h.back(), t.hyper.width, t.hyper.width, t.tA, t.hyper.width, false, t.hyper_h.back(), nullptr}}, t.d_t_wamb, 2, nullptr);
-    r.mlp_jvp_bwd(t.hyper, t.t_hyper_in, t.th_h, t.hyper_h, t.tA, t.tB, nullptr, pm);
-  }
   pm = r.dense_bwd(t.hyper_out, {{t.hyper_h.back(), t.hyper.width, t.hyper.width, t.g0, t.hyper.width, false, t.hyper_h.back(), t.grad + t.hyper.hidden.back().b}}, t.dwamb, 2, nullptr);
   r.mlp_bwd(t.hyper, t.hyper_in, t.hyper_h, t.g0, t.g1, t.d_hyper_in, pm);
-  if (so) {   // part 3: exp_se3 tangents (second derivatives) and the warp net's tangents
-    se3_jvp_bwd(st, M, t.wv, t.x, t.t_wv, t.d_t_xw, t.du, t.ghat, t.d_t_wv, t.dwv_extra);
-    r.dense_jvp_bwd(t.warp_w, {{t.tw_h.back(), t.warp.width, t.warp.width, t.tA, t.warp.width, false}}, t.d_t_wv, 6, nullptr);
-    pm = r.dense_jvp_bwd(t.warp_v, {{t.tw_h.back(), t.warp.width, t.warp.width, t.tA, t.warp.width, true, t.warp_h.back(), nullptr}}, t.d_t_wv + 3, 6, nullptr);
-    r.mlp_jvp_bwd(t.warp, t.t_warp_in, t.tw_h, t.warp_h, t.tA, t.tB, nullptr, pm);
-  }
   se3_bwd(st, M, t.wv, t.x, t.dxw, so ? t.dwv_extra : nullptr, t.dwv);
   r.dense_bwd(t.warp_w, {{t.warp_h.back(), t.warp.width, t.warp.width, t.g0, t.warp.width, false}}, t.dwv, 6, nullptr);
   pm = r.dense_bwd(t.warp_v, {{t.warp_h.back(), t.warp.width, t.warp.width, t.g0, t.warp.width, true, t.warp_h.back(), t.grad + t.warp.hidden.back().b}}, t.dwv + 3, 6, nullptr);
@@ -1369,8 +1384,10 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   const float norm_weight = objective ? objective->norm_loss_weight : 0.f;
   const bool elastic = objective && objective->elastic_loss_weight != 0.f;      // second order like the norm loss: needs the tangent pass and its backward
   const bool want_sg = (flags & NERFDS_TRAIN_SIGMA_GRAD) != 0 || norm_weight != 0.f || elastic;
-  // the tangent passes (sigma gradient, norm loss) read the fp32 activations: those steps keep the layer-by-layer backward
-  t->half_step = t->fused_fwd && t->fused_bwd && !want_sg;
+  // the tangent passes (sigma gradient, norm loss, elastic regulariser) read the primal ReLU masks only: the primal pass stays on the fused f16 step
+  // (NERFDS_TRAIN_HALF_TANGENTS=0: fp32 activations and the layer-by-layer backward for those steps, as through round 4's first half)
+  static const bool half_tangents = !(getenv("NERFDS_TRAIN_HALF_TANGENTS") && std::string(getenv("NERFDS_TRAIN_HALF_TANGENTS")) == "0");
+  t->half_step = t->fused_fwd && t->fused_bwd && (!want_sg || half_tangents);
   if (t->half_step) pack_fused_backward(*t, st);
   {
     int e = 6;
@@ -1389,7 +1406,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   // flow does not cover: auxiliary losses, tangent passes, one level, the layer-by-layer kernels)
   static const bool merged_on = !(getenv("NERFDS_TRAIN_MERGED") && std::string(getenv("NERFDS_TRAIN_MERGED")) == "0");
   int rc;
-  if (merged_on && t->half_step && Nf > 0 && !obp && resample_has_sources(Nc, Nf) && t->g0 && 11 * (int64_t)R * (Nc + Nf) <= (int64_t)t->max_rays * (Nc + Nf) * t->trunk[0].width) {
+  if (merged_on && t->half_step && !want_sg && Nf > 0 && !obp && resample_has_sources(Nc, Nf) && t->g0 && 11 * (int64_t)R * (Nc + Nf) <= (int64_t)t->max_rays * (Nc + Nf) * t->trunk[0].width) {
     rc = run_merged(*t, st, R, t->zc, rays, target_rgb, ex, W, rnd);
     if (rc != NERFDS_OK) return rc;
   } else {
@@ -1438,7 +1455,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     loss_host[14] = tm[13 + fl]; loss_host[15] = tm[13];                                              // weighted mask occlusion regulariser: fine, coarse
     if (nonfinite && !(flags & NERFDS_TRAIN_GRADS_ONLY))
       return t->fail(NERFDS_ENONFINITE, "non-finite gradient: the Adam update of this step was skipped (f16 activations / scaled f16 g overflowed? NERFDS_TRAIN_G16=0 "
-                                        "keeps g in fp32; a step with the sigma-gradient flag keeps fp32 activations)");
+                                        "keeps g in fp32, NERFDS_TRAIN_HALF_TANGENTS=0 fp32 activations for the steps with a tangent pass)");
   }
   return NERFDS_OK;
 }

@@ -1056,6 +1056,16 @@ __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__
   if (i < n) dst[i] += src[i];
 }
 void add_inplace(hipStream_t st, float* dst, const float* src, long long n) { LAUNCH(k_add_inplace, n, st, dst, src, n); }
+__global__ void k_expand_half(const uint16_t* __restrict__ h, float* __restrict__ out, long long n8) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  const h8 v = *reinterpret_cast<const h8*>(h + 8 * i);
+  float4 a = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]), b = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+  *reinterpret_cast<float4*>(out + 8 * i) = a;
+  *reinterpret_cast<float4*>(out + 8 * i + 4) = b;
+}
+void expand_half(hipStream_t st, const uint16_t* h16, float* out, long long n) { LAUNCH(k_expand_half, n / 8, st, h16, out, n / 8); }
 // Singular values / vectors of a 3 x 3 matrix through the eigen-decomposition of J^T J (cyclic Jacobi in double: the warp Jacobian is close to a
 // rotation, its singular values close to each other - any basis of a (near-)degenerate eigenspace gives the same sum over i of f'(s_i) u_i v_i^T).
 __global__ void k_elastic_loss(int R, int S, float weight, int by_weight, const float* __restrict__ weights, const float* __restrict__ t_xw,
