@@ -124,23 +124,32 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void train
 
 // the trainer's arithmetic: 16-bit split operands everywhere, fp32 products in the warp field
 using KernelPlan = PlanT<TRAIN_PLAN.mask, TRAIN_PLAN.warp, TRAIN_PLAN.hyp, TRAIN_PLAN.trunk, TRAIN_PLAN.rgb>;
+// MODE 1 (the shared networks alone, 64 - 128 wide): their activations fit 256 registers, so EIGHT waves - two per SIMD, two per ray - share the
+// workgroup's weight ring and the stream is walked once per 256 samples instead of once per 128 (the narrow backward chains' change).
+// -DNERFDS_FWD_SHARED_WAVES8=0: four waves as the other modes.
+#ifndef NERFDS_FWD_SHARED_WAVES8
+#define NERFDS_FWD_SHARED_WAVES8 1
+#endif
+struct SharedOnlyPlan : KernelPlan { static constexpr bool EIGHT_WAVES = NERFDS_FWD_SHARED_WAVES8 != 0; };
+template <int MODE> using PlanOfMode = std::conditional_t<MODE == FWD_SHARED_ONLY, SharedOnlyPlan, KernelPlan>;
 }  // namespace nerfds
 
 template <bool WIDE, int MODE> static void launch_train(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream) {
   using namespace nerfds;
-  using SH = Shape<KernelPlan, WIDE>;
+  using PLM = PlanOfMode<MODE>;
+  using SH = Shape<PLM, WIDE>;
   constexpr int lds = BIAS_OFF + bias_bytes<NERFDS_GRAPH>() + SH::RAYS * (int)sizeof(WaveLdsT<SH::MAXS>);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = train_forward_kernel<NERFDS_GRAPH, KernelPlan, WIDE, TRAIN_TAG, MODE>;
+  auto kern = train_forward_kernel<NERFDS_GRAPH, PLM, WIDE, TRAIN_TAG, MODE>;
   allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
   const long long groups = ((long long)ka.num_rays + SH::RAYS - 1) / SH::RAYS;
   const int grid = (int)(groups < num_cus ? groups : num_cus);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wg_waves<KernelPlan>()), lds, static_cast<hipStream_t>(stream), ka, to);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wg_waves<PLM>()), lds, static_cast<hipStream_t>(stream), ka, to);
 }
 // ka.nc = samples of the level (ka.nf unused); ka.wstream[1] / ka.bias[1] = the level's NerfMLP; to.mode = FWD_* (the partial modes exist in the
 // f16-store build only: the merged step is a plain step)
 extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream) {
-  const bool wide = ka.nc > nerfds::Shape<nerfds::KernelPlan, false>::MAXS;
+  const bool wide = ka.nc > nerfds::Shape<nerfds::KernelPlan, false>::MAXS;      // (MAXS does not depend on the wave count)
   if constexpr (nerfds::TRAIN_HALF) {
     if (to.mode == nerfds::FWD_SHARED_ONLY) { if (wide) launch_train<true, nerfds::FWD_SHARED_ONLY>(ka, to, num_cus, stream); else launch_train<false, nerfds::FWD_SHARED_ONLY>(ka, to, num_cus, stream); return; }
     if (to.mode == nerfds::FWD_NERF_ONLY) { if (wide) launch_train<true, nerfds::FWD_NERF_ONLY>(ka, to, num_cus, stream); else launch_train<false, nerfds::FWD_NERF_ONLY>(ka, to, num_cus, stream); return; }
