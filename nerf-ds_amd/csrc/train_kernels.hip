@@ -395,7 +395,8 @@ __global__ void k_relu_mask3(float* __restrict__ t, const float* __restrict__ y,
   if (!(y[(row / 3) * N + n] > 0.f)) t[i] = 0.f;
 }
 // d x' = R e_j + (d x' / d (w, v)) d(w, v)_j
-__global__ void k_se3_jvp(long long M, const float* __restrict__ wv, const float* __restrict__ x, const float* __restrict__ t_wv,
+// (launch bounds: without them hipcc budgets 128 registers - a 1024-thread block - and spills 194 / 1128 values of the dual numbers to scratch)
+__global__ __launch_bounds__(256) void k_se3_jvp(long long M, const float* __restrict__ wv, const float* __restrict__ x, const float* __restrict__ t_wv,
                           float* __restrict__ t_xw) {
   const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (m >= M) return;
@@ -552,7 +553,7 @@ __device__ __forceinline__ D1<Dual> tconst(float c, const D1<Dual>*) { return {d
 
 // backward of k_se3_jvp (t_xw_j = R e_j + J t_wv_j) for upstream a_j = d t_xw_j, plus the rotation used by target_norm (<du, R ghat>):
 //   d t_wv_j = J^T a_j,   d (w, v) += grad_{(w,v)} [ sum_j <a_j, R e_j + DF[t_wv_j]> + <du, R ghat> ]     (second derivatives of exp_se3)
-__global__ void k_se3_jvp_bwd(long long M, const float* __restrict__ wv, const float* __restrict__ x, const float* __restrict__ t_wv,
+__global__ __launch_bounds__(256) void k_se3_jvp_bwd(long long M, const float* __restrict__ wv, const float* __restrict__ x, const float* __restrict__ t_wv,
                               const float* __restrict__ d_t_xw, const float* __restrict__ du, const float* __restrict__ ghat,
                               float* __restrict__ d_t_wv, float* __restrict__ dwv_extra) {
   const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
