@@ -27,8 +27,8 @@ Other modes (not the driver's default line):
              (8 192 rays per rank at N = 8) through the drop-in top level, evaluation.render_image + make_model_fn:
              the all-gather of chunk i overlaps the kernel of chunk i + 1.  `scaling` = "strong".
   --train    BASELINE configs[3]: one training step (random-ray batch of 4096, MSE loss of both levels, backward,
-             Adam) of the nerf_ds graph; metric "training rays/s"; roofline = HBM (every layer of the step is
-             HBM-bound by construction).
+             Adam) of the nerf_ds graph; metric "training rays/s"; roofline = MFMA on SURVEY 8d's algorithmic FLOPs (3 x the
+             forward's); the HBM bytes of the layer-store design are reported beside it as `traffic` / `design_bytes_per_step`.
 """
 import argparse
 import json
@@ -126,6 +126,7 @@ def cpu_baseline(cfg, params, budget_s=25.0, rays_full=None):
   return obj, keep
 
 
+TOLERANCE = 1e-4        # BASELINE.json north_star: composited RGB within 1e-4 rel of the reference on identical rays
 PIXEL_FLOOR = 1e-2      # per-pixel relative error: |d rgb| / max(|rgb|, PIXEL_FLOOR) - dark pixels are not excused by the brightest one
 
 
@@ -206,31 +207,37 @@ def run_train(args, device, emit=True):
   if os.path.exists(tpath) and R == 4096 and fused_bwd:
     tj = json.load(open(tpath))
     traffic, traffic_source = tj['hbm_bytes_per_step'], f"{TRAIN_TRAFFIC_FILE} ({tj['measured_on']})"
-  flop = 3 * FLOP_PER_RAY * R                    # fwd + bwd ~ 3 x forward
+  flop = 3 * FLOP_PER_RAY * R                    # fwd + bwd ~ 3 x forward, every network at 192 rows per ray (the algorithmic figure)
+  # what the step executes: the level-independent networks at M_shared rows (128 per ray when merged), the NerfMLPs at 192 (SURVEY 8 layer table, MACs per sample)
+  MAC_SHARED, MAC_NERF = 126080 + 91136 + 26368, 485376 + 65536 + 1024 + 72064
+  flop_exec = 3 * 2.0 * (MAC_SHARED * float(M_shared) + MAC_NERF * float(M))
+  # matrix-pipe floor of the EXECUTED work at the arithmetic the gradient tests need: forward and data gradient three bf16 MFMAs per
+  # product (split bf16), weight gradient ONE f16 MFMA per product on the stored operands with f16 g (3 + 3 + 1 of 9; fp32 g: 3 + 3 + 3)
+  floor_ms = (7 / 9 if g16 else 1) * 3 * flop_exec / 2.5e15 * 1e3
   result = {
-      'metric': 'training rays/sec (batch 4096, MSE of both levels + backward + Adam, full warp+NerfMLP)',
+      'metric': 'training rays/sec (batch 4096, rgb-only objective: MSE of both levels + backward + Adam, full warp+NerfMLP)',
       'value': R / dt, 'unit': 'rays/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt * 1e3,
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16x2 (forward and data-gradient chains: split bf16 operands, fp32 accumulate; activations stored as f16 + ReLU bits, the weight-gradient operand g as loss-scaled f16: weight gradients one f16 MFMA per product; data gradients and sums fp32)',
       'data': 'synthetic',
       'config': {'workload': f"BASELINE configs[3]: training step, {R} random rays of 64 synthetic frames, 64 coarse + 64 fine samples, nerf_ds graph, "
-                             'loss = MSE(fine) + MSE(coarse), backward through every network, Adam; sampling jitter drawn on chip',
+                             'loss = MSE(fine) + MSE(coarse) ONLY (configs[3] as written; the full configs/nerf_ds.gin objective - norm loss, warp regulariser, '
+                             'mask, back-facing - is the `full_objective` field / tools/objective_time.py), backward through every network, Adam; sampling jitter drawn on chip',
                  'rays_per_step': R, 'parallelism': 'single GPU', 'exchange': 'none (1 GPU)'},
-      'roofline': {'bound': 'hbm', 'achieved': hbm_bytes / dt / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': hbm_bytes / dt / 8e12,
+      # SURVEY 8d prices the step by its ALGORITHMIC FLOPs (3 x 333.15 MFLOP per ray, ~30 MB of true input / parameter / gradient bytes): by that
+      # definition the step is MFMA-bound and `frac` is the fraction of the 2.5 PFLOP/s dense peak.  The HBM figures describe the DESIGN (layer
+      # activations stored for the backward), not the problem: `traffic` = measured bytes per step, `design_bytes_per_step` = this design's own model.
+      'roofline': {'bound': 'mfma', 'achieved': flop / dt / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': flop / dt / 2.5e15,
                    'traffic': traffic, 'traffic_source': traffic_source,
                    'kernel': ('whole step, level-independent networks once per sample position (three fused forward launches: coarse, new samples, fine NerfMLP; two NerfMLP '
                               'data-gradient chains + one chain per shared network over all positions; the hidden-layer weight gradients of an MLP in one launch)' if (fused_bwd and merged)
                               else 'whole step (per level: one fused forward launch, four fused data-gradient chains, one weight-gradient launch per layer segment)' if fused_bwd
                               else 'whole step (one fused forward launch per level + about 100 backward layer kernels; each is HBM-bound)' if fused_fwd
                               else 'whole step (about 150 layer kernels; each is HBM-bound)'),
-                   'algorithmic_bytes_per_step': hbm_bytes,
+                   'algorithmic_flop_per_step': flop, 'executed_flop_per_step': flop_exec, 'executed_tflops': flop_exec / dt / 1e12,
+                   'design_bytes_per_step': hbm_bytes, 'design_hbm_gbps': hbm_bytes / dt / 1e9, 'design_hbm_frac_of_8000': hbm_bytes / dt / 8e12,
                    'traffic_model': (f"forward f16 Y + ReLU bits; chains write g once ({'f16' if g16 else 'fp32'}); weight gradient reads X (f16) + g" if fused_bwd else
                                      'fp32 activations: forward ' + ('Y (fused: X stays on chip)' if fused_fwd else 'X + Y') + ', weight gradient X + dY, data gradient dY + Y + dX'),
-                   'algorithmic_tflops': flop / dt / 1e12, 'mfma_frac_of_2500': flop / dt / 2.5e15,
-                   # the matrix-pipe floor of the step: forward + data gradient + weight gradient (3 x the forward's FLOPs), three bf16 MFMAs
-                   # per product at the split-bf16 arithmetic the gradient tests need, at the 2.5 PFLOP/s dense peak
-                   # (f16 g: the weight gradient is ONE f16 MFMA per product on the stored operands: 3 + 3 + 1 of 9; round 3 / early round 4: bf16 g, two)
-                   'mfma_floor_ms': (7 / 9 if g16 else 1) * 3 * flop / 2.5e15 * 1e3,
-                   'ms_over_mfma_floor': dt * 1e3 / ((7 / 9 if g16 else 1) * 3 * flop / 2.5e15 * 1e3)},
+                   'mfma_floor_ms': floor_ms, 'ms_over_mfma_floor': dt * 1e3 / floor_ms},
       'loss_first': losses[0], 'loss_last': losses[-1],
   }
   if not args.no_cpu_baseline:
@@ -507,8 +514,14 @@ def main():
       result['cpu_baseline'], sample = cpu_baseline(cfg, params, rays_full=(rays if static else None))
     else:
       result['cpu_baseline'] = None
+    # north_star's contract on composited RGB, said at the top level of the line: `value` is the arithmetic named by --precision (bf16 by
+    # default, the arithmetic the roofline target names) and carries its OWN verdict here; the number that holds the tolerance is
+    # `parity_path` (split bf16) below, with its own meets_tolerance
+    result['tolerance'] = TOLERANCE
+    result['meets_tolerance'] = None            # unknown until an error is measured (no CPU baseline sample: N > 1 or --no-cpu-baseline)
     if sample:
       result['rgb_max_rel_err'], result['rgb_max_pixel_rel_err'] = rgb_error(model, cfg, params, sample, args.precision)
+      result['meets_tolerance'] = bool(result['rgb_max_rel_err'] <= TOLERANCE)
       result['err_reference'] = ('CPU oracle (torch fp32) on the cpu_baseline sample: same rays, same injected uniforms; rgb_max_rel_err = max |d rgb| / max |rgb|, '
                                  'rgb_max_pixel_rel_err = max |d rgb| / max(|rgb|, 1e-2) per pixel and channel; worst of the levels')
     if world == 1 and not args.no_other_paths and not args.strong and not static:
@@ -551,6 +564,7 @@ def main():
                                       f'{args.rays} rays of the frame, both levels, same Philox sampling stream - NOT the CPU oracle, which sees the cpu_baseline sample only')
         errs = [e for e in (pp['rgb_max_rel_err'], pp['full_frame_rgb_max_rel_err']) if e is not None]
         pp['meets_1e-4'] = bool(errs) and max(errs) <= 1e-4
+        pp['tolerance'], pp['meets_tolerance'] = TOLERANCE, pp['meets_1e-4']
         pix = [e for e in (pp['rgb_max_pixel_rel_err'], pp['full_frame_rgb_max_pixel_rel_err']) if e is not None]
         pp['meets_1e-4_per_pixel'] = bool(pix) and max(pix) <= 1e-4
         pp['note'] = ('split bf16 (hi + lo) operands, three MFMAs per product, fp32 accumulate: the fastest arithmetic that meets '
@@ -564,8 +578,8 @@ def main():
         tr = run_train(targs, device, emit=False)
         result['train_step'] = {k: tr[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'loss_first', 'loss_last')}
         result['train_step']['workload'] = tr['config']['workload']
-        result['train_step']['roofline'] = {k: tr['roofline'][k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_step',
-                                                                         'algorithmic_tflops', 'mfma_floor_ms', 'ms_over_mfma_floor')}
+        result['train_step']['roofline'] = {k: tr['roofline'][k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_flop_per_step',
+                                                                         'executed_flop_per_step', 'design_bytes_per_step', 'design_hbm_gbps', 'mfma_floor_ms', 'ms_over_mfma_floor')}
     print(json.dumps(result), flush=True)
 
   if world > 1:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NERFDS_ABI_VERSION 5
+#define NERFDS_ABI_VERSION 6
 
 /* error codes */
 #define NERFDS_OK         0
@@ -188,12 +188,22 @@ typedef struct nerfds_extra {
   int32_t use_stratified_sampling;   /* NerfModel.use_stratified_sampling */
   /* render_opts of NerfModel.__call__ (filter_sigma, models.py:38-66): densities below dust_threshold, and of samples whose
    * observation-space point lies outside the box [xmin, xmax, ymin, ymax, zmin, zmax], are zeroed before compositing (models.py:1288);
-   * the per-sample 'sigma' output stays unfiltered (models.py:1271).  render_opt_flags = 0: render_opts is None. */
+   * the per-sample 'sigma' output stays unfiltered (models.py:1271).  render_opt_flags = 0: render_opts is None.
+   * FINE level only, as in the reference: __call__ forwards render_opts to the 'fine' render_samples call (models.py:1545) and not to
+   * the 'coarse' one (models.py:1493-1517, default None at :884) - the coarse outputs and the pdf the fine depths are drawn from are
+   * those of an unfiltered render; a single-level model (num_fine_samples == 0) never sees the options. */
   uint32_t render_opt_flags;         /* NERFDS_OPT_* */
   float dust_threshold;
   float bounding_box[6];
   int32_t use_linear_disparity;      /* NerfModel.use_linear_disparity: coarse depths linear in 1 / z (model_utils.py:73-76) */
+  /* The use_sample_at_infinity kwarg of NerfModel.__call__ (models.py:1433, 1484-1485): NERFDS_TRISTATE_NONE = the model's
+   * use_sample_at_infinity, NERFDS_TRISTATE_TRUE / _FALSE = the override.  It reaches the FINE level only (models.py:1544); the
+   * coarse level always composites with the model's value (models.py:1509), as does a single-level model. */
+  int32_t sample_at_infinity_override;   /* NERFDS_TRISTATE_* */
 } nerfds_extra;
+#define NERFDS_TRISTATE_NONE  0
+#define NERFDS_TRISTATE_TRUE  1
+#define NERFDS_TRISTATE_FALSE 2
 #define NERFDS_OPT_DUST_THRESHOLD 1u
 #define NERFDS_OPT_BOUNDING_BOX   2u
 
@@ -356,6 +366,10 @@ const char* nerfds_trainer_last_error(const nerfds_trainer* t);
 int nerfds_kernel_time_ms(nerfds_ctx* ctx, int reset, double* total_ms);
 
 /* ---- host-only helpers (no device needed): exposed so that the weight-stream packing can be tested on CPU ---- */
+/* Diagnostic: the library's "dynamic LDS above 64 KiB" launch attribute is set once per (kernel, device) pair (csrc/lds_attr.h); this is
+ * the table's own test-and-set on an arbitrary key - 1 the first time a pair is seen, 0 afterwards.  No device call, no reference
+ * counterpart (the reference's launches are XLA's). */
+int nerfds_debug_lds_attr_first_use(uint64_t kernel_key, int device);
 /* Size in bytes of the packed MFMA weight stream / padded bias array for `which` (0 = shared mask+warp+hyper
  * nets, 1 = NerfMLP) at precision `prec`; negative on error. */
 int64_t nerfds_pack_stream_bytes(const nerfds_model_cfg* cfg, int which, uint32_t prec);

@@ -38,11 +38,12 @@ struct KArgs {
   int nc, nf;
   int stratified;
   int lindisp;               // use_linear_disparity (model_utils.py:73-76)
-  int sample_at_infinity;
+  int sample_at_infinity;        // the 'coarse' level: the model's value (models.py:1509)
+  int sample_at_infinity_fine;   // the 'fine' level: the per-call override, else the model's value (models.py:1484-1485, 1544)
   int white_bkgd;
   float near_, far_;
   float mask_ratio;
-  // render_opts (filter_sigma, models.py:38-66): opt_flags bit 0 dust threshold, bit 1 bounding box (xmin, xmax, ymin, ymax, zmin, zmax)
+  // render_opts (filter_sigma, models.py:38-66; the FINE level only, models.py:1545): opt_flags bit 0 dust threshold, bit 1 bounding box (xmin, xmax, ymin, ymax, zmin, zmax)
   int opt_flags;
   float dust_threshold;
   float bbox[6];

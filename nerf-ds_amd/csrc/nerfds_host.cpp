@@ -397,6 +397,8 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   if (ctx->cfg.use_predicted_mask && !rays->warp_id && !rays->encoded_mask)
     return ctx->fail(NERFDS_EINVAL, "the mask network looks its embedding up from metadata['warp'] ids (models.py:924-926): pass warp_id or encoded_mask");
   if (extra->render_opt_flags & ~(NERFDS_OPT_DUST_THRESHOLD | NERFDS_OPT_BOUNDING_BOX)) return ctx->fail(NERFDS_EINVAL, "unknown render_opt_flags");
+  if (extra->sample_at_infinity_override < NERFDS_TRISTATE_NONE || extra->sample_at_infinity_override > NERFDS_TRISTATE_FALSE)
+    return ctx->fail(NERFDS_EINVAL, "sample_at_infinity_override must be a NERFDS_TRISTATE_* value");
   if (extra->mask_ratio != 1.0f && ctx->cfg.use_predicted_mask && !rays->gt_mask)
     return ctx->fail(NERFDS_EINVAL, "rays_dict['mask'] is required when mask_ratio != 1");
   if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(NERFDS_EDEVICE, "hipSetDevice failed");
@@ -448,7 +450,10 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   ka.nc = ctx->cfg.num_coarse_samples; ka.nf = ctx->cfg.num_fine_samples;
   ka.stratified = extra->use_stratified_sampling;
   ka.lindisp = extra->use_linear_disparity;
+  // per level (models.py:1509 vs :1544): the coarse level keeps the model's value, the per-call override reaches the fine level only
   ka.sample_at_infinity = ctx->cfg.use_sample_at_infinity;
+  ka.sample_at_infinity_fine = extra->sample_at_infinity_override == NERFDS_TRISTATE_NONE ? ctx->cfg.use_sample_at_infinity
+                               : (extra->sample_at_infinity_override == NERFDS_TRISTATE_TRUE ? 1 : 0);
   ka.white_bkgd = ctx->cfg.use_white_background;
   ka.near_ = extra->near; ka.far_ = extra->far;
   ka.mask_ratio = extra->mask_ratio;

@@ -1326,6 +1326,9 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   if (!rays || !target_rgb || !ex || !rays->origins || !rays->directions || !rays->warp_id) return t->fail(NERFDS_EINVAL, "null argument");
   if (rays->num_rays <= 0 || rays->num_rays > t->max_rays) return t->fail(NERFDS_EINVAL, "num_rays must be in [1, max_rays = %lld]", (long long)t->max_rays);
   if (ex->mask_ratio != 1.0f && !rays->gt_mask) return t->fail(NERFDS_EINVAL, "rays_dict['mask'] is required when mask_ratio != 1");
+  // train_step calls model.apply without use_sample_at_infinity / render_opts (training.py:441-455): both levels composite with the model's value
+  if (ex->sample_at_infinity_override != NERFDS_TRISTATE_NONE || ex->render_opt_flags != 0)
+    return t->fail(NERFDS_ENOTSUP, "the training step takes neither a use_sample_at_infinity override nor render_opts (training.py:441-455 passes neither)");
   if (hipSetDevice(t->device) != hipSuccess) return t->fail(NERFDS_EDEVICE, "hipSetDevice failed");
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const int R = (int)rays->num_rays, Nc = t->cfg.num_coarse_samples, Nf = t->cfg.num_fine_samples;

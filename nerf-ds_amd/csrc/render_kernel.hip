@@ -23,7 +23,7 @@ namespace nerfds {
 // Compositing of one level (model_utils.py:95-159, 272-317; models.py:1346-1415) -> ray record.
 // ------------------------------------------------------------------------------------------------
 template <class G, class LT>
-DEVI void composite(const KArgs& ka, const RayConst& rc, int ray, int lane, int S, bool at_infinity, LT& L,
+DEVI void composite(const KArgs& ka, const RayConst& rc, int ray, int lane, int S, bool at_infinity, int opt_flags, LT& L,
                     float* __restrict__ rec_out, float* __restrict__ smp_out) {
   const float dnorm = sqrtf(rc.d[0] * rc.d[0] + rc.d[1] * rc.d[1] + rc.d[2] * rc.d[2]);
   const float last = at_infinity ? 1e10f : 1e-19f;
@@ -47,9 +47,11 @@ DEVI void composite(const KArgs& ka, const RayConst& rc, int ray, int lane, int 
     for (int c = 0; c < 3; ++c) xo[c] = __fadd_rn(rc.o[c], __fmul_rn(z, rc.d[c]));
     // render_opts (filter_sigma, models.py:38-66, applied at models.py:1288 to the ACTIVATED density; the per-sample 'sigma' output below is
     // the unfiltered one, models.py:1271): (sigma >= dust_threshold) * sigma, then (point inside the box) * sigma.  Uniform flags, selects.
+    // opt_flags is the LEVEL's: NerfModel.__call__ hands render_opts to the fine render_samples only (models.py:1545; the coarse call,
+    // models.py:1493-1517, leaves the default None), so the coarse level - and the pdf the fine depths are drawn from - is never filtered.
     float sig_f = sigma;
-    if (ka.opt_flags & 1) sig_f = (sig_f >= ka.dust_threshold) ? sig_f : 0.f * sig_f;
-    if (ka.opt_flags & 2) {
+    if (opt_flags & 1) sig_f = (sig_f >= ka.dust_threshold) ? sig_f : 0.f * sig_f;
+    if (opt_flags & 2) {
       const bool in = (xo[0] >= ka.bbox[0]) & (xo[0] <= ka.bbox[1]) & (xo[1] >= ka.bbox[2]) & (xo[1] <= ka.bbox[3]) &
                       (xo[2] >= ka.bbox[4]) & (xo[2] <= ka.bbox[5]);
       sig_f = in ? sig_f : 0.f * sig_f;
@@ -369,7 +371,8 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
     if (q == 0) {
       float* rec = live ? ((nf > 0) ? ka.ray_coarse : ka.ray_fine) : nullptr;
       float* smp = live ? ((nf > 0) ? ka.smp_coarse : ka.smp_fine) : nullptr;
-      composite<G>(ka, rc, ray, lane, nc, ka.sample_at_infinity != 0, L,
+      // the 'coarse' render_samples call (models.py:1493-1517): the MODEL's use_sample_at_infinity (:1509), no render_opts
+      composite<G>(ka, rc, ray, lane, nc, ka.sample_at_infinity != 0, 0, L,
                    rec ? rec + (size_t)ray * RAY_REC : nullptr,
                    smp ? smp + (size_t)ray * nc * SAMPLE_REC : nullptr);
       WAVE_SYNC();
@@ -402,7 +405,8 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
       }
       ray_sync();
       if (q == 0)
-        composite<G>(ka, rc, ray, lane, n, ka.sample_at_infinity != 0, L,
+        // the 'fine' call (models.py:1528-1552): the per-call use_sample_at_infinity override (:1544) and render_opts (:1545)
+        composite<G>(ka, rc, ray, lane, n, ka.sample_at_infinity_fine != 0, ka.opt_flags, L,
                      (live && ka.ray_fine) ? ka.ray_fine + (size_t)ray * RAY_REC : nullptr,
                      (live && ka.smp_fine) ? ka.smp_fine + (size_t)ray * n * SAMPLE_REC : nullptr);
       ray_sync();

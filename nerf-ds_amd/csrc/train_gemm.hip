@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "train_gemm.h"
+#include "lds_attr.h"
 
 namespace nerfds_train {
 
@@ -1191,9 +1192,9 @@ template <int KC, int WAVES, bool P3, int MODE> static void launch_dma(hipStream
   typedef DmaShape<KC, WAVES> S;
   const int lds = S::NS * S::TILE_BYTES + S::IMG_BYTES;
   auto kern = k_dense_dma<KC, WAVES, P3, MODE>;
-  static int per_cu = 0;                                        // resident workgroups per CU (registers / LDS decide)
+  static int per_cu = 0;                                        // resident workgroups per CU (registers / LDS decide: the same on every device of a node)
+  nerfds::allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
   if (per_cu == 0) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     int n = 0;
     per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 64 * WAVES, lds) == hipSuccess && n > 0) ? n : 1;
   }
@@ -1225,8 +1226,8 @@ template <int KC, int WAVES, bool P3 = false> static void launch(hipStream_t st,
   const int lds = 2 * KC * 1024 * (P3 ? 3 : 2);
   auto kern = k_dense_ws<KC, WAVES, P3>;
   static int per_cu = 0;
+  nerfds::allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
   if (per_cu == 0) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     int n = 0;
     per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 64 * WAVES, lds) == hipSuccess && n > 0) ? n : 1;
   }
@@ -1310,8 +1311,7 @@ int wgrad_grid(const WgradArgs& A, int num_cus) {
 template <int TPW, int IPW, bool ROW, bool FULL, bool DYH> static void launch_wgrad_t(hipStream_t st, const WgradArgs& A, int grid) {
   auto kern = k_wgrad<TPW, IPW, ROW, FULL, DYH>;
   typedef WgShape<TPW, IPW, FULL> S;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS); attr = true; }
+  nerfds::allow_dynamic_lds(reinterpret_cast<const void*>(kern), S::LDS);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), S::LDS, st, A);
 }
 template <int TPW, int IPW, bool ROW, bool FULL = false> static void launch_wgrad(hipStream_t st, const WgradArgs& A, int grid) {
@@ -1321,8 +1321,7 @@ template <int TPW, int IPW, bool ROW, bool FULL = false> static void launch_wgra
 template <int KT, int NT> static void launch_wgrad_tr(hipStream_t st, const WgradArgs& A, int grid) {
   typedef WtShape<KT, NT> S;
   auto kern = k_wgrad_tr<KT, NT>;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS); attr = true; }
+  nerfds::allow_dynamic_lds(reinterpret_cast<const void*>(kern), S::LDS);
   const long long tiles = (A.M + S::SPS - 1) / S::SPS;
   const int nl = A.nl > 1 ? A.nl : 1;
   long long per = grid / nl;                                          // workgroups per layer
@@ -1389,8 +1388,8 @@ template <int KCN, int IPW> static void launch_bwd_fused(hipStream_t st, const B
   typedef BfShape<KCN, IPW> S;
   auto kern = k_bwd_fused<KCN, IPW>;
   static int per_cu = 0;
+  nerfds::allow_dynamic_lds(reinterpret_cast<const void*>(kern), S::LDS);
   if (per_cu == 0) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS);
     int n = 0;
     per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, S::LDS) == hipSuccess && n > 0) ? n : 1;
   }

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFDS_LIB', os.path.join(_HERE, '_lib', 'libnerfds_hip.so'))   # NERFDS_LIB: development builds
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def resolve_device(device=None):
@@ -91,9 +91,10 @@ class Extra(C.Structure):
               ('hyper_sheet_alpha', C.c_float), ('norm_input_alpha', C.c_float), ('mask_ratio', C.c_float),
               ('near', C.c_float), ('far', C.c_float), ('use_stratified_sampling', C.c_int32),
               ('render_opt_flags', C.c_uint32), ('dust_threshold', C.c_float), ('bounding_box', C.c_float * 6),
-              ('use_linear_disparity', C.c_int32)]
+              ('use_linear_disparity', C.c_int32), ('sample_at_infinity_override', C.c_int32)]
 
 
+TRISTATE_NONE, TRISTATE_TRUE, TRISTATE_FALSE = 0, 1, 2
 OPT_DUST_THRESHOLD, OPT_BOUNDING_BOX = 1, 2
 
 
@@ -131,7 +132,8 @@ SYMBOLS = ('nerfds_abi_version', 'nerfds_struct_size', 'nerfds_precision_plan', 
            'nerfds_frame_images', 'nerfds_trainer_create', 'nerfds_trainer_destroy', 'nerfds_trainer_param_count',
            'nerfds_trainer_num_leaves', 'nerfds_trainer_leaf', 'nerfds_trainer_params', 'nerfds_trainer_grads',
            'nerfds_trainer_download', 'nerfds_trainer_upload', 'nerfds_trainer_reset_optimizer', 'nerfds_trainer_step', 'nerfds_trainer_apply', 'nerfds_trainer_clip_gradients', 'nerfds_trainer_target_norm',
-           'nerfds_trainer_last_error', 'nerfds_trainer_debug_read', 'nerfds_trainer_nonfinite', 'nerfds_trainer_set_step')
+           'nerfds_trainer_last_error', 'nerfds_trainer_debug_read', 'nerfds_trainer_nonfinite', 'nerfds_trainer_set_step',
+           'nerfds_debug_lds_attr_first_use')
 
 _lib = None
 
@@ -167,6 +169,7 @@ def load():
                                         C.c_void_p, C.c_void_p]
   lib.nerfds_frame_images.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
+  lib.nerfds_debug_lds_attr_first_use.argtypes = [C.c_uint64, C.c_int]
   if lib.nerfds_abi_version() != ABI_VERSION:
     raise RuntimeError('libnerfds_hip.so ABI version mismatch: rebuild')
   lib.nerfds_struct_size.argtypes = [C.c_int]

@@ -184,12 +184,22 @@ class NerfModel:
   # -- NerfModel.__call__ -------------------------------------------------------------------------------
   def apply(self, variables: Dict[str, Any], rays_dict: Dict[str, Any], extra_params: Dict[str, Any], *,
             rngs=None, mutable=False, metadata_encoded=False, use_warp=True, return_points=False,
-            return_weights=False, return_samples=False, return_nv_details=True, near=None, far=None,
-            use_sample_at_infinity=None, render_opts=None, use_sigma_gradient=False, use_predicted_norm=False,
-            mask_ratio=1, sharp_weights_std=1.0, t_rand=None, u_rand=None, precision: Optional[str] = None,
+            return_weights=False, return_samples=False, return_warp_jacobian=False, return_hyper_jacobian=False,
+            return_hyper_c_jacobian=False, return_nv_details=True, near=None, far=None,
+            use_sample_at_infinity=None, render_opts=None, deterministic=False, screw_input_mode=None,
+            use_sigma_gradient=False, use_predicted_norm=False,
+            mask_ratio=1, sharp_weights_std=1.0, x_for_rgb_alpha=4.0, norm_override=None,
+            t_rand=None, u_rand=None, precision: Optional[str] = None,
             stream: Optional[torch.cuda.Stream] = None, reload_params: bool = False, ray_offset: int = 0,
             records_out: Optional[Dict[str, torch.Tensor]] = None):
-    """``records_out``: optional {'fine' | 'coarse': float32 device tensor [R, 26]} the per-ray records of that level are
+    """NerfModel.__call__ (models.py:1419-1565), every keyword of the reference's signature (models.py:1419-1443); DESIGN.md section 2 lists what
+    each one reaches per level.  Keywords whose non-default value selects a path no shipped config or caller uses are rejected loudly:
+    return_*_jacobian (the trainer's elastic loss carries the warp Jacobian, csrc/nerfds_train.cpp), screw_input_mode other than None / 'none'
+    (models.py:554-561), norm_override (a debugging hack: norm_input * -2, models.py:1139-1140).  ``deterministic`` is accepted and ignored, as in
+    the reference (it is not forwarded to render_samples); ``x_for_rgb_alpha`` is read only under window_x_in_rgb_condition (models.py:1202-1206),
+    which config.py rejects.
+
+    ``records_out``: optional {'fine' | 'coarse': float32 device tensor [R, 26]} the per-ray records of that level are
     written into (e.g. a slice of a frame buffer) instead of a fresh allocation.  ``ray_offset``: Philox counter of the first
     ray (csrc/philox.h), so that a frame rendered in chunks draws what one call over all its rays would."""
     cfg = self.cfg
@@ -208,10 +218,19 @@ class NerfModel:
     if bool(use_predicted_norm) != bool(cfg.predict_norm):
       raise ValueError('use_predicted_norm must equal NerfModel.predict_norm: the rgb branch width depends on it '
                        '(models.py:2707-2739 initialises the parameters with the same flag)')
-    if use_sample_at_infinity is not None and bool(use_sample_at_infinity) != bool(cfg.use_sample_at_infinity):
-      raise NotImplementedError('per-call use_sample_at_infinity override')
+    # use_sample_at_infinity: per-call override of the FINE level only (models.py:1484-1485, 1544); the coarse level, and a single-level
+    # model, composite with cfg.use_sample_at_infinity (models.py:1509)
+    inf_cfg = bool(cfg.use_sample_at_infinity)
+    inf_fine = inf_cfg if (use_sample_at_infinity is None or nf == 0) else bool(use_sample_at_infinity)
     if not use_warp and cfg.use_warp:
       raise NotImplementedError('use_warp=False on a warp model raises in the reference too (SURVEY.md 8a quirk 2)')
+    if return_warp_jacobian or return_hyper_jacobian or return_hyper_c_jacobian:
+      raise NotImplementedError('return_*_jacobian on the render surface (the elastic loss of Trainer.step carries the warp Jacobian)')
+    if screw_input_mode not in (None, 'none', 'None'):
+      raise NotImplementedError(f'screw_input_mode={screw_input_mode!r}: the rgb branch has no screw-axis condition (models.py:554-561)')
+    if norm_override is not None:
+      raise NotImplementedError('norm_override (models.py:1139-1140)')
+    del deterministic, x_for_rgb_alpha
 
     dev = self.device
     f32 = lambda a: torch.as_tensor(np.asarray(a) if not isinstance(a, torch.Tensor) else a).to(dev, torch.float32).contiguous()
@@ -279,6 +298,8 @@ class NerfModel:
                     int(cfg.use_stratified_sampling))
     N.set_render_opts(extra, render_opts)
     extra.use_linear_disparity = int(cfg.use_linear_disparity)
+    extra.sample_at_infinity_override = N.TRISTATE_NONE if use_sample_at_infinity is None else \
+        (N.TRISTATE_TRUE if use_sample_at_infinity else N.TRISTATE_FALSE)
     rnd = N.Rand(ptr(t_rand), ptr(u_rand), _seed_from_rngs(rngs), int(ray_offset))
     out = N.Out(ptr(rec_fine), ptr(rec_coarse), ptr(smp_fine), ptr(smp_coarse))
     flags = N.PREC[precision or self.precision]
@@ -298,15 +319,16 @@ class NerfModel:
         origins = cr['origins'].reshape(-1, 3)[first_pixel:first_pixel + R]
         directions = cr['directions'].reshape(-1, 3)[first_pixel:first_pixel + R]
       ret[level] = self._unpack(rec, smp, S, batch_shape, origins, directions, return_points, return_weights,
-                                sharp_weights_std)
+                                sharp_weights_std, inf_fine if (two and level == 'fine') else inf_cfg)
     if use_sigma_gradient:
       # target_norm = normalize(R normalize(-d sigma / d x)) per sample (models.py:1065-1077, 1273-1277, 1328).  The fused render
       # kernel does not carry tangents; the trainer's forward-mode pass does (csrc/nerfds_train.cpp sigma_gradient), on the same
       # depths: injected uniforms are passed on, and the on-chip Philox stream is keyed identically in both (csrc/philox.h).
       if camera is not None:
         raise NotImplementedError('use_sigma_gradient with fused camera rays: pass origins / directions')
-      if metadata_encoded or render_opts is not None:
-        raise NotImplementedError('use_sigma_gradient with metadata_encoded / render_opts (the tangent pass is the trainer\'s: ids, no render_opts)')
+      if metadata_encoded or render_opts is not None or inf_fine != inf_cfg:
+        raise NotImplementedError('use_sigma_gradient with metadata_encoded / render_opts / a use_sample_at_infinity override '
+                                  '(the tangent pass is the trainer\'s: ids, no render_opts, the model\'s use_sample_at_infinity)')
       tn = self._target_norm(params, reloaded, origins, directions, viewdirs, warp_id, gt_mask, extra_params, float(mask_ratio),
                              near, far, t_rand, u_rand, rnd.seed, int(ray_offset))
       for level in ret:
@@ -317,7 +339,7 @@ class NerfModel:
 
   __call__ = apply
 
-  def _unpack(self, rec, smp, S, batch_shape, origins, directions, return_points, return_weights, sharp_std):
+  def _unpack(self, rec, smp, S, batch_shape, origins, directions, return_points, return_weights, sharp_std, at_infinity=True):
     cfg = self.cfg
     o = {}
     for k, (a, n) in N.RAY_FIELDS.items():
@@ -340,7 +362,14 @@ class NerfModel:
       o['points'] = origins[:, None, :] + o['z_vals'][..., None] * directions[:, None, :]
       o['delta_x'] = o['warped_points'][..., :3] - o['points']          # models.py:1363
       if cfg.use_mask_sharp_weights:
-        o['sharp_weights'] = sharpen_weights(o['weights'], o['z_vals'], sharp_std)
+        # models.py:1239-1245: sharp_weights come from cal_weights, whose sample_at_infinity is ALWAYS the default True (model_utils.py:162)
+        # whatever the level composites with; the two differ in the last sample's alpha only (last delta 1e10 against 1e-19)
+        w = o['weights']
+        if not at_infinity:
+          dn = torch.linalg.norm(directions, dim=-1)
+          w = w.clone()
+          w[:, -1] = (1.0 - torch.exp(-o['sigma'][:, -1] * (1e10 * dn))) * o['accum_prod'][:, -1]
+        o['sharp_weights'] = sharpen_weights(w, o['z_vals'], sharp_std)
       if not cfg.use_predicted_mask:
         del o['predicted_mask']
       if not cfg.predict_norm:

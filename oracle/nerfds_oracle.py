@@ -607,7 +607,13 @@ class NerfModel:
       u_rand = as_t(u_rand)
     common = dict(use_warp=use_warp, use_predicted_norm=use_predicted_norm, mask_ratio=mask_ratio,
                   sharp_weights_std=sharp_weights_std, compute_sigma_gradient=compute_sigma_gradient,
-                  metadata_encoded=metadata_encoded, render_opts=render_opts)
+                  metadata_encoded=metadata_encoded)
+    # Per-level kwargs of the two render_samples calls (models.py:1493-1517 vs 1528-1552; DESIGN.md section 2 has the whole table): every
+    # kwarg is forwarded identically to both levels EXCEPT
+    #   use_sample_at_infinity  coarse = self.use_sample_at_infinity (:1509), fine = the per-call override (:1484-1485, :1544)
+    #   render_opts             coarse = not passed, i.e. None (:884),        fine = render_opts (:1545)
+    #   coarse_depth            coarse = None (:1502), fine = coarse_ret['depth'] (:1537) - read only under use_coarse_depth_for_mask
+    #                           (:956-958, default False :210, no gin file sets it; not built: config.py rejects it)
 
     z_vals, points = sample_along_rays(t_rand, origins, directions, cfg.num_coarse_samples, near, far,
                                        cfg.use_stratified_sampling, cfg.use_linear_disparity)
@@ -619,7 +625,7 @@ class NerfModel:
       z_vals, points = sample_pdf(u_rand, z_vals_mid, coarse_ret['weights'][..., 1:-1], origins, directions,
                                   z_vals, cfg.num_fine_samples, cfg.use_stratified_sampling)
       out['fine'] = self.render_samples('fine', points, z_vals, directions, viewdirs, metadata, extra_params,
-                                        mask, use_sample_at_infinity=use_sample_at_infinity, **common)
+                                        mask, use_sample_at_infinity=use_sample_at_infinity, render_opts=render_opts, **common)
     for level in out:
       if not return_weights:
         del out[level]['weights']

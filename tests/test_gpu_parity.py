@@ -466,19 +466,27 @@ def test_metadata_encoded_interpolated_embeddings(prec):
 @pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
 def test_render_opts_filter_sigma(prec):
   """render_opts (filter_sigma, models.py:38-66, 1288): dust threshold and bounding box against the oracle; the per-sample 'sigma' stays
-  unfiltered (models.py:1271) while alpha / weights see the filter."""
+  unfiltered (models.py:1271) while alpha / weights see the filter.  FINE level only: NerfModel.__call__ forwards render_opts to the
+  'fine' render_samples call (models.py:1545) and not to the 'coarse' one (models.py:1493-1517), so the coarse level - every output of it, and
+  the fine depths drawn from its weights - is that of the render without options, bit for bit."""
   cfg, params, rng, rays, t, u = _tiny_case(seed=9)
   cfg = cfg.replace(use_mask_sharp_weights=False)
   model = _model(cfg)
   om = O.NerfModel(cfg, params)
   kw = dict(t_rand=t, u_rand=u, use_predicted_norm=True)
   plain = O.to_numpy(om.apply(rays, EXTRA, compute_sigma_gradient=False, return_weights=True, **kw))
+  got_plain = model.apply({'params': params}, rays, EXTRA, precision=prec, return_weights=True, **kw)
   thr = float(np.median(plain['fine']['sigma']))
   for opts in ({'dust_threshold': thr}, {'bounding_box': (-0.3, 0.4, -0.5, 0.5, -0.2, 0.6)},
                {'dust_threshold': thr * 0.5, 'bounding_box': (-0.6, 0.6, -0.6, 0.6, -0.6, 0.6)}):
     ref = O.to_numpy(om.apply(rays, EXTRA, compute_sigma_gradient=False, return_weights=True, render_opts=opts, **kw))
     got = model.apply({'params': params}, rays, EXTRA, precision=prec, render_opts=opts, return_weights=True, **kw)
     assert _relerr(ref['fine']['rgb'], plain['fine']['rgb']) > 1e-3          # the options do something on this case
+    for k in ref['coarse']:                                                   # ... and nothing at all to the coarse level
+      assert np.array_equal(ref['coarse'][k], plain['coarse'][k]), k
+    for k in got['coarse']:
+      assert torch.equal(got['coarse'][k], got_plain['coarse'][k]), (opts, k)
+    assert torch.equal(got['fine']['z_vals'], got_plain['fine']['z_vals'])    # the pdf of the resample is the unfiltered one
     for level in ('coarse', 'fine'):
       for k in ('rgb', 'depth', 'acc', 'ray_norm'):
         assert _relerr(got[level][k].cpu().numpy(), ref[level][k]) < 1e-4, (opts, level, k)
@@ -486,6 +494,40 @@ def test_render_opts_filter_sigma(prec):
       assert _relerr(got[level]['weights'].cpu().numpy(), ref[level]['weights']) < 2e-4
   with pytest.raises(ValueError):
     model.apply({'params': params}, rays, EXTRA, precision=prec, render_opts={'nonsense': 1}, **kw)
+  # a single-level model never sees the options (only the 'coarse' call exists, models.py:1493-1517)
+  cfg1 = static_config()
+  p1 = init_params(cfg1, 3, bias_scale=0.1)
+  R = t.shape[0]
+  t1 = rng.random((R, cfg1.num_coarse_samples))
+  m1 = _model(cfg1)
+  a = m1.apply({'params': p1}, rays, EXTRA, precision=prec, t_rand=t1, use_predicted_norm=cfg1.predict_norm)
+  b = m1.apply({'params': p1}, rays, EXTRA, precision=prec, t_rand=t1, use_predicted_norm=cfg1.predict_norm, render_opts={'dust_threshold': 1e9})
+  assert torch.equal(a['coarse']['rgb'], b['coarse']['rgb']) and float(a['coarse']['acc'].max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
+@pytest.mark.parametrize('cfg_inf,call_inf', [(True, False), (False, True), (True, None)])
+def test_use_sample_at_infinity_override_reaches_the_fine_level_only(prec, cfg_inf, call_inf):
+  """The use_sample_at_infinity kwarg of NerfModel.__call__ (models.py:1433, 1484-1485) goes to the 'fine' render_samples call (models.py:1544);
+  the 'coarse' call keeps self.use_sample_at_infinity (models.py:1509).  Both levels against the oracle, plus sharp_weights, which come from
+  cal_weights with its default sample_at_infinity=True whatever the level composites with (models.py:1239-1245, model_utils.py:162)."""
+  cfg, params, rng, rays, t, u = _tiny_case(seed=12)
+  cfg = cfg.replace(use_sample_at_infinity=cfg_inf)
+  kw = dict(t_rand=t, u_rand=u, use_predicted_norm=True, return_weights=True, use_sample_at_infinity=call_inf)
+  om = O.NerfModel(cfg, params)
+  ref = O.to_numpy(om.apply(rays, EXTRA, compute_sigma_gradient=False, **kw))
+  model = _model(cfg)
+  got = model.apply({'params': params}, rays, EXTRA, precision=prec, **kw)
+  for level in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'med_depth', 'acc', 'weights', 'sharp_weights'):
+      e = _relerr(got[level][k].cpu().numpy(), ref[level][k])
+      assert e <= (1e-4 if k == 'rgb' else 1e-3), (level, k, e)
+  if call_inf is not None:
+    base = model.apply({'params': params}, rays, EXTRA, precision=prec, **dict(kw, use_sample_at_infinity=None))
+    for k in got['coarse']:                                                   # the override does not touch the coarse level
+      assert torch.equal(got['coarse'][k], base['coarse'][k]), k
+    assert not torch.equal(got['fine']['acc'], base['fine']['acc'])           # ... and does reach the fine one (acc drops / gains the last sample)
 
 
 @pytest.mark.gpu
