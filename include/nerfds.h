@@ -337,6 +337,13 @@ int nerfds_trainer_upload(nerfds_trainer* t, int which, const float* host);
 int nerfds_trainer_target_norm(nerfds_trainer* t, int level, int64_t num_rays, float* host);
 int nerfds_trainer_reset_optimizer(nerfds_trainer* t);   /* zero the Adam moments and the step count */
 int nerfds_trainer_set_step(nerfds_trainer* t, int64_t step);   /* the optimizer's step count (resuming from a checkpoint: OptimizerState.step) */
+/* The optimizer's step count = the number of updates actually APPLIED (it lives on the device and does not advance on an update skipped for a
+ * non-finite gradient: flax's OptimizerState.step, what a checkpoint stores); synchronises the device. */
+int nerfds_trainer_get_step(nerfds_trainer* t, int64_t* step_out);
+/* Dynamic loss scaling of the plain step's stored f16 g: the scale is 2^(6 + ceil(log2 num_rays) + log2_adjust).  A step whose gradient came out
+ * non-finite because g left f16's range is re-run by the caller at a lower adjust (nerfds_amd/training.py: -2 per retry, +1 back after 1000 clean
+ * steps) - with a fixed scale the deterministic retry would overflow the same way.  [-40, 16]; no reference counterpart (the reference's g is fp32). */
+int nerfds_trainer_set_loss_scale_adjust(nerfds_trainer* t, int32_t log2_adjust);
 /* Development / tests: HOST copy of an internal device buffer of the last step (the f16 activations, ReLU bits and per-layer
  * gradients g_l of the fused backward, the head / input gradients): "<net>_h16_<l>", "<net>_bits_<l>", "<net>_g_<l>" with net = mask |
  * warp | hyper | trunk, "rgb_h16", "rgb_bits", "rgb_g", "d_rgb_logit", "d_alpha", "d_trunk_in", "d_hyper_in", "d_warp_in",

@@ -313,8 +313,10 @@ int nerfds_ctx_create(nerfds_ctx** out, int device, const nerfds_model_cfg* cfg)
     return NERFDS_ENOTSUP;
   }
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
-    g_create_error = "no such HIP device (the HIP path has no CPU fallback)";
+  const hipError_t dc = hipGetDeviceCount(&ndev);
+  if (dc != hipSuccess || device < 0 || device >= ndev) {
+    g_create_error = std::string("no such HIP device (the HIP path has no CPU fallback): device ") + std::to_string(device) + ", hipGetDeviceCount -> " +
+                     std::to_string(ndev) + " (" + hipGetErrorString(dc) + ")";
     return NERFDS_EDEVICE;
   }
   std::unique_ptr<nerfds_ctx> c(new nerfds_ctx);

@@ -70,7 +70,12 @@ struct nerfds_trainer {
   LayerP mask_out, warp_w, warp_v, hyper_out, bott[2], alpha[2], rgb_h[2], rgb_out[2];
   int64_t warp_tbl = -1, mask_tbl = -1;
   float *theta = nullptr, *grad = nullptr, *m1 = nullptr, *m2 = nullptr;
-  int64_t adam_t = 0;
+  // the optimizer's step count + the bias corrections of the update being applied, on the DEVICE (train_kernels.hip k_adam_prepare): 8 + 2 x 4 bytes
+  unsigned char* adam_dev = nullptr;
+  long long* adam_step() const { return reinterpret_cast<long long*>(adam_dev); }
+  float* adam_corr() const { return reinterpret_cast<float*>(adam_dev + 8); }
+  // dynamic loss scaling of the stored f16 g (include/nerfds.h nerfds_trainer_set_loss_scale_adjust): log2 offset on the heuristic exponent
+  int g_scale_adjust = 0;
   float* ws = nullptr;      // one workspace allocation
   size_t ws_floats = 0;
   float* loss_dev = nullptr;
@@ -158,6 +163,7 @@ struct nerfds_trainer {
   }
   ~nerfds_trainer() {
     for (float* p : {theta, grad, m1, m2, ws, loss_dev, tws, terms_dev, nws}) if (p) (void)hipFree(p);
+    if (adam_dev) (void)hipFree(adam_dev);
     if (wpack) (void)hipFree(wpack);
     if (grad_rep) (void)hipFree(grad_rep);
     for (int i = 0; i < SIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (join_ev[i]) (void)hipEventDestroy(join_ev[i]); }
@@ -1133,12 +1139,13 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
   carve(*t);      // sizes only
   const size_t pbytes = (size_t)t->P * sizeof(float);
   if (hipMalloc(&t->theta, pbytes) != hipSuccess || hipMalloc(&t->grad, pbytes) != hipSuccess || hipMalloc(&t->m1, pbytes) != hipSuccess ||
-      hipMalloc(&t->m2, pbytes) != hipSuccess || hipMalloc(&t->loss_dev, 2 * sizeof(float)) != hipSuccess || hipMalloc(&t->terms_dev, 16 * sizeof(float)) != hipSuccess ||
+      hipMalloc(&t->m2, pbytes) != hipSuccess || hipMalloc(&t->loss_dev, 2 * sizeof(float)) != hipSuccess || hipMalloc(&t->adam_dev, 16) != hipSuccess || hipMalloc(&t->terms_dev, 16 * sizeof(float)) != hipSuccess ||
       hipMalloc(&t->ws, t->ws_floats * sizeof(float)) != hipSuccess) {
     g_train_error = "hipMalloc failed (workspace of " + std::to_string(t->ws_floats * 4 >> 20) + " MiB)";
     return NERFDS_ENOMEM;
   }
   (void)hipMemset(t->terms_dev, 0, 16 * sizeof(float));      // [8]: the non-finite-gradient flag (adam_update)
+  (void)hipMemset(t->adam_dev, 0, 16);
   (void)hipMemset(t->theta, 0, pbytes); (void)hipMemset(t->m1, 0, pbytes); (void)hipMemset(t->m2, 0, pbytes); (void)hipMemset(t->grad, 0, pbytes);
   carve(*t);
   {
@@ -1270,7 +1277,26 @@ long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* h
 
 int nerfds_trainer_set_step(nerfds_trainer* t, int64_t step) {
   if (!t || step < 0) return NERFDS_EINVAL;
-  t->adam_t = step;
+  (void)hipSetDevice(t->device);
+  const long long v = step;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(t->adam_step(), &v, sizeof v, hipMemcpyHostToDevice) != hipSuccess)
+    return t->fail(NERFDS_EDEVICE, "step upload failed");
+  return NERFDS_OK;
+}
+
+int nerfds_trainer_get_step(nerfds_trainer* t, int64_t* step_out) {
+  if (!t || !step_out) return NERFDS_EINVAL;
+  (void)hipSetDevice(t->device);
+  long long v = 0;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, t->adam_step(), sizeof v, hipMemcpyDeviceToHost) != hipSuccess)
+    return t->fail(NERFDS_EDEVICE, "step read-back failed");
+  *step_out = v;
+  return NERFDS_OK;
+}
+
+int nerfds_trainer_set_loss_scale_adjust(nerfds_trainer* t, int32_t log2_adjust) {
+  if (!t || log2_adjust < -40 || log2_adjust > 16) return NERFDS_EINVAL;
+  t->g_scale_adjust = log2_adjust;
   return NERFDS_OK;
 }
 
@@ -1286,19 +1312,17 @@ int nerfds_trainer_nonfinite(nerfds_trainer* t) {
 int nerfds_trainer_reset_optimizer(nerfds_trainer* t) {
   if (!t) return NERFDS_EINVAL;
   (void)hipSetDevice(t->device);
+  (void)hipDeviceSynchronize();
   (void)hipMemset(t->m1, 0, (size_t)t->P * 4); (void)hipMemset(t->m2, 0, (size_t)t->P * 4);
-  t->adam_t = 0;
+  (void)hipMemset(t->adam_dev, 0, 16);
   return NERFDS_OK;
 }
 
 static void adam_update(nerfds_trainer* t, float learning_rate, hipStream_t st) {
-  const double b1 = 0.9, b2 = 0.999;
-  const double tt = (double)(t->adam_t + 1);
   unsigned* flag = reinterpret_cast<unsigned*>(t->terms_dev + 8);
   (void)hipMemsetAsync(flag, 0, sizeof(unsigned), st);
-  adam(st, t->theta, t->grad, t->m1, t->m2, t->P, learning_rate, (float)b1, (float)b2, 1e-8f, (float)(1.0 - std::pow(b1, tt)),
-       (float)(1.0 - std::pow(b2, tt)), flag);
-  t->adam_t += 1;       // (a skipped update still counts as a step: the host learns of it at its next read-back)
+  // the step count advances on the device, and only if the update is applied (a skipped update leaves parameters, moments AND the count alone)
+  adam(st, t->theta, t->grad, t->m1, t->m2, t->P, learning_rate, 0.9f, 0.999f, 1e-8f, t->adam_step(), t->adam_corr(), flag);
 }
 
 int nerfds_trainer_clip_gradients(nerfds_trainer* t, float grad_max_val, float grad_max_norm, void* hip_stream) {
@@ -1395,7 +1419,13 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   {
     int e = 6;
     while ((1 << (e - 6)) < R && e < 40) ++e;
-    if (const char* s = getenv("NERFDS_TRAIN_G_SCALE_LOG2")) e = atoi(s);
+    e += t->g_scale_adjust;                    // dynamic loss scaling: the host lowers it after an overflow (training.py Trainer.step)
+    if (const char* s = getenv("NERFDS_TRAIN_G_SCALE_LOG2")) {      // development override of the exponent: a whole number in [-30, 40], anything else ignored
+      char* end = nullptr;
+      const long v = std::strtol(s, &end, 10);
+      if (end != s && *end == '\0' && v >= -30 && v <= 40) e = (int)v;
+    }
+    e = e < -30 ? -30 : (e > 40 ? 40 : e);
     t->g_scale = (t->half_step && t->g16) ? std::ldexp(1.f, e) : 1.f;
   }
   t->keep_tangents = norm_weight != 0.f || elastic;

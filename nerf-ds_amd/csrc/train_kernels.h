@@ -72,8 +72,8 @@ void se3_jvp(hipStream_t, long long M, const float* wv, const float* x, const fl
 void trunk_in_jvp(hipStream_t, const Dims&, long long M, const float* xw, const float* wamb, const float* t_xw, const float* t_wamb, const Windows&, float* t_tin);
 void target_norm(hipStream_t, long long M, const float* t_alpha, const float* wv, float* out);
 void clip_gradients(hipStream_t, float* g, long long n, float max_val, float max_norm, float* sumsq_scratch);
-void adam(hipStream_t, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2,
-          unsigned* nonfinite_flag);      // flag != 0 after the gradient check: nothing is updated
+void adam(hipStream_t, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, long long* step_dev,
+          float* corr_dev, unsigned* nonfinite_flag);      // flag != 0 after the gradient check: nothing is updated
 // fused forward: weight streams / biases / folded rgb layer from the current parameters (see train_kernels.hip)
 // map: two units (2 KiB) per fragment; stream: split bf16 (two units), fragments [x6_lo, x6_hi) exact fp32 (wide_f32) or three units (hi | mid | lo)
 void pack_stream(hipStream_t, const float* theta, const float* fold, long long P, const int* map, void* stream, int nfrag, int x6_lo, int x6_hi, int wide_f32 = 0);

@@ -951,10 +951,21 @@ __global__ void k_nonfinite(const float* __restrict__ g, long long n, unsigned* 
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i < n && !isfinite(g[i])) atomicOr(flag, 1u);
 }
+// The optimizer's step count lives on the DEVICE (state[0] as int64; state[1], state[2] = the bias corrections 1 - b^t of the step about to be
+// applied): a skipped update must not advance it - the moments did not move, so neither may the bias correction nor the checkpointed
+// OptimizerState.step (flax 0.3.4 optim/adam.py: step + 1 only in apply_gradient) - and the host does not know about the skip when it enqueues.
+__global__ void k_adam_prepare(const unsigned* __restrict__ skip, long long* __restrict__ step, float* __restrict__ corr, double b1, double b2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || *skip != 0u) return;
+  const long long t = *step + 1;
+  *step = t;
+  corr[0] = (float)(1.0 - pow(b1, (double)t));
+  corr[1] = (float)(1.0 - pow(b2, (double)t));
+}
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, long long n,
-                       float lr, float b1, float b2, float eps, float c1, float c2, const unsigned* __restrict__ skip) {
+                       float lr, float b1, float b2, float eps, const float* __restrict__ corr, const unsigned* __restrict__ skip) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= n || *skip != 0u) return;
+  const float c1 = corr[0], c2 = corr[1];
   const float gi = g[i];
   const float a = (1.0f - b1) * gi + b1 * m1[i];
   const float b = (1.0f - b2) * gi * gi + b2 * m2[i];
@@ -1182,10 +1193,11 @@ void clip_gradients(hipStream_t st, float* g, long long n, float max_val, float 
   LAUNCH(k_clip_val_sumsq, n, st, g, n, max_val, sumsq_scratch);
   if (max_norm > 0.f) LAUNCH(k_clip_norm, n, st, g, n, max_norm, 1e-7f, sumsq_scratch);
 }
-void adam(hipStream_t st, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, float c1, float c2,
-          unsigned* nonfinite_flag) {
+void adam(hipStream_t st, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, long long* step_dev,
+          float* corr_dev, unsigned* nonfinite_flag) {
   LAUNCH(k_nonfinite, n, st, g, n, nonfinite_flag);
-  LAUNCH(k_adam, n, st, p, g, m1, m2, n, lr, b1, b2, eps, c1, c2, nonfinite_flag);
+  hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(1), 0, st, nonfinite_flag, step_dev, corr_dev, (double)b1, (double)b2);
+  LAUNCH(k_adam, n, st, p, g, m1, m2, n, lr, b1, b2, eps, corr_dev, nonfinite_flag);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -177,10 +177,14 @@ def extra_params_from_gin(path: str) -> Dict[str, float]:
   return out
 
 
-def objective_from_gin(path: str, step: int = 0) -> Dict[str, Any]:
+def objective_from_gin(path: str, step: int = 0, honour_hyper_reg_loss_weight: bool = False) -> Dict[str, Any]:
   """The ``objective`` dict of ``Trainer.step`` at training step ``step``, from the loss switches and weights train.py reads out of
   ``TrainConfig`` / ``SpecularConfig`` (train.py:313-355: ``scalar_params``, the static flags of ``training.train_step``, ``state.norm_loss_weight``;
-  defaults as configs.py:40-110, 222-252 and training.py:36-56).  A switched-off loss contributes no key, so ``{}`` (falsy) selects the plain rgb step."""
+  defaults as configs.py:40-110, 222-252 and training.py:36-56).  A switched-off loss contributes no key, so ``{}`` (falsy) selects the plain rgb step.
+
+  ``TrainConfig.hyper_reg_loss_weight``: train.py builds ``ScalarParams`` without it (train.py:312-325, and no ``.replace`` in the loop sets it), so
+  the reference trains with the dataclass default 0.0 (training.py:49) whatever the gin file says - ``use_hyper_reg_loss=True`` only adds the
+  statistic.  The default here reproduces the reference AS IT RUNS (weight 0, no key); ``honour_hyper_reg_loss_weight=True`` takes the gin value."""
   from . import sched
   b = resolve(path)
   g = lambda k, d: b.get(k, d)
@@ -189,7 +193,7 @@ def objective_from_gin(path: str, step: int = 0) -> Dict[str, Any]:
   if g('TrainConfig.use_warp_reg_loss', False):
     ob.update(warp_reg_loss_weight=float(g('TrainConfig.warp_reg_loss_weight', 0.0)), warp_reg_loss_alpha=float(g('TrainConfig.warp_reg_loss_alpha', -2.0)),
               warp_reg_loss_scale=float(g('TrainConfig.warp_reg_loss_scale', 0.001)))
-  if g('TrainConfig.use_hyper_reg_loss', False):
+  if g('TrainConfig.use_hyper_reg_loss', False) and honour_hyper_reg_loss_weight:
     ob['hyper_reg_loss_weight'] = float(g('TrainConfig.hyper_reg_loss_weight', 0.0))
   if g('TrainConfig.use_background_loss', False):      # batch['background_points'] comes from the data source (train.py; batch size
     ob.update(background_loss_weight=float(g('TrainConfig.background_loss_weight', 0.0)),              # TrainConfig.background_points_batch_size)

@@ -58,6 +58,8 @@ def _bind(lib):
   lib.nerfds_trainer_grads.restype = C.c_void_p
   lib.nerfds_trainer_reset_optimizer.argtypes = [C.c_void_p]
   lib.nerfds_trainer_set_step.argtypes = [C.c_void_p, C.c_int64]
+  lib.nerfds_trainer_get_step.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+  lib.nerfds_trainer_set_loss_scale_adjust.argtypes = [C.c_void_p, C.c_int32]
   lib.nerfds_trainer_nonfinite.argtypes = [C.c_void_p]
   lib.nerfds_trainer_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
   lib.nerfds_trainer_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -78,9 +80,15 @@ class Trainer:
   """Owns the flat fp32 parameter / gradient / Adam vectors on one MI355X."""
 
   def __init__(self, cfg: NerfModelConfig, params: Optional[Dict[str, Any]] = None, max_rays: int = 4096,
-               device: Optional[torch.device] = None):
+               device: Optional[torch.device] = None, warp_embeds=None):
+    """``warp_embeds``: the list of warp ids present in the dataset (model.warp_embeds = embeddings_dict['warp'], models.py:248-250): what the
+    background regulariser draws its random ids from (training.py:163).  None = range(num_warp_embeds), which is the same thing when the
+    training ids are contiguous from 0 - with sparse ids it would regularise GLO rows no ray ever trains."""
     cfg.validate()
     self.cfg = cfg
+    self.warp_embeds = None if warp_embeds is None else torch.as_tensor(np.asarray(list(warp_embeds)).astype(np.int64)).reshape(-1)
+    if self.warp_embeds is not None and (self.warp_embeds.numel() == 0 or int(self.warp_embeds.min()) < 0 or int(self.warp_embeds.max()) >= cfg.num_warp_embeds):
+      raise ValueError('warp_embeds must be a non-empty list of ids in [0, num_warp_embeds)')
     self._lib = _bind(N.load())
     if not torch.cuda.is_available():
       raise RuntimeError('Trainer needs an MI355X (torch.cuda is not available); there is no CPU path')
@@ -93,6 +101,12 @@ class Trainer:
       raise (NotImplementedError if rc == -95 else RuntimeError)(f'nerfds_trainer_create failed ({rc}): {msg}')
     self._h = h
     self.max_rays = max_rays
+    # dynamic loss scaling of the plain step's f16 g (include/nerfds.h nerfds_trainer_set_loss_scale_adjust): log2 offset, lowered by 2 when a
+    # step's gradient comes out non-finite (the step is re-run), raised by 1 towards 0 after `loss_scale_growth_interval` clean steps
+    self.loss_scale_adjust = 0
+    self.loss_scale_growth_interval = 1000
+    self.max_overflow_retries = 8
+    self._clean_steps = 0
     self.num_params = int(self._lib.nerfds_trainer_param_count(h))
     self.leaves = []
     name = C.create_string_buffer(256)
@@ -181,6 +195,15 @@ class Trainer:
     if rc < 0:
       raise RuntimeError(f'nerfds_trainer_nonfinite failed ({rc})')
     return bool(rc)
+
+  @property
+  def optimizer_step(self) -> int:
+    """OptimizerState.step: the number of Adam updates actually applied (an update skipped for a non-finite gradient does not count)."""
+    v = C.c_int64()
+    rc = self._lib.nerfds_trainer_get_step(self._h, C.byref(v))
+    if rc != 0:
+      raise RuntimeError(f'nerfds_trainer_get_step failed ({rc})')
+    return int(v.value)
 
   def get_params(self) -> Dict[str, Any]:
     return self._tree(self._download(0))
@@ -273,8 +296,11 @@ class Trainer:
         bp = f32(batch['background_points']).reshape(-1, 3)
         gen = torch.Generator(device='cpu').manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
         bid = batch.get('background_ids')        # the reference draws them: random.choice(key, model.warp_embeds, ...); injectable for tests
-        if bid is None:
-          bid = torch.randint(0, self.cfg.num_warp_embeds, (bp.shape[0],), generator=gen)
+        if bid is None:     # random.choice(key, model.warp_embeds, ...): uniform over the ids PRESENT in the dataset
+          if self.warp_embeds is not None:
+            bid = self.warp_embeds[torch.randint(0, self.warp_embeds.numel(), (bp.shape[0],), generator=gen)]
+          else:
+            bid = torch.randint(0, self.cfg.num_warp_embeds, (bp.shape[0],), generator=gen)
         bid = (bid if isinstance(bid, torch.Tensor) else torch.as_tensor(np.asarray(bid).astype(np.int64))).to(dev).reshape(-1).to(torch.int32).contiguous()
         std = float(objective.get('background_noise_std', 0.0))
         if std != 0.0:
@@ -293,24 +319,46 @@ class Trainer:
     elif data_parallel and not grouped:
       raise RuntimeError('data_parallel=True needs an initialised torch.distributed process group')
     clip = grad_max_val > 0.0 or grad_max_norm > 0.0
-    rc = self._lib.nerfds_trainer_step(self._h, C.byref(rays), target.data_ptr(), C.byref(ex), C.byref(rnd), C.byref(ob) if ob is not None else None,
-                                       float(learning_rate),
-                                       (GRADS_ONLY if (grads_only or data_parallel or clip) else 0) | (SIGMA_GRAD if sigma_gradient else 0), loss,
-                                       C.c_void_p(s.cuda_stream))
+    deferred = bool(data_parallel or clip)          # Adam runs in nerfds_trainer_apply, after the all-reduce / the clip
+    flags = (GRADS_ONLY if (grads_only or deferred) else 0) | (SIGMA_GRAD if sigma_gradient else 0)
     self._last_rays = R
-    if rc == -34:      # NERFDS_ENONFINITE: the gradient held an inf / NaN, the update was skipped as a whole (include/nerfds.h)
-      raise FloatingPointError((self._lib.nerfds_trainer_last_error(self._h) or b'').decode())
-    if rc != 0:
-      raise RuntimeError(f'nerfds_trainer_step failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
-    if data_parallel:       # one rank per GPU, each with its own rays: ONE all-reduce of the 6 MB gradient vector (training.py:502)
-      with torch.cuda.stream(s):
-        allreduce_mean_(self.grads_tensor(), force=True)
-    if clip:                # utils.clip_gradients after the pmean (training.py:502-504)
-      rc = self._lib.nerfds_trainer_clip_gradients(self._h, float(grad_max_val), float(grad_max_norm), C.c_void_p(s.cuda_stream))
-      if rc != 0:
-        raise RuntimeError(f'nerfds_trainer_clip_gradients failed ({rc})')
-    if (data_parallel or clip) and not grads_only:
-      self.apply_gradients(learning_rate, s)
+    retries = 0
+    while True:
+      # One attempt = forward + backward (+ all-reduce, clip, Adam).  A non-finite gradient skips the update as a whole on the device (parameters,
+      # moments and step count untouched).  The usual cause is the loss-scaled f16 g leaving f16's range (the reference's fp32 g cannot): the
+      # attempt is repeated at a quarter of the scale - same seed, same samples - up to max_overflow_retries times; what still overflows then
+      # (an f16 ACTIVATION beyond 65504: no scale helps) is raised.  The gradient all-reduce spreads an inf / NaN to every rank, so all ranks
+      # of a data-parallel step take the same decision.
+      self._lib.nerfds_trainer_set_loss_scale_adjust(self._h, int(self.loss_scale_adjust))
+      rc = self._lib.nerfds_trainer_step(self._h, C.byref(rays), target.data_ptr(), C.byref(ex), C.byref(rnd), C.byref(ob) if ob is not None else None,
+                                         float(learning_rate), flags, loss, C.c_void_p(s.cuda_stream))
+      overflow = rc == -34      # NERFDS_ENONFINITE: the update of this step was skipped (include/nerfds.h)
+      if rc != 0 and not overflow:
+        raise RuntimeError(f'nerfds_trainer_step failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
+      if not overflow and deferred:
+        if data_parallel:       # one rank per GPU, each with its own rays: ONE all-reduce of the 6 MB gradient vector (training.py:502)
+          with torch.cuda.stream(s):
+            allreduce_mean_(self.grads_tensor(), force=True)
+        if clip:                # utils.clip_gradients after the pmean (training.py:502-504)
+          rc = self._lib.nerfds_trainer_clip_gradients(self._h, float(grad_max_val), float(grad_max_norm), C.c_void_p(s.cuda_stream))
+          if rc != 0:
+            raise RuntimeError(f'nerfds_trainer_clip_gradients failed ({rc})')
+        if not grads_only:
+          self.apply_gradients(learning_rate, s)
+          overflow = self.nonfinite()      # nerfds_trainer_apply cannot report it (asynchronous): read the device flag back
+      if not overflow:
+        break
+      self._clean_steps = 0
+      msg = (self._lib.nerfds_trainer_last_error(self._h) or b'non-finite gradient: the Adam update of this step was skipped').decode()
+      if retries >= self.max_overflow_retries or self.loss_scale_adjust <= -40 + 2:
+        raise FloatingPointError(f'{msg} [after {retries} retries at lower loss scales; loss_scale_adjust = {self.loss_scale_adjust}]')
+      retries += 1
+      self.loss_scale_adjust -= 2
+    if not grads_only:
+      self._clean_steps += 1
+      if self.loss_scale_adjust < 0 and self._clean_steps >= self.loss_scale_growth_interval:
+        self.loss_scale_adjust += 1
+        self._clean_steps = 0
     del keep
     fine, coarse = float(loss[0]), float(loss[1])
     two = self.cfg.num_fine_samples > 0

@@ -74,3 +74,15 @@ def test_training_objectives_of_the_reference_gin_files():
   # base.gin (HyperNeRF): the background regulariser is ON (base.gin:65-66), the elastic loss off, no specular terms
   assert objective_from_gin('/root/reference/configs/base.gin', 0) == dict(background_loss_weight=1.0, background_noise_std=0.001)
 
+
+
+def test_hyper_reg_weight_follows_the_reference_as_it_runs(tmp_path):
+  """train.py never hands TrainConfig.hyper_reg_loss_weight to ScalarParams (train.py:312-325): the reference trains with the dataclass
+  default 0.0 (training.py:49) even under use_hyper_reg_loss=True.  objective_from_gin reproduces that; the gin value is opt-in."""
+  from nerfds_amd.gin_subset import objective_from_gin
+  gin = tmp_path / 'h.gin'
+  gin.write_text('TrainConfig.use_hyper_reg_loss = True\nTrainConfig.hyper_reg_loss_weight = 0.01\n'
+                 'TrainConfig.use_warp_reg_loss = True\nTrainConfig.warp_reg_loss_weight = 0.001\n')
+  ob = objective_from_gin(str(gin))
+  assert 'hyper_reg_loss_weight' not in ob and ob['warp_reg_loss_weight'] == 0.001
+  assert objective_from_gin(str(gin), honour_hyper_reg_loss_weight=True)['hyper_reg_loss_weight'] == 0.01

@@ -602,6 +602,48 @@ def test_nonfinite_gradient_skips_the_update_and_is_reported():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('path', ['fused', 'clip'])
+def test_dynamic_loss_scaling_and_step_count(path):
+  """A g that leaves f16's range is a property of the loss scale, not of the problem (the reference's g is fp32): the step is re-run at a lower
+  scale - same seed, same samples - until the gradient is finite, on the fused path (Adam inside nerfds_trainer_step) and on the deferred one
+  (clip / data-parallel: Adam in nerfds_trainer_apply, where the skip used to go unnoticed).  The optimizer's step count is the number of updates
+  APPLIED: a skipped update leaves parameters, moments and the count alone (flax OptimizerState.step)."""
+  import copy
+  from nerfds_amd.training import Trainer
+  cfg, params, batch, t, u = _problem(32, 8, 8, seed=7)
+  kw = dict(t_rand=t, u_rand=u, mask_ratio=1.0, **({'grad_max_norm': 1e3} if path == 'clip' else {}))
+  ref = Trainer(cfg, params, max_rays=32)
+  p0 = dict(tree_leaves(ref.get_params()))
+  ref.step(batch, EX, 1e-3, **kw)
+  assert ref.optimizer_step == 1 and ref.loss_scale_adjust == 0
+  tr = Trainer(cfg, params, max_rays=32)
+  tr.loss_scale_adjust = 16                                  # 2^27 x a head gradient of ~1e-3: beyond f16 -> overflow on the first attempts
+  tr.step(batch, EX, 1e-3, **kw)
+  assert tr.loss_scale_adjust < 16 and tr.loss_scale_adjust % 2 == 0 and not tr.nonfinite()
+  assert tr.optimizer_step == 1                              # ONE update applied, however many attempts it took
+  pa, pb = dict(tree_leaves(ref.get_params())), dict(tree_leaves(tr.get_params()))
+  moved, differ, total = 0.0, 0, 0
+  for k, v in p0.items():
+    moved = max(moved, float(np.abs(pa[k] - v).max()))
+    differ += int((np.abs(pa[k] - pb[k]) > 1e-4).sum())       # Adam's first step is -lr sign(g) per element: the two runs differ only where
+    total += v.size                                           # g is so close to 0 that the f16 rounding of g at another exponent flips its sign
+  assert moved > 5e-4 and differ <= 0.02 * total, (moved, differ, total)
+  # what no loss scale cures - an ACTIVATION beyond 65504 - is still raised, after the retries, with nothing applied
+  big = copy.deepcopy(params)
+  big['nerf_mlps_coarse']['trunk_mlp']['hidden_1']['kernel'] = np.asarray(big['nerf_mlps_coarse']['trunk_mlp']['hidden_1']['kernel']) * 3e5
+  bad = Trainer(cfg, big, max_rays=32)
+  bad.max_overflow_retries = 2
+  before = bad.get_params()
+  with pytest.raises(FloatingPointError):
+    bad.step(batch, EX, 1e-3, **kw)
+  assert bad.optimizer_step == 0 and bad.loss_scale_adjust == -4
+  for (ka, a), (kb, b) in zip(tree_leaves(before), tree_leaves(bad.get_params())):
+    assert np.array_equal(np.asarray(a), np.asarray(b)), ka
+  m1, m2 = bad.get_opt_state()
+  assert all(not np.any(v) for _, v in tree_leaves(m1)) and all(not np.any(v) for _, v in tree_leaves(m2))
+
+
+@pytest.mark.gpu
 def test_gradient_scale_of_the_f16_g_arrays(monkeypatch):
   """The chains store g_scale * g as f16 (loss scaling) and the weight-gradient kernels undo the power of two: the gradients do not depend on
   it while g stays in range (2^8 .. 2^22 here: every leaf within 2e-3 of the default scale's, the differences being f16 roundings of g at another
