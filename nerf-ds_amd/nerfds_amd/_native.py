@@ -143,6 +143,10 @@ def load():
   global _lib
   if _lib is not None:
     return _lib
+  # torch FIRST: it ships its own HIP runtime (torch/lib/libamdhip64.so) and the library must bind to THAT copy - the one that owns the
+  # tensors and streams it is handed.  Loaded the other way round the process holds two HIP runtimes (this library's from /opt/rocm, then
+  # torch's) and neither finds the GPU afterwards ("no ROCm-capable device is detected": build() + smoke() in one process, round 5).
+  import torch  # noqa: F401
   if not os.path.exists(LIB_PATH):
     raise RuntimeError(f'{LIB_PATH} is not built: run `make -C nerf-ds_amd/csrc -j8` (there is no CPU fallback)')
   lib = C.CDLL(LIB_PATH)
