@@ -322,6 +322,24 @@ typedef struct nerfds_train_objective {
 } nerfds_train_objective;
 #define NERFDS_TRAIN_GRADS_ONLY 1u
 #define NERFDS_TRAIN_SIGMA_GRAD 2u   /* also evaluate the sigma gradient (models.py:1035-1077) -> nerfds_trainer_target_norm */
+/* ---- A caller-defined loss on the rendered rays (training.py:441-494: jax.value_and_grad of an arbitrary _loss_fn through model.apply) -------
+ * nerfds_trainer_forward: model.apply on the trainer's current parameters - rgb / depth / acc of each level (model_utils.py:138-148) into DEVICE
+ * arrays, any of them NULL = not wanted; a single-level model writes its one level through `coarse`.
+ * nerfds_render_rays_bwd: the vector-Jacobian product of that map - d_fine / d_coarse hold d loss / d rgb [R][3], d loss / d depth [R], d loss / d acc
+ * [R] of the level (DEVICE, NULL = zero; a NULL struct = all zero) - into the trainer's gradient vector (nerfds_trainer_grads, leaves by
+ * nerfds_trainer_leaf), which is overwritten; no optimizer update: follow with nerfds_trainer_clip_gradients / an all-reduce / nerfds_trainer_apply, or
+ * read the vector and step any optimizer on nerfds_trainer_params.  The backward re-runs the forward (the workspace holds ONE level's activations, so
+ * nothing survives between the two calls: same rays, same extra, same rnd -> same samples; the Philox stream is keyed by (seed, ray)) - a step
+ * costs the forward twice; nerfds_trainer_step remains the fast path for the reference's own losses.  The fine depths are drawn from the coarse
+ * weights behind a stop_gradient (model_utils.py:264), as in the reference.  med_depth and the other record fields are not differentiable outputs
+ * here.  The stored f16 g of the backward is loss-scaled for gradients of the size of a mean squared error's (2 / (3 R) per unit of colour): a loss
+ * reduced differently should set nerfds_trainer_set_loss_scale_adjust (nerfds_amd.autograd does it from max |cotangent|). */
+typedef struct nerfds_level_out { float* rgb; float* depth; float* acc; } nerfds_level_out;
+typedef struct nerfds_level_cotangent { const float* d_rgb; const float* d_depth; const float* d_acc; } nerfds_level_cotangent;
+int nerfds_trainer_forward(nerfds_trainer* t, const nerfds_rays* rays, const nerfds_extra* extra, const nerfds_rand* rnd, const nerfds_level_out* fine,
+                           const nerfds_level_out* coarse, void* hip_stream);
+int nerfds_render_rays_bwd(nerfds_trainer* t, const nerfds_rays* rays, const nerfds_extra* extra, const nerfds_rand* rnd,
+                           const nerfds_level_cotangent* d_fine, const nerfds_level_cotangent* d_coarse, void* hip_stream);
 int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_cfg* cfg, int64_t max_rays);
 int nerfds_trainer_destroy(nerfds_trainer* t);
 int64_t nerfds_trainer_param_count(const nerfds_trainer* t);

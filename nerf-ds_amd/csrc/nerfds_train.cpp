@@ -74,6 +74,11 @@ struct nerfds_trainer {
   unsigned char* adam_dev = nullptr;
   long long* adam_step() const { return reinterpret_cast<long long*>(adam_dev); }
   float* adam_corr() const { return reinterpret_cast<float*>(adam_dev + 8); }
+  // a caller-defined loss (nerfds_trainer_forward / nerfds_render_rays_bwd): per level (0 coarse, 1 fine) the cotangents that replace the squared error's
+  // gradient, where the level's rgb / depth / acc go, and "stop after the forward of each level" (set for the duration of one call)
+  LevelCot cot[2] = {{0, nullptr, nullptr, nullptr}, {0, nullptr, nullptr, nullptr}};
+  LevelOut lout[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  bool fwd_only = false;
   // dynamic loss scaling of the stored f16 g (include/nerfds.h nerfds_trainer_set_loss_scale_adjust): log2 offset on the heuristic exponent
   int g_scale_adjust = 0;
   float* ws = nullptr;      // one workspace allocation
@@ -832,7 +837,7 @@ int run_merged(nerfds_trainer& t, hipStream_t st, int R, const float* zc, const 
   trunk_in(st, D, Mc, t.xw, t.wamb, W, t.trunk_in);
   alpha_post(st, D, R, Nc, t.alphav, t.wv, viewdirs, W, t.sigma, t.cond);
   composite_loss(st, R, Nc, zc, rays->directions, t.sigma, t.rgb_logit, target, t.cfg.use_sample_at_infinity, t.cfg.use_white_background, t.rgb_ray, t.wc,
-                 t.loss_dev + 0, t.d_rgb_logit, t.d_alpha);
+                 t.loss_dev + 0, t.d_rgb_logit, t.d_alpha, t.cot[0], t.lout[0]);
   fused_backward(t, st, 0, 0, Mc, t.d_rgb_logit, 3, t.d_alpha, t.d_trunk_in, D.trunk_in);
   rc.fork(false); wg_nerf(rc, 0);
   trunk_in_bwd(st, D, Mc, t.d_trunk_in, t.xw, t.wamb, W, nullptr, nullptr, t.dxw, t.dwamb);          // position rows of block A
@@ -852,7 +857,7 @@ int run_merged(nerfds_trainer& t, hipStream_t st, int R, const float* zc, const 
   trunk_in(st, D, Mf, xw_f, wamb_f, W, t.trunk_in);
   alpha_post(st, D, R, S, t.alphav, wv_f, viewdirs, W, t.sigma, t.cond);
   composite_loss(st, R, S, t.zf, rays->directions, t.sigma, t.rgb_logit, target, t.cfg.use_sample_at_infinity, t.cfg.use_white_background, t.rgb_ray, t.weights,
-                 t.loss_dev + 1, t.d_rgb_logit, t.d_alpha);
+                 t.loss_dev + 1, t.d_rgb_logit, t.d_alpha, t.cot[1], t.lout[1]);
   fused_backward(t, st, 0, 1, Mf, t.d_rgb_logit, 3, t.d_alpha, t.d_trunk_in, D.trunk_in);
   rf.fork(false); wg_nerf(rf, 1);
   trunk_in_bwd(st, D, Mf, t.d_trunk_in, xw_f, wamb_f, W, nullptr, nullptr, dxw_f, dwamb_f);
@@ -960,7 +965,11 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   r.dense_fwd(t.rgb_out[level], {{t.rgb_hv, t.rgb_h[level].N, t.rgb_h[level].N, nullptr, 0, false}}, t.rgb_logit, 3, false);
   }
   composite_loss(st, R, S, z, rays->directions, t.sigma, t.rgb_logit, target, t.cfg.use_sample_at_infinity, t.cfg.use_white_background, t.rgb_ray,
-                 weights_out, t.loss_dev + level, t.d_rgb_logit, t.d_alpha);
+                 weights_out, t.loss_dev + level, t.d_rgb_logit, t.d_alpha, t.cot[level], t.lout[level]);
+  if (t.fwd_only) {      // nerfds_trainer_forward: the level's outputs are written (and the weights the resample reads); no backward
+    if (!r.ok) return t.fail(NERFDS_ENOTSUP, "%s", r.unsupported_what.c_str());
+    return NERFDS_OK;
+  }
   if (want_sigma_gradient) {
     if (t.half_step) {      // the tangent pass reads the primal layers' ReLU masks as fp32 arrays: the f16 activations, widened (their sign is all it uses)
       for (int l = 0; l < t.warp.depth; ++l) expand_half(st, t.warp_h16[l], t.warp_h[l], M * t.warp.width);
@@ -1344,10 +1353,53 @@ int nerfds_trainer_apply(nerfds_trainer* t, float learning_rate, void* hip_strea
   return NERFDS_OK;
 }
 
+// nerfds_trainer_step, nerfds_trainer_forward and nerfds_render_rays_bwd are one flow: forward + backward of both levels.  target_rgb == nullptr is
+// allowed when the caller's cotangents (t->cot) replace the built-in squared error or when only the forward runs (t->fwd_only).
+static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* ex, const nerfds_rand* rnd,
+                     const nerfds_train_objective* objective, float learning_rate, uint32_t flags, float* loss_host, void* hip_stream);
+
 int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* ex, const nerfds_rand* rnd,
                         const nerfds_train_objective* objective, float learning_rate, uint32_t flags, float* loss_host, void* hip_stream) {
   if (!t) return NERFDS_EINVAL;
-  if (!rays || !target_rgb || !ex || !rays->origins || !rays->directions || !rays->warp_id) return t->fail(NERFDS_EINVAL, "null argument");
+  if (!target_rgb) return t->fail(NERFDS_EINVAL, "null argument");
+  return step_impl(t, rays, target_rgb, ex, rnd, objective, learning_rate, flags, loss_host, hip_stream);
+}
+
+namespace {
+struct CallScope {      // the per-call fields of a caller-defined loss never outlive the call
+  nerfds_trainer* t;
+  ~CallScope() { t->cot[0] = t->cot[1] = LevelCot{0, nullptr, nullptr, nullptr}; t->lout[0] = t->lout[1] = LevelOut{nullptr, nullptr, nullptr}; t->fwd_only = false; }
+};
+}  // namespace
+
+int nerfds_trainer_forward(nerfds_trainer* t, const nerfds_rays* rays, const nerfds_extra* ex, const nerfds_rand* rnd, const nerfds_level_out* fine,
+                           const nerfds_level_out* coarse, void* hip_stream) {
+  if (!t) return NERFDS_EINVAL;
+  CallScope scope{t};
+  const bool two = t->cfg.num_fine_samples > 0;
+  // a single-level model has only the 'coarse' level (as the reference's out dict): its outputs go where `coarse` points
+  if (coarse) t->lout[0] = LevelOut{coarse->rgb, coarse->depth, coarse->acc};
+  if (fine && two) t->lout[1] = LevelOut{fine->rgb, fine->depth, fine->acc};
+  if (fine && !two && (fine->rgb || fine->depth || fine->acc)) return t->fail(NERFDS_EINVAL, "this model has no fine level (num_fine_samples == 0)");
+  t->fwd_only = true;
+  const int rc = step_impl(t, rays, nullptr, ex, rnd, nullptr, 0.f, NERFDS_TRAIN_GRADS_ONLY, nullptr, hip_stream);
+  return rc;
+}
+
+int nerfds_render_rays_bwd(nerfds_trainer* t, const nerfds_rays* rays, const nerfds_extra* ex, const nerfds_rand* rnd, const nerfds_level_cotangent* d_fine,
+                           const nerfds_level_cotangent* d_coarse, void* hip_stream) {
+  if (!t) return NERFDS_EINVAL;
+  CallScope scope{t};
+  const bool two = t->cfg.num_fine_samples > 0;
+  t->cot[0] = LevelCot{1, d_coarse ? d_coarse->d_rgb : nullptr, d_coarse ? d_coarse->d_depth : nullptr, d_coarse ? d_coarse->d_acc : nullptr};
+  t->cot[1] = LevelCot{1, (d_fine && two) ? d_fine->d_rgb : nullptr, (d_fine && two) ? d_fine->d_depth : nullptr, (d_fine && two) ? d_fine->d_acc : nullptr};
+  if (d_fine && !two && (d_fine->d_rgb || d_fine->d_depth || d_fine->d_acc)) return t->fail(NERFDS_EINVAL, "this model has no fine level (num_fine_samples == 0)");
+  return step_impl(t, rays, nullptr, ex, rnd, nullptr, 0.f, NERFDS_TRAIN_GRADS_ONLY, nullptr, hip_stream);
+}
+
+static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* target_rgb, const nerfds_extra* ex, const nerfds_rand* rnd,
+                     const nerfds_train_objective* objective, float learning_rate, uint32_t flags, float* loss_host, void* hip_stream) {
+  if (!rays || !ex || !rays->origins || !rays->directions || !rays->warp_id) return t->fail(NERFDS_EINVAL, "null argument");
   if (rays->num_rays <= 0 || rays->num_rays > t->max_rays) return t->fail(NERFDS_EINVAL, "num_rays must be in [1, max_rays = %lld]", (long long)t->max_rays);
   if (ex->mask_ratio != 1.0f && !rays->gt_mask) return t->fail(NERFDS_EINVAL, "rays_dict['mask'] is required when mask_ratio != 1");
   // train_step calls model.apply without use_sample_at_infinity / render_opts (training.py:441-455): both levels composite with the model's value
@@ -1439,7 +1491,7 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
   // flow does not cover: auxiliary losses, tangent passes, one level, the layer-by-layer kernels)
   static const bool merged_on = !(getenv("NERFDS_TRAIN_MERGED") && std::string(getenv("NERFDS_TRAIN_MERGED")) == "0");
   int rc;
-  if (merged_on && t->half_step && !want_sg && Nf > 0 && !obp && resample_has_sources(Nc, Nf) && t->g0 && 11 * (int64_t)R * (Nc + Nf) <= (int64_t)t->max_rays * (Nc + Nf) * t->trunk[0].width) {
+  if (merged_on && !t->fwd_only && t->half_step && !want_sg && Nf > 0 && !obp && resample_has_sources(Nc, Nf) && t->g0 && 11 * (int64_t)R * (Nc + Nf) <= (int64_t)t->max_rays * (Nc + Nf) * t->trunk[0].width) {
     rc = run_merged(*t, st, R, t->zc, rays, target_rgb, ex, W, rnd);
     if (rc != NERFDS_OK) return rc;
   } else {
@@ -1450,6 +1502,11 @@ int nerfds_trainer_step(nerfds_trainer* t, const nerfds_rays* rays, const float*
     rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights, want_sg_fine, obp, norm_weight);
     if (rc != NERFDS_OK) return rc;
   }
+  }
+  if (t->fwd_only) {
+    hipError_t fe = hipGetLastError();
+    if (fe != hipSuccess) return t->fail(NERFDS_EDEVICE, "kernel launch failed: %s", hipGetErrorString(fe));
+    return NERFDS_OK;
   }
   if (objective && objective->background_loss_weight != 0.f) {
     rc = run_background(*t, st, *objective, W);

@@ -56,8 +56,12 @@ void expand_half(hipStream_t, const uint16_t* h16, float* out, long long n);    
 void elastic_loss(hipStream_t, int R, int S, float weight, int by_weight, const float* weights, const float* t_xw, float* term, float* d_t_xw);
 void background_loss(hipStream_t, long long B, const float* x, const float* xw, float weight, float alpha, float scale, float* term, float* dxw);
 void alpha_post(hipStream_t, const Dims&, int R, int S, const float* alpha, const float* wv, const float* viewdirs, const Windows&, float* sigma, float* cond);
+// cotangents of a level's per-ray outputs from a caller-defined loss (nerfds_render_rays_bwd) / where nerfds_trainer_forward wants them written
+struct LevelCot { int on; const float* d_rgb; const float* d_depth; const float* d_acc; };
+struct LevelOut { float* rgb; float* depth; float* acc; };
 void composite_loss(hipStream_t, int R, int S, const float* z, const float* dirs, const float* sigma, const float* rgb_logit, const float* target,
-                    int at_infinity, int white, float* rgb_ray, float* weights, float* loss, float* d_rgb_logit, float* d_alpha);
+                    int at_infinity, int white, float* rgb_ray, float* weights, float* loss, float* d_rgb_logit, float* d_alpha, const LevelCot& cot = LevelCot{0, nullptr, nullptr, nullptr},
+                    const LevelOut& out = LevelOut{nullptr, nullptr, nullptr});
 void relu_bwd(hipStream_t, float* dy, const float* y, long long n);
 void relu_bwd_colsum(hipStream_t, float* dy, const float* y, long long M, int N, float* db);
 void colsum_add(hipStream_t, const float* dz, long long M, int N, int ld, float* db);

@@ -632,17 +632,20 @@ __global__ __launch_bounds__(256) void k_mse_sum(int R, const float* __restrict_
   }
   if (threadIdx.x == 0) *loss += part[0];
 }
+// `cot` (nerfds_render_rays_bwd, a caller-defined loss): the cotangents of the level's per-ray outputs - d loss / d rgb [R][3], / d depth [R], / d acc [R],
+// each nullable = zero - REPLACE the gradient of the built-in squared error (target may then be null: no loss is reported).  `out`: rgb / depth / acc of
+// the level (model_utils.py:138-148) for nerfds_trainer_forward.
 __global__ __launch_bounds__(256) void k_composite_loss(int R, int S, const float* __restrict__ z, const float* __restrict__ dirs, const float* __restrict__ sigma,
                                  const float* __restrict__ rgb_logit, const float* __restrict__ target, int at_infinity, int white,
                                  float* __restrict__ rgb_ray, float* __restrict__ weights, float* __restrict__ loss,
-                                 float* __restrict__ d_rgb_logit, float* __restrict__ d_alpha) {
+                                 float* __restrict__ d_rgb_logit, float* __restrict__ d_alpha, LevelCot cot, LevelOut out) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= R) return;                                     // whole waves
   const float* zr = z + (size_t)r * S;
   const float dn = sqrtf(dirs[3 * r] * dirs[3 * r] + dirs[3 * r + 1] * dirs[3 * r + 1] + dirs[3 * r + 2] * dirs[3 * r + 2]);
   const float last = at_infinity ? 1e10f : 1e-19f;
-  float carryT = 1.0f, acc[3] = {0.f, 0.f, 0.f}, wsum = 0.f;
+  float carryT = 1.0f, acc[3] = {0.f, 0.f, 0.f}, wsum = 0.f, dsum = 0.f, asum = 0.f;
   for (int c0 = 0; c0 < S; c0 += 64) {
     const int s = c0 + lane;
     const bool valid = s < S;
@@ -658,18 +661,31 @@ __global__ __launch_bounds__(256) void k_composite_loss(int R, int S, const floa
     if (valid) {
       weights[m] = w;
       wsum += w;
+      dsum += w * zr[s];                                            // model_utils.py:139
+      asum += (at_infinity && s == S - 1) ? 0.f : w;                 // model_utils.py:141, 147-148
       for (int c = 0; c < 3; ++c) acc[c] += w / (1.0f + expf(-rgb_logit[3 * m + c]));
     }
   }
   wsum = wave_sum(wsum);
+  const bool ext = cot.on != 0;
   float g[3], gsum = 0.f, l = 0.f;
   for (int c = 0; c < 3; ++c) {
     acc[c] = wave_sum(acc[c]);
     if (white) acc[c] += 1.0f - wsum;
-    const float e = acc[c] - target[3 * r + c];
+    const float e = target != nullptr ? acc[c] - target[3 * r + c] : 0.f;
     l += e * e;
-    g[c] = 2.0f * e / (3.0f * (float)R);
+    g[c] = ext ? (cot.d_rgb != nullptr ? cot.d_rgb[3 * r + c] : 0.f) : 2.0f * e / (3.0f * (float)R);
     gsum += g[c];
+  }
+  const float g_depth = (ext && cot.d_depth != nullptr) ? cot.d_depth[r] : 0.f;
+  const float g_acc = (ext && cot.d_acc != nullptr) ? cot.d_acc[r] : 0.f;
+  if (out.rgb != nullptr || out.depth != nullptr || out.acc != nullptr) {
+    dsum = wave_sum(dsum); asum = wave_sum(asum);
+    if (lane == 0) {
+      if (out.rgb != nullptr) for (int c = 0; c < 3; ++c) out.rgb[3 * r + c] = acc[c];
+      if (out.depth != nullptr) out.depth[r] = dsum;
+      if (out.acc != nullptr) out.acc[r] = asum;
+    }
   }
   if (lane == 0) {
     for (int c = 0; c < 3; ++c) rgb_ray[3 * r + c] = acc[c];      // the loss is summed from these in a fixed order (k_mse_sum): a float atomic per ray
@@ -688,6 +704,8 @@ __global__ __launch_bounds__(256) void k_composite_loss(int R, int S, const floa
     const float om = (1.0f - a) + 1e-10f;
     const float Ti = (a > 0.f) ? w / a : 0.f;     // T_i (only its product with d a / d sigma matters; a == 0 only if sigma == 0)
     float G = white ? -gsum : 0.f;
+    // d depth / d w_i = z_i, d acc / d w_i = 1 except for the sample at infinity (zero unless the caller's loss reads depth / acc)
+    G += g_depth * zr[valid ? s : S - 1] + ((at_infinity && s >= S - 1) ? 0.f : g_acc);
     float dl[3];
     for (int c = 0; c < 3; ++c) {
       const float col = 1.0f / (1.0f + expf(-rgb_logit[3 * m + c]));
@@ -1156,10 +1174,11 @@ void alpha_post(hipStream_t st, const Dims& D, int R, int S, const float* alpha,
                      sigma, cond);
 }
 void composite_loss(hipStream_t st, int R, int S, const float* z, const float* dirs, const float* sigma, const float* rgb_logit, const float* target,
-                    int at_infinity, int white, float* rgb_ray, float* weights, float* loss, float* d_rgb_logit, float* d_alpha) {
+                    int at_infinity, int white, float* rgb_ray, float* weights, float* loss, float* d_rgb_logit, float* d_alpha, const LevelCot& cot,
+                    const LevelOut& out) {
   hipLaunchKernelGGL(k_composite_loss, dim3((R + 3) / 4), dim3(256), 0, st, R, S, z, dirs, sigma, rgb_logit, target, at_infinity, white, rgb_ray, weights,
-                     loss, d_rgb_logit, d_alpha);
-  hipLaunchKernelGGL(k_mse_sum, dim3(1), dim3(256), 0, st, R, rgb_ray, target, loss);
+                     loss, d_rgb_logit, d_alpha, cot, out);
+  if (target != nullptr) hipLaunchKernelGGL(k_mse_sum, dim3(1), dim3(256), 0, st, R, rgb_ray, target, loss);
 }
 void relu_bwd(hipStream_t st, float* dy, const float* y, long long n) { LAUNCH(k_relu_bwd, n, st, dy, y, n); }
 void colsum_add(hipStream_t st, const float* dz, long long M, int N, int ld, float* db) {      // N <= 256

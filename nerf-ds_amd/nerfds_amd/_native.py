@@ -132,7 +132,7 @@ SYMBOLS = ('nerfds_abi_version', 'nerfds_struct_size', 'nerfds_precision_plan', 
            'nerfds_frame_images', 'nerfds_trainer_create', 'nerfds_trainer_destroy', 'nerfds_trainer_param_count',
            'nerfds_trainer_num_leaves', 'nerfds_trainer_leaf', 'nerfds_trainer_params', 'nerfds_trainer_grads',
            'nerfds_trainer_download', 'nerfds_trainer_upload', 'nerfds_trainer_reset_optimizer', 'nerfds_trainer_step', 'nerfds_trainer_apply', 'nerfds_trainer_clip_gradients', 'nerfds_trainer_target_norm',
-           'nerfds_trainer_last_error', 'nerfds_trainer_debug_read', 'nerfds_trainer_nonfinite', 'nerfds_trainer_set_step', 'nerfds_trainer_get_step', 'nerfds_trainer_set_loss_scale_adjust',
+           'nerfds_trainer_last_error', 'nerfds_trainer_debug_read', 'nerfds_trainer_nonfinite', 'nerfds_trainer_set_step', 'nerfds_trainer_get_step', 'nerfds_trainer_set_loss_scale_adjust', 'nerfds_trainer_forward', 'nerfds_render_rays_bwd',
            'nerfds_debug_lds_attr_first_use')
 
 _lib = None

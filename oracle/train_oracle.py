@@ -128,6 +128,27 @@ def loss_and_grads(cfg, params, rays_dict, target_rgb, extra_params, t_rand, u_r
   return losses, tree, {lvl: {k: v.detach() for k, v in o.items() if torch.is_tensor(v)} for lvl, o in out.items()}
 
 
+def custom_loss_and_grads(cfg, params, rays_dict, extra_params, t_rand, u_rand, loss_fn, dtype=torch.float64, use_predicted_norm=True, mask_ratio=1.0):
+  """``jax.value_and_grad(_loss_fn)`` for an ARBITRARY loss of the model outputs (training.py:441-494): ``loss_fn(out)`` gets the
+  {'coarse': {...}, 'fine': {...}} dict of torch tensors (rgb, depth, acc, weights, ...) and returns a scalar.  Returns (loss, grads tree, out)."""
+  model = O.NerfModel(cfg, params, dtype=dtype)
+  leaves = list(_leaves(model.params))
+  for _, v in leaves:
+    v.requires_grad_(True)
+  out = model.apply(rays_dict, extra_params, t_rand=t_rand, u_rand=u_rand, use_predicted_norm=use_predicted_norm, mask_ratio=mask_ratio,
+                    return_weights=True, return_points=True, compute_sigma_gradient=False)
+  total = loss_fn(out)
+  grads = torch.autograd.grad(total, [v for _, v in leaves], allow_unused=True)
+  tree = {}
+  for (n, v), g in zip(leaves, grads):
+    node = tree
+    parts = n.split('/')
+    for p in parts[:-1]:
+      node = node.setdefault(p, {})
+    node[parts[-1]] = (g if g is not None else torch.zeros_like(v)).detach().cpu().numpy()
+  return float(total), tree, {lvl: {k: v.detach() for k, v in o.items() if torch.is_tensor(v)} for lvl, o in out.items()}
+
+
 def adam_step(param, grad, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
   """flax.optim.Adam.apply_param_gradient (flax 0.3.4): step is the 0-based count BEFORE this update."""
   m = (1.0 - b1) * grad + b1 * m

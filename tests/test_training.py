@@ -113,6 +113,62 @@ def test_hip_gradients_match_autograd_oracle(R, Nc, Nf, ratio, gemm):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('R,Nc,Nf,reduction', [(24, 8, 8, 'mean'), (40, 16, 16, 'sum'), (17, 12, 0, 'mean')])
+def test_caller_defined_loss_through_autograd(R, Nc, Nf, reduction):
+  """The loss-agnostic backward (include/nerfds.h nerfds_trainer_forward / nerfds_render_rays_bwd behind nerfds_amd.autograd): a loss the fused step does
+  not know - L1 on the colours of both levels, a squared pull on the fine level's acc, a weight on the coarse depth - written in torch on the
+  renderer's outputs, differentiated with loss.backward(), against torch autograd through the fp64 oracle (jax.value_and_grad of an arbitrary _loss_fn,
+  training.py:441-494): forward values, the loss and EVERY parameter leaf.  'sum' reduction: cotangents R times larger than a mean's - the loss scale
+  of the backward's f16 g follows the cotangents."""
+  import torch
+  from nerfds_amd.autograd import DifferentiableRenderer
+  from oracle import train_oracle as T
+  cfg, params, batch, t, u = _problem(R, Nc, Nf, seed=11)
+  top = 'fine' if Nf else 'coarse'
+  red = (lambda x: x.mean()) if reduction == 'mean' else (lambda x: x.sum())
+
+  def loss_fn(out, gt):
+    l = red((out[top]['rgb'][..., :3] - gt).abs()) + 0.3 * red((out[top]['acc'] - 0.7) ** 2) + 0.1 * red(out['coarse']['depth'])
+    if Nf:
+      l = l + 0.5 * red((out['coarse']['rgb'][..., :3] - gt).abs())
+    return l
+  want_loss, G, ref = T.custom_loss_and_grads(cfg, params, batch, EX, t, u if Nf else None, lambda o: loss_fn(o, torch.as_tensor(batch['rgb'], dtype=torch.float64)))
+  render = DifferentiableRenderer(cfg, params, max_rays=R)
+  out = render(batch, EX, t_rand=t, u_rand=u if Nf else None)
+  assert set(out) == set(ref)
+  for lv in out:
+    for k in ('rgb', 'depth', 'acc'):
+      e = np.abs(out[lv][k].detach().cpu().numpy() - ref[lv][k].numpy()).max() / max(np.abs(ref[lv][k].numpy()).max(), 1e-6)
+      assert e < 2e-4, (lv, k, e)
+  loss = loss_fn(out, torch.as_tensor(batch['rgb'], dtype=torch.float32, device=render.device))
+  assert abs(float(loss) - want_loss) < 2e-4 * max(1.0, abs(want_loss))
+  loss.backward()
+  assert render.params.grad is not None and bool(torch.isfinite(render.params.grad).all())
+  got, want = dict(tree_leaves(render.grads_tree())), dict(tree_leaves(G))
+  assert set(got) == set(want)
+  gmax = max(np.abs(v).max() for v in want.values())
+  worst = (0.0, '')
+  for name, w in want.items():
+    g = got[name].reshape(w.shape)
+    l2 = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))
+    err = np.abs(g - w).max() / max(np.abs(w).max(), 1e-3 * gmax)
+    worst = max(worst, (float(l2), name))
+    # L1 cotangents are +-1 / N wherever the error changes sign: a sample whose colour error is ~0 can take the other sign at 16-bit operands, which a
+    # squared error does not see (its cotangent is ~0 there) - hence 8e-3 where the rgb-MSE test has 4e-3
+    assert l2 < 8e-3 and err < 4e-2, f'{name}: l2 {l2:.2e}, max {err:.2e}'
+  print(f'caller-defined loss ({R} rays, {Nc}+{Nf}, {reduction}): worst l2 {worst[0]:.2e} ({worst[1]}), loss scale adjust {render.trainer.loss_scale_adjust}', file=sys.stderr)
+  # any torch optimizer on the leaf: the in-place update IS the library's parameter vector, and the next pass sees it
+  opt = torch.optim.SGD([render.params], lr=1e-2 if reduction == 'mean' else 1e-2 / R)
+  first = float(loss)
+  for _ in range(5):
+    opt.step(); opt.zero_grad()
+    out = render(batch, EX, t_rand=t, u_rand=u if Nf else None)
+    loss = loss_fn(out, torch.as_tensor(batch['rgb'], dtype=torch.float32, device=render.device))
+    loss.backward()
+  assert float(loss) < first, (first, float(loss))
+
+
+@pytest.mark.gpu
 def test_adam_update_and_loss_decrease():
   from nerfds_amd.training import Trainer
   from oracle import train_oracle as T
