@@ -218,5 +218,22 @@ template <class G> using BwdMask = BwdNet<G::MASK_W, G::MASK_DEPTH, 1>;
 template <class G> using BwdWarp = BwdNet<G::WARP_W, G::WARP_DEPTH, 6>;
 template <class G> using BwdHyper = BwdNet<G::HYP_W, G::HYP_DEPTH, G::HYP_DIMS>;
 template <class G> using BwdNerf = BwdNet<G::TRUNK_W, G::TRUNK_DEPTH, 3, true, G::RGB_W>;
+// the trunk behind its alpha head alone (no rgb branch): the backward of the TANGENT pass of the second-order terms, whose cotangent enters at
+// the alpha head's tangent (d sigma_raw / d x, models.py:1035-1077)
+template <class G> using BwdTrunkAlpha = BwdNet<G::TRUNK_W, G::TRUNK_DEPTH, 4>;
+
+// ---- Tangent chains of the second-order terms (norm loss, elastic regulariser; train_bwd_kernel.hip train_tangent_kernel) ----
+// Forward-mode tangents of a ReLU MLP are a masked LINEAR chain: t_l = 1[h_l > 0] * (W_l^T t_{l-1}), no bias, the mask the primal layer's.
+// One stream per network in FORWARD orientation, split bf16 like the data-gradient chains: layer 0 (raw tangent input -> width), layers
+// 1 .. skip-1, the skip layer over [hidden | raw input] (modules.py:66-67), layers skip+1 .. depth-1, then the head as one 32-row tile.
+template <int W_, int DEPTH_, int IN_DIM_, int NHEAD_> struct TanNet {
+  static constexpr int W = W_, DEPTH = DEPTH_, IN_DIM = IN_DIM_, IN_KC = chunks(IN_DIM_), NHEAD = NHEAD_, SKIP = 4;
+  static constexpr int WG_WAVES = (NERFDS_BWD_WAVES8 && W_ <= 128) ? 8 : 4;
+  // (field.h's Pipe reads the length of a one-stream graph under this name)
+  static constexpr int BWD_FRAGS = (W_ / 32) * (2 * chunks(IN_DIM_) + (DEPTH_ - 1) * (W_ / 16)) + W_ / 16;
+};
+template <class G> using TanWarp = TanNet<G::WARP_W, G::WARP_DEPTH, Dims<G>::WARP_IN, 6>;
+template <class G> using TanHyper = TanNet<G::HYP_W, G::HYP_DEPTH, Dims<G>::HYP_IN, G::HYP_DIMS>;
+template <class G> using TanTrunk = TanNet<G::TRUNK_W, G::TRUNK_DEPTH, Dims<G>::TRUNK_IN, 4>;
 
 }  // namespace nerfds

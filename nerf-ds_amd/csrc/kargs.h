@@ -114,6 +114,12 @@ struct TrainBwd {
   // stored g sits in f16's range (loss scaling); the raw-input gradient is multiplied by g_inv_scale on its way out and the weight-gradient
   // kernels by the same factor (WgradArgs::out_scale).  1 / 1 for fp32 g.
   float g_scale, g_inv_scale;
+  // Tangent rows (the second-order terms: three tangents per sample, rows 3 m + k): mask_div = 3 reads the ReLU bits of row r / 3 - the PRIMAL
+  // layer's mask of the sample (0 / 1: bits of row r).
+  int mask_div;
+  // scale_dev != nullptr: {g_scale, g_inv_scale} are read from DEVICE memory instead (a power of two picked on the device from the largest
+  // cotangent of this launch, train_kernels.hip k_pick_scale): the cotangents of the tangent pass have no a-priori size
+  const float* scale_dev;
 };
 
 typedef void (*launch_fn)(const KArgs& ka, int num_cus, void* stream);

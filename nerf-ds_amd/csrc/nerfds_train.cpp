@@ -31,6 +31,7 @@ extern "C" void nerfds_launch_train_fwd16_nerfds(const nerfds::KArgs& ka, const 
 // train_bwd_kernel.hip: the data-gradient chain of one network (0 NerfMLP, 1 hyper sheet, 2 warp, 3 mask)
 extern "C" void nerfds_launch_train_bwd_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);      // g as fp32
 extern "C" void nerfds_launch_train_bwd16_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);    // g as scaled f16
+extern "C" void nerfds_launch_train_tan16_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);    // tangent forward chains (train_bwd_kernel.hip)
 
 using namespace nerfds_train;
 
@@ -135,6 +136,24 @@ struct nerfds_trainer {
   int* bmap[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   void* bstream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int bfrags[5] = {0, 0, 0, 0, 0};
+  // Fused tangent pass of the second-order terms (round 5; train_bwd_kernel.hip train_tangent_kernel + the data-gradient chains on tangent rows):
+  // index maps / streams of the tangent FORWARD chains [trunk + alpha head coarse, fine, hyper sheet, warp field] and of the reversed
+  // trunk-behind-its-alpha-head chain [coarse, fine] (graphs.h TanNet / BwdTrunkAlpha), re-packed from theta in the steps that run tangents;
+  // the tangents of every hidden layer (tw16 / th16 / tt16: [3 M][width] f16, scaled by tan_x_scale) and their cotangents (gw16 / gh16 / gt16,
+  // scaled on the device: tan_slot) are the operands of the tangent pass's weight gradients.  NERFDS_TRAIN_FUSED_TAN=0: layer by layer on fp32 rows.
+  bool fused_tan = false;
+  int* tmap[4] = {nullptr, nullptr, nullptr, nullptr};
+  void* tstream[4] = {nullptr, nullptr, nullptr, nullptr};
+  int tfrags[4] = {0, 0, 0, 0};
+  int* amap[2] = {nullptr, nullptr};
+  void* astream[2] = {nullptr, nullptr};
+  int afrags[2] = {0, 0};
+  uint16_t* tws16 = nullptr;      // the tangents (allocated on first use)
+  uint16_t* gws16 = nullptr;      // their cotangents (allocated on first use by a step that differentiates the tangent pass)
+  std::vector<uint16_t*> tw16, th16, tt16, gw16, gh16, gt16;
+  float* tan_slot = nullptr;      // device [3][4]: {amax bits, scale, 1 / scale, 1 / (scale * tan_x_scale)} of the trunk / hyper / warp cotangents (pick_scale)
+  // the power of two the stored tangents carry: 2^-6 puts the largest raw tangent input (d posenc / d x at the 2^7 band... 2^6 * window) at 1
+  float tan_x_scale = 0.015625f;
   uint16_t* hws = nullptr;   // f16 activations + ReLU bits
   std::vector<uint16_t*> mask_h16, warp_h16, hyper_h16, trunk_h16, mask_bits, warp_bits, hyper_bits, trunk_bits;
   uint16_t *rgb_h16 = nullptr, *rgb_bits = nullptr;
@@ -167,7 +186,10 @@ struct nerfds_trainer {
     return code;
   }
   ~nerfds_trainer() {
-    for (float* p : {theta, grad, m1, m2, ws, loss_dev, tws, terms_dev, nws}) if (p) (void)hipFree(p);
+    for (float* p : {theta, grad, m1, m2, ws, loss_dev, tws, terms_dev, nws, tan_slot}) if (p) (void)hipFree(p);
+    for (uint16_t* p : {tws16, gws16}) if (p) (void)hipFree(p);
+    for (int i = 0; i < 4; ++i) { if (tmap[i]) (void)hipFree(tmap[i]); if (tstream[i]) (void)hipFree(tstream[i]); }
+    for (int i = 0; i < 2; ++i) { if (amap[i]) (void)hipFree(amap[i]); if (astream[i]) (void)hipFree(astream[i]); }
     if (adam_dev) (void)hipFree(adam_dev);
     if (wpack) (void)hipFree(wpack);
     if (grad_rep) (void)hipFree(grad_rep);
@@ -225,6 +247,10 @@ struct Run {
   // reads, which amplifies the 16-bit operand rounding of the two-way split to ~1 % on the warp-field gradients (measured
   // against the fp64 oracle).  Those layers run the three-way split (fp32-level products).
   bool precise_layers = false;
+  // Weight gradients of the TANGENT pass (fused tangent chains): rows are tangents - no bias gradients -, the f16 X operand carries
+  // t.tan_x_scale and the f16 g a scale picked on the device (tan_slot: {amax, scale, 1 / scale, 1 / (scale * tan_x_scale)})
+  bool tan = false;
+  const float* tan_slot = nullptr;
   // Every dense layer of the step runs on the hand-written MFMA kernels of train_gemm.hip.  A shape they do not cover is an
   // error (NERFDS_ENOTSUP from the step), never a detour through a library GEMM.
   std::string unsupported_what;
@@ -295,6 +321,11 @@ struct Run {
     A.dy_half = dy_half ? 1 : 0;
     A.out_scale = dy_half ? 1.f / t.g_scale : 1.f;
     A.colsum = rep(bias_grad);
+    if (tan) {
+      A.colsum = nullptr;
+      if (dy_half) { A.out_scale = 1.f; A.out_scale_dev = tan_slot + (x_half ? 3 : 2); }      // g scaled on the device; X scaled only when it is a stored f16 tangent
+      else A.out_scale = x_half ? 1.f / t.tan_x_scale : 1.f;                                      // a head: fp32 cotangent, f16 tangent
+    }
     if (!(wgrad_supported(A) && wgrad(wgrad_stream(), A, wgrad_grid(A, t.num_cus)))) unsupported("weight gradient", K, N, M);
   }
   // fork(): the side streams wait for everything issued to st so far, and the weight-gradient launches that follow rotate over
@@ -329,9 +360,10 @@ struct Run {
       WgradArgs A{reinterpret_cast<const float*>(h16[0]), m.width, m.width, g[1], m.width, m.width, M, nullptr, rep(t.grad + m.hidden[1].w),
                   static_cast<const char*>(t.wpack) + WPACK_BYTES, 0, 0, t.P, nrep()};
       A.x_half = 1; A.dy_half = 1; A.out_scale = 1.f / t.g_scale; A.colsum = rep(t.grad + m.hidden[1].b);
+      if (tan) { A.out_scale = 1.f; A.out_scale_dev = tan_slot + 3; A.colsum = nullptr; }
       A.nl = m.depth - 1;
       for (int l = 1; l < m.depth; ++l) {
-        A.mx[l - 1] = h16[l - 1]; A.mdy[l - 1] = g[l]; A.mdw[l - 1] = rep(t.grad + m.hidden[l].w); A.mcs[l - 1] = rep(t.grad + m.hidden[l].b);
+        A.mx[l - 1] = h16[l - 1]; A.mdy[l - 1] = g[l]; A.mdw[l - 1] = rep(t.grad + m.hidden[l].w); A.mcs[l - 1] = tan ? nullptr : rep(t.grad + m.hidden[l].b);
       }
       if (wgrad_supported(A) && wgrad_multi_supported(A)) {
         if (!wgrad(wgrad_stream(), A, wgrad_grid(A, t.num_cus))) unsupported("weight gradient (layers batched)", m.width, m.width, M);
@@ -496,7 +528,8 @@ bool ensure_tangent_ws(nerfds_trainer& t) {
   size_t need = 0;
   std::vector<std::pair<float**, size_t>> views;
   auto take = [&](float** p, size_t n) { views.push_back({p, n}); need += (n + 63) & ~(size_t)63; };
-  take(&t.t_warp_in, M3 * D.warp_ld); take(&t.t_hyper_in, M3 * D.hyper_ld); take(&t.tA, M3 * TW); take(&t.tB, M3 * TW);
+  take(&t.t_warp_in, M3 * D.warp_ld); take(&t.t_hyper_in, M3 * D.hyper_ld);
+  if (!t.fused_tan) { take(&t.tA, M3 * TW); take(&t.tB, M3 * TW); }      // ping-pong rows of the layer-by-layer tangent pass
   take(&t.t_wv, M3 * 6); take(&t.t_xw, M3 * 3); take(&t.t_wamb, M3 * 2); take(&t.t_tin, M3 * D.trunk_in); take(&t.t_alpha, M3 * 4);
   take(&t.tn[0], R * Nc * 3); take(&t.tn[1], R * S * 3);
   if (hipMalloc(&t.tws, need * sizeof(float)) != hipSuccess) return false;
@@ -512,9 +545,11 @@ bool ensure_norm_ws(nerfds_trainer& t) {
   size_t need = 0;
   std::vector<std::pair<float**, size_t>> views;
   auto take = [&](float** p, size_t n) { views.push_back({p, n}); need += (n + 63) & ~(size_t)63; };
-  t.tw_h.assign(t.warp.depth, nullptr); for (auto& p : t.tw_h) take(&p, M3 * t.warp.width);
-  t.th_h.assign(t.hyper.depth, nullptr); for (auto& p : t.th_h) take(&p, M3 * t.hyper.width);
-  t.tt_h.assign(t.trunk[0].depth, nullptr); for (auto& p : t.tt_h) take(&p, M3 * t.trunk[0].width);
+  if (!t.fused_tan) {      // (the fused tangent pass keeps the hidden tangents as f16: ensure_tan16)
+    t.tw_h.assign(t.warp.depth, nullptr); for (auto& p : t.tw_h) take(&p, M3 * t.warp.width);
+    t.th_h.assign(t.hyper.depth, nullptr); for (auto& p : t.th_h) take(&p, M3 * t.hyper.width);
+    t.tt_h.assign(t.trunk[0].depth, nullptr); for (auto& p : t.tt_h) take(&p, M3 * t.trunk[0].width);
+  }
   take(&t.d_t_alpha, M3 * 4); take(&t.d_t_tin, M3 * D.trunk_in); take(&t.d_t_xw, M3 * 3); take(&t.d_t_wamb, M3 * 2); take(&t.d_t_wv, M3 * 6);
   take(&t.du, M * 3); take(&t.ghat, M * 3); take(&t.dwamb_extra, M * 2); take(&t.dwv_extra, M * 6);
   if (hipMalloc(&t.nws, need * sizeof(float)) != hipSuccess) return false;
@@ -522,6 +557,8 @@ bool ensure_norm_ws(nerfds_trainer& t) {
   for (auto& v : views) { *v.first = base; base += (v.second + 63) & ~(size_t)63; }
   return true;
 }
+
+void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* t_in, int ld_in, float* t_head, int ld_head);
 
 // d sigma_raw / d x by forward-mode tangents through warp MLP -> exp_se3, hyper sheet, posenc, trunk, alpha head
 // (the mask is a constant input, models.py:1035-1069), then target_norm (models.py:1077, 1273-1277, 1328).  Uses the
@@ -531,6 +568,19 @@ void sigma_gradient(nerfds_trainer& t, Run& r, int level, const Windows& W) {
   hipStream_t st = r.st;
   const int64_t M = r.M;
   encode_tangents(st, D, M, t.x, W, t.t_warp_in, t.t_hyper_in);
+  if (t.fused_tan && t.half_step) {
+    // ONE launch per network (train_bwd_kernel.hip train_tangent_kernel): the three tangents of a sample as three rows of a masked linear chain in
+    // split bf16, masks = the primal layers' stored ReLU bits, hidden tangents to HBM once as scaled f16 (what the tangent pass's weight gradients
+    // read), between the networks the element-wise tangent kernels as before.  (Through round 4: 42 + 30 layer launches per level on fp32 rows.)
+    fused_tangent(t, st, 2, level, 3 * M, t.t_warp_in, D.warp_ld, t.t_wv, 6);
+    se3_jvp(st, M, t.wv, t.x, t.t_wv, t.t_xw);
+    if (t.tangents_warp_only) return;
+    fused_tangent(t, st, 1, level, 3 * M, t.t_hyper_in, D.hyper_ld, t.t_wamb, 2);
+    trunk_in_jvp(st, D, M, t.xw, t.wamb, t.t_xw, t.t_wamb, W, t.t_tin);
+    fused_tangent(t, st, 4, level, 3 * M, t.t_tin, D.trunk_in, t.t_alpha, 4);
+    target_norm(st, M, t.t_alpha, t.wv, t.tn[level]);
+    return;
+  }
   const bool keep = t.nws != nullptr && t.keep_tangents;
   r.precise_layers = true;       // as the primal warp field: its tangent goes through the 2^7-frequency posenc
   float* tw = r.mlp_jvp(t.warp, t.t_warp_in, t.warp_h, t.tA, t.tB, keep ? &t.tw_h : nullptr);
@@ -712,6 +762,77 @@ bool build_fused_backward(nerfds_trainer& t) {
       return false;
     t.bfrags[which] = (int)(wb / 2048);
   }
+  // ---- the tangent pass of the second-order terms (graphs.h TanNet / BwdTrunkAlpha): forward-orientation maps of trunk + alpha head (per level),
+  // hyper sheet, warp field; the reversed trunk behind its alpha head alone (per level) ----
+  static const bool tan_on = !(getenv("NERFDS_TRAIN_FUSED_TAN") && std::string(getenv("NERFDS_TRAIN_FUSED_TAN")) == "0");
+  if (tan_on) {
+    auto upload = [&](const std::vector<uint8_t>& w, int** map_dev, void** stream_dev, int* frags_out) {
+      std::vector<int> map(w.size() / 4);
+      const float* wf = reinterpret_cast<const float*>(w.data());
+      for (size_t i = 0; i < map.size(); ++i) map[i] = (int)wf[i];
+      if (hipMalloc(map_dev, map.size() * 4) != hipSuccess || hipMalloc(stream_dev, w.size()) != hipSuccess ||
+          hipMemcpy(*map_dev, map.data(), map.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return false;
+      *frags_out = (int)(w.size() / 2048);
+      return true;
+    };
+    auto head_layer = [&](std::function<float(int, int)> Wf, int width, int n_out) {
+      nerfds::Layer L = layer(std::move(Wf), {tile_seg(width)}, 1, n_out);
+      L.is_head = true;
+      return L;
+    };
+    // a modules.MLP in forward orientation (pack.h emit_mlp with index values): W(r, c) = kernel[r][c]
+    auto emit_fwd = [&](nerfds::StreamWriter& sw, const MlpP& m) {
+      const int W = m.width, kc = nerfds::chunks(m.in_dim);
+      auto raw_seg = [&](int row0) { std::vector<int> r; nerfds::rows_linear(r, kc, [&](int sl) { return sl < m.in_dim ? row0 + sl : -1; }); return nerfds::Seg{std::move(r), nerfds::P_F32}; };
+      for (int l = 0; l < m.depth; ++l) {
+        const int64_t w = m.hidden[l].w;
+        std::vector<nerfds::Seg> segs;
+        if (l == 0) segs.push_back(raw_seg(0));
+        else {
+          segs.push_back(tile_seg(W));
+          if (l == m.skip) segs.push_back(raw_seg(W));
+        }
+        sw.emit(layer([=](int r, int c) { return idx(w + (int64_t)r * W + c); }, std::move(segs), W / 32, W));
+      }
+    };
+    for (int which = 0; which < 4; ++which) {
+      if (which == 1 && levels < 2) continue;
+      const MlpP* m = which <= 1 ? &t.trunk[which] : (which == 2 ? &t.hyper : &t.warp);
+      const int frags = which <= 1 ? nerfds::TanTrunk<G>::BWD_FRAGS : (which == 2 ? nerfds::TanHyper<G>::BWD_FRAGS : nerfds::TanWarp<G>::BWD_FRAGS);
+      const int in_dim_k = which <= 1 ? nerfds::TanTrunk<G>::IN_DIM : (which == 2 ? nerfds::TanHyper<G>::IN_DIM : nerfds::TanWarp<G>::IN_DIM);
+      if (m->skip != 4 || (m->depth != 8 && m->depth != 6) || m->in_dim != in_dim_k) return false;
+      std::vector<uint8_t> w((size_t)nerfds::pad_units(2 * frags) * 1024, 0);
+      nerfds::StreamWriter sw{w.data(), nullptr};
+      emit_fwd(sw, *m);
+      const int W = m->width;
+      if (which <= 1) {
+        const int64_t al = t.alpha[which].w;
+        sw.emit(head_layer([=](int r, int c) { return idx(al + (int64_t)r * 4 + c); }, W, 4));                                  // t_alpha = t_h7 W_alpha
+      } else if (which == 2) {
+        const int64_t ho = t.hyper_out.w;
+        sw.emit(head_layer([=](int r, int c) { return idx(ho + (int64_t)r * 2 + c); }, W, 2));
+      } else {
+        const int64_t ww = t.warp_w.w, wv = t.warp_v.w;
+        sw.emit(head_layer([=](int r, int c) { return c < 3 ? idx(ww + (int64_t)r * 3 + c) : idx(wv + (int64_t)r * 3 + (c - 3)); }, W, 6));   // [w | v] (warping.py:217-218)
+      }
+      if ((int64_t)sw.wbytes != (int64_t)frags * 2048) return false;
+      if (!upload(w, &t.tmap[which], &t.tstream[which], &t.tfrags[which])) return false;
+    }
+    for (int lv = 0; lv < levels; ++lv) {
+      const MlpP& m = t.trunk[lv];
+      const int frags = nerfds::BwdTrunkAlpha<G>::BWD_FRAGS;
+      std::vector<uint8_t> w((size_t)nerfds::pad_units(2 * frags) * 1024, 0);
+      nerfds::StreamWriter sw{w.data(), nullptr};
+      const int64_t al = t.alpha[lv].w;
+      sw.emit(layer([=](int j, int k) { return idx(al + (int64_t)k * 4 + j); }, {lin_seg(0, 4)}, m.width / 32, m.width));          // g_7 <- W_alpha d t_alpha
+      emit_trunk(sw, m);
+      if ((int64_t)sw.wbytes != (int64_t)frags * 2048) return false;
+      if (!upload(w, &t.amap[lv], &t.astream[lv], &t.afrags[lv])) return false;
+    }
+    if (hipMalloc(&t.tan_slot, 16 * sizeof(float)) != hipSuccess) return false;
+    t.fused_tan = true;
+  }
   // f16 activations + ReLU bits of every hidden layer (one allocation), the sink of the input-gradient stores
   const int64_t M = t.max_rays * (t.cfg.num_coarse_samples + t.cfg.num_fine_samples);
   size_t need = 0;
@@ -737,6 +858,71 @@ bool build_fused_backward(nerfds_trainer& t) {
 void pack_fused_backward(nerfds_trainer& t, hipStream_t st) {
   for (int which = 0; which < 5; ++which)
     if (t.bmap[which]) pack_stream(st, t.theta, t.fold, t.P, t.bmap[which], t.bstream[which], t.bfrags[which], 0, 0);
+}
+
+// the streams of the tangent pass from the current parameters (steps that run tangents only)
+void pack_fused_tangents(nerfds_trainer& t, hipStream_t st) {
+  for (int which = 0; which < 4; ++which)
+    if (t.tmap[which]) pack_stream(st, t.theta, t.fold, t.P, t.tmap[which], t.tstream[which], t.tfrags[which], 0, 0);
+  for (int lv = 0; lv < 2; ++lv)
+    if (t.amap[lv]) pack_stream(st, t.theta, t.fold, t.P, t.amap[lv], t.astream[lv], t.afrags[lv], 0, 0);
+}
+// f16 [3 M][width] per hidden layer of warp field, hyper sheet, trunk: the tangents (ensure_tan16: `all` = one array per layer - a step that
+// differentiates the tangent pass reads them as X of its weight gradients; otherwise ONE array per network that every layer overwrites: the
+// chain stores unconditionally, and nobody reads) and their cotangents (ensure_tan16_g)
+static bool carve16(nerfds_trainer& t, uint16_t** base_out, std::vector<uint16_t*>& w, std::vector<uint16_t*>& h, std::vector<uint16_t*>& tr, bool all) {
+  const int64_t M3 = 3 * t.max_rays * (t.cfg.num_coarse_samples + t.cfg.num_fine_samples);
+  size_t need = 0;
+  std::vector<std::pair<uint16_t**, size_t>> views;
+  auto take = [&](uint16_t** p, size_t n) { views.push_back({p, n}); need += (n + 127) & ~(size_t)127; };
+  auto net = [&](std::vector<uint16_t*>& v, int depth, int width) {
+    v.assign(depth, nullptr);
+    for (int l = 0; l < (all ? depth : 1); ++l) take(&v[l], (size_t)M3 * width);
+  };
+  net(w, t.warp.depth, t.warp.width); net(h, t.hyper.depth, t.hyper.width); net(tr, t.trunk[0].depth, t.trunk[0].width);
+  if (hipMalloc(base_out, need * sizeof(uint16_t)) != hipSuccess) return false;
+  uint16_t* base = *base_out;
+  for (auto& v : views) { *v.first = base; base += (v.second + 127) & ~(size_t)127; }
+  if (!all) for (auto* v : {&w, &h, &tr}) for (size_t l = 1; l < v->size(); ++l) (*v)[l] = (*v)[0];
+  return true;
+}
+bool ensure_tan16(nerfds_trainer& t, bool all) {
+  if (t.tws16 && (!all || t.tw16.size() < 2 || t.tw16[1] != t.tw16[0])) return true;
+  if (t.tws16) { (void)hipDeviceSynchronize(); (void)hipFree(t.tws16); t.tws16 = nullptr; }      // grown from the aliased form to one array per layer
+  return carve16(t, &t.tws16, t.tw16, t.th16, t.tt16, all);
+}
+bool ensure_tan16_g(nerfds_trainer& t) {
+  if (t.gws16) return true;
+  return carve16(t, &t.gws16, t.gw16, t.gh16, t.gt16, true);
+}
+// tangent FORWARD chain of net 1 hyper sheet, 2 warp field, 4 trunk + alpha head of `level`: t_in [3 M][ld_in] -> t_head [3 M][ld_head], hidden tangents -> store16
+void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* t_in, int ld_in, float* t_head, int ld_head) {
+  nerfds::TrainBwd tb{};
+  tb.M = M3; tb.d_head = t_in; tb.ld_head = ld_in; tb.d_in = t_head; tb.ld_in = ld_head; tb.sink = t.sink;
+  tb.g_half = 1; tb.g_scale = t.tan_x_scale; tb.g_inv_scale = 1.f / t.tan_x_scale; tb.mask_div = 3;
+  const std::vector<uint16_t*>* bits = nullptr;
+  const std::vector<uint16_t*>* store = nullptr;
+  if (net == 1) { tb.wstream = t.tstream[2]; bits = &t.hyper_bits; store = &t.th16; }
+  else if (net == 2) { tb.wstream = t.tstream[3]; bits = &t.warp_bits; store = &t.tw16; }
+  else { tb.wstream = t.tstream[level]; bits = &t.trunk_bits; store = &t.tt16; }
+  for (size_t l = 0; l < bits->size(); ++l) { tb.bits[l] = (*bits)[l]; tb.g[l] = reinterpret_cast<float*>((*store)[l]); }
+  nerfds_launch_train_tan16_nerfds(tb, net, t.num_cus, st);
+}
+// data-gradient chain of the TANGENT pass: cotangent of the head's tangent [3 M][ld_head] (its scale picked on the device: slot) -> g of every hidden
+// tangent (f16, store16) and, if d_in, the cotangent of the raw tangent input [3 M][ld_in]
+void fused_tangent_backward(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* d_head, int ld_head, float* d_in, int ld_in,
+                            const float* slot) {
+  nerfds::TrainBwd tb{};
+  tb.M = M3; tb.d_head = d_head; tb.ld_head = ld_head; tb.sink = t.sink;
+  tb.d_in = d_in ? d_in : t.sink; tb.ld_in = d_in ? ld_in : 0;            // ld_in 0: every input-gradient store goes to the sink (no parameters behind t_in)
+  tb.g_half = 1; tb.g_scale = 1.f; tb.g_inv_scale = 1.f; tb.scale_dev = slot + 1; tb.mask_div = 3;
+  const std::vector<uint16_t*>* bits = nullptr;
+  const std::vector<uint16_t*>* store = nullptr;
+  if (net == 1) { tb.wstream = t.bstream[2]; bits = &t.hyper_bits; store = &t.gh16; }
+  else if (net == 2) { tb.wstream = t.bstream[3]; bits = &t.warp_bits; store = &t.gw16; }
+  else { tb.wstream = t.astream[level]; bits = &t.trunk_bits; store = &t.gt16; }
+  for (size_t l = 0; l < bits->size(); ++l) { tb.bits[l] = (*bits)[l]; tb.g[l] = reinterpret_cast<float*>((*store)[l]); }
+  nerfds_launch_train_bwd16_nerfds(tb, net, t.num_cus, st);
 }
 
 // the data-gradient chain of one network: net 0 NerfMLP of `level`, 1 hyper sheet, 2 warp field, 3 mask net
@@ -971,7 +1157,7 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
     return NERFDS_OK;
   }
   if (want_sigma_gradient) {
-    if (t.half_step) {      // the tangent pass reads the primal layers' ReLU masks as fp32 arrays: the f16 activations, widened (their sign is all it uses)
+    if (t.half_step && !t.fused_tan) {      // the layer-by-layer tangent pass reads the primal layers' ReLU masks as fp32 arrays: the f16 activations, widened (their sign is all it uses)
       for (int l = 0; l < t.warp.depth; ++l) expand_half(st, t.warp_h16[l], t.warp_h[l], M * t.warp.width);
       if (!t.tangents_warp_only) {
         for (int l = 0; l < t.hyper.depth; ++l) expand_half(st, t.hyper_h16[l], t.hyper_h[l], M * t.hyper.width);
@@ -1003,7 +1189,46 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
   // Backward of the tangent pass (second order: norm loss, elastic regulariser), BEFORE the primal backward: it reads the primal layers' ReLU masks in
   // the fp32 activation arrays - which the half step's chains are about to overwrite with g - and leaves what the primal backward adds to its
   // own upstream gradients: dxw_reg / dwamb_extra (second-derivative terms of the encodings) and dwv_extra (of exp_se3).
-  if (so) {
+  if (so && t.fused_tan && t.half_step) {
+    // Fused: the backward of a tangent chain is the network's data-gradient chain on the tangent rows (train_bwd_kernel.hip: masks of row r / 3, the
+    // cotangent's loss scale picked on the device), and its weight gradients are k_wgrad_tr products of the stored f16 tangents with the chain's f16 g -
+    // the primal step's kernels, three rows per sample, no bias terms.
+    Run rt{t, st, 3 * M};
+    rt.tan = true;
+    auto as_f = [](const std::vector<uint16_t*>& v) { std::vector<float*> o; for (auto* p : v) o.push_back(reinterpret_cast<float*>(p)); return o; };
+    const std::vector<float*> gt = as_f(t.gt16), gh = as_f(t.gh16), gw = as_f(t.gw16);
+    const float target = 5.f;                 // the largest cotangent lands at 2^5: 2^11 of headroom below f16's largest value for what the layers amplify (as g_scale)
+    if (nl) {   // part 1: alpha head, trunk, trunk input (adds second-derivative terms to d x', d w)
+      pick_scale(st, t.d_t_alpha, 3 * M * 4, target, t.tan_x_scale, t.tan_slot);
+      rt.tan_slot = t.tan_slot;
+      fused_tangent_backward(t, st, 4, level, 3 * M, t.d_t_alpha, 4, t.d_t_tin, D.trunk_in, t.tan_slot);
+      rt.fork(false);
+      rt.head_wgrads(t.alpha[level], t.tt16.back(), trunk.width, t.d_t_alpha, 4);
+      rt.mlp_wgrads(trunk, t.t_tin, t.tt16, gt);
+      trunk_in_jvp_bwd(st, D, M, t.d_t_tin, t.xw, t.wamb, t.t_xw, t.t_wamb, W, t.d_t_xw, t.d_t_wamb, t.dxw_reg, t.dwamb_extra);
+      if (hreg) add_inplace(st, t.dwamb_extra, t.dwamb_reg, 2 * M);
+    }
+    if (el) elastic_loss(st, R, S, ob->elastic_weight, ob->elastic_by_weight, weights_out, t.t_xw, t.terms_dev + 12, t.d_t_xw);
+    if (nl) {   // part 2: hyper sheet tangents
+      pick_scale(st, t.d_t_wamb, 3 * M * 2, target, t.tan_x_scale, t.tan_slot + 4);
+      rt.tan_slot = t.tan_slot + 4;
+      fused_tangent_backward(t, st, 1, level, 3 * M, t.d_t_wamb, 2, nullptr, 0, t.tan_slot + 4);
+      rt.fork(false);
+      rt.head_wgrads(t.hyper_out, t.th16.back(), t.hyper.width, t.d_t_wamb, 2);
+      rt.mlp_wgrads(t.hyper, t.t_hyper_in, t.th16, gh);
+    }
+    // part 3: exp_se3 tangents (second derivatives) and the warp net's tangents
+    se3_jvp_bwd(st, M, t.wv, t.x, t.t_wv, t.d_t_xw, t.du, t.ghat, t.d_t_wv, t.dwv_extra);
+    pick_scale(st, t.d_t_wv, 3 * M * 6, target, t.tan_x_scale, t.tan_slot + 8);
+    rt.tan_slot = t.tan_slot + 8;
+    fused_tangent_backward(t, st, 2, level, 3 * M, t.d_t_wv, 6, nullptr, 0, t.tan_slot + 8);
+    rt.fork(false);
+    rt.head_wgrads(t.warp_w, t.tw16.back(), t.warp.width, t.d_t_wv, 6);
+    rt.head_wgrads(t.warp_v, t.tw16.back(), t.warp.width, t.d_t_wv + 3, 6);
+    rt.mlp_wgrads(t.warp, t.t_warp_in, t.tw16, gw);
+    rt.wg_turn = -1;                          // (the side streams are joined with the primal backward's, below)
+    if (!rt.ok) return t.fail(NERFDS_ENOTSUP, "%s", rt.unsupported_what.c_str());
+  } else if (so) {
     const float* tout_m = t.trunk_h.back();
     bool pm2;
     if (nl) {   // part 1: alpha head, trunk, trunk input (adds second-derivative terms to d x', d w)
@@ -1483,6 +1708,12 @@ static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* ta
   t->keep_tangents = norm_weight != 0.f || elastic;
   if ((norm_weight != 0.f || elastic) && (!ensure_tangent_ws(*t) || !ensure_norm_ws(*t))) return t->fail(NERFDS_ENOMEM, "hipMalloc of the norm-loss workspace failed");
   if (want_sg && !ensure_tangent_ws(*t)) return t->fail(NERFDS_ENOMEM, "hipMalloc of the tangent workspace failed");
+  if (want_sg && t->fused_tan && t->half_step) {
+    if (3LL * t->max_rays * (Nc + Nf) >= (1LL << 31)) return t->fail(NERFDS_EINVAL, "tangent rows are indexed in 31 bits: max_rays * samples * 3 is too large");
+    // the hidden tangents: one f16 array per layer when the step differentiates the tangent pass (its weight gradients read them), one per network otherwise
+    if (!ensure_tan16(*t, t->keep_tangents) || (t->keep_tangents && !ensure_tan16_g(*t))) return t->fail(NERFDS_ENOMEM, "hipMalloc of the f16 tangent workspace failed");
+    pack_fused_tangents(*t, st);
+  }
   // the elastic regulariser reads the tangents of the COARSE level only: without the norm loss (or the caller's flag) the fine level runs no tangent pass
   const bool want_sg_fine = (flags & NERFDS_TRAIN_SIGMA_GRAD) != 0 || norm_weight != 0.f;
   t->tn_valid = want_sg_fine;

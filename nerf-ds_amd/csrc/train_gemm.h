@@ -51,6 +51,9 @@ struct WgradArgs {
   float* colsum;
   // dy_half: what reaches dw / colsum is multiplied by out_scale (0 = 1): the chains write g times a power of two so that it fits f16.
   float out_scale;
+  // != nullptr: one more factor, read from DEVICE memory (the scale of a tangent cotangent array is picked on the device, train_kernels.hip
+  // pick_scale; slot[3] = 1 / (scale * x_scale)); applies to every kernel, fp32 dY included
+  const float* out_scale_dev;
   // nl > 1 (x_half and dy_half only): ONE launch computes nl weight gradients of the same shape and row count - the hidden layers of one MLP,
   // whose chain leaves all their g at once: workgroup b works on layer b % nl, as workgroup b / nl of gridDim / nl.  Layer i: X = mx[i],
   // dY = mdy[i] (ldx / ldy as above), destination mdw[i] / mcs[i] (replicas as above); x, dy, dw, colsum must equal entry 0.

@@ -705,7 +705,7 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
     }
   }
   wait_vm_lgkm0<0>();
-  const float osc = (DYH && A.out_scale != 0.f) ? A.out_scale : 1.f;       // f16 dY carries the chains' power-of-two scale
+  const float osc = ((DYH && A.out_scale != 0.f) ? A.out_scale : 1.f) * (A.out_scale_dev != nullptr ? *A.out_scale_dev : 1.f);       // f16 dY carries the chains' power-of-two scale
   if (A.colsum != nullptr) {           // bias gradient: each dY item adds its 8-sample sums (two items per feature and workgroup)
     float* cdst = A.colsum + (A.nrep > 1 ? (size_t)(blockIdx.x % A.nrep) * A.rep_stride : 0);
 #pragma unroll
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(512) void k_wgrad_tr(const WgradArgs A) {
     st = st + 1 == S::NS ? 0 : st + 1;
   }
   wait_vm_lgkm0<0>();
-  const float osc = A.out_scale != 0.f ? A.out_scale : 1.f;
+  const float osc = (A.out_scale != 0.f ? A.out_scale : 1.f) * (A.out_scale_dev != nullptr ? *A.out_scale_dev : 1.f);
   const size_t rep = A.nrep > 1 ? (size_t)(wg % A.nrep) * A.rep_stride : 0;
   const int m = lane & 31, h = lane >> 5;
   if (sums) {
@@ -971,8 +971,10 @@ __global__ __launch_bounds__(256) void k_wgrad_head(const WgradArgs A) {
   }
   __syncthreads();
   const size_t rep = A.nrep > 1 ? (size_t)(blockIdx.x % A.nrep) * A.rep_stride : 0;
+  // (X may carry a power-of-two scale - the stored f16 tangents of the second-order terms: out_scale / out_scale_dev undo it)
+  const float osc = (A.out_scale != 0.f ? A.out_scale : 1.f) * (A.out_scale_dev != nullptr ? *A.out_scale_dev : 1.f);
   for (int e = threadIdx.x; e < K * N; e += 256)
-    unsafeAtomicAdd(A.dw + rep + e, (sm[e] + sm[(K * N + N) + e]) + (sm[2 * (K * N + N) + e] + sm[3 * (K * N + N) + e]));
+    unsafeAtomicAdd(A.dw + rep + e, osc * ((sm[e] + sm[(K * N + N) + e]) + (sm[2 * (K * N + N) + e] + sm[3 * (K * N + N) + e])));
   if (A.colsum != nullptr && threadIdx.x < N)
     unsafeAtomicAdd(A.colsum + rep + threadIdx.x, (float)((scs[0][threadIdx.x] + scs[1][threadIdx.x]) + (scs[2][threadIdx.x] + scs[3][threadIdx.x])));
 }

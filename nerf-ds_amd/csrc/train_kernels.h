@@ -49,6 +49,8 @@ void aux_losses(hipStream_t, int R, int S, const Objective&, const float* z, con
                 const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg, float* d_alpha, float* d_pm,
                 const float* wamb = nullptr, float* term_hyper = nullptr, float* dwamb_reg = nullptr, float* term_occlusion = nullptr);   // hyper-point regulariser: ambient coordinates in, its term and d / d wamb out
 void add_inplace(hipStream_t, float* dst, const float* src, long long n);
+// slot[4] (device) <- {amax bits of x[0..n), 2^(target_log2 - floor(log2 amax)), its inverse, 1 / (scale * x_scale)}
+void pick_scale(hipStream_t, const float* x, long long n, float target_log2, float x_scale, float* slot);
 void expand_half(hipStream_t, const uint16_t* h16, float* out, long long n);      // out[i] = float(f16 h16[i]); n a multiple of 8, both 16-byte aligned
 // background regulariser (training.py:159-183): term += weight * mean_i general_loss(|xw_i - x_i|^2, alpha, scale); dxw = its gradient w.r.t. xw
 // elastic regulariser (training.py:112-156 'log_svals', 274-295): t_xw = the tangents of the warped point, row 3 m + j = d x' / d x_j (the Jacobian's

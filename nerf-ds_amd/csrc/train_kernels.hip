@@ -1095,6 +1095,37 @@ __global__ void k_expand_half(const uint16_t* __restrict__ h, float* __restrict_
   *reinterpret_cast<float4*>(out + 8 * i) = a;
   *reinterpret_cast<float4*>(out + 8 * i + 4) = b;
 }
+// Loss scale of a tangent cotangent array, picked ON THE DEVICE (no host round trip in the middle of a step): slot = {amax bits, scale, 1 / scale,
+// extra} with scale = 2^(target_log2 - floor(log2 amax)) - the cotangents of the tangent pass (norm loss, elastic regulariser) have no a-priori
+// size the way the rgb loss's 2 / (3 R) has (nerfds_train.cpp g_scale).  amax == 0 or not finite: scale 1 (a non-finite cotangent reaches the
+// gradient check of the update as it is).  slot[3] = 1 / (scale * x_scale): what the weight-gradient kernels multiply with when their X operand
+// carries x_scale (WgradArgs::out_scale_dev).
+__global__ void k_amax(const float* __restrict__ x, long long n, unsigned* __restrict__ slot) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  float a = i < n ? fabsf(x[i]) : 0.f;
+  if (!(a == a)) a = __uint_as_float(0x7f800000u);                       // NaN counts as inf
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) a = fmaxf(a, __shfl_xor(a, d, 64));
+  if ((threadIdx.x & 63) == 0 && a > 0.f) atomicMax(slot, __float_as_uint(a));     // non-negative floats order like their bits
+}
+__global__ void k_pick_scale(float* __restrict__ slot, float target_log2, float x_scale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float a = slot[0];
+  float sc = 1.f;
+  if (a > 0.f && a < 3.0e38f) {
+    int e;
+    (void)frexpf(a, &e);                                                   // a = m 2^e, m in [0.5, 1)
+    float k = target_log2 - (float)(e - 1);
+    k = fminf(fmaxf(k, -60.f), 60.f);
+    sc = exp2f(k);
+  }
+  slot[1] = sc; slot[2] = 1.f / sc; slot[3] = 1.f / (sc * x_scale);
+}
+void pick_scale(hipStream_t st, const float* x, long long n, float target_log2, float x_scale, float* slot) {
+  (void)hipMemsetAsync(slot, 0, 4 * sizeof(float), st);
+  LAUNCH(k_amax, n, st, x, n, reinterpret_cast<unsigned*>(slot));
+  hipLaunchKernelGGL(k_pick_scale, dim3(1), dim3(1), 0, st, slot, target_log2, x_scale);
+}
 void expand_half(hipStream_t st, const uint16_t* h16, float* out, long long n) { LAUNCH(k_expand_half, n / 8, st, h16, out, n / 8); }
 // Singular values / vectors of a 3 x 3 matrix through the eigen-decomposition of J^T J (cyclic Jacobi in double: the warp Jacobian is close to a
 // rotation, its singular values close to each other - any basis of a (near-)degenerate eigenspace gives the same sum over i of f'(s_i) u_i v_i^T).
