@@ -372,19 +372,25 @@ __global__ void k_alpha_post(Dims D, int R, int S, const float* __restrict__ alp
 // ---- sigma gradient (models.py:1035-1077): forward-mode tangents of sigma_raw w.r.t. the observation-space
 // point, 3 directions per sample, tangent row 3 m + j <-> d / d x_j.  The mask is a constant input (cal_single_pt_sigma takes
 // it as an argument), the GLO columns have zero tangents.
+// (one thread per (sample, column) of the wider of the two inputs: one cosf per feature for the three rows, coalesced stores)
 __global__ void k_encode_tangents(Dims D, long long M, const float* __restrict__ x, Windows W, float* __restrict__ t_warp_in,
                                   float* __restrict__ t_hyper_in) {
+  const int LD = D.warp_ld > D.hyper_ld ? D.warp_ld : D.hyper_ld;
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (i >= 3 * M) return;
-  const long long m = i / 3;
-  const int j = (int)(i % 3);
+  if (i >= M * LD) return;
+  const long long m = i / LD;
+  const int g = (int)(i - m * LD);
   const float p[3] = {x[3 * m], x[3 * m + 1], x[3 * m + 2]};
-  float* tw = t_warp_in + i * D.warp_ld;
-  for (int g = D.warp_in; g < D.warp_ld; ++g) tw[g] = 0.f;
-  for (int g = 0; g < D.warp_in; ++g) tw[g] = (g < 6 * D.warp_bands && g % 3 == j) ? posenc_dval<3>(g, p, W.warp) : 0.f;
-  float* th = t_hyper_in + i * D.hyper_ld;
-  for (int g = D.hyper_in; g < D.hyper_ld; ++g) th[g] = 0.f;
-  for (int g = 0; g < D.hyper_in; ++g) th[g] = (g < 6 * D.hyp_bands && g % 3 == j) ? posenc_dval<3>(g, p, W.hyp) : 0.f;
+  if (g < D.warp_ld) {
+    const float dv = (g < 6 * D.warp_bands) ? posenc_dval<3>(g, p, W.warp) : 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t_warp_in[(3 * m + j) * D.warp_ld + g] = (g < 6 * D.warp_bands && g % 3 == j) ? dv : 0.f;
+  }
+  if (g < D.hyper_ld) {
+    const float dv = (g < 6 * D.hyp_bands) ? posenc_dval<3>(g, p, W.hyp) : 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t_hyper_in[(3 * m + j) * D.hyper_ld + g] = (g < 6 * D.hyp_bands && g % 3 == j) ? dv : 0.f;
+  }
 }
 // tangent through a ReLU: t[3 m + j][n] = 0 where y[m][n] <= 0
 __global__ void k_relu_mask3(float* __restrict__ t, const float* __restrict__ y, long long M, int N) {
@@ -413,15 +419,29 @@ __global__ __launch_bounds__(256) void k_se3_jvp(long long M, const float* __res
     }
   }
 }
+// One thread per (sample, feature): the derivative factor of a feature - one cosf - serves the sample's three tangent rows, and consecutive threads
+// write consecutive floats of a row.  (Through round 4: one thread per tangent ROW, 52 cosf each and every store instruction 64 rows apart: 0.75 ms
+// per launch on 524 288 samples where the bytes take 0.1.)  Same arithmetic per element, same bits.
 __global__ void k_trunk_in_jvp(Dims D, long long M, const float* __restrict__ xw, const float* __restrict__ wamb, const float* __restrict__ t_xw,
                                const float* __restrict__ t_wamb, Windows W, float* __restrict__ t_tin) {
+  const int TI = D.trunk_in, NS = 6 * D.sp_bands;
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (i >= 3 * M) return;
-  const long long m = i / 3;
-  const float p[3] = {xw[3 * m], xw[3 * m + 1], xw[3 * m + 2]}, a[2] = {wamb[2 * m], wamb[2 * m + 1]};
-  float* t = t_tin + i * D.trunk_in;
-  for (int g = 0; g < 6 * D.sp_bands; ++g) t[g] = posenc_dval<3>(g, p, W.sp) * t_xw[3 * i + g % 3];
-  for (int g = 0; g < 4 * D.hp_bands; ++g) t[6 * D.sp_bands + g] = posenc_dval<2>(g, a, W.hp) * t_wamb[2 * i + g % 2];
+  if (i >= M * TI) return;
+  const long long m = i / TI;
+  const int g = (int)(i - m * TI);
+  float dv;
+  int ch;
+  const float* tsrc;
+  int tld;
+  if (g < NS) {
+    const float p[3] = {xw[3 * m], xw[3 * m + 1], xw[3 * m + 2]};
+    dv = posenc_dval<3>(g, p, W.sp); ch = g % 3; tsrc = t_xw; tld = 3;
+  } else {
+    const float a[2] = {wamb[2 * m], wamb[2 * m + 1]};
+    dv = posenc_dval<2>(g - NS, a, W.hp); ch = (g - NS) % 2; tsrc = t_wamb; tld = 2;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) t_tin[(3 * m + j) * TI + g] = dv * tsrc[(3 * m + j) * tld + ch];
 }
 // sigma_gradient = normalize(-grad) (models.py:1069, 1077); target_norm = normalize(R sigma_gradient) ('warped', models.py:1273-1277)
 __global__ void k_target_norm(long long M, const float* __restrict__ t_alpha, const float* __restrict__ wv, float* __restrict__ target_norm) {
@@ -500,39 +520,39 @@ __global__ void k_norm_loss(int R, int S, float weight, const float* __restrict_
 
 // backward of k_trunk_in_jvp: d tangent(x'), d tangent(w), and - because the features' derivative factors depend on x' and w
 // themselves - second-derivative contributions to the PRIMAL gradients of x' and the ambient coordinates
+// One thread per (sample, channel) - three spatial channels, two ambient ones: the channel's 2 x bands features share their angles (sc = 1 is the
+// same angle + pi/2), so a thread evaluates cosf / sinf once per feature for the sample's THREE tangent rows.  (Through round 4: one thread per
+// sample looping over rows, channels and features - 2 x 52 x 3 libm calls - 0.8 ms per launch on 524 288 samples.)  Same arithmetic per term and
+// the same order of the sums over the features of a channel; the second-derivative terms are summed per row first, then over the three rows.
 __global__ void k_trunk_in_jvp_bwd(Dims D, long long M, const float* __restrict__ d_t_tin, const float* __restrict__ xw, const float* __restrict__ wamb,
                                    const float* __restrict__ t_xw, const float* __restrict__ t_wamb, Windows W, float* __restrict__ d_t_xw,
                                    float* __restrict__ d_t_wamb, float* __restrict__ dxw_extra, float* __restrict__ dwamb_extra) {
-  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (m >= M) return;
-  const float p[3] = {xw[3 * m], xw[3 * m + 1], xw[3 * m + 2]}, a[2] = {wamb[2 * m], wamb[2 * m + 1]};
-  float ex[3] = {0.f, 0.f, 0.f}, ea[2] = {0.f, 0.f};
-  for (int j = 0; j < 3; ++j) {
-    const long long i = 3 * m + j;
-    const float* dt = d_t_tin + i * D.trunk_in;
-    for (int c = 0; c < 3; ++c) {
-      float acc = 0.f;
-      for (int bs = 0; bs < 2 * D.sp_bands; ++bs) {
-        const int g = 3 * bs + c, band = g / 6, sc = (g % 6) / 3;
-        const float arg = p[c] * (float)(1 << band) + (sc ? 1.57079637f : 0.0f), sc2 = (float)(1 << band);
-        acc += dt[g] * W.sp[band] * sc2 * cosf(arg);
-        ex[c] += dt[g] * t_xw[3 * i + c] * (-W.sp[band] * sc2 * sc2 * sinf(arg));
-      }
-      d_t_xw[3 * i + c] = acc;
-    }
-    for (int c = 0; c < 2; ++c) {
-      float acc = 0.f;
-      for (int bs = 0; bs < 2 * D.hp_bands; ++bs) {
-        const int g = 2 * bs + c, band = g / 4, sc = (g % 4) / 2;
-        const float arg = a[c] * (float)(1 << band) + (sc ? 1.57079637f : 0.0f), sc2 = (float)(1 << band);
-        acc += dt[6 * D.sp_bands + g] * W.hp[band] * sc2 * cosf(arg);
-        ea[c] += dt[6 * D.sp_bands + g] * t_wamb[2 * i + c] * (-W.hp[band] * sc2 * sc2 * sinf(arg));
-      }
-      d_t_wamb[2 * i + c] = acc;
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= 5 * M) return;
+  const long long m = i / 5;
+  const int c5 = (int)(i - 5 * m);
+  const bool sp = c5 < 3;
+  const int c = sp ? c5 : c5 - 3, C = sp ? 3 : 2, nb = sp ? D.sp_bands : D.hp_bands, g0 = sp ? 0 : 6 * D.sp_bands;
+  const float pc = sp ? xw[3 * m + c] : wamb[2 * m + c];
+  const float* win = sp ? W.sp : W.hp;
+  const float* tt = sp ? t_xw : t_wamb;
+  float* dtt = sp ? d_t_xw : d_t_wamb;
+  float acc[3] = {0.f, 0.f, 0.f}, ex[3] = {0.f, 0.f, 0.f};
+  for (int bs = 0; bs < 2 * nb; ++bs) {
+    const int g = C * bs + c, band = g / (2 * C), sc = (g % (2 * C)) / C;
+    const float sc2 = (float)(1 << band), arg = pc * sc2 + (sc ? 1.57079637f : 0.0f);
+    const float fc = win[band] * sc2 * cosf(arg), fs = -win[band] * sc2 * sc2 * sinf(arg);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float dt = d_t_tin[(3 * m + j) * D.trunk_in + g0 + g];
+      acc[j] += dt * fc;
+      ex[j] += dt * tt[(3 * m + j) * C + c] * fs;
     }
   }
-  for (int c = 0; c < 3; ++c) dxw_extra[3 * m + c] += ex[c];
-  dwamb_extra[2 * m] = ea[0]; dwamb_extra[2 * m + 1] = ea[1];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) dtt[(3 * m + j) * C + c] = acc[j];
+  if (sp) dxw_extra[3 * m + c] += (ex[0] + ex[1]) + ex[2];
+  else dwamb_extra[2 * m + c] = (ex[0] + ex[1]) + ex[2];
 }
 
 // single-direction dual over any scalar T (float or Dual): the nested type D1<Dual> differentiates a directional derivative
@@ -1069,7 +1089,7 @@ void norm_loss(hipStream_t st, int R, int S, float weight, const float* weights,
 }
 void trunk_in_jvp_bwd(hipStream_t st, const Dims& D, long long M, const float* d_t_tin, const float* xw, const float* wamb, const float* t_xw,
                       const float* t_wamb, const Windows& W, float* d_t_xw, float* d_t_wamb, float* dxw_extra, float* dwamb_extra) {
-  LAUNCH(k_trunk_in_jvp_bwd, M, st, D, M, d_t_tin, xw, wamb, t_xw, t_wamb, W, d_t_xw, d_t_wamb, dxw_extra, dwamb_extra);
+  LAUNCH(k_trunk_in_jvp_bwd, 5 * M, st, D, M, d_t_tin, xw, wamb, t_xw, t_wamb, W, d_t_xw, d_t_wamb, dxw_extra, dwamb_extra);
 }
 void se3_jvp_bwd(hipStream_t st, long long M, const float* wv, const float* x, const float* t_wv, const float* d_t_xw, const float* du,
                  const float* ghat, float* d_t_wv, float* dwv_extra) {
@@ -1100,13 +1120,22 @@ __global__ void k_expand_half(const uint16_t* __restrict__ h, float* __restrict_
 // size the way the rgb loss's 2 / (3 R) has (nerfds_train.cpp g_scale).  amax == 0 or not finite: scale 1 (a non-finite cotangent reaches the
 // gradient check of the update as it is).  slot[3] = 1 / (scale * x_scale): what the weight-gradient kernels multiply with when their X operand
 // carries x_scale (WgradArgs::out_scale_dev).
-__global__ void k_amax(const float* __restrict__ x, long long n, unsigned* __restrict__ slot) {
-  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  float a = i < n ? fabsf(x[i]) : 0.f;
-  if (!(a == a)) a = __uint_as_float(0x7f800000u);                       // NaN counts as inf
+__global__ __launch_bounds__(256) void k_amax(const float* __restrict__ x, long long n, unsigned* __restrict__ slot) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = fabsf(x[i]);
+    if (!(v == v)) v = __uint_as_float(0x7f800000u);                     // NaN counts as inf
+    a = fmaxf(a, v);
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) a = fmaxf(a, __shfl_xor(a, d, 64));
-  if ((threadIdx.x & 63) == 0 && a > 0.f) atomicMax(slot, __float_as_uint(a));     // non-negative floats order like their bits
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (a > 0.f) atomicMax(slot, __float_as_uint(a));                    // non-negative floats order like their bits; one atomic per block
+  }
 }
 __global__ void k_pick_scale(float* __restrict__ slot, float target_log2, float x_scale) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1123,7 +1152,8 @@ __global__ void k_pick_scale(float* __restrict__ slot, float target_log2, float 
 }
 void pick_scale(hipStream_t st, const float* x, long long n, float target_log2, float x_scale, float* slot) {
   (void)hipMemsetAsync(slot, 0, 4 * sizeof(float), st);
-  LAUNCH(k_amax, n, st, x, n, reinterpret_cast<unsigned*>(slot));
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_amax, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(slot));
   hipLaunchKernelGGL(k_pick_scale, dim3(1), dim3(1), 0, st, slot, target_log2, x_scale);
 }
 void expand_half(hipStream_t st, const uint16_t* h16, float* out, long long n) { LAUNCH(k_expand_half, n / 8, st, h16, out, n / 8); }
@@ -1229,13 +1259,13 @@ void mask_in_bwd(hipStream_t st, const Dims& D, int R, int S, const float* d_mas
 void sum_partials(hipStream_t st, const float* part, int slabs, long long n, float* out) { LAUNCH(k_sum_partials, n, st, part, slabs, n, out); }
 void fill(hipStream_t st, float* p, long long n, float v) { LAUNCH(k_fill, n, st, p, n, v); }
 void encode_tangents(hipStream_t st, const Dims& D, long long M, const float* x, const Windows& W, float* t_warp_in, float* t_hyper_in) {
-  LAUNCH(k_encode_tangents, 3 * M, st, D, M, x, W, t_warp_in, t_hyper_in);
+  LAUNCH(k_encode_tangents, M * (D.warp_ld > D.hyper_ld ? D.warp_ld : D.hyper_ld), st, D, M, x, W, t_warp_in, t_hyper_in);
 }
 void relu_mask3(hipStream_t st, float* t, const float* y, long long M, int N) { LAUNCH(k_relu_mask3, 3 * M * N, st, t, y, M, N); }
 void se3_jvp(hipStream_t st, long long M, const float* wv, const float* x, const float* t_wv, float* t_xw) { LAUNCH(k_se3_jvp, M, st, M, wv, x, t_wv, t_xw); }
 void trunk_in_jvp(hipStream_t st, const Dims& D, long long M, const float* xw, const float* wamb, const float* t_xw, const float* t_wamb,
                   const Windows& W, float* t_tin) {
-  LAUNCH(k_trunk_in_jvp, 3 * M, st, D, M, xw, wamb, t_xw, t_wamb, W, t_tin);
+  LAUNCH(k_trunk_in_jvp, M * D.trunk_in, st, D, M, xw, wamb, t_xw, t_wamb, W, t_tin);
 }
 void target_norm(hipStream_t st, long long M, const float* t_alpha, const float* wv, float* out) { LAUNCH(k_target_norm, M, st, M, t_alpha, wv, out); }
 void clip_gradients(hipStream_t st, float* g, long long n, float max_val, float max_norm, float* sumsq_scratch) {
