@@ -294,6 +294,9 @@ template <class G, class PL> struct Pipe {
                 "a spread trigger unit may not share a consumption step with the first unit of the next stage");
   static_assert(RD <= SU && RD >= 2, "prefetch reaches at most one stage ahead");
   u32x4 ring[RD];
+#ifdef NERFDS_PROF
+  unsigned long long t_chain = 0, t_eval = 0, t_ray = 0;      // measurement build: cycles inside the layer chains / the field evaluations / compositing + resampling
+#endif
   rsrc_t cur;       // stream of the segment being walked
   rsrc_t next;      // stream of the segment walked next (wrap-around prefetch)
   int lane16;
@@ -832,6 +835,20 @@ template <int W> DEVI void x3_epi_op(int i, const f32x16 (&prev)[2], X3Epi& e, C
   }
 #endif
 }
+#ifdef NERFDS_PROF
+// s_memtime at a pinned place of the instruction stream: the asm "rewrites" one register of what the surrounding code produces / consumes
+template <int P> DEVI unsigned chunk_word(const Chunk<P>& c) { unsigned w; __builtin_memcpy(&w, &c, 4); return w; }
+DEVI unsigned long long prof_now(unsigned& tie) {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(tie) :: "memory");
+  return t;
+}
+#define NERFDS_PROF_BEGIN(tievar) unsigned long long prof_t0_ = prof_now(tievar)
+#define NERFDS_PROF_END(acc, tievar) do { (acc) += prof_now(tievar) - prof_t0_; } while (0)
+#else
+#define NERFDS_PROF_BEGIN(tievar) do { } while (0)
+#define NERFDS_PROF_END(acc, tievar) do { } while (0)
+#endif
 template <class T> struct seg_chunks;
 template <int P, int NT, int K> struct seg_chunks<Chunk<P>[NT][K]> { static constexpr int value = K; };
 template <class... Ins> struct seg_total { static constexpr int value = (seg_chunks<Ins>::value + ... + 0); };
@@ -852,7 +869,13 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Chunk<PO> (&out)[NT][2 * OT], Ins&.
   // (uniform one-unit plans only: in the mixed plan - f16 networks around a split-bf16 warp field - the asm epilogue build gave
   // run-to-run differences on ~1 % of the rays of the fine level; the C++ epilogue build of the same kernel is clean)
   constexpr bool ASM_EPI = PL::NT == 1 && is_single(PO) && RELU && PL::UNIFORM;
+#ifdef NERFDS_PROF
+  unsigned prof_tie_ = (unsigned)bias_base(pipe.lane16);
+  NERFDS_PROF_BEGIN(prof_tie_);
+  const int hb = (int)prof_tie_;          // (every bias read of the layer depends on the timer's asm: the chain starts behind it)
+#else
   const int hb = bias_base(pipe.lane16);
+#endif
   auto no_slot = [](int, int) {};
   if constexpr (!TRAIN && X1_PIN && is_single(PO) && RELU && NT == 2 && TP == 1 && (OT > 1) && PL::UNIFORM) {
     // One-unit two-N-tile render kernels, tiles one at a time: the conversion of tile t (its two accumulators rest in `prev`) is issued as
@@ -1057,13 +1080,23 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Chunk<PO> (&out)[NT][2 * OT], Ins&.
       }
     }
   }
+#ifdef NERFDS_PROF
+  prof_tie_ = chunk_word(out[0][2 * OT - 1]);      // the layer's last output chunk exists: the chain and its conversion are behind us
+#endif
+  NERFDS_PROF_END(pipe.t_chain, prof_tie_);
   cur.bt += OT;
 }
 
 // Output head (<= 16 logical outputs, duplicated in both lane halves by the packer): logical output j = acc[j].
 template <class G, class PL, int NT, int P, int K>
 DEVI void head(Pipe<G, PL>& pipe, Cursor& cur, f32x16 (&acc)[1][NT], Chunk<P> (&in)[NT][K]) {
+#ifdef NERFDS_PROF
+  unsigned prof_tie_ = (unsigned)bias_base(pipe.lane16);
+  NERFDS_PROF_BEGIN(prof_tie_);
+  const int hb = (int)prof_tie_;
+#else
   const int hb = bias_base(pipe.lane16);
+#endif
   {
     const f32x16 bv = load_bias(cur.bt, hb);
 #pragma unroll
@@ -1072,6 +1105,10 @@ DEVI void head(Pipe<G, PL>& pipe, Cursor& cur, f32x16 (&acc)[1][NT], Chunk<P> (&
   int j = 0;
   auto no_slot = [](int, int) {};
   accum<G, PL, NT, 1>(acc, pipe, cur, in, j, no_slot);
+#ifdef NERFDS_PROF
+  prof_tie_ = __builtin_bit_cast(unsigned, acc[0][0][0]);
+#endif
+  NERFDS_PROF_END(pipe.t_chain, prof_tie_);
   cur.bt += 1;
 }
 

@@ -54,6 +54,11 @@ struct KArgs {
   float win_sp[MAX_BANDS];     // alpha = nerf_alpha        (models.py:507)
   float win_hp[MAX_BANDS];     // alpha = hyper_alpha       (models.py:515)
   float win_nm[MAX_BANDS];     // alpha = norm_input_alpha  (models.py:1147)
+#ifdef NERFDS_PROF
+  // MEASUREMENT BUILD ONLY (tools/prof_phases.sh): [0] kernel cycles summed over waves, [1] cycles inside dense() / head() (the MFMA chains),
+  // [2] cycles inside eval_shared / eval_nerf (chains + input encodings + per-sample math), [3] waves, [4] cycles in composite() / resample()
+  unsigned long long* prof;
+#endif
 };
 
 // Where the training forward writes what the backward pass reads (nerfds_train.cpp workspace, row-major [R * S][width] fp32).

@@ -466,6 +466,12 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   window(ka.win_hp, ctx->cfg.hyper_point_max_deg, extra->hyper_alpha);
   window(ka.win_nm, ctx->cfg.norm_input_max_deg, extra->norm_input_alpha);
 
+#ifdef NERFDS_PROF
+  static unsigned long long* prof_dev = nullptr;        // MEASUREMENT BUILD ONLY (tools/prof_phases.sh)
+  if (!prof_dev) (void)hipMalloc(&prof_dev, 16 * sizeof(unsigned long long));
+  (void)hipMemset(prof_dev, 0, 16 * sizeof(unsigned long long));
+  ka.prof = prof_dev;
+#endif
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
   const bool timed = ctx->timing && ctx->events.size() < nerfds_ctx::MAX_TIMED;
@@ -485,6 +491,17 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
     ctx->events.push_back(ev);
   }
   if (e != hipSuccess) return ctx->fail(NERFDS_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+#ifdef NERFDS_PROF
+  {
+    unsigned long long p[16] = {};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(p, prof_dev, sizeof p, hipMemcpyDeviceToHost);
+    if (p[3]) fprintf(stderr, "NERFDS_PROF rays=%lld waves=%llu cycles/wave=%.0f  layer chains %.1f%%  field evaluation outside the chains (encodings, exp_se3, heads' activations) %.1f%%  "
+                              "compositing (both levels) %.1f%%  resampling: pdf / cdf / bins %.1f%%, inverse cdf %.1f%%, rank sort %.1f%%, state move %.1f%%  rest (ray setup, syncs) %.1f%%\n", (long long)rays->num_rays, p[3],
+                      (double)p[0] / p[3], 100.0 * p[1] / p[0], 100.0 * ((double)p[2] - (double)p[1]) / p[0], 100.0 * p[4] / p[0], 100.0 * p[5] / p[0], 100.0 * p[6] / p[0], 100.0 * p[7] / p[0],
+                      100.0 * p[8] / p[0], 100.0 * ((double)p[0] - (double)p[2] - (double)p[4] - (double)(p[5] + p[6] + p[7] + p[8])) / p[0]);
+  }
+#endif
   return NERFDS_OK;
 }
 

@@ -121,8 +121,21 @@ DEVI void composite(const KArgs& ka, const RayConst& rc, int ray, int lane, int 
 // Coarse -> fine: inverse-CDF resample + sorted union (model_utils.py:193-269; models.py:1522-1526).
 // On entry zs[0..nc) = coarse z, ws[0..nc) = coarse weights.  On exit zs[0..nc+nf) = sorted union.
 // ------------------------------------------------------------------------------------------------
-template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int nc, int nf, LT& L) {
+#ifdef NERFDS_PROF
+#define NERFDS_RS_MARK(k) do { unsigned tie_ = __builtin_bit_cast(unsigned, L.zn[lane]); const unsigned long long now_ = prof_now(tie_); prof_rs[k] += now_ - prof_last; prof_last = now_; } while (0)
+#else
+#define NERFDS_RS_MARK(k) do { } while (0)
+#endif
+template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int nc, int nf, LT& L
+#ifdef NERFDS_PROF
+                                       , unsigned long long (&prof_rs)[4]
+#endif
+                                       ) {
   constexpr int MAX_SAMPLES = LT::MAX_S;
+#ifdef NERFDS_PROF
+  unsigned prof_tie0 = (unsigned)lane;
+  unsigned long long prof_last = prof_now(prof_tie0);
+#endif
   const int nb = nc - 1;          // bins = mid points (nc-1 of them); cdf has nb entries, cdf[0] = 0
   const int nw = nc - 2;          // weights[..., 1:-1]
   // pdf / cdf
@@ -146,6 +159,7 @@ template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int n
     if (i < nb) L.zn[i] = 0.5f * (L.zs[i + 1] + L.zs[i]);      // bins (models.py:1522)
   }
   WAVE_SYNC();
+  NERFDS_RS_MARK(0);
   // inverse CDF for my fine samples
   float zf[MAX_SAMPLES / 64];
 #pragma unroll
@@ -193,13 +207,68 @@ template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int n
     if (k < nf) L.zn[nc + k] = zf[j];
   }
   WAVE_SYNC();
+  NERFDS_RS_MARK(1);
   constexpr int NJ = MAX_SAMPLES / 64, NSTATE = 1 + (SV_COUNT - SV_WP);
   int rk[NJ];
   float st[NJ][NSTATE];
-  {
-    // rank of union element i = #{q : z_q < z_i or (z_q == z_i and q < i)}.  One pass over the union for ALL of the lane's elements,
-    // four values per (broadcast) LDS read and four reads in flight: as one dependent 4-byte read per comparison this loop was the
-    // largest single piece of the per-ray phases (~20 k of their ~34 k cycles per ray group).
+  // rank of union element i = #{q : z_q < z_i or (z_q == z_i and q < i)} (the union = [coarse | new]: on ties the coarse sample first, then the
+  // lower index - any order of equal depths gives the same sorted z, model_utils.py:267, and the same per-sample state).
+  if (ka.near_ <= ka.far_) {
+    // The coarse depths are ALREADY in ascending order (model_utils.py:75-89: z rises with t, the stratified jitter stays inside a sample's own
+    // bin; equal depths - near == far - keep their index order), so only the nf NEW samples need counting:
+    //   coarse i : rank = i + #{new k : z_k < z_i}
+    //   new k    : rank = #{coarse i : z_i <= z_k} (a binary search in the sorted coarse depths) + #{new j : z_j < z_k or (z_j == z_k and j < k)}
+    // one pass over the NEW depths for all of the lane's elements, four values per (broadcast) LDS read.  (Through round 4 every element was
+    // counted against the whole union, 2 x 128 x 128 compare / select / add steps per ray: measured with the phase timers of tools/prof_phases.sh
+    // at 6.0 % of the bf16 kernel and 2.4 % of the split-bf16 kernel - more than compositing both levels.)
+    float vc[NJ], vn[NJ];
+    int rn[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int i = lane + 64 * j;
+      vc[j] = L.zn[i < nc ? i : nc - 1];
+      vn[j] = L.zn[nc + (i < nf ? i : nf - 1)];
+      rk[j] = i;                               // the coarse samples below it
+      int lo = 0, hi = nc;                     // #{coarse <= vn}: upper bound in the sorted coarse depths
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (L.zn[mid] <= vn[j]) lo = mid + 1; else hi = mid;
+      }
+      rn[j] = lo;
+    }
+    // (uniform tests: with 64 + 64 samples a lane holds ONE live coarse and ONE live new element - the second slot of either array is past the end)
+    auto count = [&](float o, int q) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (64 * j < nc) rk[j] += (o < vc[j]) ? 1 : 0;
+        if (64 * j < nf) rn[j] += (o < vn[j] || (o == vn[j] && q < lane + 64 * j)) ? 1 : 0;
+      }
+    };
+    const float* znew = L.zn + nc;             // (16-byte aligned when nc is a multiple of 4; the scalar tail loop covers the rest)
+    const int n4 = (nc & 3) ? 0 : (nf & ~3);
+#pragma unroll 4
+    for (int q = 0; q < n4; q += 4) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(&znew[q]);
+      count(o[0], q); count(o[1], q + 1); count(o[2], q + 2); count(o[3], q + 3);
+    }
+    for (int q = n4; q < nf; ++q) count(znew[q], q);
+    // this lane's union element i = lane + 64 j is coarse sample i (i < nc) or new sample i - nc
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int i = lane + 64 * j;
+      // new sample k = i - nc lives in lane (k & 63), slot (k >> 6) of the arrays above: fetch its rank from there (every lane takes part
+      // in the shuffles - a permute reads nothing from a lane that is switched off -, the select picks)
+      const int k = i >= nc ? i - nc : 0;
+      int r = 0;
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int got = __shfl(rn[jj], k & 63, 64);
+        r = ((k >> 6) == jj) ? got : r;
+      }
+      rk[j] = i >= nc ? r : rk[j];
+    }
+  } else {
+    // (near > far: descending coarse depths - no shipped configuration; every element against the whole union, as through round 4)
     float v[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -219,6 +288,9 @@ template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int n
     }
     for (int q = n4; q < n; ++q) count(L.zn[q], q);
   }
+#ifdef NERFDS_PROF
+  { unsigned tie_ = (unsigned)rk[0]; const unsigned long long now_ = prof_now(tie_); rk[0] = (int)tie_; prof_rs[2] += now_ - prof_last; prof_last = now_; }
+#endif
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int i = lane + 64 * j;
@@ -241,6 +313,7 @@ template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int n
     }
   }
   WAVE_SYNC();
+  NERFDS_RS_MARK(3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -264,6 +337,19 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
 
   using PP = Pipe<G, PL>;
   Pipe<G, PL> pipe;
+#ifdef NERFDS_PROF
+  unsigned prof_k_ = (unsigned)lane;
+  const unsigned long long prof_start = prof_now(prof_k_);
+  unsigned long long prof_rs[4] = {0, 0, 0, 0};
+#define NERFDS_EVAL(call) do { unsigned tie_ = (unsigned)lane; NERFDS_PROF_BEGIN(tie_); call; tie_ = __builtin_bit_cast(unsigned, L.sv[0][lane]); NERFDS_PROF_END(pipe.t_eval, tie_); } while (0)
+#else
+#define NERFDS_EVAL(call) call
+#endif
+#ifdef NERFDS_PROF
+#define NERFDS_RAYPHASE(call) do { unsigned tie_ = (unsigned)lane; NERFDS_PROF_BEGIN(tie_); call; tie_ = __builtin_bit_cast(unsigned, L.zs[lane]); NERFDS_PROF_END(pipe.t_ray, tie_); } while (0)
+#else
+#define NERFDS_RAYPHASE(call) call
+#endif
   const rsrc_t rs_nerf[2] = {make_rsrc(ka.wstream[1], PP::NERF_PAD * 1024), make_rsrc(ka.wstream[2], PP::NERF_PAD * 1024)};
   const rsrc_t rs_shared = PP::HAS_SHARED ? make_rsrc(ka.wstream[0], PP::SHARED_PAD * 1024) : rs_nerf[0];
   pipe.cur = pipe.next = PP::HAS_SHARED ? rs_shared : rs_nerf[0];
@@ -361,22 +447,26 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
     for (int sb = 0; sb < nc; sb += BATCH) {
       const Samples<NT> sm = samples_at(sb + 32 * NT * q, nc);
       if constexpr (PP::HAS_SHARED) { pipe.cur = rs_shared; pipe.next = rs_nerf[0]; }
-      eval_shared<G, PL, NT>(ka, rc, pipe, lane, sm, L);
+      NERFDS_EVAL((eval_shared<G, PL, NT>(ka, rc, pipe, lane, sm, L)));
       pipe.cur = rs_nerf[0];
       if constexpr (PP::HAS_SHARED) pipe.next = rs_shared;      // another coarse batch, the fine level's new samples, or the next ray group
       else pipe.next = (sb + BATCH < nc) ? rs_nerf[0] : (nf > 0 ? rs_nerf[1] : rs_nerf[0]);
-      eval_nerf<G, PL, NT>(ka, pipe, 0, lane, sm, L);
+      NERFDS_EVAL((eval_nerf<G, PL, NT>(ka, pipe, 0, lane, sm, L)));
     }
     ray_sync();
     if (q == 0) {
       float* rec = live ? ((nf > 0) ? ka.ray_coarse : ka.ray_fine) : nullptr;
       float* smp = live ? ((nf > 0) ? ka.smp_coarse : ka.smp_fine) : nullptr;
       // the 'coarse' render_samples call (models.py:1493-1517): the MODEL's use_sample_at_infinity (:1509), no render_opts
-      composite<G>(ka, rc, ray, lane, nc, ka.sample_at_infinity != 0, 0, L,
+      NERFDS_RAYPHASE((composite<G>(ka, rc, ray, lane, nc, ka.sample_at_infinity != 0, 0, L,
                    rec ? rec + (size_t)ray * RAY_REC : nullptr,
-                   smp ? smp + (size_t)ray * nc * SAMPLE_REC : nullptr);
+                   smp ? smp + (size_t)ray * nc * SAMPLE_REC : nullptr)));
       WAVE_SYNC();
+#ifdef NERFDS_PROF
+      if (nf > 0) resample(ka, ray, lane, nc, nf, L, prof_rs);
+#else
       if (nf > 0) resample(ka, ray, lane, nc, nf, L);
+#endif
     }
     ray_sync();
 
@@ -394,24 +484,34 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
           sm.slot[nt] = reinterpret_cast<const int*>(L.cdf)[k];
         }
         if constexpr (PP::HAS_SHARED) { pipe.cur = rs_shared; pipe.next = (sb + BATCH < nf) ? rs_shared : rs_nerf[1]; }
-        eval_shared<G, PL, NT>(ka, rc, pipe, lane, sm, L);
+        NERFDS_EVAL((eval_shared<G, PL, NT>(ka, rc, pipe, lane, sm, L)));
       }
       ray_sync();              // a NerfMLP batch reads slots that other waves of the ray have written
       for (int sb = 0; sb < n; sb += BATCH) {
         const Samples<NT> sm = samples_at(sb + 32 * NT * q, n);
         pipe.cur = rs_nerf[1];
         pipe.next = (sb + BATCH < n) ? rs_nerf[1] : (PP::HAS_SHARED ? rs_shared : rs_nerf[0]);
-        eval_nerf<G, PL, NT>(ka, pipe, 1, lane, sm, L);
+        NERFDS_EVAL((eval_nerf<G, PL, NT>(ka, pipe, 1, lane, sm, L)));
       }
       ray_sync();
       if (q == 0)
         // the 'fine' call (models.py:1528-1552): the per-call use_sample_at_infinity override (:1544) and render_opts (:1545)
-        composite<G>(ka, rc, ray, lane, n, ka.sample_at_infinity_fine != 0, ka.opt_flags, L,
+        NERFDS_RAYPHASE((composite<G>(ka, rc, ray, lane, n, ka.sample_at_infinity_fine != 0, ka.opt_flags, L,
                      (live && ka.ray_fine) ? ka.ray_fine + (size_t)ray * RAY_REC : nullptr,
-                     (live && ka.smp_fine) ? ka.smp_fine + (size_t)ray * n * SAMPLE_REC : nullptr);
+                     (live && ka.smp_fine) ? ka.smp_fine + (size_t)ray * n * SAMPLE_REC : nullptr)));
       ray_sync();
     }
   }
+#ifdef NERFDS_PROF
+  {
+    const unsigned long long total = prof_now(prof_k_) - prof_start;
+    if (lane == 0 && ka.prof != nullptr) {
+      atomicAdd(ka.prof + 0, total); atomicAdd(ka.prof + 1, pipe.t_chain); atomicAdd(ka.prof + 2, pipe.t_eval); atomicAdd(ka.prof + 3, 1ull);
+      atomicAdd(ka.prof + 4, pipe.t_ray);
+      for (int k = 0; k < 4; ++k) atomicAdd(ka.prof + 5 + k, prof_rs[k]);
+    }
+  }
+#endif
 }
 
 using KernelPlan =
