@@ -50,8 +50,15 @@ FLOP_PER_RAY = 333.15e6          # BASELINE.md section 2, nerf_ds graph, 192 fie
 PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f32': 157.3, 'f16': 2500.0, 'mixed': 2500.0}
 EXTRA = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
 # where the committed PMC measurement of the headline kernel lives (separate rocprofv3 passes of this command, tools/prof_bench.sh)
-TRAFFIC_FILE = 'profiles/r4_bf16_hbm_traffic.json'
-TRAIN_TRAFFIC_FILE = 'profiles/r4_train_hbm_traffic.json'
+def _latest(*names):
+  for n in names:
+    if os.path.exists(os.path.join(ROOT, n)):
+      return n
+  return names[0]
+
+
+TRAFFIC_FILE = _latest('profiles/r5_bf16_hbm_traffic.json', 'profiles/r4_bf16_hbm_traffic.json')
+TRAIN_TRAFFIC_FILE = _latest('profiles/r5_train_hbm_traffic.json', 'profiles/r4_train_hbm_traffic.json')
 
 
 def synth_rays(R, n_ids, seed, device):
