@@ -47,7 +47,7 @@ import torch.distributed as dist
 
 FLOP_PER_RAY = 333.15e6          # BASELINE.md section 2, nerf_ds graph, 192 field evaluations per ray
 # dense MFMA peaks, MI355X_MICROARCH.md (bf16 = f16 rate; the split / mixed modes are priced against the same peak)
-PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f32': 157.3, 'f16': 2500.0, 'mixed': 2500.0}
+PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f32': 157.3, 'f16': 2500.0, 'mixed': 2500.0, 'bf16x3_fine': 2500.0}
 EXTRA = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
 # where the committed PMC measurement of the headline kernel lives (separate rocprofv3 passes of this command, tools/prof_bench.sh)
 def _latest(*names):
@@ -150,6 +150,13 @@ def rgb_error(model, cfg, params, sample, precision):
     err = max(err, float(d.max() / max(np.abs(ref).max(), 1e-6)))
     pix = max(pix, float((d / np.maximum(np.abs(ref), PIXEL_FLOOR)).max()))
   return err, pix
+
+
+def rgb_error_by_level(model, cfg, params, sample, precision):
+  """max |d rgb| / max |rgb| of the composited RGB against the oracle on the cpu_baseline sample, per level."""
+  out = model.apply({'params': params}, sample['rays'], EXTRA, t_rand=sample['t'], u_rand=sample['u'],
+                    use_predicted_norm=cfg.predict_norm, precision=precision)
+  return {lv: float(np.abs(out[lv]['rgb'].cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-6)) for lv, ref in sample['rgb'].items()}
 
 
 def layer_dims(cfg):
@@ -349,7 +356,7 @@ def main():
   ap.add_argument('--warmup', type=int, default=2)
   ap.add_argument('--rays', type=int, default=None, help='rays per rank per step (default: one 800x600 frame; --graph static: the 64x64 image); with --strong: rays of the ONE frame')
   ap.add_argument('--chunk', type=int, default=65536)
-  ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'f32', 'f16', 'mixed'])
+  ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'f32', 'f16', 'mixed', 'bf16x3_fine'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-other-paths', action='store_true', help='skip the parity_path / other_paths legs (N = 1 only)')
   ap.add_argument('--graph', default='nerf_ds', choices=['nerf_ds', 'hypernerf', 'static'],
@@ -361,6 +368,8 @@ def main():
   ap.add_argument('--no-train-line', action='store_true', help='skip the train_step leg of the default run (N = 1 only)')
   ap.add_argument('--train', action='store_true', help='BASELINE configs[3]: the training step instead of the render')
   ap.add_argument('--train-rays', type=int, default=4096)
+  ap.add_argument('--no-full-objective', dest='full_objective', action='store_false',
+                  help='skip the full configs/nerf_ds.gin objective leg of the training line (profiles of the rgb step)')
   args = ap.parse_args()
   if args.sweep:
     args.graph, args.samples = 'hypernerf', 128
@@ -480,12 +489,19 @@ def main():
     launch_s = kernel_ms / max(n_launch, 1) * 1e-3
     ach = rays_per_launch * flop_per_ray / launch_s / 1e12 if n_launch else None
     mult = 3.0 if prec == 'bf16x3' else 1.0       # split bf16: three MFMAs per product (the mixed plan: only its warp field; not priced)
-    exe = rays_per_launch * exec_per_ray * mult / launch_s / 1e12 if n_launch else None
+    exec_ray = exec_per_ray
+    if prec == 'bf16x3_fine' and nf:              # split bf16 except the coarse level's NerfMLP: one f16 MFMA per product there
+      shared_f, nerf_f = stream_fragments(args.graph)
+      tl = lambda n: -(-n // 32)
+      exec_ray, mult = 32768.0 * (3 * (tl(nc) + tl(nf)) * shared_f + tl(nc) * nerf_f + 3 * tl(nc + nf) * nerf_f), 1.0
+    elif prec == 'bf16x3_fine':
+      mult = 3.0
+    exe = rays_per_launch * exec_ray * mult / launch_s / 1e12 if n_launch else None
     peak = PEAK_TFLOPS[prec]
     return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': (ach / peak) if ach else None,
             'traffic': None, 'traffic_source': None, 'kernel': kernel_name % prec, 'avg_launch_ms': launch_s * 1e3, 'launches': n_launch,
             'algorithmic_flop_per_launch': rays_per_launch * flop_per_ray,
-            'executed_mfma_flop_per_launch': (rays_per_launch * exec_per_ray * mult) if prec != 'mixed' else None,
+            'executed_mfma_flop_per_launch': (rays_per_launch * exec_ray * mult) if prec != 'mixed' else None,
             'executed_frac': (exe / (157.3 if prec == 'f32' else 2500.0)) if (exe and prec != 'mixed') else None}
 
   if args.sweep:
@@ -597,6 +613,30 @@ def main():
         pp['note'] = ('split bf16 (hi + lo) operands, three MFMAs per product, fp32 accumulate: the fastest arithmetic that meets '
                       "north_star's 1e-4 on composited RGB (profiles/r4_precision_budget.md: no arithmetic below three MFMA-equivalents per product holds it at frame size)")
         result['parity_path'] = pp
+      # The same frame with the COARSE level's NerfMLP in one f16 MFMA per product (precision 'bf16x3_fine'): the fine level - the one render_fn returns,
+      # evaluation.py:121-124 - sees of it only the weights its depths are drawn from and holds 1e-4; the coarse level's own RGB is f16-grade.  Its own
+      # object, NOT the parity_path: `meets_tolerance_both_levels` is False by construction and says so.
+      if args.precision != 'bf16x3_fine':
+        steps = max(10, args.steps)
+        el, nl, kms = timed(steps, 2, 'bf16x3_fine')
+        r = roofline_of('bf16x3_fine', nl, kms)
+        by_level = rgb_error_by_level(model, cfg, params, sample, 'bf16x3_fine') if sample else {}
+        ref_f, ref_c, got_f, got_c = (torch.empty_like(frame) for _ in range(4))
+        step_weak(7, 'f32', ref_f, ref_c)
+        step_weak(7, 'bf16x3_fine', got_f, got_c)
+        torch.cuda.synchronize()
+        ff = {lv: float((g[:, :3] - rr[:, :3]).abs().max() / rr[:, :3].abs().max()) for lv, g, rr in (('fine', got_f, ref_f), ('coarse', got_c, ref_c))}
+        worst_fine = max([e for e in (by_level.get('fine'), ff['fine']) if e is not None])
+        worst_coarse = max([e for e in (by_level.get('coarse'), ff['coarse']) if e is not None])
+        result['parity_path_fine_level'] = {
+            'precision': 'bf16x3_fine', 'value': args.rays / (el / steps), 'unit': 'rays/s', 'ms_per_step': el * 1e3 / steps, 'steps': steps, 'warmup': 2,
+            'roofline': r, 'roofline_frac': r['frac'], 'avg_launch_ms': r['avg_launch_ms'],
+            'fine_level_rgb_max_rel_err': by_level.get('fine'), 'coarse_level_rgb_max_rel_err': by_level.get('coarse'),
+            'full_frame_fine_level_rgb_max_rel_err': ff['fine'], 'full_frame_coarse_level_rgb_max_rel_err': ff['coarse'],
+            'tolerance': TOLERANCE, 'meets_tolerance_fine_level': bool(worst_fine <= TOLERANCE), 'meets_tolerance_both_levels': bool(max(worst_fine, worst_coarse) <= TOLERANCE),
+            'note': ("split bf16 everywhere except the coarse level's NerfMLP (one f16 MFMA per product): render_fn / render_image return the FINE level only "
+                     '(evaluation.py:121-124), and every array they return is within 1e-4; model.apply also returns the coarse level, whose composited RGB is f16-grade '
+                     'in this mode.  The number that holds 1e-4 on BOTH levels is parity_path.')}
       result['other_paths'] = list(paths.values())
       if not args.no_train_line:
         # BASELINE configs[3] in the same run (the full line: --train): the 4096-ray training step, 10 timed steps after 3 warm-ups

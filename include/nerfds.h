@@ -51,7 +51,12 @@ extern "C" {
                                    FLOPs in one f16 MFMA per product.  Does NOT meet the 1e-4 tolerance: measured 4.6e-4 on the
                                    bench sample, bounded at 2e-3 in tests (profiles/r3_precision_budget.md: no plan with a
                                    one-MFMA network meets it; only BF16X3 and F32 do) */
-#define NERFDS_PREC_COUNT   5u
+#define NERFDS_PREC_BF16X3_FINE 5u  /* split bf16 everywhere EXCEPT the coarse level's NerfMLP, which runs one f16 MFMA per product: the fine
+                                   * level - the one render_fn returns (evaluation.py:121-124) - sees of the coarse NerfMLP only the weights its depths
+                                   * are drawn from and stays within 1e-4 (measured 3.8e-5 against 3.7e-5 for NERFDS_PREC_BF16X3 on 131 072 rays of the
+                                   * bench frame); the COARSE level's own outputs are f16-grade (rgb 5e-4).  17 % fewer MFMAs than BF16X3.  A
+                                   * single-level model runs plain BF16X3. */
+#define NERFDS_PREC_COUNT   6u
 #define NERFDS_PREC_MASK    7u
 /* Other flags. */
 #define NERFDS_FLAG_USE_WARP_OFF  (1u << 4)  /* NerfModel.__call__(use_warp=False), models.py:1468 - rejected if the graph has a warp */
@@ -238,6 +243,8 @@ int64_t nerfds_struct_size(int which);
  * plan_out = {MaskMLP, SE3 warp field, hyper sheet, NerfMLP trunk (+ alpha head), rgb branch}.  Uniform for every value
  * but NERFDS_PREC_MIXED.  (No reference counterpart: the reference's layers are all fp32 nn.Dense, modules.py:61-65.) */
 int nerfds_precision_plan(uint32_t prec, int32_t plan_out[5]);
+/* the same for the NerfMLP of one level (0 coarse, 1 fine): differs from nerfds_precision_plan only under NERFDS_PREC_BF16X3_FINE */
+int nerfds_precision_plan_level(uint32_t prec, int32_t level, int32_t plan_out[5]);
 int nerfds_ctx_create(nerfds_ctx** out, int device, const nerfds_model_cfg* cfg);
 int nerfds_ctx_load_weights(nerfds_ctx* ctx, const nerfds_weights* w);
 int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_extra* extra,
@@ -398,6 +405,9 @@ int nerfds_debug_lds_attr_first_use(uint64_t kernel_key, int device);
 /* Size in bytes of the packed MFMA weight stream / padded bias array for `which` (0 = shared mask+warp+hyper
  * nets, 1 = NerfMLP) at precision `prec`; negative on error. */
 int64_t nerfds_pack_stream_bytes(const nerfds_model_cfg* cfg, int which, uint32_t prec);
+/* the exact size of the NerfMLP stream of one level (which == 1; level 0 coarse, 1 fine): smaller than nerfds_pack_stream_bytes for the coarse
+ * level under NERFDS_PREC_BF16X3_FINE (one unit per fragment); nerfds_pack_stream_bytes returns the larger of the two */
+int64_t nerfds_pack_stream_bytes_level(const nerfds_model_cfg* cfg, int which, int level, uint32_t prec);
 int64_t nerfds_pack_bias_floats(const nerfds_model_cfg* cfg, int which);
 /* Output tiles per group in the stream of that (graph, precision) kernel: within a group the stream holds, chunk by chunk, one fragment
  * of each tile.  2, except 1 for the kernels that carry two N-tiles per wave (nerf_ds / HyperNeRF graph in bf16 / f16); negative on error. */

@@ -200,9 +200,12 @@ template <int P> DEVI void mma(f32x16& acc, const WFrag<P>& w, const Chunk<P>& c
 #ifndef NERFDS_NT
 #define NERFDS_NT 1
 #endif
-template <int PM, int PW, int PH, int PT, int PR> struct PlanT {
+template <int PM, int PW, int PH, int PT, int PR, int PTC = -1, int PRC = -1> struct PlanT {
   static constexpr int MASK = PM, WARP = PW, HYP = PH, TRUNK = PT, RGB = PR;
-  static constexpr Plan value() { return Plan{PM, PW, PH, PT, PR}; }
+  // the coarse level's NerfMLP in its own arithmetic (graphs.h Plan::trunk_c): HAS_C, and what eval_nerf<..., CP = true> runs in
+  static constexpr bool HAS_C = PTC >= 0;
+  static constexpr int TRUNK_C = HAS_C ? PTC : PT, RGB_C = HAS_C ? PRC : PR;
+  static constexpr Plan value() { return Plan{PM, PW, PH, PT, PR, PTC, PRC}; }
   static constexpr bool UNIFORM = PM == PW && PW == PH && PH == PT && PT == PR;
   // (plans that mix two-unit networks in keep one N-tile: a 128-wide split-bf16 network with two N-tiles is 256 registers of activations too)
   static constexpr int NT = (is_single(PM) && is_single(PW) && is_single(PH) && is_single(PT) && is_single(PR)) ? NERFDS_NT : 1;
@@ -219,7 +222,7 @@ template <int PM, int PW, int PH, int PT, int PR> struct PlanT {
 #define NERFDS_BWD_STAGES 4
 #endif
 constexpr int NUM_STAGES = NERFDS_KERNEL_KIND == 2 ? NERFDS_BWD_STAGES : 4;
-enum { SEG_SHARED = 0, SEG_NERF = 1 };  // the two weight streams (Pipe)
+enum { SEG_SHARED = 0, SEG_NERF = 1, SEG_NERF_C = 2 };  // the weight streams (Pipe); SEG_NERF_C: a coarse NerfMLP in its own arithmetic (PlanT::HAS_C)
 constexpr int RING_BYTES = NUM_STAGES * STAGE_BYTES;
 // Work shape.  NT = N-tiles (32 samples) per wave and evaluation; SPLIT = waves that share one ray's batch of
 // 32 * NT * SPLIT samples; RAYS = rays in flight per workgroup (each with its own RayLds block).
@@ -248,11 +251,13 @@ constexpr int SPREAD_AT = 1;
 // stream lengths of a graph (graphs.h) or of a reversed network of the training backward (one stream, walked as SEG_NERF)
 template <class G, class = void> struct StreamUnits {
   static constexpr int shared(Plan p) { return shared_units<G>(p); }
-  static constexpr int nerf(Plan p) { return nerf_units<G>(p); }
+  static constexpr int nerf(Plan p) { return nerf_units<G>(level_plan(p, 1)); }
+  static constexpr int nerf_c(Plan p) { return nerf_units<G>(level_plan(p, 0)); }
 };
 template <class G> struct StreamUnits<G, std::void_t<decltype(G::BWD_FRAGS)>> {
   static constexpr int shared(Plan) { return 0; }
   static constexpr int nerf(Plan p) { return G::BWD_FRAGS * frag_parts(p.trunk); }
+  static constexpr int nerf_c(Plan p) { return nerf(p); }
 };
 // waves that share the ring: the render / forward shapes (wg_waves), or what a chain graph of the training backward asks for (graphs.h BwdNet)
 template <class G, class PL, class = void> struct PipeWaves { static constexpr int value = wg_waves<PL>(); };
@@ -268,12 +273,15 @@ template <class G, class PL> struct Pipe {
   // results are reused: same networks, same inputs - models.py:1291-1300 evaluates them again and gets the same values) and
   // nerf(fine) on every batch of the sorted union.
   static constexpr int SHARED_UNITS = StreamUnits<G>::shared(PL::value()), NERF_UNITS = StreamUnits<G>::nerf(PL::value());
+  static constexpr int NERF_C_UNITS = StreamUnits<G>::nerf_c(PL::value());      // the coarse level's NerfMLP stream (== NERF_UNITS unless PL::HAS_C)
   static constexpr bool HAS_SHARED = SHARED_UNITS > 0;
   // stream positions count the zero padding at the end of each stream (graphs.h pad_units)
-  static constexpr int SHARED_PAD = pad_units(SHARED_UNITS), NERF_PAD = pad_units(NERF_UNITS);
-  static constexpr int seg_used(int seg) { return (seg == SEG_SHARED ? SHARED_PAD : NERF_PAD) / SU; }       // stages that hold data
+  static constexpr int SHARED_PAD = pad_units(SHARED_UNITS), NERF_PAD = pad_units(NERF_UNITS), NERF_C_PAD = pad_units(NERF_C_UNITS);
+  static constexpr int seg_units(int seg) { return seg == SEG_SHARED ? SHARED_UNITS : (seg == SEG_NERF_C ? NERF_C_UNITS : NERF_UNITS); }
+  static constexpr int seg_used(int seg) { return pad_units(seg_units(seg)) / SU; }                          // stages that hold data
   static constexpr int seg_stages(int seg) { return cdiv(seg_used(seg), NS) * NS; }                          // incl. hole stages
-  static_assert((!HAS_SHARED || seg_used(SEG_SHARED) >= NS - 1) && seg_used(SEG_NERF) >= NS - 1, "the wrap prefetch needs NS - 1 stages in every segment");
+  static_assert((!HAS_SHARED || seg_used(SEG_SHARED) >= NS - 1) && seg_used(SEG_NERF) >= NS - 1 && seg_used(SEG_NERF_C) >= NS - 1,
+                "the wrap prefetch needs NS - 1 stages in every segment");
   static constexpr int WAVES = PipeWaves<G, PL>::value;
   static constexpr int PIECES = SU / WAVES;                       // 1 KiB LDS-DMA pieces per wave per stage
   // LDS -> register prefetch distance in units: a ds_read_b128 takes ~100+ cycles to return under load, a bf16 unit is
@@ -415,7 +423,7 @@ template <class G, class PL> struct Pipe {
   DEVI void finish_segment(int seg) {
     if (SPREAD_DMA) {             // pieces whose trigger unit lies in the zero padding of the last stage
       constexpr int EVERY = SU / PIECES;
-      const int last = (seg == SEG_SHARED ? SHARED_UNITS : NERF_UNITS) - 1, s = seg_used(seg) - 1;
+      const int last = seg_units(seg) - 1, s = seg_used(seg) - 1;
 #pragma unroll
       for (int k = 0; k < PIECES; ++k)
         if (s * SU + k * EVERY + SPREAD_AT % EVERY > last) issue_stage(seg, s + NS - 1, k, k + 1);
@@ -868,7 +876,7 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Chunk<PO> (&out)[NT][2 * OT], Ins&.
   static_assert(OT % TP == 0, "layers have an even number of 32-feature tiles");
   // (uniform one-unit plans only: in the mixed plan - f16 networks around a split-bf16 warp field - the asm epilogue build gave
   // run-to-run differences on ~1 % of the rays of the fine level; the C++ epilogue build of the same kernel is clean)
-  constexpr bool ASM_EPI = PL::NT == 1 && is_single(PO) && RELU && PL::UNIFORM;
+  constexpr bool ASM_EPI = PL::NT == 1 && is_single(PO) && RELU && PL::UNIFORM && !PL::HAS_C;
 #ifdef NERFDS_PROF
   unsigned prof_tie_ = (unsigned)bias_base(pipe.lane16);
   NERFDS_PROF_BEGIN(prof_tie_);
@@ -1533,13 +1541,14 @@ DEVI void eval_shared(const KArgs& ka, const RayConst& rc, Pipe<G, PL>& pipe, in
 // ---- NerfMLP of one level (modules.py:243-313; models.py:1043-1047, 1268-1270) on one batch of 32 * NT samples whose warped
 // point, ambient coordinates and rotation are parked at their slots (eval_shared, possibly of an earlier pass: the coarse
 // samples of the fine level).  Parks sigma, rgb and the raw predicted normal at the slots.
-template <class G, class PL, int NT, class LT, class TO = NoTrain>
+template <class G, class PL, int NT, class LT, class TO = NoTrain, bool CP = false>
 DEVI void eval_nerf(const KArgs& ka, Pipe<G, PL>& pipe, int level, int lane, const Samples<NT>& sm, LT& L,
                     const TO& to = TO(), size_t row = 0) {
   using D = Dims<G>;
   const int h = lane >> 5;
+  constexpr int NSEG = (CP && PL::HAS_C) ? SEG_NERF_C : SEG_NERF;      // CP: the coarse level's own arithmetic and stream (PlanT::HAS_C)
   std::conditional_t<TO::ON, TrainCursor, Cursor> cur;
-  cur.seg = SEG_NERF;
+  cur.seg = NSEG;
   cur.pos = 0;
   cur.bt = D::SHARED_BIAS_TILES + level * D::NERF_BIAS_TILES;
   WAVE_SYNC();                                                // the parked state was written by the twin lane / an earlier pass
@@ -1553,7 +1562,7 @@ DEVI void eval_nerf(const KArgs& ka, Pipe<G, PL>& pipe, int level, int lane, con
   }
   constexpr int TW16 = G::TRUNK_W / 16, TW32 = G::TRUNK_W / 32;
   {
-    constexpr int P = PL::TRUNK, PR = PL::RGB;
+    constexpr int P = CP ? PL::TRUNK_C : PL::TRUNK, PR = CP ? PL::RGB_C : PL::RGB;
     Chunk<P> in0[NT][D::TRUNK_KC], a[NT][TW16], b[NT][TW16];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -1638,7 +1647,7 @@ DEVI void eval_nerf(const KArgs& ka, Pipe<G, PL>& pipe, int level, int lane, con
         L.sv[SV_RGB + 2][s] = sigmoid_f(hacc[0][nt][2]);
       }
   }
-  pipe.finish_segment(SEG_NERF);
+  pipe.finish_segment(NSEG);
 }
 #undef NERFDS_TRAIN_ROW
 #undef NERFDS_TRAIN_HEAD

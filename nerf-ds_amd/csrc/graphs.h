@@ -56,8 +56,15 @@ constexpr int chunks(int feats) { return cdiv(feats, 16); }   // k16 chunks need
 // condition inputs, rgb hidden_0's output and the rgb head.  The uniform plans are the round-1 kernels; the mixed
 // plan (NERFDS_PREC_MIXED) keeps the networks whose error is amplified downstream (the warp field moves the points
 // that the 2^7-frequency encoding of the template reads) in split bf16 and runs the bulk of the FLOPs in one MFMA.
-struct Plan { int mask, warp, hyp, trunk, rgb; };
+// trunk_c / rgb_c (>= 0): the COARSE level's NerfMLP in its own arithmetic.  The fine level sees of the coarse NerfMLP only the compositing weights its
+// depths are drawn from (model_utils.py:193-269, behind a stop_gradient), and render_fn returns the fine level alone (evaluation.py:121-124):
+// measured over 131 072 rays of the bench frame (tools/precision_study_gpu.py --levels, profiles/r5_precision_levels.md), a coarse NerfMLP in ONE
+// f16 MFMA per product leaves the fine level's composited RGB where the all-split-bf16 run has it (3.8e-5 against 3.7e-5) while the coarse level's
+// own RGB is f16-grade (4.7e-4); one bf16 MFMA is not enough (fine level 2.7e-4).
+struct Plan { int mask, warp, hyp, trunk, rgb; int trunk_c = -1, rgb_c = -1; };
 constexpr Plan uniform_plan(int p) { return Plan{p, p, p, p, p}; }
+// the plan the NerfMLP of `level` (0 coarse, 1 fine) runs in
+constexpr Plan level_plan(Plan p, int level) { return (level == 0 && p.trunk_c >= 0) ? Plan{p.mask, p.warp, p.hyp, p.trunk_c, p.rgb_c} : Plan{p.mask, p.warp, p.hyp, p.trunk, p.rgb}; }
 #ifndef NERFDS_MIX_MASK
 #define NERFDS_MIX_MASK P_F16
 #endif
@@ -73,10 +80,11 @@ constexpr Plan uniform_plan(int p) { return Plan{p, p, p, p, p}; }
 #ifndef NERFDS_MIX_RGB
 #define NERFDS_MIX_RGB P_F16
 #endif
-constexpr int NUM_PLANS = 5;     // == number of NERFDS_PREC_* values of include/nerfds.h
+constexpr int NUM_PLANS = 6;     // == number of NERFDS_PREC_* values of include/nerfds.h
 constexpr Plan plan_of(int prec_index) {
   return prec_index == 4 ? Plan{NERFDS_MIX_MASK, NERFDS_MIX_WARP, NERFDS_MIX_HYP, NERFDS_MIX_TRUNK, NERFDS_MIX_RGB}
-                         : uniform_plan(prec_index);
+         : prec_index == 5 ? Plan{P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_F16, P_F16}      // NERFDS_PREC_BF16X3_FINE
+                           : uniform_plan(prec_index);
 }
 // The plan of the fused training forward (train_fwd_kernel.hip): split bf16 operands as the trainer's layer
 // kernels (train_gemm.hip), exact fp32 products in the warp field (its 16-bit rounding is amplified to ~1 % on the warp-field

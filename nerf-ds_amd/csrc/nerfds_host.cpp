@@ -32,6 +32,8 @@ void nerfds_launch_nerfds_f16(const KArgs&, int, void*);
 void nerfds_launch_static_f16(const KArgs&, int, void*);
 void nerfds_launch_hyper_f16(const KArgs&, int, void*);
 void nerfds_launch_nerfds_mixed(const KArgs&, int, void*);
+void nerfds_launch_nerfds_bf16x3f(const KArgs&, int, void*);
+void nerfds_launch_hyper_bf16x3f(const KArgs&, int, void*);
 void nerfds_launch_static_mixed(const KArgs&, int, void*);
 void nerfds_launch_hyper_mixed(const KArgs&, int, void*);
 void nerfds_launch_camera_rays(const nerfds::CameraParams&, long long, long long, const float*, float*, float*, float*, void*);
@@ -198,7 +200,8 @@ NerfNet nerf_views(const Weights::Nerf& s) {
 }
 
 template <class G> void pack_which(StreamWriter& sw, const Weights& W, int which, int level, Plan pl) {
-  if (which == 0) pack_shared<G>(sw, shared_views(W), pl); else pack_nerf<G>(sw, nerf_views(W.nerf[level]), pl);
+  // (level_plan: a plan may run the coarse level's NerfMLP in its own arithmetic - NERFDS_PREC_BF16X3_FINE)
+  if (which == 0) pack_shared<G>(sw, shared_views(W), pl); else pack_nerf<G>(sw, nerf_views(W.nerf[level]), level_plan(pl, level));
 }
 // the kernels the Makefile builds in the two-N-tile shape (NT2FLAGS): nerf_ds / HyperNeRF graph, bf16 / f16
 static int tile_pair_of(int graph, int prec) {
@@ -211,16 +214,18 @@ void pack_dispatch(int graph, StreamWriter& sw, const Weights& W, int which, int
   else if (graph == GraphStatic::ID) pack_which<GraphStatic>(sw, W, which, level, pl);
   else pack_which<GraphHyperNeRF>(sw, W, which, level, pl);
 }
-template <class G> void stream_dims(int which, int prec, int64_t* wbytes, int64_t* bfloats) {
+// level: the NerfMLP stream of that level (which == 1); -1: the larger of the two (a buffer that holds either)
+template <class G> void stream_dims(int which, int level, int prec, int64_t* wbytes, int64_t* bfloats) {
   using D = Dims<G>;
   const Plan pl = plan_of(prec);
-  *wbytes = (int64_t)pad_units(which == 0 ? shared_units<G>(pl) : nerf_units<G>(pl)) * 1024;   // zero padded to whole stages
+  const int nu = level < 0 ? std::max(nerf_units<G>(level_plan(pl, 0)), nerf_units<G>(level_plan(pl, 1))) : nerf_units<G>(level_plan(pl, level));
+  *wbytes = (int64_t)pad_units(which == 0 ? shared_units<G>(pl) : nu) * 1024;   // zero padded to whole stages
   *bfloats = (int64_t)(which == 0 ? D::SHARED_BIAS_TILES : D::NERF_BIAS_TILES) * 32;
 }
-void stream_dims_dispatch(int graph, int which, int prec, int64_t* wb, int64_t* bf) {
-  if (graph == GraphNerfDS::ID) stream_dims<GraphNerfDS>(which, prec, wb, bf);
-  else if (graph == GraphStatic::ID) stream_dims<GraphStatic>(which, prec, wb, bf);
-  else stream_dims<GraphHyperNeRF>(which, prec, wb, bf);
+void stream_dims_dispatch(int graph, int which, int level, int prec, int64_t* wb, int64_t* bf) {
+  if (graph == GraphNerfDS::ID) stream_dims<GraphNerfDS>(which, level, prec, wb, bf);
+  else if (graph == GraphStatic::ID) stream_dims<GraphStatic>(which, level, prec, wb, bf);
+  else stream_dims<GraphHyperNeRF>(which, level, prec, wb, bf);
 }
 
 void window(float* out, int bands, float alpha) {   // model_utils.py:420-436
@@ -264,9 +269,10 @@ struct nerfds_ctx {
 static launch_fn launcher(int graph, uint32_t prec) {
   static_assert(NUM_PLANS == NERFDS_PREC_COUNT, "graphs.h plan_of covers every NERFDS_PREC_* value");
   static const launch_fn tab[3][NUM_PLANS] = {
-      {nerfds_launch_nerfds_bf16, nerfds_launch_nerfds_bf16x3, nerfds_launch_nerfds_f32, nerfds_launch_nerfds_f16, nerfds_launch_nerfds_mixed},
-      {nerfds_launch_static_bf16, nerfds_launch_static_bf16x3, nerfds_launch_static_f32, nerfds_launch_static_f16, nerfds_launch_static_mixed},
-      {nerfds_launch_hyper_bf16, nerfds_launch_hyper_bf16x3, nerfds_launch_hyper_f32, nerfds_launch_hyper_f16, nerfds_launch_hyper_mixed}};
+      {nerfds_launch_nerfds_bf16, nerfds_launch_nerfds_bf16x3, nerfds_launch_nerfds_f32, nerfds_launch_nerfds_f16, nerfds_launch_nerfds_mixed, nerfds_launch_nerfds_bf16x3f},
+      // (the static graph has ONE level, the one render_fn returns: NERFDS_PREC_BF16X3_FINE is plain split bf16 there - effective_prec)
+      {nerfds_launch_static_bf16, nerfds_launch_static_bf16x3, nerfds_launch_static_f32, nerfds_launch_static_f16, nerfds_launch_static_mixed, nerfds_launch_static_bf16x3},
+      {nerfds_launch_hyper_bf16, nerfds_launch_hyper_bf16x3, nerfds_launch_hyper_f32, nerfds_launch_hyper_f16, nerfds_launch_hyper_mixed, nerfds_launch_hyper_bf16x3f}};
   return tab[graph][prec];
 }
 
@@ -290,6 +296,12 @@ int64_t nerfds_struct_size(int which) {
 int nerfds_precision_plan(uint32_t prec, int32_t plan_out[5]) {
   if (prec >= NERFDS_PREC_COUNT || !plan_out) return NERFDS_EINVAL;
   const Plan pl = plan_of((int)prec);
+  plan_out[0] = pl.mask; plan_out[1] = pl.warp; plan_out[2] = pl.hyp; plan_out[3] = pl.trunk; plan_out[4] = pl.rgb;
+  return NERFDS_OK;
+}
+int nerfds_precision_plan_level(uint32_t prec, int32_t level, int32_t plan_out[5]) {
+  if (prec >= NERFDS_PREC_COUNT || !plan_out || level < 0 || level > 1) return NERFDS_EINVAL;
+  const Plan pl = level_plan(plan_of((int)prec), level);
   plan_out[0] = pl.mask; plan_out[1] = pl.warp; plan_out[2] = pl.hyp; plan_out[3] = pl.trunk; plan_out[4] = pl.rgb;
   return NERFDS_OK;
 }
@@ -362,7 +374,7 @@ static int ensure_packed(nerfds_ctx* ctx, uint32_t prec) {
   const int levels = ctx->cfg.num_fine_samples > 0 ? 2 : 1;
   for (int which = 0; which < 1 + levels; ++which) {
     int64_t wb = 0, bf = 0;
-    stream_dims_dispatch(ctx->graph, which ? 1 : 0, (int)prec, &wb, &bf);
+    stream_dims_dispatch(ctx->graph, which ? 1 : 0, which ? which - 1 : 0, (int)prec, &wb, &bf);
     std::vector<uint8_t> w((size_t)wb);
     std::vector<float> b((size_t)bf);
     StreamWriter sw{w.data(), b.data()};
@@ -384,8 +396,10 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   if (!ctx) return NERFDS_EINVAL;
   if (!rays || !extra || !out) return ctx->fail(NERFDS_EINVAL, "null argument");
   if (!ctx->W.loaded) return ctx->fail(NERFDS_EINVAL, "nerfds_ctx_load_weights has not been called");
-  const uint32_t prec = flags & NERFDS_PREC_MASK;
+  uint32_t prec = flags & NERFDS_PREC_MASK;
   if (prec >= NERFDS_PREC_COUNT) return ctx->fail(NERFDS_EINVAL, "unknown precision %u", prec);
+  // a single-level model's one level IS the level render_fn returns: no coarse pass to run cheaply
+  if (prec == NERFDS_PREC_BF16X3_FINE && ctx->cfg.num_fine_samples == 0) prec = NERFDS_PREC_BF16X3;
   if ((flags & NERFDS_FLAG_USE_WARP_OFF) && ctx->cfg.use_warp)
     return ctx->fail(NERFDS_ENOTSUP, "use_warp=False on a warp model is not runnable in the reference either (SURVEY.md 8a quirk 2)");
   if (rays->num_rays < 0 || rays->num_rays > 0x7fffffff) return ctx->fail(NERFDS_EINVAL, "num_rays out of range");
@@ -577,7 +591,15 @@ int64_t nerfds_pack_stream_bytes(const nerfds_model_cfg* cfg, int which, uint32_
   const int g = graph_of(*cfg);
   if (g < 0) return NERFDS_ENOTSUP;
   int64_t wb, bf;
-  stream_dims_dispatch(g, which, (int)prec, &wb, &bf);
+  stream_dims_dispatch(g, which, -1, (int)prec, &wb, &bf);      // (the larger of the two levels' NerfMLP streams: a buffer that holds either)
+  return wb;
+}
+int64_t nerfds_pack_stream_bytes_level(const nerfds_model_cfg* cfg, int which, int level, uint32_t prec) {
+  if (!cfg || prec >= NERFDS_PREC_COUNT || which < 0 || which > 1 || level < 0 || level > 1) return NERFDS_EINVAL;
+  const int g = graph_of(*cfg);
+  if (g < 0) return NERFDS_ENOTSUP;
+  int64_t wb, bf;
+  stream_dims_dispatch(g, which, level, (int)prec, &wb, &bf);
   return wb;
 }
 int nerfds_pack_tile_pair(const nerfds_model_cfg* cfg, uint32_t prec) {
@@ -591,7 +613,7 @@ int64_t nerfds_pack_bias_floats(const nerfds_model_cfg* cfg, int which) {
   const int g = graph_of(*cfg);
   if (g < 0) return NERFDS_ENOTSUP;
   int64_t wb, bf;
-  stream_dims_dispatch(g, which, 0, &wb, &bf);
+  stream_dims_dispatch(g, which, -1, 0, &wb, &bf);
   return bf;
 }
 int nerfds_pack_stream(const nerfds_model_cfg* cfg, const nerfds_weights* w, int which, int level, uint32_t prec,

@@ -350,7 +350,8 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
 #else
 #define NERFDS_RAYPHASE(call) call
 #endif
-  const rsrc_t rs_nerf[2] = {make_rsrc(ka.wstream[1], PP::NERF_PAD * 1024), make_rsrc(ka.wstream[2], PP::NERF_PAD * 1024)};
+  // (a single-level model's one NerfMLP is the level render_fn returns: it runs in the fine plan - the host passes its stream in both slots)
+  const rsrc_t rs_nerf[2] = {make_rsrc(ka.wstream[1], PP::NERF_C_PAD * 1024), make_rsrc(ka.wstream[2], PP::NERF_PAD * 1024)};
   const rsrc_t rs_shared = PP::HAS_SHARED ? make_rsrc(ka.wstream[0], PP::SHARED_PAD * 1024) : rs_nerf[0];
   pipe.cur = pipe.next = PP::HAS_SHARED ? rs_shared : rs_nerf[0];
   pipe.lane16 = lane * 16;
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
       pipe.cur = rs_nerf[0];
       if constexpr (PP::HAS_SHARED) pipe.next = rs_shared;      // another coarse batch, the fine level's new samples, or the next ray group
       else pipe.next = (sb + BATCH < nc) ? rs_nerf[0] : (nf > 0 ? rs_nerf[1] : rs_nerf[0]);
-      NERFDS_EVAL((eval_nerf<G, PL, NT>(ka, pipe, 0, lane, sm, L)));
+      NERFDS_EVAL((eval_nerf<G, PL, NT, WaveLds, NoTrain, PL::HAS_C>(ka, pipe, 0, lane, sm, L)));
     }
     ray_sync();
     if (q == 0) {
@@ -517,6 +518,9 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
 using KernelPlan =
 #if defined(NERFDS_MIXED)
     PlanT<NERFDS_MIX_MASK, NERFDS_MIX_WARP, NERFDS_MIX_HYP, NERFDS_MIX_TRUNK, NERFDS_MIX_RGB>;
+#elif defined(NERFDS_X3_FINE)
+    // NERFDS_PREC_BF16X3_FINE (graphs.h plan_of(5)): split bf16 everywhere except the coarse level's NerfMLP, which runs one f16 MFMA per product
+    PlanT<P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_F16, P_F16>;
 #else
     PlanT<NERFDS_PREC, NERFDS_PREC, NERFDS_PREC, NERFDS_PREC, NERFDS_PREC>;
 #endif

@@ -26,7 +26,7 @@ def resolve_device(device=None):
 MAX_DEPTH = 16
 RAY_REC = 26
 SAMPLE_REC = 18
-PREC = {'bf16': 0, 'bf16x3': 1, 'f32': 2, 'f16': 3, 'mixed': 4}
+PREC = {'bf16': 0, 'bf16x3': 1, 'f32': 2, 'f16': 3, 'mixed': 4, 'bf16x3_fine': 5}
 
 # per-ray record slices (enum nerfds_ray_field)
 RAY_FIELDS = {
@@ -126,8 +126,8 @@ class Out(C.Structure):
 
 
 # every symbol include/nerfds.h declares
-SYMBOLS = ('nerfds_abi_version', 'nerfds_struct_size', 'nerfds_precision_plan', 'nerfds_ctx_create', 'nerfds_ctx_load_weights', 'nerfds_render_rays',
-           'nerfds_encode_embed', 'nerfds_ctx_destroy', 'nerfds_last_error', 'nerfds_kernel_time_ms', 'nerfds_pack_stream_bytes',
+SYMBOLS = ('nerfds_abi_version', 'nerfds_struct_size', 'nerfds_precision_plan', 'nerfds_precision_plan_level', 'nerfds_ctx_create', 'nerfds_ctx_load_weights', 'nerfds_render_rays',
+           'nerfds_encode_embed', 'nerfds_ctx_destroy', 'nerfds_last_error', 'nerfds_kernel_time_ms', 'nerfds_pack_stream_bytes', 'nerfds_pack_stream_bytes_level',
            'nerfds_pack_bias_floats', 'nerfds_pack_tile_pair', 'nerfds_pack_stream', 'nerfds_debug_mfma', 'nerfds_camera_to_rays',
            'nerfds_frame_images', 'nerfds_trainer_create', 'nerfds_trainer_destroy', 'nerfds_trainer_param_count',
            'nerfds_trainer_num_leaves', 'nerfds_trainer_leaf', 'nerfds_trainer_params', 'nerfds_trainer_grads',
@@ -152,6 +152,7 @@ def load():
   lib = C.CDLL(LIB_PATH)
   lib.nerfds_abi_version.restype = C.c_int
   lib.nerfds_precision_plan.argtypes = [C.c_uint32, C.POINTER(C.c_int32)]
+  lib.nerfds_precision_plan_level.argtypes = [C.c_uint32, C.c_int32, C.POINTER(C.c_int32)]
   lib.nerfds_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(ModelCfg)]
   lib.nerfds_ctx_load_weights.argtypes = [C.c_void_p, C.POINTER(Weights)]
   lib.nerfds_render_rays.argtypes = [C.c_void_p, C.POINTER(Rays), C.POINTER(Extra), C.POINTER(Rand), C.POINTER(Out),
@@ -163,6 +164,8 @@ def load():
   lib.nerfds_kernel_time_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
   lib.nerfds_pack_stream_bytes.argtypes = [C.POINTER(ModelCfg), C.c_int, C.c_uint32]
   lib.nerfds_pack_stream_bytes.restype = C.c_int64
+  lib.nerfds_pack_stream_bytes_level.argtypes = [C.POINTER(ModelCfg), C.c_int, C.c_int, C.c_uint32]
+  lib.nerfds_pack_stream_bytes_level.restype = C.c_int64
   lib.nerfds_pack_tile_pair.argtypes = [C.POINTER(ModelCfg), C.c_uint32]
   lib.nerfds_pack_bias_floats.argtypes = [C.POINTER(ModelCfg), C.c_int]
   lib.nerfds_pack_bias_floats.restype = C.c_int64

@@ -155,6 +155,33 @@ def test_nerf_ds_trained_regime_and_deterministic_sampling():
         assert e <= (1e-4 if k == 'rgb' else 1e-3), (prec, level, k, e)
 
 
+@pytest.mark.parametrize('graph', ['nerf_ds', 'hypernerf'])
+def test_fine_level_parity_mode_on_both_two_level_graphs(graph):
+  """precision='bf16x3_fine': the coarse level's NerfMLP in one f16 MFMA per product, everything else split bf16.  Fine level (what render_fn
+  returns): every per-ray output at the parity bounds of the split-bf16 kernel; coarse level: the level-independent networks' outputs (split bf16
+  here too: the fine level reuses them) at parity bounds, the NerfMLP's (rgb, depth, acc) at the f16 kernel's."""
+  from nerfds_amd import hypernerf_config
+  mk = nerf_ds_config if graph == 'nerf_ds' else hypernerf_config
+  cfg = mk(num_warp_embeds=4, num_coarse_samples=16, num_fine_samples=16)
+  params = init_params(cfg, 2, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  R = 40
+  rays, rng = _rays(R, 4, 3)
+  t, u = rng.random((R, 16)), rng.random((R, 16))
+  ref = O.NerfModel(cfg, params).apply(rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=cfg.predict_norm, compute_sigma_gradient=False)
+  out = _model(cfg).apply({'params': params}, rays, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=cfg.predict_norm, precision='bf16x3_fine')
+  for k in ('rgb', 'depth', 'acc', 'ray_delta_x', 'ray_hyper_points', 'med_depth'):
+    e = _relerr(out['fine'][k].cpu().numpy(), ref['fine'][k].numpy())
+    print(f'bf16x3_fine {graph} fine {k}: {e:.2e}', file=sys.stderr)
+    assert e <= (1e-4 if k == 'rgb' else 1e-3), ('fine', k, e)
+  assert _pixerr(out['fine']['rgb'].cpu().numpy(), ref['fine']['rgb'].numpy()) <= 2e-4
+  for k in ('ray_delta_x', 'ray_hyper_points'):                  # warp field / hyper sheet at the coarse positions: split bf16 (weighted with f16-grade weights)
+    assert _relerr(out['coarse'][k].cpu().numpy(), ref['coarse'][k].numpy()) <= 4 * RTOL['f16'], k
+  for k in ('rgb', 'depth', 'acc'):
+    e = _relerr(out['coarse'][k].cpu().numpy(), ref['coarse'][k].numpy())
+    print(f'bf16x3_fine {graph} coarse {k}: {e:.2e}', file=sys.stderr)
+    assert e <= (RTOL['f16'] if k == 'rgb' else 4 * RTOL['f16']), ('coarse', k, e)
+
+
 @pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'f16', 'bf16', 'mixed'])
 def test_windows_partially_open(prec):
   """warp_alpha / nerf_alpha mid-schedule: fractional Hann windows on the top bands (model_utils.py:420-436)."""

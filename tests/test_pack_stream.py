@@ -49,9 +49,9 @@ def _pack(cfg, params, which, level, prec):
   lib = N.load()
   cs = _cfg_struct(cfg)
   holder = _WeightsHolder(cfg, params)
-  nb = lib.nerfds_pack_stream_bytes(C.byref(cs), which, N.PREC[prec])
+  nb = lib.nerfds_pack_stream_bytes_level(C.byref(cs), which, level, N.PREC[prec])
   nf = lib.nerfds_pack_bias_floats(C.byref(cs), which)
-  assert nb >= 0 and nf >= 0
+  assert 0 <= nb <= lib.nerfds_pack_stream_bytes(C.byref(cs), which, N.PREC[prec]) and nf >= 0
   w = np.zeros(max(nb, 1), np.uint8)
   b = np.zeros(max(nf, 1), np.float32)
   rc = lib.nerfds_pack_stream(C.byref(cs), C.byref(holder.struct), which, level, N.PREC[prec], w.ctypes.data, b.ctypes.data)
@@ -82,10 +82,14 @@ def _unchunk_tiles(ch):
 WTOL = {'f32': 1e-6, 'bf16x3': 3e-5, 'bf16': 2e-2, 'f16': 2.5e-3}      # weight rounding only (activations stay fp64 here)
 
 
-def _plan(prec):
-  """The per-network precisions of a NERFDS_PREC_* value, as the library was built (csrc/graphs.h plan_of)."""
+def _plan(prec, level=None):
+  """The per-network precisions of a NERFDS_PREC_* value, as the library was built (csrc/graphs.h plan_of); level: the plan the NerfMLP of that
+  level runs in (differs under 'bf16x3_fine' only: the coarse level's NerfMLP in one f16 MFMA per product)."""
   out = (C.c_int32 * 5)()
-  assert N.load().nerfds_precision_plan(N.PREC[prec], out) == 0
+  if level is None:
+    assert N.load().nerfds_precision_plan(N.PREC[prec], out) == 0
+  else:
+    assert N.load().nerfds_precision_plan_level(N.PREC[prec], level, out) == 0
   return dict(zip(('mask', 'warp', 'hyp', 'trunk', 'rgb'), (E.PREC_NAMES[v] for v in out)))
 
 
@@ -95,6 +99,12 @@ def test_precision_plans():
   mixed = _plan('mixed')
   assert mixed['trunk'] in ('f16', 'bf16') and mixed['warp'] in ('bf16x3', 'f32'), mixed   # one MFMA per product in the trunk
   assert N.load().nerfds_precision_plan(99, (C.c_int32 * 5)()) == -22
+  # 'bf16x3_fine': split bf16 everywhere but the coarse level's NerfMLP (the fine level sees only its compositing weights)
+  assert set(_plan('bf16x3_fine').values()) == {'bf16x3'} and set(_plan('bf16x3_fine', 1).values()) == {'bf16x3'}
+  c = _plan('bf16x3_fine', 0)
+  assert (c['trunk'], c['rgb']) == ('f16', 'f16') and (c['mask'], c['warp'], c['hyp']) == ('bf16x3',) * 3
+  for prec in ('bf16', 'bf16x3', 'f32', 'f16', 'mixed'):
+    assert _plan(prec, 0) == _plan(prec, 1) == _plan(prec)
 
 
 @pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
@@ -129,7 +139,7 @@ def test_shared_nets_stream_matches_oracle(prec):
   _assert_consumed(s)
 
 
-@pytest.mark.parametrize('prec', ['f32', 'mixed'])
+@pytest.mark.parametrize('prec', ['f32', 'mixed', 'bf16x3_fine'])
 @pytest.mark.parametrize('graph', ['nerf_ds', 'static', 'hypernerf'])
 @pytest.mark.parametrize('level', [0, 1])
 def test_nerf_mlp_stream_matches_oracle(graph, level, prec):
@@ -147,7 +157,7 @@ def test_nerf_mlp_stream_matches_oracle(graph, level, prec):
   rng = np.random.default_rng(1)
   n = 5
   s = _pack(cfg, p, 1, level, prec)
-  plan = _plan(prec)
+  plan = _plan(prec, level)
   pt, pr = plan['trunk'], plan['rgb']
   T = lambda a: torch.as_tensor(a, dtype=torch.float64)
   f = rng.normal(size=(n, cfg.trunk_in_dim))

@@ -129,6 +129,7 @@ def main():
   ap.add_argument('--chunk', type=int, default=8192)
   ap.add_argument('--modes', default='bf16x3,f16x3,f16mx8,bf16mx8,i8x2,i8x2u,f16w2,f16')
   ap.add_argument('--layers', action='store_true', help='layer granularity: every trunk layer / network alone in f16 (one MFMA), the rest split bf16')
+  ap.add_argument('--levels', action='store_true', help='level granularity: the COARSE NerfMLP alone in one MFMA (f16 / bf16), everything else split bf16 - what the fine level (the one render_fn returns) sees of a cheap coarse pass')
   ap.add_argument('--out', default=None)
   ap.add_argument('--device', default='cuda')
   args = ap.parse_args()
@@ -192,6 +193,10 @@ def main():
       plans.append((f'x3, {name} f16', sel, None))
     sel = {id(k): 'f16' for pth, k in walk(om.params) if 'trunk_mlp/hidden_' in pth and not pth.endswith('hidden_0')}
     plans.append(('x3, trunk hidden_1..7 f16', sel, None))
+  if args.levels:
+    for m in ('f16', 'bf16', 'f16w2'):
+      sel = {id(k): m for pth, k in walk(om.params) if pth.startswith('/nerf_mlps_coarse')}
+      plans.append((f'x3, coarse NerfMLP {m}', sel, None))
   for name, sel, cost in plans:
     t0 = time.time()
     got = render('bf16x3' if sel is not None else name, sel)

@@ -4,7 +4,7 @@ TAG=${1:-train_r2}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $GRAFT_REPO_ROOT/bench.py --train --steps 6 --warmup 3 --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $GRAFT_REPO_ROOT/bench.py --train --steps 6 --warmup 3 --no-cpu-baseline --no-full-objective > $OUT/trace.log 2>&1
 python - <<PY > $OUT/summary.txt
 import glob, sqlite3
 for db in glob.glob('$OUT/trace/**/*_results.db', recursive=True):

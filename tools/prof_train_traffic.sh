@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 STEPS=3; WARM=1
-CMD="python $GRAFT_REPO_ROOT/bench.py --train --steps $STEPS --warmup $WARM --no-cpu-baseline"
+CMD="python $GRAFT_REPO_ROOT/bench.py --train --steps $STEPS --warmup $WARM --no-cpu-baseline --no-full-objective"
 timeout 900 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $CMD > $OUT/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $CMD > $OUT/pmc_write.log 2>&1
 python - $OUT $((STEPS + WARM)) <<'PY' | tee $OUT/traffic.json
