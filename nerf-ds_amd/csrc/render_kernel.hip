@@ -17,6 +17,11 @@
 #include "field.h"
 #include "launch.h"
 
+// N-tiles per wave of the coarse NerfMLP under NERFDS_PREC_BF16X3_FINE (1: as every other evaluation of that kernel; A/B)
+#ifndef NERFDS_COARSE_NT
+#define NERFDS_COARSE_NT 2
+#endif
+
 namespace nerfds {
 
 // ------------------------------------------------------------------------------------------------
@@ -445,6 +450,31 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
       return sm;
     };
     // ---- coarse level: every network on every sample ----
+    if constexpr (PL::HAS_C && PP::HAS_SHARED && NT == 1 && NERFDS_COARSE_NT == 2) {
+      // NERFDS_PREC_BF16X3_FINE: the coarse NerfMLP runs one f16 MFMA per product, and at one MFMA per fragment a single N-tile is bound by the
+      // LDS reads of the weight ring (1 KiB per MFMA and wave, four waves: the CU's 128 B / clk).  So the level-independent networks (split bf16,
+      // 32 samples per wave and batch as everywhere) run first on ALL coarse samples of the ray, then the coarse NerfMLP takes TWO N-tiles per
+      // wave - 64 samples, a 64 + 64 ray's whole coarse level - per walk of its stream: every fragment read feeds two MFMAs, and the stream is
+      // staged (and its barriers paid) once per 64 samples instead of twice.
+      for (int sb = 0; sb < nc; sb += BATCH) {
+        const Samples<NT> sm = samples_at(sb + 32 * NT * q, nc);
+        pipe.cur = rs_shared; pipe.next = (sb + BATCH < nc) ? rs_shared : rs_nerf[0];
+        NERFDS_EVAL((eval_shared<G, PL, NT>(ka, rc, pipe, lane, sm, L)));
+      }
+      ray_sync();              // (wide shape: a wave's 64 NerfMLP samples include slots its partner wave has just written)
+      constexpr int NTC = 2, BATCHC = 32 * NTC * SPLIT;
+      for (int sb = 0; sb < nc; sb += BATCHC) {
+        Samples<NTC> smc;
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) {
+          const int sx = sb + 32 * NTC * q + 32 * nt + ln;
+          smc.slot[nt] = sx < nc ? sx : nc - 1;
+          smc.z[nt] = L.zs[smc.slot[nt]];
+        }
+        pipe.cur = rs_nerf[0]; pipe.next = (sb + BATCHC < nc) ? rs_nerf[0] : rs_shared;
+        NERFDS_EVAL((eval_nerf<G, PL, NTC, WaveLds, NoTrain, true>(ka, pipe, 0, lane, smc, L)));
+      }
+    } else {
     for (int sb = 0; sb < nc; sb += BATCH) {
       const Samples<NT> sm = samples_at(sb + 32 * NT * q, nc);
       if constexpr (PP::HAS_SHARED) { pipe.cur = rs_shared; pipe.next = rs_nerf[0]; }
@@ -453,6 +483,7 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
       if constexpr (PP::HAS_SHARED) pipe.next = rs_shared;      // another coarse batch, the fine level's new samples, or the next ray group
       else pipe.next = (sb + BATCH < nc) ? rs_nerf[0] : (nf > 0 ? rs_nerf[1] : rs_nerf[0]);
       NERFDS_EVAL((eval_nerf<G, PL, NT, WaveLds, NoTrain, PL::HAS_C>(ka, pipe, 0, lane, sm, L)));
+    }
     }
     ray_sync();
     if (q == 0) {
