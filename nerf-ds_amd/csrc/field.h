@@ -872,7 +872,8 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Chunk<PO> (&out)[NT][2 * OT], Ins&.
   constexpr bool BWD_IN = std::is_same_v<CUR, BwdInCursor>;
   constexpr bool BWD = std::is_same_v<CUR, BwdCursor> || BWD_IN;
   constexpr bool TRAIN = std::is_same_v<CUR, TrainCursor> || BWD;
-  static_assert(!TRAIN || (NT == 1 && !is_single(PO)), "the training kernels run two-unit plans: one N-tile, C++ epilogue");
+  static_assert(!TRAIN || (NT == 1 && (!is_single(PO) || (BWD && PO == P_F16))),
+                "the training kernels run two-unit plans (one N-tile, C++ epilogue); the backward chains of the TANGENT pass may run one f16 MFMA per product");
   static_assert(OT % TP == 0, "layers have an even number of 32-feature tiles");
   // (uniform one-unit plans only: in the mixed plan - f16 networks around a split-bf16 warp field - the asm epilogue build gave
   // run-to-run differences on ~1 % of the rays of the fine level; the C++ epilogue build of the same kernel is clean)
@@ -1052,7 +1053,7 @@ DEVI void dense(Pipe<G, PL>& pipe, CUR& cur, Chunk<PO> (&out)[NT][2 * OT], Ins&.
         }
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) tile_epilogue<PO, NT, false>(out, ot + tp, acc[tp]);
-        if constexpr (PO == P_BF16X3) {
+        if constexpr (PO == P_BF16X3 || PO == P_F16) {
           if (TRAIN_HALF) {
 #pragma unroll
             for (int tp = 0; tp < TP; ++tp) store_tile_g16(cur.row16 + 32 * (ot + tp), acc[tp][0]);

@@ -31,6 +31,7 @@ extern "C" void nerfds_launch_train_fwd16_nerfds(const nerfds::KArgs& ka, const 
 // train_bwd_kernel.hip: the data-gradient chain of one network (0 NerfMLP, 1 hyper sheet, 2 warp, 3 mask)
 extern "C" void nerfds_launch_train_bwd_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);      // g as fp32
 extern "C" void nerfds_launch_train_bwd16_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);    // g as scaled f16
+extern "C" void nerfds_launch_train_bwd16f_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);   // the same chains in one f16 MFMA per product (tangent pass only)
 extern "C" void nerfds_launch_train_tan16_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);    // tangent forward chains (train_bwd_kernel.hip)
 
 using namespace nerfds_train;
@@ -148,6 +149,10 @@ struct nerfds_trainer {
   int* amap[2] = {nullptr, nullptr};
   void* astream[2] = {nullptr, nullptr};
   int afrags[2] = {0, 0};
+  // the reversed streams of the tangent pass's backward as ONE f16 unit per fragment: [trunk + alpha coarse, fine, hyper, warp] (tan_bwd_f16: the
+  // second-order terms' data-gradient chains in one f16 MFMA per product; NERFDS_TRAIN_TAN_BWD_F16=0: split bf16 like the primal chains)
+  bool tan_bwd_f16 = false;
+  void* bstream16[4] = {nullptr, nullptr, nullptr, nullptr};
   uint16_t* tws16 = nullptr;      // the tangents (allocated on first use)
   uint16_t* gws16 = nullptr;      // their cotangents (allocated on first use by a step that differentiates the tangent pass)
   std::vector<uint16_t*> tw16, th16, tt16, gw16, gh16, gt16;
@@ -190,6 +195,7 @@ struct nerfds_trainer {
     for (uint16_t* p : {tws16, gws16}) if (p) (void)hipFree(p);
     for (int i = 0; i < 4; ++i) { if (tmap[i]) (void)hipFree(tmap[i]); if (tstream[i]) (void)hipFree(tstream[i]); }
     for (int i = 0; i < 2; ++i) { if (amap[i]) (void)hipFree(amap[i]); if (astream[i]) (void)hipFree(astream[i]); }
+    for (int i = 0; i < 4; ++i) if (bstream16[i]) (void)hipFree(bstream16[i]);
     if (adam_dev) (void)hipFree(adam_dev);
     if (wpack) (void)hipFree(wpack);
     if (grad_rep) (void)hipFree(grad_rep);
@@ -831,6 +837,13 @@ bool build_fused_backward(nerfds_trainer& t) {
       if (!upload(w, &t.amap[lv], &t.astream[lv], &t.afrags[lv])) return false;
     }
     if (hipMalloc(&t.tan_slot, 16 * sizeof(float)) != hipSuccess) return false;
+    static const bool f16_on = !(getenv("NERFDS_TRAIN_TAN_BWD_F16") && std::string(getenv("NERFDS_TRAIN_TAN_BWD_F16")) == "0");
+    if (f16_on) {
+      const int fr[4] = {t.afrags[0], t.afrags[1], t.bfrags[2], t.bfrags[3]};
+      for (int i = 0; i < 4; ++i)
+        if (fr[i] > 0 && hipMalloc(&t.bstream16[i], (size_t)fr[i] * 1024) != hipSuccess) return false;
+      t.tan_bwd_f16 = true;
+    }
     t.fused_tan = true;
   }
   // f16 activations + ReLU bits of every hidden layer (one allocation), the sink of the input-gradient stores
@@ -866,6 +879,12 @@ void pack_fused_tangents(nerfds_trainer& t, hipStream_t st) {
     if (t.tmap[which]) pack_stream(st, t.theta, t.fold, t.P, t.tmap[which], t.tstream[which], t.tfrags[which], 0, 0);
   for (int lv = 0; lv < 2; ++lv)
     if (t.amap[lv]) pack_stream(st, t.theta, t.fold, t.P, t.amap[lv], t.astream[lv], t.afrags[lv], 0, 0);
+  if (t.tan_bwd_f16) {      // the same maps, one f16 unit per fragment (k_pack_stream mode 2)
+    for (int lv = 0; lv < 2; ++lv)
+      if (t.amap[lv]) pack_stream(st, t.theta, t.fold, t.P, t.amap[lv], t.bstream16[lv], t.afrags[lv], 0, 0, 2);
+    pack_stream(st, t.theta, t.fold, t.P, t.bmap[2], t.bstream16[2], t.bfrags[2], 0, 0, 2);
+    pack_stream(st, t.theta, t.fold, t.P, t.bmap[3], t.bstream16[3], t.bfrags[3], 0, 0, 2);
+  }
 }
 // f16 [3 M][width] per hidden layer of warp field, hyper sheet, trunk: the tangents (ensure_tan16: `all` = one array per layer - a step that
 // differentiates the tangent pass reads them as X of its weight gradients; otherwise ONE array per network that every layer overwrites: the
@@ -918,11 +937,16 @@ void fused_tangent_backward(nerfds_trainer& t, hipStream_t st, int net, int leve
   tb.g_half = 1; tb.g_scale = 1.f; tb.g_inv_scale = 1.f; tb.scale_dev = slot + 1; tb.mask_div = 3;
   const std::vector<uint16_t*>* bits = nullptr;
   const std::vector<uint16_t*>* store = nullptr;
-  if (net == 1) { tb.wstream = t.bstream[2]; bits = &t.hyper_bits; store = &t.gh16; }
-  else if (net == 2) { tb.wstream = t.bstream[3]; bits = &t.warp_bits; store = &t.gw16; }
-  else { tb.wstream = t.astream[level]; bits = &t.trunk_bits; store = &t.gt16; }
+  const bool f16 = t.tan_bwd_f16;
+  if (net == 1) { tb.wstream = f16 ? t.bstream16[2] : t.bstream[2]; bits = &t.hyper_bits; store = &t.gh16; }
+  else if (net == 2) { tb.wstream = f16 ? t.bstream16[3] : t.bstream[3]; bits = &t.warp_bits; store = &t.gw16; }
+  else { tb.wstream = f16 ? t.bstream16[level] : t.astream[level]; bits = &t.trunk_bits; store = &t.gt16; }
   for (size_t l = 0; l < bits->size(); ++l) { tb.bits[l] = (*bits)[l]; tb.g[l] = reinterpret_cast<float*>((*store)[l]); }
-  nerfds_launch_train_bwd16_nerfds(tb, net, t.num_cus, st);
+  // The backward of the tangent pass carries the SECOND-ORDER terms' gradients only (norm loss, elastic regulariser).  Its chains hand every g to the
+  // weight gradients as f16 anyway; run in one f16 MFMA per product they also PROPAGATE it at 11 bits per layer - measured on the gradient tests of
+  // those terms (bounds unchanged) - at a third of the MFMAs.  The primal chains and the tangent FORWARD (target_norm) stay split bf16.
+  if (f16) nerfds_launch_train_bwd16f_nerfds(tb, net, t.num_cus, st);
+  else nerfds_launch_train_bwd16_nerfds(tb, net, t.num_cus, st);
 }
 
 // the data-gradient chain of one network: net 0 NerfMLP of `level`, 1 hyper sheet, 2 warp field, 3 mask net

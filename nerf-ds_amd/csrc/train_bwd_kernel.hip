@@ -42,7 +42,9 @@ DEVI void bwd_input(Pipe<BG, PL>& pipe, BwdCursor& cur, float* in_row, int acc, 
 
 template <class BG, class PL>
 DEVI void bwd_chain(const TrainBwd& tb, Pipe<BG, PL>& pipe, int lane, long long r, int live) {
-  constexpr int W = BG::W, D = BG::DEPTH, W16 = W / 16, W32 = W / 32, P = P_BF16X3, MW = W / 64;
+  // P: split bf16 - or, for the backward of the TANGENT pass (second-order terms only; launch_bwd<BG, true>), one f16 MFMA per product
+  constexpr int W = BG::W, D = BG::DEPTH, W16 = W / 16, W32 = W / 32, P = PL::TRUNK, MW = W / 64;
+  static_assert(P == P_BF16X3 || P == P_F16, "chain arithmetic");
   static_assert(BG::SKIP == 4 && (D == 8 || D == 6) && W % 64 == 0, "chains are written out for depth 8 / 6, skip 4");
   const int h = lane >> 5;
   BwdCursor cur;
@@ -184,9 +186,10 @@ __global__ __launch_bounds__(64 * BG::WG_WAVES) void train_backward_kernel(const
 
 }  // namespace nerfds
 
-template <class BG> static void launch_bwd(const nerfds::TrainBwd& tb, int num_cus, void* stream) {
+template <class BG, bool F16 = false> static void launch_bwd(const nerfds::TrainBwd& tb, int num_cus, void* stream) {
   using namespace nerfds;
-  using PLX = PlanT<P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3>;      // the data-gradient chains: split bf16 throughout
+  // the data-gradient chains: split bf16 throughout; F16: one f16 MFMA per product (the tangent pass's backward, nerfds_train.cpp)
+  using PLX = std::conditional_t<F16, PlanT<P_F16, P_F16, P_F16, P_F16, P_F16>, PlanT<P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3>>;
   auto kern = train_backward_kernel<BG, PLX, TRAIN_TAG>;
   allow_dynamic_lds(reinterpret_cast<const void*>(kern), RING_BYTES);
   constexpr int WAVES = BG::WG_WAVES, ROWS = 32 * WAVES;
@@ -208,6 +211,13 @@ extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::TrainBwd& 
 }
 
 #if NERFDS_TRAIN_HALF
+// the backward chains of the tangent pass in one f16 MFMA per product: net 1 hyper sheet, 2 warp field, 4 trunk + alpha head (f16-store build only)
+extern "C" void nerfds_launch_train_bwd16f_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream) {
+  using G = nerfds::NERFDS_GRAPH;
+  if (net == 1) launch_bwd<nerfds::BwdHyper<G>, true>(tb, num_cus, stream);
+  else if (net == 2) launch_bwd<nerfds::BwdWarp<G>, true>(tb, num_cus, stream);
+  else launch_bwd<nerfds::BwdTrunkAlpha<G>, true>(tb, num_cus, stream);
+}
 template <class TG> static void launch_tan(const nerfds::TrainBwd& tb, int num_cus, void* stream) {
   using namespace nerfds;
   using PLX = PlanT<P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3>;

@@ -1310,6 +1310,14 @@ __global__ void k_pack_stream(const float* __restrict__ theta, const float* __re
   float v[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = map_value(theta, fold, P, mi[i]);
+  if (wide_f32 == 2) {                                    // ONE f16 unit per fragment (graphs.h P_F16): the tangent pass's backward chains
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 hv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hv[i] = (_Float16)v[i];
+    *reinterpret_cast<h8*>(stream + (size_t)frag * 1024 + lane * 16) = hv;
+    return;
+  }
   if (wide_f32 && frag >= x6_lo && frag < x6_hi) {        // the range keeps exact fp32: k-slots 0-3 | 4-7 (graphs.h P_F32), two units
     unsigned char* ff = stream + (size_t)frag * 2048 + lane * 16;
     *reinterpret_cast<float4*>(ff) = make_float4(v[0], v[1], v[2], v[3]);
