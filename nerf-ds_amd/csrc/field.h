@@ -304,6 +304,7 @@ template <class G, class PL> struct Pipe {
   u32x4 ring[RD];
 #ifdef NERFDS_PROF
   unsigned long long t_chain = 0, t_eval = 0, t_ray = 0;      // measurement build: cycles inside the layer chains / the field evaluations / compositing + resampling
+  unsigned long long t_wait = 0, t_bar = 0, n_bound = 0;       // -DNERFDS_PROF_BOUND: cycles in the stage boundaries' s_waitcnt / s_barrier (+ one timer read each), boundaries
 #endif
   rsrc_t cur;       // stream of the segment being walked
   rsrc_t next;      // stream of the segment walked next (wrap-around prefetch)
@@ -356,6 +357,10 @@ template <class G, class PL> struct Pipe {
 #pragma unroll
     for (int t = s + 2; t <= s + NS - 2; ++t)
       if (t >= seg_stages(seg) || t < seg_used(seg)) young += PIECES;
+#ifdef NERFDS_PROF_BOUND
+    unsigned long long pb0, pb1, pb2;
+    asm volatile("s_memtime %0" : "=s"(pb0) :: "memory");        // (valid behind the lgkmcnt(0) below)
+#endif
     // (A counted lgkmcnt in the pinned chains - the 8 youngest ring reads left in flight, safe there because program order is source order -
     // measured +-0 against the full drain: 38.25 against 38.26 ms per 65 536 rays, profiles/r4_ab/ab_x3_pin_variants.txt; not kept.)
     if (young == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -368,7 +373,14 @@ template <class G, class PL> struct Pipe {
     else if (young == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
     else if (young == 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
     else __builtin_trap();                       // (a count this list does not spell out)
+#ifdef NERFDS_PROF_BOUND
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pb1) :: "memory");
+#endif
     __builtin_amdgcn_s_barrier();      // raw barrier (no compiler-added fences)
+#ifdef NERFDS_PROF_BOUND
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pb2) :: "memory");
+    t_wait += pb1 - pb0; t_bar += pb2 - pb1; n_bound += 1;
+#endif
     // SPREAD_DMA: the pieces of stage s + NS - 1 are issued one by one between the MFMAs of stage s (spread_piece) instead of
     // back to back behind the barrier, where nothing covers their issue time (a hole stage has no MFMAs: issued here)
     if (!SPREAD_DMA || s >= seg_used(seg)) issue_stage(seg, s + NS - 1);
@@ -398,6 +410,15 @@ template <class G, class PL> struct Pipe {
   }
   // unit u has been consumed (or skipped): its ring slot takes unit u + RD (stage (u / SU) + 1 is resident)
   DEVI void refill(int seg, int u) {
+#if defined(NERFDS_EXP_LO)
+    // measurement builds (wrong or unchecked results, never shipped): what the LDS read of every second unit costs (1: not read at all), and the
+    // same unit fetched with a vector load from the stream in L2 instead of from its LDS copy (2)
+    if (X3_INTERLEAVE && (u & 1)) {
+      if (NERFDS_EXP_LO == 2 && (u + RD) / SU < seg_used(seg))
+        ring[u % RD] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(cur, lane16, (u + RD) * 1024, 0));
+      return;
+    }
+#endif
     if ((u + RD) / SU < seg_used(seg)) ring[u % RD] = unit(u + RD);
   }
   template <int P> DEVI WFrag<P> frag(int u) const {

@@ -514,6 +514,8 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
                               "compositing (both levels) %.1f%%  resampling: pdf / cdf / bins %.1f%%, inverse cdf %.1f%%, rank sort %.1f%%, state move %.1f%%  rest (ray setup, syncs) %.1f%%\n", (long long)rays->num_rays, p[3],
                       (double)p[0] / p[3], 100.0 * p[1] / p[0], 100.0 * ((double)p[2] - (double)p[1]) / p[0], 100.0 * p[4] / p[0], 100.0 * p[5] / p[0], 100.0 * p[6] / p[0], 100.0 * p[7] / p[0],
                       100.0 * p[8] / p[0], 100.0 * ((double)p[0] - (double)p[2] - (double)p[4] - (double)(p[5] + p[6] + p[7] + p[8])) / p[0]);
+    if (p[11]) fprintf(stderr, "NERFDS_PROF_BOUND stage boundaries per wave %.0f: s_waitcnt %.1f cycles each (%.1f%% of the wave), s_barrier + one timer read %.1f cycles each (%.1f%%)\n",
+                       (double)p[11] / p[3], (double)p[9] / p[11], 100.0 * p[9] / p[0], (double)p[10] / p[11], 100.0 * p[10] / p[0]);
   }
 #endif
   return NERFDS_OK;

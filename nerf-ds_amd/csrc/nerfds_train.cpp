@@ -33,6 +33,7 @@ extern "C" void nerfds_launch_train_bwd_nerfds(const nerfds::TrainBwd& tb, int n
 extern "C" void nerfds_launch_train_bwd16_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);    // g as scaled f16
 extern "C" void nerfds_launch_train_bwd16f_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);   // the same chains in one f16 MFMA per product (tangent pass only)
 extern "C" void nerfds_launch_train_tan16_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream);    // tangent forward chains (train_bwd_kernel.hip)
+extern "C" void nerfds_launch_train_tan16f_nerfds(const nerfds::TrainBwd& tb, int num_cus, void* stream);            // the trunk's, one f16 MFMA per product
 
 using namespace nerfds_train;
 
@@ -153,6 +154,9 @@ struct nerfds_trainer {
   // second-order terms' data-gradient chains in one f16 MFMA per product; NERFDS_TRAIN_TAN_BWD_F16=0: split bf16 like the primal chains)
   bool tan_bwd_f16 = false;
   void* bstream16[4] = {nullptr, nullptr, nullptr, nullptr};
+  // the trunk's tangent FORWARD stream of each level as one f16 unit per fragment (tan_fwd_f16: NERFDS_TRAIN_TAN_FWD_F16=1, training steps only)
+  bool tan_fwd_f16 = false;
+  void* tstream16[2] = {nullptr, nullptr};
   uint16_t* tws16 = nullptr;      // the tangents (allocated on first use)
   uint16_t* gws16 = nullptr;      // their cotangents (allocated on first use by a step that differentiates the tangent pass)
   std::vector<uint16_t*> tw16, th16, tt16, gw16, gh16, gt16;
@@ -196,6 +200,7 @@ struct nerfds_trainer {
     for (int i = 0; i < 4; ++i) { if (tmap[i]) (void)hipFree(tmap[i]); if (tstream[i]) (void)hipFree(tstream[i]); }
     for (int i = 0; i < 2; ++i) { if (amap[i]) (void)hipFree(amap[i]); if (astream[i]) (void)hipFree(astream[i]); }
     for (int i = 0; i < 4; ++i) if (bstream16[i]) (void)hipFree(bstream16[i]);
+    for (int i = 0; i < 2; ++i) if (tstream16[i]) (void)hipFree(tstream16[i]);
     if (adam_dev) (void)hipFree(adam_dev);
     if (wpack) (void)hipFree(wpack);
     if (grad_rep) (void)hipFree(grad_rep);
@@ -837,12 +842,23 @@ bool build_fused_backward(nerfds_trainer& t) {
       if (!upload(w, &t.amap[lv], &t.astream[lv], &t.afrags[lv])) return false;
     }
     if (hipMalloc(&t.tan_slot, 16 * sizeof(float)) != hipSuccess) return false;
+    // a one-unit-per-fragment stream of `frags` fragments, zero-padded to whole stages (the kernel's descriptor covers pad_units(frags) units)
+    auto alloc16 = [](void** p, int frags) {
+      const size_t bytes = (size_t)nerfds::pad_units(frags) * 1024;
+      return hipMalloc(p, bytes) == hipSuccess && hipMemset(*p, 0, bytes) == hipSuccess;
+    };
     static const bool f16_on = !(getenv("NERFDS_TRAIN_TAN_BWD_F16") && std::string(getenv("NERFDS_TRAIN_TAN_BWD_F16")) == "0");
     if (f16_on) {
       const int fr[4] = {t.afrags[0], t.afrags[1], t.bfrags[2], t.bfrags[3]};
       for (int i = 0; i < 4; ++i)
-        if (fr[i] > 0 && hipMalloc(&t.bstream16[i], (size_t)fr[i] * 1024) != hipSuccess) return false;
+        if (fr[i] > 0 && !alloc16(&t.bstream16[i], fr[i])) return false;
       t.tan_bwd_f16 = true;
+    }
+    static const bool f16_fwd = getenv("NERFDS_TRAIN_TAN_FWD_F16") && std::string(getenv("NERFDS_TRAIN_TAN_FWD_F16")) == "1";
+    if (f16_fwd) {
+      for (int i = 0; i < levels; ++i)
+        if (!alloc16(&t.tstream16[i], t.tfrags[i])) return false;
+      t.tan_fwd_f16 = true;
     }
     t.fused_tan = true;
   }
@@ -879,6 +895,9 @@ void pack_fused_tangents(nerfds_trainer& t, hipStream_t st) {
     if (t.tmap[which]) pack_stream(st, t.theta, t.fold, t.P, t.tmap[which], t.tstream[which], t.tfrags[which], 0, 0);
   for (int lv = 0; lv < 2; ++lv)
     if (t.amap[lv]) pack_stream(st, t.theta, t.fold, t.P, t.amap[lv], t.astream[lv], t.afrags[lv], 0, 0);
+  if (t.tan_fwd_f16)
+    for (int lv = 0; lv < 2; ++lv)
+      if (t.tstream16[lv]) pack_stream(st, t.theta, t.fold, t.P, t.tmap[lv], t.tstream16[lv], t.tfrags[lv], 0, 0, 2);
   if (t.tan_bwd_f16) {      // the same maps, one f16 unit per fragment (k_pack_stream mode 2)
     for (int lv = 0; lv < 2; ++lv)
       if (t.amap[lv]) pack_stream(st, t.theta, t.fold, t.P, t.amap[lv], t.bstream16[lv], t.afrags[lv], 0, 0, 2);
@@ -925,7 +944,9 @@ void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_
   else if (net == 2) { tb.wstream = t.tstream[3]; bits = &t.warp_bits; store = &t.tw16; }
   else { tb.wstream = t.tstream[level]; bits = &t.trunk_bits; store = &t.tt16; }
   for (size_t l = 0; l < bits->size(); ++l) { tb.bits[l] = (*bits)[l]; tb.g[l] = reinterpret_cast<float*>((*store)[l]); }
-  nerfds_launch_train_tan16_nerfds(tb, net, t.num_cus, st);
+  // (experiment, off: the trunk's chain of a step that differentiates the tangent pass in one f16 MFMA per product - see profiles/r5_ab/README.md)
+  if (net == 4 && t.tan_fwd_f16 && t.keep_tangents) { tb.wstream = t.tstream16[level]; nerfds_launch_train_tan16f_nerfds(tb, t.num_cus, st); }
+  else nerfds_launch_train_tan16_nerfds(tb, net, t.num_cus, st);
 }
 // data-gradient chain of the TANGENT pass: cotangent of the head's tangent [3 M][ld_head] (its scale picked on the device: slot) -> g of every hidden
 // tangent (f16, store16) and, if d_in, the cotangent of the raw tangent input [3 M][ld_in]

@@ -541,6 +541,7 @@ __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void rende
       atomicAdd(ka.prof + 0, total); atomicAdd(ka.prof + 1, pipe.t_chain); atomicAdd(ka.prof + 2, pipe.t_eval); atomicAdd(ka.prof + 3, 1ull);
       atomicAdd(ka.prof + 4, pipe.t_ray);
       for (int k = 0; k < 4; ++k) atomicAdd(ka.prof + 5 + k, prof_rs[k]);
+      atomicAdd(ka.prof + 9, pipe.t_wait); atomicAdd(ka.prof + 10, pipe.t_bar); atomicAdd(ka.prof + 11, pipe.n_bound);
     }
   }
 #endif

@@ -107,7 +107,9 @@ DEVI void bwd_chain(const TrainBwd& tb, Pipe<BG, PL>& pipe, int lane, long long 
 #if NERFDS_TRAIN_HALF
 template <class TG, class PL>
 DEVI void tan_chain(const TrainBwd& tb, Pipe<TG, PL>& pipe, int lane, long long r) {
-  constexpr int W = TG::W, D = TG::DEPTH, W16 = W / 16, W32 = W / 32, P = P_BF16X3, MW = W / 64, KC = TG::IN_KC;
+  // P: split bf16 - or (launch_tan<TG, true>: experiment NERFDS_TRAIN_TAN_FWD_F16, nerfds_train.cpp) one f16 MFMA per product
+  constexpr int W = TG::W, D = TG::DEPTH, W16 = W / 16, W32 = W / 32, P = PL::TRUNK, MW = W / 64, KC = TG::IN_KC;
+  static_assert(P == P_BF16X3 || P == P_F16, "chain arithmetic");
   static_assert(TG::SKIP == 4 && (D == 8 || D == 6) && W % 64 == 0 && TG::NHEAD <= 16, "chains are written out for depth 8 / 6, skip 4");
   const int h = lane >> 5;
   BwdCursor cur;
@@ -218,9 +220,9 @@ extern "C" void nerfds_launch_train_bwd16f_nerfds(const nerfds::TrainBwd& tb, in
   else if (net == 2) launch_bwd<nerfds::BwdWarp<G>, true>(tb, num_cus, stream);
   else launch_bwd<nerfds::BwdTrunkAlpha<G>, true>(tb, num_cus, stream);
 }
-template <class TG> static void launch_tan(const nerfds::TrainBwd& tb, int num_cus, void* stream) {
+template <class TG, bool F16 = false> static void launch_tan(const nerfds::TrainBwd& tb, int num_cus, void* stream) {
   using namespace nerfds;
-  using PLX = PlanT<P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3>;
+  using PLX = std::conditional_t<F16, PlanT<P_F16, P_F16, P_F16, P_F16, P_F16>, PlanT<P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3>>;
   auto kern = train_tangent_kernel<TG, PLX, TRAIN_TAG>;
   allow_dynamic_lds(reinterpret_cast<const void*>(kern), RING_BYTES);
   constexpr int WAVES = TG::WG_WAVES, ROWS = 32 * WAVES;
@@ -234,5 +236,9 @@ extern "C" void nerfds_launch_train_tan16_nerfds(const nerfds::TrainBwd& tb, int
   if (net == 1) launch_tan<nerfds::TanHyper<G>>(tb, num_cus, stream);
   else if (net == 2) launch_tan<nerfds::TanWarp<G>>(tb, num_cus, stream);
   else launch_tan<nerfds::TanTrunk<G>>(tb, num_cus, stream);
+}
+// the trunk's tangent forward chain in one f16 MFMA per product (a training step that differentiates the tangent pass; never the rendered target_norm)
+extern "C" void nerfds_launch_train_tan16f_nerfds(const nerfds::TrainBwd& tb, int num_cus, void* stream) {
+  launch_tan<nerfds::TanTrunk<nerfds::NERFDS_GRAPH>, true>(tb, num_cus, stream);
 }
 #endif

@@ -256,26 +256,34 @@ __device__ __forceinline__ Dual operator/(const Dual& a, const Dual& b) {
 }
 __device__ __forceinline__ Dual operator*(const Dual& a, float b) { Dual r; r.v = a.v * b; for (int i = 0; i < 6; ++i) r.g[i] = a.g[i] * b; return r; }
 __device__ __forceinline__ Dual dsqrt(const Dual& a) { Dual r; r.v = sqrtf(a.v); const float k = 0.5f / r.v; for (int i = 0; i < 6; ++i) r.g[i] = a.g[i] * k; return r; }
-__device__ __forceinline__ Dual dsin(const Dual& a) { Dual r; r.v = sinf(a.v); const float k = cosf(a.v); for (int i = 0; i < 6; ++i) r.g[i] = a.g[i] * k; return r; }
-__device__ __forceinline__ Dual dcos(const Dual& a) { Dual r; r.v = cosf(a.v); const float k = -sinf(a.v); for (int i = 0; i < 6; ++i) r.g[i] = a.g[i] * k; return r; }
 __device__ __forceinline__ float dsqrt(float a) { return sqrtf(a); }
-__device__ __forceinline__ float dsin(float a) { return sinf(a); }
-__device__ __forceinline__ float dcos(float a) { return cosf(a); }
 __device__ __forceinline__ float tconst(float c, const float*) { return c; }
 __device__ __forceinline__ Dual tconst(float c, const Dual*) { return dconst(c); }
+// sin / cos of a (nested) dual whose innermost value is a0, given s = sinf(a0), c = cosf(a0): the same numbers dsin / dcos produce (every level of a
+// nested dual evaluates sinf / cosf on the SAME a0), with the two libm calls made once by the caller instead of once per level and component
+__device__ __forceinline__ float base_of(float a) { return a; }
+__device__ __forceinline__ float base_of(const Dual& a) { return a.v; }
+__device__ __forceinline__ float dsin_sc(float, float s, float) { return s; }
+__device__ __forceinline__ float dcos_sc(float, float, float c) { return c; }
+__device__ __forceinline__ Dual dsin_sc(const Dual& a, float s, float c) { Dual r; r.v = s; for (int i = 0; i < 6; ++i) r.g[i] = a.g[i] * c; return r; }
+__device__ __forceinline__ Dual dcos_sc(const Dual& a, float s, float c) { Dual r; r.v = c; const float k = -s; for (int i = 0; i < 6; ++i) r.g[i] = a.g[i] * k; return r; }
 
 // R (row major) and p of exp_se3 for raw head outputs (w, v)
 template <class T> __device__ void se3_Rp(const T (&w_raw)[3], const T (&v_raw)[3], T (&Rm)[9], T (&p)[3]) {
   const T* tag = nullptr;
   const T theta = dsqrt(w_raw[0] * w_raw[0] + w_raw[1] * w_raw[1] + w_raw[2] * w_raw[2]);      // no epsilon, as the reference
   T w[3], v[3];
+#pragma unroll
   for (int i = 0; i < 3; ++i) { w[i] = w_raw[i] / theta; v[i] = v_raw[i] / theta; }
-  const T st = dsin(theta), ct = dcos(theta);
+  const float th0 = base_of(theta), s0 = sinf(th0), c0 = cosf(th0);
+  const T st = dsin_sc(theta, s0, c0), ct = dcos_sc(theta, s0, c0);
   const T one = tconst(1.0f, tag), zero = tconst(0.0f, tag);
   const T omc = one - ct, tms = theta - st;
   const T W[9] = {zero, -w[2], w[1], w[2], zero, -w[0], -w[1], w[0], zero};
+#pragma unroll
   for (int r = 0; r < 3; ++r) {
     T g[3];
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
       const T w2 = W[3 * r] * W[c] + W[3 * r + 1] * W[3 + c] + W[3 * r + 2] * W[6 + c];
       const T id = (r == c) ? one : zero;
@@ -567,53 +575,72 @@ template <class T> __device__ __forceinline__ D1<T> operator/(const D1<T>& a, co
 }
 template <class T> __device__ __forceinline__ D1<T> operator*(const D1<T>& a, float b) { return {a.v * b, a.d * b}; }
 template <class T> __device__ __forceinline__ D1<T> dsqrt(const D1<T>& a) { const T r = dsqrt(a.v); return {r, a.d / (r + r)}; }
-template <class T> __device__ __forceinline__ D1<T> dsin(const D1<T>& a) { return {dsin(a.v), a.d * dcos(a.v)}; }
-template <class T> __device__ __forceinline__ D1<T> dcos(const D1<T>& a) { return {dcos(a.v), -(a.d * dsin(a.v))}; }
-__device__ __forceinline__ D1<Dual> tconst(float c, const D1<Dual>*) { return {dconst(c), dconst(0.f)}; }
+template <class T> __device__ __forceinline__ float base_of(const D1<T>& a) { return base_of(a.v); }
+template <class T> __device__ __forceinline__ D1<T> dsin_sc(const D1<T>& a, float s, float c) { return {dsin_sc(a.v, s, c), a.d * dcos_sc(a.v, s, c)}; }
+template <class T> __device__ __forceinline__ D1<T> dcos_sc(const D1<T>& a, float s, float c) { return {dcos_sc(a.v, s, c), -(a.d * dsin_sc(a.v, s, c))}; }
+template <class T> __device__ __forceinline__ D1<T> tconst(float c, const D1<T>*) { return {tconst(c, (const T*)nullptr), tconst(0.f, (const T*)nullptr)}; }
 
 // backward of k_se3_jvp (t_xw_j = R e_j + J t_wv_j) for upstream a_j = d t_xw_j, plus the rotation used by target_norm (<du, R ghat>):
 //   d t_wv_j = J^T a_j,   d (w, v) += grad_{(w,v)} [ sum_j <a_j, R e_j + DF[t_wv_j]> + <du, R ghat> ]     (second derivatives of exp_se3)
+// One thread per (sample, direction i of (w, v)): component i of every gradient above is a derivative along e_i, so the thread runs exp_se3 on
+// single-direction duals - D1<float> seeded with e_i for the first-order pieces, D1<D1<float>> (outer: along t_wv_j, inner: along e_i) for the
+// second-order one - 2 and 4 floats per scalar.  (Until round 5's end one thread per sample carried all six directions at once, 7 and 14 floats per
+// scalar: 256 registers, 403 spilled, 1.5 KiB of scratch per lane, one wave per SIMD.)
+// Measured alone (one stream, both levels of a 4096-ray step): 1.53 ms before, 0.67 ms now; held to two or four waves per SIMD the compiler spills to
+// scratch (228 - 908 bytes per lane) and the kernel is SLOWER than before (1.63 ms at two) - it is left the whole register file.
 __global__ __launch_bounds__(256) void k_se3_jvp_bwd(long long M, const float* __restrict__ wv, const float* __restrict__ x, const float* __restrict__ t_wv,
                               const float* __restrict__ d_t_xw, const float* __restrict__ du, const float* __restrict__ ghat,
                               float* __restrict__ d_t_wv, float* __restrict__ dwv_extra) {
-  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (m >= M) return;
-  float extra[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  {  // first-order pieces from the 6-direction dual
-    Dual w[3], v[3];
-    for (int i = 0; i < 3; ++i) { w[i] = dconst(wv[6 * m + i]); w[i].g[i] = 1.f; v[i] = dconst(wv[6 * m + 3 + i]); v[i].g[3 + i] = 1.f; }
-    Dual Rm[9], p[3];
-    se3_Rp<Dual>(w, v, Rm, p);
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= 6 * M) return;
+  const long long m = idx / 6;
+  const int i = (int)(idx - 6 * m);
+  const float xs[3] = {x[3 * m], x[3 * m + 1], x[3 * m + 2]};
+  float wvs[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) wvs[k] = wv[6 * m + k];
+  float extra = 0.f;
+  {  // first-order pieces: d / d (w, v)_i of x' and of R
+    D1<float> w[3], v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { w[k] = {wvs[k], i == k ? 1.f : 0.f}; v[k] = {wvs[3 + k], i == 3 + k ? 1.f : 0.f}; }
+    D1<float> Rm[9], p[3];
+    se3_Rp<D1<float>>(w, v, Rm, p);
+    float xd[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) xd[r] = (Rm[3 * r] * xs[0] + Rm[3 * r + 1] * xs[1] + Rm[3 * r + 2] * xs[2] + p[r]).d;
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
-      float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float acc = 0.f;
+#pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const Dual xr = Rm[3 * r] * x[3 * m] + Rm[3 * r + 1] * x[3 * m + 1] + Rm[3 * r + 2] * x[3 * m + 2] + p[r];
         const float a = d_t_xw[(3 * m + j) * 3 + r];
-        for (int i = 0; i < 6; ++i) { acc[i] += a * xr.g[i]; extra[i] += a * Rm[3 * r + j].g[i]; }     // J^T a_j ; grad <a_j, R e_j>
+        acc += a * xd[r]; extra += a * Rm[3 * r + j].d;                                              // J^T a_j ; grad <a_j, R e_j>
       }
-      for (int i = 0; i < 6; ++i) d_t_wv[(3 * m + j) * 6 + i] = acc[i];
+      d_t_wv[(3 * m + j) * 6 + i] = acc;
     }
+#pragma unroll
     for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) {
-        const float k = du[3 * m + r] * ghat[3 * m + c];
-        for (int i = 0; i < 6; ++i) extra[i] += k * Rm[3 * r + c].g[i];                                  // grad <du, R ghat>
-      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) extra += du[3 * m + r] * ghat[3 * m + c] * Rm[3 * r + c].d;           // grad <du, R ghat>
   }
-  for (int j = 0; j < 3; ++j) {  // grad_{(w,v)} <a_j, DF[t_wv_j]>: the directional derivative along t_wv_j, differentiated again
-    D1<Dual> w[3], v[3];
-    for (int i = 0; i < 3; ++i) {
-      w[i].v = dconst(wv[6 * m + i]); w[i].v.g[i] = 1.f; w[i].d = dconst(t_wv[(3 * m + j) * 6 + i]);
-      v[i].v = dconst(wv[6 * m + 3 + i]); v[i].v.g[3 + i] = 1.f; v[i].d = dconst(t_wv[(3 * m + j) * 6 + 3 + i]);
+#pragma unroll 1
+  for (int j = 0; j < 3; ++j) {  // grad_{(w,v)} <a_j, DF[t_wv_j]>: the directional derivative along t_wv_j, differentiated again along e_i
+    D1<D1<float>> w[3], v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      w[k].v = {wvs[k], i == k ? 1.f : 0.f};         w[k].d = {t_wv[(3 * m + j) * 6 + k], 0.f};
+      v[k].v = {wvs[3 + k], i == 3 + k ? 1.f : 0.f}; v[k].d = {t_wv[(3 * m + j) * 6 + 3 + k], 0.f};
     }
-    D1<Dual> Rm[9], p[3];
-    se3_Rp<D1<Dual>>(w, v, Rm, p);
+    D1<D1<float>> Rm[9], p[3];
+    se3_Rp<D1<D1<float>>>(w, v, Rm, p);
+#pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const D1<Dual> xr = Rm[3 * r] * x[3 * m] + Rm[3 * r + 1] * x[3 * m + 1] + Rm[3 * r + 2] * x[3 * m + 2] + p[r];
-      const float a = d_t_xw[(3 * m + j) * 3 + r];
-      for (int i = 0; i < 6; ++i) extra[i] += a * xr.d.g[i];
+      const D1<D1<float>> xr = Rm[3 * r] * xs[0] + Rm[3 * r + 1] * xs[1] + Rm[3 * r + 2] * xs[2] + p[r];
+      extra += d_t_xw[(3 * m + j) * 3 + r] * xr.d.d;
     }
   }
-  for (int i = 0; i < 6; ++i) dwv_extra[6 * m + i] = extra[i];
+  dwv_extra[6 * m + i] = extra;
 }
 
 // ---- compositing (model_utils.py:95-159), MSE loss (training.py:265-274) and the backward of both; one WAVE per ray ----
@@ -1093,7 +1120,7 @@ void trunk_in_jvp_bwd(hipStream_t st, const Dims& D, long long M, const float* d
 }
 void se3_jvp_bwd(hipStream_t st, long long M, const float* wv, const float* x, const float* t_wv, const float* d_t_xw, const float* du,
                  const float* ghat, float* d_t_wv, float* dwv_extra) {
-  hipLaunchKernelGGL(k_se3_jvp_bwd, grid1(M, 64), dim3(64), 0, st, M, wv, x, t_wv, d_t_xw, du, ghat, d_t_wv, dwv_extra);
+  LAUNCH(k_se3_jvp_bwd, 6 * M, st, M, wv, x, t_wv, d_t_xw, du, ghat, d_t_wv, dwv_extra);
 }
 void aux_losses(hipStream_t st, int R, int S, const Objective& ob, const float* z, const float* weights, const float* x, const float* xw,
                 const float* alpha, const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg,
