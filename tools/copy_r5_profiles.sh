@@ -7,6 +7,8 @@ for k in bf16 bf16x3; do
   cp $P/hbm_traffic.json profiles/r5_${k}_hbm_traffic.json
   cp $P/bench_under_rocprof.json profiles/r5_${k}_bench_under_rocprof.json
 done
+cp gpurun_out/profile_r5_bf16x3_fine/summary.txt profiles/r5_bf16x3_fine_rocprof_summary.txt
+cp gpurun_out/profile_r5_bf16x3_fine/bench_under_rocprof.json profiles/r5_bf16x3_fine_bench_under_rocprof.json
 cp gpurun_out/prof_r5_train/summary.txt profiles/r5_train_rocprof_summary.txt
 cp gpurun_out/prof_r5_train/bench_under_rocprof.json profiles/r5_train_bench_under_rocprof.json
 python - <<'PY'

@@ -9,6 +9,7 @@ timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>
 timeout 1800 bash tools/final_bench.sh r5 > $O/final_bench.log 2>&1
 bash tools/prof_bench.sh r5_bf16 > /dev/null 2>&1
 bash tools/prof_bench.sh r5_bf16x3 --precision bf16x3 > /dev/null 2>&1
+bash tools/prof_bench.sh r5_bf16x3_fine --precision bf16x3_fine > /dev/null 2>&1
 for k in bf16 bf16x3; do
   P=gpurun_out/profile_r5_$k
   python tools/traffic_from_summary.py $P/summary.txt "render_rays_kernel<GraphNerfDS, $k>" profiles/r5_${k}_rocprof_summary.txt "round 5 (final build)" > $P/hbm_traffic.json
