@@ -1119,6 +1119,189 @@ int run_merged(nerfds_trainer& t, hipStream_t st, int R, const float* zc, const 
   return NERFDS_OK;
 }
 
+// run_merged with the whole objective (round 5): the per-ray auxiliary losses and the second-order terms (norm loss at both levels, elastic regulariser
+// at the coarse one) on the same position rows.  What the shared networks contribute to those terms is shared like their primal pass: the tangent
+// chains of the warp field and the hyper sheet (three rows per position) run ONCE over [coarse | new] positions, the fine level reads them gathered into
+// its row order, and every gradient the fine level leaves on them - cotangents of the tangents of x' and of the ambient coordinates, the exp_se3
+// rotation term of target_norm, the predicted mask's gradient - is scattered back and added to the coarse level's before ONE backward of the
+// tangent chains and ONE primal backward.  Per level remain: the NerfMLP, its tangent chain and their backwards.  A third less shared-network work,
+// primal and tangent, than the level-by-level flow (run_level twice), same sums in a different order (tests/test_training.py, every term and leaf).
+int run_merged_full(nerfds_trainer& t, hipStream_t st, int R, const float* zc, const nerfds_rays* rays, const float* target, const nerfds_extra* ex,
+                    const Windows& W, const nerfds_rand* rnd, const Objective& ob, float norm_weight) {
+  const Dims& D = t.D;
+  const int Nc = t.cfg.num_coarse_samples, Nf = t.cfg.num_fine_samples, S = Nc + Nf, strat = ex->use_stratified_sampling;
+  const int64_t Mc = (int64_t)R * Nc, Mn = (int64_t)R * Nf, Mf = Mc + Mn, Ms = Mc + Mn;
+  const float* viewdirs = rays->viewdirs ? rays->viewdirs : rays->directions;
+  const int VD = 6 * D.vd_bands, NM = 6 * D.nm_bands, CW = VD + NM;
+  const bool nl = norm_weight != 0.f, el = ob.elastic_weight != 0.f, so = nl || el, hreg = ob.hyper_reg_weight != 0.f;
+  const int64_t Mt = nl ? Ms : Mc;            // positions with tangents (the elastic regulariser alone: the coarse block's warp tangents)
+  // scratch in buffers only the layer-by-layer backward uses (g0 / g1 / g2: M x 256 floats each): the fine level's gathered inputs and what it leaves
+  float* p0 = t.g0; float* p1 = t.g1;
+  auto take = [](float*& p, int64_t n) { float* r = p; p += (n + 63) & ~(int64_t)63; return r; };
+  float* xw_f = take(p0, 3 * Mf); float* wamb_f = take(p0, 2 * Mf); float* wv_f = take(p0, 6 * Mf); float* x_f = take(p0, 3 * Mf);
+  float* ml_f = take(p0, Mf); float* t_xw_f = take(p0, 9 * Mf); float* t_wamb_f = take(p0, 6 * Mf);
+  float* dxw_f = take(p1, 3 * Mf); float* dwamb_f = take(p1, 2 * Mf); float* d_t_xw_f = take(p1, 9 * Mf); float* d_t_wamb_f = take(p1, 6 * Mf);
+  float* dxw_reg_f = take(p1, 3 * Mf); float* dwamb_extra_f = take(p1, 2 * Mf); float* d_pm_f = take(p1, Mf); float* du_f = take(p1, 3 * Mf);
+  float* ghat_f = take(p1, 3 * Mf); float* rot_f = take(p1, 6 * Mf); float* rot = take(p1, 6 * Ms);
+  float* z_new = t.g2; int* src = reinterpret_cast<int*>(z_new + Mn);
+  auto as_f = [](const std::vector<uint16_t*>& v) { std::vector<float*> o; for (auto* p : v) o.push_back(reinterpret_cast<float*>(p)); return o; };
+  const std::vector<float*> gt = as_f(t.gt16), gh = as_f(t.gh16), gw = as_f(t.gw16);
+  const float scale_target = 5.f;             // (run_level: the largest cotangent lands at 2^5)
+  bool ok = true; std::string what;
+  auto wg_nerf = [&](Run& r, int level) {
+    const MlpP& trunk = t.trunk[level];
+    const LayerP& K = t.rgb_h[level];
+    const int TW = trunk.width, RW = K.N;
+    r.head_wgrads(t.rgb_out[level], t.rgb_h16, RW, t.d_rgb_logit, 3);
+    r.head_wgrads(t.alpha[level], t.trunk_h16.back(), TW, t.d_alpha, 4);
+    r.weight_grad(reinterpret_cast<const float*>(t.trunk_h16.back()), TW, TW, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(TW + VD) * RW, -1, true, t.grad + K.b, t.g16);
+    r.weight_grad(t.cond, CW, VD, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)TW * RW, -1, false, nullptr, t.g16);
+    r.weight_grad(t.cond + VD, CW, NM, t.rgb_hv, RW, RW, t.grad + K.w + (int64_t)(2 * TW + VD) * RW, -1, false, nullptr, t.g16);
+    r.mlp_wgrads(trunk, t.trunk_in, t.trunk_h16, t.trunk_h);
+  };
+  // the level's own part of the objective beyond the rgb loss, BEFORE its primal NerfMLP backward (it adds to d_alpha): the trunk's tangent chain ->
+  // target_norm, the per-ray auxiliary terms, the norm loss, the backward of the trunk's tangent chain down to the tangents of x' / the ambient
+  // coordinates (in the level's row order), the rotation term of target_norm, the elastic regulariser.  Arrays *_l: the level's rows.
+  auto second_order = [&](int level, int Sl, const float* z, const float* weights, const float* x_l, const float* xw_l, const float* wamb_l, const float* wv_l,
+                          const float* ml_l, const float* t_xw_l, const float* t_wamb_l, float* d_t_xw_l, float* d_t_wamb_l, float* dxw_reg_l,
+                          float* dwamb_extra_l, float* d_pm_l, float* du_l, float* ghat_l, float* rot_l) {
+    const int64_t M = (int64_t)R * Sl;
+    const MlpP& trunk = t.trunk[level];
+    Objective obl = ob;
+    if (level != 0) { obl.hyper_reg_weight = 0.f; obl.elastic_weight = 0.f; }
+    if (nl) {
+      trunk_in_jvp(st, D, M, xw_l, wamb_l, t_xw_l, t_wamb_l, W, t.t_tin);
+      fused_tangent(t, st, 4, level, 3 * M, t.t_tin, D.trunk_in, t.t_alpha, 4);
+      target_norm(st, M, t.t_alpha, wv_l, t.tn[level]);
+    }
+    aux_losses(st, R, Sl, obl, z, weights, x_l, xw_l, t.alphav, viewdirs, ml_l, rays->gt_mask, t.terms_dev + 4 * level, dxw_reg_l, t.d_alpha, d_pm_l, wamb_l,
+               t.terms_dev + 9 + level, t.dwamb_reg, t.terms_dev + 13 + level);
+    const bool el_l = el && level == 0;
+    if (nl) {
+      norm_loss(st, R, Sl, norm_weight, weights, t.alphav, t.t_alpha, wv_l, t.tn[level], t.terms_dev + 4 * level + 3, t.d_alpha, t.d_t_alpha, du_l, ghat_l);
+      Run rt{t, st, 3 * M};
+      rt.tan = true;
+      pick_scale(st, t.d_t_alpha, 3 * M * 4, scale_target, t.tan_x_scale, t.tan_slot);
+      rt.tan_slot = t.tan_slot;
+      fused_tangent_backward(t, st, 4, level, 3 * M, t.d_t_alpha, 4, t.d_t_tin, D.trunk_in, t.tan_slot);
+      rt.fork(false);
+      rt.head_wgrads(t.alpha[level], t.tt16.back(), trunk.width, t.d_t_alpha, 4);
+      rt.mlp_wgrads(trunk, t.t_tin, t.tt16, gt);
+      trunk_in_jvp_bwd(st, D, M, t.d_t_tin, xw_l, wamb_l, t_xw_l, t_wamb_l, W, d_t_xw_l, d_t_wamb_l, dxw_reg_l, dwamb_extra_l);
+      if (hreg && level == 0) add_inplace(st, dwamb_extra_l, t.dwamb_reg, 2 * M);
+      se3_rot_bwd(st, M, wv_l, du_l, ghat_l, rot_l);
+      rt.wg_turn = -1;                        // (joined with the level's primal weight gradients)
+      if (!rt.ok) { ok = false; what = rt.unsupported_what; }
+    } else if (el_l) {
+      (void)hipMemsetAsync(d_t_xw_l, 0, (size_t)9 * M * sizeof(float), st);
+    }
+    if (el_l) elastic_loss(st, R, Sl, ob.elastic_weight, ob.elastic_by_weight, weights, t_xw_l, t.terms_dev + 12, d_t_xw_l);
+  };
+  // ---------------- coarse level forward (shared networks on block A + coarse NerfMLP) and its loss ----------------
+  Run rc{t, st, Mc};
+  encode_inputs(st, D, R, Nc, rays->origins, rays->directions, zc, rays->warp_id, t.cfg.num_warp_embeds, t.theta + t.warp_tbl, t.theta + t.mask_tbl, W,
+                t.x, t.mask_in, t.warp_in, t.hyper_in);
+  fused_forward(t, st, 0, R, Nc, zc, rays, ex, W);
+  mask_post(st, D, R, Nc, t.mask_logit, rays->gt_mask, ex->mask_ratio, t.warp_in, t.hyper_in);
+  se3_fwd(st, Mc, t.wv, t.x, t.xw);
+  trunk_in(st, D, Mc, t.xw, t.wamb, W, t.trunk_in);
+  alpha_post(st, D, R, Nc, t.alphav, t.wv, viewdirs, W, t.sigma, t.cond);
+  composite_loss(st, R, Nc, zc, rays->directions, t.sigma, t.rgb_logit, target, t.cfg.use_sample_at_infinity, t.cfg.use_white_background, t.rgb_ray, t.wc,
+                 t.loss_dev + 0, t.d_rgb_logit, t.d_alpha, t.cot[0], t.lout[0]);
+  // ---------------- the fine level's new samples: shared networks only (block B) ----------------
+  resample(st, R, Nc, Nf, zc, t.wc, strat, rnd ? rnd->u_rand : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->first_ray : 0, t.zf, t.rs_scratch, z_new, src);
+  encode_inputs(st, D, R, Nf, rays->origins, rays->directions, z_new, rays->warp_id, t.cfg.num_warp_embeds, t.theta + t.warp_tbl, t.theta + t.mask_tbl, W,
+                t.x + 3 * Mc, t.mask_in + Mc * D.mask_in, t.warp_in + Mc * D.warp_ld, t.hyper_in + Mc * D.hyper_ld);
+  fused_forward(t, st, 1, R, Nf, z_new, rays, ex, W, 1, Mc);
+  mask_post(st, D, R, Nf, t.mask_logit + Mc, rays->gt_mask, ex->mask_ratio, t.warp_in + Mc * D.warp_ld, t.hyper_in + Mc * D.hyper_ld);
+  se3_fwd(st, Mn, t.wv + 6 * Mc, t.x + 3 * Mc, t.xw + 3 * Mc);
+  // ---------------- the shared networks' tangent chains, once over the positions ----------------
+  if (so) {
+    encode_tangents(st, D, Mt, t.x, W, t.t_warp_in, t.t_hyper_in);
+    fused_tangent(t, st, 2, 0, 3 * Mt, t.t_warp_in, D.warp_ld, t.t_wv, 6);
+    se3_jvp(st, Mt, t.wv, t.x, t.t_wv, t.t_xw);
+    if (nl) fused_tangent(t, st, 1, 0, 3 * Mt, t.t_hyper_in, D.hyper_ld, t.t_wamb, 2);
+  }
+  // ---------------- coarse level: second-order and auxiliary terms, NerfMLP backward ----------------
+  second_order(0, Nc, zc, t.wc, t.x, t.xw, t.wamb, t.wv, t.mask_logit, t.t_xw, t.t_wamb, t.d_t_xw, t.d_t_wamb, t.dxw_reg, t.dwamb_extra, t.d_pm, t.du, t.ghat, rot);
+  fused_backward(t, st, 0, 0, Mc, t.d_rgb_logit, 3, t.d_alpha, t.d_trunk_in, D.trunk_in);
+  rc.fork(false); wg_nerf(rc, 0);
+  trunk_in_bwd(st, D, Mc, t.d_trunk_in, t.xw, t.wamb, W, t.dxw_reg, nl ? t.dwamb_extra : (hreg ? t.dwamb_reg : nullptr), t.dxw, t.dwamb);
+  // ---------------- fine level: NerfMLP on the sorted union of the positions ----------------
+  gather_rows(st, Mf, src, t.xw, t.wamb, t.wv, xw_f, wamb_f, wv_f);
+  gather_cols(st, Mf, src, 1, 3, t.x, x_f);
+  gather_cols(st, Mf, src, 1, 1, t.mask_logit, ml_f);
+  if (nl) { gather_cols(st, Mf, src, 3, 3, t.t_xw, t_xw_f); gather_cols(st, Mf, src, 3, 2, t.t_wamb, t_wamb_f); }
+  rc.join();
+  if (!rc.ok) return t.fail(NERFDS_ENOTSUP, "%s", rc.unsupported_what.c_str());
+  Run rf{t, st, Mf};
+  fused_forward(t, st, 1, R, S, t.zf, rays, ex, W, 2, 0, xw_f, wamb_f, wv_f);
+  trunk_in(st, D, Mf, xw_f, wamb_f, W, t.trunk_in);
+  alpha_post(st, D, R, S, t.alphav, wv_f, viewdirs, W, t.sigma, t.cond);
+  composite_loss(st, R, S, t.zf, rays->directions, t.sigma, t.rgb_logit, target, t.cfg.use_sample_at_infinity, t.cfg.use_white_background, t.rgb_ray, t.weights,
+                 t.loss_dev + 1, t.d_rgb_logit, t.d_alpha, t.cot[1], t.lout[1]);
+  second_order(1, S, t.zf, t.weights, x_f, xw_f, wamb_f, wv_f, ml_f, t_xw_f, t_wamb_f, d_t_xw_f, d_t_wamb_f, dxw_reg_f, dwamb_extra_f, d_pm_f, du_f, ghat_f, rot_f);
+  fused_backward(t, st, 0, 1, Mf, t.d_rgb_logit, 3, t.d_alpha, t.d_trunk_in, D.trunk_in);
+  rf.fork(false); wg_nerf(rf, 1);
+  trunk_in_bwd(st, D, Mf, t.d_trunk_in, xw_f, wamb_f, W, dxw_reg_f, nl ? dwamb_extra_f : nullptr, dxw_f, dwamb_f);
+  scatter_rows(st, Mf, src, Mc, dxw_f, dwamb_f, t.dxw, t.dwamb);
+  scatter_cols(st, Mf, src, Mc, 1, 1, d_pm_f, t.d_pm);
+  if (nl) {
+    scatter_cols(st, Mf, src, Mc, 3, 3, d_t_xw_f, t.d_t_xw);
+    scatter_cols(st, Mf, src, Mc, 3, 2, d_t_wamb_f, t.d_t_wamb);
+    scatter_cols(st, Mf, src, Mc, 1, 6, rot_f, rot);
+  }
+  if (!ok) return t.fail(NERFDS_ENOTSUP, "%s", what.c_str());
+  // ---------------- the backward of the shared networks' tangent chains, once over the positions ----------------
+  if (so) {
+    Run rt{t, st, 3 * Mt};
+    rt.tan = true;
+    if (nl) {
+      pick_scale(st, t.d_t_wamb, 3 * Mt * 2, scale_target, t.tan_x_scale, t.tan_slot + 4);
+      rt.tan_slot = t.tan_slot + 4;
+      fused_tangent_backward(t, st, 1, 0, 3 * Mt, t.d_t_wamb, 2, nullptr, 0, t.tan_slot + 4);
+      rt.fork(false);
+      rt.head_wgrads(t.hyper_out, t.th16.back(), t.hyper.width, t.d_t_wamb, 2);
+      rt.mlp_wgrads(t.hyper, t.t_hyper_in, t.th16, gh);
+    }
+    se3_jvp_bwd(st, Mt, t.wv, t.x, t.t_wv, t.d_t_xw, nullptr, nullptr, t.d_t_wv, t.dwv_extra, nl ? rot : nullptr);
+    if (Mt < Ms) (void)hipMemsetAsync(t.dwv_extra + 6 * Mt, 0, (size_t)6 * (Ms - Mt) * sizeof(float), st);
+    pick_scale(st, t.d_t_wv, 3 * Mt * 6, scale_target, t.tan_x_scale, t.tan_slot + 8);
+    rt.tan_slot = t.tan_slot + 8;
+    fused_tangent_backward(t, st, 2, 0, 3 * Mt, t.d_t_wv, 6, nullptr, 0, t.tan_slot + 8);
+    rt.fork(false);
+    rt.head_wgrads(t.warp_w, t.tw16.back(), t.warp.width, t.d_t_wv, 6);
+    rt.head_wgrads(t.warp_v, t.tw16.back(), t.warp.width, t.d_t_wv + 3, 6);
+    rt.mlp_wgrads(t.warp, t.t_warp_in, t.tw16, gw);
+    rt.wg_turn = -1;
+    if (!rt.ok) return t.fail(NERFDS_ENOTSUP, "%s", rt.unsupported_what.c_str());
+  }
+  // ---------------- the shared networks' primal backward, once over every position row ----------------
+  rf.M = Ms;
+  fused_backward(t, st, 1, 1, Ms, t.dwamb, 2, nullptr, t.d_hyper_in, D.hyper_ld);
+  rf.fork(false);
+  rf.head_wgrads(t.hyper_out, t.hyper_h16.back(), t.hyper.width, t.dwamb, 2);
+  rf.mlp_wgrads(t.hyper, t.hyper_in, t.hyper_h16, t.hyper_h);
+  se3_bwd(st, Ms, t.wv, t.x, t.dxw, so ? t.dwv_extra : nullptr, t.dwv);
+  fused_backward(t, st, 2, 1, Ms, t.dwv, 6, nullptr, t.d_warp_in, D.warp_ld);
+  rf.fork(false);
+  rf.head_wgrads(t.warp_w, t.warp_h16.back(), t.warp.width, t.dwv, 6);
+  rf.head_wgrads(t.warp_v, t.warp_h16.back(), t.warp.width, t.dwv + 3, 6);
+  rf.mlp_wgrads(t.warp, t.warp_in, t.warp_h16, t.warp_h);
+  shared_in_bwd(st, D, R, Nc, t.d_warp_in, t.d_hyper_in, t.mask_logit, ex->mask_ratio, t.d_pm, rays->warp_id, t.cfg.num_warp_embeds, t.grad + t.warp_tbl, t.d_mask_logit);
+  shared_in_bwd(st, D, R, Nf, t.d_warp_in + Mc * D.warp_ld, t.d_hyper_in + Mc * D.hyper_ld, t.mask_logit + Mc, ex->mask_ratio, t.d_pm + Mc, rays->warp_id,
+                t.cfg.num_warp_embeds, t.grad + t.warp_tbl, t.d_mask_logit + Mc);
+  fused_backward(t, st, 3, 1, Ms, t.d_mask_logit, 1, nullptr, t.d_mask_in, D.mask_in);
+  mask_in_bwd(st, D, R, Nc, t.d_mask_in, rays->warp_id, t.cfg.num_warp_embeds, t.grad + t.mask_tbl);
+  mask_in_bwd(st, D, R, Nf, t.d_mask_in + Mc * D.mask_in, rays->warp_id, t.cfg.num_warp_embeds, t.grad + t.mask_tbl);
+  rf.fork(true);
+  rf.head_wgrads(t.mask_out, t.mask_h16.back(), t.mask.width, t.d_mask_logit, 1);
+  rf.mlp_wgrads(t.mask, t.mask_in, t.mask_h16, t.mask_h);
+  rf.join();
+  if (!rf.ok) return t.fail(NERFDS_ENOTSUP, "%s", rf.unsupported_what.c_str());
+  return NERFDS_OK;
+}
+
 // Background regulariser (training.py:159-183, 468-479): the SE(3) field alone on a batch of points that should not move, each with the GLO row of
 // its id and mask 0 (models.py:766-773 apply_warp), loss = weight * mean general_loss(|warp(x) - x|^2).  Runs after the levels on their (now free)
 // buffers, layer by layer on the MFMA layer kernels (the three-way split forward of the warp field, as every step's): points as "rays" of one
@@ -1767,8 +1950,15 @@ static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* ta
   // flow does not cover: auxiliary losses, tangent passes, one level, the layer-by-layer kernels)
   static const bool merged_on = !(getenv("NERFDS_TRAIN_MERGED") && std::string(getenv("NERFDS_TRAIN_MERGED")) == "0");
   int rc;
-  if (merged_on && !t->fwd_only && t->half_step && !want_sg && Nf > 0 && !obp && resample_has_sources(Nc, Nf) && t->g0 && 11 * (int64_t)R * (Nc + Nf) <= (int64_t)t->max_rays * (Nc + Nf) * t->trunk[0].width) {
+  // NERFDS_TRAIN_MERGED_FULL=0: steps with auxiliary / second-order terms level by level, as through most of round 5 (A/B)
+  static const bool merged_full_on = !(getenv("NERFDS_TRAIN_MERGED_FULL") && std::string(getenv("NERFDS_TRAIN_MERGED_FULL")) == "0");
+  const bool mergeable = merged_on && !t->fwd_only && t->half_step && Nf > 0 && resample_has_sources(Nc, Nf) && t->g0 &&
+                         64 * (int64_t)R * (Nc + Nf) <= (int64_t)t->max_rays * (Nc + Nf) * t->trunk[0].width;
+  if (mergeable && !want_sg && !obp) {
     rc = run_merged(*t, st, R, t->zc, rays, target_rgb, ex, W, rnd);
+    if (rc != NERFDS_OK) return rc;
+  } else if (mergeable && merged_full_on && obp && !(flags & NERFDS_TRAIN_SIGMA_GRAD) && (!want_sg || (t->fused_tan && t->keep_tangents))) {
+    rc = run_merged_full(*t, st, R, t->zc, rays, target_rgb, ex, W, rnd, *obp, norm_weight);
     if (rc != NERFDS_OK) return rc;
   } else {
   rc = run_level(*t, st, 0, R, Nc, t->zc, rays, target_rgb, ex, W, t->wc, want_sg, obp, norm_weight);

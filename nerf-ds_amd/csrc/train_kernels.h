@@ -30,6 +30,8 @@ void resample(hipStream_t, int R, int Nc, int Nf, const float* zc, const float* 
 bool resample_has_sources(int Nc, int Nf);
 void gather_rows(hipStream_t, long long M, const int* src, const float* xw, const float* wamb, const float* wv, float* xw_f, float* wamb_f, float* wv_f);
 void scatter_rows(hipStream_t, long long M, const int* src, long long add_below, const float* dxw_f, const float* dwamb_f, float* dxw, float* dwamb);
+void gather_cols(hipStream_t, long long M, const int* src, int rp, int C, const float* in, float* out);                              // out[i] = in[src[i]], rp x C floats per sample
+void scatter_cols(hipStream_t, long long M, const int* src, long long add_below, int rp, int C, const float* in_f, float* out);    // out[src[i]] (+)= in_f[i]
 void encode_inputs(hipStream_t, const Dims&, int R, int S, const float* o, const float* d, const float* z, const uint32_t* warp_id, int n_embeds,
                    const float* warp_tbl, const float* mask_tbl, const Windows&, float* x, float* mask_in, float* warp_in, float* hyper_in);
 void bias_act(hipStream_t, float* y, const float* b, long long M, int N, int ld, int relu);
@@ -44,7 +46,8 @@ void norm_loss(hipStream_t, int R, int S, float weight, const float* weights, co
 void trunk_in_jvp_bwd(hipStream_t, const Dims&, long long M, const float* d_t_tin, const float* xw, const float* wamb, const float* t_xw,
                       const float* t_wamb, const Windows&, float* d_t_xw, float* d_t_wamb, float* dxw_extra, float* dwamb_extra);
 void se3_jvp_bwd(hipStream_t, long long M, const float* wv, const float* x, const float* t_wv, const float* d_t_xw, const float* du,
-                 const float* ghat, float* d_t_wv, float* dwv_extra);
+                 const float* ghat, float* d_t_wv, float* dwv_extra, const float* extra_in = nullptr);
+void se3_rot_bwd(hipStream_t, long long M, const float* wv, const float* du, const float* ghat, float* out);
 void aux_losses(hipStream_t, int R, int S, const Objective&, const float* z, const float* weights, const float* x, const float* xw, const float* alpha,
                 const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg, float* d_alpha, float* d_pm,
                 const float* wamb = nullptr, float* term_hyper = nullptr, float* dwamb_reg = nullptr, float* term_occlusion = nullptr);   // hyper-point regulariser: ambient coordinates in, its term and d / d wamb out

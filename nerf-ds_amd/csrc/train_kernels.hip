@@ -182,6 +182,22 @@ __global__ void k_scatter_rows(long long M, const int* __restrict__ src, long lo
   for (int c = 0; c < 2; ++c) dwamb[2 * s + c] = (add ? dwamb[2 * s + c] : 0.f) + dwamb_f[2 * i + c];
 }
 
+// the same for any per-position array of `rp` rows x C floats per sample (rp = 3: the tangent rows 3 m + j): one thread per element
+__global__ void k_gather_cols(long long M, const int* __restrict__ src, int rp, int C, const float* __restrict__ in, float* __restrict__ out) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int W = rp * C;
+  if (i >= M * W) return;
+  const long long m = i / W;
+  out[i] = in[(long long)src[m] * W + (i - m * W)];
+}
+__global__ void k_scatter_cols(long long M, const int* __restrict__ src, long long add_below, int rp, int C, const float* __restrict__ in_f, float* __restrict__ out) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int W = rp * C;
+  if (i >= M * W) return;
+  const long long m = i / W, s = src[m], o = s * W + (i - m * W);
+  out[o] = (s < add_below ? out[o] : 0.f) + in_f[i];
+}
+
 // ---- inputs of the three shared nets (models.py:931-975, 729-732; modules.py:367-434; warping.py:200-237) --------
 __global__ void k_encode_inputs(Dims D, int R, int S, const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z,
                                 const uint32_t* __restrict__ warp_id, int n_embeds, const float* __restrict__ warp_tbl,
@@ -590,7 +606,8 @@ template <class T> __device__ __forceinline__ D1<T> tconst(float c, const D1<T>*
 // scratch (228 - 908 bytes per lane) and the kernel is SLOWER than before (1.63 ms at two) - it is left the whole register file.
 __global__ __launch_bounds__(256) void k_se3_jvp_bwd(long long M, const float* __restrict__ wv, const float* __restrict__ x, const float* __restrict__ t_wv,
                               const float* __restrict__ d_t_xw, const float* __restrict__ du, const float* __restrict__ ghat,
-                              float* __restrict__ d_t_wv, float* __restrict__ dwv_extra) {
+                              float* __restrict__ d_t_wv, float* __restrict__ dwv_extra, const float* __restrict__ extra_in) {
+  // du / ghat null: no rotation term here (the merged step forms it per level, k_se3_rot_bwd, and hands the sum in as extra_in)
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (idx >= 6 * M) return;
   const long long m = idx / 6;
@@ -619,10 +636,12 @@ __global__ __launch_bounds__(256) void k_se3_jvp_bwd(long long M, const float* _
       }
       d_t_wv[(3 * m + j) * 6 + i] = acc;
     }
+    if (du != nullptr) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+      for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) extra += du[3 * m + r] * ghat[3 * m + c] * Rm[3 * r + c].d;           // grad <du, R ghat>
+        for (int c = 0; c < 3; ++c) extra += du[3 * m + r] * ghat[3 * m + c] * Rm[3 * r + c].d;         // grad <du, R ghat>
+    }
   }
 #pragma unroll 1
   for (int j = 0; j < 3; ++j) {  // grad_{(w,v)} <a_j, DF[t_wv_j]>: the directional derivative along t_wv_j, differentiated again along e_i
@@ -640,7 +659,27 @@ __global__ __launch_bounds__(256) void k_se3_jvp_bwd(long long M, const float* _
       extra += d_t_xw[(3 * m + j) * 3 + r] * xr.d.d;
     }
   }
-  dwv_extra[6 * m + i] = extra;
+  dwv_extra[6 * m + i] = extra + (extra_in != nullptr ? extra_in[6 * m + i] : 0.f);
+}
+// the rotation term alone: out[m][i] = d / d (w, v)_i <du_m, R(w, v) ghat_m> (bilinear in the LEVEL's (du, ghat): the merged step evaluates it per level
+// in the level's row order and adds the levels up per sample position)
+__global__ __launch_bounds__(256) void k_se3_rot_bwd(long long M, const float* __restrict__ wv, const float* __restrict__ du, const float* __restrict__ ghat,
+                                                     float* __restrict__ out) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= 6 * M) return;
+  const long long m = idx / 6;
+  const int i = (int)(idx - 6 * m);
+  D1<float> w[3], v[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { w[k] = {wv[6 * m + k], i == k ? 1.f : 0.f}; v[k] = {wv[6 * m + 3 + k], i == 3 + k ? 1.f : 0.f}; }
+  D1<float> Rm[9], p[3];
+  se3_Rp<D1<float>>(w, v, Rm, p);
+  float extra = 0.f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) extra += du[3 * m + r] * ghat[3 * m + c] * Rm[3 * r + c].d;
+  out[6 * m + i] = extra;
 }
 
 // ---- compositing (model_utils.py:95-159), MSE loss (training.py:265-274) and the backward of both; one WAVE per ray ----
@@ -1083,6 +1122,12 @@ void gather_rows(hipStream_t st, long long M, const int* src, const float* xw, c
 void scatter_rows(hipStream_t st, long long M, const int* src, long long add_below, const float* dxw_f, const float* dwamb_f, float* dxw, float* dwamb) {
   LAUNCH(k_scatter_rows, M, st, M, src, add_below, dxw_f, dwamb_f, dxw, dwamb);
 }
+void gather_cols(hipStream_t st, long long M, const int* src, int rp, int C, const float* in, float* out) {
+  LAUNCH(k_gather_cols, M * rp * C, st, M, src, rp, C, in, out);
+}
+void scatter_cols(hipStream_t st, long long M, const int* src, long long add_below, int rp, int C, const float* in_f, float* out) {
+  LAUNCH(k_scatter_cols, M * rp * C, st, M, src, add_below, rp, C, in_f, out);
+}
 bool resample_has_sources(int Nc, int Nf) { return Nc <= 256 && Nf <= 256; }
 void resample(hipStream_t st, int R, int Nc, int Nf, const float* zc, const float* wc, int stratified, const float* u_rand, uint64_t seed, long long first_ray, float* zf, float* scratch,
               float* z_new, int* src) {
@@ -1119,8 +1164,11 @@ void trunk_in_jvp_bwd(hipStream_t st, const Dims& D, long long M, const float* d
   LAUNCH(k_trunk_in_jvp_bwd, 5 * M, st, D, M, d_t_tin, xw, wamb, t_xw, t_wamb, W, d_t_xw, d_t_wamb, dxw_extra, dwamb_extra);
 }
 void se3_jvp_bwd(hipStream_t st, long long M, const float* wv, const float* x, const float* t_wv, const float* d_t_xw, const float* du,
-                 const float* ghat, float* d_t_wv, float* dwv_extra) {
-  LAUNCH(k_se3_jvp_bwd, 6 * M, st, M, wv, x, t_wv, d_t_xw, du, ghat, d_t_wv, dwv_extra);
+                 const float* ghat, float* d_t_wv, float* dwv_extra, const float* extra_in) {
+  LAUNCH(k_se3_jvp_bwd, 6 * M, st, M, wv, x, t_wv, d_t_xw, du, ghat, d_t_wv, dwv_extra, extra_in);
+}
+void se3_rot_bwd(hipStream_t st, long long M, const float* wv, const float* du, const float* ghat, float* out) {
+  LAUNCH(k_se3_rot_bwd, 6 * M, st, M, wv, du, ghat, out);
 }
 void aux_losses(hipStream_t st, int R, int S, const Objective& ob, const float* z, const float* weights, const float* x, const float* xw,
                 const float* alpha, const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg,

@@ -556,18 +556,21 @@ def test_gradients_match_the_oracle_at_multi_tile_size(full):
   # run by 7.3e-3 on warp_field/branches_v/logit/bias and 4.6e-3 on trunk/hidden_5/bias at this size - and which side of that noise a given build lands
   # on moves with one-ulp changes upstream (measured on these two leaves: 3.3e-3 / 3.9e-3 with one shared-network pass per level, 7.9e-3 / 5.1e-3 in
   # the merged step - deterministic, the same with fp32 or f16 g arrays and with every weight-gradient kernel).  So: 6e-3, or 2 x the fp32 oracle's own
-  # difference on the leaf.  Full objective: L2_TOL_2ND (measured 6.0e-3).
-  if full:
-    for name, e in errs.items():
-      assert e < L2_TOL_2ND['mfma'], (name, e)
-    return
+  # difference on the leaf.
+  # Full objective: the norm loss differentiates d sigma / d x of a ReLU network - piecewise constant in the parameters - so ONE hidden unit of one
+  # high-weight sample whose pre-activation rounds to the other side of zero moves the loss term by 1e-4 of itself and the warp field's leaves by 2 %.
+  # At this size the fp32 run of the oracle differs from its fp64 run by 2.6e-2 on warp_field/branches_w/logit/bias (1.7 - 2.0e-2 on the warp trunk),
+  # and the step that evaluates the shared networks once per position (round 5, run_merged_full: the NerfMLP reads the warped point the backward
+  # differentiates at) lands within 6 % of those very numbers - on the fp32 side of that unit - where the level-by-level flow happens to land on the fp64
+  # side (6.2e-3).  Same yardstick as for the rgb loss: the bound, or 2 x the oracle's own fp32-against-fp64 difference on the leaf.
   import torch
-  _, G32, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, dtype=torch.float32)
+  bound = L2_TOL_2ND['mfma'] if full else 6e-3
+  _, G32, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, dtype=torch.float32, **({'objective': obj} if full else {}))
   w32 = dict(tree_leaves(G32))
   for name, e in errs.items():
     w = want[name]
     noise = float(np.linalg.norm(w32[name].reshape(w.shape) - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size)))
-    assert e < max(6e-3, 2.0 * noise), (name, e, noise)
+    assert e < max(bound, 2.0 * noise), (name, e, noise)
 
 
 @pytest.mark.gpu
