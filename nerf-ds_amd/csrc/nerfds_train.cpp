@@ -569,7 +569,7 @@ bool ensure_norm_ws(nerfds_trainer& t) {
   return true;
 }
 
-void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* t_in, int ld_in, float* t_head, int ld_head);
+void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* t_in, int ld_in, float* t_head, int ld_head, int mask_div = 3);
 
 // d sigma_raw / d x by forward-mode tangents through warp MLP -> exp_se3, hyper sheet, posenc, trunk, alpha head
 // (the mask is a constant input, models.py:1035-1069), then target_norm (models.py:1077, 1273-1277, 1328).  Uses the
@@ -934,10 +934,11 @@ bool ensure_tan16_g(nerfds_trainer& t) {
   return carve16(t, &t.gws16, t.gw16, t.gh16, t.gt16, true);
 }
 // tangent FORWARD chain of net 1 hyper sheet, 2 warp field, 4 trunk + alpha head of `level`: t_in [3 M][ld_in] -> t_head [3 M][ld_head], hidden tangents -> store16
-void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* t_in, int ld_in, float* t_head, int ld_head) {
+// (mask_div 3: three tangent rows per sample, row r reads the masks of sample r / 3; 1: one row per sample - the reverse-mode second-order path)
+void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* t_in, int ld_in, float* t_head, int ld_head, int mask_div) {
   nerfds::TrainBwd tb{};
   tb.M = M3; tb.d_head = t_in; tb.ld_head = ld_in; tb.d_in = t_head; tb.ld_in = ld_head; tb.sink = t.sink;
-  tb.g_half = 1; tb.g_scale = t.tan_x_scale; tb.g_inv_scale = 1.f / t.tan_x_scale; tb.mask_div = 3;
+  tb.g_half = 1; tb.g_scale = t.tan_x_scale; tb.g_inv_scale = 1.f / t.tan_x_scale; tb.mask_div = mask_div;
   const std::vector<uint16_t*>* bits = nullptr;
   const std::vector<uint16_t*>* store = nullptr;
   if (net == 1) { tb.wstream = t.tstream[2]; bits = &t.hyper_bits; store = &t.th16; }
@@ -951,11 +952,11 @@ void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_
 // data-gradient chain of the TANGENT pass: cotangent of the head's tangent [3 M][ld_head] (its scale picked on the device: slot) -> g of every hidden
 // tangent (f16, store16) and, if d_in, the cotangent of the raw tangent input [3 M][ld_in]
 void fused_tangent_backward(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* d_head, int ld_head, float* d_in, int ld_in,
-                            const float* slot) {
+                            const float* slot, int mask_div = 3) {
   nerfds::TrainBwd tb{};
   tb.M = M3; tb.d_head = d_head; tb.ld_head = ld_head; tb.sink = t.sink;
   tb.d_in = d_in ? d_in : t.sink; tb.ld_in = d_in ? ld_in : 0;            // ld_in 0: every input-gradient store goes to the sink (no parameters behind t_in)
-  tb.g_half = 1; tb.g_scale = 1.f; tb.g_inv_scale = 1.f; tb.scale_dev = slot + 1; tb.mask_div = 3;
+  tb.g_half = 1; tb.g_scale = 1.f; tb.g_inv_scale = 1.f; tb.scale_dev = slot + 1; tb.mask_div = mask_div;
   const std::vector<uint16_t*>* bits = nullptr;
   const std::vector<uint16_t*>* store = nullptr;
   const bool f16 = t.tan_bwd_f16;
@@ -968,6 +969,21 @@ void fused_tangent_backward(nerfds_trainer& t, hipStream_t st, int net, int leve
   // those terms (bounds unchanged) - at a third of the MFMAs.  The primal chains and the tangent FORWARD (target_norm) stay split bf16.
   if (f16) nerfds_launch_train_bwd16f_nerfds(tb, net, t.num_cus, st);
   else nerfds_launch_train_bwd16_nerfds(tb, net, t.num_cus, st);
+}
+
+// d (one scalar per row) / d input of a network by its data-gradient chain in split bf16, at scale 1, on the primal ReLU bits: net 4 trunk behind its
+// alpha head (of `level`), 1 hyper sheet, 2 warp field.  The f16 g the chain stores on its way goes to the tangent pass's g arrays (nobody reads it).
+void fused_reverse(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M, const float* d_head, int ld_head, float* d_in, int ld_in) {
+  nerfds::TrainBwd tb{};
+  tb.M = M; tb.d_head = d_head; tb.ld_head = ld_head; tb.d_in = d_in; tb.ld_in = ld_in; tb.sink = t.sink;
+  tb.g_half = 1; tb.g_scale = 1.f; tb.g_inv_scale = 1.f; tb.mask_div = 0;
+  const std::vector<uint16_t*>* bits = nullptr;
+  const std::vector<uint16_t*>* store = nullptr;
+  if (net == 1) { tb.wstream = t.bstream[2]; bits = &t.hyper_bits; store = &t.gh16; }
+  else if (net == 2) { tb.wstream = t.bstream[3]; bits = &t.warp_bits; store = &t.gw16; }
+  else { tb.wstream = t.astream[level]; bits = &t.trunk_bits; store = &t.gt16; }
+  for (size_t l = 0; l < bits->size(); ++l) { tb.bits[l] = (*bits)[l]; tb.g[l] = reinterpret_cast<float*>((*store)[l]); }
+  nerfds_launch_train_bwd16_nerfds(tb, net, t.num_cus, st);
 }
 
 // the data-gradient chain of one network: net 0 NerfMLP of `level`, 1 hyper sheet, 2 warp field, 3 mask net
@@ -1143,7 +1159,15 @@ int run_merged_full(nerfds_trainer& t, hipStream_t st, int R, const float* zc, c
   float* dxw_f = take(p1, 3 * Mf); float* dwamb_f = take(p1, 2 * Mf); float* d_t_xw_f = take(p1, 9 * Mf); float* d_t_wamb_f = take(p1, 6 * Mf);
   float* dxw_reg_f = take(p1, 3 * Mf); float* dwamb_extra_f = take(p1, 2 * Mf); float* d_pm_f = take(p1, Mf); float* du_f = take(p1, 3 * Mf);
   float* ghat_f = take(p1, 3 * Mf); float* rot_f = take(p1, 6 * Mf); float* rot = take(p1, 6 * Ms);
+  // the reverse-mode second-order path (below): per-level scratch in the level's row order (_l) and in position order (_p)
+  float* sa_l = take(p1, 3 * Mf); float* sb_l = take(p1, 2 * Mf); float* sc_l = take(p1, 6 * Mf); float* sb_p = take(p1, 2 * Ms); float* sc_p = take(p1, 6 * Ms);
+  float* gx_p = take(p1, 3 * Ms); float* gx_l = take(p1, 3 * Mf); float* dir_l = take(p1, 3 * Mf); float* dir_p = take(p1, 3 * Ms); float* cot_l = take(p1, 4 * Mf);
+  float* dtx_p = take(p1, 3 * Ms); float* dtw_p = take(p1, 2 * Ms); float* rot_p = take(p1, 6 * Ms);
   float* z_new = t.g2; int* src = reinterpret_cast<int*>(z_new + Mn);
+  // NERFDS_TRAIN_REVERSE_SIGMA=0: the three-unit-direction tangent pass for the norm loss, as before (A/B, fallback; the elastic regulariser needs the
+  // whole warp Jacobian and keeps it)
+  static const bool rev_on = !(getenv("NERFDS_TRAIN_REVERSE_SIGMA") && std::string(getenv("NERFDS_TRAIN_REVERSE_SIGMA")) == "0");
+  const bool rev = nl && !el && rev_on;
   auto as_f = [](const std::vector<uint16_t*>& v) { std::vector<float*> o; for (auto* p : v) o.push_back(reinterpret_cast<float*>(p)); return o; };
   const std::vector<float*> gt = as_f(t.gt16), gh = as_f(t.gh16), gw = as_f(t.gw16);
   const float scale_target = 5.f;             // (run_level: the largest cotangent lands at 2^5)
@@ -1169,6 +1193,94 @@ int run_merged_full(nerfds_trainer& t, hipStream_t st, int R, const float* zc, c
     const MlpP& trunk = t.trunk[level];
     Objective obl = ob;
     if (level != 0) { obl.hyper_reg_weight = 0.f; obl.elastic_weight = 0.f; }
+    if (rev) {
+      // ---- reverse mode for grad_x sigma, forward over reverse for its gradient (train_kernels.hip k_fill_head4 ...).  Shared networks: in POSITION
+      // order (their ReLU bits live there) - the coarse level's rows ARE positions [0, Mc); the fine level's cotangents / directions are scattered to the
+      // positions (each exactly once) and the results gathered back. ----
+      const bool fine = level != 0;
+      const int64_t Mp = fine ? Ms : Mc;
+      const float* x_p = t.x; const float* wv_p = t.wv;
+      // (A) d sigma_raw / d x: trunk + alpha head, encodings, hyper sheet, exp_se3, warp field - one row per sample, split bf16
+      fill_head4(st, M, nullptr, 1.f, cot_l);
+      fused_reverse(t, st, 4, level, M, cot_l, 4, t.d_t_tin, D.trunk_in);
+      trunk_in_bwd(st, D, M, t.d_t_tin, xw_l, wamb_l, W, nullptr, nullptr, sa_l, sb_l);          // a = d sigma / d x', b = d sigma / d ambient
+      se3_bwd(st, M, wv_l, x_l, sa_l, nullptr, sc_l);                                             // c = d sigma / d (w, v)
+      const float* b_pp = sb_l; const float* c_pp = sc_l;
+      if (fine) { scatter_cols(st, M, src, 0, 1, 2, sb_l, sb_p); scatter_cols(st, M, src, 0, 1, 6, sc_l, sc_p); b_pp = sb_p; c_pp = sc_p; }
+      fused_reverse(t, st, 1, 0, Mp, b_pp, 2, t.d_hyper_in, D.hyper_ld);
+      fused_reverse(t, st, 2, 0, Mp, c_pp, 6, t.d_warp_in, D.warp_ld);
+      posenc_rev_x(st, D, Mp, x_p, t.d_warp_in, t.d_hyper_in, W, gx_p);
+      const float* gx_ll = gx_p;
+      if (fine) { gather_cols(st, M, src, 1, 3, gx_p, gx_l); gx_ll = gx_l; }
+      sigma_grad_assemble(st, M, wv_l, sa_l, gx_ll, t.t_alpha);
+      target_norm(st, M, t.t_alpha, wv_l, t.tn[level]);
+      aux_losses(st, R, Sl, obl, z, weights, x_l, xw_l, t.alphav, viewdirs, ml_l, rays->gt_mask, t.terms_dev + 4 * level, dxw_reg_l, t.d_alpha, d_pm_l, wamb_l,
+                 t.terms_dev + 9 + level, t.dwamb_reg, t.terms_dev + 13 + level);
+      norm_loss(st, R, Sl, norm_weight, weights, t.alphav, t.t_alpha, wv_l, t.tn[level], t.terms_dev + 4 * level + 3, t.d_alpha, t.d_t_alpha, du_l, ghat_l);
+      // (B) the tangent pass along c = d L / d (grad_x sigma), ONE row per sample, scaled to O(1) by a power of two K (slot 12 .. 15)
+      pick_scale(st, t.d_t_alpha, 3 * M * 4, 0.f, 1.f, t.tan_slot + 12);
+      make_dir(st, M, t.d_t_alpha, t.tan_slot + 12, dir_l, cot_l);
+      const float* dir_pp = dir_l;
+      if (fine) { scatter_cols(st, M, src, 0, 1, 3, dir_l, dir_p); dir_pp = dir_p; }
+      encode_tangent_dir(st, D, Mp, x_p, dir_pp, W, t.t_warp_in, t.t_hyper_in);
+      fused_tangent(t, st, 2, 0, Mp, t.t_warp_in, D.warp_ld, t.t_wv, 6, 1);
+      se3_jvp_dir(st, Mp, wv_p, x_p, dir_pp, t.t_wv, t.t_xw);
+      fused_tangent(t, st, 1, 0, Mp, t.t_hyper_in, D.hyper_ld, t.t_wamb, 2, 1);
+      const float* txw_l = t.t_xw; const float* twa_l = t.t_wamb;
+      if (fine) { gather_cols(st, M, src, 1, 3, t.t_xw, const_cast<float*>(t_xw_l)); gather_cols(st, M, src, 1, 2, t.t_wamb, const_cast<float*>(t_wamb_l)); txw_l = t_xw_l; twa_l = t_wamb_l; }
+      trunk_in_jvp(st, D, M, xw_l, wamb_l, txw_l, twa_l, W, t.t_tin, 1);
+      fused_tangent(t, st, 4, level, M, t.t_tin, D.trunk_in, t.t_alpha, 4, 1);
+      // (C) its backward from the head cotangent 1 / K, and the weight gradients: products of (B)'s stored tangents and (C)'s g, one row per sample
+      {
+        Run rt{t, st, M};
+        rt.tan = true;
+        pick_scale(st, cot_l, M * 4, scale_target, t.tan_x_scale, t.tan_slot);
+        rt.tan_slot = t.tan_slot;
+        fused_tangent_backward(t, st, 4, level, M, cot_l, 4, t.d_t_tin, D.trunk_in, t.tan_slot, 1);
+        rt.fork(false);
+        rt.head_wgrads(t.alpha[level], t.tt16.back(), trunk.width, cot_l, 4);
+        rt.mlp_wgrads(trunk, t.t_tin, t.tt16, gt);
+        rt.wg_turn = -1;
+        if (!rt.ok) { ok = false; what = rt.unsupported_what; }
+      }
+      trunk_in_jvp_bwd(st, D, M, t.d_t_tin, xw_l, wamb_l, txw_l, twa_l, W, d_t_xw_l, d_t_wamb_l, dxw_reg_l, dwamb_extra_l, 1);
+      if (hreg && level == 0) add_inplace(st, dwamb_extra_l, t.dwamb_reg, 2 * M);
+      se3_rot_bwd(st, M, wv_l, du_l, ghat_l, rot_l);
+      const float* dtx_pp = d_t_xw_l; const float* dtw_pp = d_t_wamb_l; const float* rot_pp = rot_l;
+      if (fine) {
+        scatter_cols(st, M, src, 0, 1, 3, d_t_xw_l, dtx_p); scatter_cols(st, M, src, 0, 1, 2, d_t_wamb_l, dtw_p); scatter_cols(st, M, src, 0, 1, 6, rot_l, rot_p);
+        dtx_pp = dtx_p; dtw_pp = dtw_p; rot_pp = rot_p;
+      }
+      {
+        Run rt{t, st, Mp};
+        rt.tan = true;
+        pick_scale(st, dtw_pp, Mp * 2, scale_target, t.tan_x_scale, t.tan_slot + 4);
+        rt.tan_slot = t.tan_slot + 4;
+        fused_tangent_backward(t, st, 1, 0, Mp, dtw_pp, 2, nullptr, 0, t.tan_slot + 4, 1);
+        rt.fork(false);
+        rt.head_wgrads(t.hyper_out, t.th16.back(), t.hyper.width, dtw_pp, 2);
+        rt.mlp_wgrads(t.hyper, t.t_hyper_in, t.th16, gh);
+        // exp_se3's second derivatives: this level's share of dwv_extra, per position (the coarse level writes its block and clears the rest, the
+        // fine level adds to all of it), on top of the level's rotation term
+        if (!fine) {
+          se3_jvp_bwd(st, Mp, wv_p, x_p, t.t_wv, dtx_pp, nullptr, nullptr, t.d_t_wv, t.dwv_extra, rot_pp, dir_pp);
+          (void)hipMemsetAsync(t.dwv_extra + 6 * Mc, 0, (size_t)6 * (Ms - Mc) * sizeof(float), st);
+        } else {
+          add_inplace(st, t.dwv_extra, rot_pp, 6 * Mp);
+          se3_jvp_bwd(st, Mp, wv_p, x_p, t.t_wv, dtx_pp, nullptr, nullptr, t.d_t_wv, t.dwv_extra, t.dwv_extra, dir_pp);
+        }
+        pick_scale(st, t.d_t_wv, Mp * 6, scale_target, t.tan_x_scale, t.tan_slot + 8);
+        rt.tan_slot = t.tan_slot + 8;
+        fused_tangent_backward(t, st, 2, 0, Mp, t.d_t_wv, 6, nullptr, 0, t.tan_slot + 8, 1);
+        rt.fork(false);
+        rt.head_wgrads(t.warp_w, t.tw16.back(), t.warp.width, t.d_t_wv, 6);
+        rt.head_wgrads(t.warp_v, t.tw16.back(), t.warp.width, t.d_t_wv + 3, 6);
+        rt.mlp_wgrads(t.warp, t.t_warp_in, t.tw16, gw);
+        rt.wg_turn = -1;
+        if (!rt.ok) { ok = false; what = rt.unsupported_what; }
+      }
+      return;
+    }
     if (nl) {
       trunk_in_jvp(st, D, M, xw_l, wamb_l, t_xw_l, t_wamb_l, W, t.t_tin);
       fused_tangent(t, st, 4, level, 3 * M, t.t_tin, D.trunk_in, t.t_alpha, 4);
@@ -1216,7 +1328,7 @@ int run_merged_full(nerfds_trainer& t, hipStream_t st, int R, const float* zc, c
   mask_post(st, D, R, Nf, t.mask_logit + Mc, rays->gt_mask, ex->mask_ratio, t.warp_in + Mc * D.warp_ld, t.hyper_in + Mc * D.hyper_ld);
   se3_fwd(st, Mn, t.wv + 6 * Mc, t.x + 3 * Mc, t.xw + 3 * Mc);
   // ---------------- the shared networks' tangent chains, once over the positions ----------------
-  if (so) {
+  if (so && !rev) {
     encode_tangents(st, D, Mt, t.x, W, t.t_warp_in, t.t_hyper_in);
     fused_tangent(t, st, 2, 0, 3 * Mt, t.t_warp_in, D.warp_ld, t.t_wv, 6);
     se3_jvp(st, Mt, t.wv, t.x, t.t_wv, t.t_xw);
@@ -1231,7 +1343,7 @@ int run_merged_full(nerfds_trainer& t, hipStream_t st, int R, const float* zc, c
   gather_rows(st, Mf, src, t.xw, t.wamb, t.wv, xw_f, wamb_f, wv_f);
   gather_cols(st, Mf, src, 1, 3, t.x, x_f);
   gather_cols(st, Mf, src, 1, 1, t.mask_logit, ml_f);
-  if (nl) { gather_cols(st, Mf, src, 3, 3, t.t_xw, t_xw_f); gather_cols(st, Mf, src, 3, 2, t.t_wamb, t_wamb_f); }
+  if (nl && !rev) { gather_cols(st, Mf, src, 3, 3, t.t_xw, t_xw_f); gather_cols(st, Mf, src, 3, 2, t.t_wamb, t_wamb_f); }
   rc.join();
   if (!rc.ok) return t.fail(NERFDS_ENOTSUP, "%s", rc.unsupported_what.c_str());
   Run rf{t, st, Mf};
@@ -1246,14 +1358,14 @@ int run_merged_full(nerfds_trainer& t, hipStream_t st, int R, const float* zc, c
   trunk_in_bwd(st, D, Mf, t.d_trunk_in, xw_f, wamb_f, W, dxw_reg_f, nl ? dwamb_extra_f : nullptr, dxw_f, dwamb_f);
   scatter_rows(st, Mf, src, Mc, dxw_f, dwamb_f, t.dxw, t.dwamb);
   scatter_cols(st, Mf, src, Mc, 1, 1, d_pm_f, t.d_pm);
-  if (nl) {
+  if (nl && !rev) {
     scatter_cols(st, Mf, src, Mc, 3, 3, d_t_xw_f, t.d_t_xw);
     scatter_cols(st, Mf, src, Mc, 3, 2, d_t_wamb_f, t.d_t_wamb);
     scatter_cols(st, Mf, src, Mc, 1, 6, rot_f, rot);
   }
   if (!ok) return t.fail(NERFDS_ENOTSUP, "%s", what.c_str());
   // ---------------- the backward of the shared networks' tangent chains, once over the positions ----------------
-  if (so) {
+  if (so && !rev) {
     Run rt{t, st, 3 * Mt};
     rt.tan = true;
     if (nl) {

@@ -44,10 +44,17 @@ void trunk_in_bwd(hipStream_t, const Dims&, long long M, const float* dtin, cons
 void norm_loss(hipStream_t, int R, int S, float weight, const float* weights, const float* alpha, const float* t_alpha, const float* wv,
                const float* target_norm, float* term, float* d_alpha, float* d_t_alpha, float* du, float* ghat);
 void trunk_in_jvp_bwd(hipStream_t, const Dims&, long long M, const float* d_t_tin, const float* xw, const float* wamb, const float* t_xw,
-                      const float* t_wamb, const Windows&, float* d_t_xw, float* d_t_wamb, float* dxw_extra, float* dwamb_extra);
+                      const float* t_wamb, const Windows&, float* d_t_xw, float* d_t_wamb, float* dxw_extra, float* dwamb_extra, int rp = 3);
 void se3_jvp_bwd(hipStream_t, long long M, const float* wv, const float* x, const float* t_wv, const float* d_t_xw, const float* du,
-                 const float* ghat, float* d_t_wv, float* dwv_extra, const float* extra_in = nullptr);
+                 const float* ghat, float* d_t_wv, float* dwv_extra, const float* extra_in = nullptr, const float* dir = nullptr);
 void se3_rot_bwd(hipStream_t, long long M, const float* wv, const float* du, const float* ghat, float* out);
+// the reverse-mode second-order path (train_kernels.hip: k_fill_head4 ...)
+void fill_head4(hipStream_t, long long M, const float* scale_dev, float value, float* out);
+void posenc_rev_x(hipStream_t, const Dims&, long long M, const float* x, const float* d_warp_in, const float* d_hyper_in, const Windows&, float* gx);
+void sigma_grad_assemble(hipStream_t, long long M, const float* wv, const float* a, const float* gx, float* t_alpha);
+void make_dir(hipStream_t, long long M, const float* d_t_alpha, const float* slot, float* dir, float* cot);
+void encode_tangent_dir(hipStream_t, const Dims&, long long M, const float* x, const float* dir, const Windows&, float* t_warp_in, float* t_hyper_in);
+void se3_jvp_dir(hipStream_t, long long M, const float* wv, const float* x, const float* dir, const float* t_wv, float* t_xw);
 void aux_losses(hipStream_t, int R, int S, const Objective&, const float* z, const float* weights, const float* x, const float* xw, const float* alpha,
                 const float* viewdirs, const float* mask_logit, const float* gt_mask, float* terms, float* dxw_reg, float* d_alpha, float* d_pm,
                 const float* wamb = nullptr, float* term_hyper = nullptr, float* dwamb_reg = nullptr, float* term_occlusion = nullptr);   // hyper-point regulariser: ambient coordinates in, its term and d / d wamb out
@@ -78,7 +85,7 @@ void fill(hipStream_t, float* p, long long n, float v);
 void encode_tangents(hipStream_t, const Dims&, long long M, const float* x, const Windows&, float* t_warp_in, float* t_hyper_in);
 void relu_mask3(hipStream_t, float* t, const float* y, long long M, int N);
 void se3_jvp(hipStream_t, long long M, const float* wv, const float* x, const float* t_wv, float* t_xw);
-void trunk_in_jvp(hipStream_t, const Dims&, long long M, const float* xw, const float* wamb, const float* t_xw, const float* t_wamb, const Windows&, float* t_tin);
+void trunk_in_jvp(hipStream_t, const Dims&, long long M, const float* xw, const float* wamb, const float* t_xw, const float* t_wamb, const Windows&, float* t_tin, int rp = 3);
 void target_norm(hipStream_t, long long M, const float* t_alpha, const float* wv, float* out);
 void clip_gradients(hipStream_t, float* g, long long n, float max_val, float max_norm, float* sumsq_scratch);
 void adam(hipStream_t, float* p, const float* g, float* m1, float* m2, long long n, float lr, float b1, float b2, float eps, long long* step_dev,

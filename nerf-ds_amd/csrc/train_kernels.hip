@@ -446,8 +446,9 @@ __global__ __launch_bounds__(256) void k_se3_jvp(long long M, const float* __res
 // One thread per (sample, feature): the derivative factor of a feature - one cosf - serves the sample's three tangent rows, and consecutive threads
 // write consecutive floats of a row.  (Through round 4: one thread per tangent ROW, 52 cosf each and every store instruction 64 rows apart: 0.75 ms
 // per launch on 524 288 samples where the bytes take 0.1.)  Same arithmetic per element, same bits.
+// rp: tangent rows per sample - 3 (unit directions, row 3 m + j) or 1 (ONE direction per sample: the reverse-mode second-order path)
 __global__ void k_trunk_in_jvp(Dims D, long long M, const float* __restrict__ xw, const float* __restrict__ wamb, const float* __restrict__ t_xw,
-                               const float* __restrict__ t_wamb, Windows W, float* __restrict__ t_tin) {
+                               const float* __restrict__ t_wamb, Windows W, float* __restrict__ t_tin, int rp) {
   const int TI = D.trunk_in, NS = 6 * D.sp_bands;
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= M * TI) return;
@@ -464,6 +465,7 @@ __global__ void k_trunk_in_jvp(Dims D, long long M, const float* __restrict__ xw
     const float a[2] = {wamb[2 * m], wamb[2 * m + 1]};
     dv = posenc_dval<2>(g - NS, a, W.hp); ch = (g - NS) % 2; tsrc = t_wamb; tld = 2;
   }
+  if (rp == 1) { t_tin[m * TI + g] = dv * tsrc[m * tld + ch]; return; }
 #pragma unroll
   for (int j = 0; j < 3; ++j) t_tin[(3 * m + j) * TI + g] = dv * tsrc[(3 * m + j) * tld + ch];
 }
@@ -550,7 +552,7 @@ __global__ void k_norm_loss(int R, int S, float weight, const float* __restrict_
 // the same order of the sums over the features of a channel; the second-derivative terms are summed per row first, then over the three rows.
 __global__ void k_trunk_in_jvp_bwd(Dims D, long long M, const float* __restrict__ d_t_tin, const float* __restrict__ xw, const float* __restrict__ wamb,
                                    const float* __restrict__ t_xw, const float* __restrict__ t_wamb, Windows W, float* __restrict__ d_t_xw,
-                                   float* __restrict__ d_t_wamb, float* __restrict__ dxw_extra, float* __restrict__ dwamb_extra) {
+                                   float* __restrict__ d_t_wamb, float* __restrict__ dxw_extra, float* __restrict__ dwamb_extra, int rp) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= 5 * M) return;
   const long long m = i / 5;
@@ -568,13 +570,15 @@ __global__ void k_trunk_in_jvp_bwd(Dims D, long long M, const float* __restrict_
     const float fc = win[band] * sc2 * cosf(arg), fs = -win[band] * sc2 * sc2 * sinf(arg);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const float dt = d_t_tin[(3 * m + j) * D.trunk_in + g0 + g];
-      acc[j] += dt * fc;
-      ex[j] += dt * tt[(3 * m + j) * C + c] * fs;
+      if (j < rp) {
+        const float dt = d_t_tin[(rp * m + j) * D.trunk_in + g0 + g];
+        acc[j] += dt * fc;
+        ex[j] += dt * tt[(rp * m + j) * C + c] * fs;
+      }
     }
   }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) dtt[(3 * m + j) * C + c] = acc[j];
+  for (int j = 0; j < 3; ++j) if (j < rp) dtt[(rp * m + j) * C + c] = acc[j];
   if (sp) dxw_extra[3 * m + c] += (ex[0] + ex[1]) + ex[2];
   else dwamb_extra[2 * m + c] = (ex[0] + ex[1]) + ex[2];
 }
@@ -606,8 +610,9 @@ template <class T> __device__ __forceinline__ D1<T> tconst(float c, const D1<T>*
 // scratch (228 - 908 bytes per lane) and the kernel is SLOWER than before (1.63 ms at two) - it is left the whole register file.
 __global__ __launch_bounds__(256) void k_se3_jvp_bwd(long long M, const float* __restrict__ wv, const float* __restrict__ x, const float* __restrict__ t_wv,
                               const float* __restrict__ d_t_xw, const float* __restrict__ du, const float* __restrict__ ghat,
-                              float* __restrict__ d_t_wv, float* __restrict__ dwv_extra, const float* __restrict__ extra_in) {
+                              float* __restrict__ d_t_wv, float* __restrict__ dwv_extra, const float* __restrict__ extra_in, const float* __restrict__ dir) {
   // du / ghat null: no rotation term here (the merged step forms it per level, k_se3_rot_bwd, and hands the sum in as extra_in)
+  // dir non-null: ONE tangent row per sample, t_xw = R dir + J t_wv (k_se3_jvp_dir), instead of the three unit directions e_j
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (idx >= 6 * M) return;
   const long long m = idx / 6;
@@ -626,15 +631,19 @@ __global__ __launch_bounds__(256) void k_se3_jvp_bwd(long long M, const float* _
     float xd[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) xd[r] = (Rm[3 * r] * xs[0] + Rm[3 * r + 1] * xs[1] + Rm[3 * r + 2] * xs[2] + p[r]).d;
+    const int rp = dir != nullptr ? 1 : 3;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      float acc = 0.f;
+      if (j < rp) {
+        float acc = 0.f;
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float a = d_t_xw[(3 * m + j) * 3 + r];
-        acc += a * xd[r]; extra += a * Rm[3 * r + j].d;                                              // J^T a_j ; grad <a_j, R e_j>
+        for (int r = 0; r < 3; ++r) {
+          const float a = d_t_xw[(rp * m + j) * 3 + r];
+          const float rd = dir != nullptr ? Rm[3 * r].d * dir[3 * m] + Rm[3 * r + 1].d * dir[3 * m + 1] + Rm[3 * r + 2].d * dir[3 * m + 2] : Rm[3 * r + j].d;
+          acc += a * xd[r]; extra += a * rd;                                                        // J^T a_j ; grad <a_j, R e_j> (<a, R dir>)
+        }
+        d_t_wv[(rp * m + j) * 6 + i] = acc;
       }
-      d_t_wv[(3 * m + j) * 6 + i] = acc;
     }
     if (du != nullptr) {
 #pragma unroll
@@ -643,20 +652,21 @@ __global__ __launch_bounds__(256) void k_se3_jvp_bwd(long long M, const float* _
         for (int c = 0; c < 3; ++c) extra += du[3 * m + r] * ghat[3 * m + c] * Rm[3 * r + c].d;         // grad <du, R ghat>
     }
   }
+  const int rp2 = dir != nullptr ? 1 : 3;
 #pragma unroll 1
-  for (int j = 0; j < 3; ++j) {  // grad_{(w,v)} <a_j, DF[t_wv_j]>: the directional derivative along t_wv_j, differentiated again along e_i
+  for (int j = 0; j < rp2; ++j) {  // grad_{(w,v)} <a_j, DF[t_wv_j]>: the directional derivative along t_wv_j, differentiated again along e_i
     D1<D1<float>> w[3], v[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      w[k].v = {wvs[k], i == k ? 1.f : 0.f};         w[k].d = {t_wv[(3 * m + j) * 6 + k], 0.f};
-      v[k].v = {wvs[3 + k], i == 3 + k ? 1.f : 0.f}; v[k].d = {t_wv[(3 * m + j) * 6 + 3 + k], 0.f};
+      w[k].v = {wvs[k], i == k ? 1.f : 0.f};         w[k].d = {t_wv[(rp2 * m + j) * 6 + k], 0.f};
+      v[k].v = {wvs[3 + k], i == 3 + k ? 1.f : 0.f}; v[k].d = {t_wv[(rp2 * m + j) * 6 + 3 + k], 0.f};
     }
     D1<D1<float>> Rm[9], p[3];
     se3_Rp<D1<D1<float>>>(w, v, Rm, p);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const D1<D1<float>> xr = Rm[3 * r] * xs[0] + Rm[3 * r + 1] * xs[1] + Rm[3 * r + 2] * xs[2] + p[r];
-      extra += d_t_xw[(3 * m + j) * 3 + r] * xr.d.d;
+      extra += d_t_xw[(rp2 * m + j) * 3 + r] * xr.d.d;
     }
   }
   dwv_extra[6 * m + i] = extra + (extra_in != nullptr ? extra_in[6 * m + i] : 0.f);
@@ -1160,12 +1170,102 @@ void norm_loss(hipStream_t st, int R, int S, float weight, const float* weights,
   LAUNCH(k_norm_loss, (long long)R * S, st, R, S, weight, weights, alpha, t_alpha, wv, target_norm, term, d_alpha, d_t_alpha, du, ghat);
 }
 void trunk_in_jvp_bwd(hipStream_t st, const Dims& D, long long M, const float* d_t_tin, const float* xw, const float* wamb, const float* t_xw,
-                      const float* t_wamb, const Windows& W, float* d_t_xw, float* d_t_wamb, float* dxw_extra, float* dwamb_extra) {
-  LAUNCH(k_trunk_in_jvp_bwd, 5 * M, st, D, M, d_t_tin, xw, wamb, t_xw, t_wamb, W, d_t_xw, d_t_wamb, dxw_extra, dwamb_extra);
+                      const float* t_wamb, const Windows& W, float* d_t_xw, float* d_t_wamb, float* dxw_extra, float* dwamb_extra, int rp) {
+  LAUNCH(k_trunk_in_jvp_bwd, 5 * M, st, D, M, d_t_tin, xw, wamb, t_xw, t_wamb, W, d_t_xw, d_t_wamb, dxw_extra, dwamb_extra, rp);
 }
 void se3_jvp_bwd(hipStream_t st, long long M, const float* wv, const float* x, const float* t_wv, const float* d_t_xw, const float* du,
-                 const float* ghat, float* d_t_wv, float* dwv_extra, const float* extra_in) {
-  LAUNCH(k_se3_jvp_bwd, 6 * M, st, M, wv, x, t_wv, d_t_xw, du, ghat, d_t_wv, dwv_extra, extra_in);
+                 const float* ghat, float* d_t_wv, float* dwv_extra, const float* extra_in, const float* dir) {
+  LAUNCH(k_se3_jvp_bwd, 6 * M, st, M, wv, x, t_wv, d_t_xw, du, ghat, d_t_wv, dwv_extra, extra_in, dir);
+}
+// ---- the reverse-mode second-order path (round 5, nerfds_train.cpp run_merged_full `rev`): d sigma_raw / d x by ONE reverse pass per sample (the
+// networks' data-gradient chains with the cotangent e_sigma), the norm loss's cotangent c = d L / d (grad_x sigma) from it, and then - forward over
+// reverse - the tangent pass along the ONE direction c per sample and its backward: grad_theta <c, grad_x sigma> = grad_theta D_c sigma.  A third of
+// the tangent rows of the three-unit-direction scheme.  The element-wise pieces between the chains:
+// e_sigma as head cotangents [M][4] (scaled), or any constant first column
+__global__ void k_fill_head4(long long M, const float* __restrict__ scale_dev, float value, float* __restrict__ out) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  *reinterpret_cast<float4*>(out + 4 * m) = make_float4(scale_dev != nullptr ? value * scale_dev[0] : value, 0.f, 0.f, 0.f);
+}
+// gx[m][j] = sum over the posenc columns g with g % 3 == j of d_in[m][g] * d posenc_g / d x_j, warp field input + hyper sheet input (the transpose of
+// k_encode_tangents: same columns, same factors; the GLO / mask columns do not depend on x)
+__global__ void k_posenc_rev_x(Dims D, long long M, const float* __restrict__ x, const float* __restrict__ d_warp_in, const float* __restrict__ d_hyper_in,
+                               Windows W, float* __restrict__ gx) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= 3 * M) return;
+  const long long m = i / 3;
+  const int j = (int)(i - 3 * m);
+  const float p[3] = {x[3 * m], x[3 * m + 1], x[3 * m + 2]};
+  float acc = 0.f;
+  for (int g = j; g < 6 * D.warp_bands; g += 3) acc += d_warp_in[m * D.warp_ld + g] * posenc_dval<3>(g, p, W.warp);
+  for (int g = j; g < 6 * D.hyp_bands; g += 3) acc += d_hyper_in[m * D.hyper_ld + g] * posenc_dval<3>(g, p, W.hyp);
+  gx[i] = acc;
+}
+// grad_x sigma = R^T a + gx (a = d sigma / d x', gx = the part through the two networks' inputs), written where the tangent pass leaves it: column 0 of
+// rows 3 m + j of t_alpha [3 M][4] (k_target_norm / k_norm_loss read it there)
+__global__ void k_sigma_grad_assemble(long long M, const float* __restrict__ wv, const float* __restrict__ a, const float* __restrict__ gx, float* __restrict__ t_alpha) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float w[3] = {wv[6 * m], wv[6 * m + 1], wv[6 * m + 2]}, v[3] = {wv[6 * m + 3], wv[6 * m + 4], wv[6 * m + 5]};
+  float Rm[9], p[3];
+  se3_Rp<float>(w, v, Rm, p);
+  for (int j = 0; j < 3; ++j) {
+    const float g = Rm[j] * a[3 * m] + Rm[3 + j] * a[3 * m + 1] + Rm[6 + j] * a[3 * m + 2] + gx[3 * m + j];
+    *reinterpret_cast<float4*>(t_alpha + (3 * m + j) * 4) = make_float4(g, 0.f, 0.f, 0.f);
+  }
+}
+// the direction of the tangent pass: dir[m][j] = K * d_t_alpha[3 m + j][0] (K = slot[1], a power of two picked from the largest cotangent: the pass is
+// linear in the direction, and the f16 stores of its hidden tangents want O(1) values), and the cotangent of its head, [1 / K, 0, 0, 0] per sample
+__global__ void k_make_dir(long long M, const float* __restrict__ d_t_alpha, const float* __restrict__ slot, float* __restrict__ dir, float* __restrict__ cot) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float K = slot[1], inv = slot[2];
+  for (int j = 0; j < 3; ++j) dir[3 * m + j] = K * d_t_alpha[(3 * m + j) * 4];
+  *reinterpret_cast<float4*>(cot + 4 * m) = make_float4(inv, 0.f, 0.f, 0.f);
+}
+// k_encode_tangents along ONE direction per sample: t_in[m][g] = d posenc_g / d x_{g % 3} * dir[m][g % 3]
+__global__ void k_encode_tangent_dir(Dims D, long long M, const float* __restrict__ x, const float* __restrict__ dir, Windows W, float* __restrict__ t_warp_in,
+                                     float* __restrict__ t_hyper_in) {
+  const int LD = D.warp_ld > D.hyper_ld ? D.warp_ld : D.hyper_ld;
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= M * LD) return;
+  const long long m = i / LD;
+  const int g = (int)(i - m * LD);
+  const float p[3] = {x[3 * m], x[3 * m + 1], x[3 * m + 2]};
+  const float dj = dir[3 * m + g % 3];
+  if (g < D.warp_ld) t_warp_in[m * D.warp_ld + g] = (g < 6 * D.warp_bands) ? posenc_dval<3>(g, p, W.warp) * dj : 0.f;
+  if (g < D.hyper_ld) t_hyper_in[m * D.hyper_ld + g] = (g < 6 * D.hyp_bands) ? posenc_dval<3>(g, p, W.hyp) * dj : 0.f;
+}
+// k_se3_jvp along ONE direction per sample: t_xw = R dir + (d x' / d (w, v)) t_wv
+__global__ __launch_bounds__(256) void k_se3_jvp_dir(long long M, const float* __restrict__ wv, const float* __restrict__ x, const float* __restrict__ dir,
+                                                     const float* __restrict__ t_wv, float* __restrict__ t_xw) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  Dual w[3], v[3];
+  for (int i = 0; i < 3; ++i) { w[i] = dconst(wv[6 * m + i]); w[i].g[i] = 1.f; v[i] = dconst(wv[6 * m + 3 + i]); v[i].g[3 + i] = 1.f; }
+  Dual Rm[9], p[3];
+  se3_Rp<Dual>(w, v, Rm, p);
+  for (int r = 0; r < 3; ++r) {
+    const Dual xr = Rm[3 * r] * x[3 * m] + Rm[3 * r + 1] * x[3 * m + 1] + Rm[3 * r + 2] * x[3 * m + 2] + p[r];
+    float acc = Rm[3 * r].v * dir[3 * m] + Rm[3 * r + 1].v * dir[3 * m + 1] + Rm[3 * r + 2].v * dir[3 * m + 2];
+    for (int i = 0; i < 6; ++i) acc += xr.g[i] * t_wv[6 * m + i];
+    t_xw[3 * m + r] = acc;
+  }
+}
+void fill_head4(hipStream_t st, long long M, const float* scale_dev, float value, float* out) { LAUNCH(k_fill_head4, M, st, M, scale_dev, value, out); }
+void posenc_rev_x(hipStream_t st, const Dims& D, long long M, const float* x, const float* d_warp_in, const float* d_hyper_in, const Windows& W, float* gx) {
+  LAUNCH(k_posenc_rev_x, 3 * M, st, D, M, x, d_warp_in, d_hyper_in, W, gx);
+}
+void sigma_grad_assemble(hipStream_t st, long long M, const float* wv, const float* a, const float* gx, float* t_alpha) {
+  LAUNCH(k_sigma_grad_assemble, M, st, M, wv, a, gx, t_alpha);
+}
+void make_dir(hipStream_t st, long long M, const float* d_t_alpha, const float* slot, float* dir, float* cot) { LAUNCH(k_make_dir, M, st, M, d_t_alpha, slot, dir, cot); }
+void encode_tangent_dir(hipStream_t st, const Dims& D, long long M, const float* x, const float* dir, const Windows& W, float* t_warp_in, float* t_hyper_in) {
+  const int LD = D.warp_ld > D.hyper_ld ? D.warp_ld : D.hyper_ld;
+  LAUNCH(k_encode_tangent_dir, M * LD, st, D, M, x, dir, W, t_warp_in, t_hyper_in);
+}
+void se3_jvp_dir(hipStream_t st, long long M, const float* wv, const float* x, const float* dir, const float* t_wv, float* t_xw) {
+  LAUNCH(k_se3_jvp_dir, M, st, M, wv, x, dir, t_wv, t_xw);
 }
 void se3_rot_bwd(hipStream_t st, long long M, const float* wv, const float* du, const float* ghat, float* out) {
   LAUNCH(k_se3_rot_bwd, 6 * M, st, M, wv, du, ghat, out);
@@ -1339,8 +1439,8 @@ void encode_tangents(hipStream_t st, const Dims& D, long long M, const float* x,
 void relu_mask3(hipStream_t st, float* t, const float* y, long long M, int N) { LAUNCH(k_relu_mask3, 3 * M * N, st, t, y, M, N); }
 void se3_jvp(hipStream_t st, long long M, const float* wv, const float* x, const float* t_wv, float* t_xw) { LAUNCH(k_se3_jvp, M, st, M, wv, x, t_wv, t_xw); }
 void trunk_in_jvp(hipStream_t st, const Dims& D, long long M, const float* xw, const float* wamb, const float* t_xw, const float* t_wamb,
-                  const Windows& W, float* t_tin) {
-  LAUNCH(k_trunk_in_jvp, M * D.trunk_in, st, D, M, xw, wamb, t_xw, t_wamb, W, t_tin);
+                  const Windows& W, float* t_tin, int rp) {
+  LAUNCH(k_trunk_in_jvp, M * D.trunk_in, st, D, M, xw, wamb, t_xw, t_wamb, W, t_tin, rp);
 }
 void target_norm(hipStream_t st, long long M, const float* t_alpha, const float* wv, float* out) { LAUNCH(k_target_norm, M, st, M, t_alpha, wv, out); }
 void clip_gradients(hipStream_t st, float* g, long long n, float max_val, float max_norm, float* sumsq_scratch) {
