@@ -156,6 +156,7 @@ struct nerfds_trainer {
   void* bstream16[4] = {nullptr, nullptr, nullptr, nullptr};
   // the trunk's tangent FORWARD stream of each level as one f16 unit per fragment (tan_fwd_f16: NERFDS_TRAIN_TAN_FWD_F16=1, training steps only)
   bool tan_fwd_f16 = false;
+  bool rev_fwd_f16 = false;      // the reverse-mode path's directional tangent pass of the trunk in f16 (NERFDS_TRAIN_REV_FWD_F16=0: split bf16)
   void* tstream16[2] = {nullptr, nullptr};
   uint16_t* tws16 = nullptr;      // the tangents (allocated on first use)
   uint16_t* gws16 = nullptr;      // their cotangents (allocated on first use by a step that differentiates the tangent pass)
@@ -569,7 +570,8 @@ bool ensure_norm_ws(nerfds_trainer& t) {
   return true;
 }
 
-void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* t_in, int ld_in, float* t_head, int ld_head, int mask_div = 3);
+void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* t_in, int ld_in, float* t_head, int ld_head, int mask_div = 3,
+                   bool f16_ok = false);
 
 // d sigma_raw / d x by forward-mode tangents through warp MLP -> exp_se3, hyper sheet, posenc, trunk, alpha head
 // (the mask is a constant input, models.py:1035-1069), then target_norm (models.py:1077, 1273-1277, 1328).  Uses the
@@ -855,11 +857,11 @@ bool build_fused_backward(nerfds_trainer& t) {
       t.tan_bwd_f16 = true;
     }
     static const bool f16_fwd = getenv("NERFDS_TRAIN_TAN_FWD_F16") && std::string(getenv("NERFDS_TRAIN_TAN_FWD_F16")) == "1";
-    if (f16_fwd) {
-      for (int i = 0; i < levels; ++i)
-        if (!alloc16(&t.tstream16[i], t.tfrags[i])) return false;
-      t.tan_fwd_f16 = true;
-    }
+    static const bool rev_f16 = !(getenv("NERFDS_TRAIN_REV_FWD_F16") && std::string(getenv("NERFDS_TRAIN_REV_FWD_F16")) == "0");
+    for (int i = 0; i < levels; ++i)
+      if (!alloc16(&t.tstream16[i], t.tfrags[i])) return false;
+    t.tan_fwd_f16 = f16_fwd;
+    t.rev_fwd_f16 = rev_f16;
     t.fused_tan = true;
   }
   // f16 activations + ReLU bits of every hidden layer (one allocation), the sink of the input-gradient stores
@@ -895,7 +897,7 @@ void pack_fused_tangents(nerfds_trainer& t, hipStream_t st) {
     if (t.tmap[which]) pack_stream(st, t.theta, t.fold, t.P, t.tmap[which], t.tstream[which], t.tfrags[which], 0, 0);
   for (int lv = 0; lv < 2; ++lv)
     if (t.amap[lv]) pack_stream(st, t.theta, t.fold, t.P, t.amap[lv], t.astream[lv], t.afrags[lv], 0, 0);
-  if (t.tan_fwd_f16)
+  if (t.tan_fwd_f16 || t.rev_fwd_f16)
     for (int lv = 0; lv < 2; ++lv)
       if (t.tstream16[lv]) pack_stream(st, t.theta, t.fold, t.P, t.tmap[lv], t.tstream16[lv], t.tfrags[lv], 0, 0, 2);
   if (t.tan_bwd_f16) {      // the same maps, one f16 unit per fragment (k_pack_stream mode 2)
@@ -935,7 +937,10 @@ bool ensure_tan16_g(nerfds_trainer& t) {
 }
 // tangent FORWARD chain of net 1 hyper sheet, 2 warp field, 4 trunk + alpha head of `level`: t_in [3 M][ld_in] -> t_head [3 M][ld_head], hidden tangents -> store16
 // (mask_div 3: three tangent rows per sample, row r reads the masks of sample r / 3; 1: one row per sample - the reverse-mode second-order path)
-void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* t_in, int ld_in, float* t_head, int ld_head, int mask_div) {
+// f16_ok: the caller's tangents feed weight gradients only (the reverse-mode path: target_norm comes from the reverse pass), so the trunk's chain may
+// run in one f16 MFMA per product like the tangent pass's backward chains
+void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* t_in, int ld_in, float* t_head, int ld_head, int mask_div,
+                   bool f16_ok) {
   nerfds::TrainBwd tb{};
   tb.M = M3; tb.d_head = t_in; tb.ld_head = ld_in; tb.d_in = t_head; tb.ld_in = ld_head; tb.sink = t.sink;
   tb.g_half = 1; tb.g_scale = t.tan_x_scale; tb.g_inv_scale = 1.f / t.tan_x_scale; tb.mask_div = mask_div;
@@ -946,7 +951,7 @@ void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_
   else { tb.wstream = t.tstream[level]; bits = &t.trunk_bits; store = &t.tt16; }
   for (size_t l = 0; l < bits->size(); ++l) { tb.bits[l] = (*bits)[l]; tb.g[l] = reinterpret_cast<float*>((*store)[l]); }
   // (experiment, off: the trunk's chain of a step that differentiates the tangent pass in one f16 MFMA per product - see profiles/r5_ab/README.md)
-  if (net == 4 && t.tan_fwd_f16 && t.keep_tangents) { tb.wstream = t.tstream16[level]; nerfds_launch_train_tan16f_nerfds(tb, t.num_cus, st); }
+  if (net == 4 && t.tstream16[level] && ((f16_ok && t.rev_fwd_f16) || (t.tan_fwd_f16 && t.keep_tangents))) { tb.wstream = t.tstream16[level]; nerfds_launch_train_tan16f_nerfds(tb, t.num_cus, st); }
   else nerfds_launch_train_tan16_nerfds(tb, net, t.num_cus, st);
 }
 // data-gradient chain of the TANGENT pass: cotangent of the head's tangent [3 M][ld_head] (its scale picked on the device: slot) -> g of every hidden
@@ -1229,7 +1234,7 @@ int run_merged_full(nerfds_trainer& t, hipStream_t st, int R, const float* zc, c
       const float* txw_l = t.t_xw; const float* twa_l = t.t_wamb;
       if (fine) { gather_cols(st, M, src, 1, 3, t.t_xw, const_cast<float*>(t_xw_l)); gather_cols(st, M, src, 1, 2, t.t_wamb, const_cast<float*>(t_wamb_l)); txw_l = t_xw_l; twa_l = t_wamb_l; }
       trunk_in_jvp(st, D, M, xw_l, wamb_l, txw_l, twa_l, W, t.t_tin, 1);
-      fused_tangent(t, st, 4, level, M, t.t_tin, D.trunk_in, t.t_alpha, 4, 1);
+      fused_tangent(t, st, 4, level, M, t.t_tin, D.trunk_in, t.t_alpha, 4, 1, true);
       // (C) its backward from the head cotangent 1 / K, and the weight gradients: products of (B)'s stored tangents and (C)'s g, one row per sample
       {
         Run rt{t, st, M};
