@@ -91,7 +91,9 @@ constexpr Plan plan_of(int prec_index) {
 // gradients by the 2^7-frequency encoding of the warped point).  Two units per fragment (three in a P_BF16X6 warp field).
 // (NERFDS_TRAIN_WARP_X6: the warp field in P_BF16X6 instead - 6 x 32 MFMA cycles per fragment where fp32 takes 8 x 64.  Measured 21.2 ->
 // 20.8 ms per step, but two warp-side leaves of the multi-tile gradient test move from just under to just over their bounds
-// (6.4e-3 against 6e-3, 2.0e-2 against 1.5e-2): the exact fp32 products stay the default.)
+// (6.4e-3 against 6e-3, 2.0e-2 against 1.5e-2): the exact fp32 products stay the default.  Round 5, re-measured at 11.4 ms per step: 11.3 ms with it, the
+// multi-tile rgb test's warp leaves at 2.1e-2 (fp32: 7.9e-3) - and 1.9e-2 with ALL NINE products of the three-way split, so it is not the dropped
+// terms but the bf16 MFMA's internal accumulation that is coarser than the fp32 MFMA's.)
 #ifdef NERFDS_TRAIN_WARP_X6
 constexpr Plan TRAIN_PLAN = Plan{P_BF16X3, P_BF16X6, P_BF16X3, P_BF16X3, P_BF16X3};
 #else
