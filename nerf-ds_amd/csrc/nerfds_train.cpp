@@ -154,6 +154,14 @@ struct nerfds_trainer {
   // second-order terms' data-gradient chains in one f16 MFMA per product; NERFDS_TRAIN_TAN_BWD_F16=0: split bf16 like the primal chains)
   bool tan_bwd_f16 = false;
   void* bstream16[4] = {nullptr, nullptr, nullptr, nullptr};
+  // OPTION (NERFDS_TRAIN_BWD_F16=1, read at every step; off): the PRIMAL data-gradient chains in one f16 MFMA per product too - the five reversed
+  // streams as f16 units.  Every g these chains produce is handed to the weight gradients as loss-scaled f16 already; on f16 operands they also
+  // PROPAGATE it at 11 bits per layer (fp32 accumulate).  rgb step 11.7 -> 10.3 ms, nerf_ds.gin 22.6 -> 21.3.  Against the fp64 oracle: 64 rays 2.97e-3
+  // (2.90e-3 in split bf16), 33 rays 3.2e-3 (2.8e-3), multi-tile 8.8e-3 on the noisy leaf (7.9e-3), but the 6-ray case 1.4e-3 (3.5e-4) and the 16-ray
+  // golden digests 2.2e-3 / 1.4e-3 (6.9e-4 / 1.1e-4), and the head cotangents times the loss scale must now fit f16 (split bf16 has fp32's range:
+  // the scale sweep of test_gradient_scale_of_the_f16_g_arrays overflows at 2^22) - so it is the caller's choice, not the default.
+  bool bwd_f16 = false;
+  void* pstream16[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // the trunk's tangent FORWARD stream of each level as one f16 unit per fragment (tan_fwd_f16: NERFDS_TRAIN_TAN_FWD_F16=1, training steps only)
   bool tan_fwd_f16 = false;
   bool rev_fwd_f16 = false;      // the reverse-mode path's directional tangent pass of the trunk in f16 (NERFDS_TRAIN_REV_FWD_F16=0: split bf16)
@@ -201,6 +209,7 @@ struct nerfds_trainer {
     for (int i = 0; i < 4; ++i) { if (tmap[i]) (void)hipFree(tmap[i]); if (tstream[i]) (void)hipFree(tstream[i]); }
     for (int i = 0; i < 2; ++i) { if (amap[i]) (void)hipFree(amap[i]); if (astream[i]) (void)hipFree(astream[i]); }
     for (int i = 0; i < 4; ++i) if (bstream16[i]) (void)hipFree(bstream16[i]);
+    for (int i = 0; i < 5; ++i) if (pstream16[i]) (void)hipFree(pstream16[i]);
     for (int i = 0; i < 2; ++i) if (tstream16[i]) (void)hipFree(tstream16[i]);
     if (adam_dev) (void)hipFree(adam_dev);
     if (wpack) (void)hipFree(wpack);
@@ -887,8 +896,21 @@ bool build_fused_backward(nerfds_trainer& t) {
 }
 
 void pack_fused_backward(nerfds_trainer& t, hipStream_t st) {
+  const bool f16_on = getenv("NERFDS_TRAIN_BWD_F16") && std::string(getenv("NERFDS_TRAIN_BWD_F16")) == "1";
+  t.bwd_f16 = false;
   for (int which = 0; which < 5; ++which)
     if (t.bmap[which]) pack_stream(st, t.theta, t.fold, t.P, t.bmap[which], t.bstream[which], t.bfrags[which], 0, 0);
+  if (f16_on && t.g16) {
+    for (int which = 0; which < 5; ++which) {
+      if (!t.bmap[which]) continue;
+      if (!t.pstream16[which]) {
+        const size_t bytes = (size_t)nerfds::pad_units(t.bfrags[which]) * 1024;
+        if (hipMalloc(&t.pstream16[which], bytes) != hipSuccess || hipMemset(t.pstream16[which], 0, bytes) != hipSuccess) return;
+      }
+      pack_stream(st, t.theta, t.fold, t.P, t.bmap[which], t.pstream16[which], t.bfrags[which], 0, 0, 2);
+    }
+    t.bwd_f16 = true;
+  }
 }
 
 // the streams of the tangent pass from the current parameters (steps that run tangents only)
@@ -1005,7 +1027,10 @@ void fused_backward(nerfds_trainer& t, hipStream_t st, int net, int level, int64
   else if (net == 2) { tb.wstream = t.bstream[3]; bits = &t.warp_bits; g = &t.warp_h; }
   else { tb.wstream = t.bstream[4]; bits = &t.mask_bits; g = &t.mask_h; }
   for (size_t l = 0; l < bits->size(); ++l) { tb.bits[l] = (*bits)[l]; tb.g[l] = (*g)[l]; }
-  if (tb.g_half) nerfds_launch_train_bwd16_nerfds(tb, net, t.num_cus, st);
+  if (tb.g_half && t.bwd_f16) {
+    tb.wstream = t.pstream16[net == 0 ? level : (net == 1 ? 2 : (net == 2 ? 3 : 4))];
+    nerfds_launch_train_bwd16f_nerfds(tb, net, t.num_cus, st);
+  } else if (tb.g_half) nerfds_launch_train_bwd16_nerfds(tb, net, t.num_cus, st);
   else nerfds_launch_train_bwd_nerfds(tb, net, t.num_cus, st);
 }
 

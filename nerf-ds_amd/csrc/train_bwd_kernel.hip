@@ -213,11 +213,14 @@ extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::TrainBwd& 
 }
 
 #if NERFDS_TRAIN_HALF
-// the backward chains of the tangent pass in one f16 MFMA per product: net 1 hyper sheet, 2 warp field, 4 trunk + alpha head (f16-store build only)
+// the data-gradient chains in one f16 MFMA per product (the primal step's - NERFDS_TRAIN_BWD_F16 - and the tangent pass's): net 0 NerfMLP, 1 hyper sheet,
+// 2 warp field, 3 mask net, 4 trunk + alpha head (f16-store build only)
 extern "C" void nerfds_launch_train_bwd16f_nerfds(const nerfds::TrainBwd& tb, int net, int num_cus, void* stream) {
   using G = nerfds::NERFDS_GRAPH;
   if (net == 1) launch_bwd<nerfds::BwdHyper<G>, true>(tb, num_cus, stream);
   else if (net == 2) launch_bwd<nerfds::BwdWarp<G>, true>(tb, num_cus, stream);
+  else if (net == 0) launch_bwd<nerfds::BwdNerf<G>, true>(tb, num_cus, stream);
+  else if (net == 3) launch_bwd<nerfds::BwdMask<G>, true>(tb, num_cus, stream);
   else launch_bwd<nerfds::BwdTrunkAlpha<G>, true>(tb, num_cus, stream);
 }
 template <class TG, bool F16 = false> static void launch_tan(const nerfds::TrainBwd& tb, int num_cus, void* stream) {
