@@ -581,6 +581,7 @@ bool ensure_norm_ws(nerfds_trainer& t) {
 
 void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* t_in, int ld_in, float* t_head, int ld_head, int mask_div = 3,
                    bool f16_ok = false);
+void fused_reverse(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M, const float* d_head, int ld_head, float* d_in, int ld_in);
 
 // d sigma_raw / d x by forward-mode tangents through warp MLP -> exp_se3, hyper sheet, posenc, trunk, alpha head
 // (the mask is a constant input, models.py:1035-1069), then target_norm (models.py:1077, 1273-1277, 1328).  Uses the
@@ -589,6 +590,25 @@ void sigma_gradient(nerfds_trainer& t, Run& r, int level, const Windows& W) {
   const Dims& D = t.D;
   hipStream_t st = r.st;
   const int64_t M = r.M;
+  static const bool rev_on = !(getenv("NERFDS_TRAIN_REVERSE_SIGMA") && std::string(getenv("NERFDS_TRAIN_REVERSE_SIGMA")) == "0");
+  if (t.fused_tan && t.half_step && rev_on && !t.keep_tangents && !t.tangents_warp_only && t.g1) {
+    // target_norm alone (NERFDS_TRAIN_SIGMA_GRAD without a term that differentiates it: NerfModel.apply(use_sigma_gradient=True)): d sigma_raw / d x by
+    // ONE reverse pass per sample - the networks' data-gradient chains with the cotangent e_sigma, as jax.grad does it (models.py:1035-1069) - instead
+    // of three forward-mode rows (run_merged_full `rev` (A)); scratch in the layer-by-layer backward's buffers, the chains' f16 g into the tangent arrays
+    float* p = t.g1;
+    auto take = [&](int64_t n) { float* q = p; p += (n + 63) & ~(int64_t)63; return q; };
+    float* cot = take(4 * M); float* sa = take(3 * M); float* sb = take(2 * M); float* sc = take(6 * M); float* gx = take(3 * M);
+    fill_head4(st, M, nullptr, 1.f, cot);
+    fused_reverse(t, st, 4, level, M, cot, 4, t.t_tin, D.trunk_in);
+    trunk_in_bwd(st, D, M, t.t_tin, t.xw, t.wamb, W, nullptr, nullptr, sa, sb);
+    se3_bwd(st, M, t.wv, t.x, sa, nullptr, sc);
+    fused_reverse(t, st, 1, 0, M, sb, 2, t.d_hyper_in, D.hyper_ld);
+    fused_reverse(t, st, 2, 0, M, sc, 6, t.d_warp_in, D.warp_ld);
+    posenc_rev_x(st, D, M, t.x, t.d_warp_in, t.d_hyper_in, W, gx);
+    sigma_grad_assemble(st, M, t.wv, sa, gx, t.t_alpha);
+    target_norm(st, M, t.t_alpha, t.wv, t.tn[level]);
+    return;
+  }
   encode_tangents(st, D, M, t.x, W, t.t_warp_in, t.t_hyper_in);
   if (t.fused_tan && t.half_step) {
     // ONE launch per network (train_bwd_kernel.hip train_tangent_kernel): the three tangents of a sample as three rows of a masked linear chain in
@@ -1006,9 +1026,10 @@ void fused_reverse(nerfds_trainer& t, hipStream_t st, int net, int level, int64_
   tb.g_half = 1; tb.g_scale = 1.f; tb.g_inv_scale = 1.f; tb.mask_div = 0;
   const std::vector<uint16_t*>* bits = nullptr;
   const std::vector<uint16_t*>* store = nullptr;
-  if (net == 1) { tb.wstream = t.bstream[2]; bits = &t.hyper_bits; store = &t.gh16; }
-  else if (net == 2) { tb.wstream = t.bstream[3]; bits = &t.warp_bits; store = &t.gw16; }
-  else { tb.wstream = t.astream[level]; bits = &t.trunk_bits; store = &t.gt16; }
+  // (a step that differentiates no tangent pass has no g arrays: the tangent arrays - one per network then, every layer over the same rows - take the stores)
+  if (net == 1) { tb.wstream = t.bstream[2]; bits = &t.hyper_bits; store = t.gh16.empty() ? &t.th16 : &t.gh16; }
+  else if (net == 2) { tb.wstream = t.bstream[3]; bits = &t.warp_bits; store = t.gw16.empty() ? &t.tw16 : &t.gw16; }
+  else { tb.wstream = t.astream[level]; bits = &t.trunk_bits; store = t.gt16.empty() ? &t.tt16 : &t.gt16; }
   for (size_t l = 0; l < bits->size(); ++l) { tb.bits[l] = (*bits)[l]; tb.g[l] = reinterpret_cast<float*>((*store)[l]); }
   nerfds_launch_train_bwd16_nerfds(tb, net, t.num_cus, st);
 }
