@@ -359,7 +359,7 @@ template <class G, class PL> struct Pipe {
       if (t >= seg_stages(seg) || t < seg_used(seg)) young += PIECES;
 #ifdef NERFDS_PROF_BOUND
     unsigned long long pb0, pb1, pb2;
-    asm volatile("s_memtime %0" : "=s"(pb0) :: "memory");        // (valid behind the lgkmcnt(0) below)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pb0) :: "memory");      // (the ring reads in flight are drained HERE in this build: t_wait = the vmcnt part + one timer read)
 #endif
     // (A counted lgkmcnt in the pinned chains - the 8 youngest ring reads left in flight, safe there because program order is source order -
     // measured +-0 against the full drain: 38.25 against 38.26 ms per 65 536 rays, profiles/r4_ab/ab_x3_pin_variants.txt; not kept.)
