@@ -547,6 +547,42 @@ def test_gradient_clipping_matches_utils_clip_gradients():
   _assert_same_update(a._download(0), b._download(0), 1e-3)
 
 
+_FALLBACK_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from tests.test_training import _problem, EX, OBJECTIVE, tree_leaves
+from nerfds_amd.training import Trainer
+from oracle import train_oracle as T
+cfg, params, batch, t, u = _problem(24, 16, 16)
+ob = dict(OBJECTIVE, norm_loss_weight=0.05, hyper_reg_loss_weight=0.01)
+L, G, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=ob)
+tr = Trainer(cfg, params, max_rays=24)
+stats = tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=ob)
+got, want = dict(tree_leaves(tr.get_grads())), dict(tree_leaves(G))
+gmax = max(np.abs(v).max() for v in want.values())
+worst = max(float(np.linalg.norm(got[k].reshape(w.shape) - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size))) for k, w in want.items())
+print('WORST %%.3e LOSSDIFF %%.3e' %% (worst, abs(stats['loss/total'] - L['total'])))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('env', [{'NERFDS_TRAIN_REVERSE_SIGMA': '0'}, {'NERFDS_TRAIN_MERGED_FULL': '0'}, {'NERFDS_TRAIN_REV_FWD_F16': '0', 'NERFDS_TRAIN_TAN_BWD_F16': '0'}],
+                         ids=['three_directions', 'level_by_level', 'split_bf16_tangent_chains'])
+def test_fallback_flows_of_the_objective_step(env):
+  """The switches that restore the earlier flows of the whole-objective step (read once per process, hence a subprocess each): the three-unit-direction
+  tangent pass instead of the reverse-mode one, the level-by-level flow instead of the shared networks once per position, split-bf16 tangent chains
+  instead of f16 - same objective as test_norm_loss_second_order_matches_the_oracle (only_norm=False), same oracle, same bound."""
+  import subprocess
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  e = dict(os.environ, **env)
+  out = subprocess.run([sys.executable, '-c', _FALLBACK_SNIPPET % root], env=e, capture_output=True, text=True, timeout=600, cwd=root)
+  line = [l for l in out.stdout.splitlines() if l.startswith('WORST')]
+  assert line, out.stderr[-800:]
+  worst, lossdiff = float(line[0].split()[1]), float(line[0].split()[3])
+  print(f'fallback {env}: worst leaf l2 {worst:.2e}', file=sys.stderr)
+  assert worst < L2_TOL_2ND['mfma'] and lossdiff < 2e-5, line
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('full', [False, True])
 def test_gradients_match_the_oracle_at_multi_tile_size(full):
