@@ -547,6 +547,30 @@ def test_gradient_clipping_matches_utils_clip_gradients():
   _assert_same_update(a._download(0), b._download(0), 1e-3)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('R,Nc,Nf', [(37, 12, 20), (50, 24, 8)])
+def test_whole_objective_step_at_ragged_shapes(R, Nc, Nf):
+  """The whole-objective step (shared networks once per position, reverse-mode norm loss) where nothing divides anything: a ray count that is no multiple
+  of the workgroup's four rays, Nc != Nf (the gathers / scatters between the fine level's row order and the position rows), a trainer built for more rays
+  than the batch holds.  Same objective and bound as test_norm_loss_second_order_matches_the_oracle."""
+  from nerfds_amd.training import Trainer
+  from oracle import train_oracle as T
+  cfg, params, batch, t, u = _problem(R, Nc, Nf)
+  ob = dict(OBJECTIVE, norm_loss_weight=0.05, hyper_reg_loss_weight=0.01)
+  L, G, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=ob)
+  tr = Trainer(cfg, params, max_rays=R + 7)
+  stats = tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=ob)
+  assert abs(stats['loss/total'] - L['total']) < 2e-5 * max(1.0, abs(L['total']))
+  got, want = dict(tree_leaves(tr.get_grads())), dict(tree_leaves(G))
+  gmax = max(np.abs(v).max() for v in want.values())
+  worst = (0.0, '')
+  for name, w in want.items():
+    l2 = float(np.linalg.norm(got[name].reshape(w.shape) - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size)))
+    worst = max(worst, (l2, name))
+    assert l2 < L2_TOL_2ND['mfma'], (name, l2)
+  print(f'ragged ({R} rays, {Nc}+{Nf}): worst leaf l2 {worst[0]:.2e} ({worst[1]})', file=sys.stderr)
+
+
 _FALLBACK_SNIPPET = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
