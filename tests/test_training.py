@@ -548,15 +548,18 @@ def test_gradient_clipping_matches_utils_clip_gradients():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('R,Nc,Nf', [(37, 12, 20), (50, 24, 8)])
-def test_whole_objective_step_at_ragged_shapes(R, Nc, Nf):
+@pytest.mark.parametrize('R,Nc,Nf,elastic', [(37, 12, 20, False), (50, 24, 8, False), (37, 12, 20, True)])
+def test_whole_objective_step_at_ragged_shapes(R, Nc, Nf, elastic):
   """The whole-objective step (shared networks once per position, reverse-mode norm loss) where nothing divides anything: a ray count that is no multiple
   of the workgroup's four rays, Nc != Nf (the gathers / scatters between the fine level's row order and the position rows), a trainer built for more rays
-  than the batch holds.  Same objective and bound as test_norm_loss_second_order_matches_the_oracle."""
+  than the batch holds.  Same objective and bound as test_norm_loss_second_order_matches_the_oracle; `elastic` adds the elastic regulariser - with it the
+  norm loss runs on the three-direction tangent pass (the regulariser needs the whole warp Jacobian), both second-order terms in one step."""
   from nerfds_amd.training import Trainer
   from oracle import train_oracle as T
   cfg, params, batch, t, u = _problem(R, Nc, Nf)
   ob = dict(OBJECTIVE, norm_loss_weight=0.05, hyper_reg_loss_weight=0.01)
+  if elastic:
+    ob.update(elastic_loss_weight=0.01, elastic_reduce_method='weight')
   L, G, _ = T.loss_and_grads(cfg, params, batch, batch['rgb'], EX, t, u, objective=ob)
   tr = Trainer(cfg, params, max_rays=R + 7)
   stats = tr.step(batch, EX, 0.0, t_rand=t, u_rand=u, grads_only=True, objective=ob)
@@ -568,7 +571,7 @@ def test_whole_objective_step_at_ragged_shapes(R, Nc, Nf):
     l2 = float(np.linalg.norm(got[name].reshape(w.shape) - w) / max(np.linalg.norm(w), 1e-3 * gmax * np.sqrt(w.size)))
     worst = max(worst, (l2, name))
     assert l2 < L2_TOL_2ND['mfma'], (name, l2)
-  print(f'ragged ({R} rays, {Nc}+{Nf}): worst leaf l2 {worst[0]:.2e} ({worst[1]})', file=sys.stderr)
+  print(f'ragged ({R} rays, {Nc}+{Nf}, elastic={elastic}): worst leaf l2 {worst[0]:.2e} ({worst[1]})', file=sys.stderr)
 
 
 _FALLBACK_SNIPPET = r"""
