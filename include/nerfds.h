@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NERFDS_ABI_VERSION 6
+#define NERFDS_ABI_VERSION 7
 
 /* error codes */
 #define NERFDS_OK         0
@@ -369,6 +369,45 @@ int nerfds_trainer_get_step(nerfds_trainer* t, int64_t* step_out);
  * non-finite because g left f16's range is re-run by the caller at a lower adjust (nerfds_amd/training.py: -2 per retry, +1 back after 1000 clean
  * steps) - with a fixed scale the deterministic retry would overflow the same way.  [-40, 16]; no reference counterpart (the reference's g is fp32). */
 int nerfds_trainer_set_loss_scale_adjust(nerfds_trainer* t, int32_t log2_adjust);
+/* ---- Numeric policy of the trainer's f16 storage, and the diagnosis of a skipped update (ABI 7) ----------------------------------------------
+ * No reference counterpart: the reference's step is fp32 throughout and cannot overflow (training.py:494-508).  This trainer stores activations,
+ * the chains' g, the second-order terms' tangents and their cotangents as (power-of-two scaled) f16; an element beyond 65504 becomes inf there, the
+ * gradient check of the update finds it, and the update is skipped as a whole (NERFDS_ENONFINITE).  The caller then asks WHICH array overflowed
+ * (nerfds_trainer_overflow_sources) and re-runs the step - same rays, same seed - under a policy that removes that source:
+ *   NERFDS_OVF_PRIMAL_G      lower loss_scale_log2_adjust            (the stored g of the primal chains left f16's range)
+ *   NERFDS_OVF_TANGENT /     lower tangent_scale_log2_adjust and / or chain_arith = NERFDS_CHAINS_SPLIT_BF16
+ *   NERFDS_OVF_COTANGENT     (the second-order terms' stored tangents / cotangents, or a value BETWEEN the layers of a chain run in one f16 MFMA per product)
+ *   NERFDS_OVF_ACTIVATION    fp32_step = 1: fp32 activations and fp32 g, layer by layer - no f16 storage anywhere, the arithmetic range of the reference
+ *   NERFDS_OVF_FP32          nothing: an fp32 value of the FORWARD pass is inf / NaN (a loss, a head output, the screw axis, a warped point) - the
+ *                            reference's step would carry the same inf / NaN into its parameters; fp32_step = 1 confirms it without f16 in the way
+ *   NERFDS_OVF_FP32_BACKWARD an fp32 cotangent of the BACKWARD pass (a head's, the warped points', the screw axes', the ambient coordinates') and
+ *   NERFDS_OVF_FP32_SECOND_ORDER   NERFDS_OVF_FP32_SECOND_ORDER (the norm loss / elastic terms' fp32 tangents and cotangents): a CONSEQUENCE when a
+ *                            TANGENT / COTANGENT array overflowed (the second-order chains' outputs feed the primal backward), genuine - as FP32 - otherwise
+ * Causality runs ACTIVATION -> TANGENT -> COTANGENT -> PRIMAL_G: the earliest source set is the one to remove.
+ * nerfds_amd/training.py Trainer.step implements that ladder; it ends in fp32_step, so a step the reference could take is never refused. */
+#define NERFDS_CHAINS_DEFAULT 0     /* the second-order terms' chains in one f16 MFMA per product where the build does so */
+#define NERFDS_CHAINS_SPLIT_BF16 1  /* every chain in split bf16: operands with fp32's exponent range */
+typedef struct nerfds_train_numerics {
+  int32_t loss_scale_log2_adjust;     /* [-40, 16]: as nerfds_trainer_set_loss_scale_adjust */
+  int32_t tangent_scale_log2_adjust;  /* [-24, 12]: stored tangents carry 2^(-6 + adjust), the device-picked cotangent scale aims its largest element at 2^(5 + adjust) */
+  int32_t chain_arith;                /* NERFDS_CHAINS_* */
+  int32_t fp32_step;                  /* 0 / 1 */
+  int32_t diagnose;                   /* 0 / 1: the step also scans the COARSE NerfMLP's arrays before the fine level overwrites them (a repeated attempt, to attribute its overflow) */
+} nerfds_train_numerics;
+int nerfds_trainer_set_numerics(nerfds_trainer* t, const nerfds_train_numerics* numerics);   /* takes effect at the next step; all zero = the default */
+int nerfds_trainer_get_numerics(const nerfds_trainer* t, nerfds_train_numerics* numerics);
+#define NERFDS_OVF_ACTIVATION 1u
+#define NERFDS_OVF_PRIMAL_G 2u
+#define NERFDS_OVF_TANGENT 4u
+#define NERFDS_OVF_COTANGENT 8u
+#define NERFDS_OVF_FP32 16u
+#define NERFDS_OVF_FP32_SECOND_ORDER 32u
+#define NERFDS_OVF_FP32_BACKWARD 64u
+#define NERFDS_OVF_DETAIL_SHIFT 8     /* bits 8 .. 29: WHICH fp32 array (csrc/nerfds_train.cpp nerfds_trainer_overflow_sources lists them); diagnosis only, not part of the contract */
+/* Scans the stored arrays of the LAST step for inf / NaN (synchronises the device; a pass over the workspace: call it after a skipped update only).
+ * Arrays a later level of the same step overwrote (the coarse NerfMLP's, under the fine level's) are seen only if the step ran with numerics.diagnose = 1;
+ * mask 0 after a skipped update = unattributed: repeat the attempt with diagnose = 1 and ask again. */
+int nerfds_trainer_overflow_sources(nerfds_trainer* t, uint32_t* mask_out);
 /* Development / tests: HOST copy of an internal device buffer of the last step (the f16 activations, ReLU bits and per-layer
  * gradients g_l of the fused backward, the head / input gradients): "<net>_h16_<l>", "<net>_bits_<l>", "<net>_g_<l>" with net = mask |
  * warp | hyper | trunk, "rgb_h16", "rgb_bits", "rgb_g", "d_rgb_logit", "d_alpha", "d_trunk_in", "d_hyper_in", "d_warp_in",

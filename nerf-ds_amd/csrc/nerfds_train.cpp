@@ -84,15 +84,32 @@ struct nerfds_trainer {
   bool fwd_only = false;
   // dynamic loss scaling of the stored f16 g (include/nerfds.h nerfds_trainer_set_loss_scale_adjust): log2 offset on the heuristic exponent
   int g_scale_adjust = 0;
+  // Numeric policy of a step (include/nerfds.h nerfds_train_numerics; the host's overflow ladder, nerfds_amd/training.py Trainer.step, sets it):
+  //   tan_scale_adjust  log2 offset on BOTH powers of two of the second-order terms' f16 storage: the stored tangents' (2^(-6 + adjust)) and the target the
+  //                     device-picked cotangent scale aims at (2^(5 + adjust)) - lower = more headroom for what the chains amplify
+  //   chain_arith       0: the chains the build runs in one f16 MFMA per product (tan_bwd_f16 / rev_fwd_f16 / tan_fwd_f16 / bwd_f16) do; 1: every chain in split
+  //                     bf16 (operands with fp32's exponent range: nothing overflows BETWEEN the layers of a chain)
+  //   fp32_step         the step keeps fp32 activations and fp32 g and runs layer by layer (no f16 storage anywhere: the arithmetic range of the reference's step)
+  int tan_scale_adjust = 0, chain_arith = 0;
+  bool fp32_step = false;
+  bool diag = false;         // nerfds_train_numerics.diagnose: scan the coarse NerfMLP's arrays before the fine level overwrites them (diag_scan_nerf)
+  bool use_tan_bwd_f16() const { return tan_bwd_f16 && chain_arith == 0; }
+  bool use_rev_fwd_f16() const { return rev_fwd_f16 && chain_arith == 0; }
+  bool use_tan_fwd_f16() const { return tan_fwd_f16 && chain_arith == 0; }
+  float scale_target() const { return 5.f + (float)tan_scale_adjust; }      // the largest cotangent of a tangent chain lands at 2^5 by default: 2^11 of headroom
+  // what the last step ran on (nerfds_trainer_overflow_sources scans these rows): rays, rows of the tangent arrays, second-order terms on / off
+  int64_t last_R = 0, last_tan_rows = 0;
+  bool last_half = false, last_keep_tangents = false, last_tan16 = false;
   float* ws = nullptr;      // one workspace allocation
   size_t ws_floats = 0;
   float* loss_dev = nullptr;
   float* tws = nullptr;     // tangent workspace of the sigma gradient (allocated on first use)
-  float *t_warp_in, *t_hyper_in, *tA, *tB, *t_wv, *t_xw, *t_wamb, *t_tin, *t_alpha;
+  float *t_warp_in = nullptr, *t_hyper_in = nullptr, *tA = nullptr, *tB = nullptr, *t_wv = nullptr, *t_xw = nullptr, *t_wamb = nullptr, *t_tin = nullptr, *t_alpha = nullptr;
+  float* tws32 = nullptr;   // tA / tB and the fp32 hidden tangents of the layer-by-layer tangent pass when the fused one is built too (fp32_step / NERFDS_TRAIN_HALF_TANGENTS=0)
   float* tn[2] = {nullptr, nullptr};      // target_norm of the coarse / fine level of the last step
   float* nws = nullptr;     // norm-loss workspace: stored tangents of every layer + tangent gradients (allocated on first use)
   std::vector<float*> tw_h, th_h, tt_h;
-  float *d_t_alpha, *d_t_tin, *d_t_xw, *d_t_wamb, *d_t_wv, *du, *ghat, *dwamb_extra, *dwv_extra;
+  float *d_t_alpha = nullptr, *d_t_tin = nullptr, *d_t_xw = nullptr, *d_t_wamb = nullptr, *d_t_wv = nullptr, *du = nullptr, *ghat = nullptr, *dwamb_extra = nullptr, *dwv_extra = nullptr;
   bool tn_valid = false;
   bool tangents_warp_only = false;   // this step's tangent pass stops at the warped point (elastic regulariser without norm loss / sigma-gradient flag)
   bool keep_tangents = false;
@@ -204,7 +221,7 @@ struct nerfds_trainer {
     return code;
   }
   ~nerfds_trainer() {
-    for (float* p : {theta, grad, m1, m2, ws, loss_dev, tws, terms_dev, nws, tan_slot}) if (p) (void)hipFree(p);
+    for (float* p : {theta, grad, m1, m2, ws, loss_dev, tws, tws32, terms_dev, nws, tan_slot}) if (p) (void)hipFree(p);
     for (uint16_t* p : {tws16, gws16}) if (p) (void)hipFree(p);
     for (int i = 0; i < 4; ++i) { if (tmap[i]) (void)hipFree(tmap[i]); if (tstream[i]) (void)hipFree(tstream[i]); }
     for (int i = 0; i < 2; ++i) { if (amap[i]) (void)hipFree(amap[i]); if (astream[i]) (void)hipFree(astream[i]); }
@@ -344,7 +361,8 @@ struct Run {
     A.colsum = rep(bias_grad);
     if (tan) {
       A.colsum = nullptr;
-      if (dy_half) { A.out_scale = 1.f; A.out_scale_dev = tan_slot + (x_half ? 3 : 2); }      // g scaled on the device; X scaled only when it is a stored f16 tangent
+      // g scaled on the device; X carries tan_x_scale: a stored f16 tangent does, a raw fp32 tangent input is multiplied on its way into f16 (x_scale)
+      if (dy_half) { A.out_scale = 1.f; A.out_scale_dev = tan_slot + 3; if (!x_half) A.x_scale = t.tan_x_scale; }
       else A.out_scale = x_half ? 1.f / t.tan_x_scale : 1.f;                                      // a head: fp32 cotangent, f16 tangent
     }
     if (!(wgrad_supported(A) && wgrad(wgrad_stream(), A, wgrad_grid(A, t.num_cus)))) unsupported("weight gradient", K, N, M);
@@ -575,6 +593,30 @@ bool ensure_norm_ws(nerfds_trainer& t) {
   take(&t.du, M * 3); take(&t.ghat, M * 3); take(&t.dwamb_extra, M * 2); take(&t.dwv_extra, M * 6);
   if (hipMalloc(&t.nws, need * sizeof(float)) != hipSuccess) return false;
   float* base = t.nws;
+  for (auto& v : views) { *v.first = base; base += (v.second + 63) & ~(size_t)63; }
+  return true;
+}
+
+// The layer-by-layer tangent pass on fp32 rows (sigma_gradient / run_level below, !half_step) when the trainer was built with the fused tangent chains:
+// ensure_tangent_ws / ensure_norm_ws then leave out its ping-pong rows tA / tB and the fp32 hidden tangents tw_h / th_h / tt_h - a step that keeps fp32
+// activations (nerfds_train_numerics.fp32_step, NERFDS_TRAIN_HALF_TANGENTS=0) allocates them here, on first use (`keep`: the hidden tangents too).
+bool ensure_tangent_ws32(nerfds_trainer& t, bool keep) {
+  if (!t.fused_tan) return true;                       // the two functions above allocated them
+  if (t.tws32 && (!keep || !t.tt_h.empty())) return true;
+  if (t.tws32) { (void)hipDeviceSynchronize(); (void)hipFree(t.tws32); t.tws32 = nullptr; t.tA = t.tB = nullptr; t.tw_h.clear(); t.th_h.clear(); t.tt_h.clear(); }
+  const int64_t M3 = 3 * t.max_rays * (t.cfg.num_coarse_samples + t.cfg.num_fine_samples);
+  const int TW = t.trunk[0].width;
+  size_t need = 0;
+  std::vector<std::pair<float**, size_t>> views;
+  auto take = [&](float** p, size_t n) { views.push_back({p, n}); need += (n + 63) & ~(size_t)63; };
+  take(&t.tA, M3 * TW); take(&t.tB, M3 * TW);
+  if (keep) {
+    t.tw_h.assign(t.warp.depth, nullptr); for (auto& p : t.tw_h) take(&p, M3 * t.warp.width);
+    t.th_h.assign(t.hyper.depth, nullptr); for (auto& p : t.th_h) take(&p, M3 * t.hyper.width);
+    t.tt_h.assign(t.trunk[0].depth, nullptr); for (auto& p : t.tt_h) take(&p, M3 * t.trunk[0].width);
+  }
+  if (hipMalloc(&t.tws32, need * sizeof(float)) != hipSuccess) { t.tA = t.tB = nullptr; t.tw_h.clear(); t.th_h.clear(); t.tt_h.clear(); return false; }
+  float* base = t.tws32;
   for (auto& v : views) { *v.first = base; base += (v.second + 63) & ~(size_t)63; }
   return true;
 }
@@ -916,7 +958,7 @@ bool build_fused_backward(nerfds_trainer& t) {
 }
 
 void pack_fused_backward(nerfds_trainer& t, hipStream_t st) {
-  const bool f16_on = getenv("NERFDS_TRAIN_BWD_F16") && std::string(getenv("NERFDS_TRAIN_BWD_F16")) == "1";
+  const bool f16_on = getenv("NERFDS_TRAIN_BWD_F16") && std::string(getenv("NERFDS_TRAIN_BWD_F16")) == "1" && t.chain_arith == 0;
   t.bwd_f16 = false;
   for (int which = 0; which < 5; ++which)
     if (t.bmap[which]) pack_stream(st, t.theta, t.fold, t.P, t.bmap[which], t.bstream[which], t.bfrags[which], 0, 0);
@@ -939,10 +981,10 @@ void pack_fused_tangents(nerfds_trainer& t, hipStream_t st) {
     if (t.tmap[which]) pack_stream(st, t.theta, t.fold, t.P, t.tmap[which], t.tstream[which], t.tfrags[which], 0, 0);
   for (int lv = 0; lv < 2; ++lv)
     if (t.amap[lv]) pack_stream(st, t.theta, t.fold, t.P, t.amap[lv], t.astream[lv], t.afrags[lv], 0, 0);
-  if (t.tan_fwd_f16 || t.rev_fwd_f16)
+  if (t.use_tan_fwd_f16() || t.use_rev_fwd_f16())
     for (int lv = 0; lv < 2; ++lv)
       if (t.tstream16[lv]) pack_stream(st, t.theta, t.fold, t.P, t.tmap[lv], t.tstream16[lv], t.tfrags[lv], 0, 0, 2);
-  if (t.tan_bwd_f16) {      // the same maps, one f16 unit per fragment (k_pack_stream mode 2)
+  if (t.use_tan_bwd_f16()) {      // the same maps, one f16 unit per fragment (k_pack_stream mode 2)
     for (int lv = 0; lv < 2; ++lv)
       if (t.amap[lv]) pack_stream(st, t.theta, t.fold, t.P, t.amap[lv], t.bstream16[lv], t.afrags[lv], 0, 0, 2);
     pack_stream(st, t.theta, t.fold, t.P, t.bmap[2], t.bstream16[2], t.bfrags[2], 0, 0, 2);
@@ -984,6 +1026,7 @@ bool ensure_tan16_g(nerfds_trainer& t) {
 void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* t_in, int ld_in, float* t_head, int ld_head, int mask_div,
                    bool f16_ok) {
   nerfds::TrainBwd tb{};
+  t.last_tan_rows = std::max(t.last_tan_rows, M3);
   tb.M = M3; tb.d_head = t_in; tb.ld_head = ld_in; tb.d_in = t_head; tb.ld_in = ld_head; tb.sink = t.sink;
   tb.g_half = 1; tb.g_scale = t.tan_x_scale; tb.g_inv_scale = 1.f / t.tan_x_scale; tb.mask_div = mask_div;
   const std::vector<uint16_t*>* bits = nullptr;
@@ -993,7 +1036,7 @@ void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_
   else { tb.wstream = t.tstream[level]; bits = &t.trunk_bits; store = &t.tt16; }
   for (size_t l = 0; l < bits->size(); ++l) { tb.bits[l] = (*bits)[l]; tb.g[l] = reinterpret_cast<float*>((*store)[l]); }
   // (experiment, off: the trunk's chain of a step that differentiates the tangent pass in one f16 MFMA per product - see profiles/r5_ab/README.md)
-  if (net == 4 && t.tstream16[level] && ((f16_ok && t.rev_fwd_f16) || (t.tan_fwd_f16 && t.keep_tangents))) { tb.wstream = t.tstream16[level]; nerfds_launch_train_tan16f_nerfds(tb, t.num_cus, st); }
+  if (net == 4 && t.tstream16[level] && ((f16_ok && t.use_rev_fwd_f16()) || (t.use_tan_fwd_f16() && t.keep_tangents))) { tb.wstream = t.tstream16[level]; nerfds_launch_train_tan16f_nerfds(tb, t.num_cus, st); }
   else nerfds_launch_train_tan16_nerfds(tb, net, t.num_cus, st);
 }
 // data-gradient chain of the TANGENT pass: cotangent of the head's tangent [3 M][ld_head] (its scale picked on the device: slot) -> g of every hidden
@@ -1001,12 +1044,13 @@ void fused_tangent(nerfds_trainer& t, hipStream_t st, int net, int level, int64_
 void fused_tangent_backward(nerfds_trainer& t, hipStream_t st, int net, int level, int64_t M3, const float* d_head, int ld_head, float* d_in, int ld_in,
                             const float* slot, int mask_div = 3) {
   nerfds::TrainBwd tb{};
+  t.last_tan_rows = std::max(t.last_tan_rows, M3);
   tb.M = M3; tb.d_head = d_head; tb.ld_head = ld_head; tb.sink = t.sink;
   tb.d_in = d_in ? d_in : t.sink; tb.ld_in = d_in ? ld_in : 0;            // ld_in 0: every input-gradient store goes to the sink (no parameters behind t_in)
   tb.g_half = 1; tb.g_scale = 1.f; tb.g_inv_scale = 1.f; tb.scale_dev = slot + 1; tb.mask_div = mask_div;
   const std::vector<uint16_t*>* bits = nullptr;
   const std::vector<uint16_t*>* store = nullptr;
-  const bool f16 = t.tan_bwd_f16;
+  const bool f16 = t.use_tan_bwd_f16();
   if (net == 1) { tb.wstream = f16 ? t.bstream16[2] : t.bstream[2]; bits = &t.hyper_bits; store = &t.gh16; }
   else if (net == 2) { tb.wstream = f16 ? t.bstream16[3] : t.bstream[3]; bits = &t.warp_bits; store = &t.gw16; }
   else { tb.wstream = f16 ? t.bstream16[level] : t.astream[level]; bits = &t.trunk_bits; store = &t.gt16; }
@@ -1094,6 +1138,42 @@ void fused_forward(nerfds_trainer& t, hipStream_t st, int level, int R, int S, c
   else nerfds_launch_train_fwd_nerfds(ka, to, t.num_cus, st);
 }
 
+// nerfds_train_numerics.diagnose: the NerfMLP arrays of `level` (M rows) scanned for inf / NaN into the overflow flags, at the point of the step where that
+// level's chains have run and the next level has not yet overwritten them (the coarse level's arrays are invisible to nerfds_trainer_overflow_sources
+// afterwards).  `second`: the level ran a tangent pass whose backward was differentiated (tan_rows rows of tt16 / gt16).
+void diag_scan_nerf(nerfds_trainer& t, hipStream_t st, int64_t M, bool second, int64_t tan_rows) {
+  if (!t.diag) return;
+  unsigned* flags = reinterpret_cast<unsigned*>(t.terms_dev + 15);
+  auto r8 = [](int64_t n) { return n & ~(int64_t)7; };
+  const int TW = t.trunk[0].width, RW = t.rgb_h[0].N;
+  if (t.half_step) {
+    for (auto* p : t.trunk_h16) if (p) scan_half(st, p, r8(M * TW), flags, NERFDS_OVF_ACTIVATION);
+    if (t.rgb_h16) scan_half(st, t.rgb_h16, r8(M * RW), flags, NERFDS_OVF_ACTIVATION);
+    for (auto* p : t.trunk_h) {
+      if (t.g16) scan_half(st, reinterpret_cast<const uint16_t*>(p), r8(M * TW), flags, NERFDS_OVF_PRIMAL_G);
+      else scan_float(st, p, M * TW, flags, NERFDS_OVF_PRIMAL_G);
+    }
+    if (t.g16) scan_half(st, reinterpret_cast<const uint16_t*>(t.rgb_hv), r8(M * RW), flags, NERFDS_OVF_PRIMAL_G);
+    else scan_float(st, t.rgb_hv, M * RW, flags, NERFDS_OVF_PRIMAL_G);
+  }
+  scan_float(st, t.alphav, M * 4, flags, NERFDS_OVF_FP32 | (1u << (NERFDS_OVF_DETAIL_SHIFT + 2)));
+  scan_float(st, t.rgb_logit, M * 3, flags, NERFDS_OVF_FP32 | (1u << (NERFDS_OVF_DETAIL_SHIFT + 3)));
+  scan_float(st, t.d_alpha, M * 4, flags, NERFDS_OVF_FP32_BACKWARD | (1u << (NERFDS_OVF_DETAIL_SHIFT + 6)));
+  scan_float(st, t.d_rgb_logit, M * 3, flags, NERFDS_OVF_FP32_BACKWARD | (1u << (NERFDS_OVF_DETAIL_SHIFT + 7)));
+  scan_float(st, t.d_trunk_in, M * t.D.trunk_in, flags, NERFDS_OVF_FP32_BACKWARD | (1u << (NERFDS_OVF_DETAIL_SHIFT + 11)));
+  if (second && t.fused_tan && t.half_step && tan_rows > 0) {
+    const uint16_t* prev = nullptr;
+    for (auto* p : t.tt16) { if (p && p != prev) scan_half(st, p, r8(tan_rows * TW), flags, NERFDS_OVF_TANGENT); prev = p; }
+    prev = nullptr;
+    for (auto* p : t.gt16) { if (p && p != prev) scan_half(st, p, r8(tan_rows * TW), flags, NERFDS_OVF_COTANGENT); prev = p; }
+    // the raw tangent input of the trunk enters its weight gradients as f16 at the stored tangents' scale (WgradArgs::x_scale)
+    scan_float(st, t.t_tin, tan_rows * t.D.trunk_in, flags, NERFDS_OVF_TANGENT, 65504.f / t.tan_x_scale);
+    scan_float(st, t.t_alpha, tan_rows * 4, flags, NERFDS_OVF_FP32_SECOND_ORDER | (1u << (NERFDS_OVF_DETAIL_SHIFT + 12)));
+    scan_float(st, t.d_t_alpha, tan_rows * 4, flags, NERFDS_OVF_FP32_SECOND_ORDER | (1u << (NERFDS_OVF_DETAIL_SHIFT + 13)));
+    scan_float(st, t.d_t_tin, tan_rows * t.D.trunk_in, flags, NERFDS_OVF_FP32_SECOND_ORDER | (1u << (NERFDS_OVF_DETAIL_SHIFT + 14)));
+  }
+}
+
 // The plain two-level step with the level-independent networks evaluated - and differentiated - ONCE per sample position (round 4).
 // The mask network, the SE(3) field and the hyper sheet see only the observation-space point, the GLO rows and the mask; the fine level's
 // sorted union repeats the Nc coarse positions, and the reference runs the three networks there a second time (models.py:1528-1546 over
@@ -1139,6 +1219,7 @@ int run_merged(nerfds_trainer& t, hipStream_t st, int R, const float* zc, const 
   fused_backward(t, st, 0, 0, Mc, t.d_rgb_logit, 3, t.d_alpha, t.d_trunk_in, D.trunk_in);
   rc.fork(false); wg_nerf(rc, 0);
   trunk_in_bwd(st, D, Mc, t.d_trunk_in, t.xw, t.wamb, W, nullptr, nullptr, t.dxw, t.dwamb);          // position rows of block A
+  diag_scan_nerf(t, st, Mc, false, 0);
   // ---------------- the fine level's new samples: shared networks only (block B), under the coarse weight gradients ----------------
   resample(st, R, Nc, Nf, zc, t.wc, strat, rnd ? rnd->u_rand : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->first_ray : 0, t.zf, t.rs_scratch, z_new, src);
   encode_inputs(st, D, R, Nf, rays->origins, rays->directions, z_new, rays->warp_id, t.cfg.num_warp_embeds, t.theta + t.warp_tbl, t.theta + t.mask_tbl, W,
@@ -1221,7 +1302,7 @@ int run_merged_full(nerfds_trainer& t, hipStream_t st, int R, const float* zc, c
   const bool rev = nl && !el && rev_on;
   auto as_f = [](const std::vector<uint16_t*>& v) { std::vector<float*> o; for (auto* p : v) o.push_back(reinterpret_cast<float*>(p)); return o; };
   const std::vector<float*> gt = as_f(t.gt16), gh = as_f(t.gh16), gw = as_f(t.gw16);
-  const float scale_target = 5.f;             // (run_level: the largest cotangent lands at 2^5)
+  const float scale_target = t.scale_target();   // (run_level: the largest cotangent lands at 2^5; nerfds_train_numerics moves it)
   bool ok = true; std::string what;
   auto wg_nerf = [&](Run& r, int level) {
     const MlpP& trunk = t.trunk[level];
@@ -1390,6 +1471,7 @@ int run_merged_full(nerfds_trainer& t, hipStream_t st, int R, const float* zc, c
   fused_backward(t, st, 0, 0, Mc, t.d_rgb_logit, 3, t.d_alpha, t.d_trunk_in, D.trunk_in);
   rc.fork(false); wg_nerf(rc, 0);
   trunk_in_bwd(st, D, Mc, t.d_trunk_in, t.xw, t.wamb, W, t.dxw_reg, nl ? t.dwamb_extra : (hreg ? t.dwamb_reg : nullptr), t.dxw, t.dwamb);
+  diag_scan_nerf(t, st, Mc, nl, rev ? Mc : 3 * Mc);
   // ---------------- fine level: NerfMLP on the sorted union of the positions ----------------
   gather_rows(st, Mf, src, t.xw, t.wamb, t.wv, xw_f, wamb_f, wv_f);
   gather_cols(st, Mf, src, 1, 3, t.x, x_f);
@@ -1588,7 +1670,7 @@ int run_level(nerfds_trainer& t, hipStream_t st, int level, int R, int S, const 
     rt.tan = true;
     auto as_f = [](const std::vector<uint16_t*>& v) { std::vector<float*> o; for (auto* p : v) o.push_back(reinterpret_cast<float*>(p)); return o; };
     const std::vector<float*> gt = as_f(t.gt16), gh = as_f(t.gh16), gw = as_f(t.gw16);
-    const float target = 5.f;                 // the largest cotangent lands at 2^5: 2^11 of headroom below f16's largest value for what the layers amplify (as g_scale)
+    const float target = t.scale_target();    // the largest cotangent lands at 2^5: 2^11 of headroom below f16's largest value for what the layers amplify (as g_scale)
     if (nl) {   // part 1: alpha head, trunk, trunk input (adds second-derivative terms to d x', d w)
       pick_scale(st, t.d_t_alpha, 3 * M * 4, target, t.tan_x_scale, t.tan_slot);
       rt.tan_slot = t.tan_slot;
@@ -1764,7 +1846,7 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
   carve(*t);      // sizes only
   const size_t pbytes = (size_t)t->P * sizeof(float);
   if (hipMalloc(&t->theta, pbytes) != hipSuccess || hipMalloc(&t->grad, pbytes) != hipSuccess || hipMalloc(&t->m1, pbytes) != hipSuccess ||
-      hipMalloc(&t->m2, pbytes) != hipSuccess || hipMalloc(&t->loss_dev, 2 * sizeof(float)) != hipSuccess || hipMalloc(&t->adam_dev, 16) != hipSuccess || hipMalloc(&t->terms_dev, 16 * sizeof(float)) != hipSuccess ||
+      hipMalloc(&t->m2, pbytes) != hipSuccess || hipMalloc(&t->loss_dev, 4 * sizeof(float)) != hipSuccess || hipMalloc(&t->adam_dev, 16) != hipSuccess || hipMalloc(&t->terms_dev, 16 * sizeof(float)) != hipSuccess ||
       hipMalloc(&t->ws, t->ws_floats * sizeof(float)) != hipSuccess) {
     g_train_error = "hipMalloc failed (workspace of " + std::to_string(t->ws_floats * 4 >> 20) + " MiB)";
     return NERFDS_ENOMEM;
@@ -1925,6 +2007,106 @@ int nerfds_trainer_set_loss_scale_adjust(nerfds_trainer* t, int32_t log2_adjust)
   return NERFDS_OK;
 }
 
+int nerfds_trainer_set_numerics(nerfds_trainer* t, const nerfds_train_numerics* n) {
+  if (!t || !n) return NERFDS_EINVAL;
+  if (n->loss_scale_log2_adjust < -40 || n->loss_scale_log2_adjust > 16 || n->tangent_scale_log2_adjust < -24 || n->tangent_scale_log2_adjust > 12 ||
+      (n->chain_arith != NERFDS_CHAINS_DEFAULT && n->chain_arith != NERFDS_CHAINS_SPLIT_BF16) || (n->fp32_step != 0 && n->fp32_step != 1) || (n->diagnose != 0 && n->diagnose != 1))
+    return t->fail(NERFDS_EINVAL, "nerfds_train_numerics: loss_scale_log2_adjust in [-40, 16], tangent_scale_log2_adjust in [-24, 12], chain_arith 0 / 1, fp32_step 0 / 1, diagnose 0 / 1");
+  t->g_scale_adjust = n->loss_scale_log2_adjust;
+  t->tan_scale_adjust = n->tangent_scale_log2_adjust;
+  t->chain_arith = n->chain_arith;
+  t->fp32_step = n->fp32_step != 0;
+  t->diag = n->diagnose != 0;
+  return NERFDS_OK;
+}
+
+int nerfds_trainer_get_numerics(const nerfds_trainer* t, nerfds_train_numerics* n) {
+  if (!t || !n) return NERFDS_EINVAL;
+  n->loss_scale_log2_adjust = t->g_scale_adjust; n->tangent_scale_log2_adjust = t->tan_scale_adjust; n->chain_arith = t->chain_arith; n->fp32_step = t->fp32_step ? 1 : 0; n->diagnose = t->diag ? 1 : 0;
+  return NERFDS_OK;
+}
+
+// Which stored array of the LAST step holds an inf / NaN (called by the host after NERFDS_ENONFINITE / nerfds_trainer_nonfinite, never inside a step: the
+// scans cost a pass over the workspace).  Rows: what the last step wrote (last_R rays; the tangent arrays up to the rows its chains ran on).
+int nerfds_trainer_overflow_sources(nerfds_trainer* t, uint32_t* mask_out) {
+  if (!t || !mask_out) return NERFDS_EINVAL;
+  *mask_out = 0;
+  if (hipSetDevice(t->device) != hipSuccess) return t->fail(NERFDS_EDEVICE, "hipSetDevice failed");
+  if (hipDeviceSynchronize() != hipSuccess) return t->fail(NERFDS_EDEVICE, "device synchronisation failed");
+  if (t->last_R <= 0) return NERFDS_OK;
+  unsigned* flags = reinterpret_cast<unsigned*>(t->terms_dev + 15);      // (cleared at the start of the step; a diagnose step has OR-ed the coarse level's in)
+  hipStream_t st = nullptr;
+  const int Nc = t->cfg.num_coarse_samples, Nf = t->cfg.num_fine_samples;
+  const int64_t M = t->last_R * (int64_t)(Nc + Nf);
+  const int RW = t->rgb_h[0].N, TW = t->trunk[0].width;
+  auto r8 = [](int64_t n) { return n & ~(int64_t)7; };
+  if (t->last_half) {
+    auto net16 = [&](const std::vector<uint16_t*>& h, int width) { for (auto* p : h) if (p) scan_half(st, p, r8(M * width), flags, NERFDS_OVF_ACTIVATION); };
+    net16(t->mask_h16, t->mask.width); net16(t->warp_h16, t->warp.width); net16(t->hyper_h16, t->hyper.width); net16(t->trunk_h16, TW);
+    if (t->rgb_h16) scan_half(st, t->rgb_h16, r8(M * RW), flags, NERFDS_OVF_ACTIVATION);
+    // the stored g of the primal chains: (loss-scaled) f16 in the first half of the fp32 activation arrays, or fp32 (NERFDS_TRAIN_G16=0)
+    auto netg = [&](const std::vector<float*>& g, int width) {
+      for (auto* p : g) {
+        if (!p) continue;
+        if (t->g16) scan_half(st, reinterpret_cast<const uint16_t*>(p), r8(M * width), flags, NERFDS_OVF_PRIMAL_G);
+        else scan_float(st, p, M * width, flags, NERFDS_OVF_PRIMAL_G);
+      }
+    };
+    netg(t->mask_h, t->mask.width); netg(t->warp_h, t->warp.width); netg(t->hyper_h, t->hyper.width); netg(t->trunk_h, TW);
+    if (t->g16) scan_half(st, reinterpret_cast<const uint16_t*>(t->rgb_hv), r8(M * RW), flags, NERFDS_OVF_PRIMAL_G);
+    else scan_float(st, t->rgb_hv, M * RW, flags, NERFDS_OVF_PRIMAL_G);
+  }
+  if (t->last_tan16 && t->last_tan_rows > 0) {
+    const int64_t T = std::min<int64_t>(t->last_tan_rows, 3 * t->max_rays * (int64_t)(Nc + Nf));
+    auto tan16 = [&](const std::vector<uint16_t*>& v, int width, unsigned bit) {
+      const uint16_t* prev = nullptr;
+      for (auto* p : v) { if (p && p != prev) scan_half(st, p, r8(T * width), flags, bit); prev = p; }
+    };
+    tan16(t->tw16, t->warp.width, NERFDS_OVF_TANGENT); tan16(t->th16, t->hyper.width, NERFDS_OVF_TANGENT); tan16(t->tt16, TW, NERFDS_OVF_TANGENT);
+    if (t->last_keep_tangents && t->gws16) {
+      tan16(t->gw16, t->warp.width, NERFDS_OVF_COTANGENT); tan16(t->gh16, t->hyper.width, NERFDS_OVF_COTANGENT); tan16(t->gt16, TW, NERFDS_OVF_COTANGENT);
+    }
+  }
+  // fp32 values no power of two rescues: the losses, the heads' outputs and cotangents, the second-order terms' fp32 cotangents.  Beside the class bit
+  // (NERFDS_OVF_FP32 / _FP32_SECOND_ORDER) each array sets its own DETAIL bit (1 << (NERFDS_OVF_DETAIL_SHIFT + k), k in the order below): diagnosis only.
+  int k = 0;
+  auto f32 = [&](const float* p, int64_t n, unsigned cls) { if (p && n > 0) scan_float(st, p, n, flags, cls | (1u << (NERFDS_OVF_DETAIL_SHIFT + k))); ++k; };
+  f32(t->loss_dev, 2, NERFDS_OVF_FP32);                 // 0 rgb losses
+  f32(t->terms_dev, 8, NERFDS_OVF_FP32);                // 1 auxiliary terms ...
+  f32(t->terms_dev + 9, 6, NERFDS_OVF_FP32); --k;       //   ... (same detail bit)
+  f32(t->alphav, M * 4, NERFDS_OVF_FP32);               // 2 alpha head output
+  f32(t->rgb_logit, M * 3, NERFDS_OVF_FP32);            // 3 rgb head output
+  f32(t->wv, M * 6, NERFDS_OVF_FP32);                   // 4 screw axis
+  f32(t->xw, M * 3, NERFDS_OVF_FP32);                   // 5 warped points
+  f32(t->d_alpha, M * 4, NERFDS_OVF_FP32_BACKWARD);              // 6 alpha head cotangent
+  f32(t->d_rgb_logit, M * 3, NERFDS_OVF_FP32_BACKWARD);          // 7 rgb head cotangent
+  f32(t->dwv, M * 6, NERFDS_OVF_FP32_BACKWARD);                  // 8 screw axis cotangent
+  f32(t->dxw, M * 3, NERFDS_OVF_FP32_BACKWARD);                  // 9 warped point cotangent
+  f32(t->dwamb, M * 2, NERFDS_OVF_FP32_BACKWARD);                // 10 ambient coordinate cotangent
+  f32(t->d_trunk_in, M * t->D.trunk_in, NERFDS_OVF_FP32_BACKWARD);   // 11 trunk input cotangent
+  if (t->last_keep_tangents && t->nws && t->tws) {
+    const int64_t T = std::min<int64_t>(std::max<int64_t>(t->last_tan_rows, M), 3 * M);
+    scan_float(st, t->t_tin, T * t->D.trunk_in, flags, NERFDS_OVF_TANGENT, 65504.f / t->tan_x_scale);      // raw tangent inputs: f16 at the tangents' scale in their weight gradients
+    scan_float(st, t->t_warp_in, T * t->D.warp_ld, flags, NERFDS_OVF_TANGENT, 65504.f / t->tan_x_scale);
+    scan_float(st, t->t_hyper_in, T * t->D.hyper_ld, flags, NERFDS_OVF_TANGENT, 65504.f / t->tan_x_scale);
+    f32(t->t_alpha, T * 4, NERFDS_OVF_FP32_SECOND_ORDER);       // 12 d (sigma_raw, n) / d x
+    f32(t->d_t_alpha, T * 4, NERFDS_OVF_FP32_SECOND_ORDER);     // 13 its cotangent (norm loss)
+    f32(t->d_t_tin, T * t->D.trunk_in, NERFDS_OVF_FP32_SECOND_ORDER);   // 14
+    f32(t->d_t_wv, T * 6, NERFDS_OVF_FP32_SECOND_ORDER);        // 15
+    f32(t->dwv_extra, M * 6, NERFDS_OVF_FP32_SECOND_ORDER);     // 16 exp_se3's second-derivative terms
+    f32(t->du, M * 3, NERFDS_OVF_FP32_SECOND_ORDER);            // 17
+    f32(t->ghat, M * 3, NERFDS_OVF_FP32_SECOND_ORDER);          // 18
+    f32(t->tan_slot, 16, NERFDS_OVF_FP32_SECOND_ORDER);         // 19 device-picked scales (amax of a non-finite cotangent array)
+    f32(t->tn[0], t->last_R * (int64_t)Nc * 3, NERFDS_OVF_FP32_SECOND_ORDER);   // 20 target_norm, coarse
+    if (Nf > 0) f32(t->tn[1], M * 3, NERFDS_OVF_FP32_SECOND_ORDER);             // 21 target_norm, fine
+  }
+  unsigned f = 0;
+  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipMemcpy(&f, flags, sizeof f, hipMemcpyDeviceToHost) != hipSuccess)
+    return t->fail(NERFDS_EDEVICE, "overflow scan failed");
+  *mask_out = f;
+  return NERFDS_OK;
+}
+
 int nerfds_trainer_nonfinite(nerfds_trainer* t) {
   if (!t) return NERFDS_EINVAL;
   (void)hipSetDevice(t->device);
@@ -1954,7 +2136,7 @@ int nerfds_trainer_clip_gradients(nerfds_trainer* t, float grad_max_val, float g
   if (!t) return NERFDS_EINVAL;
   if (!(grad_max_val > 0.f) && !(grad_max_norm > 0.f)) return NERFDS_OK;
   if (hipSetDevice(t->device) != hipSuccess) return t->fail(NERFDS_EDEVICE, "hipSetDevice failed");
-  clip_gradients(static_cast<hipStream_t>(hip_stream), t->grad, t->P, grad_max_val, grad_max_norm, t->loss_dev);   // loss_dev[0] doubles as scratch between steps
+  clip_gradients(static_cast<hipStream_t>(hip_stream), t->grad, t->P, grad_max_val, grad_max_norm, t->loss_dev + 2);   // loss_dev[2]: scratch of the norm (the losses in [0], [1] stay readable: overflow diagnosis)
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return t->fail(NERFDS_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));
   return NERFDS_OK;
@@ -2074,6 +2256,7 @@ static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* ta
     }
   }
   (void)hipMemsetAsync(t->terms_dev, 0, 8 * sizeof(float), st);
+  (void)hipMemsetAsync(t->terms_dev + 15, 0, sizeof(float), st);            // [15]: overflow-source flags (diag_scan_nerf inside the step, nerfds_trainer_overflow_sources after it)
   (void)hipMemsetAsync(t->terms_dev + 9, 0, 6 * sizeof(float), st);          // ... [12]: elastic regulariser, [13], [14]: mask occlusion regulariser (coarse / fine)
   // [9], [10]: hyper-point regulariser of the coarse / fine level, [11]: background loss ([8]: non-finite flag)
   const float norm_weight = objective ? objective->norm_loss_weight : 0.f;
@@ -2082,8 +2265,10 @@ static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* ta
   // the tangent passes (sigma gradient, norm loss, elastic regulariser) read the primal ReLU masks only: the primal pass stays on the fused f16 step
   // (NERFDS_TRAIN_HALF_TANGENTS=0: fp32 activations and the layer-by-layer backward for those steps, as through round 4's first half)
   static const bool half_tangents = !(getenv("NERFDS_TRAIN_HALF_TANGENTS") && std::string(getenv("NERFDS_TRAIN_HALF_TANGENTS")) == "0");
-  t->half_step = t->fused_fwd && t->fused_bwd && (!want_sg || half_tangents);
+  t->half_step = t->fused_fwd && t->fused_bwd && (!want_sg || half_tangents) && !t->fp32_step;
   if (t->half_step) pack_fused_backward(*t, st);
+  t->tan_x_scale = std::ldexp(1.f, -6 + t->tan_scale_adjust);
+  t->last_R = R; t->last_tan_rows = 0; t->last_half = t->half_step;
   {
     int e = 6;
     while ((1 << (e - 6)) < R && e < 40) ++e;
@@ -2099,6 +2284,8 @@ static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* ta
   t->keep_tangents = norm_weight != 0.f || elastic;
   if ((norm_weight != 0.f || elastic) && (!ensure_tangent_ws(*t) || !ensure_norm_ws(*t))) return t->fail(NERFDS_ENOMEM, "hipMalloc of the norm-loss workspace failed");
   if (want_sg && !ensure_tangent_ws(*t)) return t->fail(NERFDS_ENOMEM, "hipMalloc of the tangent workspace failed");
+  if (want_sg && !t->half_step && !ensure_tangent_ws32(*t, t->keep_tangents)) return t->fail(NERFDS_ENOMEM, "hipMalloc of the fp32 tangent workspace failed");
+  t->last_keep_tangents = t->keep_tangents; t->last_tan16 = want_sg && t->fused_tan && t->half_step;
   if (want_sg && t->fused_tan && t->half_step) {
     if (3LL * t->max_rays * (Nc + Nf) >= (1LL << 31)) return t->fail(NERFDS_EINVAL, "tangent rows are indexed in 31 bits: max_rays * samples * 3 is too large");
     // the hidden tangents: one f16 array per layer when the step differentiates the tangent pass (its weight gradients read them), one per network otherwise
@@ -2126,6 +2313,7 @@ static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* ta
   } else {
   rc = run_level(*t, st, 0, R, Nc, t->zc, rays, target_rgb, ex, W, t->wc, want_sg, obp, norm_weight);
   if (rc != NERFDS_OK) return rc;
+  if (Nf > 0 && !t->fwd_only) diag_scan_nerf(*t, st, (int64_t)R * Nc, t->keep_tangents, 3LL * R * Nc);
   if (Nf > 0) {
     resample(st, R, Nc, Nf, t->zc, t->wc, strat, rnd ? rnd->u_rand : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->first_ray : 0, t->zf, t->rs_scratch);
     rc = run_level(*t, st, 1, R, Nc + Nf, t->zf, rays, target_rgb, ex, W, t->weights, want_sg_fine, obp, norm_weight);

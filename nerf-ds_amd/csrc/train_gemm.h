@@ -47,6 +47,10 @@ struct WgradArgs {
   // aligned rows): a one-term operand.  With an f16 X both operands go to the MFMAs as they are (k_wgrad_tr: one MFMA per product); an fp32 X
   // is split into f16 hi + lo (two MFMAs per product).
   int dy_half;
+  // dy_half with an fp32 X: X is multiplied by x_scale (0 = 1) before it is split into f16 hi + lo - a power of two that keeps it inside f16's range (the raw
+  // inputs of the PRIMAL layers are encodings, |x| <= 1; those of the tangent pass are derivatives of encodings, up to 2^7 |t_x'|: they carry the stored
+  // tangents' scale, and out_scale_dev divides it out again)
+  float x_scale;
   // colsum != nullptr: += the column sums of dY (the bias gradient of the layer), a by-product of the tile conversion; replicas as dw.
   float* colsum;
   // dy_half: what reaches dw / colsum is multiplied by out_scale (0 = 1): the chains write g times a power of two so that it fits f16.

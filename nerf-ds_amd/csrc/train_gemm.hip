@@ -622,11 +622,13 @@ __global__ __launch_bounds__(512) void k_wgrad(const WgradArgs A) {
         if (threadIdx.x + 512 * j >= KI) cs[j] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
         if constexpr (DYH) {                              // f16 dY: X as f16 hi + lo (an f16 X: lo = 0)
           f16x8 xh, xl;
+          const float xsc = A.x_scale != 0.f ? A.x_scale : 1.f;      // (an fp32 X beyond f16's range - a raw TANGENT input - would become inf here: WgradArgs::x_scale)
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const _Float16 a = (_Float16)f[i];
+            const float v = f[i] * xsc;
+            const _Float16 a = (_Float16)v;
             xh[i] = a;
-            xl[i] = (_Float16)(f[i] - (float)a);
+            xl[i] = (_Float16)(v - (float)a);
           }
           *reinterpret_cast<u32x4*>(img + c_dst[j]) = __builtin_bit_cast(u32x4, xh);
           *reinterpret_cast<u32x4*>(img + c_dst[j] + 1024) = __builtin_bit_cast(u32x4, xl);

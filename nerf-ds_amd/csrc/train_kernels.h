@@ -61,6 +61,9 @@ void aux_losses(hipStream_t, int R, int S, const Objective&, const float* z, con
 void add_inplace(hipStream_t, float* dst, const float* src, long long n);
 // slot[4] (device) <- {amax bits of x[0..n), 2^(target_log2 - floor(log2 amax)), its inverse, 1 / (scale * x_scale)}
 void pick_scale(hipStream_t, const float* x, long long n, float target_log2, float x_scale, float* slot);
+// overflow diagnosis after a failed gradient check: flags |= bit if the f16 / fp32 array holds an inf or a NaN (scan_half: n a multiple of 8, 16-byte aligned)
+void scan_half(hipStream_t, const uint16_t* p, long long n, unsigned* flags, unsigned bit);
+void scan_float(hipStream_t, const float* p, long long n, unsigned* flags, unsigned bit, float limit = 3.4028234e38f);      // |p[i]| > limit counts (an fp32 array on its way into f16)
 void expand_half(hipStream_t, const uint16_t* h16, float* out, long long n);      // out[i] = float(f16 h16[i]); n a multiple of 8, both 16-byte aligned
 // background regulariser (training.py:159-183): term += weight * mean_i general_loss(|xw_i - x_i|^2, alpha, scale); dxw = its gradient w.r.t. xw
 // elastic regulariser (training.py:112-156 'log_svals', 274-295): t_xw = the tangents of the warped point, row 3 m + j = d x' / d x_j (the Jacobian's

@@ -1065,6 +1065,23 @@ __global__ void k_nonfinite(const float* __restrict__ g, long long n, unsigned* 
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i < n && !isfinite(g[i])) atomicOr(flag, 1u);
 }
+// Overflow diagnosis, run by nerfds_trainer_overflow_sources AFTER a step whose gradient check failed (never inside a step): which stored array holds an
+// inf / NaN.  f16: exponent field all ones; fp32: !isfinite.  One atomicOr per block that finds one.
+__global__ __launch_bounds__(256) void k_scan_half(const uint16_t* __restrict__ p, long long n8, unsigned* __restrict__ flags, unsigned bit) {
+  unsigned bad = 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const uint4 v = reinterpret_cast<const uint4*>(p)[i];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bad |= (unsigned)(((w[k] & 0x7c00u) == 0x7c00u) | ((w[k] & 0x7c000000u) == 0x7c000000u));
+  }
+  if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(flags, bit);
+}
+__global__ __launch_bounds__(256) void k_scan_float(const float* __restrict__ p, long long n, unsigned* __restrict__ flags, unsigned bit, float limit) {
+  unsigned bad = 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) bad |= !(fabsf(p[i]) <= limit);      // (NaN: false)
+  if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(flags, bit);
+}
 // The optimizer's step count lives on the DEVICE (state[0] as int64; state[1], state[2] = the bias corrections 1 - b^t of the step about to be
 // applied): a skipped update must not advance it - the moments did not move, so neither may the bias correction nor the checkpointed
 // OptimizerState.step (flax 0.3.4 optim/adam.py: step + 1 only in apply_gradient) - and the host does not know about the skip when it enqueues.
@@ -1330,6 +1347,14 @@ void pick_scale(hipStream_t st, const float* x, long long n, float target_log2, 
   const long long blocks = (n + 255) / 256;
   hipLaunchKernelGGL(k_amax, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(slot));
   hipLaunchKernelGGL(k_pick_scale, dim3(1), dim3(1), 0, st, slot, target_log2, x_scale);
+}
+void scan_half(hipStream_t st, const uint16_t* p, long long n, unsigned* flags, unsigned bit) {      // n a multiple of 8, p 16-byte aligned
+  const long long n8 = n / 8, blocks = (n8 + 255) / 256;
+  if (n8 > 0) hipLaunchKernelGGL(k_scan_half, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, p, n8, flags, bit);
+}
+void scan_float(hipStream_t st, const float* p, long long n, unsigned* flags, unsigned bit, float limit) {
+  const long long blocks = (n + 255) / 256;
+  if (n > 0) hipLaunchKernelGGL(k_scan_float, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, p, n, flags, bit, limit);
 }
 void expand_half(hipStream_t st, const uint16_t* h16, float* out, long long n) { LAUNCH(k_expand_half, n / 8, st, h16, out, n / 8); }
 // Singular values / vectors of a 3 x 3 matrix through the eigen-decomposition of J^T J (cyclic Jacobi in double: the warp Jacobian is close to a

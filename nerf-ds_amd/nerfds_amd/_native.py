@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFDS_LIB', os.path.join(_HERE, '_lib', 'libnerfds_hip.so'))   # NERFDS_LIB: development builds
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def resolve_device(device=None):
@@ -132,7 +132,7 @@ SYMBOLS = ('nerfds_abi_version', 'nerfds_struct_size', 'nerfds_precision_plan', 
            'nerfds_frame_images', 'nerfds_trainer_create', 'nerfds_trainer_destroy', 'nerfds_trainer_param_count',
            'nerfds_trainer_num_leaves', 'nerfds_trainer_leaf', 'nerfds_trainer_params', 'nerfds_trainer_grads',
            'nerfds_trainer_download', 'nerfds_trainer_upload', 'nerfds_trainer_reset_optimizer', 'nerfds_trainer_step', 'nerfds_trainer_apply', 'nerfds_trainer_clip_gradients', 'nerfds_trainer_target_norm',
-           'nerfds_trainer_last_error', 'nerfds_trainer_debug_read', 'nerfds_trainer_nonfinite', 'nerfds_trainer_set_step', 'nerfds_trainer_get_step', 'nerfds_trainer_set_loss_scale_adjust', 'nerfds_trainer_forward', 'nerfds_render_rays_bwd',
+           'nerfds_trainer_last_error', 'nerfds_trainer_debug_read', 'nerfds_trainer_nonfinite', 'nerfds_trainer_set_step', 'nerfds_trainer_get_step', 'nerfds_trainer_set_loss_scale_adjust', 'nerfds_trainer_set_numerics', 'nerfds_trainer_get_numerics', 'nerfds_trainer_overflow_sources', 'nerfds_trainer_forward', 'nerfds_render_rays_bwd',
            'nerfds_debug_lds_attr_first_use')
 
 _lib = None

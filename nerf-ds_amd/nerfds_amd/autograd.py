@@ -67,6 +67,7 @@ class DifferentiableRenderer:
     self._lib = _bind(self.trainer._lib)
     self.params = self.trainer.params_tensor().requires_grad_(True)      # a LEAF aliasing the library's parameter vector
     self.auto_loss_scale = True
+    self.loss_scale_adjust = 0      # log2 offset of the backward's loss scale (set from max |cotangent| when auto_loss_scale; this renderer's, not the trainer's)
 
   # -- marshalling ---------------------------------------------------------------------------------------
   def _pack(self, rays_dict, extra_params, t_rand, u_rand, mask_ratio, near, far, seed, ray_offset):
@@ -129,27 +130,34 @@ class DifferentiableRenderer:
     R, tr = call['R'], self.trainer
     two = self.cfg.num_fine_samples > 0
     c = [None if (x is None or x.numel() == 0) else x.detach().to(self.device, torch.float32).contiguous() for x in cots]
+    # The backward's stored f16 g is scaled for head gradients of a mean squared error's size, at most 2 / (3 R) per unit of colour error
+    # (csrc/nerfds_train.cpp g_scale): the caller's cotangents are brought to that size by a power of two.  The adjustment is THIS renderer's
+    # (self.loss_scale_adjust) - the trainer's own policy (Trainer.step's overflow ladder) is restored after the call, so a caller who mixes
+    # render.trainer.step() with autograd passes does not inherit a scale chosen for someone else's cotangents.
+    adjust = int(getattr(self, 'loss_scale_adjust', 0))
     if self.auto_loss_scale:
-      # the backward's stored f16 g is scaled for head gradients of a mean squared error's size, at most 2 / (3 R) per unit of colour error
-      # (csrc/nerfds_train.cpp g_scale): bring the caller's cotangents to that size by the power of two
       gmax = max([float(x.abs().max()) for x in c if x is not None] + [0.0])
       if gmax > 0.0 and np.isfinite(gmax):
-        tr.loss_scale_adjust = int(np.clip(np.floor(np.log2((2.0 / (3.0 * R)) / gmax)), -40, 16))
+        adjust = int(np.clip(np.floor(np.log2((2.0 / (3.0 * R)) / gmax)), -40, 16))
     ptr = lambda x: x.data_ptr() if x is not None else None
     df = _LevelCot(ptr(c[0]), ptr(c[1]), ptr(c[2])) if two else None
     dc = _LevelCot(ptr(c[3]), ptr(c[4]), ptr(c[5]))
     retries = 0
-    while True:
-      self._lib.nerfds_trainer_set_loss_scale_adjust(tr._h, int(tr.loss_scale_adjust))
-      rc = self._lib.nerfds_render_rays_bwd(tr._h, C.byref(call['rays']), C.byref(call['ex']), C.byref(call['rnd']),
-                                            C.byref(df) if df is not None else None, C.byref(dc), self._stream())
-      if rc != 0:
-        raise RuntimeError(f'nerfds_render_rays_bwd failed ({rc}): {(self._lib.nerfds_trainer_last_error(tr._h) or b"").decode()}')
-      grad = tr.grads_tensor().clone()
-      if bool(torch.isfinite(grad).all()) or retries >= tr.max_overflow_retries or tr.loss_scale_adjust <= -38:
-        return grad
-      retries += 1                    # the scaled f16 g left f16's range: a quarter of the scale, same samples (as Trainer.step)
-      tr.loss_scale_adjust -= 2
+    try:
+      while True:
+        self._lib.nerfds_trainer_set_loss_scale_adjust(tr._h, adjust)
+        rc = self._lib.nerfds_render_rays_bwd(tr._h, C.byref(call['rays']), C.byref(call['ex']), C.byref(call['rnd']),
+                                              C.byref(df) if df is not None else None, C.byref(dc), self._stream())
+        if rc != 0:
+          raise RuntimeError(f'nerfds_render_rays_bwd failed ({rc}): {(self._lib.nerfds_trainer_last_error(tr._h) or b"").decode()}')
+        grad = tr.grads_tensor().clone()
+        if bool(torch.isfinite(grad).all()) or retries >= tr.max_overflow_retries or adjust <= -38:
+          self.loss_scale_adjust = adjust
+          return grad
+        retries += 1                    # the scaled f16 g left f16's range: a quarter of the scale, same samples (as Trainer.step)
+        adjust -= 2
+    finally:
+      tr._set_numerics()                # the trainer's own policy back in place
 
   # -- conveniences ----------------------------------------------------------------------------------------
   def grads_tree(self) -> Dict[str, Any]:

@@ -26,6 +26,22 @@ class Objective(C.Structure):
               ('elastic_loss_weight', C.c_float), ('elastic_reduce_by_weight', C.c_int32), ('mask_occlusion_reg_loss_weight', C.c_float)]
 
 
+class Numerics(C.Structure):
+  """nerfds_train_numerics (include/nerfds.h): the numeric policy of the trainer's f16 storage."""
+  _fields_ = [('loss_scale_log2_adjust', C.c_int32), ('tangent_scale_log2_adjust', C.c_int32), ('chain_arith', C.c_int32), ('fp32_step', C.c_int32), ('diagnose', C.c_int32)]
+
+
+# nerfds_trainer_overflow_sources bits (include/nerfds.h NERFDS_OVF_*)
+OVF_ACTIVATION, OVF_PRIMAL_G, OVF_TANGENT, OVF_COTANGENT, OVF_FP32, OVF_FP32_SECOND_ORDER, OVF_FP32_BACKWARD = 1, 2, 4, 8, 16, 32, 64
+_OVF_NAMES = ((OVF_ACTIVATION, 'f16 activation'), (OVF_PRIMAL_G, 'loss-scaled f16 g of the primal chains'), (OVF_TANGENT, 'stored f16 tangents'),
+              (OVF_COTANGENT, 'stored f16 cotangents of the tangent pass'), (OVF_FP32, 'fp32 value of the forward pass (loss / head output / warp)'),
+              (OVF_FP32_SECOND_ORDER, 'fp32 tangent / cotangent of the second-order terms'), (OVF_FP32_BACKWARD, 'fp32 cotangent of the backward pass'))
+
+
+def overflow_names(mask: int) -> str:
+  return ', '.join(n for b, n in _OVF_NAMES if mask & b) or 'unattributed (an array a later level overwrote)'
+
+
 class _DevVec:
   """Zero-copy torch view of a library-owned fp32 device vector (through __cuda_array_interface__)."""
 
@@ -60,6 +76,9 @@ def _bind(lib):
   lib.nerfds_trainer_set_step.argtypes = [C.c_void_p, C.c_int64]
   lib.nerfds_trainer_get_step.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
   lib.nerfds_trainer_set_loss_scale_adjust.argtypes = [C.c_void_p, C.c_int32]
+  lib.nerfds_trainer_set_numerics.argtypes = [C.c_void_p, C.POINTER(Numerics)]
+  lib.nerfds_trainer_get_numerics.argtypes = [C.c_void_p, C.POINTER(Numerics)]
+  lib.nerfds_trainer_overflow_sources.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
   lib.nerfds_trainer_nonfinite.argtypes = [C.c_void_p]
   lib.nerfds_trainer_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
   lib.nerfds_trainer_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -101,12 +120,22 @@ class Trainer:
       raise (NotImplementedError if rc == -95 else RuntimeError)(f'nerfds_trainer_create failed ({rc}): {msg}')
     self._h = h
     self.max_rays = max_rays
-    # dynamic loss scaling of the plain step's f16 g (include/nerfds.h nerfds_trainer_set_loss_scale_adjust): log2 offset, lowered by 2 when a
-    # step's gradient comes out non-finite (the step is re-run), raised by 1 towards 0 after `loss_scale_growth_interval` clean steps
+    # Numeric policy of the f16 storage (include/nerfds.h nerfds_train_numerics), moved by the overflow ladder of step():
+    #   loss_scale_adjust     log2 offset of the primal chains' stored g, lowered by 2 when THAT array overflowed
+    #   tangent_scale_adjust  log2 offset of the second-order terms' stored tangents / cotangents, lowered by 2 when THOSE overflowed
+    #   split_chains          every chain in split bf16 (fp32's exponent range between the layers) instead of one f16 MFMA per product
+    #   fp32_step             fp32 activations and g, layer by layer: the arithmetic range of the reference's step (the ladder's last rung)
+    # each relaxes one notch towards the default after `loss_scale_growth_interval` clean steps.
     self.loss_scale_adjust = 0
+    self.tangent_scale_adjust = 0
+    self.split_chains = False
+    self.fp32_step = False
     self.loss_scale_growth_interval = 1000
-    self.max_overflow_retries = 8
+    self.max_overflow_retries = 12
     self._clean_steps = 0
+    self.record_leaves = False     # diagnosis: overflow_events also lists the gradient leaves that were non-finite (downloads the gradient per event)
+    self.overflow_events = []      # (step call index, source mask, action) of every skipped-and-repeated attempt, newest last (bounded)
+    self._calls = 0
     self.num_params = int(self._lib.nerfds_trainer_param_count(h))
     self.leaves = []
     name = C.create_string_buffer(256)
@@ -187,6 +216,82 @@ class Trainer:
     rc = self._lib.nerfds_trainer_debug_read(self._h, name.encode(), out.ctypes.data, out.nbytes)
     if rc < 0:
       raise RuntimeError(f'nerfds_trainer_debug_read failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
+    return out
+
+  def _set_numerics(self, diagnose: bool = False) -> None:
+    n = Numerics(int(self.loss_scale_adjust), int(self.tangent_scale_adjust), 1 if self.split_chains else 0, 1 if self.fp32_step else 0, 1 if diagnose else 0)
+    rc = self._lib.nerfds_trainer_set_numerics(self._h, C.byref(n))
+    if rc != 0:
+      raise RuntimeError(f'nerfds_trainer_set_numerics failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
+
+  def overflow_sources(self) -> int:
+    """NERFDS_OVF_* mask of the stored arrays of the last step that hold an inf / NaN (nerfds_trainer_overflow_sources; synchronises, scans the workspace)."""
+    m = C.c_uint32(0)
+    rc = self._lib.nerfds_trainer_overflow_sources(self._h, C.byref(m))
+    if rc != 0:
+      raise RuntimeError(f'nerfds_trainer_overflow_sources failed ({rc}): {(self._lib.nerfds_trainer_last_error(self._h) or b"").decode()}')
+    return int(m.value)
+
+  def _escalate(self, src: int, unattributed_turn: int) -> str:
+    """One rung of the overflow ladder: changes the policy so that the source `src` of the failed attempt cannot recur; returns what it did."""
+    # Causality runs activation -> tangents -> cotangents -> primal g (the second-order chains' outputs feed the primal backward; a non-finite value
+    # spreads to everything behind it): the EARLIEST source set is the one to remove, what lies behind it is its consequence.
+    acts = []
+    second = src & (OVF_TANGENT | OVF_COTANGENT)
+    if src & (OVF_ACTIVATION | OVF_FP32) or (not second and src & (OVF_FP32_SECOND_ORDER | OVF_FP32_BACKWARD)):
+      # an activation beyond f16's range, or an fp32 value of the step itself that is inf / NaN with no f16 array in front of it: no power of two helps
+      self.fp32_step = True
+      return 'fp32 step'
+    if second:
+      if not self.split_chains:
+        self.split_chains = True
+        acts.append('split-bf16 chains')
+      if self.tangent_scale_adjust > -16:
+        self.tangent_scale_adjust -= 2
+        acts.append(f'tangent scale 2^{self.tangent_scale_adjust}')
+      elif not acts:
+        self.fp32_step = True
+        acts.append('fp32 step')
+    elif src & OVF_PRIMAL_G:
+      if self.loss_scale_adjust > -24:
+        self.loss_scale_adjust -= 2
+        acts.append(f'loss scale 2^{self.loss_scale_adjust}')
+      else:
+        self.fp32_step = True
+        acts.append('fp32 step')
+    if not acts:
+      # unattributed (the coarse NerfMLP's arrays are overwritten by the fine level's): second-order side first, then the primal scale, alternating;
+      # after two rounds of both, the fp32 step
+      if unattributed_turn >= 4:
+        self.fp32_step = True
+        acts.append('fp32 step')
+      elif unattributed_turn % 2 == 0:
+        self.split_chains = True
+        self.tangent_scale_adjust = max(self.tangent_scale_adjust - 2, -16)
+        acts.append(f'split-bf16 chains, tangent scale 2^{self.tangent_scale_adjust}')
+      else:
+        self.loss_scale_adjust = max(self.loss_scale_adjust - 2, -24)
+        acts.append(f'loss scale 2^{self.loss_scale_adjust}')
+    return ' + '.join(acts)
+
+  def _relax(self) -> None:
+    """After `loss_scale_growth_interval` clean steps: one notch back towards the default policy (fp32 step first, then the scales, then the chains)."""
+    if self.fp32_step:
+      self.fp32_step = False
+    elif self.loss_scale_adjust < 0 or self.tangent_scale_adjust < 0:
+      self.loss_scale_adjust = min(self.loss_scale_adjust + 1, 0) if self.loss_scale_adjust < 0 else self.loss_scale_adjust
+      self.tangent_scale_adjust = min(self.tangent_scale_adjust + 1, 0)
+    elif self.split_chains:
+      self.split_chains = False
+
+  def nonfinite_leaves(self):
+    """Names of the gradient leaves that hold an inf / NaN after the last attempt, with their counts (diagnosis: downloads the gradient vector)."""
+    g = self._download(1)
+    out = []
+    for name, off, rows, cols in self.leaves:
+      n = int((~np.isfinite(g[off:off + rows * cols])).sum())
+      if n:
+        out.append((name, n, rows * cols))
     return out
 
   def nonfinite(self) -> bool:
@@ -322,14 +427,12 @@ class Trainer:
     deferred = bool(data_parallel or clip)          # Adam runs in nerfds_trainer_apply, after the all-reduce / the clip
     flags = (GRADS_ONLY if (grads_only or deferred) else 0) | (SIGMA_GRAD if sigma_gradient else 0)
     self._last_rays = R
-    retries = 0
-    while True:
-      # One attempt = forward + backward (+ all-reduce, clip, Adam).  A non-finite gradient skips the update as a whole on the device (parameters,
-      # moments and step count untouched).  The usual cause is the loss-scaled f16 g leaving f16's range (the reference's fp32 g cannot): the
-      # attempt is repeated at a quarter of the scale - same seed, same samples - up to max_overflow_retries times; what still overflows then
-      # (an f16 ACTIVATION beyond 65504: no scale helps) is raised.  The gradient all-reduce spreads an inf / NaN to every rank, so all ranks
-      # of a data-parallel step take the same decision.
-      self._lib.nerfds_trainer_set_loss_scale_adjust(self._h, int(self.loss_scale_adjust))
+    retries = unattributed = 0
+    self._calls += 1
+
+    def attempt(diagnose: bool = False) -> bool:
+      """forward + backward (+ all-reduce, clip, Adam) under the current policy; True = the gradient was non-finite and the update was skipped"""
+      self._set_numerics(diagnose)
       rc = self._lib.nerfds_trainer_step(self._h, C.byref(rays), target.data_ptr(), C.byref(ex), C.byref(rnd), C.byref(ob) if ob is not None else None,
                                          float(learning_rate), flags, loss, C.c_void_p(s.cuda_stream))
       overflow = rc == -34      # NERFDS_ENONFINITE: the update of this step was skipped (include/nerfds.h)
@@ -346,18 +449,49 @@ class Trainer:
         if not grads_only:
           self.apply_gradients(learning_rate, s)
           overflow = self.nonfinite()      # nerfds_trainer_apply cannot report it (asynchronous): read the device flag back
-      if not overflow:
+      return overflow
+
+    def sources() -> int:
+      raw = self.overflow_sources()
+      if data_parallel:         # every rank must climb the same rung: OR of the masks (as a MAX over one int per bit - RCCL has no bitwise OR)
+        bits = torch.tensor([1 if raw & (1 << b) else 0 for b in range(30)], dtype=torch.int32, device=dev)
+        dist.all_reduce(bits, op=dist.ReduceOp.MAX)
+        raw = sum(int(v) << b for b, v in enumerate(bits.tolist()))
+      return raw
+
+    while True:
+      # One attempt = forward + backward (+ all-reduce, clip, Adam).  A non-finite gradient skips the update as a whole on the device (parameters,
+      # moments and step count untouched).  The reference's fp32 step cannot overflow (training.py:494-508); this one stores f16, so the attempt is
+      # DIAGNOSED (which stored array holds the inf: overflow_sources; the coarse NerfMLP's arrays, which the fine level overwrites, by repeating the
+      # attempt once with numerics.diagnose) and repeated - same seed, same samples - under a policy without that source (_escalate: the primal loss
+      # scale for the primal g, split-bf16 chains / the tangent scale for the second-order terms, the fp32 step for an activation), ending in the
+      # fp32 step; only what is non-finite THERE - as it would be in the reference - is raised.  The gradient all-reduce spreads an inf / NaN to
+      # every rank and the source masks are OR-ed over the ranks, so all ranks take the same decision.
+      if not attempt():
         break
       self._clean_steps = 0
-      msg = (self._lib.nerfds_trainer_last_error(self._h) or b'non-finite gradient: the Adam update of this step was skipped').decode()
-      if retries >= self.max_overflow_retries or self.loss_scale_adjust <= -40 + 2:
-        raise FloatingPointError(f'{msg} [after {retries} retries at lower loss scales; loss_scale_adjust = {self.loss_scale_adjust}]')
+      raw = sources()
+      if raw & 127 == 0 and not self.fp32_step and self.cfg.num_fine_samples > 0:
+        if not attempt(diagnose=True):      # (the sums of a step are atomics: a borderline overflow need not recur - then this attempt's update stands)
+          self.overflow_events.append((self._calls, 0, 'did not recur', 0))
+          break
+        raw = sources()
+      src = raw & 127           # the class bits; raw >> 8: which fp32 array (diagnosis, kept in overflow_events)
+      policy = (f'loss_scale_adjust = {self.loss_scale_adjust}, tangent_scale_adjust = {self.tangent_scale_adjust}, split_chains = {self.split_chains}, '
+                f'fp32_step = {self.fp32_step}')
+      if self.fp32_step or retries >= self.max_overflow_retries:
+        # (fp32 step: no f16 storage took part - the gradient of THIS batch at THESE parameters is inf / NaN in fp32 arithmetic, as in the reference)
+        raise FloatingPointError(f'non-finite gradient: the Adam update of this step was skipped; source: {overflow_names(src)} (fp32 detail bits {raw >> 8:#x}) [after {retries} '
+                                 f'repeated attempts; {policy}]')
+      action = self._escalate(src, unattributed)
+      unattributed += 1 if src == 0 else 0
       retries += 1
-      self.loss_scale_adjust -= 2
+      self.overflow_events.append((self._calls, src, action, raw >> 8) + ((self.nonfinite_leaves(),) if self.record_leaves else ()))
+      del self.overflow_events[:-256]
     if not grads_only:
       self._clean_steps += 1
-      if self.loss_scale_adjust < 0 and self._clean_steps >= self.loss_scale_growth_interval:
-        self.loss_scale_adjust += 1
+      if self._clean_steps >= self.loss_scale_growth_interval:
+        self._relax()
         self._clean_steps = 0
     del keep
     fine, coarse = float(loss[0]), float(loss[1])

@@ -8,13 +8,28 @@ for p in (os.path.join(_ROOT, 'nerf-ds_amd'), _ROOT):
   if p not in sys.path:
     sys.path.insert(0, p)
 
+# Collection order of the GPU suite: unit -> integration.  `pytest -x` stops at the first failure, and files are collected alphabetically: in
+# round 5 one flaky integration test (test_end_to_end, third in the alphabet) hid 147 of the 150 GPU tests, every hot-path parity test among them, from
+# the driver's run.  The parity tests of the hot path come first, then the trainer's oracle tests (row T), then the callers either
+# side of the path (8f), and last whatever composes them or spawns processes.  The exit code stays honest - a failure anywhere still fails the run.
+_ORDER = ('test_golden', 'test_gpu_parity', 'test_camera', 'test_render_image_gpu', 'test_frames', 'test_train_gemm', 'test_training',
+          'test_pack_stream', 'test_launch_guard', 'test_checkpoint', 'test_rccl_single_gpu', 'test_end_to_end')
+
 
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
 def pytest_collection_modifyitems(config, items):
-  """GPU tests are skipped (not failed) when no device is visible, so a bare `pytest tests/` works anywhere."""
+  """Orders the files unit -> integration (see _ORDER; stable within a file, unknown files before the integration tests), and skips - not fails - the GPU
+  tests when no device is visible, so a bare `pytest tests/` works anywhere."""
+  rank = {name: i for i, name in enumerate(_ORDER)}
+  last = rank['test_rccl_single_gpu']
+
+  def key(item):
+    mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    return rank.get(mod, last - 0.5)
+  items.sort(key=key)
   try:
     import torch
     have_gpu = torch.cuda.is_available()

@@ -25,7 +25,7 @@ def test_library_loads_and_exports_header_symbols():
   assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
   for s in declared:
     assert hasattr(lib, s), s
-  assert lib.nerfds_abi_version() == N.ABI_VERSION == 6
+  assert lib.nerfds_abi_version() == N.ABI_VERSION == 7
   # every ctypes mirror has the size the library was compiled with (N.load() checks the render-side structs itself)
   from nerfds_amd.training import Objective
   assert lib.nerfds_struct_size(7) == C.sizeof(Objective) == 88 and lib.nerfds_struct_size(99) == -1
