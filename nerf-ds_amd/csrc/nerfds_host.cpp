@@ -270,7 +270,7 @@ static launch_fn launcher(int graph, uint32_t prec) {
   static_assert(NUM_PLANS == NERFDS_PREC_COUNT, "graphs.h plan_of covers every NERFDS_PREC_* value");
   static const launch_fn tab[3][NUM_PLANS] = {
       {nerfds_launch_nerfds_bf16, nerfds_launch_nerfds_bf16x3, nerfds_launch_nerfds_f32, nerfds_launch_nerfds_f16, nerfds_launch_nerfds_mixed, nerfds_launch_nerfds_bf16x3f},
-      // (the static graph has ONE level, the one render_fn returns: NERFDS_PREC_BF16X3_FINE is plain split bf16 there - effective_prec)
+      // (the static graph has no mixed-level kernel: nerfds_render_rays maps NERFDS_PREC_BF16X3_FINE to NERFDS_PREC_BF16X3 before it packs or launches)
       {nerfds_launch_static_bf16, nerfds_launch_static_bf16x3, nerfds_launch_static_f32, nerfds_launch_static_f16, nerfds_launch_static_mixed, nerfds_launch_static_bf16x3},
       {nerfds_launch_hyper_bf16, nerfds_launch_hyper_bf16x3, nerfds_launch_hyper_f32, nerfds_launch_hyper_f16, nerfds_launch_hyper_mixed, nerfds_launch_hyper_bf16x3f}};
   return tab[graph][prec];
@@ -398,8 +398,10 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   if (!ctx->W.loaded) return ctx->fail(NERFDS_EINVAL, "nerfds_ctx_load_weights has not been called");
   uint32_t prec = flags & NERFDS_PREC_MASK;
   if (prec >= NERFDS_PREC_COUNT) return ctx->fail(NERFDS_EINVAL, "unknown precision %u", prec);
-  // a single-level model's one level IS the level render_fn returns: no coarse pass to run cheaply
-  if (prec == NERFDS_PREC_BF16X3_FINE && ctx->cfg.num_fine_samples == 0) prec = NERFDS_PREC_BF16X3;
+  // ONE effective precision per call, used for the packed streams, their sizes and the launcher alike.  NERFDS_PREC_BF16X3_FINE is plain split bf16
+  // (a) on a single-level model - its one level IS the level render_fn returns, there is no coarse pass to run cheaply - and (b) on the static graph,
+  // for which no mixed-level kernel is built (the launcher table holds the bf16x3 kernel there: it must read bf16x3-packed streams at BOTH levels)
+  if (prec == NERFDS_PREC_BF16X3_FINE && (ctx->cfg.num_fine_samples == 0 || ctx->graph == GraphStatic::ID)) prec = NERFDS_PREC_BF16X3;
   if ((flags & NERFDS_FLAG_USE_WARP_OFF) && ctx->cfg.use_warp)
     return ctx->fail(NERFDS_ENOTSUP, "use_warp=False on a warp model is not runnable in the reference either (SURVEY.md 8a quirk 2)");
   if (rays->num_rays < 0 || rays->num_rays > 0x7fffffff) return ctx->fail(NERFDS_EINVAL, "num_rays out of range");

@@ -1296,6 +1296,13 @@ int run_merged_full(nerfds_trainer& t, hipStream_t st, int R, const float* zc, c
   float* gx_p = take(p1, 3 * Ms); float* gx_l = take(p1, 3 * Mf); float* dir_l = take(p1, 3 * Mf); float* dir_p = take(p1, 3 * Ms); float* cot_l = take(p1, 4 * Mf);
   float* dtx_p = take(p1, 3 * Ms); float* dtw_p = take(p1, 2 * Ms); float* rot_p = take(p1, 6 * Ms);
   float* z_new = t.g2; int* src = reinterpret_cast<int*>(z_new + Mn);
+  {   // what was just carved must fit the scratch buffers (each max_rays * (Nc + Nf) * trunk width floats): checked on the ACTUAL footprint, not on a
+      // hand-kept constant - a narrower trunk (or more scratch views) fails here instead of writing past g0 / g1 / g2
+    const int64_t cap = t.max_rays * (int64_t)(Nc + Nf) * t.trunk[0].width;
+    if (p0 - t.g0 > cap || p1 - t.g1 > cap || Mn + Mf > cap)
+      return t.fail(NERFDS_ENOTSUP, "run_merged_full: scratch of %lld / %lld floats does not fit the %lld-float layer buffers (trunk width %d)",
+                    (long long)(p0 - t.g0), (long long)(p1 - t.g1), (long long)cap, t.trunk[0].width);
+  }
   // NERFDS_TRAIN_REVERSE_SIGMA=0: the three-unit-direction tangent pass for the norm loss, as before (A/B, fallback; the elastic regulariser needs the
   // whole warp Jacobian and keeps it)
   static const bool rev_on = !(getenv("NERFDS_TRAIN_REVERSE_SIGMA") && std::string(getenv("NERFDS_TRAIN_REVERSE_SIGMA")) == "0");

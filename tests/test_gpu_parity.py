@@ -266,6 +266,30 @@ def test_static_graph_config1(prec):
   assert 'ray_rotation_field' not in out['coarse'] and out['coarse']['ray_hyper_points'].shape == (R, 0)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('prec', ['bf16x3', 'bf16x3_fine'])
+def test_static_graph_two_levels(prec):
+  """The static graph with a fine level (coarse + fine, 16 + 16).  'bf16x3_fine' has no kernel of its own on this graph: the call runs plain split
+  bf16 - streams packed, sized AND launched at that one precision (round 5 packed the coarse level as f16 under a bf16x3 kernel) - so both levels
+  hold north_star's 1e-4 and the two precisions agree bit for bit."""
+  cfg = static_config(num_coarse_samples=16, num_fine_samples=16)
+  params = init_params(cfg, 0, bias_scale=0.05)
+  R = 40
+  rays, rng = _rays(R, 1, 8, spread=1.0)
+  rays['origins'] = rays['origins'] * 0 + np.array([0.0, 0.0, -4.0]) + rng.normal(size=(R, 3)) * 0.01
+  t, u = rng.random((R, 16)), rng.random((R, 16))
+  ref = O.NerfModel(cfg, params).apply(rays, EXTRA, t_rand=t, u_rand=u, compute_sigma_gradient=False)
+  m = _model(cfg)
+  out = m.apply({'params': params}, rays, EXTRA, t_rand=t, u_rand=u, precision=prec)
+  assert set(out) == {'coarse', 'fine'}
+  for lv in ('coarse', 'fine'):
+    e = _relerr(out[lv]['rgb'].cpu().numpy(), ref[lv]['rgb'].numpy())
+    assert e <= RTOL['bf16x3'], (lv, e)
+  base = m.apply({'params': params}, rays, EXTRA, t_rand=t, u_rand=u, precision='bf16x3')
+  for lv in ('coarse', 'fine'):
+    assert np.array_equal(out[lv]['rgb'].cpu().numpy(), base[lv]['rgb'].cpu().numpy()), lv
+
+
 @pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
 @pytest.mark.parametrize('Nc,Nf', [(16, 16), (128, 128)])
 def test_hypernerf_base_gin_graph(prec, Nc, Nf):
