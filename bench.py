@@ -57,8 +57,8 @@ def _latest(*names):
   return names[0]
 
 
-TRAFFIC_FILE = _latest('profiles/r5_bf16_hbm_traffic.json', 'profiles/r4_bf16_hbm_traffic.json')
-TRAIN_TRAFFIC_FILE = _latest('profiles/r5_train_hbm_traffic.json', 'profiles/r4_train_hbm_traffic.json')
+TRAFFIC_FILE = _latest('profiles/r6_bf16_hbm_traffic.json', 'profiles/r5_bf16_hbm_traffic.json', 'profiles/r4_bf16_hbm_traffic.json')
+TRAIN_TRAFFIC_FILE = _latest('profiles/r6_train_hbm_traffic.json', 'profiles/r4_train_hbm_traffic.json')      # (round 5's file divided 9 steps' bytes by 4: not used)
 
 
 def synth_rays(R, n_ids, seed, device):
@@ -230,7 +230,7 @@ def run_train(args, device, emit=True):
   bwd_f16 = g16 and os.environ.get('NERFDS_TRAIN_BWD_F16', '0') == '1'
   floor_ms = ((5 / 9 if bwd_f16 else 7 / 9) if g16 else 1) * 3 * flop_exec / 2.5e15 * 1e3
   result = {
-      'metric': 'training rays/sec (batch 4096, rgb-only objective: MSE of both levels + backward + Adam, full warp+NerfMLP)',
+      'metric': f'training rays/sec (batch {R}, rgb-only objective: MSE of both levels + backward + Adam, full warp+NerfMLP)',
       'value': R / dt, 'unit': 'rays/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt * 1e3,
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16x2 (forward and data-gradient chains: split bf16 operands, fp32 accumulate; activations stored as f16 + ReLU bits, the weight-gradient operand g as loss-scaled f16: weight gradients one f16 MFMA per product; data gradients and sums fp32)' if not bwd_f16 else 'bf16x2 forward, f16 backward (NERFDS_TRAIN_BWD_F16=1: data-gradient chains and weight gradients one f16 MFMA per product)',
       'data': 'synthetic',
@@ -257,7 +257,7 @@ def run_train(args, device, emit=True):
   }
   # OPTION, measured beside the default: the data-gradient chains in one f16 MFMA per product (NERFDS_TRAIN_BWD_F16=1, read at every step; off by
   # default - it costs accuracy on small batches and loss-scale range, csrc/nerfds_train.cpp)
-  if os.environ.get('NERFDS_TRAIN_BWD_F16') is None and g16:
+  if os.environ.get('NERFDS_TRAIN_BWD_F16') is None and g16 and not getattr(args, 'no_option_legs', False):
     try:
       os.environ['NERFDS_TRAIN_BWD_F16'] = '1'
       for _ in range(2):
@@ -389,6 +389,7 @@ def main():
   ap.add_argument('--no-train-line', action='store_true', help='skip the train_step leg of the default run (N = 1 only)')
   ap.add_argument('--train', action='store_true', help='BASELINE configs[3]: the training step instead of the render')
   ap.add_argument('--train-rays', type=int, default=4096)
+  ap.add_argument('--no-option-legs', action='store_true', help='--train: time the default step only (no NERFDS_TRAIN_BWD_F16 option leg): what the profiling scripts run, so that every launch they count belongs to a default step')
   ap.add_argument('--no-full-objective', dest='full_objective', action='store_false',
                   help='skip the full configs/nerf_ds.gin objective leg of the training line (profiles of the rgb step)')
   args = ap.parse_args()
@@ -572,6 +573,11 @@ def main():
                    'parallelism': f'ray-shard x{world}' + (' of every chunk (evaluation.render_image)' if args.strong else ''),
                    'exchange': exchange},
         'roofline': roof,
+        # both fractions of the headline kernel at the top level: ALGORITHMIC FLOPs (what the roofline object prices) and the MFMA FLOPs the
+        # kernel actually executes (fewer: the shared networks run once per sample position, the linear bottleneck is folded) over the same duration
+        'roofline_frac_algorithmic': roof.get('frac'),
+        'roofline_frac_executed_mfma': (roof['executed_mfma_flop_per_launch'] / (roof['avg_launch_ms'] * 1e-3) / 1e12 / roof['peak']
+                                        if roof.get('executed_mfma_flop_per_launch') and roof.get('avg_launch_ms') else None),
     }
     sample = None
     if world == 1 and not args.no_cpu_baseline:
@@ -634,6 +640,11 @@ def main():
         pp['note'] = ('split bf16 (hi + lo) operands, three MFMAs per product, fp32 accumulate: the fastest arithmetic that meets '
                       "north_star's 1e-4 on composited RGB (profiles/r4_precision_budget.md: no arithmetic below three MFMA-equivalents per product holds it at frame size)")
         result['parity_path'] = pp
+        # said at the TOP of the line: `value` is the arithmetic north_star's roofline clause names (bf16, outside the 1e-4 tolerance); the number that
+        # satisfies the tolerance on BOTH levels is this one
+        result['value_at_tolerance'] = pp['value'] if pp['meets_tolerance'] else None
+        result['roofline_frac_at_tolerance'] = pp['roofline_frac'] if pp['meets_tolerance'] else None
+        result['precision_at_tolerance'] = 'bf16x3' if pp['meets_tolerance'] else None
       # The same frame with the COARSE level's NerfMLP in one f16 MFMA per product (precision 'bf16x3_fine'): the fine level - the one render_fn returns,
       # evaluation.py:121-124 - sees of it only the weights its depths are drawn from and holds 1e-4; the coarse level's own RGB is f16-grade.  Its own
       # object, NOT the parity_path: `meets_tolerance_both_levels` is False by construction and says so.

@@ -10,9 +10,11 @@ Deviations, all deliberate (DESIGN.md "Out of scope"):
   * per-sample tensors (sigma, alpha, weights, ...) are produced only when asked for
     (``return_weights`` / ``return_points`` / ``return_samples``): the reference always returns ~15
     per-sample arrays that render.py then throws away (render.py:192-193);
-  * ``target_norm`` (d sigma / d x, models.py:1065-1077) is produced on request only (``use_sigma_gradient=True``: the rays go
-    through the trainer's tangent pass in blocks, ``_target_norm`` below); the render kernel itself does not compute it because
-    render.py discards it;
+  * ``target_norm`` (d sigma / d x, models.py:1065-1077) is produced on request only (``return_target_norm=True``, a keyword of this mirror: the
+    rays go through the trainer's reverse pass in blocks, ``_target_norm`` below); the render kernel itself does not compute it because render.py
+    discards it.  The reference's own keyword ``use_sigma_gradient=True`` means something else - the rgb branch reads stop_gradient(d sigma / d x)
+    instead of the predicted normal, and it asserts ``not use_predicted_norm`` (models.py:1107-1112); no shipped gin sets it (defaults.gin:176) and
+    it is rejected here;
   * sampling randomness: JAX threefry streams cannot be reproduced, so either inject ``t_rand`` / ``u_rand``
     or an on-chip Philox4x32 stream keyed by the integer seed derived from ``rngs`` is used.
 """
@@ -187,7 +189,7 @@ class NerfModel:
             return_weights=False, return_samples=False, return_warp_jacobian=False, return_hyper_jacobian=False,
             return_hyper_c_jacobian=False, return_nv_details=True, near=None, far=None,
             use_sample_at_infinity=None, render_opts=None, deterministic=False, screw_input_mode=None,
-            use_sigma_gradient=False, use_predicted_norm=False,
+            use_sigma_gradient=False, use_predicted_norm=False, return_target_norm=False,
             mask_ratio=1, sharp_weights_std=1.0, x_for_rgb_alpha=4.0, norm_override=None,
             t_rand=None, u_rand=None, precision: Optional[str] = None,
             stream: Optional[torch.cuda.Stream] = None, reload_params: bool = False, ray_offset: int = 0,
@@ -212,9 +214,14 @@ class NerfModel:
       # filter_sigma runs on the RAW density on that path (models.py:1236-1237) and on the activated one for compositing (models.py:1288);
       # sharp_weights is rebuilt on the host from the composited weights, which is the same thing only without render_opts
       raise NotImplementedError('render_opts together with per-sample outputs of a use_mask_sharp_weights model (sharp_weights)')
-    if use_sigma_gradient and not (cfg.use_warp and cfg.use_predicted_mask and cfg.has_hyper and nf > 0):
-      raise NotImplementedError('use_sigma_gradient=True (target_norm, models.py:1065-1077) is built for the nerf_ds graph: '
-                                'the tangent pass lives in the trainer, which covers only that graph')
+    if use_sigma_gradient:
+      # models.py:1107-1112: norm_input = stop_gradient(sigma_gradient) feeds the rgb branch INSTEAD of the predicted normal, and the reference asserts
+      # `not use_predicted_norm` - a different graph from the one the fused kernel evaluates; configs/defaults.gin:176 leaves it False everywhere
+      raise NotImplementedError('use_sigma_gradient=True (the rgb branch conditioned on stop_gradient(d sigma / d x), models.py:1107-1112) is not built; '
+                                "for out[level]['target_norm'] pass return_target_norm=True")
+    if return_target_norm and not (cfg.use_warp and cfg.use_predicted_mask and cfg.has_hyper and nf > 0):
+      raise NotImplementedError('return_target_norm=True (target_norm, models.py:1065-1077) is built for the nerf_ds graph: '
+                                'the reverse pass lives in the trainer, which covers only that graph')
     if bool(use_predicted_norm) != bool(cfg.predict_norm):
       raise ValueError('use_predicted_norm must equal NerfModel.predict_norm: the rgb branch width depends on it '
                        '(models.py:2707-2739 initialises the parameters with the same flag)')
@@ -320,14 +327,14 @@ class NerfModel:
         directions = cr['directions'].reshape(-1, 3)[first_pixel:first_pixel + R]
       ret[level] = self._unpack(rec, smp, S, batch_shape, origins, directions, return_points, return_weights,
                                 sharp_weights_std, inf_fine if (two and level == 'fine') else inf_cfg)
-    if use_sigma_gradient:
+    if return_target_norm:
       # target_norm = normalize(R normalize(-d sigma / d x)) per sample (models.py:1065-1077, 1273-1277, 1328).  The fused render
       # kernel does not carry tangents; the trainer's forward-mode pass does (csrc/nerfds_train.cpp sigma_gradient), on the same
       # depths: injected uniforms are passed on, and the on-chip Philox stream is keyed identically in both (csrc/philox.h).
       if camera is not None:
-        raise NotImplementedError('use_sigma_gradient with fused camera rays: pass origins / directions')
+        raise NotImplementedError('return_target_norm with fused camera rays: pass origins / directions')
       if metadata_encoded or render_opts is not None or inf_fine != inf_cfg:
-        raise NotImplementedError('use_sigma_gradient with metadata_encoded / render_opts / a use_sample_at_infinity override '
+        raise NotImplementedError('return_target_norm with metadata_encoded / render_opts / a use_sample_at_infinity override '
                                   '(the tangent pass is the trainer\'s: ids, no render_opts, the model\'s use_sample_at_infinity)')
       tn = self._target_norm(params, reloaded, origins, directions, viewdirs, warp_id, gt_mask, extra_params, float(mask_ratio),
                              near, far, t_rand, u_rand, rnd.seed, int(ray_offset))

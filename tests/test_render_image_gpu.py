@@ -245,8 +245,9 @@ def test_trainer_draws_the_stratified_jitter_on_chip():
 
 
 def test_target_norm_on_the_render_surface():
-  """NerfModel.apply(use_sigma_gradient=True) (models.py:1065-1077, 1107-1111, 1328): out[level]['target_norm'] through the
-  trainer's tangent pass, in blocks, against the oracle's autograd."""
+  """NerfModel.apply(return_target_norm=True): out[level]['target_norm'] (models.py:1065-1077, 1328) through the trainer's reverse pass, in blocks,
+  against the oracle's autograd.  The reference's keyword use_sigma_gradient=True means something else (the rgb branch reads stop_gradient(d sigma /
+  d x) and asserts not use_predicted_norm, models.py:1107-1112): it is rejected, not re-purposed."""
   from nerfds_amd.model import NerfModel
   from oracle import nerfds_oracle as O
   cfg = nerf_ds_config(num_warp_embeds=4, num_coarse_samples=12, num_fine_samples=12)
@@ -258,7 +259,9 @@ def test_target_norm_on_the_render_surface():
   ref = O.NerfModel(cfg, params).apply(flat, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, compute_sigma_gradient=True)
   m = NerfModel(cfg, device=torch.device('cuda', 0), precision='f32')
   m.sigma_gradient_block = 16                            # two blocks of 16 / 14 rays
-  out = m.apply({'params': params}, f, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, use_sigma_gradient=True, precision='f32')
+  with pytest.raises(NotImplementedError):
+    m.apply({'params': params}, f, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, use_sigma_gradient=True, precision='f32')
+  out = m.apply({'params': params}, f, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, return_target_norm=True, precision='f32')
   for level, S in (('coarse', 12), ('fine', 24)):
     got = out[level]['target_norm'].cpu().numpy()
     assert got.shape == (5, 6, S, 3)
