@@ -24,3 +24,4 @@ python tools/objective_time.py > $O/objective_time.txt 2>&1
 python bench.py --train --train-rays 512 --no-cpu-baseline > gpurun_out/final_r6/bench_train_reference_batch_512.json 2>/dev/null
 cat $O/gputests.log $O/smoke.log $O/objective_time.txt; tail -20 $O/final_bench.log | cut -c1-330
 head -12 gpurun_out/prof_r6_train/summary.txt | cut -c1-170; head -6 gpurun_out/prof_r6_train_traffic/traffic.json
+timeout 600 bash tools/power_probe_r6.sh > $O/power_probe.txt 2>&1
