@@ -12,7 +12,7 @@ for p in (os.path.join(_ROOT, 'nerf-ds_amd'), _ROOT):
 # round 5 one flaky integration test (test_end_to_end, third in the alphabet) hid 147 of the 150 GPU tests, every hot-path parity test among them, from
 # the driver's run.  The parity tests of the hot path come first, then the trainer's oracle tests (row T), then the callers either
 # side of the path (8f), and last whatever composes them or spawns processes.  The exit code stays honest - a failure anywhere still fails the run.
-_ORDER = ('test_golden', 'test_gpu_parity', 'test_camera', 'test_render_image_gpu', 'test_frames', 'test_train_gemm', 'test_training',
+_ORDER = ('test_overflow_policy', 'test_golden', 'test_gpu_parity', 'test_camera', 'test_render_image_gpu', 'test_frames', 'test_train_gemm', 'test_training',
           'test_pack_stream', 'test_launch_guard', 'test_checkpoint', 'test_rccl_single_gpu', 'test_end_to_end')
 
 

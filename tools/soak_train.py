@@ -33,5 +33,6 @@ for i, l in log:
   print(f'step {i:4d}  total {l["loss/total"]:.5f}  rgb fine {l.get("loss/fine", float("nan")):.5f} coarse {l.get("loss/coarse", float("nan")):.5f}  norm fine {l.get("loss/norm/fine", 0):.6f}  mask fine {l.get("loss/mask/fine", 0):.6f}')
 first = np.mean([l['loss/total'] for i, l in log if i < 8]); last = np.mean([l['loss/total'] for i, l in log if i >= steps - 8])
 print(f'{steps} steps in {dt:.1f} s ({dt / steps * 1e3:.1f} ms per step incl. the per-step read-back of the loss terms); mean total loss of the first 8 steps {first:.5f}, of the last 8 {last:.5f}; '
-      f'optimizer steps applied {tr.optimizer_step}; loss-scale adjustment min {min(adj)} max {max(adj)} final {adj[-1]}')
+      f'optimizer steps applied {tr.optimizer_step}; loss-scale adjustment min {min(adj)} max {max(adj)} final {adj[-1]}; overflow events (call, source mask, action, fp32 detail) {tr.overflow_events}; '
+      f'final policy: tangent_scale_adjust {tr.tangent_scale_adjust} split_chains {tr.split_chains} fp32_step {tr.fp32_step}')
 assert np.isfinite(last) and last < first and tr.optimizer_step == steps, (first, last, tr.optimizer_step)
