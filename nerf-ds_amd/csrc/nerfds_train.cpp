@@ -122,6 +122,7 @@ struct nerfds_trainer {
   // these two - the tail of one runs under the streaming phase of the next.  Forked / joined with events inside every level.
   static constexpr int SIDE = 6;     // at most; nside = the streams in use (NERFDS_TRAIN_SIDE_STREAMS, default 3; 0 = none)
   int nside = 0;
+  int nside_eff = 0;                 // the side streams THIS step uses (a small batch: one - step_impl)
   hipStream_t side[SIDE] = {};
   hipEvent_t fork_ev = nullptr, join_ev[SIDE] = {};
   // Fragment packs of the layers (train_gemm.h): the first step packs each (weight block, orientation, split) when it is first used and
@@ -373,19 +374,19 @@ struct Run {
   bool wg_main = true;     // the caller's stream takes a turn too (false while it still has chains to launch)
   hipStream_t wgrad_stream() {
     if (wg_turn < 0) return st;
-    const int k = wg_turn++ % (t.nside + (wg_main ? 1 : 0));
+    const int k = wg_turn++ % (t.nside_eff + (wg_main ? 1 : 0));
     return wg_main ? (k == 0 ? st : t.side[k - 1]) : t.side[k];
   }
   void fork(bool with_main = true) {
     if (!t.side[0]) return;
     (void)hipEventRecord(t.fork_ev, st);
-    for (int i = 0; i < t.nside; ++i) (void)hipStreamWaitEvent(t.side[i], t.fork_ev, 0);
+    for (int i = 0; i < t.nside_eff; ++i) (void)hipStreamWaitEvent(t.side[i], t.fork_ev, 0);
     if (wg_turn < 0) wg_turn = 0;
     wg_main = with_main;
   }
   void join() {
     if (wg_turn < 0) return;
-    for (int i = 0; i < t.nside; ++i) { (void)hipEventRecord(t.join_ev[i], t.side[i]); (void)hipStreamWaitEvent(st, t.join_ev[i], 0); }
+    for (int i = 0; i < t.nside_eff; ++i) { (void)hipEventRecord(t.join_ev[i], t.side[i]); (void)hipStreamWaitEvent(st, t.join_ev[i], 0); }
     wg_turn = -1;
   }
   // Weight and bias gradients of an MLP whose data-gradient chain has run (fused backward): g[l] = d loss / d pre-activation of
@@ -1880,9 +1881,16 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
     want_side = want_side < 0 ? 0 : (want_side > nerfds_trainer::SIDE ? nerfds_trainer::SIDE : want_side);
     if (t->fused_bwd && want_side > 0) {
       bool ok = hipEventCreateWithFlags(&t->fork_ev, hipEventDisableTiming) == hipSuccess;
-      t->nside = want_side;
+      t->nside = t->nside_eff = want_side;
+      // The side streams at the device's LEAST priority (NERFDS_TRAIN_SIDE_PRIO=0: default priority; A/B), so that the workgroups of the chains / element-wise kernels
+      // on the caller's stream - the step's critical path - are dispatched ahead of queued weight-gradient workgroups
+      const char* sp = getenv("NERFDS_TRAIN_SIDE_PRIO");
+      const bool side_prio = !(sp && std::string(sp) == "0");
+      int prio_least = 0, prio_greatest = 0;
+      if (side_prio) (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
       for (int i = 0; i < t->nside && ok; ++i)
-        ok = hipStreamCreateWithFlags(&t->side[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&t->join_ev[i], hipEventDisableTiming) == hipSuccess;
+        ok = (side_prio ? hipStreamCreateWithPriority(&t->side[i], hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(&t->side[i], hipStreamNonBlocking)) == hipSuccess &&
+             hipEventCreateWithFlags(&t->join_ev[i], hipEventDisableTiming) == hipSuccess;
       if (!ok) { g_train_error = "hipStreamCreate failed (weight-gradient side streams)"; return NERFDS_EDEVICE; }
     }
     if (hipMalloc(&t->wpack, WPACK_BYTES + 256) != hipSuccess || hipMemset(t->wpack, 0, WPACK_BYTES + 256) != hipSuccess) { g_train_error = "hipMalloc failed (weight fragments)"; return NERFDS_ENOMEM; }
@@ -2276,6 +2284,11 @@ static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* ta
   if (t->half_step) pack_fused_backward(*t, st);
   t->tan_x_scale = std::ldexp(1.f, -6 + t->tan_scale_adjust);
   t->last_R = R; t->last_tan_rows = 0; t->last_half = t->half_step;
+  {   // A small batch's weight-gradient launches are short, and three side streams of them keep the CUs from the (dependent) kernels of the caller's
+      // stream - the step's critical path: ONE side stream up to NERFDS_TRAIN_SIDE_SMALL rays (default 768: at 512 rays one stream is 4 % faster, from 1024 rays on three are)
+    static const int small_rays = [] { const char* e = getenv("NERFDS_TRAIN_SIDE_SMALL"); return e ? atoi(e) : 768; }();
+    t->nside_eff = (R <= small_rays && t->nside > 1) ? 1 : t->nside;
+  }
   {
     int e = 6;
     while ((1 << (e - 6)) < R && e < 40) ++e;
@@ -2342,11 +2355,16 @@ static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* ta
     // gradient of rgb hidden_0's trunk_out rows, just summed) and c = the bias gradient of rgb hidden_0:
     //   d K[bottleneck rows] = Wb^T S + bb (x) c,   d Wb = S K_b^T,   d bb = K_b c      (exact: bott = trunk_out Wb + bb)
     const int TW = t->trunk[0].width, VD = 6 * t->D.vd_bands;
+    // (three latency-bound launches per level on leaves of that level only: the fine level's on a side stream, beside the coarse level's - 75 us of a step's
+    // serial tail, 3 % of a 512-ray step)
+    const bool par = Nf > 0 && t->side[0] != nullptr;
+    if (par) { (void)hipEventRecord(t->fork_ev, st); (void)hipStreamWaitEvent(t->side[0], t->fork_ev, 0); }
     for (int lv = 0; lv < (Nf > 0 ? 2 : 1); ++lv) {
       const LayerP& K = t->rgb_h[lv];
-      bott_grads(st, TW, K.N, t->theta + t->bott[lv].w, t->theta + t->bott[lv].b, t->theta + K.w, t->grad + K.w + (int64_t)(TW + VD) * K.N, t->grad + K.b,
+      bott_grads((par && lv == 1) ? t->side[0] : st, TW, K.N, t->theta + t->bott[lv].w, t->theta + t->bott[lv].b, t->theta + K.w, t->grad + K.w + (int64_t)(TW + VD) * K.N, t->grad + K.b,
                  t->grad + K.w, t->grad + t->bott[lv].w, t->grad + t->bott[lv].b);
     }
+    if (par) { (void)hipEventRecord(t->join_ev[0], t->side[0]); (void)hipStreamWaitEvent(st, t->join_ev[0], 0); }
   }
   if (!(flags & NERFDS_TRAIN_GRADS_ONLY)) adam_update(t, learning_rate, st);
   hipError_t e = hipGetLastError();

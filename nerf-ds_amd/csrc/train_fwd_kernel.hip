@@ -149,9 +149,15 @@ template <bool WIDE, int MODE> static void launch_train(const nerfds::KArgs& ka,
 // ka.nc = samples of the level (ka.nf unused); ka.wstream[1] / ka.bias[1] = the level's NerfMLP; to.mode = FWD_* (the partial modes exist in the
 // f16-store build only: the merged step is a plain step)
 extern "C" void NERFDS_CAT(nerfds_launch_, NERFDS_NAME)(const nerfds::KArgs& ka, const nerfds::TrainOut& to, int num_cus, void* stream) {
-  const bool wide = ka.nc > nerfds::Shape<nerfds::KernelPlan, false>::MAXS;      // (MAXS does not depend on the wave count)
+  // WIDE: 2 rays per workgroup and twice the waves per ray (built for Nc + Nf > 128) - and ALSO the shape of a SMALL batch: with 4 rays per workgroup
+  // a batch of 512 rays (the reference's own, configs/nerf_ds.gin:4) fills 128 of the 256 CUs, each walking the weight stream twice per level; as 256
+  // workgroups of 2 rays every CU walks it once (measured at 512 rays: DESIGN 11.5).  The shared-networks-only mode keeps its shape (its 8-wave
+  // workgroup covers a ray's 64 new samples in one walk already).  Same arithmetic per sample in either shape.
+  const bool few = 2LL * ((ka.num_rays + 3) / 4) <= (long long)num_cus;
+  const bool wide_s = ka.nc > nerfds::Shape<nerfds::KernelPlan, false>::MAXS;      // (MAXS does not depend on the wave count)
+  const bool wide = wide_s || few;
   if constexpr (nerfds::TRAIN_HALF) {
-    if (to.mode == nerfds::FWD_SHARED_ONLY) { if (wide) launch_train<true, nerfds::FWD_SHARED_ONLY>(ka, to, num_cus, stream); else launch_train<false, nerfds::FWD_SHARED_ONLY>(ka, to, num_cus, stream); return; }
+    if (to.mode == nerfds::FWD_SHARED_ONLY) { if (wide_s) launch_train<true, nerfds::FWD_SHARED_ONLY>(ka, to, num_cus, stream); else launch_train<false, nerfds::FWD_SHARED_ONLY>(ka, to, num_cus, stream); return; }
     if (to.mode == nerfds::FWD_NERF_ONLY) { if (wide) launch_train<true, nerfds::FWD_NERF_ONLY>(ka, to, num_cus, stream); else launch_train<false, nerfds::FWD_NERF_ONLY>(ka, to, num_cus, stream); return; }
   }
   if (wide) launch_train<true, nerfds::FWD_FULL>(ka, to, num_cus, stream);

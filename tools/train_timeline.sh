@@ -5,7 +5,7 @@ TAG=${1:-tl}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/tl_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace -d $OUT/trace -o t --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --train --steps 3 --warmup 2 --no-cpu-baseline --no-full-objective > $OUT/trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace -d $OUT/trace -o t --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --train --steps 3 --warmup 2 --no-cpu-baseline --no-full-objective --no-option-legs ${TRAIN_ARGS:-} > $OUT/trace.log 2>&1
 python - $OUT <<'PY' > $GRAFT_REPO_ROOT/gpurun_out/timeline_$TAG.txt
 import csv, glob, sys, os
 f = glob.glob(os.path.join(sys.argv[1], 'trace', '**', '*kernel_trace.csv'), recursive=True)[0]
