@@ -1894,8 +1894,14 @@ int nerfds_trainer_create(nerfds_trainer** out, int device, const nerfds_model_c
       int prio_least = 0, prio_greatest = 0;
       if (side_prio) (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
       for (int i = 0; i < t->nside && ok; ++i)
-        ok = (side_prio ? hipStreamCreateWithPriority(&t->side[i], hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(&t->side[i], hipStreamNonBlocking)) == hipSuccess &&
-             hipEventCreateWithFlags(&t->join_ev[i], hipEventDisableTiming) == hipSuccess;
+      {
+        // (a runtime that refuses the priority gets a plain stream: the priority is scheduling advice, not something the step's correctness rests on)
+        if (!(side_prio && hipStreamCreateWithPriority(&t->side[i], hipStreamNonBlocking, prio_least) == hipSuccess)) {
+          (void)hipGetLastError();
+          ok = hipStreamCreateWithFlags(&t->side[i], hipStreamNonBlocking) == hipSuccess;
+        }
+        ok = ok && hipEventCreateWithFlags(&t->join_ev[i], hipEventDisableTiming) == hipSuccess;
+      }
       if (!ok) { g_train_error = "hipStreamCreate failed (weight-gradient side streams)"; return NERFDS_EDEVICE; }
     }
     if (hipMalloc(&t->wpack, WPACK_BYTES + 256) != hipSuccess || hipMemset(t->wpack, 0, WPACK_BYTES + 256) != hipSuccess) { g_train_error = "hipMalloc failed (weight fragments)"; return NERFDS_ENOMEM; }
