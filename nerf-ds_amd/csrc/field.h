@@ -519,6 +519,9 @@ template <bool RELU> DEVI void store_tile(float* row_tile, const f32x16& acc) {
   }
 }
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+#if defined(NERFDS_EXP_NOSTORE)
+__device__ uint16_t g_exp_store_sink[32 * 256];      // (measurement builds only: where variant 2 sends every tile store)
+#endif
 // A tile of 16-bit values (f16 activations, f16 g): pk[2g], pk[2g + 1] = this lane's features 8g + 4h + 0..3 of its sample, as packed pairs.
 // The two lanes of a sample (l, l + 32) trade halves with v_permlane32_swap - afterwards lane half h owns features 16h .. 16h + 15 of the
 // tile - and each lane writes TWO 16-byte pieces instead of four 8-byte ones (`row16` points at the lane's feature 16h of tile 0).  A training
@@ -536,8 +539,22 @@ DEVI void store_tile_pk16(uint16_t* row_tile, const unsigned (&pk)[8]) {
     x[i] = r[0]; y[i] = r[1];
   }
   const u32x4 s0 = {x[0], x[1], y[0], y[1]}, s1 = {x[2], x[3], y[2], y[3]};
+#if defined(NERFDS_EXP_NOSTORE)
+  // measurement builds (wrong results, never shipped; tools/variant.sh): 1 = the tile stores are not issued at all (what they cost in total: issue slots
+  // + what the stage boundaries' vmcnt waits spend on them); 2 = issued, but all to one 2-KiB sink (same instructions, no HBM
+  // write stream behind them: what is left is the issue cost)
+  if (NERFDS_EXP_NOSTORE == 1) { asm volatile("" :: "v"(s0), "v"(s1)); return; }
+  // (3: the sink addressed like the rows of a 256-wide array - lane l writes row l & 31, half l >> 5: 16-byte pieces 512 bytes apart, the shipped
+  // scatter pattern without the HBM stream)
+  row_tile = NERFDS_EXP_NOSTORE == 3 ? g_exp_store_sink + (threadIdx.x & 31) * 256 + ((threadIdx.x >> 5) & 1) * 16 : g_exp_store_sink + (threadIdx.x & 63) * 16;
+#endif
+#if defined(NERFDS_EXP_NT_STORE)
+  __builtin_nontemporal_store(s0, reinterpret_cast<u32x4*>(row_tile));
+  __builtin_nontemporal_store(s1, reinterpret_cast<u32x4*>(row_tile + 8));
+#else
   *reinterpret_cast<u32x4*>(row_tile) = s0;
   *reinterpret_cast<u32x4*>(row_tile + 8) = s1;
+#endif
 #endif
 }
 // The same tile as f16 (round to nearest even; an activation beyond 65504 becomes inf and shows up as an inf weight gradient - the trainer
