@@ -237,7 +237,7 @@ typedef struct nerfds_ctx nerfds_ctx;
 int nerfds_abi_version(void);
 /* sizeof the public structs as THIS library was compiled, for a binding to check its own declarations against (host only):
  * which = 0 nerfds_model_cfg, 1 nerfds_weights, 2 nerfds_camera, 3 nerfds_rays, 4 nerfds_extra, 5 nerfds_rand, 6 nerfds_out,
- * 7 nerfds_train_objective; anything else: -1. */
+ * 7 nerfds_train_objective, 8 nerfds_train_numerics; anything else: -1. */
 int64_t nerfds_struct_size(int which);
 /* The arithmetic (NERFDS_PREC_BF16 / BF16X3 / F32 / F16) each network runs in under a NERFDS_PREC_* value of this build:
  * plan_out = {MaskMLP, SE3 warp field, hyper sheet, NerfMLP trunk (+ alpha head), rgb branch}.  Uniform for every value

@@ -289,6 +289,7 @@ int64_t nerfds_struct_size(int which) {
     case 5: return sizeof(nerfds_rand);
     case 6: return sizeof(nerfds_out);
     case 7: return sizeof(nerfds_train_objective);
+    case 8: return sizeof(nerfds_train_numerics);
     default: return -1;
   }
 }

@@ -27,8 +27,8 @@ def test_library_loads_and_exports_header_symbols():
     assert hasattr(lib, s), s
   assert lib.nerfds_abi_version() == N.ABI_VERSION == 7
   # every ctypes mirror has the size the library was compiled with (N.load() checks the render-side structs itself)
-  from nerfds_amd.training import Objective
-  assert lib.nerfds_struct_size(7) == C.sizeof(Objective) == 88 and lib.nerfds_struct_size(99) == -1
+  from nerfds_amd.training import Numerics, Objective
+  assert lib.nerfds_struct_size(7) == C.sizeof(Objective) == 88 and lib.nerfds_struct_size(8) == C.sizeof(Numerics) == 20 and lib.nerfds_struct_size(99) == -1
   assert [lib.nerfds_struct_size(i) for i in range(7)] == [C.sizeof(s) for s in (N.ModelCfg, N.Weights, N.CameraStruct, N.Rays, N.Extra, N.Rand, N.Out)]
 
 
