@@ -363,6 +363,12 @@ template <class G, class PL> struct Pipe {
 #endif
     // (A counted lgkmcnt in the pinned chains - the 8 youngest ring reads left in flight, safe there because program order is source order -
     // measured +-0 against the full drain: 38.25 against 38.26 ms per 65 536 rays, profiles/r4_ab/ab_x3_pin_variants.txt; not kept.)
+#if defined(NERFDS_EXP_LOOSE_VMCNT)
+    // measurement build (UNSAFE: weights may be read before they land - timing only, tools/variant.sh): the boundary does not wait for vector-memory
+    // operations at all - what the counted vmcnt wait, which on gfx950 also covers every STORE issued since, costs the kernels that store
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (false)
+#endif
     if (young == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else if (young == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else if (young == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
