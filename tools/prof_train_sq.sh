@@ -6,7 +6,7 @@ TAG=${1:-r6}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/train_sq_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --train --steps 3 --warmup 1 --no-cpu-baseline --no-full-objective --no-option-legs ${TRAIN_ARGS:-}"
+CMD="python $GRAFT_REPO_ROOT/${BENCH_SCRIPT:-bench.py --train} --steps 3 --warmup 1 --no-cpu-baseline --no-full-objective --no-option-legs ${TRAIN_ARGS:-}"
 timeout 900 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM SQ_INSTS_LDS -d $OUT/pmc -o p -- $CMD > $OUT/pmc.log 2>&1
 timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU -d $OUT/pmc2 -o p -- $CMD > $OUT/pmc2.log 2>&1
 python - <<PY > $OUT/summary.txt

@@ -8,7 +8,7 @@ from nerfds_amd import nerf_ds_config, init_params
 from nerfds_amd import _native as N
 from nerfds_amd.training import Trainer
 ap = argparse.ArgumentParser(); ap.add_argument('--rays', type=int, default=4096); ap.add_argument('--steps', type=int, default=30)
-a = ap.parse_args()
+a, _ = ap.parse_known_args()
 R = a.rays
 dev = torch.device('cuda', 0)
 cfg = nerf_ds_config(num_warp_embeds=64, near=0.3, far=1.7)
