@@ -533,15 +533,25 @@ __device__ uint16_t g_exp_store_sink[32 * 256];      // (measurement builds only
 // tile - and each lane writes TWO 16-byte pieces instead of four 8-byte ones (`row16` points at the lane's feature 16h of tile 0).  A training
 // kernel runs one wave per SIMD and a global store occupies the wave for its whole issue (address + data transfer of 64 lanes), MFMA pipe
 // idle: what the stores cost is their NUMBER, not their bytes.
-constexpr int ROW16_H = 16;      // offset of lane half 1 in a row of 16-bit features
+// NERFDS_STORE_SECTOR (round 6 experiment, default 0 - measured +-0: 11.35 - 11.50 against 11.47 - 11.51 ms per step): WHICH 16 features a lane half ends up with.  0 (shipped): half h owns features 16h .. 16h + 15 - its
+// two stores go to bytes [32h, 32h + 16) and [32h + 16, 32h + 32) of the row's 64-byte tile segment, so each store INSTRUCTION leaves two 16-byte pieces 32
+// bytes apart in every row.  1: half h owns features 8h .. 8h + 7 and 16 + 8h .. 16 + 8h + 7 - the first instruction writes bytes [0, 32) of the segment (half 0
+// the first 16, half 1 the next), the second [32, 64): every instruction writes whole 32-byte sectors.  Same bytes in the same places either way.
+#ifndef NERFDS_STORE_SECTOR
+#define NERFDS_STORE_SECTOR 0
+#endif
+constexpr int ROW16_H = NERFDS_STORE_SECTOR ? 8 : 16;      // offset of lane half 1 in a row of 16-bit features
+constexpr int ROW16_2ND = NERFDS_STORE_SECTOR ? 16 : 8;   // offset of a lane's second 16-byte piece
 DEVI void store_tile_pk16(uint16_t* row_tile, const unsigned (&pk)[8]) {
 #if defined(__HIP_DEVICE_COMPILE__)
   unsigned x[4], y[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    // swaps pk[i] of lanes 32..63 with pk[4 + i] of lanes 0..31: half 0 ends with (own, partner's) features of groups 0 and 1, half 1 with
-    // (partner's, own) features of groups 2 and 3
-    const u32x2 r = __builtin_amdgcn_permlane32_swap(pk[i], pk[4 + i], false, false);
+    // v_permlane32_swap(a, b): a of lanes 32..63 <-> b of lanes 0..31.  SECTOR 0: (pk[i], pk[4 + i]) - half 0 ends with (own, partner's) features of groups
+    // 0 and 1, half 1 with (partner's, own) features of groups 2 and 3.  SECTOR 1: (pk[i], pk[2 + i]) and (pk[4 + i], pk[6 + i]) - half 0 ends with groups 0
+    // and 2, half 1 with groups 1 and 3 (a group = 8 consecutive features, its first four in half 0's registers, its last four in half 1's).
+    const int ia = NERFDS_STORE_SECTOR ? (i < 2 ? i : 2 + i) : i, ib = NERFDS_STORE_SECTOR ? ia + 2 : 4 + i;
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(pk[ia], pk[ib], false, false);
     x[i] = r[0]; y[i] = r[1];
   }
   const u32x4 s0 = {x[0], x[1], y[0], y[1]}, s1 = {x[2], x[3], y[2], y[3]};
@@ -556,10 +566,10 @@ DEVI void store_tile_pk16(uint16_t* row_tile, const unsigned (&pk)[8]) {
 #endif
 #if defined(NERFDS_EXP_NT_STORE)
   __builtin_nontemporal_store(s0, reinterpret_cast<u32x4*>(row_tile));
-  __builtin_nontemporal_store(s1, reinterpret_cast<u32x4*>(row_tile + 8));
+  __builtin_nontemporal_store(s1, reinterpret_cast<u32x4*>(row_tile + ROW16_2ND));
 #else
   *reinterpret_cast<u32x4*>(row_tile) = s0;
-  *reinterpret_cast<u32x4*>(row_tile + 8) = s1;
+  *reinterpret_cast<u32x4*>(row_tile + ROW16_2ND) = s1;
 #endif
 #endif
 }
