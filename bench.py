@@ -679,6 +679,12 @@ def main():
         result['train_step']['workload'] = tr['config']['workload']
         result['train_step']['roofline'] = {k: tr['roofline'][k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_flop_per_step',
                                                                          'executed_flop_per_step', 'design_bytes_per_step', 'design_hbm_gbps', 'mfma_floor_ms', 'ms_over_mfma_floor')}
+        # the same step at the batch the reference itself trains at (configs/nerf_ds.gin:4 batch_size = 512; BASELINE configs[3] quotes 4096)
+        targs.train_rays, targs.steps, targs.no_option_legs = 512, 20, True
+        tr5 = run_train(targs, device, emit=False)
+        result['train_step_reference_batch'] = {'rays': 512, 'ms_per_step': tr5['ms_per_step'], 'value': tr5['value'], 'unit': tr5['unit'], 'steps': 20, 'warmup': 3,
+                                                'roofline_frac': tr5['roofline']['frac'], 'full_objective_ms_per_step': tr5.get('full_objective', {}).get('ms_per_step'),
+                                                'note': 'configs/nerf_ds.gin:4 ships batch_size = 512: a chain of ~150 dependent launches, not a load (DESIGN 11.5)'}
     print(json.dumps(result), flush=True)
 
   if world > 1:
