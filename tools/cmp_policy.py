@@ -1,5 +1,7 @@
-import sys, numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/nerf-ds_amd')
+"""GPU: every rung of the overflow ladder (default / split-bf16 chains / fp32 step) against the fp64 oracle on the rgb-only step - worst gradient leaves."""
+import os, sys, numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nerf-ds_amd'))
 from tests.test_training import _problem, EX, OBJECTIVE, tree_leaves
 from nerfds_amd.training import Trainer
 from oracle import train_oracle as T
