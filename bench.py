@@ -47,7 +47,7 @@ import torch.distributed as dist
 
 FLOP_PER_RAY = 333.15e6          # BASELINE.md section 2, nerf_ds graph, 192 field evaluations per ray
 # dense MFMA peaks, MI355X_MICROARCH.md (bf16 = f16 rate; the split / mixed modes are priced against the same peak)
-PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f32': 157.3, 'f16': 2500.0, 'mixed': 2500.0, 'bf16x3_fine': 2500.0}
+PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f32': 157.3, 'f16': 2500.0, 'mixed': 2500.0, 'bf16x3_fine': 2500.0, 'f16x3': 2500.0}
 EXTRA = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
 # where the committed PMC measurement of the headline kernel lives (separate rocprofv3 passes of this command, tools/prof_bench.sh)
 def _latest(*names):
@@ -377,7 +377,7 @@ def main():
   ap.add_argument('--warmup', type=int, default=2)
   ap.add_argument('--rays', type=int, default=None, help='rays per rank per step (default: one 800x600 frame; --graph static: the 64x64 image); with --strong: rays of the ONE frame')
   ap.add_argument('--chunk', type=int, default=65536)
-  ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'f32', 'f16', 'mixed', 'bf16x3_fine'])
+  ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3', 'f32', 'f16', 'mixed', 'bf16x3_fine', 'f16x3'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-other-paths', action='store_true', help='skip the parity_path / other_paths legs (N = 1 only)')
   ap.add_argument('--graph', default='nerf_ds', choices=['nerf_ds', 'hypernerf', 'static'],
@@ -510,7 +510,7 @@ def main():
     and the once-per-position evaluation of the level-independent networks out - for judging the matrix pipe itself."""
     launch_s = kernel_ms / max(n_launch, 1) * 1e-3
     ach = rays_per_launch * flop_per_ray / launch_s / 1e12 if n_launch else None
-    mult = 3.0 if prec == 'bf16x3' else 1.0       # split bf16: three MFMAs per product (the mixed plan: only its warp field; not priced)
+    mult = 3.0 if prec in ('bf16x3', 'f16x3') else 1.0       # split bf16 / split f16: three MFMAs per product (the mixed plan: only its warp field; not priced)
     exec_ray = exec_per_ray
     if prec == 'bf16x3_fine' and nf:              # split bf16 except the coarse level's NerfMLP: one f16 MFMA per product there
       shared_f, nerf_f = stream_fragments(args.graph)
@@ -612,15 +612,16 @@ def main():
           pix = max(pix, float((d / r[:, :3].abs().clamp_min(PIXEL_FLOOR)).max()))
         return err, pix
       paths = {}
-      for prec in ('bf16x3', 'f16', 'mixed'):
+      for prec in ('bf16x3', 'f16x3', 'f16', 'mixed'):
         if prec == args.precision:
           continue
-        steps = max(10, args.steps) if prec == 'bf16x3' else 3
-        el, nl, kms = timed(steps, 2 if prec == 'bf16x3' else 1, prec)
+        full = prec in ('bf16x3', 'f16x3')      # the parity-grade arithmetics get the headline's treatment
+        steps = max(10, args.steps) if full else 3
+        el, nl, kms = timed(steps, 2 if full else 1, prec)
         r = roofline_of(prec, nl, kms)
         e_glob, e_pix = rgb_error(model, cfg, params, sample, prec) if sample else (None, None)
         paths[prec] = {'precision': prec, 'value': args.rays / (el / steps), 'unit': 'rays/s', 'ms_per_step': el * 1e3 / steps, 'steps': steps,
-                       'warmup': 2 if prec == 'bf16x3' else 1, 'roofline': r, 'roofline_frac': r['frac'], 'avg_launch_ms': r['avg_launch_ms'],
+                       'warmup': 2 if full else 1, 'roofline': r, 'roofline_frac': r['frac'], 'avg_launch_ms': r['avg_launch_ms'],
                        'rgb_max_rel_err': e_glob, 'rgb_max_pixel_rel_err': e_pix}
       if 'mixed' in paths:
         plan = (C_int32 * 5)()
@@ -639,12 +640,25 @@ def main():
         pp['meets_1e-4_per_pixel'] = bool(pix) and max(pix) <= 1e-4
         pp['note'] = ('split bf16 (hi + lo) operands, three MFMAs per product, fp32 accumulate: the fastest arithmetic that meets '
                       "north_star's 1e-4 on composited RGB (profiles/r4_precision_budget.md: no arithmetic below three MFMA-equivalents per product holds it at frame size)")
+        pp['scene_dependence'] = ('holds 1e-4 on THIS frame; on other random-init scenes of the same graph a few dozen badly conditioned rays of 480 000 leave it (worst 1.2e-3) '
+                                  'where the fp32-MFMA kernel and split f16 hold it: profiles/r6_parity_sweep.jsonl, DESIGN 11.7')
         result['parity_path'] = pp
-        # said at the TOP of the line: `value` is the arithmetic north_star's roofline clause names (bf16, outside the 1e-4 tolerance); the number that
-        # satisfies the tolerance on BOTH levels is this one
-        result['value_at_tolerance'] = pp['value'] if pp['meets_tolerance'] else None
-        result['roofline_frac_at_tolerance'] = pp['roofline_frac'] if pp['meets_tolerance'] else None
-        result['precision_at_tolerance'] = 'bf16x3' if pp['meets_tolerance'] else None
+      pq = paths.pop('f16x3', None)
+      if pq is not None:
+        # split f16 (hi + lo f16 operands, three MFMAs per product: NERFDS_PREC_F16X3, round 6): the arithmetic that holds 1e-4 on every scene tried
+        pq['full_frame_rgb_max_rel_err'], pq['full_frame_rgb_max_pixel_rel_err'] = full_frame_error('f16x3')
+        pq['full_frame_reference'] = f'the fp32-MFMA kernel on all {args.rays} rays of the frame, both levels, same Philox sampling stream'
+        errs = [e for e in (pq['rgb_max_rel_err'], pq['full_frame_rgb_max_rel_err']) if e is not None]
+        pq['tolerance'], pq['meets_tolerance'] = TOLERANCE, bool(errs) and max(errs) <= TOLERANCE
+        pq['note'] = ('split f16 (hi + lo, 11 + 11 significand bits) operands, three MFMAs per product, fp32 accumulate: fp32-MFMA-grade RGB at the MFMA count of split bf16; '
+                      'holds 1e-4 on all 14 (graph, scene) frames of tools/parity_sweep.py (worst 8.5e-5, no ray of 6.7 M over 1e-4); range of f16: an activation beyond 65504 is inf')
+        result['parity_path_f16x3'] = pq
+      # said at the TOP of the line: `value` is the arithmetic north_star's roofline clause names (bf16, outside the 1e-4 tolerance); the number that
+      # satisfies the tolerance on BOTH levels - and not only on this frame (parity_path.scene_dependence) - is the split-f16 kernel's
+      best = pq if (pq is not None and pq['meets_tolerance']) else (pp if (pp is not None and pp['meets_tolerance']) else None)
+      result['value_at_tolerance'] = best['value'] if best else None
+      result['roofline_frac_at_tolerance'] = best['roofline_frac'] if best else None
+      result['precision_at_tolerance'] = best['precision'] if best else None
       # The same frame with the COARSE level's NerfMLP in one f16 MFMA per product (precision 'bf16x3_fine'): the fine level - the one render_fn returns,
       # evaluation.py:121-124 - sees of it only the weights its depths are drawn from and holds 1e-4; the coarse level's own RGB is f16-grade.  Its own
       # object, NOT the parity_path: `meets_tolerance_both_levels` is False by construction and says so.

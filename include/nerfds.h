@@ -56,7 +56,10 @@ extern "C" {
                                    * are drawn from and stays within 1e-4 (measured 3.8e-5 against 3.7e-5 for NERFDS_PREC_BF16X3 on 131 072 rays of the
                                    * bench frame); the COARSE level's own outputs are f16-grade (rgb 5e-4).  17 % fewer MFMAs than BF16X3.  A
                                    * single-level model runs plain BF16X3. */
-#define NERFDS_PREC_COUNT   6u
+#define NERFDS_PREC_F16X3   6u  /* split f16 (hi + lo, 11 + 11 significand bits) x3 MFMA on v_mfma_f32_32x32x16_f16: the MFMA count of NERFDS_PREC_BF16X3 at ~20 x
+                                   * its accuracy on composited RGB (fp32-MFMA grade: holds 1e-4 on the badly conditioned rays where split bf16 does not);
+                                   * f16's RANGE: an activation beyond 65504 is inf here, which split bf16 (fp32's exponent range) cannot produce */
+#define NERFDS_PREC_COUNT   7u
 #define NERFDS_PREC_MASK    7u
 /* Other flags. */
 #define NERFDS_FLAG_USE_WARP_OFF  (1u << 4)  /* NerfModel.__call__(use_warp=False), models.py:1468 - rejected if the graph has a warp */

@@ -63,16 +63,31 @@ extern __shared__ __attribute__((aligned(16))) char g_smem[];
 // ------------------------------------------------------------------------------------------------
 // Operand containers
 // ------------------------------------------------------------------------------------------------
+// NERFDS_X3_F16 (a compile-time fact of the translation unit; Makefile PREC_f16x3): the operands of the SPLIT arithmetic (P_BF16X3: hi + lo, three MFMAs
+// per product) are f16 pairs instead of bf16 pairs - 11 + 11 significand bits instead of 8 + 8, the same MFMA count on v_mfma_f32_32x32x16_f16.  Round 4's
+// precision budget measured it 20 x more accurate on composited RGB (profiles/r4_precision_budget.md); round 6 built it because split bf16 leaves 1e-4 on a
+// few dozen badly conditioned rays of 480 000 in some random-init scenes where the fp32-MFMA kernel holds it (tools/parity_sweep.py).
+// Range: an activation beyond 65504 is inf in this arithmetic (bf16 keeps fp32's range) - the reason split bf16 remains the other parity mode.
+#ifndef NERFDS_X3_F16
+#define NERFDS_X3_F16 0
+#endif
+#if NERFDS_X3_F16
+typedef f16x8 x3x8;
+#define NERFDS_X3_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
+typedef bf16x8 x3x8;
+#define NERFDS_X3_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
 template <int P> struct Chunk;   // 16 k-slots x 32 samples of activations (this lane: 8 slots of 1 sample)
 template <> struct Chunk<P_BF16> { bf16x8 v; };
-template <> struct Chunk<P_BF16X3> { bf16x8 hi, lo; };
+template <> struct Chunk<P_BF16X3> { x3x8 hi, lo; };
 template <> struct Chunk<P_F32> { float v[8]; };
 template <> struct Chunk<P_F16> { f16x8 v; };
 template <> struct Chunk<P_BF16X6> { bf16x8 hi, mid, lo; };
 
 template <int P> struct WFrag;   // 32 out rows x 16 k-slots of weights (this lane: 8 slots of 1 row)
 template <> struct WFrag<P_BF16> { bf16x8 v; };
-template <> struct WFrag<P_BF16X3> { bf16x8 hi, lo; };
+template <> struct WFrag<P_BF16X3> { x3x8 hi, lo; };
 template <> struct WFrag<P_F32> { f32x4 a, b; };
 template <> struct WFrag<P_F16> { f16x8 v; };
 template <> struct WFrag<P_BF16X6> { bf16x8 hi, mid, lo; };
@@ -120,9 +135,23 @@ template <> DEVI void make_chunk<P_BF16X3>(Chunk<P_BF16X3>& c, const float (&x)[
   // pair by pair, float(hi) taken from the PACKED pair's bits (shift / mask): one v_cvt_pk per pair for hi and one for lo.  Element by element
   // hipcc converts some elements twice (once in the pair, once alone for the subtraction): 10 VALU per pair instead of 6 - 7.  Same bits out.
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
   u32x4_ uh, ul;
+#if NERFDS_X3_F16
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {        // hi = f16(x) (round to nearest even), lo = f16(x - float(hi)): one v_cvt_pk_f16_f32 per pair each
+    const f32x2 r = {x[2 * k], x[2 * k + 1]};
+    const f16x2 h = __builtin_convertvector(r, f16x2);
+    const f32x2 d = r - __builtin_convertvector(h, f32x2);
+    uh[k] = __builtin_bit_cast(unsigned, h);
+    ul[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(d, f16x2));
+#if defined(NERFDS_EXP_X3_NOLO)
+    ul[k] = 0u;
+#endif
+  }
+#else
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const f32x2 r = {x[2 * k], x[2 * k + 1]};
@@ -131,8 +160,9 @@ template <> DEVI void make_chunk<P_BF16X3>(Chunk<P_BF16X3>& c, const float (&x)[
     uh[k] = hb;
     ul[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2));
   }
-  c.hi = __builtin_bit_cast(bf16x8, uh);
-  c.lo = __builtin_bit_cast(bf16x8, ul);
+#endif
+  c.hi = __builtin_bit_cast(x3x8, uh);
+  c.lo = __builtin_bit_cast(x3x8, ul);
 }
 template <> DEVI void make_chunk<P_BF16X6>(Chunk<P_BF16X6>& c, const float (&x)[8]) {
 #pragma unroll
@@ -166,9 +196,9 @@ template <int P> DEVI void mma(f32x16& acc, const WFrag<P>& w, const Chunk<P>& c
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.v, c.v, acc, 0, 0, 0);
   } else if constexpr (P == P_BF16X3) {
     // (w_hi + w_lo)(x_hi + x_lo) ~= w_hi x_lo + w_lo x_hi + w_hi x_hi ; small terms first.
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, c.lo, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, c.hi, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, c.hi, acc, 0, 0, 0);
+    acc = NERFDS_X3_MFMA(w.hi, c.lo, acc, 0, 0, 0);
+    acc = NERFDS_X3_MFMA(w.lo, c.hi, acc, 0, 0, 0);
+    acc = NERFDS_X3_MFMA(w.hi, c.hi, acc, 0, 0, 0);
   } else if constexpr (P == P_BF16X6) {
     // every product of total order <= 2 of (hi + mid + lo)(hi + mid + lo), small terms first: fp32-grade (measured 1e-6 vs fp64)
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, c.lo, acc, 0, 0, 0);
@@ -434,8 +464,11 @@ template <class G, class PL> struct Pipe {
     } else if constexpr (P == P_F16) {
       w.v = __builtin_bit_cast(f16x8, ring[u % RD]);
     } else if constexpr (P == P_BF16X3) {
-      w.hi = __builtin_bit_cast(bf16x8, ring[u % RD]);
-      w.lo = __builtin_bit_cast(bf16x8, ring[(u + 1) % RD]);
+      w.hi = __builtin_bit_cast(x3x8, ring[u % RD]);
+      w.lo = __builtin_bit_cast(x3x8, ring[(u + 1) % RD]);
+#if defined(NERFDS_EXP_X3_NOLO)
+      if (NERFDS_EXP_X3_NOLO == 2) w.lo = x3x8{};
+#endif
     } else if constexpr (P == P_BF16X6) {
       static_assert(RD >= 4 || P != P_BF16X6, "three units of one fragment and one of the next");
       w.hi = __builtin_bit_cast(bf16x8, ring[u % RD]);
@@ -724,12 +757,12 @@ DEVI void accum(f32x16 (&acc)[TP][NT], Pipe<G, PL>& pipe, Cursor& cur, const Chu
         if (m < 4) { pipe.refill(cur.seg, u + m); pipe.spread_piece(cur.seg, u + m); }
         win(3 * j + m);
       };
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, c.lo, acc[0][0], 0, 0, 0); after(0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, c.lo, acc[1][0], 0, 0, 0); after(1);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.lo, c.hi, acc[0][0], 0, 0, 0); after(2);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.lo, c.hi, acc[1][0], 0, 0, 0); after(3);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, c.hi, acc[0][0], 0, 0, 0); after(4);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, c.hi, acc[1][0], 0, 0, 0); after(5);
+      acc[0][0] = NERFDS_X3_MFMA(w0.hi, c.lo, acc[0][0], 0, 0, 0); after(0);
+      acc[1][0] = NERFDS_X3_MFMA(w1.hi, c.lo, acc[1][0], 0, 0, 0); after(1);
+      acc[0][0] = NERFDS_X3_MFMA(w0.lo, c.hi, acc[0][0], 0, 0, 0); after(2);
+      acc[1][0] = NERFDS_X3_MFMA(w1.lo, c.hi, acc[1][0], 0, 0, 0); after(3);
+      acc[0][0] = NERFDS_X3_MFMA(w0.hi, c.hi, acc[0][0], 0, 0, 0); after(4);
+      acc[1][0] = NERFDS_X3_MFMA(w1.hi, c.hi, acc[1][0], 0, 0, 0); after(5);
       cur.pos += 4;
       j += 2;
     }
@@ -749,12 +782,12 @@ DEVI void accum(f32x16 (&acc)[TP][NT], Pipe<G, PL>& pipe, Cursor& cur, const Chu
         if ((u + q) % PP::SU == 0) pipe.begin_stage(cur.seg, u + q);
       const WFrag<P> w0 = pipe.template frag<P>(u), w1 = pipe.template frag<P>(u + 2);
       const Chunk<P>& c = in[0][kc];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, c.lo, acc[0][0], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, c.lo, acc[1][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.lo, c.hi, acc[0][0], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.lo, c.hi, acc[1][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, c.hi, acc[0][0], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, c.hi, acc[1][0], 0, 0, 0);
+      acc[0][0] = NERFDS_X3_MFMA(w0.hi, c.lo, acc[0][0], 0, 0, 0);
+      acc[1][0] = NERFDS_X3_MFMA(w1.hi, c.lo, acc[1][0], 0, 0, 0);
+      acc[0][0] = NERFDS_X3_MFMA(w0.lo, c.hi, acc[0][0], 0, 0, 0);
+      acc[1][0] = NERFDS_X3_MFMA(w1.lo, c.hi, acc[1][0], 0, 0, 0);
+      acc[0][0] = NERFDS_X3_MFMA(w0.hi, c.hi, acc[0][0], 0, 0, 0);
+      acc[1][0] = NERFDS_X3_MFMA(w1.hi, c.hi, acc[1][0], 0, 0, 0);
 #pragma unroll
       for (int q = 0; q < 4; ++q) { pipe.refill(cur.seg, u + q); pipe.spread_piece(cur.seg, u + q); }
       cur.pos += 4;
@@ -878,21 +911,33 @@ template <int W> DEVI void x3_epi_op(int i, const f32x16 (&prev)[2], X3Epi& e, C
   const int w = i % 2, s = (i % 16) / 2, pair = 2 * (i / 16) + w, tp = pair / 8, k = pair % 8;
   if (s == 0) asm volatile("v_max_i32 %0, 0, %1" : "=v"(e.t0[w]) : "v"(prev[tp][2 * k]));
   else if (s == 1) asm volatile("v_max_i32 %0, 0, %1" : "=v"(e.t1[w]) : "v"(prev[tp][2 * k + 1]));
+#if NERFDS_X3_F16
+  // (split f16: hi = v_cvt_pk_f16_f32, float(hi) by v_cvt_f32_f16 of the packed pair's low half and - SDWA word select - of its high half: the same eight
+  // steps per pair as split bf16's shift / mask, so the windows of the pinned chain are unchanged)
+  else if (s == 2) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(e.hi[w]) : "v"(e.t0[w]), "v"(e.t1[w]));
+  else if (s == 3) asm volatile("v_cvt_f32_f16_e32 %0, %1" : "=v"(e.h0[w]) : "v"(e.hi[w]));
+  else if (s == 4) asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(e.h1[w]) : "v"(e.hi[w]));
+#else
   else if (s == 2) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(e.hi[w]) : "v"(e.t0[w]), "v"(e.t1[w]));
   else if (s == 3) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(e.h0[w]) : "v"(e.hi[w]));
   else if (s == 4) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(e.h1[w]) : "v"(e.hi[w]));
+#endif
   else if (s == 5) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(e.t0[w]) : "v"(e.t0[w]), "v"(e.h0[w]));
   else if (s == 6) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(e.t1[w]) : "v"(e.t1[w]), "v"(e.h1[w]));
   else {
+#if NERFDS_X3_F16
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(e.lo[w]) : "v"(e.t0[w]), "v"(e.t1[w]));
+#else
     asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(e.lo[w]) : "v"(e.t0[w]), "v"(e.t1[w]));
+#endif
     e.uh[tp][k] = e.hi[w];
     e.ul[tp][k] = e.lo[w];
     if (k % 4 == 3) {                                              // a chunk (8 values) of the pending group is complete
       const int sub = k / 4, t = pot + tp;
       const u32x4 rh = {e.uh[tp][4 * sub], e.uh[tp][4 * sub + 1], e.uh[tp][4 * sub + 2], e.uh[tp][4 * sub + 3]};
       const u32x4 rl = {e.ul[tp][4 * sub], e.ul[tp][4 * sub + 1], e.ul[tp][4 * sub + 2], e.ul[tp][4 * sub + 3]};
-      out[0][2 * t + sub].hi = __builtin_bit_cast(bf16x8, rh);
-      out[0][2 * t + sub].lo = __builtin_bit_cast(bf16x8, rl);
+      out[0][2 * t + sub].hi = __builtin_bit_cast(x3x8, rh);
+      out[0][2 * t + sub].lo = __builtin_bit_cast(x3x8, rl);
     }
   }
 #endif

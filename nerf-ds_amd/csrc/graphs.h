@@ -80,11 +80,12 @@ constexpr Plan level_plan(Plan p, int level) { return (level == 0 && p.trunk_c >
 #ifndef NERFDS_MIX_RGB
 #define NERFDS_MIX_RGB P_F16
 #endif
-constexpr int NUM_PLANS = 6;     // == number of NERFDS_PREC_* values of include/nerfds.h
+constexpr int NUM_PLANS = 7;     // == number of NERFDS_PREC_* values of include/nerfds.h
 constexpr Plan plan_of(int prec_index) {
   return prec_index == 4 ? Plan{NERFDS_MIX_MASK, NERFDS_MIX_WARP, NERFDS_MIX_HYP, NERFDS_MIX_TRUNK, NERFDS_MIX_RGB}
          : prec_index == 5 ? Plan{P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_BF16X3, P_F16, P_F16}      // NERFDS_PREC_BF16X3_FINE
-                           : uniform_plan(prec_index);
+         : prec_index == 6 ? uniform_plan(P_BF16X3)      // NERFDS_PREC_F16X3: the split plan; WHICH 16-bit format its hi / lo parts are is a fact of the kernel build
+                           : uniform_plan(prec_index);      //   (field.h NERFDS_X3_F16) and of the packer (pack.h StreamWriter::x3_f16)
 }
 // The plan of the fused training forward (train_fwd_kernel.hip): split bf16 operands as the trainer's layer
 // kernels (train_gemm.hip), exact fp32 products in the warp field (its 16-bit rounding is amplified to ~1 % on the warp-field

@@ -35,6 +35,9 @@ void nerfds_launch_nerfds_mixed(const KArgs&, int, void*);
 void nerfds_launch_nerfds_bf16x3f(const KArgs&, int, void*);
 void nerfds_launch_hyper_bf16x3f(const KArgs&, int, void*);
 void nerfds_launch_static_mixed(const KArgs&, int, void*);
+void nerfds_launch_nerfds_f16x3(const KArgs&, int, void*);
+void nerfds_launch_static_f16x3(const KArgs&, int, void*);
+void nerfds_launch_hyper_f16x3(const KArgs&, int, void*);
 void nerfds_launch_hyper_mixed(const KArgs&, int, void*);
 void nerfds_launch_camera_rays(const nerfds::CameraParams&, long long, long long, const float*, float*, float*, float*, void*);
 void nerfds_launch_encode_embed(const float* table, int rows, const float* meta, int channels, long long n, float* out, void* stream);
@@ -210,6 +213,7 @@ static int tile_pair_of(int graph, int prec) {
 void pack_dispatch(int graph, StreamWriter& sw, const Weights& W, int which, int level, int prec) {
   const Plan pl = plan_of(prec);
   sw.tile_pair = tile_pair_of(graph, prec);
+  sw.x3_f16 = prec == (int)NERFDS_PREC_F16X3;      // split f16: the same plan and stream geometry as split bf16, f16 hi / lo parts
   if (graph == GraphNerfDS::ID) pack_which<GraphNerfDS>(sw, W, which, level, pl);
   else if (graph == GraphStatic::ID) pack_which<GraphStatic>(sw, W, which, level, pl);
   else pack_which<GraphHyperNeRF>(sw, W, which, level, pl);
@@ -244,11 +248,10 @@ struct nerfds_ctx {
   nerfds_model_cfg cfg{};
   Weights W;
   DevBuf wstream[NUM_PLANS][3];     // [prec][shared, coarse, fine]
-  DevBuf wbias[3];          // precision independent
+  DevBuf wbias[NUM_PLANS][3];   // per precision since round 6: the split-f16 packer rescales the last hidden layer of the shared networks (pack.h balance_last_hidden), biases included
   DevBuf warp_embed, mask_embed;
   DevBuf ray_scratch;       // origins | directions generated from a camera
   bool packed[NUM_PLANS] = {};
-  bool bias_uploaded = false;
   std::string err;
   // timing: event pairs recorded around the launches since the last reset; reset returns them to the pool (no per-launch
   // hipEventCreate, nothing accumulates), and at most MAX_TIMED launches are recorded between two resets
@@ -269,10 +272,10 @@ struct nerfds_ctx {
 static launch_fn launcher(int graph, uint32_t prec) {
   static_assert(NUM_PLANS == NERFDS_PREC_COUNT, "graphs.h plan_of covers every NERFDS_PREC_* value");
   static const launch_fn tab[3][NUM_PLANS] = {
-      {nerfds_launch_nerfds_bf16, nerfds_launch_nerfds_bf16x3, nerfds_launch_nerfds_f32, nerfds_launch_nerfds_f16, nerfds_launch_nerfds_mixed, nerfds_launch_nerfds_bf16x3f},
+      {nerfds_launch_nerfds_bf16, nerfds_launch_nerfds_bf16x3, nerfds_launch_nerfds_f32, nerfds_launch_nerfds_f16, nerfds_launch_nerfds_mixed, nerfds_launch_nerfds_bf16x3f, nerfds_launch_nerfds_f16x3},
       // (the static graph has no mixed-level kernel: nerfds_render_rays maps NERFDS_PREC_BF16X3_FINE to NERFDS_PREC_BF16X3 before it packs or launches)
-      {nerfds_launch_static_bf16, nerfds_launch_static_bf16x3, nerfds_launch_static_f32, nerfds_launch_static_f16, nerfds_launch_static_mixed, nerfds_launch_static_bf16x3},
-      {nerfds_launch_hyper_bf16, nerfds_launch_hyper_bf16x3, nerfds_launch_hyper_f32, nerfds_launch_hyper_f16, nerfds_launch_hyper_mixed, nerfds_launch_hyper_bf16x3f}};
+      {nerfds_launch_static_bf16, nerfds_launch_static_bf16x3, nerfds_launch_static_f32, nerfds_launch_static_f16, nerfds_launch_static_mixed, nerfds_launch_static_bf16x3, nerfds_launch_static_f16x3},
+      {nerfds_launch_hyper_bf16, nerfds_launch_hyper_bf16x3, nerfds_launch_hyper_f32, nerfds_launch_hyper_f16, nerfds_launch_hyper_mixed, nerfds_launch_hyper_bf16x3f, nerfds_launch_hyper_f16x3}};
   return tab[graph][prec];
 }
 
@@ -359,7 +362,6 @@ int nerfds_ctx_load_weights(nerfds_ctx* ctx, const nerfds_weights* w) {
   bool ok = take_weights_dispatch(ctx->graph, ctx->W, ctx->cfg, *w, err);
   if (!ok) return ctx->fail(NERFDS_EINVAL, "load_weights: %s", err.c_str());
   for (bool& p : ctx->packed) p = false;
-  ctx->bias_uploaded = false;
   if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(NERFDS_EDEVICE, "hipSetDevice failed");
   if (!ctx->W.warp_embed.empty() &&
       ctx->warp_embed.upload(ctx->W.warp_embed.data(), ctx->W.warp_embed.size() * 4) != hipSuccess)
@@ -383,11 +385,15 @@ static int ensure_packed(nerfds_ctx* ctx, uint32_t prec) {
     if ((int64_t)sw.wbytes > wb || wb - (int64_t)sw.wbytes >= STAGE_BYTES || (int64_t)sw.bfloats != bf)
       return ctx->fail(NERFDS_EINVAL, "internal: packed stream %d has %zu bytes / %zu bias floats, kernel expects %lld / %lld",
                        which, sw.wbytes, sw.bfloats, (long long)wb, (long long)bf);
+    if (getenv("NERFDS_DEBUG_PACK")) {
+      unsigned long long sum = 0; size_t nz = 0;
+      for (size_t i = 0; i < w.size(); ++i) { sum += w[i]; nz += w[i] != 0; }
+      fprintf(stderr, "ensure_packed: prec %u which %d bytes %zu nonzero %zu checksum %llu x3_f16 %d\n", prec, which, w.size(), nz, sum, (int)sw.x3_f16);
+    }
     if (ctx->wstream[prec][which].upload(w.data(), w.size()) != hipSuccess) return ctx->fail(NERFDS_ENOMEM, "weight stream upload failed");
-    if (!ctx->bias_uploaded && ctx->wbias[which].upload(b.data(), b.size() * 4) != hipSuccess)
+    if (ctx->wbias[prec][which].upload(b.data(), b.size() * 4) != hipSuccess)
       return ctx->fail(NERFDS_ENOMEM, "bias upload failed");
   }
-  ctx->bias_uploaded = true;
   ctx->packed[prec] = true;
   return NERFDS_OK;
 }
@@ -436,7 +442,7 @@ int nerfds_render_rays(nerfds_ctx* ctx, const nerfds_rays* rays, const nerfds_ex
   ka.u_rand = rnd ? rnd->u_rand : nullptr;
   ka.seed = rnd ? rnd->seed : 0;
   ka.first_ray = rnd ? rnd->first_ray : 0;
-  for (int i = 0; i < 3; ++i) { ka.wstream[i] = ctx->wstream[prec][i].p; ka.bias[i] = static_cast<const float*>(ctx->wbias[i].p); }
+  for (int i = 0; i < 3; ++i) { ka.wstream[i] = ctx->wstream[prec][i].p; ka.bias[i] = static_cast<const float*>(ctx->wbias[prec][i].p); }
   if (ctx->cfg.num_fine_samples == 0) { ka.wstream[2] = ka.wstream[1]; ka.bias[2] = ka.bias[1]; }
 #ifdef NERFDS_EXP_ONE_NERF_STREAM
   // MEASUREMENT BUILD ONLY (tools/variant.sh, results wrong by construction): the fine level walks the coarse level's weight stream, i.e. the

@@ -62,6 +62,24 @@ inline uint16_t f32_to_f16_rne(float f) {
   return (uint16_t)(sign | h);
 }
 
+// IEEE binary16 -> fp32, exact (subnormals included)
+inline float f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+  uint32_t u;
+  if (e == 0) {
+    if (m == 0) u = sign;
+    else {                                     // subnormal: m * 2^-24
+      const float f = (float)m * 5.9604644775390625e-08f;
+      std::memcpy(&u, &f, 4);
+      u |= sign;
+    }
+  } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+  else u = sign | ((e + 112u) << 23) | (m << 13);
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
 // k-slot -> kernel-row maps -------------------------------------------------------------------------
 inline void rows_linear(std::vector<int>& rm, int n_chunks, const std::function<int(int)>& feat_to_row) {
   for (int s = 0; s < 16 * n_chunks; ++s) rm.push_back(feat_to_row(s));
@@ -92,6 +110,7 @@ struct StreamWriter {
   float* b;
   size_t wbytes = 0, bfloats = 0;
   int tile_pair = TILE_PAIR;   // tiles per group in THIS stream (graphs.h stream_tile_pair: what the consuming kernel was built with)
+  bool x3_f16 = false;         // the hi / lo parts of a split (P_BF16X3) fragment are f16, not bf16 (NERFDS_PREC_F16X3: field.h NERFDS_X3_F16)
 
   void frag_out(const Layer& L, const Seg& S, int ot, int kc) {
     const int prec = S.prec;
@@ -113,8 +132,13 @@ struct StreamWriter {
           uint16_t* dh = reinterpret_cast<uint16_t*>(frag + lane * 16);
           uint16_t* dl = reinterpret_cast<uint16_t*>(frag + 1024 + lane * 16);
           for (int i = 0; i < 8; ++i) {
-            dh[i] = f32_to_bf16_rne(v[i]);
-            dl[i] = f32_to_bf16_rne(v[i] - bf16_to_f32(dh[i]));
+            if (x3_f16) {
+              dh[i] = f32_to_f16_rne(v[i]);
+              dl[i] = f32_to_f16_rne(v[i] - f16_to_f32(dh[i]));
+            } else {
+              dh[i] = f32_to_bf16_rne(v[i]);
+              dl[i] = f32_to_bf16_rne(v[i] - bf16_to_f32(dh[i]));
+            }
           }
         } else if (prec == P_BF16X6) {
           uint16_t* dh = reinterpret_cast<uint16_t*>(frag + lane * 16);
@@ -175,7 +199,38 @@ inline Layer head_layer(const DenseView& d, std::vector<int> rows, int prec) {
 
 // A reference modules.MLP (modules.py:57-83) with `depth` hidden layers of `width`, raw input of `in_dim`
 // features in `in_chunks` linear chunks, skip re-concatenation [x, inputs] before layer `skip`.
-inline void emit_mlp(StreamWriter& sw, const DenseView* hidden, int depth, int width, int in_dim, int in_chunks, int skip, int prec) {
+// Split f16 only (StreamWriter::x3_f16): f16's normal range ends at 6.1e-5, and the output heads of the level-independent networks are initialised
+// far below it (hyper sheet N(0, 1e-5), modules.py:367-392; SE3 branches 1e-4, warping.py:156-157): their weights would keep 7 - 10 significand bits.
+// A ReLU unit is positively homogeneous - relu(s z) = s relu(z) for s > 0 - so unit j of the LAST hidden layer can carry any power of two s_j: its
+// incoming weights and bias times s_j, the head's row j divided by s_j, the function unchanged EXACTLY.  s_j = 2^round((log2 max|out_j| - log2 max|in_j|) / 2)
+// balances the two sides (in 0.1 against out 1e-5: both land at 1e-3, inside f16's normal range); a balanced unit keeps s_j = 1 and its bits.
+inline std::vector<float> balance_last_hidden(const DenseView& last, std::initializer_list<DenseView> heads, int width) {
+  std::vector<float> sc((size_t)width, 1.f);
+  for (int j = 0; j < width; ++j) {
+    double mi = last.bias ? std::fabs((double)last.bias[j]) : 0.0, mo = 0.0;
+    for (int r = 0; r < last.in_dim; ++r) mi = std::max(mi, std::fabs((double)last.W(r, j)));
+    for (const DenseView& h : heads)
+      for (int c = 0; c < h.out_dim; ++c) mo = std::max(mo, std::fabs((double)h.W(j, c)));
+    if (!(mi > 0.0) || !(mo > 0.0) || !std::isfinite(mi) || !std::isfinite(mo)) continue;
+    int e = (int)std::lround(0.5 * (std::log2(mo) - std::log2(mi)));
+    e = e < -14 ? -14 : (e > 14 ? 14 : e);
+    sc[(size_t)j] = std::ldexp(1.f, e);
+  }
+  return sc;
+}
+inline Layer scale_outputs(Layer L, std::shared_ptr<std::vector<float>> sc) {      // W(:, c), B(c) times sc[c]
+  auto W = L.W; auto B = L.B;
+  L.W = [W, sc](int r, int c) { return W(r, c) * (*sc)[(size_t)c]; };
+  L.B = [B, sc](int c) { return B(c) * (*sc)[(size_t)c]; };
+  return L;
+}
+inline Layer divide_inputs(Layer L, std::shared_ptr<std::vector<float>> sc) {      // W(r, :) divided by sc[r] (r = the hidden unit's index: rows_tile(.., 0))
+  auto W = L.W;
+  L.W = [W, sc](int r, int c) { return W(r, c) / (*sc)[(size_t)r]; };
+  return L;
+}
+inline void emit_mlp(StreamWriter& sw, const DenseView* hidden, int depth, int width, int in_dim, int in_chunks, int skip, int prec,
+                     std::shared_ptr<std::vector<float>> last_scale = nullptr) {
   for (int l = 0; l < depth; ++l) {
     std::vector<Seg> segs;
     std::vector<int> rows;
@@ -191,7 +246,8 @@ inline void emit_mlp(StreamWriter& sw, const DenseView* hidden, int depth, int w
         segs.push_back(Seg{std::move(raw), prec});
       }
     }
-    sw.emit(plain_layer(hidden[l], std::move(segs), width));
+    Layer L = plain_layer(hidden[l], std::move(segs), width);
+    sw.emit((l == depth - 1 && last_scale) ? scale_outputs(std::move(L), last_scale) : std::move(L));
   }
 }
 
@@ -212,13 +268,16 @@ struct NerfNet {
 template <class G> void pack_shared(StreamWriter& sw, const SharedNets& n, Plan pl) {
   using D = Dims<G>;
   if constexpr (G::HAS_MASK) {
-    emit_mlp(sw, n.mask_hidden, G::MASK_DEPTH, G::MASK_W, D::MASK_IN, D::MASK_KC, G::MASK_SKIP, pl.mask);
+    auto sc = (sw.x3_f16 && sw.w) ? std::make_shared<std::vector<float>>(balance_last_hidden(n.mask_hidden[G::MASK_DEPTH - 1], {n.mask_out}, G::MASK_W)) : nullptr;
+    emit_mlp(sw, n.mask_hidden, G::MASK_DEPTH, G::MASK_W, D::MASK_IN, D::MASK_KC, G::MASK_SKIP, pl.mask, sc);
     std::vector<int> rows;
     rows_tile(rows, G::MASK_W, 0);
-    sw.emit(head_layer(n.mask_out, std::move(rows), pl.mask));
+    Layer H = head_layer(n.mask_out, std::move(rows), pl.mask);
+    sw.emit(sc ? divide_inputs(std::move(H), sc) : std::move(H));
   }
   if constexpr (G::HAS_WARP) {
-    emit_mlp(sw, n.warp_hidden, G::WARP_DEPTH, G::WARP_W, D::WARP_IN, D::WARP_KC, G::WARP_SKIP, pl.warp);
+    auto sc = (sw.x3_f16 && sw.w) ? std::make_shared<std::vector<float>>(balance_last_hidden(n.warp_hidden[G::WARP_DEPTH - 1], {n.warp_w, n.warp_v}, G::WARP_W)) : nullptr;
+    emit_mlp(sw, n.warp_hidden, G::WARP_DEPTH, G::WARP_W, D::WARP_IN, D::WARP_KC, G::WARP_SKIP, pl.warp, sc);
     std::vector<int> rows;
     rows_tile(rows, G::WARP_W, 0);
     Layer L;                                   // merged head: logical outputs 0-2 = w, 3-5 = v (warping.py:217-218)
@@ -229,13 +288,15 @@ template <class G> void pack_shared(StreamWriter& sw, const SharedNets& n, Plan 
     const DenseView w = n.warp_w, v = n.warp_v;
     L.W = [w, v](int r, int c) { return c < 3 ? w.W(r, c) : v.W(r, c - 3); };
     L.B = [w, v](int c) { return c < 3 ? (w.bias ? w.bias[c] : 0.f) : (v.bias ? v.bias[c - 3] : 0.f); };
-    sw.emit(L);
+    sw.emit(sc ? divide_inputs(std::move(L), sc) : std::move(L));
   }
   if constexpr (G::HAS_HYPER) {
-    emit_mlp(sw, n.hyper_hidden, G::HYP_DEPTH, G::HYP_W, D::HYP_IN, D::HYP_KC, G::HYP_SKIP, pl.hyp);
+    auto sc = (sw.x3_f16 && sw.w) ? std::make_shared<std::vector<float>>(balance_last_hidden(n.hyper_hidden[G::HYP_DEPTH - 1], {n.hyper_out}, G::HYP_W)) : nullptr;
+    emit_mlp(sw, n.hyper_hidden, G::HYP_DEPTH, G::HYP_W, D::HYP_IN, D::HYP_KC, G::HYP_SKIP, pl.hyp, sc);
     std::vector<int> rows;
     rows_tile(rows, G::HYP_W, 0);
-    sw.emit(head_layer(n.hyper_out, std::move(rows), pl.hyp));
+    Layer H = head_layer(n.hyper_out, std::move(rows), pl.hyp);
+    sw.emit(sc ? divide_inputs(std::move(H), sc) : std::move(H));
   }
 }
 

@@ -324,7 +324,11 @@ template <class LT> DEVI void resample(const KArgs& ka, int ray, int lane, int n
 // ------------------------------------------------------------------------------------------------
 // Kernel: persistent waves, one ray per wave per iteration.
 // ------------------------------------------------------------------------------------------------
-template <class G, class PL, bool WIDE>
+// X3F16: the split arithmetic's 16-bit format is a MACRO of the translation unit (field.h NERFDS_X3_F16), not part of PL - it must still be part of the
+// kernel's NAME: two translation units that build the same template arguments with different macros emit one mangled kernel name with two bodies, and
+// the runtime binds both launchers to ONE of them (round 6 found the split-f16 launcher running the split-bf16 kernel on f16-packed weights: every product
+// ~1e-14, every output its head's bias; round 3 lost a conclusion to the same trap in the training kernels, field.h TRAIN_TAG).
+template <class G, class PL, bool WIDE, int X3F16 = NERFDS_X3_F16>
 __global__ __launch_bounds__(64 * wg_waves<PL>(), wg_waves<PL>() / 4) void render_rays_kernel(const KArgs ka) {
   using SH = Shape<PL, WIDE>;
   using WaveLds = WaveLdsT<SH::MAXS>;
@@ -563,7 +567,7 @@ template <bool WIDE> static void launch_shape(const nerfds::KArgs& ka, int num_c
   using SH = Shape<KernelPlan, WIDE>;
   constexpr int lds = BIAS_OFF + bias_bytes<NERFDS_GRAPH>() + SH::RAYS * (int)sizeof(WaveLdsT<SH::MAXS>);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = render_rays_kernel<NERFDS_GRAPH, KernelPlan, WIDE>;
+  auto kern = render_rays_kernel<NERFDS_GRAPH, KernelPlan, WIDE, NERFDS_X3_F16>;
   allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
   // one persistent workgroup per CU (LDS-bound), SH::RAYS rays per workgroup iteration
   const long long groups = ((long long)ka.num_rays + SH::RAYS - 1) / SH::RAYS;

@@ -26,7 +26,7 @@ def resolve_device(device=None):
 MAX_DEPTH = 16
 RAY_REC = 26
 SAMPLE_REC = 18
-PREC = {'bf16': 0, 'bf16x3': 1, 'f32': 2, 'f16': 3, 'mixed': 4, 'bf16x3_fine': 5}
+PREC = {'bf16': 0, 'bf16x3': 1, 'f32': 2, 'f16': 3, 'mixed': 4, 'bf16x3_fine': 5, 'f16x3': 6}
 
 # per-ray record slices (enum nerfds_ray_field)
 RAY_FIELDS = {

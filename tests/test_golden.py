@@ -36,7 +36,7 @@ def test_oracle_reproduces_golden(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', list(G.CASES))
-@pytest.mark.parametrize('prec,tol', [('f32', 1e-4), ('bf16x3', 1e-4)])
+@pytest.mark.parametrize('prec,tol', [('f32', 1e-4), ('bf16x3', 1e-4), ('f16x3', 1e-4)])
 def test_hip_matches_golden(name, prec, tol):
   from nerfds_amd.model import NerfModel
   z, cfg, params, rays, t, u = _load(name)

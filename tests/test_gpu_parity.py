@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 EXTRA = dict(nerf_alpha=8., warp_alpha=4., hyper_alpha=1., hyper_sheet_alpha=6., norm_input_alpha=4.)
 # parity grade: north_star's 1e-4.  Throughput modes: <= 2 x the worst value these tests measure (round 4: bf16 2.05e-2, f16 1.24e-3, mixed 7.3e-4)
-RTOL = {'f32': 1e-4, 'bf16x3': 1e-4, 'bf16': 3e-2, 'f16': 2.4e-3, 'mixed': 1.4e-3}
+RTOL = {'f32': 1e-4, 'bf16x3': 1e-4, 'f16x3': 1e-4, 'bf16': 3e-2, 'f16': 2.4e-3, 'mixed': 1.4e-3}
 PIXEL_FLOOR = 1e-2
 FAST = ('bf16', 'f16', 'mixed')      # throughput arithmetic: composited maps only, bounded by RTOL
 
@@ -65,7 +65,7 @@ def test_extension_is_loaded_and_mfma_layout():
   assert any('libnerfds_hip' in l for l in open('/proc/self/maps'))
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed', 'f16x3'])
 def test_nerf_ds_graph_tiny(prec):
   cfg = nerf_ds_config(num_warp_embeds=4, num_coarse_samples=8, num_fine_samples=8)
   params = init_params(cfg, 0, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
@@ -103,7 +103,7 @@ def test_nerf_ds_graph_tiny(prec):
         assert ep <= 2 * tol, (level, 'rgb per pixel', ep)
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed', 'f16x3'])
 def test_nerf_ds_graph_full_samples_init_regime(prec):
   """64 + 64 samples (nerf_ds.gin), freshly initialised weights: theta ~ 1e-4 stresses exp_se3 (quirk 5)."""
   cfg = nerf_ds_config(num_warp_embeds=8)
@@ -120,7 +120,7 @@ def test_nerf_ds_graph_full_samples_init_regime(prec):
     assert torch.isfinite(out[level]['ray_delta_x']).all()
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed', 'f16x3'])
 def test_nerf_ds_graph_256_samples_per_ray(prec):
   """BASELINE.json configs[4] shape: 128 coarse + 128 fine (256 on the fine pass) - the WIDE kernel shape
   (2 rays per workgroup, twice the waves per ray)."""
@@ -182,7 +182,7 @@ def test_fine_level_parity_mode_on_both_two_level_graphs(graph):
     assert e <= (RTOL['f16'] if k == 'rgb' else 4 * RTOL['f16']), ('coarse', k, e)
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'f16', 'bf16', 'mixed'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'f16', 'bf16', 'mixed', 'f16x3'])
 def test_windows_partially_open(prec):
   """warp_alpha / nerf_alpha mid-schedule: fractional Hann windows on the top bands (model_utils.py:420-436)."""
   cfg = nerf_ds_config(num_warp_embeds=2, num_coarse_samples=16, num_fine_samples=16)
@@ -232,7 +232,7 @@ def test_white_background_and_no_sample_at_infinity(graph, white, infinity):
       assert float(out[sorted(ref)[-1]]['rgb'].max()) <= 1.0 + 1e-5
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'f16x3'])
 def test_mask_ratio_blends_gt_mask(prec):
   cfg = nerf_ds_config(num_warp_embeds=2, num_coarse_samples=8, num_fine_samples=8)
   params = init_params(cfg, 6, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
@@ -248,7 +248,7 @@ def test_mask_ratio_blends_gt_mask(prec):
     assert _relerr(out['fine'][k].cpu().numpy(), ref['fine'][k].numpy()) <= 1e-4, k
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed', 'f16x3'])
 def test_static_graph_config1(prec):
   """BASELINE.json configs[0]: 64 samples/ray, coarse only, warp disabled."""
   cfg = static_config()
@@ -290,7 +290,7 @@ def test_static_graph_two_levels(prec):
     assert np.array_equal(out[lv]['rgb'].cpu().numpy(), base[lv]['rgb'].cpu().numpy()), lv
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed', 'f16x3'])
 @pytest.mark.parametrize('Nc,Nf', [(16, 16), (128, 128)])
 def test_hypernerf_base_gin_graph(prec, Nc, Nf):
   """configs/base.gin graph (BASELINE config 5 per SURVEY 8d): posenc identity, SE3 warp (6 bands), hyper sheet, no mask / normal;
@@ -424,7 +424,7 @@ def test_params_are_repacked_for_a_new_tree_and_tables_are_shape_checked():
     m.apply({'params': bad}, rays, EXTRA, **kw)
 
 
-@pytest.mark.parametrize('prec', ['bf16', 'f16', 'mixed', 'bf16x3', 'f32'])
+@pytest.mark.parametrize('prec', ['bf16', 'f16', 'mixed', 'bf16x3', 'f32', 'f16x3'])
 def test_kernels_are_deterministic_and_ray_order_independent(prec):
   """4096 rays at 64 + 64 samples, rendered twice and once with the rays permuted: bit-identical per ray in every arithmetic
   mode.  Guards the hand-placed synchronisation of the kernel (LDS-DMA ring protocol, asm epilogues whose MFMA -> VALU hazard
@@ -484,7 +484,7 @@ def test_encode_metadata_matches_the_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'f16x3'])
 def test_metadata_encoded_interpolated_embeddings(prec):
   """model.apply(metadata_encoded=True) on vectors interpolated between two GLO rows (the 3-channel metadata of models.py:271-294)
   against the oracle run the same way; with integer progression it reproduces the id path exactly."""
@@ -514,7 +514,7 @@ def test_metadata_encoded_interpolated_embeddings(prec):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'f16x3'])
 def test_render_opts_filter_sigma(prec):
   """render_opts (filter_sigma, models.py:38-66, 1288): dust threshold and bounding box against the oracle; the per-sample 'sigma' stays
   unfiltered (models.py:1271) while alpha / weights see the filter.  FINE level only: NerfModel.__call__ forwards render_opts to the
@@ -557,7 +557,7 @@ def test_render_opts_filter_sigma(prec):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'f16x3'])
 @pytest.mark.parametrize('cfg_inf,call_inf', [(True, False), (False, True), (True, None)])
 def test_use_sample_at_infinity_override_reaches_the_fine_level_only(prec, cfg_inf, call_inf):
   """The use_sample_at_infinity kwarg of NerfModel.__call__ (models.py:1433, 1484-1485) goes to the 'fine' render_samples call (models.py:1544);

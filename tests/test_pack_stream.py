@@ -103,11 +103,13 @@ def test_precision_plans():
   assert set(_plan('bf16x3_fine').values()) == {'bf16x3'} and set(_plan('bf16x3_fine', 1).values()) == {'bf16x3'}
   c = _plan('bf16x3_fine', 0)
   assert (c['trunk'], c['rgb']) == ('f16', 'f16') and (c['mask'], c['warp'], c['hyp']) == ('bf16x3',) * 3
-  for prec in ('bf16', 'bf16x3', 'f32', 'f16', 'mixed'):
+  for prec in ('bf16', 'bf16x3', 'f32', 'f16', 'mixed', 'f16x3'):
     assert _plan(prec, 0) == _plan(prec, 1) == _plan(prec)
+  # 'f16x3' (round 6): the split plan - two units per fragment, three MFMAs per product - whose hi / lo parts are f16: same geometry, other 16-bit format
+  assert set(_plan('f16x3').values()) == {'bf16x3'}
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x3', 'bf16', 'f16', 'mixed', 'f16x3'])
 def test_shared_nets_stream_matches_oracle(prec):
   cfg = nerf_ds_config(num_warp_embeds=3)
   p = init_params(cfg, 3, warp_head_scale=0.05, small_head_scale=0.3, bias_scale=0.1)
@@ -139,7 +141,7 @@ def test_shared_nets_stream_matches_oracle(prec):
   _assert_consumed(s)
 
 
-@pytest.mark.parametrize('prec', ['f32', 'mixed', 'bf16x3_fine'])
+@pytest.mark.parametrize('prec', ['f32', 'mixed', 'bf16x3_fine', 'f16x3'])
 @pytest.mark.parametrize('graph', ['nerf_ds', 'static', 'hypernerf'])
 @pytest.mark.parametrize('level', [0, 1])
 def test_nerf_mlp_stream_matches_oracle(graph, level, prec):

@@ -271,6 +271,39 @@ def test_target_norm_on_the_render_surface():
     assert float((out[level]['rgb'].cpu() - ref[level]['rgb'].reshape(5, 6, 3).float()).abs().max()) <= 1e-4
 
 
+def test_parity_modes_on_a_badly_conditioned_scene():
+  """north_star's 1e-4 beyond the bench's own frame (round 6, tools/parity_sweep.py): scene (seed 15, 309 GLO rows, near 0.3, far 2.0) of BASELINE configs[4]'s seven has a
+  few dozen rays on which the fp32-MFMA kernel itself sits at 8e-5 of the fp64 oracle - split bf16 (16 significand bits per operand) leaves the tolerance there (1.2e-3 on the
+  coarse level), split f16 (22 bits, NERFDS_PREC_F16X3, the same three MFMAs per product) holds it on both levels over every ray of the 800 x 600 frame."""
+  import bench
+  from nerfds_amd.model import NerfModel
+  dev = torch.device('cuda', 0)
+  cfg = nerf_ds_config(near=0.3, far=2.0, num_warp_embeds=309)
+  params = init_params(cfg, 15, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+  R = 480000
+  rays = bench.synth_rays(R, 309, 15, dev)
+  m = NerfModel(cfg, device=dev, precision='f32')
+  rec = {p: {lv: torch.empty((R, 26), device=dev) for lv in ('fine', 'coarse')} for p in ('f32', 'bf16x3', 'f16x3')}
+  for p in rec:
+    for lo in range(0, R, 65536):
+      hi = min(lo + 65536, R)
+      sl = {k: (v[lo:hi] if not isinstance(v, dict) else {'warp': v['warp'][lo:hi]}) for k, v in rays.items()}
+      m.apply({'params': params}, sl, EXTRA, rngs={'coarse': 15, 'fine': 515}, ray_offset=lo, use_predicted_norm=True, precision=p,
+              records_out={lv: rec[p][lv][lo:hi] for lv in ('fine', 'coarse')})
+  torch.cuda.synchronize()
+  err = {}
+  for p in ('bf16x3', 'f16x3'):
+    for lv in ('fine', 'coarse'):
+      ref, got = rec['f32'][lv][:, :3], rec[p][lv][:, :3]
+      assert bool(torch.isfinite(got).all())
+      d = (got - ref).abs().max(dim=1).values / ref.abs().max()
+      err[p, lv] = (float(d.max()), int((d > 1e-4).sum()))
+      print(f'scene 15, {lv}: {p} vs f32 kernel over {R} rays: max {err[p, lv][0]:.3e}, {err[p, lv][1]} rays over 1e-4')
+  assert err['f16x3', 'fine'][0] <= 1e-4 and err['f16x3', 'coarse'][0] <= 1e-4, err
+  # (recorded, not required: this is what split bf16 does on the scene - the reason the mode above exists)
+  assert err['bf16x3', 'coarse'][0] > err['f16x3', 'coarse'][0]
+
+
 def test_full_frame_error_of_the_parity_path():
   """north_star: "within 1e-4 rel on composited RGB".  The split-bf16 kernel against the fp32-MFMA kernel over EVERY ray of the
   800x600 frame the metric is quoted on (the max-over-rays statistic grows with the ray count), trained-regime weights, on-chip
@@ -284,7 +317,7 @@ def test_full_frame_error_of_the_parity_path():
   R = 480000
   rays = bench.synth_rays(R, cfg.num_warp_embeds, 100, dev)
   m = NerfModel(cfg, device=dev, precision='bf16x3')
-  rec = {p: {lv: torch.empty((R, 26), device=dev) for lv in ('fine', 'coarse')} for p in ('f32', 'bf16x3')}
+  rec = {p: {lv: torch.empty((R, 26), device=dev) for lv in ('fine', 'coarse')} for p in ('f32', 'bf16x3', 'f16x3')}
   for p in rec:
     for lo in range(0, R, 65536):
       hi = min(lo + 65536, R)
@@ -292,12 +325,13 @@ def test_full_frame_error_of_the_parity_path():
       m.apply({'params': params}, sl, EXTRA, rngs={'coarse': 7, 'fine': 507}, ray_offset=lo, use_predicted_norm=True, precision=p,
               records_out={lv: rec[p][lv][lo:hi] for lv in ('fine', 'coarse')})
   torch.cuda.synchronize()
-  for lv in ('fine', 'coarse'):
-    ref, got = rec['f32'][lv][:, :3], rec['bf16x3'][lv][:, :3]
-    assert bool(torch.isfinite(got).all())
-    err = float((got - ref).abs().max() / ref.abs().max())
-    print(f'full-frame {lv}: bf16x3 vs f32 kernel over {R} rays: {err:.3e}')
-    assert err <= 1e-4, (lv, err)
+  for p in ('bf16x3', 'f16x3'):
+    for lv in ('fine', 'coarse'):
+      ref, got = rec['f32'][lv][:, :3], rec[p][lv][:, :3]
+      assert bool(torch.isfinite(got).all())
+      err = float((got - ref).abs().max() / ref.abs().max())
+      print(f'full-frame {lv}: {p} vs f32 kernel over {R} rays: {err:.3e}')
+      assert err <= 1e-4, (p, lv, err)
   idx = torch.arange(0, R, R // 2048, device=dev)[:2048]
   sub = {k: (v[idx] if not isinstance(v, dict) else {'warp': v['warp'][idx]}) for k, v in rays.items()}
   rng = np.random.default_rng(0)
@@ -305,7 +339,7 @@ def test_full_frame_error_of_the_parity_path():
   cpu = {k: (v.cpu() if not isinstance(v, dict) else {'warp': v['warp'].cpu()}) for k, v in sub.items()}
   torch.set_num_threads(min(bench.available_cores(), 64))
   ref = O.NerfModel(cfg, params, torch.float32).apply(cpu, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, compute_sigma_gradient=False)
-  for p in ('f32', 'bf16x3'):
+  for p in ('f32', 'bf16x3', 'f16x3'):
     out = m.apply({'params': params}, sub, EXTRA, t_rand=t, u_rand=u, use_predicted_norm=True, precision=p)
     for lv in ('fine', 'coarse'):
       err = float((out[lv]['rgb'].cpu() - ref[lv]['rgb']).abs().max() / ref[lv]['rgb'].abs().max())

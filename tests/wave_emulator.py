@@ -31,6 +31,7 @@ class Stream:
   def next_frag(self, prec=None) -> np.ndarray:
     """Returns A[32 rows][2 halves][8 slots] as float64."""
     prec = prec or self.prec
+    prec = 'bf16x3' if prec == 'f16x3' else prec      # (the plan of 'f16x3' is the split plan: csrc/graphs.h plan_of(6))
     units = 1 if prec in ('bf16', 'f16') else 2
     raw = self.w[self.pos * 1024:(self.pos + units) * 1024]
     self.pos += units
@@ -41,6 +42,9 @@ class Stream:
       v = np.concatenate([p0, p1], axis=1)
     elif prec == 'f16':
       v = raw.view(np.float16).astype(np.float64).reshape(64, 8)
+    elif prec == 'bf16x3' and self.prec == 'f16x3':
+      # NERFDS_PREC_F16X3: the split plan's fragments with f16 hi / lo parts (csrc/pack.h StreamWriter::x3_f16; the kernel: field.h NERFDS_X3_F16)
+      v = raw[:1024].view(np.float16).astype(np.float64).reshape(64, 8) + raw[1024:].view(np.float16).astype(np.float64).reshape(64, 8)
     else:
       def bf(x):
         return (x.view(np.uint16).astype(np.uint32) << 16).view(np.float32).reshape(64, 8)

@@ -1,0 +1,47 @@
+"""GPU: north_star's tolerance beyond ONE frame - the split-bf16 and the split-f16 kernel against the fp32-MFMA kernel (itself within ~4e-6 of the fp64 oracle, tests/test_gpu_parity.py) over
+every ray of an 800 x 600 frame for each of the seven synthetic scenes of BASELINE configs[4] (seed, GLO rows, near, far; bench.py SWEEP_SCENES), on BOTH graphs: the
+configs/nerf_ds.gin graph at 64 + 64 samples and the configs/base.gin HyperNeRF graph at 128 + 128.  One JSON line per (graph, scene); the worst of all at the end.
+  python tools/parity_sweep.py [--rays 480000]"""
+import argparse, json, os, sys
+import numpy as np, torch
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, os.path.join(ROOT, 'nerf-ds_amd')); sys.path.insert(0, ROOT)
+import bench
+from nerfds_amd import nerf_ds_config, hypernerf_config, init_params
+from nerfds_amd.model import NerfModel
+
+ap = argparse.ArgumentParser(); ap.add_argument('--rays', type=int, default=480000); ap.add_argument('--chunk', type=int, default=65536)
+a = ap.parse_args()
+dev = torch.device('cuda', 0)
+worst = {}
+for gname, mk, extra in (('nerf_ds 64+64', lambda n, near, far: nerf_ds_config(num_warp_embeds=n, near=near, far=far), dict(bench.EXTRA)),
+                         ('hypernerf base.gin 128+128', lambda n, near, far: hypernerf_config(num_warp_embeds=n, num_coarse_samples=128, num_fine_samples=128, near=near, far=far), dict(bench.EXTRA, warp_alpha=6.0))):
+  for seed, n_ids, near, far in bench.SWEEP_SCENES:
+    cfg = mk(n_ids, near, far)
+    params = init_params(cfg, seed, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
+    rays = bench.synth_rays(a.rays, n_ids, seed, dev)
+    m = NerfModel(cfg, device=dev, precision='f32')
+    out = {}
+    for prec in ('f32', 'bf16x3', 'f16x3'):
+      f, c = torch.empty((a.rays, 26), device=dev), torch.empty((a.rays, 26), device=dev)
+      for lo in range(0, a.rays, a.chunk):
+        hi = min(lo + a.chunk, a.rays)
+        cr = {k: (v[lo:hi] if not isinstance(v, dict) else {kk: vv[lo:hi] for kk, vv in v.items()}) for k, v in rays.items()}
+        m.apply({'params': params}, cr, extra, rngs={'coarse': seed, 'fine': seed + 500}, ray_offset=lo, use_predicted_norm=cfg.predict_norm, precision=prec,
+                records_out={'fine': f[lo:hi], 'coarse': c[lo:hi]})
+      torch.cuda.synchronize()
+      out[prec] = (f, c)
+    row = {'graph': gname, 'seed': seed, 'glo_rows': n_ids, 'near': near, 'far': far, 'rays': a.rays}
+    for p in ('bf16x3', 'f16x3'):
+      for lv, i in (('fine', 0), ('coarse', 1)):
+        g, r = out[p][i][:, :3], out['f32'][i][:, :3]
+        d = (g - r).abs()
+        row[f'{p}_{lv}_rgb_max_rel_err'] = float(d.max() / r.abs().max())
+        row[f'{p}_{lv}_rays_over_1e-4'] = int(((d.max(dim=1).values / r.abs().max()) > 1e-4).sum())
+        row[f'{p}_{lv}_finite'] = bool(torch.isfinite(g).all())
+    print(json.dumps(row), flush=True)
+    for k, v in row.items():
+      if k.endswith('rel_err'):
+        worst[k] = max(worst.get(k, 0.0), v)
+    del m, out
+print(json.dumps({'worst': worst, 'tolerance': 1e-4, 'meets_tolerance': {p: all(v <= 1e-4 for k, v in worst.items() if k.startswith(p)) for p in ('bf16x3', 'f16x3')}}))
