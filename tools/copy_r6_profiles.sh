@@ -1,7 +1,7 @@
 #!/bin/bash
 # authoring container, after tools/r6_final.sh came back: the summaries of gpurun_out/ that are committed under profiles/r6_*
 cd "$(dirname "$0")/.."
-for k in bf16 bf16x3; do
+for k in bf16 bf16x3 f16x3; do
   P=gpurun_out/profile_r6_$k
   cp $P/summary.txt profiles/r6_${k}_rocprof_summary.txt
   cp $P/hbm_traffic.json profiles/r6_${k}_hbm_traffic.json
@@ -20,5 +20,6 @@ PY
 cp gpurun_out/timeline_r6.txt profiles/r6_train_timeline.txt
 cp gpurun_out/prof_r6_objective/summary.txt profiles/r6_train_full_objective_rocprof_summary.txt
 cp gpurun_out/objective_timeline_r6.txt profiles/r6_train_full_objective_timeline.txt
+cp gpurun_out/r6_final/parity_sweep.jsonl profiles/r6_parity_sweep.jsonl
 mkdir -p profiles/r6_bench_lines; cp gpurun_out/final_r6/*.json profiles/r6_bench_lines/; cp gpurun_out/r6_final/objective_time.txt profiles/r6_bench_lines/
 ls profiles | grep r6_

@@ -8,6 +8,7 @@ python bench.py --strong --no-cpu-baseline > $OUT/bench_config3_strong_n1.json 2
 python bench.py --sweep --steps 3 > $OUT/bench_config5_sweep.json 2>/dev/null
 python bench.py --samples 128 --steps 5 --warmup 2 --no-other-paths --no-cpu-baseline > $OUT/bench_nerfds_256samples.json 2>/dev/null
 python bench.py --precision bf16x3_fine --no-other-paths --no-cpu-baseline > $OUT/bench_bf16x3_fine.json 2>/dev/null
+python bench.py --precision f16x3 --no-other-paths --no-cpu-baseline > $OUT/bench_f16x3.json 2>/dev/null
 python bench.py --train > $OUT/bench_config4_train.json 2>/dev/null
 NERFDS_TRAIN_FUSED_BWD=0 python bench.py --train --no-cpu-baseline > $OUT/bench_config4_train_layerwise_backward.json 2>/dev/null
 for f in $OUT/*.json; do echo "== $f"; tail -1 $f | cut -c1-300; done

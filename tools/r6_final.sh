@@ -10,7 +10,8 @@ timeout 1800 bash tools/final_bench.sh r6 > $O/final_bench.log 2>&1
 bash tools/prof_bench.sh r6_bf16 > /dev/null 2>&1
 bash tools/prof_bench.sh r6_bf16x3 --precision bf16x3 > /dev/null 2>&1
 bash tools/prof_bench.sh r6_bf16x3_fine --precision bf16x3_fine > /dev/null 2>&1
-for k in bf16 bf16x3; do
+bash tools/prof_bench.sh r6_f16x3 --precision f16x3 > /dev/null 2>&1
+for k in bf16 bf16x3 f16x3; do
   P=gpurun_out/profile_r6_$k
   python tools/traffic_from_summary.py $P/summary.txt "render_rays_kernel<GraphNerfDS, $k>" profiles/r6_${k}_rocprof_summary.txt "round 6 (final build)" > $P/hbm_traffic.json
 done
@@ -20,6 +21,7 @@ timeout 1000 bash tools/train_timeline.sh r6 > /dev/null 2>&1
 TAG=prof_r6_objective timeout 1000 bash tools/prof_objective.sh > /dev/null 2>&1
 timeout 1000 bash tools/objective_timeline.sh r6 > /dev/null 2>&1
 python tools/objective_time.py > $O/objective_time.txt 2>&1
+python tools/parity_sweep.py > $O/parity_sweep.jsonl 2>/dev/null
 # the shape the reference trains at (configs/nerf_ds.gin:4 batch_size = 512)
 python bench.py --train --train-rays 512 --no-cpu-baseline > gpurun_out/final_r6/bench_train_reference_batch_512.json 2>/dev/null
 cat $O/gputests.log $O/smoke.log $O/objective_time.txt; tail -20 $O/final_bench.log | cut -c1-330
