@@ -11,6 +11,6 @@ probe() {  # label, command...
 }
 ( for prec in bf16 bf16x3 f16x3 bf16x3_fine; do probe $prec python bench.py --steps 400 --warmup 2 --no-cpu-baseline --no-other-paths --precision $prec; done
   probe train_4096 python bench.py --train --steps 3000 --warmup 2 --no-cpu-baseline --no-full-objective --no-option-legs
-  probe train_512 python bench.py --train --train-rays 512 --steps 12000 --warmup 2 --no-cpu-baseline --no-full-objective --no-option-legs
+  probe train_512 python bench.py --train --train-rays 512 --steps 40000 --warmup 2 --no-cpu-baseline --no-full-objective --no-option-legs
   echo "== idle"; sleep 3; rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk"; rocm-smi --showmaxpower 2>/dev/null | grep -i power ) > gpurun_out/power_probe_r6.log 2>&1
 grep -E "==|Power|sclk" gpurun_out/power_probe_r6.log | paste - - - | cut -c1-230 | head -40
