@@ -1997,6 +1997,12 @@ long long nerfds_trainer_debug_read(nerfds_trainer* t, const char* name, void* h
   else if (n == "dwamb") { p = t->dwamb; cap = M * 2 * 4; }
   else if (n == "dwv") { p = t->dwv; cap = M * 6 * 4; }
   else if (n == "d_mask_logit") { p = t->d_mask_logit; cap = M * 4; }
+  else if (n == "wv") { p = t->wv; cap = M * 6 * 4; }                    // forward state per POSITION row (merged step: [coarse | new samples])
+  else if (n == "wamb") { p = t->wamb; cap = M * 2 * 4; }
+  else if (n == "xw") { p = t->xw; cap = M * 3 * 4; }
+  else if (n == "mask_logit") { p = t->mask_logit; cap = M * 4; }
+  else if (n == "sigma") { p = t->sigma; cap = M * 4; }
+  else if (n == "rgb_logit") { p = t->rgb_logit; cap = M * 3 * 4; }
   if (!p) return t->fail(NERFDS_EINVAL, "debug_read: no buffer named %s", name);
   if (half_only && !t->half_step)
     return t->fail(NERFDS_EINVAL, "debug_read: %s is written by a half step only (the last step kept fp32 activations: tangent pass or NERFDS_TRAIN_FUSED_*=0)", name);
@@ -2256,7 +2262,6 @@ static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* ta
       std::fill(t->pack_fresh.begin(), t->pack_fresh.end(), t->pack_epoch);
     }
   }
-  if (t->fused_fwd) pack_fused_forward(*t, st);
   (void)hipMemsetAsync(t->loss_dev, 0, 2 * sizeof(float), st);
   const int strat = ex->use_stratified_sampling;
   coarse_z(st, R, Nc, ex->near, ex->far, strat, ex->use_linear_disparity, rnd ? rnd->t_rand : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->first_ray : 0, t->zc);
@@ -2292,6 +2297,7 @@ static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* ta
   // (NERFDS_TRAIN_HALF_TANGENTS=0: fp32 activations and the layer-by-layer backward for those steps, as through round 4's first half)
   static const bool half_tangents = !(getenv("NERFDS_TRAIN_HALF_TANGENTS") && std::string(getenv("NERFDS_TRAIN_HALF_TANGENTS")) == "0");
   t->half_step = t->fused_fwd && t->fused_bwd && (!want_sg || half_tangents) && !t->fp32_step;
+  if (t->fused_fwd) pack_fused_forward(*t, st);
   if (t->half_step) pack_fused_backward(*t, st);
   t->tan_x_scale = std::ldexp(1.f, -6 + t->tan_scale_adjust);
   t->last_R = R; t->last_tan_rows = 0; t->last_half = t->half_step;
