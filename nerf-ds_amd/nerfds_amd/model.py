@@ -140,7 +140,7 @@ def _seed_from_rngs(rngs) -> int:
 class NerfModel:
   """Drop-in for the reference's ``NerfModel`` on one MI355X: functional ``apply``, parameters passed in."""
 
-  def __init__(self, cfg: NerfModelConfig, device: Optional[torch.device] = None, precision: str = 'bf16'):
+  def __init__(self, cfg: NerfModelConfig, device: Optional[torch.device] = None, precision: str = 'f16x3'):
     cfg.validate()
     self.cfg = cfg
     self.precision = precision
@@ -448,7 +448,7 @@ def sharpen_weights(weights: torch.Tensor, z_vals: torch.Tensor, std: float) -> 
 
 def construct_nerf(key, batch_size: int = 0, embeddings_dict=None, near: float = 0.0, far: float = 1.0,
                    cfg: Optional[NerfModelConfig] = None, use_predicted_norm: Optional[bool] = None,
-                   use_sigma_gradient: bool = False, device=None, precision: str = 'bf16', **init_kw):
+                   use_sigma_gradient: bool = False, device=None, precision: str = 'f16x3', **init_kw):
   """models.construct_nerf (models.py:2677-2741): returns ``(model, params)``.
 
   ``key`` is an integer seed (JAX PRNG keys have no meaning here); ``embeddings_dict`` as in the reference
