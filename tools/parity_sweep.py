@@ -1,7 +1,7 @@
 """GPU: north_star's tolerance beyond ONE frame - the split-bf16 and the split-f16 kernel against the fp32-MFMA kernel (itself within ~4e-6 of the fp64 oracle, tests/test_gpu_parity.py) over
 every ray of an 800 x 600 frame for each of the seven synthetic scenes of BASELINE configs[4] (seed, GLO rows, near, far; bench.py SWEEP_SCENES), on BOTH graphs: the
 configs/nerf_ds.gin graph at 64 + 64 samples and the configs/base.gin HyperNeRF graph at 128 + 128.  One JSON line per (graph, scene); the worst of all at the end.
-  python tools/parity_sweep.py [--rays 480000]"""
+  python tools/parity_sweep.py [--rays 480000] [--extra-seeds 24]"""
 import argparse, json, os, sys
 import numpy as np, torch
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
@@ -11,12 +11,16 @@ from nerfds_amd import nerf_ds_config, hypernerf_config, init_params
 from nerfds_amd.model import NerfModel
 
 ap = argparse.ArgumentParser(); ap.add_argument('--rays', type=int, default=480000); ap.add_argument('--chunk', type=int, default=65536)
+ap.add_argument('--extra-seeds', type=int, default=0, help='instead of the seven sweep scenes: this many further random-init scenes (seeds 1000..) of the nerf_ds graph only')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 worst = {}
 for gname, mk, extra in (('nerf_ds 64+64', lambda n, near, far: nerf_ds_config(num_warp_embeds=n, near=near, far=far), dict(bench.EXTRA)),
                          ('hypernerf base.gin 128+128', lambda n, near, far: hypernerf_config(num_warp_embeds=n, num_coarse_samples=128, num_fine_samples=128, near=near, far=far), dict(bench.EXTRA, warp_alpha=6.0))):
-  for seed, n_ids, near, far in bench.SWEEP_SCENES:
+  if a.extra_seeds and not gname.startswith('nerf_ds'):
+    continue
+  scenes = bench.SWEEP_SCENES if not a.extra_seeds else [(1000 + i, (64, 128, 256, 512)[i % 4], (0.1, 0.3, 0.5)[i % 3], (1.7, 2.5, 4.0)[(i // 3) % 3]) for i in range(a.extra_seeds)]
+  for seed, n_ids, near, far in scenes:
     cfg = mk(n_ids, near, far)
     params = init_params(cfg, seed, warp_head_scale=5e-2, small_head_scale=0.3, bias_scale=0.1)
     rays = bench.synth_rays(a.rays, n_ids, seed, dev)
