@@ -123,6 +123,7 @@ struct nerfds_trainer {
   static constexpr int SIDE = 6;     // at most; nside = the streams in use (NERFDS_TRAIN_SIDE_STREAMS, default 3; 0 = none)
   int nside = 0;
   int nside_eff = 0;                 // the side streams THIS step uses (a small batch: one - step_impl)
+  int wgrad_cu_cap = 0;              // CUs the side streams' persistent weight-gradient workgroups may take THIS step (0: all - step_impl)
   hipStream_t side[SIDE] = {};
   hipEvent_t fork_ev = nullptr, join_ev[SIDE] = {};
   // Fragment packs of the layers (train_gemm.h): the first step packs each (weight block, orientation, split) when it is first used and
@@ -366,13 +367,16 @@ struct Run {
       if (dy_half) { A.out_scale = 1.f; A.out_scale_dev = tan_slot + 3; if (!x_half) A.x_scale = t.tan_x_scale; }
       else A.out_scale = x_half ? 1.f / t.tan_x_scale : 1.f;                                      // a head: fp32 cotangent, f16 tangent
     }
-    if (!(wgrad_supported(A) && wgrad(wgrad_stream(), A, wgrad_grid(A, t.num_cus)))) unsupported("weight gradient", K, N, M);
+    if (!(wgrad_supported(A) && wgrad(wgrad_stream(), A, wgrad_grid(A, wgrad_cus())))) unsupported("weight gradient", K, N, M);
   }
   // fork(): the side streams wait for everything issued to st so far, and the weight-gradient launches that follow rotate over
   // st and the side streams; join(): st waits for the side streams.  Without side streams both are no-ops.
   int wg_turn = -1;
   bool wg_main = true;     // the caller's stream takes a turn too (false while it still has chains to launch)
   int ns = 0, ns_join = 0; // side streams in the rotation since the last fork / touched since the last join
+  // CUs a weight-gradient launch on a SIDE stream may take: its workgroups are persistent, one per CU, and fill the CU's registers (k_wgrad_tr<8, 8>: two
+  // 236-register waves per SIMD), so a kernel of the caller's stream - the step's critical path - waits for one of them to END (step_impl: wgrad_cu_cap)
+  int wgrad_cus() const { return (wg_turn >= 0 && t.wgrad_cu_cap > 0 && t.wgrad_cu_cap < t.num_cus) ? t.wgrad_cu_cap : t.num_cus; }
   hipStream_t wgrad_stream() {
     if (wg_turn < 0) return st;
     const int k = wg_turn++ % (ns + (wg_main ? 1 : 0));
@@ -411,7 +415,7 @@ struct Run {
         A.mx[l - 1] = h16[l - 1]; A.mdy[l - 1] = g[l]; A.mdw[l - 1] = rep(t.grad + m.hidden[l].w); A.mcs[l - 1] = tan ? nullptr : rep(t.grad + m.hidden[l].b);
       }
       if (wgrad_supported(A) && wgrad_multi_supported(A)) {
-        if (!wgrad(wgrad_stream(), A, wgrad_grid(A, t.num_cus))) unsupported("weight gradient (layers batched)", m.width, m.width, M);
+        if (!wgrad(wgrad_stream(), A, wgrad_grid(A, wgrad_cus()))) unsupported("weight gradient (layers batched)", m.width, m.width, M);
         batched = true;
       }
     }
@@ -2301,10 +2305,19 @@ static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* ta
   if (t->half_step) pack_fused_backward(*t, st);
   t->tan_x_scale = std::ldexp(1.f, -6 + t->tan_scale_adjust);
   t->last_R = R; t->last_tan_rows = 0; t->last_half = t->half_step;
-  {   // A small batch's weight-gradient launches are short, and three side streams of them keep the CUs from the (dependent) kernels of the caller's
-      // stream - the step's critical path: ONE side stream up to NERFDS_TRAIN_SIDE_SMALL rays (default 768: at 512 rays one stream is 4 % faster, from 1024 rays on three are)
-    static const int small_rays = [] { const char* e = getenv("NERFDS_TRAIN_SIDE_SMALL"); return e ? atoi(e) : 768; }();
+  {   // Launch decisions of the side streams (A/Bs on one box each, interleaved: profiles/r6_ab/README.md).  The weight-gradient launches are
+      // persistent - one workgroup per CU, registers for nothing beside it - so a kernel of the CALLER's stream, the step's critical path, that arrives
+      // while they run waits for one of them to END (k_se3_fwd: 12 us alone, 273 us in the 4096-ray step).  Up to NERFDS_TRAIN_WGRAD_CAP_RAYS rays
+      // (default 3072), and in every step with second-order terms, they take HALF of the CUs and the other half stays free for the caller's stream:
+      // 128 rays 2.03 -> 1.79 ms, 256: 2.17 -> 1.98, 512: 2.55 -> 2.40, 1024: 3.70 -> 3.59, 3072: 8.61 -> 8.58, nerf_ds.gin objective -2 ... -12 %; the
+      // rgb-only 4096-ray step needs the whole machine for them (11.23 -> 11.42 ms capped: not capped).  NERFDS_TRAIN_WGRAD_CUS=<n> forces a cap (0: none).
+      // Streams: under the cap THREE side streams pay from 512 rays on (2.46 -> 2.40 ms; uncapped, one was 4 % faster there), ONE up to
+      // NERFDS_TRAIN_SIDE_SMALL rays (default 384: 256 rays 1.98 against 2.05 ms).
+    static const int small_rays = [] { const char* e = getenv("NERFDS_TRAIN_SIDE_SMALL"); return e ? atoi(e) : 384; }();
+    static const int cap_rays = [] { const char* e = getenv("NERFDS_TRAIN_WGRAD_CAP_RAYS"); return e ? atoi(e) : 3072; }();
+    static const int cap_env = [] { const char* e = getenv("NERFDS_TRAIN_WGRAD_CUS"); return e ? atoi(e) : -1; }();
     t->nside_eff = (R <= small_rays && t->nside > 1) ? 1 : t->nside;
+    t->wgrad_cu_cap = cap_env >= 0 ? cap_env : ((R <= cap_rays || want_sg) ? t->num_cus / 2 : 0);
   }
   {
     int e = 6;
