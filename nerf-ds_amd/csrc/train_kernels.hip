@@ -1560,6 +1560,11 @@ __global__ void k_fold_rgb(const float* __restrict__ B, const float* __restrict_
   const int r = i / W, c = i % W;
   double acc = r < TW ? (double)K[(size_t)(row_x + r) * W + c] : (double)Kb[c];
   const float* left = r < TW ? B + (size_t)r * TW : Bb;
+  // (one accumulator, the order of the host packer; unrolled so that the loads of 16 steps are in flight together - as a rolled loop of dependent
+  // L2 round trips the launch took 61 us, at the head of every step's critical path)
+#ifndef NERFDS_EXP_FOLD_ROLLED      // (measurement build: the loop as it was)
+#pragma unroll 16
+#endif
   for (int k = 0; k < TW; ++k) acc += (double)left[k] * (double)K[(size_t)k * W + c];
   fold[i] = (float)acc;
 }
@@ -1600,7 +1605,8 @@ __global__ void k_bott_dbb(int TW, int W, const float* __restrict__ K, const flo
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= TW) return;
   double acc = 0.0;
-  for (int n = 0; n < W; ++n) acc += (double)K[(size_t)k * W + n] * (double)c[n];
+#pragma unroll 16
+  for (int n = 0; n < W; ++n) acc += (double)K[(size_t)k * W + n] * (double)c[n];      // (loads of 16 steps in flight: k_fold_rgb)
   dbb[k] = (float)acc;
 }
 void bott_grads(hipStream_t st, int TW, int W, const float* Wb, const float* bb, const float* K, const float* S, const float* c, float* dKb,
