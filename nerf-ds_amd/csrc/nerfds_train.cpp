@@ -775,8 +775,8 @@ bool build_fused_forward(nerfds_trainer& t) {
   return true;
 }
 
-// every step: fold, then the three streams and their biases from the current theta
-void pack_fused_forward(nerfds_trainer& t, hipStream_t st) {
+// every step: fold (launched), then the three streams and their biases from the current theta (collected in pb: ONE launch for the step's whole packing, step_impl)
+void pack_fused_forward(nerfds_trainer& t, hipStream_t st, PackBatch& pb) {
   using G = nerfds::GraphNerfDS;
   using Dm = nerfds::Dims<G>;
   constexpr int TW = G::TRUNK_W, RW = G::RGB_W, FL = (TW + 1) * RW;
@@ -785,9 +785,9 @@ void pack_fused_forward(nerfds_trainer& t, hipStream_t st) {
     fold_rgb(st, t.theta + t.bott[lv].w, t.theta + t.bott[lv].b, t.theta + t.rgb_h[lv].w, t.theta + t.rgb_h[lv].b, TW, RW, TW + Dm::VD_FEATS,
              t.fold + (size_t)lv * FL);
   for (int which = 0; which < 1 + levels; ++which) {
-    pack_stream(st, t.theta, t.fold, t.P, t.fmap[which], t.fstream[which], t.fstream_frags[which], which == 0 ? t.f32_lo : 0, which == 0 ? t.f32_hi : 0,
-                nerfds::TRAIN_PLAN.warp == nerfds::P_F32 ? 1 : 0);
-    pack_bias(st, t.theta, t.fold, t.P, t.fbmap[which], t.fbias[which], t.fbias_n[which]);
+    pb.stream(t.fmap[which], t.fstream[which], t.fstream_frags[which], which == 0 ? t.f32_lo : 0, which == 0 ? t.f32_hi : 0,
+              nerfds::TRAIN_PLAN.warp == nerfds::P_F32 ? 1 : 0);
+    pb.bias(t.fbmap[which], t.fbias[which], t.fbias_n[which]);
   }
 }
 
@@ -967,11 +967,11 @@ bool build_fused_backward(nerfds_trainer& t) {
   return true;
 }
 
-void pack_fused_backward(nerfds_trainer& t, hipStream_t st) {
+void pack_fused_backward(nerfds_trainer& t, PackBatch& pb) {
   const bool f16_on = getenv("NERFDS_TRAIN_BWD_F16") && std::string(getenv("NERFDS_TRAIN_BWD_F16")) == "1" && t.chain_arith == 0;
   t.bwd_f16 = false;
   for (int which = 0; which < 5; ++which)
-    if (t.bmap[which]) pack_stream(st, t.theta, t.fold, t.P, t.bmap[which], t.bstream[which], t.bfrags[which], 0, 0);
+    if (t.bmap[which]) pb.stream(t.bmap[which], t.bstream[which], t.bfrags[which]);
   if (f16_on && t.g16) {
     for (int which = 0; which < 5; ++which) {
       if (!t.bmap[which]) continue;
@@ -979,7 +979,7 @@ void pack_fused_backward(nerfds_trainer& t, hipStream_t st) {
         const size_t bytes = (size_t)nerfds::pad_units(t.bfrags[which]) * 1024;
         if (hipMalloc(&t.pstream16[which], bytes) != hipSuccess || hipMemset(t.pstream16[which], 0, bytes) != hipSuccess) return;
       }
-      pack_stream(st, t.theta, t.fold, t.P, t.bmap[which], t.pstream16[which], t.bfrags[which], 0, 0, 2);
+      pb.stream(t.bmap[which], t.pstream16[which], t.bfrags[which], 0, 0, 2);
     }
     t.bwd_f16 = true;
   }
@@ -987,19 +987,21 @@ void pack_fused_backward(nerfds_trainer& t, hipStream_t st) {
 
 // the streams of the tangent pass from the current parameters (steps that run tangents only)
 void pack_fused_tangents(nerfds_trainer& t, hipStream_t st) {
+  PackBatch pb;
   for (int which = 0; which < 4; ++which)
-    if (t.tmap[which]) pack_stream(st, t.theta, t.fold, t.P, t.tmap[which], t.tstream[which], t.tfrags[which], 0, 0);
+    if (t.tmap[which]) pb.stream(t.tmap[which], t.tstream[which], t.tfrags[which]);
   for (int lv = 0; lv < 2; ++lv)
-    if (t.amap[lv]) pack_stream(st, t.theta, t.fold, t.P, t.amap[lv], t.astream[lv], t.afrags[lv], 0, 0);
+    if (t.amap[lv]) pb.stream(t.amap[lv], t.astream[lv], t.afrags[lv]);
   if (t.use_tan_fwd_f16() || t.use_rev_fwd_f16())
     for (int lv = 0; lv < 2; ++lv)
-      if (t.tstream16[lv]) pack_stream(st, t.theta, t.fold, t.P, t.tmap[lv], t.tstream16[lv], t.tfrags[lv], 0, 0, 2);
+      if (t.tstream16[lv]) pb.stream(t.tmap[lv], t.tstream16[lv], t.tfrags[lv], 0, 0, 2);
   if (t.use_tan_bwd_f16()) {      // the same maps, one f16 unit per fragment (k_pack_stream mode 2)
     for (int lv = 0; lv < 2; ++lv)
-      if (t.amap[lv]) pack_stream(st, t.theta, t.fold, t.P, t.amap[lv], t.bstream16[lv], t.afrags[lv], 0, 0, 2);
-    pack_stream(st, t.theta, t.fold, t.P, t.bmap[2], t.bstream16[2], t.bfrags[2], 0, 0, 2);
-    pack_stream(st, t.theta, t.fold, t.P, t.bmap[3], t.bstream16[3], t.bfrags[3], 0, 0, 2);
+      if (t.amap[lv]) pb.stream(t.amap[lv], t.bstream16[lv], t.afrags[lv], 0, 0, 2);
+    pb.stream(t.bmap[2], t.bstream16[2], t.bfrags[2], 0, 0, 2);
+    pb.stream(t.bmap[3], t.bstream16[3], t.bfrags[3], 0, 0, 2);
   }
+  pack_batch(st, t.theta, t.fold, t.P, pb);
 }
 // f16 [3 M][width] per hidden layer of warp field, hyper sheet, trunk: the tangents (ensure_tan16: `all` = one array per layer - a step that
 // differentiates the tangent pass reads them as X of its weight gradients; otherwise ONE array per network that every layer overwrites: the
@@ -2301,8 +2303,12 @@ static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* ta
   // (NERFDS_TRAIN_HALF_TANGENTS=0: fp32 activations and the layer-by-layer backward for those steps, as through round 4's first half)
   static const bool half_tangents = !(getenv("NERFDS_TRAIN_HALF_TANGENTS") && std::string(getenv("NERFDS_TRAIN_HALF_TANGENTS")) == "0");
   t->half_step = t->fused_fwd && t->fused_bwd && (!want_sg || half_tangents) && !t->fp32_step;
-  if (t->fused_fwd) pack_fused_forward(*t, st);
-  if (t->half_step) pack_fused_backward(*t, st);
+  {
+    PackBatch pb;
+    if (t->fused_fwd) pack_fused_forward(*t, st, pb);
+    if (t->half_step) pack_fused_backward(*t, pb);
+    pack_batch(st, t->theta, t->fold, t->P, pb);
+  }
   t->tan_x_scale = std::ldexp(1.f, -6 + t->tan_scale_adjust);
   t->last_R = R; t->last_tan_rows = 0; t->last_half = t->half_step;
   {   // Launch decisions of the side streams (A/Bs on one box each, interleaved: profiles/r6_ab/README.md).  The weight-gradient launches are

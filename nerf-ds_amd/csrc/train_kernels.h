@@ -95,8 +95,19 @@ void adam(hipStream_t, float* p, const float* g, float* m1, float* m2, long long
           float* corr_dev, unsigned* nonfinite_flag);      // flag != 0 after the gradient check: nothing is updated
 // fused forward: weight streams / biases / folded rgb layer from the current parameters (see train_kernels.hip)
 // map: two units (2 KiB) per fragment; stream: split bf16 (two units), fragments [x6_lo, x6_hi) exact fp32 (wide_f32) or three units (hi | mid | lo)
-void pack_stream(hipStream_t, const float* theta, const float* fold, long long P, const int* map, void* stream, int nfrag, int x6_lo, int x6_hi, int wide_f32 = 0);
-void pack_bias(hipStream_t, const float* theta, const float* fold, long long P, const int* map, float* out, int n);
+// The step's packing as ONE launch: streams (n = fragments; mode = k_pack_batch's wide_f32: 0 split bf16 with the three-way range [x6_lo, x6_hi), 1 that range exact
+// fp32, 2 one f16 unit per fragment) and bias vectors (mode 3, n values) collected by the host, every item gathered from the same theta / fold
+struct PackItem { const int* map; void* out; int n, x6_lo, x6_hi, mode; };
+struct PackBatch {
+  static constexpr int MAX = 28;
+  PackItem it[MAX];
+  int n = 0;
+  bool overflow = false;      // more than MAX items: a programming error, pack_batch aborts on it
+  bool stream(const int* map, void* out, int nfrag, int x6_lo = 0, int x6_hi = 0, int wide_f32 = 0) { return add(PackItem{map, out, nfrag, x6_lo, x6_hi, wide_f32}); }
+  bool bias(const int* map, float* out, int count) { return add(PackItem{map, out, count, 0, 0, 3}); }
+  bool add(const PackItem& i) { if (n >= MAX) { overflow = true; return false; } it[n++] = i; return true; }
+};
+void pack_batch(hipStream_t, const float* theta, const float* fold, long long P, const PackBatch&);
 void fold_rgb(hipStream_t, const float* B, const float* Bb, const float* K, const float* Kb, int TW, int W, int row_x, float* fold);
 // gradients of the activation-free bottleneck Dense from S = trunk_out^T g_rgb [TW x W] and c = colsum(g_rgb) [W] (fused backward):
 //   dKb[TW x W] = Wb^T S + bb (x) c,  dWb[TW x TW] = S Kb^T,  dbb[TW] = Kb c;  Wb [TW x TW], Kb = the first TW rows of K [.. x W]

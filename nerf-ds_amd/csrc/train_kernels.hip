@@ -1499,9 +1499,8 @@ __device__ __forceinline__ unsigned short bf16_rne(float f) {      // pack.h f32
 // One thread per (fragment, lane): 8 k-slots of one output row.  The map is in the two-unit layout (2 KiB per fragment); the stream
 // holds split bf16 - hi | lo units - except the fragments [x6_lo, x6_hi) (the warp field's forward): exact fp32 (wide_f32), or split three
 // ways (hi | mid | lo units, graphs.h P_BF16X6) - then every fragment behind x6_lo starts one unit later per three-way fragment before it.
-__global__ void k_pack_stream(const float* __restrict__ theta, const float* __restrict__ fold, long long P, const int* __restrict__ map,
-                              unsigned char* __restrict__ stream, int nfrag, int x6_lo, int x6_hi, int wide_f32) {
-  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_stream_item(const float* __restrict__ theta, const float* __restrict__ fold, long long P, const int* __restrict__ map,
+                                                 unsigned char* __restrict__ stream, int nfrag, int x6_lo, int x6_hi, int wide_f32, long long tid) {
   if (tid >= (long long)nfrag * 64) return;
   const int frag = (int)(tid >> 6), lane = (int)(tid & 63);
   const int4 ma = *reinterpret_cast<const int4*>(map + (size_t)frag * 512 + lane * 4);
@@ -1547,9 +1546,16 @@ __global__ void k_pack_stream(const float* __restrict__ theta, const float* __re
   *reinterpret_cast<uint4*>(fa + 1024) = make_uint4(mid[0], mid[1], mid[2], mid[3]);          // two-way: this is the "lo" unit
   if (x6) *reinterpret_cast<uint4*>(fa + 2048) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
-__global__ void k_pack_bias(const float* __restrict__ theta, const float* __restrict__ fold, long long P, const int* __restrict__ map, float* __restrict__ out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = map_value(theta, fold, P, map[i]);
+// Every stream (and bias vector) of a step's packing in ONE launch: blockIdx.y picks the item (train_kernels.h PackBatch; at 512 rays the ~20 separate
+// five-microsecond launches were 4 % of the step).  mode 0 / 1 / 2: pack_stream_item's wide_f32; 3: a bias vector of n values.
+__global__ void k_pack_batch(const float* __restrict__ theta, const float* __restrict__ fold, long long P, const PackBatch B) {
+  const PackItem I = B.it[blockIdx.y];
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (I.mode == 3) {
+    if (tid < I.n) static_cast<float*>(I.out)[tid] = map_value(theta, fold, P, I.map[tid]);
+    return;
+  }
+  pack_stream_item(theta, fold, P, I.map, static_cast<unsigned char*>(I.out), I.n, I.x6_lo, I.x6_hi, I.mode, tid);
 }
 // The activation-free bottleneck Dense folded into rgb hidden_0 (pack.h pack_nerf; modules.py:255, 296-310), in double like the host packer:
 //   fold[r][c] = K[row_x + r][c] + sum_k B[r][k] K[k][c]   (r < TW),   fold[TW][c] = Kb[c] + sum_k Bb[k] K[k][c]
@@ -1618,11 +1624,13 @@ void bott_grads(hipStream_t st, int TW, int W, const float* Wb, const float* bb,
                      static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), dWb);
   LAUNCH(k_bott_dbb, TW, st, TW, W, K, c, dbb);
 }
-void pack_stream(hipStream_t st, const float* theta, const float* fold, long long P, const int* map, void* stream, int nfrag, int x6_lo, int x6_hi, int wide_f32) {
-  LAUNCH(k_pack_stream, (long long)nfrag * 64, st, theta, fold, P, map, static_cast<unsigned char*>(stream), nfrag, x6_lo, x6_hi, wide_f32);
-}
-void pack_bias(hipStream_t st, const float* theta, const float* fold, long long P, const int* map, float* out, int n) {
-  LAUNCH(k_pack_bias, n, st, theta, fold, P, map, out, n);
+void pack_batch(hipStream_t st, const float* theta, const float* fold, long long P, const PackBatch& B) {
+  if (B.overflow) { fprintf(stderr, "nerfds_train::pack_batch: more than %d items in one batch\n", PackBatch::MAX); abort(); }
+  if (B.n <= 0) return;
+  long long most = 0;
+  for (int i = 0; i < B.n; ++i) { const long long th = B.it[i].mode == 3 ? B.it[i].n : (long long)B.it[i].n * 64; most = th > most ? th : most; }
+  if (most <= 0) return;
+  hipLaunchKernelGGL(k_pack_batch, dim3((unsigned)((most + 255) / 256), (unsigned)B.n), dim3(256), 0, st, theta, fold, P, B);
 }
 void fold_rgb(hipStream_t st, const float* B, const float* Bb, const float* K, const float* Kb, int TW, int W, int row_x, float* fold) {
   LAUNCH(k_fold_rgb, (long long)(TW + 1) * W, st, B, Bb, K, Kb, TW, W, row_x, fold);
