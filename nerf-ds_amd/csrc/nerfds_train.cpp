@@ -2391,16 +2391,15 @@ static int step_impl(nerfds_trainer* t, const nerfds_rays* rays, const float* ta
     // gradient of rgb hidden_0's trunk_out rows, just summed) and c = the bias gradient of rgb hidden_0:
     //   d K[bottleneck rows] = Wb^T S + bb (x) c,   d Wb = S K_b^T,   d bb = K_b c      (exact: bott = trunk_out Wb + bb)
     const int TW = t->trunk[0].width, VD = 6 * t->D.vd_bands;
-    // (three latency-bound launches per level on leaves of that level only: the fine level's on a side stream, beside the coarse level's - 75 us of a step's
-    // serial tail, 3 % of a 512-ray step)
-    const bool par = Nf > 0 && t->side[0] != nullptr;
-    if (par) { (void)hipEventRecord(t->fork_ev, st); (void)hipStreamWaitEvent(t->side[0], t->fork_ev, 0); }
+    // (six latency-bound products on leaves of one level each - three launches per level at the serial tail of the step, then the levels side by side on two
+    // streams, now ONE launch: train_kernels.hip k_bott_grads)
+    BottBatch bb;
     for (int lv = 0; lv < (Nf > 0 ? 2 : 1); ++lv) {
       const LayerP& K = t->rgb_h[lv];
-      bott_grads((par && lv == 1) ? t->side[0] : st, TW, K.N, t->theta + t->bott[lv].w, t->theta + t->bott[lv].b, t->theta + K.w, t->grad + K.w + (int64_t)(TW + VD) * K.N, t->grad + K.b,
-                 t->grad + K.w, t->grad + t->bott[lv].w, t->grad + t->bott[lv].b);
+      bb.lv[bb.n++] = BottItem{TW, K.N, t->theta + t->bott[lv].w, t->theta + t->bott[lv].b, t->theta + K.w, t->grad + K.w + (int64_t)(TW + VD) * K.N, t->grad + K.b,
+                               t->grad + K.w, t->grad + t->bott[lv].w, t->grad + t->bott[lv].b};
     }
-    if (par) { (void)hipEventRecord(t->join_ev[0], t->side[0]); (void)hipStreamWaitEvent(st, t->join_ev[0], 0); }
+    bott_grads(st, bb);
   }
   if (!(flags & NERFDS_TRAIN_GRADS_ONLY)) adam_update(t, learning_rate, st);
   hipError_t e = hipGetLastError();

@@ -111,7 +111,9 @@ void pack_batch(hipStream_t, const float* theta, const float* fold, long long P,
 void fold_rgb(hipStream_t, const float* B, const float* Bb, const float* K, const float* Kb, int TW, int W, int row_x, float* fold);
 // gradients of the activation-free bottleneck Dense from S = trunk_out^T g_rgb [TW x W] and c = colsum(g_rgb) [W] (fused backward):
 //   dKb[TW x W] = Wb^T S + bb (x) c,  dWb[TW x TW] = S Kb^T,  dbb[TW] = Kb c;  Wb [TW x TW], Kb = the first TW rows of K [.. x W]
-void bott_grads(hipStream_t, int TW, int W, const float* Wb, const float* bb, const float* K, const float* S, const float* c, float* dKb,
-                float* dWb, float* dbb);
+// One launch for every level (k_bott_grads).
+struct BottItem { int TW, W; const float* Wb; const float* bb; const float* K; const float* S; const float* c; float* dKb; float* dWb; float* dbb; };
+struct BottBatch { BottItem lv[2]; int n = 0; };
+void bott_grads(hipStream_t, const BottBatch&);
 
 }  // namespace nerfds_train

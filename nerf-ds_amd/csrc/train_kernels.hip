@@ -1576,12 +1576,11 @@ __global__ void k_fold_rgb(const float* __restrict__ B, const float* __restrict_
 }
 // fused backward: see train_kernels.h bott_grads.  Three small products with double accumulation like k_fold_rgb:
 //   dKb[k][n] = sum_r Wb[r][k] S[r][n] + bb[k] c[n],   dWb[r][k] = sum_n S[r][n] Kb[k][n],   dbb[k] = sum_n Kb[k][n] c[n].
-// k_small_gemm: C[i][j] = sum_r A(r, i) B(r, j) (+ u[i] v[j]) for any strides, 32 x 32 output tiles, the operands staged through LDS 32
+// small_gemm_tile: C[i][j] = sum_r A(r, i) B(r, j) (+ u[i] v[j]) for any strides, 32 x 32 output tiles, the operands staged through LDS 32
 // reduction steps at a time (as one thread per output element walking 256 operand pairs from L2 the launch took 90 us).
-__global__ __launch_bounds__(256) void k_small_gemm(int I, int J, int Rn, const float* __restrict__ A, long long sa_r, long long sa_i,
-                                                    const float* __restrict__ B, long long sb_r, long long sb_j, const float* __restrict__ u,
-                                                    const float* __restrict__ v, float* __restrict__ C) {
-  __shared__ float As[32][33], Bs[32][33];
+__device__ __forceinline__ void small_gemm_tile(float (&As)[32][33], float (&Bs)[32][33], int I, int J, int Rn, const float* __restrict__ A, long long sa_r, long long sa_i,
+                                                const float* __restrict__ B, long long sb_r, long long sb_j, const float* __restrict__ u,
+                                                const float* __restrict__ v, float* __restrict__ C) {
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
   for (int r0 = 0; r0 < Rn; r0 += 32) {
@@ -1607,22 +1606,34 @@ __global__ __launch_bounds__(256) void k_small_gemm(int I, int J, int Rn, const 
       if (i < I && j < J) C[(size_t)i * J + j] = (float)(acc[a][b] + (u ? (double)u[i] * (double)v[j] : 0.0));
     }
 }
-__global__ void k_bott_dbb(int TW, int W, const float* __restrict__ K, const float* __restrict__ c, float* __restrict__ dbb) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= TW) return;
-  double acc = 0.0;
+// bott_grads of every level in ONE launch (it was three per level, the levels side by side on two streams, at the serial tail of the step): blockIdx.z = 3 * level + product
+//   product 0: dKb (TW x W tiles), 1: dWb (TW x TW tiles), 2: dbb (the block (0, 0) alone, one thread per k)
+__global__ __launch_bounds__(256) void k_bott_grads(const BottBatch Bt) {
+  __shared__ float As[32][33], Bs[32][33];
+  const BottItem L = Bt.lv[blockIdx.z / 3];
+  const int prod = blockIdx.z % 3, TW = L.TW, W = L.W;
+  if (prod == 0) {          // i = k, j = n, reduction r: A(r, k) = Wb[r * TW + k], B(r, n) = S[r * W + n]
+    if ((int)blockIdx.x * 32 >= W || (int)blockIdx.y * 32 >= TW) return;
+    small_gemm_tile(As, Bs, TW, W, TW, L.Wb, (long long)TW, 1LL, L.S, (long long)W, 1LL, L.bb, L.c, L.dKb);
+  } else if (prod == 1) {   // i = r, j = k, reduction n: A(n, r) = S[r * W + n], B(n, k) = K[k * W + n]
+    if ((int)blockIdx.x * 32 >= TW || (int)blockIdx.y * 32 >= TW) return;
+    small_gemm_tile(As, Bs, TW, TW, W, L.S, 1LL, (long long)W, L.K, 1LL, (long long)W, nullptr, nullptr, L.dWb);
+  } else {
+    if (blockIdx.x != 0 || blockIdx.y != 0) return;
+    for (int k = threadIdx.x; k < TW; k += blockDim.x) {
+      double acc = 0.0;
 #pragma unroll 16
-  for (int n = 0; n < W; ++n) acc += (double)K[(size_t)k * W + n] * (double)c[n];      // (loads of 16 steps in flight: k_fold_rgb)
-  dbb[k] = (float)acc;
+      for (int n = 0; n < W; ++n) acc += (double)L.K[(size_t)k * W + n] * (double)L.c[n];      // (loads of 16 steps in flight: k_fold_rgb)
+      L.dbb[k] = (float)acc;
+    }
+  }
 }
-void bott_grads(hipStream_t st, int TW, int W, const float* Wb, const float* bb, const float* K, const float* S, const float* c, float* dKb,
-                float* dWb, float* dbb) {
-  // dKb: i = k, j = n, reduction r: A(r, k) = Wb[r * TW + k], B(r, n) = S[r * W + n]
-  hipLaunchKernelGGL(k_small_gemm, dim3((W + 31) / 32, (TW + 31) / 32), dim3(256), 0, st, TW, W, TW, Wb, (long long)TW, 1LL, S, (long long)W, 1LL, bb, c, dKb);
-  // dWb: i = r, j = k, reduction n: A(n, r) = S[r * W + n], B(n, k) = K[k * W + n]
-  hipLaunchKernelGGL(k_small_gemm, dim3((TW + 31) / 32, (TW + 31) / 32), dim3(256), 0, st, TW, TW, W, S, 1LL, (long long)W, K, 1LL, (long long)W,
-                     static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), dWb);
-  LAUNCH(k_bott_dbb, TW, st, TW, W, K, c, dbb);
+void bott_grads(hipStream_t st, const BottBatch& B) {
+  if (B.n <= 0) return;
+  int tw = 0, w = 0;
+  for (int i = 0; i < B.n; ++i) { tw = B.lv[i].TW > tw ? B.lv[i].TW : tw; w = B.lv[i].W > w ? B.lv[i].W : w; }
+  const int m = tw > w ? tw : w;
+  hipLaunchKernelGGL(k_bott_grads, dim3((m + 31) / 32, (tw + 31) / 32, 3 * B.n), dim3(256), 0, st, B);
 }
 void pack_batch(hipStream_t st, const float* theta, const float* fold, long long P, const PackBatch& B) {
   if (B.overflow) { fprintf(stderr, "nerfds_train::pack_batch: more than %d items in one batch\n", PackBatch::MAX); abort(); }
