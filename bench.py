@@ -612,7 +612,7 @@ def main():
           pix = max(pix, float((d / r[:, :3].abs().clamp_min(PIXEL_FLOOR)).max()))
         return err, pix
       paths = {}
-      for prec in ('bf16x3', 'f16x3', 'f16', 'mixed'):
+      for prec in ('f16x3', 'bf16x3', 'f16', 'mixed'):      # (the arithmetic that `value_at_tolerance` names is timed first, straight after the headline)
         if prec == args.precision:
           continue
         full = prec in ('bf16x3', 'f16x3')      # the parity-grade arithmetics get the headline's treatment
